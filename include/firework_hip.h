@@ -1,0 +1,214 @@
+/*
+ * firework_hip.h -- C ABI of libfirework_hip.so, the MI355X (gfx950) backend for
+ * bevy_firework's per-frame particle simulation path.
+ *
+ * The reference has no FFI: the path sits behind Bevy's system registration
+ *   (sync_spawner_data, spawn_particles, update_particles,
+ *    notify_finished_particle_spawners).chain()        reference src/plugin.rs:46-60
+ * operating on the components ParticleSpawner (src/core.rs:178-185, user-owned
+ * settings) and ParticleSpawnerData (src/core.rs:269-303, plugin-owned state).
+ * This header is what a Rust shim crate would bind (INTEGRATION.md shows the
+ * `extern "C"` block and the exclusive system that replaces the two CPU systems).
+ * Each entry point cites the reference item it replaces.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all input descriptors are copied at the call.
+ *  - every function returns fw_status (0 = ok, negative = error) unless noted;
+ *    fw_last_error() gives a message.  The library never aborts the process; the
+ *    reference's panics (zero-key curve curve.rs:45,61,211,227; out-of-range
+ *    particle_index / target_particle_type core.rs:392,453,488) become FW_EINVAL
+ *    at create time.
+ *  - one context per GPU; calls on one context must be serialised by the caller
+ *    (the reference chain is sequential too).  fw_step only ENQUEUES work on the
+ *    context's HIP stream; readers synchronise that stream.
+ *  - there is NO CPU fallback: without a usable HIP device fw_ctx_create fails
+ *    with FW_ENODEV.
+ */
+#ifndef FIREWORK_HIP_H
+#define FIREWORK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FW_ABI_VERSION 1
+#define FW_MAX_KEYS 32          /* keys per curve / gradient */
+#define FW_MAX_TYPES 8          /* particle_settings entries per spawner */
+#define FW_MAX_EMISSIONS 8      /* emission_settings entries per spawner */
+
+typedef enum fw_status {
+    FW_OK = 0,
+    FW_EINVAL = -1,    /* bad argument / descriptor (mirrors the reference's panics) */
+    FW_ENOMEM = -2,    /* host or device allocation failed */
+    FW_EHIP = -3,      /* a HIP call failed (message in fw_last_error) */
+    FW_ECAPACITY = -4, /* a particle type overflowed its device capacity (nested emission) */
+    FW_ENODEV = -5,    /* no usable HIP device / kernels not loadable */
+    FW_ESMALL = -6     /* output buffer too small; required size reported */
+} fw_status;
+
+typedef struct fw_ctx fw_ctx;
+typedef int32_t fw_spawner; /* handle, >= 0 */
+
+/* bevy_utilitarian RandF32 / RandVec3 as used by core.rs:102,107,155,157,161 */
+typedef struct fw_rand_f32 { float min, max; } fw_rand_f32;
+typedef struct fw_rand_vec3 { fw_rand_f32 magnitude; float direction[3]; float spread; } fw_rand_vec3;
+
+/* FireworkCurve<f32> (curve.rs:8-12) and FireworkGradient<LinearRgba> (curve.rs:171-175) */
+enum { FW_CURVE_CONSTANT = 0, FW_CURVE_EVEN = 1, FW_CURVE_UNEVEN = 2 };
+typedef struct fw_curve { int32_t kind; int32_t n; const float *times; const float *values; } fw_curve;
+typedef struct fw_gradient { int32_t kind; int32_t n; const float *times; const float *rgba; } fw_gradient;
+
+/* ParticleSettings (core.rs:99-142), simulation-relevant fields only; textures,
+ * fade_*, blend_mode stay on the host (they never enter update_particles). */
+typedef struct fw_particle_settings {
+    fw_rand_f32 lifetime;
+    fw_curve scale_curve;
+    fw_rand_f32 initial_scale;
+    float acceleration[3];
+    float angular_acceleration[3];
+    float linear_drag, angular_drag;
+    fw_gradient base_color, emissive_color;
+    int32_t pbr;
+    int32_t report_destroyed; /* event_handlers.particles_destroyed.is_some() (core.rs:164-167) */
+    uint32_t capacity;        /* device slots for this type; 0 = derive from the emitters */
+} fw_particle_settings;
+
+enum { FW_PACING_ONESHOT = 0, FW_PACING_ONDEMAND = 1, FW_PACING_COUNT_OVER_DURATION = 2 }; /* core.rs:12-29 */
+enum { FW_MODE_GLOBAL = 0, FW_MODE_NESTED = 1 };                                           /* core.rs:47-54 */
+enum { FW_SHAPE_POINT = 0, FW_SHAPE_SPHERE = 1, FW_SHAPE_CIRCLE = 2 };                     /* emission_shape.rs:7-15 */
+
+/* EmissionSettings (core.rs:144-162) */
+typedef struct fw_emission_settings {
+    int32_t particle_index;
+    int32_t pacing_kind;
+    uint64_t oneshot_count;
+    float count, duration, offset_start, offset_end;
+    int32_t mode;
+    int32_t target_particle_type;
+    int32_t shape_kind;
+    float shape_radius;
+    float shape_normal[3];
+    fw_rand_vec3 initial_velocity;
+    fw_rand_f32 initial_velocity_radial;
+    int32_t inherit_parent_velocity;
+    float initial_rotation[4]; /* xyzw */
+    fw_rand_vec3 initial_angular_velocity;
+} fw_emission_settings;
+
+/* ParticleSpawner (core.rs:178-185).  spawn_transform_mode is resolved by the host:
+ * it passes the chosen transform to fw_spawner_set_origin (core.rs:432-435). */
+typedef struct fw_spawner_desc {
+    const fw_particle_settings *particle_settings;
+    uint32_t n_particle_settings;
+    const fw_emission_settings *emission_settings;
+    uint32_t n_emission_settings;
+    int32_t starts_enabled;
+    uint32_t uid; /* RNG stream id; keep it stable across GPUs when sharding */
+} fw_spawner_desc;
+
+/* ParticleData (core.rs:305-321) as an AoS record for readback / upload.
+ * last_emitted_age is read separately (fw_spawner_read_last_emitted). */
+typedef struct fw_particle {
+    float position[3];
+    float velocity[3];
+    float rotation[4];
+    float angular_velocity[3];
+    float initial_scale, scale, age, lifetime;
+    float base_color[4];
+    float emissive_color[4];
+    int32_t pbr;
+} fw_particle;
+
+/* ParticleInstance (render.rs:95-103): 64 B */
+typedef struct fw_particle_instance {
+    float position[3];
+    float scale;
+    float rotation[4];
+    float base_color[4];
+    float emissive_color[4];
+} fw_particle_instance;
+
+/* ---- context ---------------------------------------------------------------- */
+/* `stream` = an existing hipStream_t to enqueue on (e.g. torch's current stream),
+ * or NULL to let the context create its own. */
+int fw_abi_version(void);
+fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out);
+fw_status fw_ctx_destroy(fw_ctx *ctx);
+const char *fw_last_error(const fw_ctx *ctx); /* ctx may be NULL: last create error */
+void *fw_ctx_stream(const fw_ctx *ctx);       /* the hipStream_t in use */
+fw_status fw_ctx_synchronize(fw_ctx *ctx);
+
+/* ---- spawners ----------------------------------------------------------------- */
+/* ParticleSpawner insertion + first sync_spawner_data (core.rs:343-365) */
+fw_status fw_spawner_create(fw_ctx *ctx, const fw_spawner_desc *desc, fw_spawner *out);
+/* Changed<ParticleSpawner>: sync_spawner_data again -- resets emission state, drops all particles */
+fw_status fw_spawner_update_settings(fw_ctx *ctx, fw_spawner h, const fw_spawner_desc *desc);
+fw_status fw_spawner_destroy(fw_ctx *ctx, fw_spawner h);
+
+/* per-frame inputs the ECS owns */
+fw_status fw_spawner_set_origin(fw_ctx *ctx, fw_spawner h, const float translation[3], const float rotation_xyzw[4]);
+fw_status fw_spawner_set_parent_velocity(fw_ctx *ctx, fw_spawner h, const float v[3]); /* core.rs:276,444-448 */
+fw_status fw_spawner_set_modifier(fw_ctx *ctx, fw_spawner h, float scale, float speed); /* EffectModifier core.rs:323-327 */
+fw_status fw_spawner_queue(fw_ctx *ctx, fw_spawner h, uint64_t count);                  /* queue_particles core.rs:284-286 */
+
+/* ---- the frame: spawn_particles then update_particles for every spawner -------- */
+fw_status fw_step(fw_ctx *ctx, float dt); /* core.rs:367-551 + 577-670 */
+
+/* ---- outputs (synchronise the stream) ------------------------------------------- */
+/* particles[i].len() for every type (core.rs:274) */
+fw_status fw_spawner_counts(fw_ctx *ctx, fw_spawner h, uint32_t *per_type, uint32_t n_types);
+/* ParticleSpawnerData::active (core.rs:288-302): *out = 0/1 */
+fw_status fw_spawner_active(fw_ctx *ctx, fw_spawner h, int32_t *out);
+/* notify_finished_particle_spawners (core.rs:674-688): *out = 1 exactly once */
+fw_status fw_spawner_poll_finished(fw_ctx *ctx, fw_spawner h, int32_t *out);
+/* copies min(count, cap) records; *n_out = count.  Order = reference Vec order. */
+fw_status fw_spawner_read_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, fw_particle *out, uint64_t cap,
+                                    uint64_t *n_out);
+fw_status fw_spawner_read_last_emitted(fw_ctx *ctx, fw_spawner h, uint32_t type, uint32_t emission_index, float *out,
+                                       uint64_t cap, uint64_t *n_out);
+/* replaces the particle vector of `type` (`particles` is a pub field in the reference) */
+fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, const fw_particle *in, uint64_t n);
+fw_status fw_spawner_write_last_emitted(fw_ctx *ctx, fw_spawner h, uint32_t type, uint32_t emission_index,
+                                        const float *in, uint64_t n);
+/* particles destroyed by the last fw_step for a type with report_destroyed (core.rs:588,596-599,660-667) */
+fw_status fw_spawner_read_destroyed(fw_ctx *ctx, fw_spawner h, uint32_t type, fw_particle *out, uint64_t cap,
+                                    uint64_t *n_out);
+/* ParticleInstance packing (render.rs:105-115,403) into a HOST buffer */
+fw_status fw_spawner_pack_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, fw_particle_instance *out, uint64_t cap,
+                                    uint64_t *n_out);
+/* same, into a DEVICE buffer on the context's stream (no sync): the render hand-off */
+fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap,
+                                           uint64_t *n_upper_bound);
+/* update_aabbs reduction (render.rs:677-703), world space; *any = 0 when no particles */
+fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out_max[3], int32_t *any);
+
+/* ---- whole-context statistics ---------------------------------------------------- */
+/* total live particles over all spawners (host value; synchronises) */
+fw_status fw_ctx_live_count(fw_ctx *ctx, uint64_t *out);
+/* enqueue a write of the total live count into a caller-owned DEVICE uint64 (no
+ * sync): feed for the RCCL all-reduce of live counts across GPUs */
+fw_status fw_ctx_live_count_device(fw_ctx *ctx, void *d_out_u64);
+/* particles that entered update_particles in the last fw_step (after spawn) */
+fw_status fw_ctx_last_step_updated(fw_ctx *ctx, uint64_t *out);
+
+/* ---- measurement hooks (bench.py / profiles) -------------------------------------- */
+/* HIP-event timing of the dominant kernel on the context's stream: enable, run
+ * steps, then read (sum of kernel durations in ms, number of launches). */
+fw_status fw_ctx_kernel_timing(fw_ctx *ctx, int32_t enable);
+fw_status fw_ctx_kernel_timing_read(fw_ctx *ctx, double *ms_total, uint64_t *launches, uint64_t *particles);
+/* device-to-device copy bandwidth probe (bytes moved R+W per second) for the measured-roofline line */
+fw_status fw_ctx_measure_copy_bandwidth(fw_ctx *ctx, uint64_t bytes, int32_t iters, double *bytes_per_s);
+
+/* ---- pure host helpers (no GPU needed; the bit-exact count arithmetic) ------------ */
+/* compute_emission_count (core.rs:553-575) exactly as fw_step's host side evaluates it */
+uint64_t fw_compute_emission_count(float time_passed_in_cycle, float last_emission, float cycle_duration,
+                                   float offset_start, float offset_end, float particles_per_cycle,
+                                   float *next_last_emission);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIREWORK_HIP_H */

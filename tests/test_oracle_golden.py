@@ -1,0 +1,173 @@
+"""The C oracle against the committed golden vectors (tests/golden/*.json):
+the reference's own two unit tests, the published Philox KATs, and the
+independent numpy-float32 restatement.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from bevy_firework_amd import settings as S
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    with open(os.path.join(G, name)) as f:
+        return json.load(f)
+
+
+def f(bits):
+    return np.array([bits], dtype=np.uint32).view(np.float32)[0]
+
+
+def b(x):
+    return int(np.asarray(x, dtype=np.float32).view(np.uint32))
+
+
+def test_reference_emission_unit_test():
+    """reference src/core.rs:806-834: total must be 23 or 22; trajectory bit-exact."""
+    d = load("emission_kat.json")
+    total = 0
+    for age_b, last_b, n, next_b in d["steps"]:
+        got_n, got_next = oracle.compute_emission_count(f(age_b), f(last_b), 3.0, 0.0, 1.0, 23.0)
+        assert got_n == n and b(got_next) == next_b
+        total += got_n
+    assert total == d["total"] and total in (22, 23)
+
+
+def test_emission_wrap_trajectories():
+    d = load("emission_wrap.json")
+    for case in d["cases"]:
+        dt = f(case["dt_bits"])
+        tpc, last = np.float32(0), np.float32(0)
+        for tpc_b, n, last_b in case["frames"]:
+            tpc = np.float32(oracle.lib().fwo_rem_euclid(np.float32(tpc + dt), case["duration"]))
+            got_n, last = oracle.compute_emission_count(tpc, last, case["duration"], case["offset_start"],
+                                                        case["offset_end"], case["count"])
+            assert b(tpc) == tpc_b and got_n == n and b(last) == last_b
+    assert d["per_cycle_160k"] == 157334 and d["per_cycle_1m"] == 983333
+
+
+def test_nested_count_kat():
+    d = load("nested_count_kat.json")
+    for case in d["cases"]:
+        last = np.float32(np.finfo(np.float32).min)
+        for age_b, n, last_b in case["rows"]:
+            got_n, last = oracle.compute_emission_count(f(age_b), last, case["lifetime"], case["offset_start"],
+                                                        case["offset_end"], case["count"])
+            assert got_n == n and b(last) == last_b
+
+
+def test_emission_count_edge_semantics():
+    # negative / NaN / saturating `as usize`
+    assert oracle.compute_emission_count(0.0, 0.5, 1.0, 0.0, 1.0, 10.0)[0] == 0
+    # f32::min ignores a NaN operand (IEEE minNum): NaN clock behaves like "end of window"
+    assert oracle.compute_emission_count(float("nan"), 0.0, 1.0, 0.0, 1.0, 10.0)[0] == 10
+    assert oracle.compute_emission_count(0.5, 0.0, float("nan"), 0.0, 1.0, 10.0)[0] == 10
+    assert oracle.compute_emission_count(0.5, 0.0, 1.0, 0.0, 1.0, float("nan"))[0] == 0  # NaN as usize -> 0
+    n, _ = oracle.compute_emission_count(1.0, 0.0, 1.0, 0.0, 1.0, float("inf"))  # between = 0 -> x/0 = inf
+    assert n == 2**64 - 1
+    assert oracle.lib().fwo_div_euclid(-7.0, 2.0) == -4.0 and oracle.lib().fwo_div_euclid(7.0, -2.0) == -3.0
+    assert oracle.lib().fwo_rem_euclid(-0.25, 1.0) == 0.75
+
+
+def test_reference_gradient_unit_test():
+    """reference src/curve.rs:246-258"""
+    d = load("curve_kat.json")["reference_test"]
+    g = S.FireworkGradient.even_samples(d["colors"])
+    for s in d["samples"]:
+        got = oracle.gradient_sample(g, s["t"])
+        assert [b(x) for x in got] == s["rgba_bits"]
+    assert list(oracle.gradient_sample(g, 0.5)) == [0.0, 1.0, 0.0, 1.0]
+
+
+def test_curves_against_numpy_restatement():
+    d = load("curve_kat.json")
+    sg = d["stress_gradient"]
+    gu = S.FireworkGradient.uneven_samples(list(zip(sg["times"], sg["colors"])))
+    ge = S.FireworkGradient.even_samples(sg["colors"])
+    for s in sg["uneven"]:
+        assert [b(x) for x in oracle.gradient_sample(gu, f(s["t_bits"]))] == s["rgba_bits"]
+    for s in sg["even"]:
+        assert [b(x) for x in oracle.gradient_sample(ge, f(s["t_bits"]))] == s["rgba_bits"]
+    for key, mk in [("f32_even_2", lambda c: S.FireworkCurve.even_samples(c["values"])),
+                    ("f32_even_3", lambda c: S.FireworkCurve.even_samples(c["values"])),
+                    ("f32_uneven_3", lambda c: S.FireworkCurve.uneven_samples(list(zip(c["times"], c["values"])))),
+                    ("f32_uneven_messy", lambda c: S.FireworkCurve.uneven_samples(
+                        [(float(t), v) for t, v in zip(c["times"], c["values"])]))]:
+        c = d[key]
+        curve = mk(c)
+        for s in c["samples"]:
+            assert b(oracle.curve_sample(curve, f(s["t_bits"]))) == s["v_bits"], key
+
+
+def test_curve_constructors_mirror_reference_panics():
+    with pytest.raises(ValueError):
+        S.FireworkCurve.even_samples([])
+    with pytest.raises(ValueError):
+        S.FireworkGradient.uneven_samples([])
+    assert S.FireworkCurve.even_samples([3.0]).kind == S.CURVE_CONSTANT
+    assert S.FireworkGradient.uneven_samples([(0.3, (1, 2, 3, 4))]).kind == S.CURVE_CONSTANT
+
+
+def test_philox_published_kat_and_uniform_stream():
+    d = load("philox_kat.json")
+    for kat in d["published"]:
+        assert [int(x) for x in oracle.philox(kat["ctr"], kat["key"])] == kat["out"]
+    for u in d["spawn_uniforms"]:
+        got = oracle.spawn_uniforms(u["seed"], u["uid"], u["emission_index"], u["serial"])
+        assert [b(x) for x in got] == u["u_bits"]
+        assert (got >= 0).all() and (got < 1).all()
+
+
+def _spawner_for(case):
+    st = case["settings"]
+
+    def grad(g):
+        kind, cols, times = g
+        if kind == 0:
+            return S.FireworkGradient.constant(cols[0])
+        if kind == 1:
+            return S.FireworkGradient.even_samples(cols)
+        return S.FireworkGradient.uneven_samples(list(zip(times, cols)))
+
+    kind, vals, times = st["scale_curve"]
+    sc = (S.FireworkCurve.constant(vals[0]) if kind == 0 else S.FireworkCurve.even_samples(vals) if kind == 1
+          else S.FireworkCurve.uneven_samples(list(zip(times, vals))))
+    ps = S.ParticleSettings(scale_curve=sc, acceleration=tuple(st["acceleration"]), linear_drag=st["linear_drag"],
+                            angular_drag=st["angular_drag"], base_color=grad(st["base_color"]),
+                            emissive_color=grad(st["emissive_color"]))
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.OnDemand())
+    return S.ParticleSpawner(particle_settings=[ps], emission_settings=[es])
+
+
+def particle_from_kat(case):
+    p = np.zeros(1, dtype=S.PARTICLE_DTYPE)
+    p["rotation"][0] = (0, 0, 0, 1)
+    for k, v in case["in"].items():
+        p[k][0] = [f(x) for x in v] if isinstance(v, list) else f(v)
+    return p
+
+
+def test_update_kats():
+    """hand-derived single-particle updates, reference src/core.rs:591-658"""
+    d = load("update_kat.json")
+    for case in d["cases"]:
+        o = oracle.OracleSpawner(_spawner_for(case))
+        o.write_particles(0, particle_from_kat(case))
+        o.update(f(case["dt_bits"]))
+        if not case["alive"]:
+            assert o.count(0) == 0, case["name"]
+            dead = o.destroyed(0)
+            assert len(dead) == 1 and b(dead["age"][0]) == case["out"]["age"]
+            # destroyed record keeps the previous frame's pose (core.rs:596-599)
+            assert [b(x) for x in dead["position"][0]] == case["in"]["position"]
+        else:
+            assert o.count(0) == 1, case["name"]
+            got = o.particles(0)[0]
+            for k, want in case["out"].items():
+                gb = [b(x) for x in np.atleast_1d(got[k])]
+                assert gb == (want if isinstance(want, list) else [want]), (case["name"], k)
+            assert list(got["rotation"]) == [0, 0, 0, 1]  # identity * rot when angular velocity is zero
