@@ -1,0 +1,129 @@
+// fw_device.h -- device-resident data layout of the firework HIP backend (gfx950).
+//
+// Particle state lives in HBM as a structure-of-arrays mirror of the reference's
+// ParticleData (reference src/core.rs:305-321), one SEGMENT per (spawner,
+// particle type) pair -- the reference's `particles: Vec<Vec<ParticleData>>`
+// (src/core.rs:274).  A segment owns two buffers (ping/pong); the update kernel
+// reads buf[parity] and writes the stably compacted survivors to buf[parity^1].
+//
+// One buffer of capacity C particles holds these planes (C is a multiple of 256,
+// every plane 16-byte aligned, one particle per lane => every load/store is a
+// full-width dwordx4 and the compacted store position of a particle is always
+// 16-byte aligned):
+//
+//   Q0  float4 {pos.x, pos.y, pos.z, age}            offset   0*C   read+write
+//   Q1  float4 {vel.x, vel.y, vel.z, initial_scale}  offset  16*C   read+write
+//   Q2  float4 {rot.x, rot.y, rot.z, rot.w}          offset  32*C   read+write
+//   Q3  float4 {angvel.x, .y, .z, lifetime}          offset  48*C   read+write
+//   Q5  float4 base_color rgba                       offset  64*C   write only
+//   Q6  float4 emissive_color rgba                   offset  80*C   write only
+//   S4  float  scale                                 offset  96*C   write only
+//   Lk  float  last_emitted_age[k]                   offset (100+4k)*C   only for
+//       emission entries that are Nested on this type (src/core.rs:320,467,493-500)
+//
+// Reads 64 B + writes 100 B per particle per frame = 164 B (the "156 B + 8 B
+// ping-pong" variant of SURVEY.md §8d); +8 B per Lk plane.  `pbr` is a per-type
+// constant (src/core.rs:462) and is not stored per particle.
+#pragma once
+#include <stdint.h>
+
+#define FW_BLOCK 256          // threads per workgroup = 4 wave64
+#define FW_ROUNDS 4           // particles per thread per tile
+#define FW_TILE (FW_BLOCK * FW_ROUNDS)
+#define FW_KEYS_MAX 400       // floats of curve keys staged in LDS per type
+#define FW_DEV_MAX_EMISSIONS 8
+
+#define FW_OFF_Q0(C) ((size_t)0)
+#define FW_OFF_Q1(C) ((size_t)16 * (C))
+#define FW_OFF_Q2(C) ((size_t)32 * (C))
+#define FW_OFF_Q3(C) ((size_t)48 * (C))
+#define FW_OFF_Q5(C) ((size_t)64 * (C))
+#define FW_OFF_Q6(C) ((size_t)80 * (C))
+#define FW_OFF_S4(C) ((size_t)96 * (C))
+#define FW_OFF_L(C, k) ((size_t)(100 + 4 * (k)) * (C))
+#define FW_BUF_BYTES(C, nl) ((size_t)(100 + 4 * (nl)) * (C))
+
+// one (spawner, particle type) segment
+struct alignas(16) FwSeg {
+    char *buf[2];
+    char *destroyed;      // fw_particle AoS records of the last step, or null
+    uint32_t capacity;    // particles per buffer, multiple of FW_BLOCK
+    uint32_t type_idx;    // -> FwType
+    uint32_t n_lplanes;   // number of Lk planes
+    uint32_t pad0;
+};
+
+// per particle type constants (ParticleSettings, reference src/core.rs:99-142)
+struct alignas(16) FwType {
+    float acc[3];
+    float lin_drag;
+    float angacc[3];
+    float ang_drag;
+    int32_t sc_kind, sc_n;   // scale_curve
+    int32_t bc_kind, bc_n;   // base_color
+    int32_t em_kind, em_n;   // emissive_color
+    int32_t pbr, report_destroyed;
+    // key pool layout (floats, each sub-array padded to a multiple of 4):
+    //  [sc_times | sc_vals | bc_times | bc_rgba | em_times | em_rgba]
+    uint32_t keys_off, keys_len;
+    uint32_t o_sc_v, o_bc_t, o_bc_v, o_em_t, o_em_v, pad0;
+};
+
+// static settings of one emission entry (EmissionSettings, src/core.rs:144-162)
+// plus the spawn-relevant ranges of its particle type
+struct alignas(16) FwEmit {
+    int32_t shape_kind;
+    float shape_radius;
+    uint32_t uid;             // spawner uid (RNG key word 1)
+    uint32_t emission_index;  // RNG counter word 2
+    float shape_arc[4];       // Quat::from_rotation_arc(Y, normal)
+    float v_mag_min, v_mag_max, v_spread;
+    int32_t inherit;
+    float v_dir[4];
+    float v_arc[4];           // from_rotation_arc(Y, direction)
+    float w_mag_min, w_mag_max, w_spread;
+    uint32_t type_idx;
+    float w_dir[4];
+    float w_arc[4];
+    float init_rot[4];
+    float radial_min, radial_max, iscale_min, iscale_max;
+    float life_min, life_max;
+    // Nested pacing (src/core.rs:474-500)
+    float n_count, n_start, n_end;
+    uint32_t n_lplane;        // which Lk plane of the PARENT type belongs to this entry
+    uint32_t pad0[2];
+};
+
+// one Global spawn operation of the current frame (src/core.rs:395-470)
+struct alignas(16) FwOp {
+    uint32_t seg;         // destination segment
+    uint32_t emit;        // -> FwEmit
+    uint32_t n;           // particles_to_spawn
+    uint32_t rel_base;    // slots already taken this frame by earlier Global ops on `seg`
+    uint64_t serial_base; // RNG serial of the first particle
+    uint32_t first_block; // first workgroup of this op in the spawn launch
+    uint32_t pad0;
+    float origin_pos[4];
+    float origin_rot[4];
+    float parent_vel[4];
+    float speed, scale;   // EffectModifier (src/core.rs:323-327)
+    uint32_t pad1[2];
+};
+
+// one Nested emission operation of the current frame (src/core.rs:471-546)
+struct alignas(16) FwNestOp {
+    uint32_t parent_seg, child_seg;
+    uint32_t emit;
+    uint32_t first_tile;  // first parent tile of this op in the nested launches
+    uint32_t n_tiles;     // parent tiles launched (upper bound)
+    uint32_t emit_slot;   // index into the device serial counters
+    float speed, scale;
+};
+
+// decoupled look-back status word: {epoch:30 | state:2 | value:32}
+#define FW_ST_AGG 1u
+#define FW_ST_INCL 2u
+
+// device-side error flags (sticky until read)
+#define FW_ERR_CAPACITY 1u
+#define FW_ERR_LOOKBACK_TIMEOUT 2u

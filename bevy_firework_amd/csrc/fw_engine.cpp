@@ -1,0 +1,1417 @@
+// fw_engine.cpp -- host side of libfirework_hip.so: the C ABI of include/firework_hip.h.
+//
+// Division of labour:
+//   host   - owns the control block of every spawner: emission clocks, enabled flags,
+//            the OnDemand queue (ParticleSpawnerData minus `particles`, reference
+//            src/core.rs:261-303) and evaluates compute_emission_count for Global
+//            entries (src/core.rs:396-428, 553-575) in bit-exact fp32;
+//   device - owns all particle state (fw_device.h) and runs spawn + update +
+//            compaction; Nested entries are counted per parent on the device.
+// A frame is: [params H2D on the copy stream] -> spawn kernel(s) -> update kernel, all
+// asynchronous; live counts come back through a pinned snapshot ring that the update
+// kernel writes directly (no memcpy in the frame).
+//
+// There is no CPU simulation path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/firework_hip.h"
+#include "fw_kernels.h"
+#include "fw_math.h"
+
+namespace {
+
+constexpr int kParamRing = 4;    // per-frame parameter buffers in flight
+constexpr int kSnapRing = 8;     // live-count snapshots in flight
+constexpr uint32_t kMinCapacity = 4096;
+constexpr uint64_t kMaxSpawnPerOp = 1ull << 30;
+constexpr uint32_t kTimingEvents = 4096;
+
+std::string g_create_error;
+
+struct CurveCopy {
+    int32_t kind = 0, n = 0;
+    std::vector<float> times, values;  // values: n (curve) or 4n (gradient)
+};
+
+struct TypeHost {
+    fw_particle_settings ps{};
+    CurveCopy scale, base, emis;
+};
+
+struct EmissionHost {
+    fw_emission_settings es{};
+    // EmissionData (reference src/core.rs:261-267)
+    float last_emission = 0.f, time_passed_in_cycle = 0.f;
+    bool enabled = false, emits_on_other_particles = false;
+    uint64_t serial = 0;      // RNG stream position (Global entries; Nested ones live on the device)
+    uint32_t emit_idx = 0;    // -> FwEmit
+    uint32_t emit_slot = 0;   // -> device serial counter (Nested)
+};
+
+struct SegHost {
+    bool in_use = false;
+    int spawner = -1, type = -1;
+    uint32_t capacity = 0;
+    uint32_t ub = 0;            // upper bound of the device count (after this frame's spawns)
+    uint64_t cum_spawn = 0;     // Global particles ever appended (host-known)
+    uint32_t frame_spawn = 0;   // ... this frame
+    uint32_t type_idx = 0, n_lplanes = 0;
+    int32_t lplane_emission[FW_MAX_EMISSIONS];
+    bool nested_fed = false;    // receives Nested children: count not host-predictable
+    char *buf[2] = {nullptr, nullptr};
+    char *destroyed = nullptr;
+};
+
+struct SpawnerHost {
+    bool alive = false;
+    uint32_t uid = 0;
+    int32_t starts_enabled = 1;
+    std::vector<TypeHost> types;
+    std::vector<EmissionHost> em;
+    std::vector<uint32_t> seg;  // per type
+    uint64_t manual_queued_count = 0;
+    bool initialized = false, finished_notified = false;
+    float origin_pos[3] = {0, 0, 0}, origin_rot[4] = {0, 0, 0, 1}, parent_vel[3] = {0, 0, 0};
+    float mod_scale = 1.f, mod_speed = 1.f;
+};
+
+template <typename T>
+struct DevArray {
+    T *d = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct fw_ctx {
+    int device = 0;
+    uint32_t seed = 0;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int update_mode = FW_MODE_FUSED;
+    uint32_t spin_limit = 1u << 16;
+
+    std::vector<SpawnerHost> spawners;
+    std::vector<SegHost> segs;
+    uint32_t n_types = 0, n_emits = 0, n_emit_slots = 0;
+    size_t keys_used = 0;
+
+    FwGlobals g{};
+    DevArray<FwSeg> d_segs;
+    DevArray<FwType> d_types;
+    DevArray<float> d_keys;
+    DevArray<FwEmit> d_emits;
+    DevArray<unsigned long long> d_emit_serial;
+    uint32_t max_seg = 0;
+    size_t tiles_cap = 0, nest_tiles_cap = 0, nest_ops_cap = 0;
+
+    // per-frame parameter ring (pinned host + device copies)
+    size_t param_bytes = 0;
+    char *h_param[kParamRing] = {};
+    char *d_param[kParamRing] = {};
+    hipEvent_t ev_copied[kParamRing] = {}, ev_consumed[kParamRing] = {};
+    bool consumed_pending[kParamRing] = {};
+
+    // live-count snapshots written by the update kernel into pinned host memory
+    uint32_t *h_snap = nullptr;  // [kSnapRing][max_seg]
+    hipEvent_t ev_snap[kSnapRing] = {};
+    bool snap_pending[kSnapRing] = {};
+    std::vector<uint64_t> snap_cum[kSnapRing];  // cum_spawn of every segment when the frame was enqueued
+
+    uint64_t frame = 0;
+    uint32_t parity = 0;
+    unsigned long long stats_before_last = 0;
+    bool stats_valid = false;
+
+    // kernel timing
+    bool timing = false;
+    std::vector<hipEvent_t> tev;
+    size_t tev_used = 0;
+    uint64_t timing_particles_start = 0;
+
+    float *d_aabb = nullptr;
+    unsigned long long *d_total = nullptr;
+    uint32_t *d_segids = nullptr;
+};
+
+namespace {
+
+#define FW_HIP(ctx, call)                                                                            \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return FW_EHIP;                                                                          \
+        }                                                                                            \
+    } while (0)
+
+fw_status fail(fw_ctx *ctx, fw_status s, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    return s;
+}
+
+uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+
+template <typename T>
+fw_status dev_reserve(fw_ctx *ctx, DevArray<T> &a, size_t need, size_t used) {
+    if (need <= a.cap) return FW_OK;
+    size_t ncap = std::max<size_t>(need, a.cap * 2 + 64);
+    T *nd = nullptr;
+    FW_HIP(ctx, hipMalloc((void **)&nd, ncap * sizeof(T)));
+    FW_HIP(ctx, hipMemset(nd, 0, ncap * sizeof(T)));
+    if (a.d && used) FW_HIP(ctx, hipMemcpy(nd, a.d, used * sizeof(T), hipMemcpyDeviceToDevice));
+    if (a.d) FW_HIP(ctx, hipFree(a.d));
+    a.d = nd;
+    a.cap = ncap;
+    return FW_OK;
+}
+
+fw_status sync(fw_ctx *ctx) {
+    FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FW_OK;
+}
+
+// grows the [2][max_seg] bookkeeping arrays and the snapshot ring
+fw_status ensure_max_seg(fw_ctx *ctx, uint32_t need) {
+    if (need <= ctx->max_seg) return FW_OK;
+    fw_status st = sync(ctx);
+    if (st) return st;
+    uint32_t nmax = std::max<uint32_t>(need, ctx->max_seg ? ctx->max_seg * 2 : 1024);
+    auto regrow2 = [&](uint32_t *&p) -> fw_status {
+        uint32_t *np = nullptr;
+        FW_HIP(ctx, hipMalloc((void **)&np, 2ull * nmax * sizeof(uint32_t)));
+        FW_HIP(ctx, hipMemset(np, 0, 2ull * nmax * sizeof(uint32_t)));
+        if (p) {
+            for (int r = 0; r < 2; r++)
+                FW_HIP(ctx, hipMemcpy(np + (size_t)r * nmax, p + (size_t)r * ctx->max_seg,
+                                      ctx->max_seg * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+            FW_HIP(ctx, hipFree(p));
+        }
+        p = np;
+        return FW_OK;
+    };
+    if ((st = regrow2(ctx->g.count))) return st;
+    if ((st = regrow2(ctx->g.spawned))) return st;
+    if ((st = regrow2(ctx->g.appended))) return st;
+    {
+        uint32_t *np = nullptr;
+        FW_HIP(ctx, hipMalloc((void **)&np, (size_t)nmax * sizeof(uint32_t)));
+        FW_HIP(ctx, hipMemset(np, 0, (size_t)nmax * sizeof(uint32_t)));
+        if (ctx->g.ndestroyed) {
+            FW_HIP(ctx, hipMemcpy(np, ctx->g.ndestroyed, ctx->max_seg * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+            FW_HIP(ctx, hipFree(ctx->g.ndestroyed));
+        }
+        ctx->g.ndestroyed = np;
+    }
+    {
+        uint32_t *nh = nullptr;
+        FW_HIP(ctx, hipHostMalloc((void **)&nh, (size_t)kSnapRing * nmax * sizeof(uint32_t), hipHostMallocDefault));
+        memset(nh, 0, (size_t)kSnapRing * nmax * sizeof(uint32_t));
+        if (ctx->h_snap) FW_HIP(ctx, hipHostFree(ctx->h_snap));
+        ctx->h_snap = nh;
+        for (int i = 0; i < kSnapRing; i++) ctx->snap_pending[i] = false;
+    }
+    if (ctx->d_segids) FW_HIP(ctx, hipFree(ctx->d_segids));
+    FW_HIP(ctx, hipMalloc((void **)&ctx->d_segids, (size_t)nmax * sizeof(uint32_t)));
+    ctx->max_seg = nmax;
+    ctx->g.max_seg = nmax;
+    return FW_OK;
+}
+
+uint32_t seg_tiles(const SegHost &s) {
+    if (!s.in_use) return 0;
+    uint32_t ub = s.nested_fed ? s.capacity : std::min(s.ub, s.capacity);
+    return std::max<uint32_t>(1, (ub + FW_TILE - 1) / FW_TILE);
+}
+
+// tile scratch sized for every segment at full capacity
+fw_status ensure_tile_arrays(fw_ctx *ctx) {
+    size_t tiles = 0, nest_tiles = 0, nest_ops = 0;
+    for (auto &s : ctx->segs)
+        if (s.in_use) tiles += (s.capacity + FW_TILE - 1) / FW_TILE + 1;
+    for (auto &sp : ctx->spawners) {
+        if (!sp.alive) continue;
+        for (auto &e : sp.em)
+            if (e.es.mode == FW_MODE_NESTED) {
+                nest_tiles += (ctx->segs[sp.seg[e.es.target_particle_type]].capacity + FW_TILE - 1) / FW_TILE + 1;
+                nest_ops++;
+            }
+    }
+    if (tiles > ctx->tiles_cap) {
+        fw_status st = sync(ctx);
+        if (st) return st;
+        size_t ncap = tiles * 2;
+        if (ctx->g.tile_cnt) hipFree(ctx->g.tile_cnt), hipFree(ctx->g.tile_off), hipFree(ctx->g.tile_status);
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_cnt, ncap * sizeof(uint32_t)));
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_off, ncap * sizeof(uint32_t)));
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_status, ncap * sizeof(unsigned long long)));
+        FW_HIP(ctx, hipMemset(ctx->g.tile_status, 0, ncap * sizeof(unsigned long long)));
+        ctx->tiles_cap = ncap;
+    }
+    if (nest_tiles > ctx->nest_tiles_cap) {
+        fw_status st = sync(ctx);
+        if (st) return st;
+        size_t ncap = nest_tiles * 2;
+        if (ctx->g.nest_tile_cnt) hipFree(ctx->g.nest_tile_cnt), hipFree(ctx->g.nest_tile_off);
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_tile_cnt, ncap * sizeof(uint32_t)));
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_tile_off, ncap * sizeof(uint32_t)));
+        ctx->nest_tiles_cap = ncap;
+    }
+    if (nest_ops > ctx->nest_ops_cap) {
+        fw_status st = sync(ctx);
+        if (st) return st;
+        size_t ncap = nest_ops * 2 + 16;
+        if (ctx->g.nest_op_npar)
+            hipFree(ctx->g.nest_op_npar), hipFree(ctx->g.nest_op_base), hipFree(ctx->g.nest_op_total),
+                hipFree(ctx->g.nest_op_serial);
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_op_npar, ncap * sizeof(uint32_t)));
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_op_base, ncap * sizeof(uint32_t)));
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_op_total, ncap * sizeof(uint32_t)));
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_op_serial, ncap * sizeof(unsigned long long)));
+        ctx->nest_ops_cap = ncap;
+    }
+    return FW_OK;
+}
+
+fw_status ensure_param_ring(fw_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->param_bytes) return FW_OK;
+    fw_status st = sync(ctx);
+    if (st) return st;
+    FW_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    size_t nb = std::max<size_t>(bytes * 2, 1 << 16);
+    for (int i = 0; i < kParamRing; i++) {
+        if (ctx->h_param[i]) hipHostFree(ctx->h_param[i]), hipFree(ctx->d_param[i]);
+        FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_param[i], nb, hipHostMallocDefault));
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_param[i], nb));
+        ctx->consumed_pending[i] = false;
+    }
+    ctx->param_bytes = nb;
+    return FW_OK;
+}
+
+fw_status upload_seg(fw_ctx *ctx, uint32_t si) {
+    const SegHost &s = ctx->segs[si];
+    FwSeg d{};
+    d.buf[0] = s.buf[0], d.buf[1] = s.buf[1];
+    d.destroyed = s.destroyed;
+    d.capacity = s.capacity;
+    d.type_idx = s.type_idx;
+    d.n_lplanes = s.n_lplanes;
+    FW_HIP(ctx, hipMemcpy(ctx->d_segs.d + si, &d, sizeof d, hipMemcpyHostToDevice));
+    return FW_OK;
+}
+
+fw_status alloc_seg_buffers(fw_ctx *ctx, SegHost &s, uint32_t capacity, bool want_destroyed) {
+    const size_t bytes = FW_BUF_BYTES((size_t)capacity, s.n_lplanes);
+    char *b = nullptr;
+    hipError_t e = hipMalloc((void **)&b, bytes * 2);
+    if (e != hipSuccess) return fail(ctx, FW_ENOMEM, std::string("hipMalloc particle buffers: ") + hipGetErrorString(e));
+    s.buf[0] = b;
+    s.buf[1] = b + bytes;
+    s.capacity = capacity;
+    s.destroyed = nullptr;
+    if (want_destroyed) {
+        e = hipMalloc((void **)&s.destroyed, (size_t)capacity * sizeof(fw_particle));
+        if (e != hipSuccess) return fail(ctx, FW_ENOMEM, "hipMalloc destroyed buffer");
+    }
+    return FW_OK;
+}
+
+// exact device counts -> host upper bounds (synchronises)
+fw_status refresh_counts_exact(fw_ctx *ctx) {
+    fw_status st = sync(ctx);
+    if (st) return st;
+    const uint32_t n = (uint32_t)ctx->segs.size();
+    if (!n) return FW_OK;
+    std::vector<uint32_t> c(n);
+    FW_HIP(ctx, hipMemcpy(c.data(), ctx->g.count + (size_t)ctx->parity * ctx->max_seg, n * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++)
+        if (ctx->segs[i].in_use) ctx->segs[i].ub = c[i];
+    for (int i = 0; i < kSnapRing; i++) ctx->snap_pending[i] = false;
+    return FW_OK;
+}
+
+fw_status check_device_errors(fw_ctx *ctx) {
+    uint32_t e = 0;
+    FW_HIP(ctx, hipMemcpy(&e, ctx->g.err, sizeof e, hipMemcpyDeviceToHost));
+    if (!e) return FW_OK;
+    uint32_t zero = 0;
+    FW_HIP(ctx, hipMemcpy(ctx->g.err, &zero, sizeof zero, hipMemcpyHostToDevice));
+    if (e & FW_ERR_CAPACITY)
+        return fail(ctx, FW_ECAPACITY,
+                    "a particle type overflowed its device capacity; particles were dropped "
+                    "(raise fw_particle_settings.capacity)");
+    return FW_OK;  // FW_ERR_LOOKBACK_TIMEOUT is informational: the fallback path produced the same result
+}
+
+fw_status grow_segment(fw_ctx *ctx, uint32_t si, uint32_t need) {
+    SegHost &s = ctx->segs[si];
+    fw_status st = refresh_counts_exact(ctx);
+    if (st) return st;
+    uint32_t ncap = round_up(std::max<uint32_t>((uint32_t)std::min<uint64_t>((uint64_t)need * 5 / 4, 0xFFFF0000ull),
+                                                s.capacity * 2),
+                             FW_TILE);
+    SegHost old = s;
+    st = alloc_seg_buffers(ctx, s, ncap, old.destroyed != nullptr);
+    if (st) {
+        s = old;
+        return st;
+    }
+    const uint32_t p = ctx->parity;
+    const uint32_t n = old.ub;  // exact after the refresh
+    auto cp = [&](size_t noff, size_t ooff, size_t elem) -> hipError_t {
+        if (!n) return hipSuccess;
+        return hipMemcpy(s.buf[p] + noff, old.buf[p] + ooff, (size_t)n * elem, hipMemcpyDeviceToDevice);
+    };
+    const size_t OC = old.capacity, NC = ncap;
+    FW_HIP(ctx, cp(FW_OFF_Q0(NC), FW_OFF_Q0(OC), 16));
+    FW_HIP(ctx, cp(FW_OFF_Q1(NC), FW_OFF_Q1(OC), 16));
+    FW_HIP(ctx, cp(FW_OFF_Q2(NC), FW_OFF_Q2(OC), 16));
+    FW_HIP(ctx, cp(FW_OFF_Q3(NC), FW_OFF_Q3(OC), 16));
+    FW_HIP(ctx, cp(FW_OFF_Q5(NC), FW_OFF_Q5(OC), 16));
+    FW_HIP(ctx, cp(FW_OFF_Q6(NC), FW_OFF_Q6(OC), 16));
+    FW_HIP(ctx, cp(FW_OFF_S4(NC), FW_OFF_S4(OC), 4));
+    for (uint32_t k = 0; k < s.n_lplanes; k++) FW_HIP(ctx, cp(FW_OFF_L(NC, k), FW_OFF_L(OC, k), 4));
+    FW_HIP(ctx, hipFree(old.buf[0]));
+    if (old.destroyed) FW_HIP(ctx, hipFree(old.destroyed));
+    if ((st = upload_seg(ctx, si))) return st;
+    return ensure_tile_arrays(ctx);
+}
+
+void copy_curve(CurveCopy &dst, int32_t kind, int32_t n, const float *times, const float *values, int stride) {
+    dst.kind = kind;
+    dst.n = n;
+    dst.values.assign(values, values + (size_t)n * stride);
+    dst.times.assign((size_t)n, 0.f);
+    if (times && kind == FW_CURVE_UNEVEN) dst.times.assign(times, times + n);
+    if (kind == FW_CURVE_UNEVEN && n >= 2) {
+        // bevy_math UnevenCore::new: drop non-finite times, stable sort by time, dedup keeping the first
+        std::vector<int> idx;
+        for (int i = 0; i < n; i++)
+            if (std::isfinite(dst.times[i])) idx.push_back(i);
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return dst.times[a] < dst.times[b]; });
+        std::vector<float> t, v;
+        for (int i : idx) {
+            if (!t.empty() && t.back() == dst.times[i]) continue;
+            t.push_back(dst.times[i]);
+            v.insert(v.end(), dst.values.begin() + (size_t)i * stride, dst.values.begin() + (size_t)(i + 1) * stride);
+        }
+        dst.times = t;
+        dst.values = v;
+        dst.n = (int32_t)t.size();
+    }
+    if (dst.n == 1) dst.kind = FW_CURVE_CONSTANT;  // curve.rs:46-49: one sample -> ConstantCurve
+}
+
+fw_status validate_desc(fw_ctx *ctx, const fw_spawner_desc *d) {
+    if (!d) return fail(ctx, FW_EINVAL, "null descriptor");
+    if (d->n_particle_settings > FW_MAX_TYPES || d->n_emission_settings > FW_MAX_EMISSIONS)
+        return fail(ctx, FW_EINVAL, "too many particle_settings / emission_settings entries");
+    if ((d->n_particle_settings && !d->particle_settings) || (d->n_emission_settings && !d->emission_settings))
+        return fail(ctx, FW_EINVAL, "null settings array");
+    for (uint32_t i = 0; i < d->n_particle_settings; i++) {
+        const fw_particle_settings &p = d->particle_settings[i];
+        const int32_t ns[3] = {p.scale_curve.n, p.base_color.n, p.emissive_color.n};
+        const int32_t ks[3] = {p.scale_curve.kind, p.base_color.kind, p.emissive_color.kind};
+        const void *vs[3] = {p.scale_curve.values, p.base_color.rgba, p.emissive_color.rgba};
+        const void *ts[3] = {p.scale_curve.times, p.base_color.times, p.emissive_color.times};
+        for (int k = 0; k < 3; k++) {
+            if (ns[k] < 1) return fail(ctx, FW_EINVAL, "Cannot create curve from 0 samples");  // curve.rs:45,61,211,227
+            if (ns[k] > FW_MAX_KEYS) return fail(ctx, FW_EINVAL, "curve has more than FW_MAX_KEYS keys");
+            if (ks[k] < 0 || ks[k] > 2 || !vs[k]) return fail(ctx, FW_EINVAL, "bad curve kind / null values");
+            if (ks[k] == FW_CURVE_UNEVEN && !ts[k]) return fail(ctx, FW_EINVAL, "uneven curve without times");
+        }
+    }
+    for (uint32_t i = 0; i < d->n_emission_settings; i++) {
+        const fw_emission_settings &e = d->emission_settings[i];
+        if (e.particle_index < 0 || (uint32_t)e.particle_index >= d->n_particle_settings)
+            return fail(ctx, FW_EINVAL, "emission_settings.particle_index out of range");  // index panic core.rs:392
+        if (e.mode == FW_MODE_NESTED &&
+            (e.target_particle_type < 0 || (uint32_t)e.target_particle_type >= d->n_particle_settings))
+            return fail(ctx, FW_EINVAL, "target_particle_type out of range");  // index panic core.rs:488
+        if (e.mode != FW_MODE_GLOBAL && e.mode != FW_MODE_NESTED) return fail(ctx, FW_EINVAL, "bad emission mode");
+        if (e.pacing_kind < 0 || e.pacing_kind > 2) return fail(ctx, FW_EINVAL, "bad pacing kind");
+        if (e.shape_kind < 0 || e.shape_kind > 2) return fail(ctx, FW_EINVAL, "bad shape kind");
+    }
+    return FW_OK;
+}
+
+// capacity heuristic: expected live count from the emitters feeding a type, x1.25 + slack
+uint32_t derive_capacity(const fw_spawner_desc *d, uint32_t t, const std::vector<uint32_t> &caps) {
+    const fw_particle_settings &p = d->particle_settings[t];
+    if (p.capacity) return round_up(std::max<uint32_t>(p.capacity, FW_TILE), FW_TILE);
+    const double life = std::max(0.0, (double)std::max(p.lifetime.min, p.lifetime.max));
+    double need = 0;
+    for (uint32_t i = 0; i < d->n_emission_settings; i++) {
+        const fw_emission_settings &e = d->emission_settings[i];
+        if ((uint32_t)e.particle_index != t) continue;
+        if (e.mode == FW_MODE_GLOBAL) {
+            if (e.pacing_kind == FW_PACING_ONESHOT)
+                need += (double)e.oneshot_count;
+            else if (e.pacing_kind == FW_PACING_COUNT_OVER_DURATION && e.duration > 0 && e.count > 0)
+                need += (double)e.count / e.duration * (life + 0.05) + 2 * (double)e.count / e.duration / 30.0;
+        } else if (e.pacing_kind == FW_PACING_COUNT_OVER_DURATION && e.count > 0) {
+            const fw_particle_settings &pp = d->particle_settings[e.target_particle_type];
+            const double plife = std::max(1e-3, (double)std::min(pp.lifetime.min, pp.lifetime.max));
+            const double pcap = caps[e.target_particle_type] ? caps[e.target_particle_type] : kMinCapacity;
+            need += pcap * (double)e.count * std::max(1.0, life / plife + 0.1);
+        }
+    }
+    need = need * 1.25 + kMinCapacity;
+    if (need > 3.0e9) need = 3.0e9;
+    return round_up((uint32_t)need, FW_TILE);
+}
+
+void fill_randvec3(const fw_rand_vec3 &r, float &mn, float &mx, float &spread, float dir[4], float arc[4]) {
+    mn = r.magnitude.min, mx = r.magnitude.max, spread = r.spread;
+    dir[0] = r.direction[0], dir[1] = r.direction[1], dir[2] = r.direction[2], dir[3] = 0.f;
+    fw_q4 q = fw_quat_from_rotation_arc(fw_v3{0.f, 1.f, 0.f}, fw_v3{r.direction[0], r.direction[1], r.direction[2]});
+    arc[0] = q.x, arc[1] = q.y, arc[2] = q.z, arc[3] = q.w;
+}
+
+uint32_t pad4(uint32_t n) { return (n + 3u) & ~3u; }
+
+// builds the device tables (types, keys, emits, segments) of one spawner
+fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std::vector<uint64_t> *carry_serial) {
+    SpawnerHost &sp = ctx->spawners[h];
+    const uint32_t nt = d->n_particle_settings, ne = d->n_emission_settings;
+    sp.uid = d->uid;
+    sp.starts_enabled = d->starts_enabled;
+    sp.types.assign(nt, TypeHost{});
+    sp.em.assign(ne, EmissionHost{});
+    sp.seg.assign(nt, 0);
+
+    fw_status st;
+    if ((st = dev_reserve(ctx, ctx->d_types, ctx->n_types + nt, ctx->n_types))) return st;
+    if ((st = dev_reserve(ctx, ctx->d_emits, ctx->n_emits + ne, ctx->n_emits))) return st;
+    if ((st = dev_reserve(ctx, ctx->d_emit_serial, ctx->n_emit_slots + ne, ctx->n_emit_slots))) return st;
+    if ((st = dev_reserve(ctx, ctx->d_keys, ctx->keys_used + (size_t)nt * FW_KEYS_MAX, ctx->keys_used))) return st;
+    if ((st = dev_reserve(ctx, ctx->d_segs, ctx->segs.size() + nt, ctx->segs.size()))) return st;
+    if ((st = ensure_max_seg(ctx, (uint32_t)ctx->segs.size() + nt))) return st;
+    ctx->g.types = ctx->d_types.d, ctx->g.emits = ctx->d_emits.d, ctx->g.keys = ctx->d_keys.d;
+    ctx->g.segs = ctx->d_segs.d, ctx->g.emit_serial = ctx->d_emit_serial.d;
+
+    std::vector<uint32_t> caps(nt, 0);
+    for (int pass = 0; pass < 2; pass++)
+        for (uint32_t t = 0; t < nt; t++) caps[t] = derive_capacity(d, t, caps);
+
+    for (uint32_t t = 0; t < nt; t++) {
+        TypeHost &T = sp.types[t];
+        const fw_particle_settings &p = d->particle_settings[t];
+        T.ps = p;
+        copy_curve(T.scale, p.scale_curve.kind, p.scale_curve.n, p.scale_curve.times, p.scale_curve.values, 1);
+        copy_curve(T.base, p.base_color.kind, p.base_color.n, p.base_color.times, p.base_color.rgba, 4);
+        copy_curve(T.emis, p.emissive_color.kind, p.emissive_color.n, p.emissive_color.times, p.emissive_color.rgba, 4);
+        T.ps.scale_curve.times = T.ps.scale_curve.values = nullptr;  // descriptors are copied, never kept
+        T.ps.base_color.times = T.ps.base_color.rgba = nullptr;
+        T.ps.emissive_color.times = T.ps.emissive_color.rgba = nullptr;
+
+        FwType dt{};
+        memcpy(dt.acc, p.acceleration, sizeof dt.acc);
+        memcpy(dt.angacc, p.angular_acceleration, sizeof dt.angacc);
+        dt.lin_drag = p.linear_drag, dt.ang_drag = p.angular_drag;
+        dt.sc_kind = T.scale.kind, dt.sc_n = T.scale.n;
+        dt.bc_kind = T.base.kind, dt.bc_n = T.base.n;
+        dt.em_kind = T.emis.kind, dt.em_n = T.emis.n;
+        dt.pbr = p.pbr, dt.report_destroyed = p.report_destroyed;
+        std::vector<float> keys;
+        auto put = [&](const std::vector<float> &v, uint32_t padded) {
+            uint32_t off = (uint32_t)keys.size();
+            keys.insert(keys.end(), v.begin(), v.end());
+            keys.resize(off + padded, 0.f);
+            return off;
+        };
+        put(T.scale.times, pad4(T.scale.n));
+        dt.o_sc_v = put(T.scale.values, pad4(T.scale.n));
+        dt.o_bc_t = put(T.base.times, pad4(T.base.n));
+        dt.o_bc_v = put(T.base.values, 4 * T.base.n);
+        dt.o_em_t = put(T.emis.times, pad4(T.emis.n));
+        dt.o_em_v = put(T.emis.values, 4 * T.emis.n);
+        if (keys.size() > FW_KEYS_MAX) return fail(ctx, FW_EINVAL, "curve keys exceed the LDS staging area");
+        dt.keys_off = (uint32_t)ctx->keys_used;
+        dt.keys_len = (uint32_t)keys.size();
+        FW_HIP(ctx, hipMemcpy(ctx->d_keys.d + ctx->keys_used, keys.data(), keys.size() * sizeof(float),
+                              hipMemcpyHostToDevice));
+        ctx->keys_used += keys.size();
+        const uint32_t type_idx = ctx->n_types++;
+        FW_HIP(ctx, hipMemcpy(ctx->d_types.d + type_idx, &dt, sizeof dt, hipMemcpyHostToDevice));
+
+        // segment
+        uint32_t si = (uint32_t)ctx->segs.size();
+        for (uint32_t k = 0; k < ctx->segs.size(); k++)
+            if (!ctx->segs[k].in_use) {
+                si = k;
+                break;
+            }
+        if (si == ctx->segs.size()) ctx->segs.push_back(SegHost{});
+        SegHost &S = ctx->segs[si];
+        S = SegHost{};
+        S.in_use = true, S.spawner = h, S.type = (int)t, S.type_idx = type_idx;
+        for (int k = 0; k < FW_MAX_EMISSIONS; k++) S.lplane_emission[k] = -1;
+        for (uint32_t i = 0; i < ne; i++) {
+            const fw_emission_settings &e = d->emission_settings[i];
+            if (e.mode == FW_MODE_NESTED && (uint32_t)e.target_particle_type == t)
+                S.lplane_emission[S.n_lplanes++] = (int32_t)i;
+            if (e.mode == FW_MODE_NESTED && (uint32_t)e.particle_index == t) S.nested_fed = true;
+        }
+        if ((st = alloc_seg_buffers(ctx, S, caps[t], p.report_destroyed != 0))) return st;
+        sp.seg[t] = si;
+        if ((st = upload_seg(ctx, si))) return st;
+        const uint32_t zero2[2] = {0, 0};
+        for (int r = 0; r < 2; r++) {
+            FW_HIP(ctx, hipMemcpy(ctx->g.count + (size_t)r * ctx->max_seg + si, zero2, 4, hipMemcpyHostToDevice));
+            FW_HIP(ctx, hipMemcpy(ctx->g.spawned + (size_t)r * ctx->max_seg + si, zero2, 4, hipMemcpyHostToDevice));
+            FW_HIP(ctx, hipMemcpy(ctx->g.appended + (size_t)r * ctx->max_seg + si, zero2, 4, hipMemcpyHostToDevice));
+        }
+        FW_HIP(ctx, hipMemcpy(ctx->g.ndestroyed + si, zero2, 4, hipMemcpyHostToDevice));
+    }
+
+    for (uint32_t i = 0; i < ne; i++) {
+        EmissionHost &E = sp.em[i];
+        const fw_emission_settings &e = d->emission_settings[i];
+        E.es = e;
+        E.last_emission = 0.f, E.time_passed_in_cycle = 0.f;  // sync_spawner_data core.rs:350-358
+        E.enabled = d->starts_enabled != 0;
+        E.emits_on_other_particles = e.mode == FW_MODE_NESTED;
+        E.serial = carry_serial && i < carry_serial->size() ? (*carry_serial)[i] : 0;
+        const fw_particle_settings &p = d->particle_settings[e.particle_index];
+        FwEmit de{};
+        de.shape_kind = e.shape_kind, de.shape_radius = e.shape_radius;
+        de.uid = d->uid, de.emission_index = i;
+        fw_q4 sa = fw_quat_from_rotation_arc(fw_v3{0.f, 1.f, 0.f},
+                                             fw_v3{e.shape_normal[0], e.shape_normal[1], e.shape_normal[2]});
+        de.shape_arc[0] = sa.x, de.shape_arc[1] = sa.y, de.shape_arc[2] = sa.z, de.shape_arc[3] = sa.w;
+        fill_randvec3(e.initial_velocity, de.v_mag_min, de.v_mag_max, de.v_spread, de.v_dir, de.v_arc);
+        fill_randvec3(e.initial_angular_velocity, de.w_mag_min, de.w_mag_max, de.w_spread, de.w_dir, de.w_arc);
+        de.inherit = e.inherit_parent_velocity;
+        de.type_idx = ctx->segs[sp.seg[e.particle_index]].type_idx;
+        memcpy(de.init_rot, e.initial_rotation, sizeof de.init_rot);
+        de.radial_min = e.initial_velocity_radial.min, de.radial_max = e.initial_velocity_radial.max;
+        de.iscale_min = p.initial_scale.min, de.iscale_max = p.initial_scale.max;
+        de.life_min = p.lifetime.min, de.life_max = p.lifetime.max;
+        de.n_count = e.count, de.n_start = e.offset_start, de.n_end = e.offset_end;
+        de.n_lplane = 0;
+        if (e.mode == FW_MODE_NESTED) {
+            const SegHost &P = ctx->segs[sp.seg[e.target_particle_type]];
+            for (uint32_t k = 0; k < P.n_lplanes; k++)
+                if (P.lplane_emission[k] == (int32_t)i) de.n_lplane = k;
+        }
+        E.emit_idx = ctx->n_emits++;
+        E.emit_slot = ctx->n_emit_slots++;
+        FW_HIP(ctx, hipMemcpy(ctx->d_emits.d + E.emit_idx, &de, sizeof de, hipMemcpyHostToDevice));
+        const unsigned long long s0 = E.serial;
+        FW_HIP(ctx, hipMemcpy(ctx->d_emit_serial.d + E.emit_slot, &s0, sizeof s0, hipMemcpyHostToDevice));
+    }
+    sp.initialized = true;
+    return ensure_tile_arrays(ctx);
+}
+
+fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
+    for (uint32_t si : sp.seg) {
+        SegHost &S = ctx->segs[si];
+        if (!S.in_use) continue;
+        if (S.buf[0]) FW_HIP(ctx, hipFree(S.buf[0]));
+        if (S.destroyed) FW_HIP(ctx, hipFree(S.destroyed));
+        S = SegHost{};
+        const uint32_t zero = 0;
+        for (int r = 0; r < 2; r++)
+            FW_HIP(ctx, hipMemcpy(ctx->g.count + (size_t)r * ctx->max_seg + si, &zero, 4, hipMemcpyHostToDevice));
+    }
+    sp.seg.clear();
+    return FW_OK;
+}
+
+SpawnerHost *get_spawner(fw_ctx *ctx, fw_spawner h) {
+    if (!ctx || h < 0 || (size_t)h >= ctx->spawners.size() || !ctx->spawners[h].alive) {
+        if (ctx) ctx->err = "invalid spawner handle";
+        return nullptr;
+    }
+    return &ctx->spawners[h];
+}
+
+// consume finished live-count snapshots to tighten the host upper bounds (no sync)
+void poll_snapshots(fw_ctx *ctx) {
+    for (int k = 0; k < kSnapRing; k++) {
+        if (!ctx->snap_pending[k]) continue;
+        if (hipEventQuery(ctx->ev_snap[k]) != hipSuccess) continue;
+        ctx->snap_pending[k] = false;
+        const uint32_t *snap = ctx->h_snap + (size_t)k * ctx->max_seg;
+        const auto &cum = ctx->snap_cum[k];
+        for (size_t i = 0; i < ctx->segs.size() && i < cum.size(); i++) {
+            SegHost &S = ctx->segs[i];
+            if (!S.in_use || S.nested_fed) continue;
+            const uint64_t b = (uint64_t)snap[i] + (S.cum_spawn - cum[i]);
+            if (b < S.ub) S.ub = (uint32_t)b;
+        }
+    }
+}
+
+fw_status read_counts(fw_ctx *ctx, std::vector<uint32_t> &out) {
+    fw_status st = sync(ctx);
+    if (st) return st;
+    out.assign(ctx->segs.size(), 0);
+    if (!out.empty())
+        FW_HIP(ctx, hipMemcpy(out.data(), ctx->g.count + (size_t)ctx->parity * ctx->max_seg,
+                              out.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return check_device_errors(ctx);
+}
+
+// ParticleSpawnerData::active (core.rs:288-302) with exact device counts
+bool spawner_active(const fw_ctx *ctx, const SpawnerHost &sp, const std::vector<uint32_t> &counts) {
+    bool any = false;
+    for (uint32_t si : sp.seg) any |= counts[si] != 0;
+    bool enabled = false;
+    for (const EmissionHost &e : sp.em) enabled |= e.emits_on_other_particles ? (e.enabled && any) : e.enabled;
+    (void)ctx;
+    return enabled;
+}
+
+}  // namespace
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+
+extern "C" {
+
+int fw_abi_version(void) { return FW_ABI_VERSION; }
+
+const char *fw_last_error(const fw_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+uint64_t fw_compute_emission_count(float t, float last, float dur, float start, float end, float per_cycle,
+                                   float *next_last) {
+    float nl = 0.f;
+    const uint64_t n = fw_emission_count(t, last, dur, start, end, per_cycle, &nl);
+    if (next_last) *next_last = nl;
+    return n;
+}
+
+fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
+    if (!out) return FW_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("no HIP device available (") + hipGetErrorString(e) +
+                         "); this backend has no CPU fallback";
+        return FW_ENODEV;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_error = "device index out of range";
+        return FW_EINVAL;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return FW_ENODEV;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName;
+        return FW_ENODEV;
+    }
+    fw_ctx *ctx = new fw_ctx();
+    ctx->device = device;
+    ctx->seed = seed;
+    auto bail = [&](const char *what, hipError_t he) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(he);
+        delete ctx;
+        return FW_EHIP;
+    };
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+            return bail("hipStreamCreate", e);
+        ctx->own_stream = true;
+    }
+    if ((e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate(copy)", e);
+    for (int i = 0; i < kParamRing; i++) {
+        if ((e = hipEventCreateWithFlags(&ctx->ev_copied[i], hipEventDisableTiming)) != hipSuccess)
+            return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&ctx->ev_consumed[i], hipEventDisableTiming)) != hipSuccess)
+            return bail("hipEventCreate", e);
+    }
+    for (int i = 0; i < kSnapRing; i++)
+        if ((e = hipEventCreateWithFlags(&ctx->ev_snap[i], hipEventDisableTiming)) != hipSuccess)
+            return bail("hipEventCreate", e);
+    if ((e = hipMalloc((void **)&ctx->g.err, 64)) != hipSuccess) return bail("hipMalloc", e);
+    hipMemset(ctx->g.err, 0, 64);
+    if ((e = hipMalloc((void **)&ctx->g.stats, 64)) != hipSuccess) return bail("hipMalloc", e);
+    hipMemset(ctx->g.stats, 0, 64);
+    if ((e = hipMalloc((void **)&ctx->d_aabb, 64)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&ctx->d_total, 64)) != hipSuccess) return bail("hipMalloc", e);
+    ctx->g.seed = seed;
+    if (const char *m = getenv("FW_UPDATE_MODE")) ctx->update_mode = !strcmp(m, "split") ? FW_MODE_SPLIT : FW_MODE_FUSED;
+    if (const char *m = getenv("FW_SPIN_LIMIT")) ctx->spin_limit = (uint32_t)strtoul(m, nullptr, 10);
+    if (ensure_max_seg(ctx, 1024) != FW_OK) {
+        g_create_error = ctx->err;
+        delete ctx;
+        return FW_EHIP;
+    }
+    *out = ctx;
+    return FW_OK;
+}
+
+fw_status fw_ctx_destroy(fw_ctx *ctx) {
+    if (!ctx) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipStreamSynchronize(ctx->copy_stream);
+    for (auto &S : ctx->segs) {
+        if (S.buf[0]) hipFree(S.buf[0]);
+        if (S.destroyed) hipFree(S.destroyed);
+    }
+    void *frees[] = {ctx->d_segs.d,       ctx->d_types.d,       ctx->d_keys.d,        ctx->d_emits.d,
+                     ctx->d_emit_serial.d, ctx->g.count,        ctx->g.spawned,       ctx->g.appended,
+                     ctx->g.ndestroyed,   ctx->g.tile_cnt,      ctx->g.tile_off,      ctx->g.tile_status,
+                     ctx->g.err,          ctx->g.stats,         ctx->g.nest_tile_cnt, ctx->g.nest_tile_off,
+                     ctx->g.nest_op_npar, ctx->g.nest_op_base,  ctx->g.nest_op_total, ctx->g.nest_op_serial,
+                     ctx->d_aabb,         ctx->d_total,         ctx->d_segids};
+    for (void *p : frees)
+        if (p) hipFree(p);
+    for (int i = 0; i < kParamRing; i++) {
+        if (ctx->h_param[i]) hipHostFree(ctx->h_param[i]);
+        if (ctx->d_param[i]) hipFree(ctx->d_param[i]);
+        hipEventDestroy(ctx->ev_copied[i]);
+        hipEventDestroy(ctx->ev_consumed[i]);
+    }
+    for (int i = 0; i < kSnapRing; i++) hipEventDestroy(ctx->ev_snap[i]);
+    if (ctx->h_snap) hipHostFree(ctx->h_snap);
+    for (hipEvent_t ev : ctx->tev) hipEventDestroy(ev);
+    hipStreamDestroy(ctx->copy_stream);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return FW_OK;
+}
+
+void *fw_ctx_stream(const fw_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+fw_status fw_ctx_synchronize(fw_ctx *ctx) {
+    if (!ctx) return FW_EINVAL;
+    fw_status st = sync(ctx);
+    if (st) return st;
+    return check_device_errors(ctx);
+}
+
+fw_status fw_spawner_create(fw_ctx *ctx, const fw_spawner_desc *desc, fw_spawner *out) {
+    if (!ctx || !out) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    fw_status st = validate_desc(ctx, desc);
+    if (st) return st;
+    if ((st = sync(ctx))) return st;
+    int h = -1;
+    for (size_t i = 0; i < ctx->spawners.size(); i++)
+        if (!ctx->spawners[i].alive) {
+            h = (int)i;
+            break;
+        }
+    if (h < 0) {
+        ctx->spawners.push_back(SpawnerHost{});
+        h = (int)ctx->spawners.size() - 1;
+    }
+    ctx->spawners[h] = SpawnerHost{};
+    ctx->spawners[h].alive = true;
+    st = build_spawner(ctx, h, desc, nullptr);
+    if (st) {
+        release_spawner_segments(ctx, ctx->spawners[h]);
+        ctx->spawners[h].alive = false;
+        return st;
+    }
+    *out = h;
+    return FW_OK;
+}
+
+fw_status fw_spawner_update_settings(fw_ctx *ctx, fw_spawner h, const fw_spawner_desc *desc) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    fw_status st = validate_desc(ctx, desc);
+    if (st) return st;
+    if ((st = sync(ctx))) return st;
+    // RNG streams never replay: carry the serials of surviving emission indices
+    std::vector<uint64_t> serials;
+    for (const EmissionHost &e : sp->em) {
+        unsigned long long s = e.serial;
+        if (e.es.mode == FW_MODE_NESTED)
+            hipMemcpy(&s, ctx->d_emit_serial.d + e.emit_slot, sizeof s, hipMemcpyDeviceToHost);
+        serials.push_back(s);
+    }
+    if ((st = release_spawner_segments(ctx, *sp))) return st;
+    const bool finished_notified = sp->finished_notified;
+    SpawnerHost keep = *sp;
+    *sp = SpawnerHost{};
+    sp->alive = true;
+    sp->manual_queued_count = keep.manual_queued_count;
+    memcpy(sp->origin_pos, keep.origin_pos, sizeof keep.origin_pos);
+    memcpy(sp->origin_rot, keep.origin_rot, sizeof keep.origin_rot);
+    memcpy(sp->parent_vel, keep.parent_vel, sizeof keep.parent_vel);
+    sp->mod_scale = keep.mod_scale, sp->mod_speed = keep.mod_speed;
+    st = build_spawner(ctx, h, desc, &serials);
+    ctx->spawners[h].finished_notified = finished_notified;
+    return st;
+}
+
+fw_status fw_spawner_destroy(fw_ctx *ctx, fw_spawner h) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    fw_status st = sync(ctx);
+    if (st) return st;
+    if ((st = release_spawner_segments(ctx, *sp))) return st;
+    *sp = SpawnerHost{};
+    return FW_OK;
+}
+
+fw_status fw_spawner_set_origin(fw_ctx *ctx, fw_spawner h, const float t[3], const float r[4]) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || !t || !r) return FW_EINVAL;
+    memcpy(sp->origin_pos, t, sizeof sp->origin_pos);
+    memcpy(sp->origin_rot, r, sizeof sp->origin_rot);
+    return FW_OK;
+}
+
+fw_status fw_spawner_set_parent_velocity(fw_ctx *ctx, fw_spawner h, const float v[3]) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || !v) return FW_EINVAL;
+    memcpy(sp->parent_vel, v, sizeof sp->parent_vel);
+    return FW_OK;
+}
+
+fw_status fw_spawner_set_modifier(fw_ctx *ctx, fw_spawner h, float scale, float speed) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp) return FW_EINVAL;
+    sp->mod_scale = scale, sp->mod_speed = speed;
+    return FW_OK;
+}
+
+fw_status fw_spawner_queue(fw_ctx *ctx, fw_spawner h, uint64_t count) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp) return FW_EINVAL;
+    sp->manual_queued_count += count;  // core.rs:284-286
+    return FW_OK;
+}
+
+// ---- the frame ---------------------------------------------------------------------------
+fw_status fw_step(fw_ctx *ctx, float dt) {
+    if (!ctx) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    poll_snapshots(ctx);
+
+    struct Level {
+        std::vector<FwOp> g;
+        std::vector<FwNestOp> n;
+    };
+    Level levels[FW_MAX_EMISSIONS];
+    for (auto &S : ctx->segs) S.frame_spawn = 0;
+
+    // spawn_particles, host half (core.rs:377-428): emission clocks and Global counts
+    for (size_t h = 0; h < ctx->spawners.size(); h++) {
+        SpawnerHost &sp = ctx->spawners[h];
+        if (!sp.alive) continue;
+        // `if data.active()` (core.rs:378): an entry that emits on other particles contributes only when
+        // some particle exists; with no particle at all the Nested arm below is a no-op anyway, so the
+        // host-side gate "any entry enabled" gives the same state transitions without a device round trip.
+        bool any_enabled = false;
+        for (const EmissionHost &e : sp.em) any_enabled |= e.enabled;
+        if (!any_enabled) continue;
+        for (size_t i = 0; i < sp.em.size(); i++) {
+            EmissionHost &E = sp.em[i];
+            if (!E.enabled) continue;
+            const fw_emission_settings &es = E.es;
+            const uint32_t dst = sp.seg[es.particle_index];
+            if (es.mode == FW_MODE_GLOBAL) {
+                uint64_t n = 0;
+                if (es.pacing_kind == FW_PACING_ONESHOT) {
+                    E.enabled = false;  // core.rs:397-400
+                    n = es.oneshot_count;
+                } else if (es.pacing_kind == FW_PACING_ONDEMAND) {
+                    n = sp.manual_queued_count;  // core.rs:401-405
+                    sp.manual_queued_count = 0;
+                } else {
+                    E.time_passed_in_cycle = fw_rem_euclid(E.time_passed_in_cycle + dt, es.duration);  // core.rs:412-414
+                    float next = 0.f;
+                    n = fw_emission_count(E.time_passed_in_cycle, E.last_emission, es.duration, es.offset_start,
+                                          es.offset_end, es.count, &next);
+                    E.last_emission = next;
+                }
+                if (!n) continue;
+                if (n > kMaxSpawnPerOp)
+                    return fail(ctx, FW_ECAPACITY, "emission count exceeds 2^30 particles in one frame");
+                SegHost &S = ctx->segs[dst];
+                if (!S.nested_fed && (uint64_t)S.ub + n > S.capacity) {
+                    fw_status st = refresh_counts_exact(ctx);
+                    if (st) return st;
+                    // the refresh dropped this frame's earlier appends from ub: add them back
+                    for (auto &X : ctx->segs) X.ub += X.frame_spawn;
+                    if ((uint64_t)S.ub + n > S.capacity) {
+                        if ((uint64_t)S.ub + n > 0xF0000000ull) return fail(ctx, FW_ECAPACITY, "particle type too large");
+                        // grow_segment copies `ub - frame_spawn` settled particles; appended ones are not on the
+                        // device yet (spawn kernels of this frame have not been enqueued)
+                        const uint32_t fs = S.frame_spawn;
+                        S.ub -= fs;
+                        const uint32_t settled = S.ub;
+                        if ((st = grow_segment(ctx, dst, (uint32_t)(settled + fs + n)))) return st;
+                        for (auto &X : ctx->segs) X.ub += X.frame_spawn;
+                    }
+                }
+                FwOp op{};
+                op.seg = dst, op.emit = E.emit_idx, op.n = (uint32_t)n;
+                op.rel_base = S.frame_spawn;
+                op.serial_base = E.serial;
+                memcpy(op.origin_pos, sp.origin_pos, sizeof sp.origin_pos);
+                memcpy(op.origin_rot, sp.origin_rot, sizeof sp.origin_rot);
+                memcpy(op.parent_vel, sp.parent_vel, sizeof sp.parent_vel);
+                op.speed = sp.mod_speed, op.scale = sp.mod_scale;
+                levels[i].g.push_back(op);
+                E.serial += n;
+                S.frame_spawn += (uint32_t)n;
+                S.cum_spawn += n;
+                S.ub = (uint32_t)std::min<uint64_t>((uint64_t)S.ub + n, 0xFFFFFFFFull);
+            } else {
+                if (es.pacing_kind != FW_PACING_COUNT_OVER_DURATION) continue;  // warn_once + continue core.rs:474-485
+                const SegHost &P = ctx->segs[sp.seg[es.target_particle_type]];
+                FwNestOp op{};
+                op.parent_seg = sp.seg[es.target_particle_type], op.child_seg = dst;
+                op.emit = E.emit_idx, op.emit_slot = E.emit_slot;
+                op.n_tiles = seg_tiles(P);
+                op.speed = sp.mod_speed, op.scale = sp.mod_scale;
+                levels[i].n.push_back(op);
+            }
+        }
+    }
+
+    // ---- lay the frame parameters out in one buffer: [seg_tile_first | FwOp[] | FwNestOp[]]
+    const uint32_t n_seg = (uint32_t)ctx->segs.size();
+    size_t n_g = 0, n_n = 0;
+    for (auto &L : levels) n_g += L.g.size(), n_n += L.n.size();
+    const size_t off_ops = round_up((n_seg + 1) * sizeof(uint32_t), 16);
+    const size_t off_nops = off_ops + n_g * sizeof(FwOp);
+    const size_t bytes = off_nops + n_n * sizeof(FwNestOp) + 16;
+    fw_status st = ensure_param_ring(ctx, bytes);
+    if (st) return st;
+    const int slot = (int)(ctx->frame % kParamRing);
+    if (ctx->consumed_pending[slot]) {
+        FW_HIP(ctx, hipEventSynchronize(ctx->ev_consumed[slot]));
+        ctx->consumed_pending[slot] = false;
+    }
+    char *hp = ctx->h_param[slot];
+    char *dp = ctx->d_param[slot];
+    uint32_t *tile_first = (uint32_t *)hp;
+    uint32_t total_tiles = 0;
+    for (uint32_t i = 0; i < n_seg; i++) {
+        tile_first[i] = total_tiles;
+        total_tiles += seg_tiles(ctx->segs[i]);
+    }
+    tile_first[n_seg] = total_tiles;
+
+    struct Launch {
+        bool nested;
+        size_t first, count;
+        uint32_t blocks;
+    };
+    std::vector<Launch> launches;
+    FwOp *h_ops = (FwOp *)(hp + off_ops);
+    FwNestOp *h_nops = (FwNestOp *)(hp + off_nops);
+    size_t gi = 0, ni = 0, pend_first = 0;
+    uint32_t pend_blocks = 0;
+    auto flush_global = [&]() {
+        if (gi > pend_first) launches.push_back(Launch{false, pend_first, gi - pend_first, pend_blocks});
+        pend_first = gi;
+        pend_blocks = 0;
+    };
+    for (auto &L : levels) {
+        for (FwOp op : L.g) {
+            op.first_block = pend_blocks;
+            pend_blocks += (op.n + FW_BLOCK - 1) / FW_BLOCK;
+            h_ops[gi++] = op;
+        }
+        if (!L.n.empty()) {
+            flush_global();
+            const size_t first = ni;
+            uint32_t tiles = 0;
+            for (FwNestOp op : L.n) {
+                op.first_tile = tiles;
+                tiles += op.n_tiles;
+                h_nops[ni++] = op;
+            }
+            launches.push_back(Launch{true, first, ni - first, tiles});
+        }
+    }
+    flush_global();
+
+    FW_HIP(ctx, hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    FW_HIP(ctx, hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
+    FW_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
+
+    const uint32_t p = ctx->parity;
+    for (const Launch &L : launches) {
+        if (!L.nested)
+            FW_HIP(ctx, fw_launch_spawn(ctx->stream, ctx->g, (const FwOp *)(dp + off_ops) + L.first, (uint32_t)L.count,
+                                        L.blocks, p));
+        else
+            FW_HIP(ctx, fw_launch_nested(ctx->stream, ctx->g, (const FwNestOp *)(dp + off_nops) + L.first,
+                                         (uint32_t)L.count, L.blocks, p));
+    }
+
+    // update_particles + compaction (core.rs:577-670)
+    const int snap = (int)(ctx->frame % kSnapRing);
+    FwUpdateArgs a{};
+    a.seg_tile_first = (const uint32_t *)dp;
+    a.n_seg = n_seg;
+    a.total_tiles = total_tiles;
+    a.parity = p;
+    a.epoch = (uint32_t)((ctx->frame + 1) & 0x3FFFFFFFu);
+    if (!a.epoch) a.epoch = 1;
+    a.dt = dt;
+    a.spin_limit = ctx->spin_limit;
+    a.host_counts = ctx->h_snap + (size_t)snap * ctx->max_seg;
+    if (ctx->timing && ctx->tev_used + 2 <= ctx->tev.size())
+        FW_HIP(ctx, hipEventRecord(ctx->tev[ctx->tev_used], ctx->stream));
+    FW_HIP(ctx, fw_launch_update(ctx->stream, ctx->g, a, ctx->update_mode));
+    if (ctx->timing && ctx->tev_used + 2 <= ctx->tev.size()) {
+        FW_HIP(ctx, hipEventRecord(ctx->tev[ctx->tev_used + 1], ctx->stream));
+        ctx->tev_used += 2;
+    }
+    FW_HIP(ctx, hipEventRecord(ctx->ev_consumed[slot], ctx->stream));
+    ctx->consumed_pending[slot] = true;
+    FW_HIP(ctx, hipEventRecord(ctx->ev_snap[snap], ctx->stream));
+    ctx->snap_pending[snap] = true;
+    ctx->snap_cum[snap].resize(n_seg);
+    for (uint32_t i = 0; i < n_seg; i++) ctx->snap_cum[snap][i] = ctx->segs[i].cum_spawn;
+
+    ctx->parity ^= 1u;
+    ctx->frame++;
+    return FW_OK;
+}
+
+// ---- outputs -----------------------------------------------------------------------------
+fw_status fw_spawner_counts(fw_ctx *ctx, fw_spawner h, uint32_t *per_type, uint32_t n_types) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || !per_type) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    std::vector<uint32_t> c;
+    fw_status st = read_counts(ctx, c);
+    if (st && st != FW_ECAPACITY) return st;
+    for (uint32_t t = 0; t < n_types && t < sp->seg.size(); t++) per_type[t] = c[sp->seg[t]];
+    return st;
+}
+
+fw_status fw_spawner_active(fw_ctx *ctx, fw_spawner h, int32_t *out) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || !out) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    std::vector<uint32_t> c;
+    fw_status st = read_counts(ctx, c);
+    if (st && st != FW_ECAPACITY) return st;
+    *out = spawner_active(ctx, *sp, c) ? 1 : 0;
+    return st;
+}
+
+fw_status fw_spawner_poll_finished(fw_ctx *ctx, fw_spawner h, int32_t *out) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || !out) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    std::vector<uint32_t> c;
+    fw_status st = read_counts(ctx, c);
+    if (st && st != FW_ECAPACITY) return st;
+    bool all_empty = true;
+    for (uint32_t si : sp->seg) all_empty &= c[si] == 0;
+    *out = 0;
+    if (all_empty && !spawner_active(ctx, *sp, c) && sp->initialized && !sp->finished_notified) {  // core.rs:679-686
+        sp->finished_notified = true;
+        *out = 1;
+    }
+    return st;
+}
+
+static fw_status read_records(fw_ctx *ctx, const char *buf, uint32_t cap_seg, uint32_t n, int32_t pbr, bool aos,
+                              fw_particle *out, uint64_t cap) {
+    const uint64_t m = std::min<uint64_t>(n, cap);
+    if (!m || !out) return FW_OK;
+    if (aos) {
+        FW_HIP(ctx, hipMemcpy(out, buf, m * sizeof(fw_particle), hipMemcpyDeviceToHost));
+        return FW_OK;
+    }
+    void *tmp = nullptr;
+    FW_HIP(ctx, hipMalloc(&tmp, m * sizeof(fw_particle)));
+    hipError_t e = fw_launch_gather(ctx->stream, buf, cap_seg, (uint32_t)m, pbr, tmp);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, tmp, m * sizeof(fw_particle), hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    FW_HIP(ctx, e);
+    return FW_OK;
+}
+
+fw_status fw_spawner_read_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, fw_particle *out, uint64_t cap,
+                                    uint64_t *n_out) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || type >= sp->seg.size()) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    std::vector<uint32_t> c;
+    fw_status st = read_counts(ctx, c);
+    if (st && st != FW_ECAPACITY) return st;
+    const SegHost &S = ctx->segs[sp->seg[type]];
+    const uint32_t n = c[sp->seg[type]];
+    if (n_out) *n_out = n;
+    fw_status st2 = read_records(ctx, S.buf[ctx->parity], S.capacity, n, sp->types[type].ps.pbr, false, out, cap);
+    return st2 ? st2 : st;
+}
+
+fw_status fw_spawner_read_last_emitted(fw_ctx *ctx, fw_spawner h, uint32_t type, uint32_t emission_index, float *out,
+                                       uint64_t cap, uint64_t *n_out) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || type >= sp->seg.size() || emission_index >= sp->em.size()) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    std::vector<uint32_t> c;
+    fw_status st = read_counts(ctx, c);
+    if (st && st != FW_ECAPACITY) return st;
+    const SegHost &S = ctx->segs[sp->seg[type]];
+    const uint32_t n = c[sp->seg[type]];
+    if (n_out) *n_out = n;
+    const uint64_t m = std::min<uint64_t>(n, cap);
+    if (!m || !out) return st;
+    int plane = -1;
+    for (uint32_t k = 0; k < S.n_lplanes; k++)
+        if (S.lplane_emission[k] == (int32_t)emission_index) plane = (int)k;
+    if (plane < 0) {
+        for (uint64_t i = 0; i < m; i++) out[i] = FW_F32_MIN;  // never touched: still vec![f32::MIN; n] (core.rs:467)
+        return st;
+    }
+    FW_HIP(ctx, hipMemcpy(out, S.buf[ctx->parity] + FW_OFF_L((size_t)S.capacity, plane), m * sizeof(float),
+                          hipMemcpyDeviceToHost));
+    return st;
+}
+
+fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, const fw_particle *in, uint64_t n) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || type >= sp->seg.size() || (n && !in) || n > 0xF0000000ull) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    fw_status st = sync(ctx);
+    if (st) return st;
+    const uint32_t si = sp->seg[type];
+    if (n > ctx->segs[si].capacity) {
+        ctx->segs[si].ub = 0;
+        const uint32_t zero = 0;
+        FW_HIP(ctx, hipMemcpy(ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, &zero, 4, hipMemcpyHostToDevice));
+        if ((st = grow_segment(ctx, si, (uint32_t)n))) return st;
+    }
+    SegHost &S = ctx->segs[si];
+    if (n) {
+        void *tmp = nullptr;
+        FW_HIP(ctx, hipMalloc(&tmp, n * sizeof(fw_particle)));
+        hipError_t e = hipMemcpy(tmp, in, n * sizeof(fw_particle), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = fw_launch_scatter(ctx->stream, S.buf[ctx->parity], S.capacity, (uint32_t)n, S.n_lplanes, tmp);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        hipFree(tmp);
+        FW_HIP(ctx, e);
+    }
+    const uint32_t n32 = (uint32_t)n;
+    FW_HIP(ctx, hipMemcpy(ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, &n32, 4, hipMemcpyHostToDevice));
+    S.ub = n32;
+    for (int i = 0; i < kSnapRing; i++) ctx->snap_pending[i] = false;
+    return FW_OK;
+}
+
+fw_status fw_spawner_write_last_emitted(fw_ctx *ctx, fw_spawner h, uint32_t type, uint32_t emission_index,
+                                        const float *in, uint64_t n) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || type >= sp->seg.size() || emission_index >= sp->em.size() || (n && !in)) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    fw_status st = sync(ctx);
+    if (st) return st;
+    const SegHost &S = ctx->segs[sp->seg[type]];
+    int plane = -1;
+    for (uint32_t k = 0; k < S.n_lplanes; k++)
+        if (S.lplane_emission[k] == (int32_t)emission_index) plane = (int)k;
+    if (plane < 0) return FW_OK;  // entry never reads it
+    const uint64_t m = std::min<uint64_t>(n, S.capacity);
+    if (m)
+        FW_HIP(ctx, hipMemcpy(S.buf[ctx->parity] + FW_OFF_L((size_t)S.capacity, plane), in, m * sizeof(float),
+                              hipMemcpyHostToDevice));
+    return FW_OK;
+}
+
+fw_status fw_spawner_read_destroyed(fw_ctx *ctx, fw_spawner h, uint32_t type, fw_particle *out, uint64_t cap,
+                                    uint64_t *n_out) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || type >= sp->seg.size()) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    fw_status st = sync(ctx);
+    if (st) return st;
+    const SegHost &S = ctx->segs[sp->seg[type]];
+    uint32_t n = 0;
+    if (S.destroyed) FW_HIP(ctx, hipMemcpy(&n, ctx->g.ndestroyed + sp->seg[type], 4, hipMemcpyDeviceToHost));
+    if (n_out) *n_out = n;
+    return read_records(ctx, S.destroyed, S.capacity, n, 0, true, out, cap);
+}
+
+fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap,
+                                           uint64_t *n_upper_bound) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || type >= sp->seg.size() || !d_out) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    const uint32_t si = sp->seg[type];
+    const SegHost &S = ctx->segs[si];
+    const uint32_t ub = (uint32_t)std::min<uint64_t>(S.nested_fed ? S.capacity : std::min(S.ub, S.capacity), cap);
+    if (n_upper_bound) *n_upper_bound = ub;
+    FW_HIP(ctx, fw_launch_pack_instances(ctx->stream, S.buf[ctx->parity], S.capacity,
+                                         ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, ub, d_out));
+    return FW_OK;
+}
+
+fw_status fw_spawner_pack_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, fw_particle_instance *out, uint64_t cap,
+                                    uint64_t *n_out) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || type >= sp->seg.size()) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    std::vector<uint32_t> c;
+    fw_status st = read_counts(ctx, c);
+    if (st && st != FW_ECAPACITY) return st;
+    const uint32_t n = c[sp->seg[type]];
+    if (n_out) *n_out = n;
+    const uint64_t m = std::min<uint64_t>(n, cap);
+    if (!m || !out) return st;
+    void *tmp = nullptr;
+    FW_HIP(ctx, hipMalloc(&tmp, m * sizeof(fw_particle_instance)));
+    uint64_t ub = 0;
+    fw_status st2 = fw_spawner_pack_instances_device(ctx, h, type, tmp, m, &ub);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, tmp, m * sizeof(fw_particle_instance), hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    FW_HIP(ctx, e);
+    return st2 ? st2 : st;
+}
+
+fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out_max[3], int32_t *any) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || !out_min || !out_max) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    std::vector<uint32_t> c;
+    fw_status st = read_counts(ctx, c);
+    if (st && st != FW_ECAPACITY) return st;
+    bool has = false;
+    for (uint32_t si : sp->seg) has |= c[si] != 0;
+    if (any) *any = has ? 1 : 0;
+    const float init[6] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f, FW_F32_MIN, FW_F32_MIN, FW_F32_MIN};
+    float res[6];
+    memcpy(res, init, sizeof res);
+    if (has) {
+        FW_HIP(ctx, hipMemcpy(ctx->d_aabb, init, sizeof init, hipMemcpyHostToDevice));
+        FW_HIP(ctx, hipMemcpy(ctx->d_segids, sp->seg.data(), sp->seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        FW_HIP(ctx, fw_launch_aabb(ctx->stream, ctx->g, ctx->d_segids, (uint32_t)sp->seg.size(), ctx->parity, ctx->d_aabb));
+        FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FW_HIP(ctx, hipMemcpy(res, ctx->d_aabb, sizeof res, hipMemcpyDeviceToHost));
+    }
+    memcpy(out_min, res, 3 * sizeof(float));
+    memcpy(out_max, res + 3, 3 * sizeof(float));
+    return st;
+}
+
+fw_status fw_ctx_live_count(fw_ctx *ctx, uint64_t *out) {
+    if (!ctx || !out) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    std::vector<uint32_t> c;
+    fw_status st = read_counts(ctx, c);
+    if (st && st != FW_ECAPACITY) return st;
+    uint64_t t = 0;
+    for (size_t i = 0; i < c.size(); i++)
+        if (ctx->segs[i].in_use) t += c[i];
+    *out = t;
+    return st;
+}
+
+fw_status fw_ctx_live_count_device(fw_ctx *ctx, void *d_out_u64) {
+    if (!ctx || !d_out_u64) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    FW_HIP(ctx, fw_launch_total(ctx->stream, ctx->g.count + (size_t)ctx->parity * ctx->max_seg,
+                                (uint32_t)ctx->segs.size(), (unsigned long long *)d_out_u64));
+    return FW_OK;
+}
+
+fw_status fw_ctx_last_step_updated(fw_ctx *ctx, uint64_t *out) {
+    if (!ctx || !out) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    fw_status st = sync(ctx);
+    if (st) return st;
+    unsigned long long now = 0;
+    FW_HIP(ctx, hipMemcpy(&now, ctx->g.stats, sizeof now, hipMemcpyDeviceToHost));
+    *out = now;  // running total of particles that entered update_particles
+    return FW_OK;
+}
+
+fw_status fw_ctx_kernel_timing(fw_ctx *ctx, int32_t enable) {
+    if (!ctx) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    fw_status st = sync(ctx);
+    if (st) return st;
+    if (enable && ctx->tev.empty()) {
+        ctx->tev.resize(kTimingEvents);
+        for (auto &ev : ctx->tev) FW_HIP(ctx, hipEventCreate(&ev));
+    }
+    ctx->timing = enable != 0;
+    ctx->tev_used = 0;
+    unsigned long long now = 0;
+    FW_HIP(ctx, hipMemcpy(&now, ctx->g.stats, sizeof now, hipMemcpyDeviceToHost));
+    ctx->timing_particles_start = now;
+    return FW_OK;
+}
+
+fw_status fw_ctx_kernel_timing_read(fw_ctx *ctx, double *ms_total, uint64_t *launches, uint64_t *particles) {
+    if (!ctx) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    fw_status st = sync(ctx);
+    if (st) return st;
+    double ms = 0;
+    for (size_t i = 0; i + 1 < ctx->tev_used; i += 2) {
+        float t = 0;
+        FW_HIP(ctx, hipEventElapsedTime(&t, ctx->tev[i], ctx->tev[i + 1]));
+        ms += t;
+    }
+    if (ms_total) *ms_total = ms;
+    if (launches) *launches = ctx->tev_used / 2;
+    unsigned long long now = 0;
+    FW_HIP(ctx, hipMemcpy(&now, ctx->g.stats, sizeof now, hipMemcpyDeviceToHost));
+    if (particles) *particles = now - ctx->timing_particles_start;
+    return FW_OK;
+}
+
+fw_status fw_ctx_measure_copy_bandwidth(fw_ctx *ctx, uint64_t bytes, int32_t iters, double *bytes_per_s) {
+    if (!ctx || !bytes_per_s || bytes < 4096 || iters < 1) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    bytes &= ~(uint64_t)0xFFF;
+    void *a = nullptr, *b = nullptr;
+    FW_HIP(ctx, hipMalloc(&a, bytes));
+    if (hipMalloc(&b, bytes) != hipSuccess) {
+        hipFree(a);
+        return fail(ctx, FW_ENOMEM, "copy probe allocation");
+    }
+    hipMemset(a, 1, bytes);
+    hipMemset(b, 0, bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    for (int i = 0; i < 3; i++) fw_launch_copy_probe(ctx->stream, a, b, bytes);
+    hipEventRecord(e0, ctx->stream);
+    for (int i = 0; i < iters; i++) fw_launch_copy_probe(ctx->stream, (i & 1) ? b : a, (i & 1) ? a : b, bytes);
+    hipEventRecord(e1, ctx->stream);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0), hipEventDestroy(e1);
+    hipFree(a), hipFree(b);
+    FW_HIP(ctx, e);
+    *bytes_per_s = 2.0 * (double)bytes * iters / (ms * 1e-3);
+    return FW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// fw_kernels.h -- launch interface between the host engine (fw_engine.cpp) and the
+// gfx950 kernels (fw_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fw_device.h"
+
+// pointers to the context's persistent device state (passed by value as a kernel argument)
+struct FwGlobals {
+    FwSeg *segs;
+    FwType *types;
+    float *keys;
+    FwEmit *emits;
+    uint32_t *count;     // [2][max_seg]  live particles per segment, by buffer parity
+    uint32_t *spawned;   // [2][max_seg]  Global spawns appended this frame
+    uint32_t *appended;  // [2][max_seg]  Nested children appended this frame
+    uint32_t *ndestroyed;  // [max_seg]   particles destroyed by the last update
+    uint32_t max_seg;
+    uint32_t seed;
+    uint32_t *tile_cnt;              // split mode: survivors per tile
+    uint32_t *tile_off;              // split mode: exclusive prefix per tile
+    unsigned long long *tile_status; // fused mode: decoupled look-back words
+    uint32_t *err;                   // sticky FW_ERR_* flags
+    unsigned long long *stats;       // [0] particles that entered update (running total)
+    unsigned long long *emit_serial; // RNG serials of Nested emission entries
+    uint32_t *nest_tile_cnt;         // children per parent tile
+    uint32_t *nest_tile_off;         // exclusive prefix of the above, per op
+    uint32_t *nest_op_npar;          // [n_ops] parents visible to the op (bound fixed once, core.rs:488)
+    uint32_t *nest_op_base;          // [n_ops] first child slot in the child segment
+    uint32_t *nest_op_total;         // [n_ops] children spawned (after clamping)
+    unsigned long long *nest_op_serial;  // [n_ops] RNG serial of the first child
+};
+
+struct FwUpdateArgs {
+    const uint32_t *seg_tile_first;  // [n_seg + 1] first tile of each segment (device)
+    uint32_t n_seg;
+    uint32_t total_tiles;
+    uint32_t parity;       // read buf[parity], write buf[parity ^ 1]
+    uint32_t epoch;        // frame number (look-back tag), never 0
+    float dt;
+    uint32_t spin_limit;   // look-back polls before the self-computed fallback
+    uint32_t *host_counts; // pinned host snapshot row for this frame (or null)
+};
+
+enum { FW_MODE_FUSED = 0, FW_MODE_SPLIT = 1 };
+
+hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *ops, uint32_t n_ops, uint32_t total_blocks,
+                           uint32_t parity);
+hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, int mode);
+hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *ops, uint32_t n_ops,
+                            uint32_t total_tiles, uint32_t parity);
+// SoA -> AoS gather of `n` particles of one segment buffer into fw_particle records (device)
+hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t n, int32_t pbr, void *d_out);
+hipError_t fw_launch_scatter(hipStream_t s, char *buf, uint32_t capacity, uint32_t n, uint32_t n_lplanes,
+                             const void *d_in);
+hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, const uint32_t *d_count,
+                                    uint32_t n_upper, void *d_out);
+hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, uint32_t n_segs, uint32_t parity,
+                          float *d_minmax6);
+hipError_t fw_launch_total(hipStream_t s, const uint32_t *counts, uint32_t n_seg, unsigned long long *d_out);
+hipError_t fw_launch_copy_probe(hipStream_t s, const void *src, void *dst, size_t bytes);

@@ -1,0 +1,863 @@
+// fw_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the firework particle backend.
+//
+// The path is a streaming fp32 update: ~0.5 flop/byte, far below the CDNA4 ridge, so
+// there is no MFMA here; every kernel is designed around HBM traffic:
+//   * one particle per lane, float4 planes (fw_device.h) -> every global access is a
+//     full-width dwordx4, 1 KiB per wave instruction, and stays 16-B aligned after
+//     stable compaction;
+//   * per-type constants arrive as scalar loads (block-uniform), curve / gradient keys
+//     are staged in LDS once per workgroup;
+//   * dead-particle compaction is order preserving (the reference's filter_map().collect()
+//     src/core.rs:589-659): wave64 ballot + mbcnt inside a wave, LDS across the four
+//     waves, and a single-pass decoupled look-back across workgroups whose status word
+//     carries its own epoch tag (8-byte agent-scope granule: no fences, no per-frame
+//     memset).  A bounded spin falls back to recomputing the prefix locally, so the
+//     kernel cannot deadlock whatever the dispatch order is.
+//
+// Arithmetic order is the reference's (fw_math.h); built with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "fw_kernels.h"
+#include "fw_math.h"
+
+#define RLX __ATOMIC_RELAXED
+#define AGENT __HIP_MEMORY_SCOPE_AGENT
+
+// ---------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t fw_lane_prefix(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ uint32_t fw_wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// largest i in [0, n) with first[i] <= x   (first[] ascending, first[0] == 0)
+__device__ __forceinline__ uint32_t fw_upper_slot(const uint32_t *first, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (first[mid] <= x)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ float4 fw_ld4(const char *plane, uint32_t i) {
+    return reinterpret_cast<const float4 *>(plane)[i];
+}
+__device__ __forceinline__ void fw_st4(char *plane, uint32_t i, float4 v) { reinterpret_cast<float4 *>(plane)[i] = v; }
+
+// alive test of update_particles: `if particle.age >= particle.lifetime { destroyed }` (core.rs:594-599)
+__device__ __forceinline__ bool fw_survives(float age, float dt, float lifetime, float *age_new) {
+    float a = age + dt;
+    *age_new = a;
+    return !(a >= lifetime);
+}
+
+__device__ __forceinline__ void fw_stage_keys(float *s_keys, const FwGlobals &g, const FwType &T) {
+    for (uint32_t i = threadIdx.x; i < T.keys_len; i += FW_BLOCK) s_keys[i] = g.keys[T.keys_off + i];
+}
+
+// ---------------------------------------------------------------------------------
+// spawn: one new ParticleData (reference src/core.rs:437-469 Global, 506-544 Nested)
+// ---------------------------------------------------------------------------------
+
+struct FwSpawnOut {
+    float4 q0, q1, q2, q3;
+};
+
+__device__ __forceinline__ fw_v3 fw_randvec3(float mag_min, float mag_max, float spread, const float dir[4],
+                                             const float arc[4], float u_angle, float u_radius, float u_mag) {
+    fw_v3 d;
+    if (spread > 0.0f) {  // cone of half-angle `spread` around `direction` (bevy_utilitarian RandVec3)
+        float spread_angle = u_angle * 2.0f * FW_PI;
+        float spread_radius = u_radius * spread;
+        float sr = sinf(spread_radius), cr = cosf(spread_radius);
+        fw_v3 local{sr * cosf(spread_angle), cr, sr * sinf(spread_angle)};
+        d = fw_quat_mul_vec3(fw_q4{arc[0], arc[1], arc[2], arc[3]}, local);
+    } else {
+        d = fw_v3{dir[0], dir[1], dir[2]};
+    }
+    float m = u_mag * (mag_max - mag_min) + mag_min;  // RandF32::generate
+    return fw_v3{d.x * m, d.y * m, d.z * m};
+}
+
+__device__ __forceinline__ FwSpawnOut fw_spawn_one(const FwEmit &e, uint32_t seed, unsigned long long serial,
+                                                   fw_v3 origin_pos, fw_q4 origin_rot, fw_v3 inherit_vel, float speed,
+                                                   float scale_mod) {
+    float u[12];
+#pragma unroll
+    for (uint32_t b = 0; b < 3; b++) {
+        fw_u4 o = fw_philox4x32_10(fw_u4{(uint32_t)serial, (uint32_t)(serial >> 32), e.emission_index, b}, seed, e.uid);
+        u[4 * b + 0] = fw_unit_f32(o.x);
+        u[4 * b + 1] = fw_unit_f32(o.y);
+        u[4 * b + 2] = fw_unit_f32(o.z);
+        u[4 * b + 3] = fw_unit_f32(o.w);
+    }
+    // EmissionShape::generate_point (emission_shape.rs:18-39)
+    fw_v3 off{0.0f, 0.0f, 0.0f};
+    if (e.shape_kind == 1) {
+        float pitch = u[0] * 2.0f * FW_PI, yaw = u[1] * FW_PI, r = u[2];
+        float cp = cosf(pitch), sp = sinf(pitch);
+        fw_v3 unit{cp * sinf(yaw), sp, cp * cosf(yaw)};
+        off = fw_v3{unit.x * r * e.shape_radius, unit.y * r * e.shape_radius, unit.z * r * e.shape_radius};
+    } else if (e.shape_kind == 2) {
+        float ang = u[0] * 2.0f * FW_PI, r = u[1];
+        float h = ang * 0.5f;
+        fw_q4 q2{0.0f, sinf(h), 0.0f, cosf(h)};  // Quat::from_rotation_y
+        fw_q4 q = fw_quat_mul(fw_q4{e.shape_arc[0], e.shape_arc[1], e.shape_arc[2], e.shape_arc[3]}, q2);
+        off = fw_quat_mul_vec3(q, fw_v3{r * e.shape_radius, 0.0f, 0.0f});
+    }
+    // velocity (core.rs:440-448)
+    fw_v3 vr = fw_randvec3(e.v_mag_min, e.v_mag_max, e.v_spread, e.v_dir, e.v_arc, u[3], u[4], u[5]);
+    fw_v3 rv = fw_quat_mul_vec3(origin_rot, vr);
+    fw_v3 n = fw_normalize_or_zero(off);
+    float radial = u[6] * (e.radial_max - e.radial_min) + e.radial_min;
+    float ix = e.inherit ? inherit_vel.x : 0.0f, iy = e.inherit ? inherit_vel.y : 0.0f,
+          iz = e.inherit ? inherit_vel.z : 0.0f;
+    float vx = speed * (rv.x + n.x * radial) + ix;
+    float vy = speed * (rv.y + n.y * radial) + iy;
+    float vz = speed * (rv.z + n.z * radial) + iz;
+    float iscale = (u[7] * (e.iscale_max - e.iscale_min) + e.iscale_min) * scale_mod;  // core.rs:450-451
+    float life = u[8] * (e.life_max - e.life_min) + e.life_min;                        // core.rs:455
+    fw_v3 w = fw_randvec3(e.w_mag_min, e.w_mag_max, e.w_spread, e.w_dir, e.w_arc, u[9], u[10], u[11]);
+    FwSpawnOut o;
+    o.q0 = make_float4(origin_pos.x + off.x, origin_pos.y + off.y, origin_pos.z + off.z, 0.0f);
+    o.q1 = make_float4(vx, vy, vz, iscale);
+    o.q2 = make_float4(e.init_rot[0], e.init_rot[1], e.init_rot[2], e.init_rot[3]);
+    o.q3 = make_float4(w.x, w.y, w.z, life);
+    return o;
+}
+
+__device__ __forceinline__ void fw_store_new(const FwGlobals &g, const FwSeg &S, char *buf, uint32_t slot,
+                                             const FwSpawnOut &o) {
+    const uint32_t C = S.capacity;
+    const FwType &T = g.types[S.type_idx];
+    const float *keys = g.keys + T.keys_off;
+    float bc[4], em[4];  // gradient.sample_clamped(0.) (core.rs:460-461)
+    fw_gradient_sample(T.bc_kind, T.bc_n, keys + T.o_bc_t, keys + T.o_bc_v, 0.0f, bc);
+    fw_gradient_sample(T.em_kind, T.em_n, keys + T.o_em_t, keys + T.o_em_v, 0.0f, em);
+    fw_st4(buf + FW_OFF_Q0(C), slot, o.q0);
+    fw_st4(buf + FW_OFF_Q1(C), slot, o.q1);
+    fw_st4(buf + FW_OFF_Q2(C), slot, o.q2);
+    fw_st4(buf + FW_OFF_Q3(C), slot, o.q3);
+    fw_st4(buf + FW_OFF_Q5(C), slot, make_float4(bc[0], bc[1], bc[2], bc[3]));
+    fw_st4(buf + FW_OFF_Q6(C), slot, make_float4(em[0], em[1], em[2], em[3]));
+    reinterpret_cast<float *>(buf + FW_OFF_S4(C))[slot] = o.q1.w;  // scale = initial_scale
+    for (uint32_t k = 0; k < S.n_lplanes; k++)                      // vec![f32::MIN; n] (core.rs:467)
+        reinterpret_cast<float *>(buf + FW_OFF_L(C, k))[slot] = FW_F32_MIN;
+}
+
+// Global emission: ops[] lists this frame's (segment, entry, count) triples; op i owns
+// workgroups [first_block_i, first_block_{i+1}).
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_spawn(FwGlobals g, const FwOp *ops, uint32_t n_ops, uint32_t parity) {
+    uint32_t lo = 0, hi = n_ops;  // op lookup (block-uniform)
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (ops[mid].first_block <= blockIdx.x)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const FwOp &op = ops[lo];
+    const uint32_t k = (blockIdx.x - op.first_block) * FW_BLOCK + threadIdx.x;
+    const uint32_t sidx = parity * g.max_seg + op.seg;
+    const FwSeg &S = g.segs[op.seg];
+    const uint32_t base = g.count[sidx] + g.appended[sidx] + op.rel_base;
+    if (k == 0) atomicAdd(&g.spawned[sidx], op.n);
+    if (k >= op.n) return;
+    const uint32_t slot = base + k;
+    if (slot >= S.capacity) {
+        atomicOr(g.err, FW_ERR_CAPACITY);
+        return;
+    }
+    const FwEmit &e = g.emits[op.emit];
+    FwSpawnOut o = fw_spawn_one(e, g.seed, op.serial_base + k, fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
+                                fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
+                                fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
+    fw_store_new(g, S, S.buf[parity], slot, o);
+}
+
+// ---------------------------------------------------------------------------------
+// update_particles (reference src/core.rs:577-670) with fused stable compaction
+// ---------------------------------------------------------------------------------
+
+__device__ __forceinline__ unsigned long long fw_pack_status(uint32_t epoch, uint32_t state, uint32_t value) {
+    return ((unsigned long long)epoch << 34) | ((unsigned long long)state << 32) | value;
+}
+
+// integrate one surviving particle and store it at `o` of the output buffer (core.rs:601-657)
+__device__ __forceinline__ void fw_integrate_store(const FwType &T, const float *s_keys, float dt, float4 q0, float4 q1,
+                                                   float4 q2, float4 q3, float age_new, char *ob, uint32_t C,
+                                                   uint32_t o) {
+    const float lifetime = q3.w;
+    const float age_percent = age_new / lifetime;
+    const float scale_factor = fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_percent);
+    const float scale = q1.w * scale_factor;
+    // explicit Euler with the OLD velocity (core.rs:626-631, 641-643)
+    const float px = q0.x + q1.x * dt, py = q0.y + q1.y * dt, pz = q0.z + q1.z * dt;
+    const float vx = q1.x + (T.acc[0] - q1.x * T.lin_drag) * dt;
+    const float vy = q1.y + (T.acc[1] - q1.y * T.lin_drag) * dt;
+    const float vz = q1.z + (T.acc[2] - q1.z * T.lin_drag) * dt;
+    // rotation = from_scaled_axis(angvel * dt) * rotation, no renormalisation (core.rs:645-647)
+    const fw_q4 dq = fw_quat_from_scaled_axis(fw_v3{q3.x * dt, q3.y * dt, q3.z * dt});
+    const fw_q4 nr = fw_quat_mul(dq, fw_q4{q2.x, q2.y, q2.z, q2.w});
+    const float wx = q3.x + (T.angacc[0] - T.ang_drag * q3.x) * dt;  // core.rs:648-650
+    const float wy = q3.y + (T.angacc[1] - T.ang_drag * q3.y) * dt;
+    const float wz = q3.z + (T.angacc[2] - T.ang_drag * q3.z) * dt;
+    float bc[4], em[4];
+    fw_gradient_sample(T.bc_kind, T.bc_n, s_keys + T.o_bc_t, s_keys + T.o_bc_v, age_percent, bc);
+    fw_gradient_sample(T.em_kind, T.em_n, s_keys + T.o_em_t, s_keys + T.o_em_v, age_percent, em);
+    fw_st4(ob + FW_OFF_Q0(C), o, make_float4(px, py, pz, age_new));
+    fw_st4(ob + FW_OFF_Q1(C), o, make_float4(vx, vy, vz, q1.w));
+    fw_st4(ob + FW_OFF_Q2(C), o, make_float4(nr.x, nr.y, nr.z, nr.w));
+    fw_st4(ob + FW_OFF_Q3(C), o, make_float4(wx, wy, wz, lifetime));
+    fw_st4(ob + FW_OFF_Q5(C), o, make_float4(bc[0], bc[1], bc[2], bc[3]));
+    fw_st4(ob + FW_OFF_Q6(C), o, make_float4(em[0], em[1], em[2], em[3]));
+    reinterpret_cast<float *>(ob + FW_OFF_S4(C))[o] = scale;
+}
+
+// destroyed record = the clone with age already advanced, pose of the previous frame (core.rs:596-599)
+__device__ __forceinline__ void fw_store_destroyed(char *dbuf, const char *ib, uint32_t C, uint32_t idx, float4 q0,
+                                                   float4 q1, float4 q2, float4 q3, float age_new, int32_t pbr,
+                                                   uint32_t d) {
+    float *rec = reinterpret_cast<float *>(dbuf) + (size_t)d * 26;
+    const float4 bc = fw_ld4(ib + FW_OFF_Q5(C), idx), em = fw_ld4(ib + FW_OFF_Q6(C), idx);
+    const float sc = reinterpret_cast<const float *>(ib + FW_OFF_S4(C))[idx];
+    rec[0] = q0.x, rec[1] = q0.y, rec[2] = q0.z;
+    rec[3] = q1.x, rec[4] = q1.y, rec[5] = q1.z;
+    rec[6] = q2.x, rec[7] = q2.y, rec[8] = q2.z, rec[9] = q2.w;
+    rec[10] = q3.x, rec[11] = q3.y, rec[12] = q3.z;
+    rec[13] = q1.w, rec[14] = sc, rec[15] = age_new, rec[16] = q3.w;
+    rec[17] = bc.x, rec[18] = bc.y, rec[19] = bc.z, rec[20] = bc.w;
+    rec[21] = em.x, rec[22] = em.y, rec[23] = em.z, rec[24] = em.w;
+    reinterpret_cast<int32_t *>(rec)[25] = pbr;
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
+    __shared__ uint32_t s_wcnt[FW_ROUNDS][4];
+    __shared__ uint32_t s_lb[8];
+
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t seg = fw_upper_slot(a.seg_tile_first, a.n_seg, tile);
+    const uint32_t first = a.seg_tile_first[seg];
+    const uint32_t tis = tile - first;
+    const uint32_t p = a.parity;
+    const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
+    const uint32_t n_tot = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
+    const uint32_t base = tis * FW_TILE;
+
+    if (n_tot == 0) {  // empty segment: its first tile still owns the bookkeeping
+        if (tis == 0 && tid == 0) {
+            g.count[oidx] = 0;
+            g.spawned[oidx] = 0;
+            g.appended[oidx] = 0;
+            g.ndestroyed[seg] = 0;
+            if (a.host_counts) a.host_counts[seg] = 0;
+        }
+        return;
+    }
+    if (base >= n_tot) return;
+    const bool is_last = ((n_tot - 1u) / FW_TILE) == tis;
+    if (tis == 0 && tid == 0 && n_tot > (a.seg_tile_first[seg + 1] - first) * FW_TILE) atomicOr(g.err, FW_ERR_CAPACITY);
+
+    // field-wise reads (block-uniform -> scalar loads); a by-value FwSeg indexed by `p` would be
+    // demoted to an LDS-backed private array
+    const FwSeg *Sp = &g.segs[seg];
+    const uint32_t C = Sp->capacity;
+    const uint32_t n_lplanes = Sp->n_lplanes;
+    const char *ib = Sp->buf[p];
+    char *ob = Sp->buf[p ^ 1u];
+    char *destroyed = Sp->destroyed;
+    const FwType T = g.types[Sp->type_idx];
+    fw_stage_keys(s_keys, g, T);
+
+    // ---- phase 1: the two planes that decide survival (age in Q0.w, lifetime in Q3.w)
+    float4 q0[FW_ROUNDS], q3[FW_ROUNDS];
+    float age_new[FW_ROUNDS];
+    bool valid[FW_ROUNDS], alive[FW_ROUNDS];
+    uint32_t lpre[FW_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < FW_ROUNDS; r++) {
+        const uint32_t idx = base + r * FW_BLOCK + tid;
+        valid[r] = idx < n_tot;
+        if (valid[r]) {
+            q0[r] = fw_ld4(ib + FW_OFF_Q0(C), idx);
+            q3[r] = fw_ld4(ib + FW_OFF_Q3(C), idx);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FW_ROUNDS; r++) {
+        alive[r] = valid[r] && fw_survives(q0[r].w, a.dt, q3[r].w, &age_new[r]);
+        const unsigned long long m = __ballot(alive[r]);
+        lpre[r] = fw_lane_prefix(m);
+        if (lane == 0) s_wcnt[r][wave] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    uint32_t rank[FW_ROUNDS];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int r = 0; r < FW_ROUNDS; r++) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if ((uint32_t)w == wave) rank[r] = cnt + lpre[r];
+            cnt += s_wcnt[r][w];
+        }
+    }
+
+    // ---- phase 2: exclusive prefix of survivors over the earlier tiles of this segment
+    uint32_t excl = 0;
+    if (FUSED) {
+        unsigned long long *status = g.tile_status;
+        if (tis > 0 && tid == 0)
+            __hip_atomic_store(&status[tile], fw_pack_status(a.epoch, FW_ST_AGG, cnt), RLX, AGENT);
+    }
+
+    // phase 3 loads are issued before the look-back wait so their latency overlaps it
+    float4 q1[FW_ROUNDS], q2[FW_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < FW_ROUNDS; r++) {
+        const uint32_t idx = base + r * FW_BLOCK + tid;
+        if (valid[r]) {
+            q1[r] = fw_ld4(ib + FW_OFF_Q1(C), idx);
+            q2[r] = fw_ld4(ib + FW_OFF_Q2(C), idx);
+        }
+    }
+
+    if (FUSED) {
+        unsigned long long *status = g.tile_status;
+        if (tis > 0) {
+            uint32_t pos = tile - 1u;
+            bool timed_out = false;
+            for (;;) {
+                const bool has = (pos >= first + tid) && (pos >= tid);
+                uint32_t st = 0, val = 0;
+                if (has) {
+                    const unsigned long long *wp = &status[pos - tid];
+                    uint32_t spins = 0;
+                    for (;;) {
+                        const unsigned long long wd = __hip_atomic_load(wp, RLX, AGENT);
+                        if ((uint32_t)(wd >> 34) == a.epoch) {
+                            st = (uint32_t)(wd >> 32) & 3u;
+                            val = (uint32_t)wd;
+                            break;
+                        }
+                        if (++spins > a.spin_limit) {
+                            timed_out = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                const unsigned long long incl = __ballot(has && st == FW_ST_INCL);
+                bool use = has;
+                if (incl) use = has && lane <= (uint32_t)(__ffsll((long long)incl) - 1);
+                const uint32_t wsum = fw_wave_sum(use ? val : 0u);
+                if (lane == 0) {
+                    s_lb[wave] = wsum;
+                    s_lb[4 + wave] = incl ? 1u : 0u;
+                }
+                if (__syncthreads_or(timed_out ? 1 : 0)) {
+                    timed_out = true;
+                    break;
+                }
+                bool found = false;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    if (!found) {
+                        excl += s_lb[w];
+                        found = s_lb[4 + w] != 0u;
+                    }
+                }
+                __syncthreads();
+                if (found || pos < first + FW_BLOCK) break;
+                pos -= FW_BLOCK;
+            }
+            if (timed_out) {
+                // Fallback (never taken when workgroups are dispatched in order): recount the
+                // survivors of all earlier particles of this segment from the input planes.
+                if (tid == 0) atomicOr(g.err, FW_ERR_LOOKBACK_TIMEOUT);
+                uint32_t c = 0;
+                for (uint32_t i = tid; i < base; i += FW_BLOCK) {
+                    float an;
+                    const float ag = fw_ld4(ib + FW_OFF_Q0(C), i).w, lf = fw_ld4(ib + FW_OFF_Q3(C), i).w;
+                    c += fw_survives(ag, a.dt, lf, &an) ? 1u : 0u;
+                }
+                c = fw_wave_sum(c);
+                __syncthreads();
+                if (lane == 0) s_lb[wave] = c;
+                __syncthreads();
+                excl = s_lb[0] + s_lb[1] + s_lb[2] + s_lb[3];
+            }
+        }
+        if (tid == 0) __hip_atomic_store(&status[tile], fw_pack_status(a.epoch, FW_ST_INCL, excl + cnt), RLX, AGENT);
+    } else {
+        excl = g.tile_off[tile];
+    }
+
+    // ---- phase 3: integrate survivors, store them at their compacted slot
+    const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
+#pragma unroll
+    for (int r = 0; r < FW_ROUNDS; r++) {
+        const uint32_t idx = base + r * FW_BLOCK + tid;
+        const uint32_t o = excl + rank[r];
+        if (alive[r]) {
+            fw_integrate_store(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], ob, C, o);
+            for (uint32_t k = 0; k < n_lplanes; k++)
+                reinterpret_cast<float *>(ob + FW_OFF_L(C, k))[o] =
+                    reinterpret_cast<const float *>(ib + FW_OFF_L(C, k))[idx];
+        } else if (valid[r] && want_destroyed) {
+            fw_store_destroyed(destroyed, ib, C, idx, q0[r], q1[r], q2[r], q3[r], age_new[r], T.pbr, idx - o);
+        }
+    }
+
+    if (is_last && tid == 0) {
+        const uint32_t nc = excl + cnt;
+        g.count[oidx] = nc;
+        g.spawned[oidx] = 0;
+        g.appended[oidx] = 0;
+        g.ndestroyed[seg] = n_tot - nc;
+        if (a.host_counts) a.host_counts[seg] = nc;
+        atomicAdd(g.stats, (unsigned long long)n_tot);
+    }
+}
+
+// split mode, pass 1: survivors per tile
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_count(FwGlobals g, FwUpdateArgs a) {
+    __shared__ uint32_t s_c[4];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t seg = fw_upper_slot(a.seg_tile_first, a.n_seg, tile);
+    const uint32_t tis = tile - a.seg_tile_first[seg];
+    const uint32_t sidx = a.parity * g.max_seg + seg;
+    const uint32_t n_tot = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
+    const uint32_t base = tis * FW_TILE;
+    uint32_t c = 0;
+    if (base < n_tot) {
+        const FwSeg &S = g.segs[seg];
+        const char *ib = S.buf[a.parity];
+        for (int r = 0; r < FW_ROUNDS; r++) {
+            const uint32_t idx = base + r * FW_BLOCK + tid;
+            if (idx < n_tot) {
+                float an;
+                c += fw_survives(fw_ld4(ib + FW_OFF_Q0(S.capacity), idx).w, a.dt,
+                                 fw_ld4(ib + FW_OFF_Q3(S.capacity), idx).w, &an)
+                         ? 1u
+                         : 0u;
+            }
+        }
+    }
+    c = fw_wave_sum(c);
+    if ((tid & 63u) == 0) s_c[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) g.tile_cnt[tile] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+
+// split mode, pass 2: one workgroup per segment scans its tiles
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_scan(FwGlobals g, FwUpdateArgs a) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_run;
+    const uint32_t seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t first = a.seg_tile_first[seg], n_tiles = a.seg_tile_first[seg + 1] - first;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += FW_BLOCK) {
+        const uint32_t t = t0 + tid;
+        const uint32_t v = t < n_tiles ? g.tile_cnt[first + t] : 0u;
+        uint32_t inc = v;  // wave inclusive scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(inc, o, 64);
+            if (lane >= (uint32_t)o) inc += u;
+        }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; w++) woff += s_w[w];
+        const uint32_t run = s_run;
+        if (t < n_tiles) g.tile_off[first + t] = run + woff + inc - v;
+        __syncthreads();
+        if (tid == FW_BLOCK - 1) s_run = run + woff + inc;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Nested emission (reference src/core.rs:471-546): parents -> children
+// ---------------------------------------------------------------------------------
+
+struct FwNestCtx {
+    uint32_t op, tile_in_op, n_par;
+};
+
+__device__ __forceinline__ uint32_t fw_nest_children(const FwEmit &e, float age, float lea, float lifetime, float *next) {
+    const uint64_t n = fw_emission_count(age, lea, lifetime, e.n_start, e.n_end, e.n_count, next);  // core.rs:490-498
+    return n > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n;
+}
+
+__device__ __forceinline__ uint32_t fw_find_nest_op(const FwNestOp *ops, uint32_t n_ops, uint32_t tile) {
+    uint32_t lo = 0, hi = n_ops;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (ops[mid].first_tile <= tile)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// pass 1: children per parent tile (reads age, lifetime, last_emitted_age: 12 B / parent)
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_nest_count(FwGlobals g, const FwNestOp *ops, uint32_t n_ops,
+                                                            uint32_t parity) {
+    __shared__ uint32_t s_c[4];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t oi = fw_find_nest_op(ops, n_ops, tile);
+    const FwNestOp &op = ops[oi];
+    const uint32_t sidx = parity * g.max_seg + op.parent_seg;
+    const uint32_t n_par = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];  // bound fixed once (core.rs:488)
+    const uint32_t base = (tile - op.first_tile) * FW_TILE;
+    if (tile == op.first_tile && tid == 0) g.nest_op_npar[oi] = n_par;  // pass 3 must not see this op's own children
+    const FwSeg &P = g.segs[op.parent_seg];
+    const FwEmit &e = g.emits[op.emit];
+    const char *ib = P.buf[parity];
+    const uint32_t C = P.capacity;
+    unsigned long long c = 0;
+    for (int r = 0; r < FW_ROUNDS; r++) {
+        const uint32_t idx = base + r * FW_BLOCK + tid;
+        if (idx < n_par) {
+            float next;
+            const float age = fw_ld4(ib + FW_OFF_Q0(C), idx).w, life = fw_ld4(ib + FW_OFF_Q3(C), idx).w;
+            const float lea = reinterpret_cast<const float *>(ib + FW_OFF_L(C, e.n_lplane))[idx];
+            c += fw_nest_children(e, age, lea, life, &next);
+        }
+    }
+    uint32_t c32 = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
+    // saturating block sum
+    unsigned long long s = c32;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((tid & 63u) == 0) s_c[tid >> 6] = s > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)s;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long t = (unsigned long long)s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        g.nest_tile_cnt[tile] = t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
+    }
+}
+
+// pass 2: one workgroup per op: scan the parent tiles, reserve child slots + RNG serials
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_nest_scan(FwGlobals g, const FwNestOp *ops, uint32_t n_ops,
+                                                           uint32_t parity) {
+    __shared__ unsigned long long s_w[4];
+    __shared__ unsigned long long s_run;
+    const uint32_t oi = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const FwNestOp &op = ops[oi];
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < op.n_tiles; t0 += FW_BLOCK) {
+        const uint32_t t = t0 + tid;
+        const unsigned long long v = t < op.n_tiles ? g.nest_tile_cnt[op.first_tile + t] : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long u = __shfl_up(inc, o, 64);
+            if (lane >= (uint32_t)o) inc += u;
+        }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        unsigned long long woff = 0;
+        for (uint32_t w = 0; w < wave; w++) woff += s_w[w];
+        const unsigned long long run = s_run;
+        const unsigned long long ex = run + woff + inc - v;
+        if (t < op.n_tiles) g.nest_tile_off[op.first_tile + t] = ex > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ex;
+        __syncthreads();
+        if (tid == FW_BLOCK - 1) s_run = run + woff + inc;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const unsigned long long total = s_run;
+        const uint32_t cidx = parity * g.max_seg + op.child_seg;
+        const uint32_t cap = g.segs[op.child_seg].capacity;
+        const uint32_t cbase = g.count[cidx] + g.spawned[cidx] + g.appended[cidx];
+        const unsigned long long room = cbase < cap ? (unsigned long long)(cap - cbase) : 0ull;
+        unsigned long long take = total;
+        if (take > room) {
+            take = room;
+            atomicOr(g.err, FW_ERR_CAPACITY);
+        }
+        g.nest_op_base[oi] = cbase;
+        g.nest_op_total[oi] = (uint32_t)take;
+        g.nest_op_serial[oi] = g.emit_serial[op.emit_slot];
+        g.emit_serial[op.emit_slot] += total;
+        g.appended[cidx] += (uint32_t)take;
+    }
+}
+
+// pass 3: per parent, recompute the count, advance last_emitted_age, write the children
+// (parent-major, emission-minor order: core.rs:488-544)
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_nest_spawn(FwGlobals g, const FwNestOp *ops, uint32_t n_ops,
+                                                            uint32_t parity) {
+    __shared__ uint32_t s_w[FW_ROUNDS][4];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t oi = fw_find_nest_op(ops, n_ops, tile);
+    const FwNestOp &op = ops[oi];
+    const uint32_t n_par = g.nest_op_npar[oi];
+    const uint32_t base = (tile - op.first_tile) * FW_TILE;
+    if (base >= n_par) return;
+    const FwSeg &P = g.segs[op.parent_seg];
+    const FwSeg &Cs = g.segs[op.child_seg];
+    const FwEmit &e = g.emits[op.emit];
+    char *pb = P.buf[parity];
+    const uint32_t PC = P.capacity;
+    uint32_t n[FW_ROUNDS], inc[FW_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < FW_ROUNDS; r++) {
+        const uint32_t idx = base + r * FW_BLOCK + tid;
+        n[r] = 0;
+        if (idx < n_par) {
+            float next;
+            const float age = fw_ld4(pb + FW_OFF_Q0(PC), idx).w, life = fw_ld4(pb + FW_OFF_Q3(PC), idx).w;
+            float *lp = reinterpret_cast<float *>(pb + FW_OFF_L(PC, e.n_lplane)) + idx;
+            n[r] = fw_nest_children(e, age, *lp, life, &next);
+            *lp = next;  // other_particle.last_emitted_age[i] = next (core.rs:500)
+        }
+        uint32_t x = n[r];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(x, o, 64);
+            if (lane >= (uint32_t)o) x += u;
+        }
+        inc[r] = x;
+        if (lane == 63) s_w[r][wave] = x;
+    }
+    __syncthreads();
+    const uint32_t tile_off = g.nest_tile_off[tile];
+    const uint32_t total = g.nest_op_total[oi], cbase = g.nest_op_base[oi];
+    const unsigned long long serial0 = g.nest_op_serial[oi];
+    uint32_t run = 0;
+#pragma unroll
+    for (int r = 0; r < FW_ROUNDS; r++) {
+        uint32_t my = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if ((uint32_t)w == wave) my = run;
+            run += s_w[r][w];
+        }
+        if (n[r] == 0) continue;
+        const uint32_t idx = base + r * FW_BLOCK + tid;
+        const uint32_t j0 = tile_off + my + inc[r] - n[r];
+        const float4 pq0 = fw_ld4(pb + FW_OFF_Q0(PC), idx), pq1 = fw_ld4(pb + FW_OFF_Q1(PC), idx),
+                     pq2 = fw_ld4(pb + FW_OFF_Q2(PC), idx);
+        for (uint32_t k = 0; k < n[r]; k++) {
+            const uint32_t j = j0 + k;
+            if (j >= total) break;
+            FwSpawnOut o = fw_spawn_one(e, g.seed, serial0 + j, fw_v3{pq0.x, pq0.y, pq0.z},
+                                        fw_q4{pq2.x, pq2.y, pq2.z, pq2.w}, fw_v3{pq1.x, pq1.y, pq1.z}, op.speed,
+                                        op.scale);
+            fw_store_new(g, Cs, Cs.buf[parity], cbase + j, o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// readback / upload / render hand-off helpers
+// ---------------------------------------------------------------------------------
+
+// SoA planes -> fw_particle records (26 x 4 B)
+__global__ void fw_k_gather(const char *buf, uint32_t C, uint32_t n, int32_t pbr, float *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i), q1 = fw_ld4(buf + FW_OFF_Q1(C), i),
+                 q2 = fw_ld4(buf + FW_OFF_Q2(C), i), q3 = fw_ld4(buf + FW_OFF_Q3(C), i),
+                 bc = fw_ld4(buf + FW_OFF_Q5(C), i), em = fw_ld4(buf + FW_OFF_Q6(C), i);
+    const float sc = reinterpret_cast<const float *>(buf + FW_OFF_S4(C))[i];
+    float *r = out + (size_t)i * 26;
+    r[0] = q0.x, r[1] = q0.y, r[2] = q0.z;
+    r[3] = q1.x, r[4] = q1.y, r[5] = q1.z;
+    r[6] = q2.x, r[7] = q2.y, r[8] = q2.z, r[9] = q2.w;
+    r[10] = q3.x, r[11] = q3.y, r[12] = q3.z;
+    r[13] = q1.w, r[14] = sc, r[15] = q0.w, r[16] = q3.w;
+    r[17] = bc.x, r[18] = bc.y, r[19] = bc.z, r[20] = bc.w;
+    r[21] = em.x, r[22] = em.y, r[23] = em.z, r[24] = em.w;
+    reinterpret_cast<int32_t *>(r)[25] = pbr;
+}
+
+__global__ void fw_k_scatter(char *buf, uint32_t C, uint32_t n, uint32_t n_lplanes, const float *in) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *r = in + (size_t)i * 26;
+    fw_st4(buf + FW_OFF_Q0(C), i, make_float4(r[0], r[1], r[2], r[15]));
+    fw_st4(buf + FW_OFF_Q1(C), i, make_float4(r[3], r[4], r[5], r[13]));
+    fw_st4(buf + FW_OFF_Q2(C), i, make_float4(r[6], r[7], r[8], r[9]));
+    fw_st4(buf + FW_OFF_Q3(C), i, make_float4(r[10], r[11], r[12], r[16]));
+    fw_st4(buf + FW_OFF_Q5(C), i, make_float4(r[17], r[18], r[19], r[20]));
+    fw_st4(buf + FW_OFF_Q6(C), i, make_float4(r[21], r[22], r[23], r[24]));
+    reinterpret_cast<float *>(buf + FW_OFF_S4(C))[i] = r[14];
+    for (uint32_t k = 0; k < n_lplanes; k++) reinterpret_cast<float *>(buf + FW_OFF_L(C, k))[i] = FW_F32_MIN;
+}
+
+// ParticleInstance packing (reference src/render.rs:95-115): {pos, scale, rot, base, emissive}
+__global__ void fw_k_pack(const char *buf, uint32_t C, const uint32_t *d_count, uint32_t n_upper, float4 *out) {
+    const uint32_t n = min(*d_count, n_upper);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i);
+        const float sc = reinterpret_cast<const float *>(buf + FW_OFF_S4(C))[i];
+        out[(size_t)i * 4 + 0] = make_float4(q0.x, q0.y, q0.z, sc);
+        out[(size_t)i * 4 + 1] = fw_ld4(buf + FW_OFF_Q2(C), i);
+        out[(size_t)i * 4 + 2] = fw_ld4(buf + FW_OFF_Q5(C), i);
+        out[(size_t)i * 4 + 3] = fw_ld4(buf + FW_OFF_Q6(C), i);
+    }
+}
+
+__device__ __forceinline__ void fw_atomic_minf(float *addr, float v) {
+    int *ia = reinterpret_cast<int *>(addr);
+    int old = __hip_atomic_load(ia, RLX, AGENT);
+    while (v < __int_as_float(old)) {
+        const int assumed = old;
+        old = atomicCAS(ia, assumed, __float_as_int(v));
+        if (old == assumed) break;
+    }
+}
+__device__ __forceinline__ void fw_atomic_maxf(float *addr, float v) {
+    int *ia = reinterpret_cast<int *>(addr);
+    int old = __hip_atomic_load(ia, RLX, AGENT);
+    while (v > __int_as_float(old)) {
+        const int assumed = old;
+        old = atomicCAS(ia, assumed, __float_as_int(v));
+        if (old == assumed) break;
+    }
+}
+
+// update_aabbs reduction (reference src/render.rs:677-703): min/max over position -/+ scale.
+// blockIdx.y = segment of the spawner; out6 = {min xyz, max xyz}, pre-set to {+MAX, -MAX}.
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, const uint32_t *seg_ids, uint32_t parity, float *out6) {
+    __shared__ float s_m[4][6];
+    const uint32_t seg = seg_ids[blockIdx.y];
+    const FwSeg &S = g.segs[seg];
+    const uint32_t n = g.count[parity * g.max_seg + seg];
+    const char *buf = S.buf[parity];
+    float mn[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
+    float mx[3] = {FW_F32_MIN, FW_F32_MIN, FW_F32_MIN};
+    for (uint32_t i = blockIdx.x * FW_BLOCK + threadIdx.x; i < n; i += gridDim.x * FW_BLOCK) {
+        const float4 q0 = fw_ld4(buf + FW_OFF_Q0(S.capacity), i);
+        const float sc = reinterpret_cast<const float *>(buf + FW_OFF_S4(S.capacity))[i];
+        mn[0] = fminf(mn[0], q0.x - sc), mn[1] = fminf(mn[1], q0.y - sc), mn[2] = fminf(mn[2], q0.z - sc);
+        mx[0] = fmaxf(mx[0], q0.x + sc), mx[1] = fmaxf(mx[1], q0.y + sc), mx[2] = fmaxf(mx[2], q0.z + sc);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o, 64));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o, 64));
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int c = 0; c < 3; c++) s_m[wave][c] = mn[c], s_m[wave][3 + c] = mx[c];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        fw_atomic_minf(&out6[c], fminf(fminf(s_m[0][c], s_m[1][c]), fminf(s_m[2][c], s_m[3][c])));
+        fw_atomic_maxf(&out6[3 + c], fmaxf(fmaxf(s_m[0][3 + c], s_m[1][3 + c]), fmaxf(s_m[2][3 + c], s_m[3][3 + c])));
+    }
+}
+
+__global__ void fw_k_total(const uint32_t *counts, uint32_t n_seg, unsigned long long *out) {
+    __shared__ unsigned long long s[4];
+    unsigned long long t = 0;
+    for (uint32_t i = threadIdx.x; i < n_seg; i += blockDim.x) t += counts[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if ((threadIdx.x & 63u) == 0) s[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = s[0] + s[1] + s[2] + s[3];
+}
+
+// float4 streaming copy: the measured-roofline probe (bytes read + written per second)
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_copy(const float4 *src, float4 *dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * FW_BLOCK + threadIdx.x; i < n4; i += (size_t)gridDim.x * FW_BLOCK)
+        dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------
+
+hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *ops, uint32_t n_ops, uint32_t total_blocks,
+                           uint32_t parity) {
+    if (!n_ops || !total_blocks) return hipSuccess;
+    hipLaunchKernelGGL(fw_k_spawn, dim3(total_blocks), dim3(FW_BLOCK), 0, s, g, ops, n_ops, parity);
+    return hipGetLastError();
+}
+
+hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, int mode) {
+    if (!a.total_tiles) return hipSuccess;
+    if (mode == FW_MODE_SPLIT) {
+        hipLaunchKernelGGL(fw_k_count, dim3(a.total_tiles), dim3(FW_BLOCK), 0, s, g, a);
+        hipLaunchKernelGGL(fw_k_scan, dim3(a.n_seg), dim3(FW_BLOCK), 0, s, g, a);
+        hipLaunchKernelGGL(fw_k_update<false>, dim3(a.total_tiles), dim3(FW_BLOCK), 0, s, g, a);
+    } else {
+        hipLaunchKernelGGL(fw_k_update<true>, dim3(a.total_tiles), dim3(FW_BLOCK), 0, s, g, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *ops, uint32_t n_ops,
+                            uint32_t total_tiles, uint32_t parity) {
+    if (!n_ops || !total_tiles) return hipSuccess;
+    hipLaunchKernelGGL(fw_k_nest_count, dim3(total_tiles), dim3(FW_BLOCK), 0, s, g, ops, n_ops, parity);
+    hipLaunchKernelGGL(fw_k_nest_scan, dim3(n_ops), dim3(FW_BLOCK), 0, s, g, ops, n_ops, parity);
+    hipLaunchKernelGGL(fw_k_nest_spawn, dim3(total_tiles), dim3(FW_BLOCK), 0, s, g, ops, n_ops, parity);
+    return hipGetLastError();
+}
+
+hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t n, int32_t pbr, void *d_out) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(fw_k_gather, dim3((n + 255) / 256), dim3(256), 0, s, buf, capacity, n, pbr, (float *)d_out);
+    return hipGetLastError();
+}
+
+hipError_t fw_launch_scatter(hipStream_t s, char *buf, uint32_t capacity, uint32_t n, uint32_t n_lplanes,
+                             const void *d_in) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(fw_k_scatter, dim3((n + 255) / 256), dim3(256), 0, s, buf, capacity, n, n_lplanes,
+                       (const float *)d_in);
+    return hipGetLastError();
+}
+
+hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, const uint32_t *d_count,
+                                    uint32_t n_upper, void *d_out) {
+    if (!n_upper) return hipSuccess;
+    uint32_t blocks = (n_upper + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fw_k_pack, dim3(blocks), dim3(256), 0, s, buf, capacity, d_count, n_upper, (float4 *)d_out);
+    return hipGetLastError();
+}
+
+hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, uint32_t n_segs, uint32_t parity,
+                          float *d_minmax6) {
+    if (!n_segs) return hipSuccess;
+    hipLaunchKernelGGL(fw_k_aabb, dim3(512, n_segs), dim3(FW_BLOCK), 0, s, g, seg_ids, parity, d_minmax6);
+    return hipGetLastError();
+}
+
+hipError_t fw_launch_total(hipStream_t s, const uint32_t *counts, uint32_t n_seg, unsigned long long *d_out) {
+    hipLaunchKernelGGL(fw_k_total, dim3(1), dim3(256), 0, s, counts, n_seg, d_out);
+    return hipGetLastError();
+}
+
+hipError_t fw_launch_copy_probe(hipStream_t s, const void *src, void *dst, size_t bytes) {
+    hipLaunchKernelGGL(fw_k_copy, dim3(2048), dim3(FW_BLOCK), 0, s, (const float4 *)src, (float4 *)dst, bytes / 16);
+    return hipGetLastError();
+}

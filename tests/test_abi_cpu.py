@@ -1,0 +1,85 @@
+"""CPU-side checks of the product library: it loads, exports every symbol of
+include/firework_hip.h, its host count arithmetic is bit-exact, and it refuses to
+run without a GPU (no fallback).  No compute calls are made here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from bevy_firework_amd import _ffi, system
+from bevy_firework_amd import settings as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def f(bits):
+    return np.array([bits], dtype=np.uint32).view(np.float32)[0]
+
+
+def b(x):
+    return int(np.asarray(x, dtype=np.float32).view(np.uint32))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _ffi.load()
+    header = open(os.path.join(ROOT, "include", "firework_hip.h")).read()
+    declared = set(re.findall(r"\b(fw_[a-z0-9_]+)\s*\(", header))
+    declared -= {"fw_status"}
+    bound = {name for name, _, _ in _ffi.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.fw_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(_ffi.ParticleSettings) == 8 + 24 + 8 + 12 + 12 + 8 + 24 + 24 + 12 + 4  # incl. tail padding
+    assert S.PARTICLE_DTYPE.itemsize == 104 and S.INSTANCE_DTYPE.itemsize == 64
+
+
+def test_host_emission_count_is_bit_exact_with_golden():
+    """fw_compute_emission_count is the arithmetic fw_step's host side uses for Global entries."""
+    d = json.load(open(os.path.join(G, "emission_kat.json")))
+    total = 0
+    for age_b, last_b, n, next_b in d["steps"]:
+        gn, gnext = system.compute_emission_count(f(age_b), f(last_b), 3.0, 0.0, 1.0, 23.0)
+        assert gn == n and b(gnext) == next_b
+        total += gn
+    assert total in (22, 23)  # reference src/core.rs:830-833
+    w = json.load(open(os.path.join(G, "emission_wrap.json")))
+    for case in w["cases"]:
+        last = np.float32(0)
+        for tpc_b, n, last_b in case["frames"]:
+            gn, last = system.compute_emission_count(f(tpc_b), last, case["duration"], case["offset_start"],
+                                                     case["offset_end"], case["count"])
+            assert gn == n and b(last) == last_b
+    nk = json.load(open(os.path.join(G, "nested_count_kat.json")))
+    for case in nk["cases"]:
+        last = np.float32(np.finfo(np.float32).min)
+        for age_b, n, last_b in case["rows"]:
+            gn, last = system.compute_emission_count(f(age_b), last, case["lifetime"], case["offset_start"],
+                                                     case["offset_end"], case["count"])
+            assert gn == n and b(last) == last_b
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(system.FwError) as e:
+        system.ParticleSystem()
+    assert e.value.status == _ffi.FW_ENODEV
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "bevy_firework_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for name in files:
+            if name.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, name)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "fw_oracle" not in src, name

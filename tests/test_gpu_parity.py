@@ -1,0 +1,200 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI.  Needs an MI355X."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from bevy_firework_amd import settings as S
+from bevy_firework_amd import workloads
+from parity import Pair, assert_particles_match
+
+pytestmark = pytest.mark.gpu
+DT = np.float32(1.0 / 60.0)
+SEED = workloads.SEED
+
+
+@pytest.fixture()
+def system():
+    from bevy_firework_amd.system import ParticleSystem
+
+    with ParticleSystem(device=0, seed=SEED) as ps:
+        yield ps
+
+
+def run(system, pair, frames, dt=DT, check_every=1, exact_all=False):
+    for fr in range(frames):
+        system.update(dt)
+        pair.step_cpu(dt)
+        if (fr + 1) % check_every == 0 or fr == frames - 1:
+            pair.check(exact_all, f"frame {fr}")
+
+
+def test_update_kats_golden(system):
+    """the hand-derived single-particle vectors of tests/golden/update_kat.json, bit-exact"""
+    import json
+    import os
+
+    from test_oracle_golden import _spawner_for, b, f, particle_from_kat
+
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "update_kat.json")))
+    for case in d["cases"]:
+        sp = _spawner_for(case)
+        sp.particle_settings[0].particles_destroyed = lambda dead: None
+        h = system.spawn(sp)
+        h.write_particles(0, particle_from_kat(case))
+        system.step(f(case["dt_bits"]))
+        if not case["alive"]:
+            assert h.count(0) == 0
+            dead = h.destroyed(0)
+            assert len(dead) == 1 and b(dead["age"][0]) == case["out"]["age"]
+            assert [b(x) for x in dead["position"][0]] == case["in"]["position"]
+        else:
+            got = h.particles(0)
+            assert len(got) == 1
+            for k, want in case["out"].items():
+                gb = [b(x) for x in np.atleast_1d(got[0][k])]
+                assert gb == (want if isinstance(want, list) else [want]), (case["name"], k)
+        system.despawn(h)
+
+
+def test_point_emitter_bit_exact(system):
+    """no trig anywhere (Point, spread 0, zero angular velocity) -> the whole state is bit-exact"""
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.3, 0.9), initial_scale=S.RandF32(0.5, 2.0),
+                            scale_curve=S.FireworkCurve.even_samples([1.0, 2.0, 0.5]),
+                            base_color=S.FireworkGradient.uneven_samples(workloads.STRESS_GRADIENT))
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(30000.0),
+                            initial_velocity=S.RandVec3(S.RandF32(1.0, 6.0), (0.0, 1.0, 0.0), 0.0),
+                            initial_velocity_radial=S.RandF32(0.0, 1.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [es]), S.Transform((1.0, 2.0, 3.0)), seed=SEED)
+    run(system, pair, 100, check_every=10, exact_all=True)
+    assert pair.gpu.count(0) > 10000
+
+
+def test_stress_test_example(system):
+    """configs[0]: examples/stress_test.rs parameters at rate 50 000 (~49k live)"""
+    spawner, tf = workloads.stress_test(rate=50000.0)
+    pair = Pair(system, spawner, tf, seed=SEED)
+    run(system, pair, 150, check_every=15)
+    assert 48000 < pair.gpu.count(0) < 50001
+
+
+def test_rotation_path(system):
+    """angular velocity != 0: from_scaled_axis + quaternion product, tolerance 1e-5"""
+    ps = S.ParticleSettings(lifetime=S.RandF32.constant(2.0), angular_acceleration=(0.1, 0.0, -0.2), angular_drag=0.3)
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(5000.0),
+                            emission_shape=S.EmissionShape.Sphere(0.5),
+                            initial_rotation=(0.0, math.sin(0.4), 0.0, math.cos(0.4)),
+                            initial_velocity=S.RandVec3(S.RandF32(0.5, 2.0), (0.6, 0.8, 0.0), 0.7),
+                            initial_angular_velocity=S.RandVec3(S.RandF32(1.0, 9.0), (0.0, 0.6, 0.8), 0.5))
+    tf = S.Transform((0.0, 1.0, 0.0), (math.sin(0.3), 0.0, 0.0, math.cos(0.3)))
+    pair = Pair(system, S.ParticleSpawner([ps], [es]), tf, seed=SEED, uid=5)
+    pair.gpu.set_parent_velocity((0.5, 0.0, -0.25))
+    pair.cpu.set_parent_velocity((0.5, 0.0, -0.25))
+    run(system, pair, 150, check_every=25)
+
+
+def test_oneshot_ondemand_and_finished(system):
+    """OneShot disables itself (core.rs:397-400); OnDemand drains the queue (401-405); finished fires once"""
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.2, 0.4))
+    one = Pair(system, S.ParticleSpawner([ps], [S.EmissionSettings(emission_pacing=S.EmissionPacing.OneShot(3000))]),
+               seed=SEED, uid=1)
+    dem = Pair(system, S.ParticleSpawner([ps], [S.EmissionSettings(emission_pacing=S.EmissionPacing.OnDemand())]),
+               seed=SEED, uid=2)
+    fired = []
+    one.gpu.on_finished.append(lambda d: fired.append(d.handle))
+    for fr in range(40):
+        if fr in (0, 3, 4, 20):
+            dem.queue(777 + fr)
+        system.update(DT)
+        one.step_cpu(DT)
+        dem.step_cpu(DT)
+        one.check(what=f"oneshot f{fr}")
+        dem.check(what=f"ondemand f{fr}")
+        assert one.gpu.active() == one.cpu.active() and dem.gpu.active() == dem.cpu.active()
+        cpu_fin = one.cpu.poll_finished()
+        assert (len(fired) == 1) == (cpu_fin or len(fired) == 1 and not cpu_fin)
+    assert fired == [one.gpu.handle] and one.gpu.count(0) == 0 and not one.gpu.active()
+    assert dem.gpu.active()
+
+
+def test_compaction_order_ragged_lifetimes(system):
+    """random lifetimes -> deaths scattered through the array; order must stay the reference's"""
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.05, 1.5))
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(200000.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [es]), seed=SEED, uid=9)
+    run(system, pair, 120, check_every=20, exact_all=True)
+    assert pair.gpu.count(0) > 100000
+
+
+def test_two_types_two_emitters_and_modifier(system):
+    p0 = S.ParticleSettings(lifetime=S.RandF32(0.5, 0.7), linear_drag=0.5)
+    p1 = S.ParticleSettings(lifetime=S.RandF32.constant(0.25), acceleration=(0.0, 1.0, 0.0),
+                            scale_curve=S.FireworkCurve.uneven_samples([(0.0, 1.0), (0.8, 1.2), (1.0, 0.0)]))
+    e0 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(9000.0),
+                            emission_shape=S.EmissionShape.Circle((0.0, 0.0, 1.0), 2.0))
+    e1 = S.EmissionSettings(particle_index=1, emission_pacing=S.EmissionPacing.CountOverDuration(500.0, 0.5, 0.2, 0.9))
+    e2 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(1234.0),
+                            initial_velocity_radial=S.RandF32(1.0, 2.0), emission_shape=S.EmissionShape.Sphere(1.0))
+    pair = Pair(system, S.ParticleSpawner([p0, p1], [e0, e1, e2]), S.Transform((0, 0, 0)), seed=SEED, uid=3,
+                modifier=S.EffectModifier(scale=2.0, speed=0.5))
+    run(system, pair, 90, check_every=10)
+
+
+def test_nested_emission(system):
+    """configs[3] shape at test size: sparks -> smoke, parent-major child order, last_emitted_age plane"""
+    spawner, tf = workloads.nested(spark_rate=3000.0, smoke_per_spark=20.0)
+    pair = Pair(system, spawner, tf, seed=SEED, uid=11)
+    for fr in range(150):
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr % 15 == 14:
+            pair.check(what=f"nested f{fr}")
+            assert np.array_equal(pair.gpu.last_emitted(0, 1), pair.cpu.last_emitted(0, 1))
+    c = pair.gpu.counts()
+    assert c[0] > 5000 and c[1] > 50000
+
+
+def test_settings_change_resets(system):
+    """Changed<ParticleSpawner> -> sync_spawner_data drops particles and restarts clocks (core.rs:343-365)"""
+    spawner, tf = workloads.stress_test(rate=20000.0)
+    pair = Pair(system, spawner, tf, seed=SEED, uid=4)
+    run(system, pair, 30, check_every=30)
+    pair.gpu.update_settings(spawner)
+    pair.cpu.reset()
+    assert pair.gpu.counts() == [0]
+    run(system, pair, 30, check_every=30)
+
+
+def test_empty_and_tiny(system):
+    """empty spawner, single particle, dt = 0"""
+    ps = S.ParticleSettings(lifetime=S.RandF32.constant(1.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [S.EmissionSettings(emission_pacing=S.EmissionPacing.OnDemand())]),
+                seed=SEED, uid=6)
+    run(system, pair, 3)
+    pair.queue(1)
+    run(system, pair, 5, exact_all=True)
+    run(system, pair, 2, dt=np.float32(0.0), exact_all=True)
+    assert pair.gpu.count(0) == 1
+
+
+def test_instances_aabb_and_invalid_settings(system):
+    spawner, tf = workloads.stress_test(rate=20000.0)
+    pair = Pair(system, spawner, tf, seed=SEED, uid=7)
+    run(system, pair, 40, check_every=40)
+    inst, parts = pair.gpu.instances(0), pair.gpu.particles(0)
+    assert np.array_equal(inst["position"], parts["position"]) and np.array_equal(inst["scale"], parts["scale"])
+    assert np.array_equal(inst["rotation"], parts["rotation"])
+    assert np.array_equal(inst["base_color"], parts["base_color"])
+    any_g, mn_g, mx_g = pair.gpu.aabb()
+    cp = pair.cpu.particles(0)
+    assert any_g
+    assert np.array_equal(mn_g, (parts["position"] - parts["scale"][:, None]).min(axis=0))
+    assert np.array_equal(mx_g, (parts["position"] + parts["scale"][:, None]).max(axis=0))
+    any_c, mn_c, mx_c = pair.cpu.aabb()
+    assert np.allclose(mn_g, mn_c, rtol=1e-5, atol=1e-5) and np.allclose(mx_g, mx_c, rtol=1e-5, atol=1e-5)
+    from bevy_firework_amd.system import FwError
+
+    bad = S.ParticleSpawner([S.ParticleSettings()], [S.EmissionSettings(particle_index=3)])
+    with pytest.raises(FwError):  # index panic core.rs:392 -> FW_EINVAL
+        system.spawn(bad)
