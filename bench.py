@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- particles updated/sec on the stress-test workload (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one frame of the hot path (fw_step = spawn_particles + update_particles
+with compaction) over the whole resident particle set; inputs are already in HBM when
+the timed region starts.  N=1 runs BASELINE.json configs[1]: one emitter, rate 1e6/s,
+lifetime 1 s -> 983 333 live particles in steady state (the reference drops one frame
+of emission per cycle wrap), Point emission, linear 2-key scale/colour curves, dt=1/60.
+N>1 gives every rank the same per-GPU work (weak scaling): emitter e lives on rank
+e mod N, no particle ever crosses GPUs; the only exchange is the RCCL all-reduce of
+live counts, bucketed over --reduce-every frames.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     : HBM roofline of the dominant kernel (fw_k_update), from HIP events on
+                 the kernel's own stream inside the timed region
+  cpu_baseline : the C oracle (a port of the reference's CPU algorithm, AoS + per-particle
+                 heap vector + clone/filter/collect) on a bounded sample, 1 thread
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES = 156  # 64 B read + 92 B written per particle-update
+ACTUAL_BYTES = 164  # what the kernel moves: +8 B (initial_scale, lifetime re-written by the ping-pong compaction)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def cpu_baseline(args, dt):
+    """Reference CPU path restated in C (oracle/), timed on this box: bounded sample of the same workload."""
+    import numpy as np
+
+    import oracle
+    from bevy_firework_amd import workloads
+
+    spawner, tf = workloads.one_million(rate=args.rate)
+    o = oracle.OracleSpawner(spawner, seed=workloads.SEED, uid=0, transform=tf)
+    fill = int(round(1.0 / float(dt))) + 2
+    for _ in range(fill):
+        o.step(dt)
+    frames, n = args.cpu_frames, 0
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        o.spawn(dt)
+        n += o.count(0)  # particles entering update_particles
+        o.update(dt)
+    el = time.perf_counter() - t0
+    return {
+        "value": n / el, "unit": "particles/s", "cores": 1, "kind": "port",
+        "sample": f"{frames} frames at {o.count(0)} live after a {fill}-frame fill, same settings/seed as the GPU run; "
+                  "1 thread because the reference runs one spawner on one core (core.rs:583-586); "
+                  f"host has {os.cpu_count()} cores",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=120)
+    ap.add_argument("--rate", type=float, default=1.0e6, help="particles/s per emitter (lifetime 1 s)")
+    ap.add_argument("--emitters-per-gpu", type=int, default=1)
+    ap.add_argument("--reduce-every", type=int, default=16, help="frames per bucketed live-count all-reduce (N>1)")
+    ap.add_argument("--cpu-frames", type=int, default=30)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from bevy_firework_amd import workloads
+    from bevy_firework_amd.system import ParticleSystem
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the particle path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    dt = np.float32(1.0 / 60.0)
+    stream = torch.cuda.Stream()
+    ps = ParticleSystem(device=local_rank, seed=workloads.SEED, stream=stream.cuda_stream)
+    total_emitters = args.emitters_per_gpu * world
+    mine = [e for e in range(total_emitters) if e % world == rank]  # round-robin sharding
+    handles = []
+    for e in mine:
+        spawner, tf = workloads.one_million(rate=args.rate)
+        handles.append(ps.spawn(spawner, tf, uid=e))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    counts_ring = torch.zeros(max(args.reduce_every, 1), dtype=torch.int64, device="cuda")
+    global_live = None
+
+    def run(n_steps):
+        nonlocal global_live
+        for k in range(n_steps):
+            ps.step(dt)
+            if dist is not None:
+                slot = k % args.reduce_every
+                ps.live_count_device(counts_ring.data_ptr() + 8 * slot)
+                if slot == args.reduce_every - 1:
+                    with torch.cuda.stream(stream):
+                        global_live = counts_ring.clone()
+                        dist.all_reduce(global_live)  # RCCL over xGMI: live counts only
+
+    # fill to steady state (setup), then the untimed warm-up
+    ps.update(dt)
+    run(int(round(1.0 / float(dt))) + 2)
+    run(args.warmup)
+    barrier()
+    before = ps.updated_total()
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    updated = ps.updated_total() - before
+    live = ps.live_count()
+    # Second pass over the same steady state with a hipEvent pair around every fw_k_update launch (on the
+    # kernel's own stream).  It is a separate pass because the event markers serialise the queue (~8 us of
+    # idle GPU per step): they would distort `value`, and `value` would distort nothing here.
+    ev_ms, ev_launches, ev_particles = (0.0, 0, 0)
+    if not args.no_events and rank == 0:
+        ps.kernel_timing(True)
+        for _ in range(min(args.steps, 1000)):
+            ps.step(dt)
+        ev_ms, ev_launches, ev_particles = ps.kernel_timing_read()
+        ps.kernel_timing(False)
+    barrier()
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        u = torch.tensor([updated, live], dtype=torch.int64, device="cuda")
+        dist.all_reduce(u)
+        updated, live = int(u[0].item()), int(u[1].item())
+
+    if rank == 0:
+        value = updated / elapsed
+        out = {
+            "metric": "particles updated/sec (stress_test, 1M live)",
+            "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: 1 emitter x rate 1e6/s x lifetime 1 s per GPU (983 333 live), Point emission, "
+                            "linear 2-key scale/colour curves, dt=1/60, spawn+update+stable compaction every step",
+                "emitters_total": total_emitters, "live_particles": live, "sharding": "emitter e -> rank e mod N",
+                "live_count_allreduce_every": args.reduce_every if world > 1 else None,
+                "update_mode": os.environ.get("FW_UPDATE_MODE", "fused"),
+            },
+            "hbm_gbs_algorithmic_whole_step": value * ALGO_BYTES / 1e9,
+        }
+        if ev_launches:
+            kt = ev_ms * 1e-3 / ev_launches
+            per_launch = ev_particles / ev_launches
+            achieved = per_launch * ALGO_BYTES / kt / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get("fw_k_update_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "fw_k_update<fused>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_particle": ALGO_BYTES, "moved_bytes_per_particle": ACTUAL_BYTES,
+                "particles_per_launch": per_launch, "avg_kernel_us": kt * 1e6, "launches": ev_launches,
+                "timing": "hipEvent pair around each launch on the context's stream, second pass over the same "
+                          "steady state (markers serialise the queue, so they are kept out of `value`)",
+            }
+        else:
+            out["roofline"] = None
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args, dt)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    ps.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,8 @@ namespace {
 
 constexpr int kParamRing = 4;    // per-frame parameter buffers in flight
 constexpr int kSnapRing = 8;     // live-count snapshots in flight
+constexpr int kSnapEvery = 4;    // frames between snapshots
+constexpr int kTabRing = 4;      // staging buffers for tile-table uploads
 constexpr uint32_t kMinCapacity = 4096;
 constexpr uint64_t kMaxSpawnPerOp = 1ull << 30;
 constexpr uint32_t kTimingEvents = 4096;
@@ -126,6 +128,16 @@ struct fw_ctx {
     hipEvent_t ev_snap[kSnapRing] = {};
     bool snap_pending[kSnapRing] = {};
     std::vector<uint64_t> snap_cum[kSnapRing];  // cum_spawn of every segment when the frame was enqueued
+
+    // device-resident segment -> tile table
+    uint32_t *d_tile_first = nullptr;
+    size_t tile_first_cap = 0;
+    std::vector<uint32_t> tiles_dev;
+    uint32_t total_tiles_dev = 0;
+    uint32_t *h_tab[kTabRing] = {};
+    hipEvent_t ev_tab[kTabRing] = {};
+    bool tab_pending[kTabRing] = {};
+    uint64_t tab_seq = 0, ring_seq = 0;
 
     uint64_t frame = 0;
     uint32_t parity = 0;
@@ -631,6 +643,61 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
     return FW_OK;
 }
 
+// The update grid covers ceil(bound / FW_TILE) tiles per segment, where `bound` is the host's upper
+// bound of the live count.  The table lives on the device and is re-sent only when a segment's
+// need leaves the band [need, need * 5/4 + 8], so steady-state frames upload nothing.
+fw_status update_tile_table(fw_ctx *ctx) {
+    const uint32_t n_seg = (uint32_t)ctx->segs.size();
+    bool dirty = ctx->tiles_dev.size() != n_seg;
+    ctx->tiles_dev.resize(n_seg, 0);
+    for (uint32_t i = 0; i < n_seg; i++) {
+        const SegHost &S = ctx->segs[i];
+        const uint32_t need = seg_tiles(S);
+        uint32_t &have = ctx->tiles_dev[i];
+        if (!S.in_use) {
+            if (have) have = 0, dirty = true;
+            continue;
+        }
+        const uint32_t cap_tiles = std::max<uint32_t>(1, (S.capacity + FW_TILE - 1) / FW_TILE);
+        if (need > have || have > need + need / 4 + 8 || have > cap_tiles) {
+            have = std::min(cap_tiles, need + std::max<uint32_t>(2, need / 8));
+            dirty = true;
+        }
+    }
+    if (!dirty && ctx->d_tile_first) return FW_OK;
+    if (n_seg + 1 > ctx->tile_first_cap) {
+        fw_status st = sync(ctx);
+        if (st) return st;
+        const size_t ncap = (size_t)(n_seg + 1) * 2 + 64;
+        if (ctx->d_tile_first) hipFree(ctx->d_tile_first);
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_tile_first, ncap * sizeof(uint32_t)));
+        for (int i = 0; i < kTabRing; i++) {
+            if (ctx->h_tab[i]) hipHostFree(ctx->h_tab[i]);
+            FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_tab[i], ncap * sizeof(uint32_t), hipHostMallocDefault));
+            ctx->tab_pending[i] = false;
+        }
+        ctx->tile_first_cap = ncap;
+    }
+    const int slot = (int)(ctx->tab_seq++ % kTabRing);
+    if (ctx->tab_pending[slot]) {
+        FW_HIP(ctx, hipEventSynchronize(ctx->ev_tab[slot]));
+        ctx->tab_pending[slot] = false;
+    }
+    uint32_t *h = ctx->h_tab[slot];
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < n_seg; i++) {
+        h[i] = total;
+        total += ctx->tiles_dev[i];
+    }
+    h[n_seg] = total;
+    ctx->total_tiles_dev = total;
+    FW_HIP(ctx, hipMemcpyAsync(ctx->d_tile_first, h, (size_t)(n_seg + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
+                               ctx->stream));
+    FW_HIP(ctx, hipEventRecord(ctx->ev_tab[slot], ctx->stream));
+    ctx->tab_pending[slot] = true;
+    return FW_OK;
+}
+
 SpawnerHost *get_spawner(fw_ctx *ctx, fw_spawner h) {
     if (!ctx || h < 0 || (size_t)h >= ctx->spawners.size() || !ctx->spawners[h].alive) {
         if (ctx) ctx->err = "invalid spawner handle";
@@ -745,6 +812,9 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     for (int i = 0; i < kSnapRing; i++)
         if ((e = hipEventCreateWithFlags(&ctx->ev_snap[i], hipEventDisableTiming)) != hipSuccess)
             return bail("hipEventCreate", e);
+    for (int i = 0; i < kTabRing; i++)
+        if ((e = hipEventCreateWithFlags(&ctx->ev_tab[i], hipEventDisableTiming)) != hipSuccess)
+            return bail("hipEventCreate", e);
     if ((e = hipMalloc((void **)&ctx->g.err, 64)) != hipSuccess) return bail("hipMalloc", e);
     hipMemset(ctx->g.err, 0, 64);
     if ((e = hipMalloc((void **)&ctx->g.stats, 64)) != hipSuccess) return bail("hipMalloc", e);
@@ -787,6 +857,11 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
         hipEventDestroy(ctx->ev_consumed[i]);
     }
     for (int i = 0; i < kSnapRing; i++) hipEventDestroy(ctx->ev_snap[i]);
+    for (int i = 0; i < kTabRing; i++) {
+        hipEventDestroy(ctx->ev_tab[i]);
+        if (ctx->h_tab[i]) hipHostFree(ctx->h_tab[i]);
+    }
+    if (ctx->d_tile_first) hipFree(ctx->d_tile_first);
     if (ctx->h_snap) hipHostFree(ctx->h_snap);
     for (hipEvent_t ev : ctx->tev) hipEventDestroy(ev);
     hipStreamDestroy(ctx->copy_stream);
@@ -991,83 +1066,19 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         }
     }
 
-    // ---- lay the frame parameters out in one buffer: [seg_tile_first | FwOp[] | FwNestOp[]]
+    // ---- segment -> tile table (device resident, re-uploaded only when a bound moves out of its band)
     const uint32_t n_seg = (uint32_t)ctx->segs.size();
+    fw_status st = update_tile_table(ctx);
+    if (st) return st;
+    const uint32_t total_tiles = ctx->total_tiles_dev;
+
     size_t n_g = 0, n_n = 0;
     for (auto &L : levels) n_g += L.g.size(), n_n += L.n.size();
-    const size_t off_ops = round_up((n_seg + 1) * sizeof(uint32_t), 16);
-    const size_t off_nops = off_ops + n_g * sizeof(FwOp);
-    const size_t bytes = off_nops + n_n * sizeof(FwNestOp) + 16;
-    fw_status st = ensure_param_ring(ctx, bytes);
-    if (st) return st;
-    const int slot = (int)(ctx->frame % kParamRing);
-    if (ctx->consumed_pending[slot]) {
-        FW_HIP(ctx, hipEventSynchronize(ctx->ev_consumed[slot]));
-        ctx->consumed_pending[slot] = false;
-    }
-    char *hp = ctx->h_param[slot];
-    char *dp = ctx->d_param[slot];
-    uint32_t *tile_first = (uint32_t *)hp;
-    uint32_t total_tiles = 0;
-    for (uint32_t i = 0; i < n_seg; i++) {
-        tile_first[i] = total_tiles;
-        total_tiles += seg_tiles(ctx->segs[i]);
-    }
-    tile_first[n_seg] = total_tiles;
-
-    struct Launch {
-        bool nested;
-        size_t first, count;
-        uint32_t blocks;
-    };
-    std::vector<Launch> launches;
-    FwOp *h_ops = (FwOp *)(hp + off_ops);
-    FwNestOp *h_nops = (FwNestOp *)(hp + off_nops);
-    size_t gi = 0, ni = 0, pend_first = 0;
-    uint32_t pend_blocks = 0;
-    auto flush_global = [&]() {
-        if (gi > pend_first) launches.push_back(Launch{false, pend_first, gi - pend_first, pend_blocks});
-        pend_first = gi;
-        pend_blocks = 0;
-    };
-    for (auto &L : levels) {
-        for (FwOp op : L.g) {
-            op.first_block = pend_blocks;
-            pend_blocks += (op.n + FW_BLOCK - 1) / FW_BLOCK;
-            h_ops[gi++] = op;
-        }
-        if (!L.n.empty()) {
-            flush_global();
-            const size_t first = ni;
-            uint32_t tiles = 0;
-            for (FwNestOp op : L.n) {
-                op.first_tile = tiles;
-                tiles += op.n_tiles;
-                h_nops[ni++] = op;
-            }
-            launches.push_back(Launch{true, first, ni - first, tiles});
-        }
-    }
-    flush_global();
-
-    FW_HIP(ctx, hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-    FW_HIP(ctx, hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
-    FW_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
-
     const uint32_t p = ctx->parity;
-    for (const Launch &L : launches) {
-        if (!L.nested)
-            FW_HIP(ctx, fw_launch_spawn(ctx->stream, ctx->g, (const FwOp *)(dp + off_ops) + L.first, (uint32_t)L.count,
-                                        L.blocks, p));
-        else
-            FW_HIP(ctx, fw_launch_nested(ctx->stream, ctx->g, (const FwNestOp *)(dp + off_nops) + L.first,
-                                         (uint32_t)L.count, L.blocks, p));
-    }
+    const bool legacy = n_n != 0 || ctx->update_mode == FW_MODE_SPLIT;
 
-    // update_particles + compaction (core.rs:577-670)
-    const int snap = (int)(ctx->frame % kSnapRing);
     FwUpdateArgs a{};
-    a.seg_tile_first = (const uint32_t *)dp;
+    a.seg_tile_first = ctx->d_tile_first;
     a.n_seg = n_seg;
     a.total_tiles = total_tiles;
     a.parity = p;
@@ -1075,20 +1086,133 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     if (!a.epoch) a.epoch = 1;
     a.dt = dt;
     a.spin_limit = ctx->spin_limit;
-    a.host_counts = ctx->h_snap + (size_t)snap * ctx->max_seg;
-    if (ctx->timing && ctx->tev_used + 2 <= ctx->tev.size())
-        FW_HIP(ctx, hipEventRecord(ctx->tev[ctx->tev_used], ctx->stream));
-    FW_HIP(ctx, fw_launch_update(ctx->stream, ctx->g, a, ctx->update_mode));
-    if (ctx->timing && ctx->tev_used + 2 <= ctx->tev.size()) {
+    const bool take_snap = (ctx->frame % kSnapEvery) == 0;
+    const int snap = (int)((ctx->frame / kSnapEvery) % kSnapRing);
+    a.host_counts = take_snap ? ctx->h_snap + (size_t)snap * ctx->max_seg : nullptr;
+
+    FwInlineOps inl;
+    int spawn_form = FW_SPAWN_NONE;
+    int slot = -1;
+
+    if (legacy) {
+        // Frames with Nested entries: parents spawned earlier in the frame must exist in memory before the
+        // per-parent pass reads them (core.rs:488), so Global ops are materialised by fw_k_spawn, level by level.
+        const size_t off_nops = n_g * sizeof(FwOp);
+        const size_t bytes = off_nops + n_n * sizeof(FwNestOp) + 16;
+        if ((st = ensure_param_ring(ctx, bytes))) return st;
+        slot = (int)(ctx->ring_seq++ % kParamRing);
+        if (ctx->consumed_pending[slot]) {
+            FW_HIP(ctx, hipEventSynchronize(ctx->ev_consumed[slot]));
+            ctx->consumed_pending[slot] = false;
+        }
+        char *hp = ctx->h_param[slot];
+        char *dp = ctx->d_param[slot];
+        struct Launch {
+            bool nested;
+            size_t first, count;
+            uint32_t blocks;
+        };
+        std::vector<Launch> launches;
+        FwOp *h_ops = (FwOp *)hp;
+        FwNestOp *h_nops = (FwNestOp *)(hp + off_nops);
+        size_t gi = 0, ni = 0, pend_first = 0;
+        uint32_t pend_blocks = 0;
+        auto flush_global = [&]() {
+            if (gi > pend_first) launches.push_back(Launch{false, pend_first, gi - pend_first, pend_blocks});
+            pend_first = gi;
+            pend_blocks = 0;
+        };
+        for (auto &L : levels) {
+            for (FwOp op : L.g) {
+                op.first_block = pend_blocks;
+                pend_blocks += (op.n + FW_BLOCK - 1) / FW_BLOCK;
+                h_ops[gi++] = op;
+            }
+            if (!L.n.empty()) {
+                flush_global();
+                const size_t first = ni;
+                uint32_t tiles = 0;
+                for (FwNestOp op : L.n) {
+                    op.first_tile = tiles;
+                    tiles += op.n_tiles;
+                    h_nops[ni++] = op;
+                }
+                launches.push_back(Launch{true, first, ni - first, tiles});
+            }
+        }
+        flush_global();
+        if (!launches.empty()) {
+            FW_HIP(ctx, hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+            FW_HIP(ctx, hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
+            FW_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
+        }
+        for (const Launch &L : launches) {
+            if (!L.nested)
+                FW_HIP(ctx, fw_launch_spawn(ctx->stream, ctx->g, (const FwOp *)dp + L.first, (uint32_t)L.count,
+                                            L.blocks, p));
+            else
+                FW_HIP(ctx, fw_launch_nested(ctx->stream, ctx->g, (const FwNestOp *)(dp + off_nops) + L.first,
+                                             (uint32_t)L.count, L.blocks, p));
+        }
+        if (launches.empty()) slot = -1;
+    } else {
+        // Global-only frame: spawn is fused into the update kernel (virtual particles).  Ops sorted by segment;
+        // the order inside a segment stays the emission order (rel_base was assigned in that order).
+        std::vector<FwOp> ops;
+        ops.reserve(n_g);
+        for (auto &L : levels) ops.insert(ops.end(), L.g.begin(), L.g.end());
+        std::stable_sort(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; });
+        a.n_ops = (uint32_t)ops.size();
+        if (ops.size() <= FW_INLINE_OPS) {
+            spawn_form = ops.empty() ? FW_SPAWN_NONE : FW_SPAWN_INLINE;
+            for (size_t i = 0; i < ops.size(); i++) inl.ops[i] = ops[i];
+        } else {
+            spawn_form = FW_SPAWN_TABLE;
+            const size_t off_ops = round_up((n_seg + 1) * sizeof(uint32_t), 16);
+            const size_t bytes = off_ops + ops.size() * sizeof(FwOp);
+            if ((st = ensure_param_ring(ctx, bytes))) return st;
+            slot = (int)(ctx->ring_seq++ % kParamRing);
+            if (ctx->consumed_pending[slot]) {
+                FW_HIP(ctx, hipEventSynchronize(ctx->ev_consumed[slot]));
+                ctx->consumed_pending[slot] = false;
+            }
+            char *hp = ctx->h_param[slot];
+            char *dp = ctx->d_param[slot];
+            uint32_t *sof = (uint32_t *)hp;
+            size_t oi = 0;
+            for (uint32_t sgi = 0; sgi <= n_seg; sgi++) {
+                while (oi < ops.size() && ops[oi].seg < sgi) oi++;
+                sof[sgi] = (uint32_t)oi;
+            }
+            sof[n_seg] = (uint32_t)ops.size();
+            memcpy(hp + off_ops, ops.data(), ops.size() * sizeof(FwOp));
+            FW_HIP(ctx, hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+            FW_HIP(ctx, hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
+            FW_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
+            a.seg_op_first = (const uint32_t *)dp;
+            a.ops = (const FwOp *)(dp + off_ops);
+        }
+    }
+
+    // update_particles + compaction (core.rs:577-670)
+    const bool timed = ctx->timing && ctx->tev_used + 2 <= ctx->tev.size();
+    if (timed) FW_HIP(ctx, hipEventRecord(ctx->tev[ctx->tev_used], ctx->stream));
+    FW_HIP(ctx, fw_launch_update(ctx->stream, ctx->g, a, spawn_form == FW_SPAWN_INLINE ? &inl : nullptr, spawn_form,
+                                 ctx->update_mode));
+    if (timed) {
         FW_HIP(ctx, hipEventRecord(ctx->tev[ctx->tev_used + 1], ctx->stream));
         ctx->tev_used += 2;
     }
-    FW_HIP(ctx, hipEventRecord(ctx->ev_consumed[slot], ctx->stream));
-    ctx->consumed_pending[slot] = true;
-    FW_HIP(ctx, hipEventRecord(ctx->ev_snap[snap], ctx->stream));
-    ctx->snap_pending[snap] = true;
-    ctx->snap_cum[snap].resize(n_seg);
-    for (uint32_t i = 0; i < n_seg; i++) ctx->snap_cum[snap][i] = ctx->segs[i].cum_spawn;
+    if (slot >= 0) {
+        FW_HIP(ctx, hipEventRecord(ctx->ev_consumed[slot], ctx->stream));
+        ctx->consumed_pending[slot] = true;
+    }
+    if (take_snap) {
+        FW_HIP(ctx, hipEventRecord(ctx->ev_snap[snap], ctx->stream));
+        ctx->snap_pending[snap] = true;
+        ctx->snap_cum[snap].resize(n_seg);
+        for (uint32_t i = 0; i < n_seg; i++) ctx->snap_cum[snap][i] = ctx->segs[i].cum_spawn;
+    }
 
     ctx->parity ^= 1u;
     ctx->frame++;

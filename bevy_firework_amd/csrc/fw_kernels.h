@@ -40,13 +40,28 @@ struct FwUpdateArgs {
     float dt;
     uint32_t spin_limit;   // look-back polls before the self-computed fallback
     uint32_t *host_counts; // pinned host snapshot row for this frame (or null)
+    // Global spawn ops fused into the update (virtual particles appended after the live ones);
+    // sorted by destination segment, emission order inside a segment
+    const FwOp *ops;               // table form (device memory), or null
+    const uint32_t *seg_op_first;  // [n_seg + 1] first op of each segment (table form)
+    uint32_t n_ops;                // ops this frame (inline form: entries of FwInlineOps used)
+    uint32_t pad0;
 };
+
+// small frames carry their spawn ops in the kernel arguments: no H2D copy, no extra dependency
+#define FW_INLINE_OPS 8
+struct FwInlineOps {
+    FwOp ops[FW_INLINE_OPS];
+};
+
+enum { FW_SPAWN_NONE = 0, FW_SPAWN_INLINE = 1, FW_SPAWN_TABLE = 2 };
 
 enum { FW_MODE_FUSED = 0, FW_MODE_SPLIT = 1 };
 
 hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *ops, uint32_t n_ops, uint32_t total_blocks,
                            uint32_t parity);
-hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, int mode);
+hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps *inl,
+                            int spawn_form, int mode);
 hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *ops, uint32_t n_ops,
                             uint32_t total_tiles, uint32_t parity);
 // SoA -> AoS gather of `n` particles of one segment buffer into fw_particle records (device)

@@ -226,12 +226,23 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
 }
 
 // destroyed record = the clone with age already advanced, pose of the previous frame (core.rs:596-599)
-__device__ __forceinline__ void fw_store_destroyed(char *dbuf, const char *ib, uint32_t C, uint32_t idx, float4 q0,
-                                                   float4 q1, float4 q2, float4 q3, float age_new, int32_t pbr,
-                                                   uint32_t d) {
+__device__ __forceinline__ void fw_store_destroyed(char *dbuf, const char *ib, uint32_t C, uint32_t idx, bool loaded,
+                                                   const FwType &T, const float *s_keys, float4 q0, float4 q1,
+                                                   float4 q2, float4 q3, float age_new, uint32_t d) {
     float *rec = reinterpret_cast<float *>(dbuf) + (size_t)d * 26;
-    const float4 bc = fw_ld4(ib + FW_OFF_Q5(C), idx), em = fw_ld4(ib + FW_OFF_Q6(C), idx);
-    const float sc = reinterpret_cast<const float *>(ib + FW_OFF_S4(C))[idx];
+    const int32_t pbr = T.pbr;
+    float4 bc, em;
+    float sc;
+    if (loaded) {
+        bc = fw_ld4(ib + FW_OFF_Q5(C), idx), em = fw_ld4(ib + FW_OFF_Q6(C), idx);
+        sc = reinterpret_cast<const float *>(ib + FW_OFF_S4(C))[idx];
+    } else {  // born and destroyed in the same frame: spawn-time colours and scale (core.rs:457-461)
+        float b4[4], e4[4];
+        fw_gradient_sample(T.bc_kind, T.bc_n, s_keys + T.o_bc_t, s_keys + T.o_bc_v, 0.0f, b4);
+        fw_gradient_sample(T.em_kind, T.em_n, s_keys + T.o_em_t, s_keys + T.o_em_v, 0.0f, e4);
+        bc = make_float4(b4[0], b4[1], b4[2], b4[3]), em = make_float4(e4[0], e4[1], e4[2], e4[3]);
+        sc = q1.w;
+    }
     rec[0] = q0.x, rec[1] = q0.y, rec[2] = q0.z;
     rec[3] = q1.x, rec[4] = q1.y, rec[5] = q1.z;
     rec[6] = q2.x, rec[7] = q2.y, rec[8] = q2.z, rec[9] = q2.w;
@@ -242,20 +253,53 @@ __device__ __forceinline__ void fw_store_destroyed(char *dbuf, const char *ib, u
     reinterpret_cast<int32_t *>(rec)[25] = pbr;
 }
 
-template <bool FUSED>
-__global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArgs a) {
+// SPAWN selects where this frame's Global spawn ops come from: none (already materialised by
+// fw_k_spawn), the kernel arguments (small frames) or a device table (many emitters).  Spawned
+// particles are "virtual" inputs with index >= the live count: generated in registers from the
+// counter RNG, then integrated, compacted and stored like loaded ones (spawn runs before update
+// in the same frame, reference src/plugin.rs:46-60) -- they never cost an extra HBM round trip.
+#define FW_OP(i) (SPAWN == FW_SPAWN_INLINE ? inl.ops[i] : a.ops[i])
+
+template <bool FUSED, int SPAWN>
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArgs a, FwInlineOps inl) {
     __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
     __shared__ uint32_t s_wcnt[FW_ROUNDS][4];
     __shared__ uint32_t s_lb[8];
 
-    const uint32_t tile = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t seg = fw_upper_slot(a.seg_tile_first, a.n_seg, tile);
+    const uint32_t seg = fw_upper_slot(a.seg_tile_first, a.n_seg, blockIdx.x);
     const uint32_t first = a.seg_tile_first[seg];
-    const uint32_t tis = tile - first;
+    uint32_t tis = blockIdx.x - first;
     const uint32_t p = a.parity;
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
-    const uint32_t n_tot = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
+    const uint32_t n_in = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
+    uint32_t o0 = 0, o1 = 0, n_spawn = 0;  // this segment's ops (contiguous: ops are sorted by segment)
+    if (SPAWN == FW_SPAWN_INLINE) {
+        for (uint32_t i = 0; i < a.n_ops; i++) {
+            if (inl.ops[i].seg == seg) {
+                if (o1 == 0) o0 = i;
+                o1 = i + 1;
+                n_spawn += inl.ops[i].n;
+            }
+        }
+    } else if (SPAWN == FW_SPAWN_TABLE) {
+        o0 = a.seg_op_first[seg], o1 = a.seg_op_first[seg + 1];
+        for (uint32_t i = o0; i < o1; i++) n_spawn += a.ops[i].n;
+    }
+    const uint32_t n_tot = n_in + n_spawn;
+    if (SPAWN != FW_SPAWN_NONE) {
+        // Tiles that hold new particles do ~1k VALU instructions per particle before they can publish their
+        // survivor count.  They are the LAST tiles of the segment; give them the FIRST workgroups so that this
+        // compute overlaps the streaming of everybody else instead of forming the kernel's tail.  At most 64
+        // tiles are front-loaded (they wait for all earlier tiles while holding a slot), so the rest of the
+        // grid -- still dispatched in tile order -- always makes progress.
+        if (n_spawn != 0) {
+            const uint32_t t_spawn = n_in / FW_TILE, t_last = (n_tot - 1u) / FW_TILE;
+            const uint32_t S = t_last - t_spawn + 1u;
+            if (S <= 64u && t_spawn != 0 && tis <= t_last) tis = tis < S ? t_spawn + tis : tis - S;
+        }
+    }
+    const uint32_t tile = first + tis;
     const uint32_t base = tis * FW_TILE;
 
     if (n_tot == 0) {  // empty segment: its first tile still owns the bookkeeping
@@ -284,17 +328,41 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArg
     fw_stage_keys(s_keys, g, T);
 
     // ---- phase 1: the two planes that decide survival (age in Q0.w, lifetime in Q3.w)
-    float4 q0[FW_ROUNDS], q3[FW_ROUNDS];
+    float4 q0[FW_ROUNDS], q1[FW_ROUNDS], q2[FW_ROUNDS], q3[FW_ROUNDS];
     float age_new[FW_ROUNDS];
-    bool valid[FW_ROUNDS], alive[FW_ROUNDS];
+    bool valid[FW_ROUNDS], alive[FW_ROUNDS], loaded[FW_ROUNDS];
     uint32_t lpre[FW_ROUNDS];
 #pragma unroll
     for (int r = 0; r < FW_ROUNDS; r++) {
         const uint32_t idx = base + r * FW_BLOCK + tid;
         valid[r] = idx < n_tot;
-        if (valid[r]) {
+        loaded[r] = idx < n_in;
+        if (loaded[r]) {
             q0[r] = fw_ld4(ib + FW_OFF_Q0(C), idx);
             q3[r] = fw_ld4(ib + FW_OFF_Q3(C), idx);
+        }
+    }
+    if (SPAWN != FW_SPAWN_NONE && base + FW_TILE > n_in) {  // block-uniform: this tile holds new particles
+        // One rolled instance of the spawn code (it is large: 3 Philox blocks + trig); the results are
+        // steered into the register arrays with static indices so they stay in VGPRs.
+#pragma unroll 1
+        for (int r = 0; r < FW_ROUNDS; r++) {
+            const uint32_t idx = base + r * FW_BLOCK + tid;
+            if (idx < n_tot && idx >= n_in) {
+                const uint32_t k = idx - n_in;
+                uint32_t oi = o0;
+                for (uint32_t i = o0; i < o1; i++)
+                    if (k >= FW_OP(i).rel_base && k - FW_OP(i).rel_base < FW_OP(i).n) oi = i;
+                const FwOp &op = FW_OP(oi);
+                const FwSpawnOut so = fw_spawn_one(
+                    g.emits[op.emit], g.seed, op.serial_base + (k - op.rel_base),
+                    fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
+                    fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
+                    fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
+#pragma unroll
+                for (int rr = 0; rr < FW_ROUNDS; rr++)
+                    if (rr == r) q0[rr] = so.q0, q1[rr] = so.q1, q2[rr] = so.q2, q3[rr] = so.q3;
+            }
         }
     }
 #pragma unroll
@@ -325,11 +393,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArg
     }
 
     // phase 3 loads are issued before the look-back wait so their latency overlaps it
-    float4 q1[FW_ROUNDS], q2[FW_ROUNDS];
 #pragma unroll
     for (int r = 0; r < FW_ROUNDS; r++) {
         const uint32_t idx = base + r * FW_BLOCK + tid;
-        if (valid[r]) {
+        if (loaded[r]) {
             q1[r] = fw_ld4(ib + FW_OFF_Q1(C), idx);
             q2[r] = fw_ld4(ib + FW_OFF_Q2(C), idx);
         }
@@ -390,8 +457,21 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArg
                 if (tid == 0) atomicOr(g.err, FW_ERR_LOOKBACK_TIMEOUT);
                 uint32_t c = 0;
                 for (uint32_t i = tid; i < base; i += FW_BLOCK) {
-                    float an;
-                    const float ag = fw_ld4(ib + FW_OFF_Q0(C), i).w, lf = fw_ld4(ib + FW_OFF_Q3(C), i).w;
+                    float an, ag = 0.0f, lf;
+                    if (i < n_in) {
+                        ag = fw_ld4(ib + FW_OFF_Q0(C), i).w, lf = fw_ld4(ib + FW_OFF_Q3(C), i).w;
+                    } else {  // a spawned particle: only its lifetime draw matters (RNG block 2, word 0)
+                        const uint32_t k = i - n_in;
+                        uint32_t oi = o0;
+                        for (uint32_t j = o0; j < o1; j++)
+                            if (k >= FW_OP(j).rel_base && k - FW_OP(j).rel_base < FW_OP(j).n) oi = j;
+                        const FwOp &op = FW_OP(oi);
+                        const FwEmit &e = g.emits[op.emit];
+                        const unsigned long long serial = op.serial_base + (k - op.rel_base);
+                        const fw_u4 o = fw_philox4x32_10(
+                            fw_u4{(uint32_t)serial, (uint32_t)(serial >> 32), e.emission_index, 2u}, g.seed, e.uid);
+                        lf = fw_unit_f32(o.x) * (e.life_max - e.life_min) + e.life_min;
+                    }
                     c += fw_survives(ag, a.dt, lf, &an) ? 1u : 0u;
                 }
                 c = fw_wave_sum(c);
@@ -414,11 +494,12 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArg
         const uint32_t o = excl + rank[r];
         if (alive[r]) {
             fw_integrate_store(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], ob, C, o);
-            for (uint32_t k = 0; k < n_lplanes; k++)
+            for (uint32_t k = 0; k < n_lplanes; k++)  // new particles: vec![f32::MIN; n] (core.rs:467)
                 reinterpret_cast<float *>(ob + FW_OFF_L(C, k))[o] =
-                    reinterpret_cast<const float *>(ib + FW_OFF_L(C, k))[idx];
+                    loaded[r] ? reinterpret_cast<const float *>(ib + FW_OFF_L(C, k))[idx] : FW_F32_MIN;
         } else if (valid[r] && want_destroyed) {
-            fw_store_destroyed(destroyed, ib, C, idx, q0[r], q1[r], q2[r], q3[r], age_new[r], T.pbr, idx - o);
+            fw_store_destroyed(destroyed, ib, C, idx, loaded[r], T, s_keys, q0[r], q1[r], q2[r], q3[r], age_new[r],
+                               idx - o);
         }
     }
 
@@ -801,14 +882,23 @@ hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *ops, u
     return hipGetLastError();
 }
 
-hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, int mode) {
+hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps *inl,
+                            int spawn_form, int mode) {
     if (!a.total_tiles) return hipSuccess;
-    if (mode == FW_MODE_SPLIT) {
-        hipLaunchKernelGGL(fw_k_count, dim3(a.total_tiles), dim3(FW_BLOCK), 0, s, g, a);
-        hipLaunchKernelGGL(fw_k_scan, dim3(a.n_seg), dim3(FW_BLOCK), 0, s, g, a);
-        hipLaunchKernelGGL(fw_k_update<false>, dim3(a.total_tiles), dim3(FW_BLOCK), 0, s, g, a);
+    static const FwInlineOps none{};
+    const FwInlineOps &io = inl ? *inl : none;
+    const dim3 grid(a.total_tiles), block(FW_BLOCK);
+    if (mode == FW_MODE_SPLIT) {  // debugging / A-B mode: three launches, no inter-workgroup traffic
+        if (spawn_form != FW_SPAWN_NONE) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(fw_k_count, grid, block, 0, s, g, a);
+        hipLaunchKernelGGL(fw_k_scan, dim3(a.n_seg), block, 0, s, g, a);
+        hipLaunchKernelGGL((fw_k_update<false, FW_SPAWN_NONE>), grid, block, 0, s, g, a, io);
+    } else if (spawn_form == FW_SPAWN_INLINE) {
+        hipLaunchKernelGGL((fw_k_update<true, FW_SPAWN_INLINE>), grid, block, 0, s, g, a, io);
+    } else if (spawn_form == FW_SPAWN_TABLE) {
+        hipLaunchKernelGGL((fw_k_update<true, FW_SPAWN_TABLE>), grid, block, 0, s, g, a, io);
     } else {
-        hipLaunchKernelGGL(fw_k_update<true>, dim3(a.total_tiles), dim3(FW_BLOCK), 0, s, g, a);
+        hipLaunchKernelGGL((fw_k_update<true, FW_SPAWN_NONE>), grid, block, 0, s, g, a, io);
     }
     return hipGetLastError();
 }
