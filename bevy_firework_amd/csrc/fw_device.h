@@ -127,3 +127,7 @@ struct alignas(16) FwNestOp {
 // device-side error flags (sticky until read)
 #define FW_ERR_CAPACITY 1u
 #define FW_ERR_LOOKBACK_TIMEOUT 2u
+#define FW_ERR_FORECAST 4u          // a forecast entry carried the wrong frame tag (internal error)
+
+// segments longer than this use look-back even when a forecast exists (the prefix is a direct sum)
+#define FW_FC_MAX_TILES 4096u

@@ -100,7 +100,9 @@ struct fw_ctx {
     bool own_stream = false;
     std::string err;
     int update_mode = FW_MODE_FUSED;
+    int update_rounds = 4;  // particles per thread in fw_k_update (1, 2 or 4); FW_UPDATE_ROUNDS overrides
     uint32_t spin_limit = 1u << 16;
+    uint32_t dbg = 0;  // FW_DEBUG: profiling-only kernel ablations (results are wrong when set)
 
     std::vector<SpawnerHost> spawners;
     std::vector<SegHost> segs;
@@ -135,9 +137,19 @@ struct fw_ctx {
     std::vector<uint32_t> tiles_dev;
     uint32_t total_tiles_dev = 0;
     uint32_t *h_tab[kTabRing] = {};
+    uint4 *d_tile_desc = nullptr;  // per tile: {segment, first tile, tile count, 0}
+    uint4 *h_desc[kTabRing] = {};
+    size_t tile_desc_cap = 0;
     hipEvent_t ev_tab[kTabRing] = {};
     bool tab_pending[kTabRing] = {};
     uint64_t tab_seq = 0, ring_seq = 0;
+
+    // survivor forecast tables (fw_k_update): [2][tiles_cap]
+    uint4 *d_fc = nullptr;
+    bool fc_ok = false;        // the previous frame left a forecast that still describes the device state
+    uint32_t fc_dt_bits = 0;   // ... computed for this dt
+    uint64_t fc_tab_seq = 0;   // ... under this tile table
+    bool use_forecast = true;  // FW_FORECAST=0 disables (A/B, debugging)
 
     uint64_t frame = 0;
     uint32_t parity = 0;
@@ -267,6 +279,10 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_off, ncap * sizeof(uint32_t)));
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_status, ncap * sizeof(unsigned long long)));
         FW_HIP(ctx, hipMemset(ctx->g.tile_status, 0, ncap * sizeof(unsigned long long)));
+        if (ctx->d_fc) hipFree(ctx->d_fc);
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_fc, 2 * ncap * sizeof(uint4)));
+        FW_HIP(ctx, hipMemset(ctx->d_fc, 0, 2 * ncap * sizeof(uint4)));
+        ctx->fc_ok = false;
         ctx->tiles_cap = ncap;
     }
     if (nest_tiles > ctx->nest_tiles_cap) {
@@ -354,20 +370,32 @@ fw_status refresh_counts_exact(fw_ctx *ctx) {
 }
 
 fw_status check_device_errors(fw_ctx *ctx) {
-    uint32_t e = 0;
-    FW_HIP(ctx, hipMemcpy(&e, ctx->g.err, sizeof e, hipMemcpyDeviceToHost));
+    uint32_t ev[8] = {};
+    FW_HIP(ctx, hipMemcpy(ev, ctx->g.err, sizeof ev, hipMemcpyDeviceToHost));
+    const uint32_t e = ev[0];
+    if (getenv("FW_TRACE") && ctx->d_tile_first) {
+        uint32_t t[2] = {77, 77};
+        hipMemcpy(t, ctx->d_tile_first, sizeof t, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[fw] check: flags=%u table=[%u,%u] ptr=%p fc=%p tiles_cap=%zu\n", e, t[0], t[1],
+                (void *)ctx->d_tile_first, (void *)ctx->d_fc, ctx->tiles_cap);
+    }
     if (!e) return FW_OK;
     uint32_t zero = 0;
     FW_HIP(ctx, hipMemcpy(ctx->g.err, &zero, sizeof zero, hipMemcpyHostToDevice));
+    if (e & FW_ERR_FORECAST)
+        return fail(ctx, FW_EHIP, "internal error: stale survivor-forecast entry (device flags " + std::to_string(e) + ")");
     if (e & FW_ERR_CAPACITY)
         return fail(ctx, FW_ECAPACITY,
                     "a particle type overflowed its device capacity; particles were dropped "
-                    "(raise fw_particle_settings.capacity)");
+                    "(raise fw_particle_settings.capacity) [device flags " + std::to_string(e) + ", segment " +
+                        std::to_string(ev[1]) + ": " + std::to_string(ev[2]) + " particles (" + std::to_string(ev[4]) +
+                        " resident), " + std::to_string(ev[3]) + " tiles launched]");
     return FW_OK;  // FW_ERR_LOOKBACK_TIMEOUT is informational: the fallback path produced the same result
 }
 
 fw_status grow_segment(fw_ctx *ctx, uint32_t si, uint32_t need) {
     SegHost &s = ctx->segs[si];
+    ctx->fc_ok = false;
     fw_status st = refresh_counts_exact(ctx);
     if (st) return st;
     uint32_t ncap = round_up(std::max<uint32_t>((uint32_t)std::min<uint64_t>((uint64_t)need * 5 / 4, 0xFFFF0000ull),
@@ -496,6 +524,7 @@ uint32_t pad4(uint32_t n) { return (n + 3u) & ~3u; }
 // builds the device tables (types, keys, emits, segments) of one spawner
 fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std::vector<uint64_t> *carry_serial) {
     SpawnerHost &sp = ctx->spawners[h];
+    ctx->fc_ok = false;
     const uint32_t nt = d->n_particle_settings, ne = d->n_emission_settings;
     sp.uid = d->uid;
     sp.starts_enabled = d->starts_enabled;
@@ -629,6 +658,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
 }
 
 fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
+    ctx->fc_ok = false;
     for (uint32_t si : sp.seg) {
         SegHost &S = ctx->segs[si];
         if (!S.in_use) continue;
@@ -664,6 +694,10 @@ fw_status update_tile_table(fw_ctx *ctx) {
             dirty = true;
         }
     }
+    if (getenv("FW_TRACE"))
+        fprintf(stderr, "[fw] frame %llu tile table dirty=%d n_seg=%u have0=%u ub0=%u\n",
+                (unsigned long long)ctx->frame, (int)dirty, n_seg, n_seg ? ctx->tiles_dev[0] : 0u,
+                n_seg ? ctx->segs[0].ub : 0u);
     if (!dirty && ctx->d_tile_first) return FW_OK;
     if (n_seg + 1 > ctx->tile_first_cap) {
         fw_status st = sync(ctx);
@@ -678,6 +712,21 @@ fw_status update_tile_table(fw_ctx *ctx) {
         }
         ctx->tile_first_cap = ncap;
     }
+    uint32_t total_new = 0;
+    for (uint32_t i = 0; i < n_seg; i++) total_new += ctx->tiles_dev[i];
+    if (total_new > ctx->tile_desc_cap) {
+        fw_status st = sync(ctx);
+        if (st) return st;
+        const size_t ncap = (size_t)total_new * 2 + 256;
+        if (ctx->d_tile_desc) hipFree(ctx->d_tile_desc);
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_tile_desc, ncap * sizeof(uint4)));
+        for (int i = 0; i < kTabRing; i++) {
+            if (ctx->h_desc[i]) hipHostFree(ctx->h_desc[i]);
+            FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_desc[i], ncap * sizeof(uint4), hipHostMallocDefault));
+            ctx->tab_pending[i] = false;
+        }
+        ctx->tile_desc_cap = ncap;
+    }
     const int slot = (int)(ctx->tab_seq++ % kTabRing);
     if (ctx->tab_pending[slot]) {
         FW_HIP(ctx, hipEventSynchronize(ctx->ev_tab[slot]));
@@ -691,8 +740,14 @@ fw_status update_tile_table(fw_ctx *ctx) {
     }
     h[n_seg] = total;
     ctx->total_tiles_dev = total;
+    uint4 *hd = ctx->h_desc[slot];
+    for (uint32_t i = 0; i < n_seg; i++)
+        for (uint32_t t = 0; t < ctx->tiles_dev[i]; t++) hd[h[i] + t] = make_uint4(i, h[i], ctx->tiles_dev[i], 0u);
     FW_HIP(ctx, hipMemcpyAsync(ctx->d_tile_first, h, (size_t)(n_seg + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
                                ctx->stream));
+    if (total)
+        FW_HIP(ctx, hipMemcpyAsync(ctx->d_tile_desc, hd, (size_t)total * sizeof(uint4), hipMemcpyHostToDevice,
+                                   ctx->stream));
     FW_HIP(ctx, hipEventRecord(ctx->ev_tab[slot], ctx->stream));
     ctx->tab_pending[slot] = true;
     return FW_OK;
@@ -823,6 +878,9 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if ((e = hipMalloc((void **)&ctx->d_total, 64)) != hipSuccess) return bail("hipMalloc", e);
     ctx->g.seed = seed;
     if (const char *m = getenv("FW_UPDATE_MODE")) ctx->update_mode = !strcmp(m, "split") ? FW_MODE_SPLIT : FW_MODE_FUSED;
+    if (const char *m = getenv("FW_DEBUG")) ctx->dbg = (uint32_t)atoi(m);
+    if (const char *m = getenv("FW_FORECAST")) ctx->use_forecast = atoi(m) != 0;
+    if (const char *m = getenv("FW_UPDATE_ROUNDS")) ctx->update_rounds = atoi(m);
     if (const char *m = getenv("FW_SPIN_LIMIT")) ctx->spin_limit = (uint32_t)strtoul(m, nullptr, 10);
     if (ensure_max_seg(ctx, 1024) != FW_OK) {
         g_create_error = ctx->err;
@@ -860,8 +918,11 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     for (int i = 0; i < kTabRing; i++) {
         hipEventDestroy(ctx->ev_tab[i]);
         if (ctx->h_tab[i]) hipHostFree(ctx->h_tab[i]);
+        if (ctx->h_desc[i]) hipHostFree(ctx->h_desc[i]);
     }
     if (ctx->d_tile_first) hipFree(ctx->d_tile_first);
+    if (ctx->d_tile_desc) hipFree(ctx->d_tile_desc);
+    if (ctx->d_fc) hipFree(ctx->d_fc);
     if (ctx->h_snap) hipHostFree(ctx->h_snap);
     for (hipEvent_t ev : ctx->tev) hipEventDestroy(ev);
     hipStreamDestroy(ctx->copy_stream);
@@ -1079,6 +1140,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
 
     FwUpdateArgs a{};
     a.seg_tile_first = ctx->d_tile_first;
+    a.tile_desc = ctx->d_tile_desc;
     a.n_seg = n_seg;
     a.total_tiles = total_tiles;
     a.parity = p;
@@ -1086,6 +1148,15 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     if (!a.epoch) a.epoch = 1;
     a.dt = dt;
     a.spin_limit = ctx->spin_limit;
+    a.dbg = ctx->dbg;
+    uint32_t dt_bits;
+    memcpy(&dt_bits, &dt, 4);
+    const bool fc_frame = !legacy && ctx->use_forecast && ctx->d_fc != nullptr;
+    if (fc_frame) {
+        a.fc_out = ctx->d_fc + (size_t)(ctx->frame & 1u) * ctx->tiles_cap;
+        if (ctx->fc_ok && ctx->fc_dt_bits == dt_bits && ctx->fc_tab_seq == ctx->tab_seq && a.epoch != 1u)
+            a.fc_in = ctx->d_fc + (size_t)((ctx->frame + 1u) & 1u) * ctx->tiles_cap;
+    }
     const bool take_snap = (ctx->frame % kSnapEvery) == 0;
     const int snap = (int)((ctx->frame / kSnapEvery) % kSnapRing);
     a.host_counts = take_snap ? ctx->h_snap + (size_t)snap * ctx->max_seg : nullptr;
@@ -1198,7 +1269,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     const bool timed = ctx->timing && ctx->tev_used + 2 <= ctx->tev.size();
     if (timed) FW_HIP(ctx, hipEventRecord(ctx->tev[ctx->tev_used], ctx->stream));
     FW_HIP(ctx, fw_launch_update(ctx->stream, ctx->g, a, spawn_form == FW_SPAWN_INLINE ? &inl : nullptr, spawn_form,
-                                 ctx->update_mode));
+                                 ctx->update_mode, ctx->update_rounds));
     if (timed) {
         FW_HIP(ctx, hipEventRecord(ctx->tev[ctx->tev_used + 1], ctx->stream));
         ctx->tev_used += 2;
@@ -1214,6 +1285,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         for (uint32_t i = 0; i < n_seg; i++) ctx->snap_cum[snap][i] = ctx->segs[i].cum_spawn;
     }
 
+    ctx->fc_ok = fc_frame;
+    ctx->fc_dt_bits = dt_bits;
+    ctx->fc_tab_seq = ctx->tab_seq;
     ctx->parity ^= 1u;
     ctx->frame++;
     return FW_OK;
@@ -1324,6 +1398,7 @@ fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, c
     fw_status st = sync(ctx);
     if (st) return st;
     const uint32_t si = sp->seg[type];
+    ctx->fc_ok = false;
     if (n > ctx->segs[si].capacity) {
         ctx->segs[si].ub = 0;
         const uint32_t zero = 0;

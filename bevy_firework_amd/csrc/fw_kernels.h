@@ -33,6 +33,7 @@ struct FwGlobals {
 
 struct FwUpdateArgs {
     const uint32_t *seg_tile_first;  // [n_seg + 1] first tile of each segment (device)
+    const uint4 *tile_desc;          // [total_tiles] {segment, its first tile, its tile count, 0} (device)
     uint32_t n_seg;
     uint32_t total_tiles;
     uint32_t parity;       // read buf[parity], write buf[parity ^ 1]
@@ -45,7 +46,10 @@ struct FwUpdateArgs {
     const FwOp *ops;               // table form (device memory), or null
     const uint32_t *seg_op_first;  // [n_seg + 1] first op of each segment (table form)
     uint32_t n_ops;                // ops this frame (inline form: entries of FwInlineOps used)
-    uint32_t pad0;
+    uint32_t dbg;                  // FW_DEBUG (profiling only, results wrong): 1 = no look-back, 2 = no integrate
+    // survivor forecast (fw_k_update header): table written last frame / table to write this frame
+    const uint4 *fc_in;            // null = forecast not applicable this frame -> decoupled look-back
+    uint4 *fc_out;
 };
 
 // small frames carry their spawn ops in the kernel arguments: no H2D copy, no extra dependency
@@ -61,7 +65,7 @@ enum { FW_MODE_FUSED = 0, FW_MODE_SPLIT = 1 };
 hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *ops, uint32_t n_ops, uint32_t total_blocks,
                            uint32_t parity);
 hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps *inl,
-                            int spawn_form, int mode);
+                            int spawn_form, int mode, int rounds);
 hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *ops, uint32_t n_ops,
                             uint32_t total_tiles, uint32_t parity);
 // SoA -> AoS gather of `n` particles of one segment buffer into fw_particle records (device)

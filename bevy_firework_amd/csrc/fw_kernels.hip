@@ -50,10 +50,25 @@ __device__ __forceinline__ uint32_t fw_upper_slot(const uint32_t *first, uint32_
     return lo;
 }
 
+// Particle buffers are reached through pointers that were themselves loaded from memory, so the compiler
+// cannot prove they are global and would emit FLAT loads/stores (which also tick lgkmcnt and so serialise
+// against every LDS / scalar-memory wait).  Casting to address space 1 gives global_load/store_dwordx4.
+typedef float fw_f4 __attribute__((ext_vector_type(4)));
+#define FW_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ float4 fw_ld4(const char *plane, uint32_t i) {
-    return reinterpret_cast<const float4 *>(plane)[i];
+    const fw_f4 v = reinterpret_cast<const FW_GLOBAL fw_f4 *>(reinterpret_cast<uintptr_t>(plane))[i];
+    return make_float4(v.x, v.y, v.z, v.w);
 }
-__device__ __forceinline__ void fw_st4(char *plane, uint32_t i, float4 v) { reinterpret_cast<float4 *>(plane)[i] = v; }
+__device__ __forceinline__ void fw_st4(char *plane, uint32_t i, float4 v) {
+    const fw_f4 x = {v.x, v.y, v.z, v.w};
+    reinterpret_cast<FW_GLOBAL fw_f4 *>(reinterpret_cast<uintptr_t>(plane))[i] = x;
+}
+__device__ __forceinline__ float fw_ld1(const char *plane, uint32_t i) {
+    return reinterpret_cast<const FW_GLOBAL float *>(reinterpret_cast<uintptr_t>(plane))[i];
+}
+__device__ __forceinline__ void fw_st1(char *plane, uint32_t i, float v) {
+    reinterpret_cast<FW_GLOBAL float *>(reinterpret_cast<uintptr_t>(plane))[i] = v;
+}
 
 // alive test of update_particles: `if particle.age >= particle.lifetime { destroyed }` (core.rs:594-599)
 __device__ __forceinline__ bool fw_survives(float age, float dt, float lifetime, float *age_new) {
@@ -151,9 +166,8 @@ __device__ __forceinline__ void fw_store_new(const FwGlobals &g, const FwSeg &S,
     fw_st4(buf + FW_OFF_Q3(C), slot, o.q3);
     fw_st4(buf + FW_OFF_Q5(C), slot, make_float4(bc[0], bc[1], bc[2], bc[3]));
     fw_st4(buf + FW_OFF_Q6(C), slot, make_float4(em[0], em[1], em[2], em[3]));
-    reinterpret_cast<float *>(buf + FW_OFF_S4(C))[slot] = o.q1.w;  // scale = initial_scale
-    for (uint32_t k = 0; k < S.n_lplanes; k++)                      // vec![f32::MIN; n] (core.rs:467)
-        reinterpret_cast<float *>(buf + FW_OFF_L(C, k))[slot] = FW_F32_MIN;
+    fw_st1(buf + FW_OFF_S4(C), slot, o.q1.w);  // scale = initial_scale
+    for (uint32_t k = 0; k < S.n_lplanes; k++) fw_st1(buf + FW_OFF_L(C, k), slot, FW_F32_MIN);  // core.rs:467
 }
 
 // Global emission: ops[] lists this frame's (segment, entry, count) triples; op i owns
@@ -222,7 +236,7 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     fw_st4(ob + FW_OFF_Q3(C), o, make_float4(wx, wy, wz, lifetime));
     fw_st4(ob + FW_OFF_Q5(C), o, make_float4(bc[0], bc[1], bc[2], bc[3]));
     fw_st4(ob + FW_OFF_Q6(C), o, make_float4(em[0], em[1], em[2], em[3]));
-    reinterpret_cast<float *>(ob + FW_OFF_S4(C))[o] = scale;
+    fw_st1(ob + FW_OFF_S4(C), o, scale);
 }
 
 // destroyed record = the clone with age already advanced, pose of the previous frame (core.rs:596-599)
@@ -260,15 +274,102 @@ __device__ __forceinline__ void fw_store_destroyed(char *dbuf, const char *ib, u
 // in the same frame, reference src/plugin.rs:46-60) -- they never cost an extra HBM round trip.
 #define FW_OP(i) (SPAWN == FW_SPAWN_INLINE ? inl.ops[i] : a.ops[i])
 
-template <bool FUSED, int SPAWN>
-__global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArgs a, FwInlineOps inl) {
+// ---- decoupled look-back over the tiles [lo, tile) of the status array ----------------------------
+// Every lane fetches LBW status words with all loads in flight at once, so a step costs one memory
+// round trip and covers LBW * BLK tiles.  Returns the exclusive sum; sets *timed_out (block-uniform)
+// when a predecessor did not publish within the spin limit.
+template <int BLK, int NW, int LBW>
+__device__ __forceinline__ uint32_t fw_lookback(const unsigned long long *status, uint32_t lo, uint32_t tile,
+                                                uint32_t epoch, uint32_t spin_limit, uint32_t *s_lb, bool *timed_out) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t excl = 0;
+    uint32_t pos = tile - 1u;
+    bool to = false;
+    for (;;) {
+        unsigned long long wd[LBW];
+        bool has[LBW];
+#pragma unroll
+        for (int j = 0; j < LBW; j++) {
+            has[j] = pos >= lo + tid + (uint32_t)j * BLK;
+            wd[j] = has[j] ? __hip_atomic_load(&status[pos - tid - (uint32_t)j * BLK], RLX, AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < LBW; j++) {
+            uint32_t st = 0, val = 0;
+            if (has[j]) {
+                uint32_t spins = 0;
+                while ((uint32_t)(wd[j] >> 34) != epoch) {
+                    if (++spins > spin_limit) {
+                        to = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    wd[j] = __hip_atomic_load(&status[pos - tid - (uint32_t)j * BLK], RLX, AGENT);
+                }
+                st = (uint32_t)(wd[j] >> 32) & 3u;
+                val = (uint32_t)wd[j];
+            }
+            const unsigned long long incl = __ballot(has[j] && st == FW_ST_INCL);
+            bool use = has[j];
+            if (incl) use = has[j] && lane <= (uint32_t)(__ffsll((long long)incl) - 1);
+            const uint32_t wsum = fw_wave_sum(use ? val : 0u);
+            if (lane == 0) {
+                s_lb[j * NW + wave] = wsum;
+                s_lb[LBW * NW + j * NW + wave] = incl ? 1u : 0u;
+            }
+        }
+        if (__syncthreads_or(to ? 1 : 0)) {
+            to = true;
+            break;
+        }
+        bool found = false;
+#pragma unroll
+        for (int w = 0; w < LBW * NW; w++) {  // nearest sub-window first, nearest wave first
+            if (!found) {
+                excl += s_lb[w];
+                found = s_lb[LBW * NW + w] != 0u;
+            }
+        }
+        __syncthreads();
+        if (found || pos < lo + LBW * BLK) break;
+        pos -= LBW * BLK;
+    }
+    *timed_out = to;
+    return excl;
+}
+
+// R = particles per thread; the workgroup has FW_TILE / R threads, so a tile is always FW_TILE
+// particles.  R = 4 (256 threads) is the measured optimum on MI355X.
+//
+// Where a tile's output offset (exclusive survivor prefix) comes from:
+//   * FORECAST (a.fc_in != null): the previous frame's kernel already evaluated, for every survivor it
+//     stored, whether it survives one more step of the same dt, and left per-tile sums in the forecast
+//     table.  The host enables this only when dt repeats bit-for-bit and nothing touched the state in
+//     between, so the sums are exact: the tile adds up its predecessors' entries (plain L2 reads of data
+//     finished a kernel ago) and never waits for a co-resident workgroup.  Only tiles that hold freshly
+//     spawned particles look back -- among themselves -- for the survivors of the new particles.
+//   * otherwise: single-pass decoupled look-back over all earlier tiles of the segment.
+template <bool FUSED, int SPAWN, int R>
+__global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdateArgs a, FwInlineOps inl) {
+    constexpr int BLK = FW_TILE / R;
+    constexpr int NW = BLK / 64;
+    constexpr int LBW = 4;  // status words per lane per look-back step
     __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
-    __shared__ uint32_t s_wcnt[FW_ROUNDS][4];
-    __shared__ uint32_t s_lb[8];
+    __shared__ uint32_t s_wcnt[R][NW];
+    __shared__ uint32_t s_lb[2 * LBW * NW];
+    __shared__ uint32_t s_part[4][NW];  // per-wave partials: forecast prefix, new survivors, next-frame sums A / B
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t seg = fw_upper_slot(a.seg_tile_first, a.n_seg, blockIdx.x);
-    const uint32_t first = a.seg_tile_first[seg];
+    // workgroup -> (segment, tile in segment): one table read instead of a dependent binary search
+    uint32_t seg, first, seg_tiles;
+    if (a.tile_desc) {
+        const uint4 d = a.tile_desc[blockIdx.x];
+        seg = d.x, first = d.y, seg_tiles = d.z;
+    } else {
+        seg = fw_upper_slot(a.seg_tile_first, a.n_seg, blockIdx.x);
+        first = a.seg_tile_first[seg];
+        seg_tiles = a.seg_tile_first[seg + 1] - first;
+    }
     uint32_t tis = blockIdx.x - first;
     const uint32_t p = a.parity;
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
@@ -287,6 +388,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArg
         for (uint32_t i = o0; i < o1; i++) n_spawn += a.ops[i].n;
     }
     const uint32_t n_tot = n_in + n_spawn;
+    const uint32_t t_spawn = n_in / FW_TILE;  // first tile that holds a new particle (if any)
     if (SPAWN != FW_SPAWN_NONE) {
         // Tiles that hold new particles do ~1k VALU instructions per particle before they can publish their
         // survivor count.  They are the LAST tiles of the segment; give them the FIRST workgroups so that this
@@ -294,27 +396,33 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArg
         // tiles are front-loaded (they wait for all earlier tiles while holding a slot), so the rest of the
         // grid -- still dispatched in tile order -- always makes progress.
         if (n_spawn != 0) {
-            const uint32_t t_spawn = n_in / FW_TILE, t_last = (n_tot - 1u) / FW_TILE;
+            const uint32_t t_last = (n_tot - 1u) / FW_TILE;
             const uint32_t S = t_last - t_spawn + 1u;
             if (S <= 64u && t_spawn != 0 && tis <= t_last) tis = tis < S ? t_spawn + tis : tis - S;
         }
     }
     const uint32_t tile = first + tis;
     const uint32_t base = tis * FW_TILE;
+    uint4 *fc_out = FUSED ? a.fc_out : nullptr;
 
-    if (n_tot == 0) {  // empty segment: its first tile still owns the bookkeeping
-        if (tis == 0 && tid == 0) {
-            g.count[oidx] = 0;
-            g.spawned[oidx] = 0;
-            g.appended[oidx] = 0;
-            g.ndestroyed[seg] = 0;
-            if (a.host_counts) a.host_counts[seg] = 0;
+    if (n_tot == 0 || base >= n_tot) {
+        if (tid == 0) {
+            if (fc_out) fc_out[tile] = make_uint4(0u, 0u, 0u, a.epoch);  // contributes nothing next frame
+            if (n_tot == 0 && tis == 0) {  // empty segment: its first tile still owns the bookkeeping
+                g.count[oidx] = 0;
+                g.spawned[oidx] = 0;
+                g.appended[oidx] = 0;
+                g.ndestroyed[seg] = 0;
+                if (a.host_counts) a.host_counts[seg] = 0;
+            }
         }
         return;
     }
-    if (base >= n_tot) return;
     const bool is_last = ((n_tot - 1u) / FW_TILE) == tis;
-    if (tis == 0 && tid == 0 && n_tot > (a.seg_tile_first[seg + 1] - first) * FW_TILE) atomicOr(g.err, FW_ERR_CAPACITY);
+    if (tis == 0 && tid == 0 && n_tot > seg_tiles * FW_TILE) {
+        atomicOr(g.err, FW_ERR_CAPACITY);
+        g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;  // diagnostics
+    }
 
     // field-wise reads (block-uniform -> scalar loads); a by-value FwSeg indexed by `p` would be
     // demoted to an LDS-backed private array
@@ -324,17 +432,16 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArg
     const char *ib = Sp->buf[p];
     char *ob = Sp->buf[p ^ 1u];
     char *destroyed = Sp->destroyed;
-    const FwType T = g.types[Sp->type_idx];
-    fw_stage_keys(s_keys, g, T);
 
-    // ---- phase 1: the two planes that decide survival (age in Q0.w, lifetime in Q3.w)
-    float4 q0[FW_ROUNDS], q1[FW_ROUNDS], q2[FW_ROUNDS], q3[FW_ROUNDS];
-    float age_new[FW_ROUNDS];
-    bool valid[FW_ROUNDS], alive[FW_ROUNDS], loaded[FW_ROUNDS];
-    uint32_t lpre[FW_ROUNDS];
+    // ---- phase 1: particle loads go out first; the planes that decide survival are Q0 (age in .w) and
+    // Q3 (lifetime in .w)
+    float4 q0[R], q1[R], q2[R], q3[R];
+    float age_new[R];
+    bool valid[R], alive[R], loaded[R];
+    uint32_t lpre[R];
 #pragma unroll
-    for (int r = 0; r < FW_ROUNDS; r++) {
-        const uint32_t idx = base + r * FW_BLOCK + tid;
+    for (int r = 0; r < R; r++) {
+        const uint32_t idx = base + r * BLK + tid;
         valid[r] = idx < n_tot;
         loaded[r] = idx < n_in;
         if (loaded[r]) {
@@ -342,12 +449,30 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArg
             q3[r] = fw_ld4(ib + FW_OFF_Q3(C), idx);
         }
     }
-    if (SPAWN != FW_SPAWN_NONE && base + FW_TILE > n_in) {  // block-uniform: this tile holds new particles
+
+    // per-type constants (scalar loads) and curve / gradient keys (staged in LDS) arrive under the loads
+    const FwType T = g.types[Sp->type_idx];
+    for (uint32_t i = tid; i < T.keys_len; i += BLK) s_keys[i] = g.keys[T.keys_off + i];
+
+    // ---- forecast prefix: entry t of the table = {survivors landing in output tile A, in A+1, A, tag}
+    const bool use_fc = FUSED && a.fc_in != nullptr && seg_tiles <= FW_FC_MAX_TILES;
+    uint32_t fc_part = 0;
+    bool fc_bad = false;
+    if (use_fc) {
+        for (uint32_t t = tid; t < seg_tiles; t += BLK) {
+            const uint4 e = a.fc_in[first + t];
+            fc_bad |= e.w != a.epoch - 1u;
+            fc_part += (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u));
+        }
+    }
+
+    const bool has_new = SPAWN != FW_SPAWN_NONE && base + FW_TILE > n_in;  // block-uniform
+    if (has_new) {
         // One rolled instance of the spawn code (it is large: 3 Philox blocks + trig); the results are
         // steered into the register arrays with static indices so they stay in VGPRs.
 #pragma unroll 1
-        for (int r = 0; r < FW_ROUNDS; r++) {
-            const uint32_t idx = base + r * FW_BLOCK + tid;
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = base + r * BLK + tid;
             if (idx < n_tot && idx >= n_in) {
                 const uint32_t k = idx - n_in;
                 uint32_t oi = o0;
@@ -360,103 +485,72 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArg
                     fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
                     fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
 #pragma unroll
-                for (int rr = 0; rr < FW_ROUNDS; rr++)
+                for (int rr = 0; rr < R; rr++)
                     if (rr == r) q0[rr] = so.q0, q1[rr] = so.q1, q2[rr] = so.q2, q3[rr] = so.q3;
             }
         }
     }
+    uint32_t new_alive = 0;  // survivors among this tile's new particles (wave-uniform partial)
 #pragma unroll
-    for (int r = 0; r < FW_ROUNDS; r++) {
+    for (int r = 0; r < R; r++) {
         alive[r] = valid[r] && fw_survives(q0[r].w, a.dt, q3[r].w, &age_new[r]);
         const unsigned long long m = __ballot(alive[r]);
         lpre[r] = fw_lane_prefix(m);
         if (lane == 0) s_wcnt[r][wave] = (uint32_t)__popcll(m);
+        if (has_new) new_alive += (uint32_t)__popcll(__ballot(alive[r] && !loaded[r]));
     }
-    __syncthreads();
-    uint32_t rank[FW_ROUNDS];
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int r = 0; r < FW_ROUNDS; r++) {
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            if ((uint32_t)w == wave) rank[r] = cnt + lpre[r];
-            cnt += s_wcnt[r][w];
-        }
+    if (use_fc) {
+        fc_part = fw_wave_sum(fc_part);
+        if (lane == 0) s_part[0][wave] = fc_part, s_part[1][wave] = new_alive;
+        if (__any(fc_bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST);
     }
 
-    // ---- phase 2: exclusive prefix of survivors over the earlier tiles of this segment
-    uint32_t excl = 0;
-    if (FUSED) {
-        unsigned long long *status = g.tile_status;
-        if (tis > 0 && tid == 0)
-            __hip_atomic_store(&status[tile], fw_pack_status(a.epoch, FW_ST_AGG, cnt), RLX, AGENT);
-    }
-
-    // phase 3 loads are issued before the look-back wait so their latency overlaps it
+    // the remaining two input planes
 #pragma unroll
-    for (int r = 0; r < FW_ROUNDS; r++) {
-        const uint32_t idx = base + r * FW_BLOCK + tid;
+    for (int r = 0; r < R; r++) {
+        const uint32_t idx = base + r * BLK + tid;
         if (loaded[r]) {
             q1[r] = fw_ld4(ib + FW_OFF_Q1(C), idx);
             q2[r] = fw_ld4(ib + FW_OFF_Q2(C), idx);
         }
     }
-
-    if (FUSED) {
-        unsigned long long *status = g.tile_status;
-        if (tis > 0) {
-            uint32_t pos = tile - 1u;
-            bool timed_out = false;
-            for (;;) {
-                const bool has = (pos >= first + tid) && (pos >= tid);
-                uint32_t st = 0, val = 0;
-                if (has) {
-                    const unsigned long long *wp = &status[pos - tid];
-                    uint32_t spins = 0;
-                    for (;;) {
-                        const unsigned long long wd = __hip_atomic_load(wp, RLX, AGENT);
-                        if ((uint32_t)(wd >> 34) == a.epoch) {
-                            st = (uint32_t)(wd >> 32) & 3u;
-                            val = (uint32_t)wd;
-                            break;
-                        }
-                        if (++spins > a.spin_limit) {
-                            timed_out = true;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                }
-                const unsigned long long incl = __ballot(has && st == FW_ST_INCL);
-                bool use = has;
-                if (incl) use = has && lane <= (uint32_t)(__ffsll((long long)incl) - 1);
-                const uint32_t wsum = fw_wave_sum(use ? val : 0u);
-                if (lane == 0) {
-                    s_lb[wave] = wsum;
-                    s_lb[4 + wave] = incl ? 1u : 0u;
-                }
-                if (__syncthreads_or(timed_out ? 1 : 0)) {
-                    timed_out = true;
-                    break;
-                }
-                bool found = false;
+    __syncthreads();
+    uint32_t rank[R];
+    uint32_t cnt = 0;
 #pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    if (!found) {
-                        excl += s_lb[w];
-                        found = s_lb[4 + w] != 0u;
-                    }
-                }
-                __syncthreads();
-                if (found || pos < first + FW_BLOCK) break;
-                pos -= FW_BLOCK;
-            }
+    for (int r = 0; r < R; r++) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            if ((uint32_t)w == wave) rank[r] = cnt + lpre[r];
+            cnt += s_wcnt[r][w];
+        }
+    }
+    uint32_t fc_excl = 0, new_cnt = 0;
+    if (use_fc) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) fc_excl += s_part[0][w], new_cnt += s_part[1][w];
+    }
+
+    // ---- phase 2: exclusive prefix of survivors over the earlier tiles of this segment
+    uint32_t excl = 0;
+    if (FUSED) {
+        // what this tile publishes / where its look-back starts
+        const bool lb_needed = use_fc ? (has_new && tis > t_spawn) : tis > 0;
+        const bool lb_publish = use_fc ? has_new : true;
+        const uint32_t lb_lo = use_fc ? first + t_spawn : first;
+        const uint32_t lb_val = use_fc ? new_cnt : cnt;
+        if (lb_publish && lb_needed && tid == 0)
+            __hip_atomic_store(&g.tile_status[tile], fw_pack_status(a.epoch, FW_ST_AGG, lb_val), RLX, AGENT);
+        uint32_t lb_excl = 0;
+        if (lb_needed && !(a.dbg & 1u)) {
+            bool timed_out = false;
+            lb_excl = fw_lookback<BLK, NW, LBW>(g.tile_status, lb_lo, tile, a.epoch, a.spin_limit, s_lb, &timed_out);
             if (timed_out) {
-                // Fallback (never taken when workgroups are dispatched in order): recount the
-                // survivors of all earlier particles of this segment from the input planes.
+                // Fallback (never taken when workgroups are dispatched in order): recount the survivors of
+                // the earlier particles of this segment (forecast mode: of the earlier NEW particles only).
                 if (tid == 0) atomicOr(g.err, FW_ERR_LOOKBACK_TIMEOUT);
                 uint32_t c = 0;
-                for (uint32_t i = tid; i < base; i += FW_BLOCK) {
+                for (uint32_t i = (use_fc ? n_in : 0u) + tid; i < base; i += BLK) {
                     float an, ag = 0.0f, lf;
                     if (i < n_in) {
                         ag = fw_ld4(ib + FW_OFF_Q0(C), i).w, lf = fw_ld4(ib + FW_OFF_Q3(C), i).w;
@@ -478,28 +572,55 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update(FwGlobals g, FwUpdateArg
                 __syncthreads();
                 if (lane == 0) s_lb[wave] = c;
                 __syncthreads();
-                excl = s_lb[0] + s_lb[1] + s_lb[2] + s_lb[3];
+                lb_excl = 0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) lb_excl += s_lb[w];
             }
         }
-        if (tid == 0) __hip_atomic_store(&status[tile], fw_pack_status(a.epoch, FW_ST_INCL, excl + cnt), RLX, AGENT);
+        if (lb_publish && tid == 0)
+            __hip_atomic_store(&g.tile_status[tile], fw_pack_status(a.epoch, FW_ST_INCL, lb_excl + lb_val), RLX, AGENT);
+        excl = fc_excl + lb_excl;
     } else {
         excl = g.tile_off[tile];
     }
 
     // ---- phase 3: integrate survivors, store them at their compacted slot
     const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
+    const uint32_t fcA = excl / FW_TILE, fc_bnd = (fcA + 1u) * FW_TILE;  // output tiles this workgroup feeds
+    uint32_t fa = 0, fb = 0;
 #pragma unroll
-    for (int r = 0; r < FW_ROUNDS; r++) {
-        const uint32_t idx = base + r * FW_BLOCK + tid;
+    for (int r = 0; r < R; r++) {
+        const uint32_t idx = base + r * BLK + tid;
         const uint32_t o = excl + rank[r];
-        if (alive[r]) {
+        if (fc_out) {  // will it survive one more step of the same dt?  (same expression as fw_survives)
+            float an2;
+            const bool nx = alive[r] && fw_survives(age_new[r], a.dt, q3[r].w, &an2);
+            fa += (uint32_t)__popcll(__ballot(nx && o < fc_bnd));
+            fb += (uint32_t)__popcll(__ballot(nx && o >= fc_bnd));
+        }
+        if (alive[r] && (a.dbg & 2u)) {  // profiling only: stream without arithmetic
+            q0[r].w = age_new[r];
+            fw_st4(ob + FW_OFF_Q0(C), o, q0[r]), fw_st4(ob + FW_OFF_Q1(C), o, q1[r]);
+            fw_st4(ob + FW_OFF_Q2(C), o, q2[r]), fw_st4(ob + FW_OFF_Q3(C), o, q3[r]);
+            fw_st4(ob + FW_OFF_Q5(C), o, q0[r]), fw_st4(ob + FW_OFF_Q6(C), o, q1[r]);
+            fw_st1(ob + FW_OFF_S4(C), o, q1[r].w);
+        } else if (alive[r]) {
             fw_integrate_store(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], ob, C, o);
             for (uint32_t k = 0; k < n_lplanes; k++)  // new particles: vec![f32::MIN; n] (core.rs:467)
-                reinterpret_cast<float *>(ob + FW_OFF_L(C, k))[o] =
-                    loaded[r] ? reinterpret_cast<const float *>(ib + FW_OFF_L(C, k))[idx] : FW_F32_MIN;
+                fw_st1(ob + FW_OFF_L(C, k), o, loaded[r] ? fw_ld1(ib + FW_OFF_L(C, k), idx) : FW_F32_MIN);
         } else if (valid[r] && want_destroyed) {
             fw_store_destroyed(destroyed, ib, C, idx, loaded[r], T, s_keys, q0[r], q1[r], q2[r], q3[r], age_new[r],
                                idx - o);
+        }
+    }
+    if (fc_out) {
+        if (lane == 0) s_part[2][wave] = fa, s_part[3][wave] = fb;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t sa = 0, sb = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) sa += s_part[2][w], sb += s_part[3][w];
+            fc_out[tile] = make_uint4(sa, sb, fcA, a.epoch);
         }
     }
 
@@ -882,23 +1003,33 @@ hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *ops, u
     return hipGetLastError();
 }
 
+template <int R>
+static void fw_launch_update_r(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps &io,
+                               int spawn_form, int mode) {
+    const dim3 grid(a.total_tiles), block(FW_TILE / R);
+    if (mode == FW_MODE_SPLIT) {  // debugging / A-B mode: three launches, no inter-workgroup traffic
+        hipLaunchKernelGGL(fw_k_count, grid, dim3(FW_BLOCK), 0, s, g, a);
+        hipLaunchKernelGGL(fw_k_scan, dim3(a.n_seg), dim3(FW_BLOCK), 0, s, g, a);
+        hipLaunchKernelGGL((fw_k_update<false, FW_SPAWN_NONE, R>), grid, block, 0, s, g, a, io);
+    } else if (spawn_form == FW_SPAWN_INLINE) {
+        hipLaunchKernelGGL((fw_k_update<true, FW_SPAWN_INLINE, R>), grid, block, 0, s, g, a, io);
+    } else if (spawn_form == FW_SPAWN_TABLE) {
+        hipLaunchKernelGGL((fw_k_update<true, FW_SPAWN_TABLE, R>), grid, block, 0, s, g, a, io);
+    } else {
+        hipLaunchKernelGGL((fw_k_update<true, FW_SPAWN_NONE, R>), grid, block, 0, s, g, a, io);
+    }
+}
+
 hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps *inl,
-                            int spawn_form, int mode) {
+                            int spawn_form, int mode, int rounds) {
     if (!a.total_tiles) return hipSuccess;
     static const FwInlineOps none{};
     const FwInlineOps &io = inl ? *inl : none;
-    const dim3 grid(a.total_tiles), block(FW_BLOCK);
-    if (mode == FW_MODE_SPLIT) {  // debugging / A-B mode: three launches, no inter-workgroup traffic
-        if (spawn_form != FW_SPAWN_NONE) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(fw_k_count, grid, block, 0, s, g, a);
-        hipLaunchKernelGGL(fw_k_scan, dim3(a.n_seg), block, 0, s, g, a);
-        hipLaunchKernelGGL((fw_k_update<false, FW_SPAWN_NONE>), grid, block, 0, s, g, a, io);
-    } else if (spawn_form == FW_SPAWN_INLINE) {
-        hipLaunchKernelGGL((fw_k_update<true, FW_SPAWN_INLINE>), grid, block, 0, s, g, a, io);
-    } else if (spawn_form == FW_SPAWN_TABLE) {
-        hipLaunchKernelGGL((fw_k_update<true, FW_SPAWN_TABLE>), grid, block, 0, s, g, a, io);
-    } else {
-        hipLaunchKernelGGL((fw_k_update<true, FW_SPAWN_NONE>), grid, block, 0, s, g, a, io);
+    if (mode == FW_MODE_SPLIT && spawn_form != FW_SPAWN_NONE) return hipErrorInvalidValue;
+    switch (rounds) {
+        case 1: fw_launch_update_r<1>(s, g, a, io, spawn_form, mode); break;
+        case 2: fw_launch_update_r<2>(s, g, a, io, spawn_form, mode); break;
+        default: fw_launch_update_r<4>(s, g, a, io, spawn_form, mode); break;
     }
     return hipGetLastError();
 }

@@ -85,7 +85,8 @@ FW_HD fw_v3 fw_quat_mul_vec3(fw_q4 q, fw_v3 v) {
 
 FW_HD fw_q4 fw_quat_from_axis_angle(fw_v3 axis, float angle) {
     float h = angle * 0.5f;
-    float s = sinf(h), c = cosf(h);
+    float s, c;
+    sincosf(h, &s, &c);
     return fw_q4{axis.x * s, axis.y * s, axis.z * s, c};
 }
 
@@ -142,8 +143,14 @@ FW_HD float fw_unit_f32(uint32_t x) { return (float)(x >> 8) * 5.9604645e-8f; }
 // returns true when the sample lies strictly between keys lo and lo+1 (fraction *s)
 FW_HD bool fw_even_interp(int n, float t, int *lo, float *s) {
     int subdivs = n - 1;
-    float step = 1.0f / (float)subdivs;
-    float steps_taken = (t - 0.0f) / step;
+    float steps_taken;
+    if ((subdivs & (subdivs - 1)) == 0) {
+        // step = 1/subdivs is a power of two: (t - 0) / step == t * subdivs exactly, no division needed
+        steps_taken = (t - 0.0f) * (float)subdivs;
+    } else {
+        float step = 1.0f / (float)subdivs;
+        steps_taken = (t - 0.0f) / step;
+    }
     if (steps_taken <= 0.0f) {
         *lo = 0;
         return false;

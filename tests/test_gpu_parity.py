@@ -127,6 +127,31 @@ def test_compaction_order_ragged_lifetimes(system):
     assert pair.gpu.count(0) > 100000
 
 
+def test_variable_dt_switches_between_forecast_and_lookback(system):
+    """constant dt -> survivor forecast; a changed dt or a touched state -> decoupled look-back; the
+    particle order and state must be identical either way (several tiles, deaths everywhere)"""
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.05, 0.8), linear_drag=0.3)
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(120000.0),
+                            initial_velocity=S.RandVec3(S.RandF32(0.0, 3.0), (0.0, 1.0, 0.0), 0.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [es]), seed=SEED, uid=21)
+    dts = [1 / 60] * 25 + [1 / 30, 1 / 60, 1 / 60, 1 / 144, 1 / 144, 1 / 144, 0.0, 1 / 60] + [1 / 60] * 20 + [0.011, 0.012, 0.013]
+    for i, dt in enumerate(dts):
+        dt = np.float32(dt)
+        system.update(dt)
+        pair.step_cpu(dt)
+        if i % 4 == 3 or i > 24:
+            pair.check(exact_all=True, what=f"frame {i} dt={dt}")
+    # touching the state between two equal-dt frames must not reuse the stale forecast
+    parts = pair.cpu.particles(0)[::3].copy()
+    pair.gpu.write_particles(0, parts)
+    pair.cpu.write_particles(0, parts)
+    for i in range(6):
+        system.update(DT)
+        pair.step_cpu(DT)
+        pair.check(exact_all=True, what=f"after write {i}")
+    assert pair.gpu.count(0) > 20000
+
+
 def test_two_types_two_emitters_and_modifier(system):
     p0 = S.ParticleSettings(lifetime=S.RandF32(0.5, 0.7), linear_drag=0.5)
     p1 = S.ParticleSettings(lifetime=S.RandF32.constant(0.25), acceleration=(0.0, 1.0, 0.0),

@@ -1,0 +1,170 @@
+// membw.hip -- HBM streaming microbenchmark for gfx950: what a float4 read+write stream can reach,
+// by access shape.  Used to set the "measured roofline" line in DESIGN.md and to choose the update
+// kernel's load/store shape.   hipcc --offload-arch=gfx950 -O3 tools/membw.hip -o tools/membw
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_ld(const float4* p) {
+    v4f v = __builtin_nontemporal_load((const v4f*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_st(float4 x, float4* p) {
+    v4f v = {x.x, x.y, x.z, x.w};
+    __builtin_nontemporal_store(v, (v4f*)p);
+}
+
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * 256 * U;
+    for (size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x; i < n4; i += stride) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t j = i + (size_t)u * 256;
+            if (j < n4) v[u] = NT ? nt_ld(&src[j]) : src[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t j = i + (size_t)u * 256;
+            if (j < n4) { if (NT) nt_st(v[u], &dst[j]); else dst[j] = v[u]; }
+        }
+    }
+}
+
+// one tile per block (no grid stride): the update kernel's shape. 4 input planes, 7 output planes.
+template <int R, bool NT>
+__global__ __launch_bounds__(256) void k_planes(const char* __restrict__ in, char* __restrict__ out, uint32_t n, uint32_t C) {
+    const uint32_t base = blockIdx.x * 256 * R;
+    float4 a[R], b[R], c[R], d[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        uint32_t i = base + r * 256 + threadIdx.x;
+        if (i < n) {
+            a[r] = ((const float4*)(in))[i];
+            b[r] = ((const float4*)(in + (size_t)16 * C))[i];
+            c[r] = ((const float4*)(in + (size_t)32 * C))[i];
+            d[r] = ((const float4*)(in + (size_t)48 * C))[i];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        uint32_t i = base + r * 256 + threadIdx.x;
+        if (i < n) {
+            float4 e = make_float4(a[r].x + b[r].x, a[r].y * c[r].y, d[r].z, a[r].w);
+            float4 f = make_float4(b[r].w, c[r].x, d[r].y, e.x);
+            if (NT) {
+                nt_st(a[r], &((float4*)(out))[i]);
+                nt_st(b[r], &((float4*)(out + (size_t)16 * C))[i]);
+                nt_st(c[r], &((float4*)(out + (size_t)32 * C))[i]);
+                nt_st(d[r], &((float4*)(out + (size_t)48 * C))[i]);
+                nt_st(e, &((float4*)(out + (size_t)64 * C))[i]);
+                nt_st(f, &((float4*)(out + (size_t)80 * C))[i]);
+                __builtin_nontemporal_store(e.y, &((float*)(out + (size_t)96 * C))[i]);
+            } else {
+                ((float4*)(out))[i] = a[r];
+                ((float4*)(out + (size_t)16 * C))[i] = b[r];
+                ((float4*)(out + (size_t)32 * C))[i] = c[r];
+                ((float4*)(out + (size_t)48 * C))[i] = d[r];
+                ((float4*)(out + (size_t)64 * C))[i] = e;
+                ((float4*)(out + (size_t)80 * C))[i] = f;
+                ((float*)(out + (size_t)96 * C))[i] = e.y;
+            }
+        }
+    }
+}
+
+// same as k_planes<4,false> but occupancy-limited through dynamic LDS (bytes per block chosen by the host)
+__global__ __launch_bounds__(256) void k_planes_occ(const char* __restrict__ in, char* __restrict__ out, uint32_t n, uint32_t C) {
+    extern __shared__ float dummy[];
+    constexpr int R = 4;
+    const uint32_t base = blockIdx.x * 256 * R;
+    float4 a[R], b[R], c[R], d[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        uint32_t i = base + r * 256 + threadIdx.x;
+        if (i < n) {
+            a[r] = ((const float4*)(in))[i];
+            b[r] = ((const float4*)(in + (size_t)16 * C))[i];
+            c[r] = ((const float4*)(in + (size_t)32 * C))[i];
+            d[r] = ((const float4*)(in + (size_t)48 * C))[i];
+        }
+    }
+    if (n == 0xFFFFFFFFu) dummy[threadIdx.x] = a[0].x;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        uint32_t i = base + r * 256 + threadIdx.x;
+        if (i < n) {
+            float4 e = make_float4(a[r].x + b[r].x, a[r].y * c[r].y, d[r].z, a[r].w);
+            float4 f = make_float4(b[r].w, c[r].x, d[r].y, e.x);
+            ((float4*)(out))[i] = a[r];
+            ((float4*)(out + (size_t)16 * C))[i] = b[r];
+            ((float4*)(out + (size_t)32 * C))[i] = c[r];
+            ((float4*)(out + (size_t)48 * C))[i] = d[r];
+            ((float4*)(out + (size_t)64 * C))[i] = e;
+            ((float4*)(out + (size_t)80 * C))[i] = f;
+            ((float*)(out + (size_t)96 * C))[i] = e.y;
+        }
+    }
+}
+
+template <typename F>
+double timeit(F f, int iters) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) f(i);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) f(i);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e-3 / iters;
+}
+
+int main(int argc, char** argv) {
+    size_t mb = argc > 1 ? atol(argv[1]) : 256;
+    size_t bytes = mb << 20;
+    char *a, *b; CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
+    CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 0, bytes));
+    size_t n4 = bytes / 16;
+    printf("copy %zu MiB -> %zu MiB (GB/s = read+write bytes)\n", mb, mb);
+    for (int blocks : {1024, 2048, 4096, 8192}) {
+        double t;
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_copy<1, false>), dim3(blocks), dim3(256), 0, 0, (const float4*)((i&1)?b:a), (float4*)((i&1)?a:b), n4); }, 20);
+        printf("  U=1 blocks=%5d        : %8.1f GB/s\n", blocks, 2.0 * bytes / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_copy<4, false>), dim3(blocks), dim3(256), 0, 0, (const float4*)((i&1)?b:a), (float4*)((i&1)?a:b), n4); }, 20);
+        printf("  U=4 blocks=%5d        : %8.1f GB/s\n", blocks, 2.0 * bytes / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_copy<4, true>), dim3(blocks), dim3(256), 0, 0, (const float4*)((i&1)?b:a), (float4*)((i&1)?a:b), n4); }, 20);
+        printf("  U=4 blocks=%5d nt     : %8.1f GB/s\n", blocks, 2.0 * bytes / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_copy<8, false>), dim3(blocks), dim3(256), 0, 0, (const float4*)((i&1)?b:a), (float4*)((i&1)?a:b), n4); }, 20);
+        printf("  U=8 blocks=%5d        : %8.1f GB/s\n", blocks, 2.0 * bytes / t / 1e9);
+    }
+    // update-kernel shape: N particles, 64 B in / 100 B out per particle, ping-pong
+    for (uint32_t n : {1000000u, 4000000u, 16000000u}) {
+        uint32_t C = (n + 1023) / 1024 * 1024 + 262144;
+        size_t pb = (size_t)100 * C;
+        char *p0, *p1; CK(hipMalloc(&p0, pb)); CK(hipMalloc(&p1, pb));
+        CK(hipMemset(p0, 0, pb)); CK(hipMemset(p1, 0, pb));
+        double t;
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_planes<4, false>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("planes n=%8u R=4        : %7.2f us  %8.1f GB/s (164 B/particle)\n", n, t * 1e6, 164.0 * n / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_planes<4, true>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("planes n=%8u R=4 nt     : %7.2f us  %8.1f GB/s\n", n, t * 1e6, 164.0 * n / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_planes<2, false>), dim3((n + 511) / 512), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("planes n=%8u R=2        : %7.2f us  %8.1f GB/s\n", n, t * 1e6, 164.0 * n / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_planes<1, false>), dim3((n + 255) / 256), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("planes n=%8u R=1        : %7.2f us  %8.1f GB/s\n", n, t * 1e6, 164.0 * n / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_planes<8, false>), dim3((n + 2047) / 2048), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("planes n=%8u R=8        : %7.2f us  %8.1f GB/s\n", n, t * 1e6, 164.0 * n / t / 1e9);
+        for (int blocks_per_cu : {1, 2, 3, 4, 6, 8}) {
+            size_t lds = 160 * 1024 / blocks_per_cu - 1024;
+            if (lds > 64 * 1024) { CK(hipFuncSetAttribute((const void*)k_planes_occ, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
+            t = timeit([&](int i) { hipLaunchKernelGGL(k_planes_occ, dim3((n + 1023) / 1024), dim3(256), lds, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+            printf("planes n=%8u R=4 %d blocks/CU : %7.2f us  %8.1f GB/s\n", n, blocks_per_cu, t * 1e6, 164.0 * n / t / 1e9);
+        }
+        CK(hipFree(p0)); CK(hipFree(p1));
+    }
+    return 0;
+}
