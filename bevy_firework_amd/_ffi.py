@@ -13,7 +13,8 @@ from typing import List
 from . import settings as S
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfirework_hip.so")
+# FW_LIB_PATH lets A/B experiments load an alternative build of the same library
+LIB_PATH = os.environ.get("FW_LIB_PATH") or os.path.join(_HERE, "csrc", "libfirework_hip.so")
 
 FW_OK, FW_EINVAL, FW_ENOMEM, FW_EHIP, FW_ECAPACITY, FW_ENODEV, FW_ESMALL = 0, -1, -2, -3, -4, -5, -6
 STATUS_NAMES = {
