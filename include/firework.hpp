@@ -1,0 +1,376 @@
+// firework.hpp -- C++ host-side mirror of the reference's plugin surface over the C ABI
+// (include/firework_hip.h).  The reference is compiled code (Rust); with no Rust toolchain in the
+// build image this header plays the role of the shim crate: same type names, defaults, argument
+// meaning and error behaviour (the reference's panics become exceptions carrying fw_last_error).
+//
+//   reference item                                  here
+//   ParticleSystemPlugin       src/plugin.rs:22-61  firework::ParticleSystemPlugin (owns one GPU context;
+//                                                   update(dt) = the chained per-frame systems)
+//   ParticleSpawner            src/core.rs:178-185  firework::ParticleSpawner
+//   ParticleSettings           src/core.rs:99-142   firework::ParticleSettings   (defaults core.rs:187-211)
+//   EmissionSettings           src/core.rs:144-162  firework::EmissionSettings   (defaults core.rs:213-227)
+//   EmissionPacing / Mode      src/core.rs:11-54    firework::EmissionPacing / EmissionMode
+//   EmissionShape              src/emission_shape.rs firework::EmissionShape
+//   FireworkCurve / Gradient   src/curve.rs         firework::FireworkCurve / FireworkGradient
+//   ParticleSpawnerData        src/core.rs:269-303  firework::ParticleSpawnerData (queue_particles, active, particles)
+//   ParticleData               src/core.rs:305-321  fw_particle
+//   EffectModifier             src/core.rs:323-336  firework::EffectModifier
+//
+// Header-only; link with -lfirework_hip.  No simulation arithmetic lives here.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "firework_hip.h"
+
+namespace firework {
+
+struct Vec3 { float x = 0, y = 0, z = 0; };
+struct Quat { float x = 0, y = 0, z = 0, w = 1; };
+struct LinearRgba {
+    float red = 1, green = 1, blue = 1, alpha = 1;
+    static LinearRgba WHITE() { return {1, 1, 1, 1}; }
+    static LinearRgba BLACK() { return {0, 0, 0, 1}; }
+};
+
+struct Error : std::runtime_error {
+    fw_status status;
+    Error(fw_status s, const std::string &m) : std::runtime_error(m), status(s) {}
+};
+
+struct RandF32 {
+    float min = 0, max = 0;
+    static RandF32 constant(float v) { return {v, v}; }
+};
+
+struct RandVec3 {
+    RandF32 magnitude;
+    Vec3 direction;
+    float spread = 0;
+    static RandVec3 constant(Vec3 v) {  // bevy_utilitarian: direction = v.normalize_or_zero(), magnitude = |v|
+        const float len = std::sqrt((v.x * v.x + v.y * v.y) + v.z * v.z);
+        const float rcp = 1.0f / len;
+        Vec3 d{0, 0, 0};
+        if (std::isfinite(rcp) && rcp > 0) d = {v.x * rcp, v.y * rcp, v.z * rcp};
+        return {RandF32::constant(len), d, 0.0f};
+    }
+};
+
+// FireworkCurve<f32> (curve.rs:8-75)
+struct FireworkCurve {
+    int32_t kind = FW_CURVE_CONSTANT;
+    std::vector<float> times, values;
+    static FireworkCurve constant(float v) { return {FW_CURVE_CONSTANT, {}, {v}}; }
+    static FireworkCurve even_samples(std::vector<float> s) {
+        if (s.empty()) throw Error(FW_EINVAL, "Cannot create curve from 0 samples");  // curve.rs:61
+        if (s.size() == 1) return constant(s[0]);
+        return {FW_CURVE_EVEN, {}, std::move(s)};
+    }
+    static FireworkCurve uneven_samples(const std::vector<std::pair<float, float>> &s) {
+        if (s.empty()) throw Error(FW_EINVAL, "Cannot create curve from 0 samples");  // curve.rs:45
+        if (s.size() == 1) return constant(s[0].second);
+        FireworkCurve c{FW_CURVE_UNEVEN, {}, {}};
+        for (auto &p : s) c.times.push_back(p.first), c.values.push_back(p.second);
+        return c;
+    }
+};
+
+// FireworkGradient<LinearRgba> (curve.rs:171-239)
+struct FireworkGradient {
+    int32_t kind = FW_CURVE_CONSTANT;
+    std::vector<float> times, rgba;
+    static FireworkGradient constant(LinearRgba c) { return {FW_CURVE_CONSTANT, {}, {c.red, c.green, c.blue, c.alpha}}; }
+    static FireworkGradient even_samples(const std::vector<LinearRgba> &s) {
+        if (s.empty()) throw Error(FW_EINVAL, "Cannot create curve from 0 samples");  // curve.rs:227
+        if (s.size() == 1) return constant(s[0]);
+        FireworkGradient g{FW_CURVE_EVEN, {}, {}};
+        for (auto &c : s) g.rgba.insert(g.rgba.end(), {c.red, c.green, c.blue, c.alpha});
+        return g;
+    }
+    static FireworkGradient uneven_samples(const std::vector<std::pair<float, LinearRgba>> &s) {
+        if (s.empty()) throw Error(FW_EINVAL, "Cannot create curve from 0 samples");  // curve.rs:211
+        if (s.size() == 1) return constant(s[0].second);
+        FireworkGradient g{FW_CURVE_UNEVEN, {}, {}};
+        for (auto &p : s) {
+            g.times.push_back(p.first);
+            g.rgba.insert(g.rgba.end(), {p.second.red, p.second.green, p.second.blue, p.second.alpha});
+        }
+        return g;
+    }
+};
+
+// EmissionPacing (core.rs:12-44)
+struct EmissionPacing {
+    int32_t kind = FW_PACING_COUNT_OVER_DURATION;
+    uint64_t one_shot = 0;
+    float count = 5, duration = 1, offset_start = 0, offset_end = 1;
+    static EmissionPacing OneShot(uint64_t n) { return {FW_PACING_ONESHOT, n, 0, 1, 0, 1}; }
+    static EmissionPacing OnDemand() { return {FW_PACING_ONDEMAND, 0, 0, 1, 0, 1}; }
+    static EmissionPacing CountOverDuration(float count, float duration, float start, float end) {
+        return {FW_PACING_COUNT_OVER_DURATION, 0, count, duration, start, end};
+    }
+    static EmissionPacing rate(float r) { return CountOverDuration(r, 1.0f, 0.0f, 1.0f); }  // core.rs:36-43
+    bool is_one_shot() const { return kind == FW_PACING_ONESHOT; }
+};
+
+// EmissionMode (core.rs:47-54)
+struct EmissionMode {
+    int32_t kind = FW_MODE_GLOBAL;
+    int32_t target_particle_type = 0;
+    static EmissionMode Global() { return {}; }
+    static EmissionMode Nested(int32_t target) { return {FW_MODE_NESTED, target}; }
+};
+
+// EmissionShape (emission_shape.rs:6-15)
+struct EmissionShape {
+    int32_t kind = FW_SHAPE_POINT;
+    float radius = 0;
+    Vec3 normal{0, 1, 0};
+    static EmissionShape Point() { return {}; }
+    static EmissionShape Sphere(float r) { return {FW_SHAPE_SPHERE, r, {0, 1, 0}}; }
+    static EmissionShape Circle(Vec3 normal, float r) { return {FW_SHAPE_CIRCLE, r, normal}; }
+};
+
+enum class SpawnTransformMode { Global, Local };  // core.rs:66-73
+
+struct ParticleSettings {  // core.rs:99-142, defaults core.rs:187-211
+    RandF32 lifetime = RandF32::constant(5.0f);
+    FireworkCurve scale_curve = FireworkCurve::constant(1.0f);
+    RandF32 initial_scale = RandF32::constant(1.0f);
+    Vec3 acceleration{0.0f, -9.81f, 0.0f};
+    Vec3 angular_acceleration{0, 0, 0};
+    float linear_drag = 0.2f, angular_drag = 0.2f;
+    FireworkGradient base_color = FireworkGradient::constant(LinearRgba::WHITE());
+    FireworkGradient emissive_color = FireworkGradient::constant(LinearRgba::BLACK());
+    float fade_edge = 0.7f, fade_scene = 1.0f;  // render-only, carried for parity
+    bool pbr = false;
+    // event_handlers.particles_destroyed (core.rs:164-167)
+    std::function<void(const std::vector<fw_particle> &)> particles_destroyed;
+    uint32_t capacity = 0;  // backend knob
+};
+
+struct EmissionSettings {  // core.rs:144-162, defaults core.rs:213-227
+    int32_t particle_index = 0;
+    EmissionPacing emission_pacing = EmissionPacing::rate(5.0f);
+    EmissionMode emission_mode = EmissionMode::Global();
+    EmissionShape emission_shape = EmissionShape::Point();
+    RandVec3 initial_velocity = RandVec3::constant({0, 0, 0});
+    RandF32 initial_velocity_radial = RandF32::constant(0.0f);
+    bool inherit_parent_velocity = true;
+    Quat initial_rotation{};
+    RandVec3 initial_angular_velocity = RandVec3::constant({0, 0, 0});
+};
+
+struct ParticleSpawner {  // core.rs:178-185, defaults core.rs:229-238
+    std::vector<ParticleSettings> particle_settings{ParticleSettings{}};
+    std::vector<EmissionSettings> emission_settings{EmissionSettings{}};
+    bool starts_enabled = true;
+    SpawnTransformMode spawn_transform_mode = SpawnTransformMode::Global;
+};
+
+struct EffectModifier { float scale = 1, speed = 1; };             // core.rs:323-336
+struct Transform { Vec3 translation{}; Quat rotation{}; };          // the fields spawn_particles reads
+
+class ParticleSystemPlugin;
+
+// ParticleSpawnerData (core.rs:269-303): handle to the device-resident state of one spawner
+class ParticleSpawnerData {
+  public:
+    void queue_particles(uint64_t count);  // core.rs:284-286
+    bool active();                         // core.rs:288-302
+    std::vector<uint32_t> counts();
+    std::vector<fw_particle> particles(uint32_t particle_type);  // data.particles[i]
+    std::vector<fw_particle> destroyed(uint32_t particle_type);
+    std::vector<fw_particle_instance> instances(uint32_t particle_type);  // render.rs:95-115
+    bool aabb(Vec3 &mn, Vec3 &mx);                                        // render.rs:677-703
+    void set_transform(const Transform &local, const Transform *global = nullptr) {
+        transform = local;
+        has_global = global != nullptr;
+        if (global) global_transform = *global;
+    }
+    void set_parent_velocity(Vec3 v);
+    void set_modifier(EffectModifier m);
+    std::function<void()> on_finished;  // observer of ParticleSpawnerFinished (core.rs:338-341)
+    fw_spawner handle = -1;
+
+  private:
+    friend class ParticleSystemPlugin;
+    ParticleSystemPlugin *sys = nullptr;
+    ParticleSpawner settings;
+    Transform transform, global_transform;
+    bool has_global = false;
+};
+
+class ParticleSystemPlugin {
+  public:
+    explicit ParticleSystemPlugin(int device = 0, uint32_t seed = 0, void *hip_stream = nullptr) {
+        const fw_status st = fw_ctx_create(device, seed, hip_stream, &ctx_);
+        if (st != FW_OK) throw Error(st, fw_last_error(nullptr));
+    }
+    ~ParticleSystemPlugin() {
+        for (auto *d : spawners_) delete d;
+        if (ctx_) fw_ctx_destroy(ctx_);
+    }
+    ParticleSystemPlugin(const ParticleSystemPlugin &) = delete;
+    ParticleSystemPlugin &operator=(const ParticleSystemPlugin &) = delete;
+
+    // commands.spawn((ParticleSpawner {..}, Transform))
+    ParticleSpawnerData *spawn(const ParticleSpawner &s, const Transform &t = {}, uint32_t uid = UINT32_MAX) {
+        std::vector<fw_particle_settings> ps(s.particle_settings.size());
+        std::vector<fw_emission_settings> es(s.emission_settings.size());
+        for (size_t i = 0; i < ps.size(); i++) {
+            const ParticleSettings &p = s.particle_settings[i];
+            fw_particle_settings &d = ps[i];
+            d = fw_particle_settings{};
+            d.lifetime = {p.lifetime.min, p.lifetime.max};
+            d.scale_curve = {p.scale_curve.kind, (int32_t)p.scale_curve.values.size(),
+                             p.scale_curve.times.empty() ? nullptr : p.scale_curve.times.data(), p.scale_curve.values.data()};
+            d.initial_scale = {p.initial_scale.min, p.initial_scale.max};
+            d.acceleration[0] = p.acceleration.x, d.acceleration[1] = p.acceleration.y, d.acceleration[2] = p.acceleration.z;
+            d.angular_acceleration[0] = p.angular_acceleration.x, d.angular_acceleration[1] = p.angular_acceleration.y;
+            d.angular_acceleration[2] = p.angular_acceleration.z;
+            d.linear_drag = p.linear_drag, d.angular_drag = p.angular_drag;
+            d.base_color = {p.base_color.kind, (int32_t)(p.base_color.rgba.size() / 4),
+                            p.base_color.times.empty() ? nullptr : p.base_color.times.data(), p.base_color.rgba.data()};
+            d.emissive_color = {p.emissive_color.kind, (int32_t)(p.emissive_color.rgba.size() / 4),
+                                p.emissive_color.times.empty() ? nullptr : p.emissive_color.times.data(),
+                                p.emissive_color.rgba.data()};
+            d.pbr = p.pbr, d.report_destroyed = p.particles_destroyed ? 1 : 0, d.capacity = p.capacity;
+        }
+        for (size_t i = 0; i < es.size(); i++) {
+            const EmissionSettings &e = s.emission_settings[i];
+            fw_emission_settings &d = es[i];
+            d = fw_emission_settings{};
+            d.particle_index = e.particle_index;
+            d.pacing_kind = e.emission_pacing.kind, d.oneshot_count = e.emission_pacing.one_shot;
+            d.count = e.emission_pacing.count, d.duration = e.emission_pacing.duration;
+            d.offset_start = e.emission_pacing.offset_start, d.offset_end = e.emission_pacing.offset_end;
+            d.mode = e.emission_mode.kind, d.target_particle_type = e.emission_mode.target_particle_type;
+            d.shape_kind = e.emission_shape.kind, d.shape_radius = e.emission_shape.radius;
+            d.shape_normal[0] = e.emission_shape.normal.x, d.shape_normal[1] = e.emission_shape.normal.y;
+            d.shape_normal[2] = e.emission_shape.normal.z;
+            auto rv = [](const RandVec3 &r) {
+                fw_rand_vec3 o{};
+                o.magnitude = {r.magnitude.min, r.magnitude.max};
+                o.direction[0] = r.direction.x, o.direction[1] = r.direction.y, o.direction[2] = r.direction.z;
+                o.spread = r.spread;
+                return o;
+            };
+            d.initial_velocity = rv(e.initial_velocity);
+            d.initial_velocity_radial = {e.initial_velocity_radial.min, e.initial_velocity_radial.max};
+            d.inherit_parent_velocity = e.inherit_parent_velocity;
+            d.initial_rotation[0] = e.initial_rotation.x, d.initial_rotation[1] = e.initial_rotation.y;
+            d.initial_rotation[2] = e.initial_rotation.z, d.initial_rotation[3] = e.initial_rotation.w;
+            d.initial_angular_velocity = rv(e.initial_angular_velocity);
+        }
+        fw_spawner_desc desc{ps.data(), (uint32_t)ps.size(), es.data(), (uint32_t)es.size(), s.starts_enabled ? 1 : 0,
+                             uid == UINT32_MAX ? next_uid_ : uid};
+        next_uid_ = desc.uid + 1;
+        fw_spawner h = -1;
+        check(fw_spawner_create(ctx_, &desc, &h));
+        auto *d = new ParticleSpawnerData();
+        d->handle = h, d->sys = this, d->settings = s, d->transform = t;
+        spawners_.push_back(d);
+        return d;
+    }
+
+    // one run of the chained systems (plugin.rs:46-60)
+    void update(float dt) {
+        for (auto *d : spawners_) {
+            const Transform &t = (d->settings.spawn_transform_mode == SpawnTransformMode::Global && d->has_global)
+                                     ? d->global_transform : d->transform;  // core.rs:432-435
+            const float tr[3] = {t.translation.x, t.translation.y, t.translation.z};
+            const float ro[4] = {t.rotation.x, t.rotation.y, t.rotation.z, t.rotation.w};
+            check(fw_spawner_set_origin(ctx_, d->handle, tr, ro));
+        }
+        check(fw_step(ctx_, dt));
+        for (auto *d : spawners_) {
+            for (size_t i = 0; i < d->settings.particle_settings.size(); i++)
+                if (d->settings.particle_settings[i].particles_destroyed) {  // core.rs:660-667
+                    auto dead = d->destroyed((uint32_t)i);
+                    if (!dead.empty()) d->settings.particle_settings[i].particles_destroyed(dead);
+                }
+            if (d->on_finished) {
+                int32_t fin = 0;
+                check(fw_spawner_poll_finished(ctx_, d->handle, &fin));  // core.rs:674-688
+                if (fin) d->on_finished();
+            }
+        }
+    }
+    void step(float dt) { check(fw_step(ctx_, dt)); }  // enqueue only: no transforms, no callbacks
+    void synchronize() { check(fw_ctx_synchronize(ctx_)); }
+    uint64_t live_count() {
+        uint64_t n = 0;
+        check(fw_ctx_live_count(ctx_, &n));
+        return n;
+    }
+    uint64_t updated_total() {
+        uint64_t n = 0;
+        check(fw_ctx_last_step_updated(ctx_, &n));
+        return n;
+    }
+    fw_ctx *raw() { return ctx_; }
+    void check(fw_status st) const {
+        if (st != FW_OK) throw Error(st, fw_last_error(ctx_));
+    }
+    void check(int st) const { check((fw_status)st); }
+
+  private:
+    fw_ctx *ctx_ = nullptr;
+    std::vector<ParticleSpawnerData *> spawners_;
+    uint32_t next_uid_ = 0;
+};
+
+inline void ParticleSpawnerData::queue_particles(uint64_t n) { sys->check(fw_spawner_queue(sys->raw(), handle, n)); }
+inline bool ParticleSpawnerData::active() {
+    int32_t a = 0;
+    sys->check(fw_spawner_active(sys->raw(), handle, &a));
+    return a != 0;
+}
+inline std::vector<uint32_t> ParticleSpawnerData::counts() {
+    std::vector<uint32_t> c(settings.particle_settings.size());
+    sys->check(fw_spawner_counts(sys->raw(), handle, c.data(), (uint32_t)c.size()));
+    return c;
+}
+inline std::vector<fw_particle> ParticleSpawnerData::particles(uint32_t t) {
+    uint64_t n = 0;
+    sys->check(fw_spawner_read_particles(sys->raw(), handle, t, nullptr, 0, &n));
+    std::vector<fw_particle> v(n);
+    if (n) sys->check(fw_spawner_read_particles(sys->raw(), handle, t, v.data(), n, &n));
+    return v;
+}
+inline std::vector<fw_particle> ParticleSpawnerData::destroyed(uint32_t t) {
+    uint64_t n = 0;
+    sys->check(fw_spawner_read_destroyed(sys->raw(), handle, t, nullptr, 0, &n));
+    std::vector<fw_particle> v(n);
+    if (n) sys->check(fw_spawner_read_destroyed(sys->raw(), handle, t, v.data(), n, &n));
+    return v;
+}
+inline std::vector<fw_particle_instance> ParticleSpawnerData::instances(uint32_t t) {
+    uint64_t n = 0;
+    sys->check(fw_spawner_pack_instances(sys->raw(), handle, t, nullptr, 0, &n));
+    std::vector<fw_particle_instance> v(n);
+    if (n) sys->check(fw_spawner_pack_instances(sys->raw(), handle, t, v.data(), n, &n));
+    return v;
+}
+inline bool ParticleSpawnerData::aabb(Vec3 &mn, Vec3 &mx) {
+    float a[3], b[3];
+    int32_t any = 0;
+    sys->check(fw_spawner_aabb(sys->raw(), handle, a, b, &any));
+    mn = {a[0], a[1], a[2]}, mx = {b[0], b[1], b[2]};
+    return any != 0;
+}
+inline void ParticleSpawnerData::set_parent_velocity(Vec3 v) {
+    const float a[3] = {v.x, v.y, v.z};
+    sys->check(fw_spawner_set_parent_velocity(sys->raw(), handle, a));
+}
+inline void ParticleSpawnerData::set_modifier(EffectModifier m) {
+    sys->check(fw_spawner_set_modifier(sys->raw(), handle, m.scale, m.speed));
+}
+
+}  // namespace firework
