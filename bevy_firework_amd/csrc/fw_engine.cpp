@@ -279,6 +279,9 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_off, ncap * sizeof(uint32_t)));
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_status, ncap * sizeof(unsigned long long)));
         FW_HIP(ctx, hipMemset(ctx->g.tile_status, 0, ncap * sizeof(unsigned long long)));
+        if (ctx->g.dbg_ts) hipFree(ctx->g.dbg_ts);
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.dbg_ts, 4 * ncap * sizeof(unsigned long long)));
+        FW_HIP(ctx, hipMemset(ctx->g.dbg_ts, 0, 4 * ncap * sizeof(unsigned long long)));
         if (ctx->d_fc) hipFree(ctx->d_fc);
         FW_HIP(ctx, hipMalloc((void **)&ctx->d_fc, 2 * ncap * sizeof(uint4)));
         FW_HIP(ctx, hipMemset(ctx->d_fc, 0, 2 * ncap * sizeof(uint4)));
@@ -905,7 +908,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
                      ctx->g.ndestroyed,   ctx->g.tile_cnt,      ctx->g.tile_off,      ctx->g.tile_status,
                      ctx->g.err,          ctx->g.stats,         ctx->g.nest_tile_cnt, ctx->g.nest_tile_off,
                      ctx->g.nest_op_npar, ctx->g.nest_op_base,  ctx->g.nest_op_total, ctx->g.nest_op_serial,
-                     ctx->d_aabb,         ctx->d_total,         ctx->d_segids};
+                     ctx->d_aabb,         ctx->d_total,         ctx->d_segids,        ctx->g.dbg_ts};
     for (void *p : frees)
         if (p) hipFree(p);
     for (int i = 0; i < kParamRing; i++) {
@@ -1582,6 +1585,17 @@ fw_status fw_ctx_kernel_timing_read(fw_ctx *ctx, double *ms_total, uint64_t *lau
     unsigned long long now = 0;
     FW_HIP(ctx, hipMemcpy(&now, ctx->g.stats, sizeof now, hipMemcpyDeviceToHost));
     if (particles) *particles = now - ctx->timing_particles_start;
+    return FW_OK;
+}
+
+// profiling hook (not in the public header): per-tile timestamps of the last update when FW_DEBUG & 8
+fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_t max_tiles, uint64_t *n_tiles) {
+    if (!ctx || !ctx->g.dbg_ts) return FW_EINVAL;
+    fw_status st = sync(ctx);
+    if (st) return st;
+    const uint64_t n = std::min<uint64_t>(max_tiles, ctx->total_tiles_dev);
+    if (n_tiles) *n_tiles = n;
+    if (n && out) FW_HIP(ctx, hipMemcpy(out, ctx->g.dbg_ts, n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return FW_OK;
 }
 

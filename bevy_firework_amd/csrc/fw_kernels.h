@@ -22,6 +22,7 @@ struct FwGlobals {
     unsigned long long *tile_status; // fused mode: decoupled look-back words
     uint32_t *err;                   // sticky FW_ERR_* flags
     unsigned long long *stats;       // [0] particles that entered update (running total)
+    unsigned long long *dbg_ts;      // FW_DEBUG & 8: 4 timestamps per tile of the last update (profiling)
     unsigned long long *emit_serial; // RNG serials of Nested emission entries
     uint32_t *nest_tile_cnt;         // children per parent tile
     uint32_t *nest_tile_off;         // exclusive prefix of the above, per op

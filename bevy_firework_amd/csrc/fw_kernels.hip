@@ -59,6 +59,11 @@ __device__ __forceinline__ float4 fw_ld4(const char *plane, uint32_t i) {
     const fw_f4 v = reinterpret_cast<const FW_GLOBAL fw_f4 *>(reinterpret_cast<uintptr_t>(plane))[i];
     return make_float4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ float4 fw_ld4_nt(const char *plane, uint32_t i) {  // bypasses the CU's L1
+    const fw_f4 v = __builtin_nontemporal_load(
+        &reinterpret_cast<const FW_GLOBAL fw_f4 *>(reinterpret_cast<uintptr_t>(plane))[i]);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void fw_st4(char *plane, uint32_t i, float4 v) {
     const fw_f4 x = {v.x, v.y, v.z, v.w};
     reinterpret_cast<FW_GLOBAL fw_f4 *>(reinterpret_cast<uintptr_t>(plane))[i] = x;
@@ -338,8 +343,16 @@ __device__ __forceinline__ uint32_t fw_lookback(const unsigned long long *status
     return excl;
 }
 
-// R = particles per thread; the workgroup has FW_TILE / R threads, so a tile is always FW_TILE
-// particles.  R = 4 (256 threads) is the measured optimum on MI355X.
+// R = rounds per tile; the workgroup has FW_TILE / R threads, so a tile is always FW_TILE particles.
+// R = 4 (256 threads) is the measured optimum on MI355X.
+//
+// Register diet.  A frame at 1M particles is ~1k tiles; what bounds the kernel there is not bandwidth but
+// how many tiles are resident at once (tile lifetime x number of "rounds" of workgroups).  Holding a tile's
+// 64 B/particle of input in VGPRs for all four rounds costs 165 VGPRs = 3 workgroups per CU = 768 slots, i.e.
+// two rounds.  So the survival planes (Q0: position+age, Q3: angular velocity+lifetime) are loaded once,
+// used for the survivor count, and parked in LDS (32 KiB per workgroup); the rounds then run as a rolled
+// loop that re-derives each lane's flags from LDS and prefetches Q1/Q2 one round ahead.  That is ~90 VGPRs:
+// four workgroups per CU (LDS-limited), 1024 slots, one round.
 //
 // Where a tile's output offset (exclusive survivor prefix) comes from:
 //   * FORECAST (a.fc_in != null): the previous frame's kernel already evaluated, for every survivor it
@@ -354,12 +367,15 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     constexpr int BLK = FW_TILE / R;
     constexpr int NW = BLK / 64;
     constexpr int LBW = 4;  // status words per lane per look-back step
+    __shared__ __attribute__((aligned(16))) float4 s_q0[FW_TILE];  // Q0 / Q3 of the tile (virtual particles included)
+    __shared__ __attribute__((aligned(16))) float4 s_q3[FW_TILE];
     __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
     __shared__ uint32_t s_wcnt[R][NW];
     __shared__ uint32_t s_lb[2 * LBW * NW];
     __shared__ uint32_t s_part[4][NW];  // per-wave partials: forecast prefix, new survivors, next-frame sums A / B
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned long long ts0 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // workgroup -> (segment, tile in segment): one table read instead of a dependent binary search
     uint32_t seg, first, seg_tiles;
     if (a.tile_desc) {
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     const uint32_t n_tot = n_in + n_spawn;
     const uint32_t t_spawn = n_in / FW_TILE;  // first tile that holds a new particle (if any)
     if (SPAWN != FW_SPAWN_NONE) {
-        // Tiles that hold new particles do ~1k VALU instructions per particle before they can publish their
+        // Tiles that hold new particles do ~3k VALU instructions per particle before they can publish their
         // survivor count.  They are the LAST tiles of the segment; give them the FIRST workgroups so that this
         // compute overlaps the streaming of everybody else instead of forming the kernel's tail.  At most 64
         // tiles are front-loaded (they wait for all earlier tiles while holding a slot), so the rest of the
@@ -424,30 +440,37 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;  // diagnostics
     }
 
-    // field-wise reads (block-uniform -> scalar loads); a by-value FwSeg indexed by `p` would be
-    // demoted to an LDS-backed private array
+    // field-wise reads (block-uniform -> scalar loads)
     const FwSeg *Sp = &g.segs[seg];
     const uint32_t C = Sp->capacity;
     const uint32_t n_lplanes = Sp->n_lplanes;
-    const char *ib = Sp->buf[p];
+    char *ib = Sp->buf[p];  // written only at the slots of this frame's new particles
     char *ob = Sp->buf[p ^ 1u];
     char *destroyed = Sp->destroyed;
 
-    // ---- phase 1: particle loads go out first; the planes that decide survival are Q0 (age in .w) and
-    // Q3 (lifetime in .w)
-    float4 q0[R], q1[R], q2[R], q3[R];
-    float age_new[R];
-    bool valid[R], alive[R], loaded[R];
-    uint32_t lpre[R];
+    // ---- phase 1: the planes that decide survival: Q0 (age in .w) and Q3 (lifetime in .w); all R loads of
+    // both planes are in flight together, then parked in LDS
+    {
+        float4 t0[R], t3[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        const uint32_t idx = base + r * BLK + tid;
-        valid[r] = idx < n_tot;
-        loaded[r] = idx < n_in;
-        if (loaded[r]) {
-            q0[r] = fw_ld4(ib + FW_OFF_Q0(C), idx);
-            q3[r] = fw_ld4(ib + FW_OFF_Q3(C), idx);
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = base + r * BLK + tid;
+            if (idx < n_in) {
+                t0[r] = fw_ld4(ib + FW_OFF_Q0(C), idx);
+                t3[r] = fw_ld4(ib + FW_OFF_Q3(C), idx);
+            }
         }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = base + r * BLK + tid;
+            if (idx < n_in) s_q0[r * BLK + tid] = t0[r], s_q3[r * BLK + tid] = t3[r];
+        }
+    }
+    // first round's Q1 / Q2 go out now; later rounds are prefetched one round ahead
+    float4 q1c = make_float4(0.f, 0.f, 0.f, 0.f), q2c = q1c;
+    if (base + tid < n_in) {
+        q1c = fw_ld4(ib + FW_OFF_Q1(C), base + tid);
+        q2c = fw_ld4(ib + FW_OFF_Q2(C), base + tid);
     }
 
     // per-type constants (scalar loads) and curve / gradient keys (staged in LDS) arrive under the loads
@@ -468,8 +491,9 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
 
     const bool has_new = SPAWN != FW_SPAWN_NONE && base + FW_TILE > n_in;  // block-uniform
     if (has_new) {
-        // One rolled instance of the spawn code (it is large: 3 Philox blocks + trig); the results are
-        // steered into the register arrays with static indices so they stay in VGPRs.
+        // New particles (src/core.rs:437-469) are materialised at their slot of the INPUT buffer -- free space
+        // behind the live ones; the host guarantees count + spawns <= capacity -- and in the LDS planes, after
+        // which they are ordinary inputs of this tile.  One rolled instance of the (large) spawn code.
 #pragma unroll 1
         for (int r = 0; r < R; r++) {
             const uint32_t idx = base + r * BLK + tid;
@@ -484,46 +508,38 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
                     fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
                     fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
                     fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
-#pragma unroll
-                for (int rr = 0; rr < R; rr++)
-                    if (rr == r) q0[rr] = so.q0, q1[rr] = so.q1, q2[rr] = so.q2, q3[rr] = so.q3;
+                s_q0[r * BLK + tid] = so.q0, s_q3[r * BLK + tid] = so.q3;
+                fw_st4(ib + FW_OFF_Q1(C), idx, so.q1);
+                fw_st4(ib + FW_OFF_Q2(C), idx, so.q2);
+                if (r == 0) q1c = so.q1, q2c = so.q2;
             }
         }
+        __builtin_amdgcn_s_waitcnt(0);  // the same lane reloads its own Q1/Q2 slots in the round loop
     }
+
+    // survivor count of the tile: each lane re-reads what it parked (same lane, no barrier needed yet)
     uint32_t new_alive = 0;  // survivors among this tile's new particles (wave-uniform partial)
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        alive[r] = valid[r] && fw_survives(q0[r].w, a.dt, q3[r].w, &age_new[r]);
-        const unsigned long long m = __ballot(alive[r]);
-        lpre[r] = fw_lane_prefix(m);
+        const uint32_t idx = base + r * BLK + tid;
+        float an;
+        const bool al = idx < n_tot && fw_survives(s_q0[r * BLK + tid].w, a.dt, s_q3[r * BLK + tid].w, &an);
+        const unsigned long long m = __ballot(al);
         if (lane == 0) s_wcnt[r][wave] = (uint32_t)__popcll(m);
-        if (has_new) new_alive += (uint32_t)__popcll(__ballot(alive[r] && !loaded[r]));
+        if (has_new) new_alive += (uint32_t)__popcll(__ballot(al && idx >= n_in));
     }
     if (use_fc) {
         fc_part = fw_wave_sum(fc_part);
         if (lane == 0) s_part[0][wave] = fc_part, s_part[1][wave] = new_alive;
         if (__any(fc_bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST);
     }
-
-    // the remaining two input planes
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const uint32_t idx = base + r * BLK + tid;
-        if (loaded[r]) {
-            q1[r] = fw_ld4(ib + FW_OFF_Q1(C), idx);
-            q2[r] = fw_ld4(ib + FW_OFF_Q2(C), idx);
-        }
-    }
     __syncthreads();
-    uint32_t rank[R];
+    const unsigned long long ts1 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t cnt = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            if ((uint32_t)w == wave) rank[r] = cnt + lpre[r];
-            cnt += s_wcnt[r][w];
-        }
+        for (int w = 0; w < NW; w++) cnt += s_wcnt[r][w];
     }
     uint32_t fc_excl = 0, new_cnt = 0;
     if (use_fc) {
@@ -584,34 +600,58 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         excl = g.tile_off[tile];
     }
 
-    // ---- phase 3: integrate survivors, store them at their compacted slot
+    const unsigned long long ts2 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    // ---- phase 3: round loop -- integrate survivors, store them at their compacted slot
     const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
     const uint32_t fcA = excl / FW_TILE, fc_bnd = (fcA + 1u) * FW_TILE;  // output tiles this workgroup feeds
     uint32_t fa = 0, fb = 0;
-#pragma unroll
+    uint32_t run = excl;  // output slot of the first survivor of (round r, wave 0)
+#pragma unroll 1
     for (int r = 0; r < R; r++) {
         const uint32_t idx = base + r * BLK + tid;
-        const uint32_t o = excl + rank[r];
+        // prefetch the next round's Q1 / Q2 (new particles were materialised above, so idx < n_tot is enough)
+        float4 q1n = make_float4(0.f, 0.f, 0.f, 0.f), q2n = q1n;
+        if (r + 1 < R && idx + BLK < n_in) {
+            q1n = fw_ld4(ib + FW_OFF_Q1(C), idx + BLK);
+            q2n = fw_ld4(ib + FW_OFF_Q2(C), idx + BLK);
+        } else if (SPAWN != FW_SPAWN_NONE && r + 1 < R && idx + BLK < n_tot) {
+            // a slot this lane materialised a moment ago: read it back from L2 (a neighbour's earlier load may
+            // have left the stale line in this CU's L1)
+            q1n = fw_ld4_nt(ib + FW_OFF_Q1(C), idx + BLK);
+            q2n = fw_ld4_nt(ib + FW_OFF_Q2(C), idx + BLK);
+        }
+        const bool valid = idx < n_tot, loaded = idx < n_in;
+        const float4 q0 = s_q0[r * BLK + tid], q3 = s_q3[r * BLK + tid];
+        float age_new;
+        const bool alive = valid && fw_survives(q0.w, a.dt, q3.w, &age_new);
+        const unsigned long long m = __ballot(alive);
+        uint32_t wbase = run;  // + survivors of the earlier waves of this round
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t c = s_wcnt[r][w];
+            if ((uint32_t)w < wave) wbase += c;
+            run += c;
+        }
+        const uint32_t o = wbase + fw_lane_prefix(m);
         if (fc_out) {  // will it survive one more step of the same dt?  (same expression as fw_survives)
             float an2;
-            const bool nx = alive[r] && fw_survives(age_new[r], a.dt, q3[r].w, &an2);
+            const bool nx = alive && fw_survives(age_new, a.dt, q3.w, &an2);
             fa += (uint32_t)__popcll(__ballot(nx && o < fc_bnd));
             fb += (uint32_t)__popcll(__ballot(nx && o >= fc_bnd));
         }
-        if (alive[r] && (a.dbg & 2u)) {  // profiling only: stream without arithmetic
-            q0[r].w = age_new[r];
-            fw_st4(ob + FW_OFF_Q0(C), o, q0[r]), fw_st4(ob + FW_OFF_Q1(C), o, q1[r]);
-            fw_st4(ob + FW_OFF_Q2(C), o, q2[r]), fw_st4(ob + FW_OFF_Q3(C), o, q3[r]);
-            fw_st4(ob + FW_OFF_Q5(C), o, q0[r]), fw_st4(ob + FW_OFF_Q6(C), o, q1[r]);
-            fw_st1(ob + FW_OFF_S4(C), o, q1[r].w);
-        } else if (alive[r]) {
-            fw_integrate_store(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], ob, C, o);
+        if (alive && (a.dbg & 2u)) {  // profiling only: stream without arithmetic
+            fw_st4(ob + FW_OFF_Q0(C), o, make_float4(q0.x, q0.y, q0.z, age_new)), fw_st4(ob + FW_OFF_Q1(C), o, q1c);
+            fw_st4(ob + FW_OFF_Q2(C), o, q2c), fw_st4(ob + FW_OFF_Q3(C), o, q3);
+            fw_st4(ob + FW_OFF_Q5(C), o, q0), fw_st4(ob + FW_OFF_Q6(C), o, q1c);
+            fw_st1(ob + FW_OFF_S4(C), o, q1c.w);
+        } else if (alive) {
+            fw_integrate_store(T, s_keys, a.dt, q0, q1c, q2c, q3, age_new, ob, C, o);
             for (uint32_t k = 0; k < n_lplanes; k++)  // new particles: vec![f32::MIN; n] (core.rs:467)
-                fw_st1(ob + FW_OFF_L(C, k), o, loaded[r] ? fw_ld1(ib + FW_OFF_L(C, k), idx) : FW_F32_MIN);
-        } else if (valid[r] && want_destroyed) {
-            fw_store_destroyed(destroyed, ib, C, idx, loaded[r], T, s_keys, q0[r], q1[r], q2[r], q3[r], age_new[r],
-                               idx - o);
+                fw_st1(ob + FW_OFF_L(C, k), o, loaded ? fw_ld1(ib + FW_OFF_L(C, k), idx) : FW_F32_MIN);
+        } else if (valid && want_destroyed) {
+            fw_store_destroyed(destroyed, ib, C, idx, loaded, T, s_keys, q0, q1c, q2c, q3, age_new, idx - o);
         }
+        q1c = q1n, q2c = q2n;
     }
     if (fc_out) {
         if (lane == 0) s_part[2][wave] = fa, s_part[3][wave] = fb;
@@ -624,6 +664,10 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         }
     }
 
+    if ((a.dbg & 8u) && g.dbg_ts && tid == 0) {
+        unsigned long long *d = g.dbg_ts + (size_t)tile * 4;
+        d[0] = ts0, d[1] = ts1, d[2] = ts2, d[3] = __builtin_amdgcn_s_memrealtime();
+    }
     if (is_last && tid == 0) {
         const uint32_t nc = excl + cnt;
         g.count[oidx] = nc;
