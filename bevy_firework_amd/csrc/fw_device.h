@@ -30,6 +30,8 @@
 #define FW_BLOCK 256          // threads per workgroup = 4 wave64
 #define FW_ROUNDS 4           // particles per thread per tile
 #define FW_TILE (FW_BLOCK * FW_ROUNDS)
+#define FW_VTILE FW_BLOCK     // tile size of the new-particle region (fw_k_update)
+#define FW_VFRONT 256u        // at most this many new-particle tiles are dispatched first
 #define FW_KEYS_MAX 400       // floats of curve keys staged in LDS per type
 #define FW_DEV_MAX_EMISSIONS 8
 

@@ -143,6 +143,7 @@ struct fw_ctx {
     hipEvent_t ev_tab[kTabRing] = {};
     bool tab_pending[kTabRing] = {};
     uint64_t tab_seq = 0, ring_seq = 0;
+    bool tab_force = false;  // a segment was (re)built: re-send the descriptors even if the tile counts are equal
 
     // survivor forecast tables (fw_k_update): [2][tiles_cap]
     uint4 *d_fc = nullptr;
@@ -251,17 +252,19 @@ fw_status ensure_max_seg(fw_ctx *ctx, uint32_t need) {
     return FW_OK;
 }
 
+// tiles the update grid must cover for a segment: the live region in tiles of FW_TILE, plus this frame's new
+// particles in tiles of FW_VTILE (fw_k_update's tiling of the index space)
 uint32_t seg_tiles(const SegHost &s) {
     if (!s.in_use) return 0;
-    uint32_t ub = s.nested_fed ? s.capacity : std::min(s.ub, s.capacity);
-    return std::max<uint32_t>(1, (ub + FW_TILE - 1) / FW_TILE);
+    const uint32_t live_ub = s.nested_fed ? s.capacity : std::min(s.ub - std::min(s.ub, s.frame_spawn), s.capacity);
+    return std::max<uint32_t>(1, (live_ub + FW_TILE - 1) / FW_TILE + (s.frame_spawn + FW_VTILE - 1) / FW_VTILE + 1);
 }
 
 // tile scratch sized for every segment at full capacity
 fw_status ensure_tile_arrays(fw_ctx *ctx) {
     size_t tiles = 0, nest_tiles = 0, nest_ops = 0;
     for (auto &s : ctx->segs)
-        if (s.in_use) tiles += (s.capacity + FW_TILE - 1) / FW_TILE + 1;
+        if (s.in_use) tiles += (s.capacity + FW_VTILE - 1) / FW_VTILE + 2;  // worst case: every slot a new particle
     for (auto &sp : ctx->spawners) {
         if (!sp.alive) continue;
         for (auto &e : sp.em)
@@ -280,8 +283,8 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_status, ncap * sizeof(unsigned long long)));
         FW_HIP(ctx, hipMemset(ctx->g.tile_status, 0, ncap * sizeof(unsigned long long)));
         if (ctx->g.dbg_ts) hipFree(ctx->g.dbg_ts);
-        FW_HIP(ctx, hipMalloc((void **)&ctx->g.dbg_ts, 4 * ncap * sizeof(unsigned long long)));
-        FW_HIP(ctx, hipMemset(ctx->g.dbg_ts, 0, 4 * ncap * sizeof(unsigned long long)));
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.dbg_ts, 8 * ncap * sizeof(unsigned long long)));
+        FW_HIP(ctx, hipMemset(ctx->g.dbg_ts, 0, 8 * ncap * sizeof(unsigned long long)));
         if (ctx->d_fc) hipFree(ctx->d_fc);
         FW_HIP(ctx, hipMalloc((void **)&ctx->d_fc, 2 * ncap * sizeof(uint4)));
         FW_HIP(ctx, hipMemset(ctx->d_fc, 0, 2 * ncap * sizeof(uint4)));
@@ -528,6 +531,7 @@ uint32_t pad4(uint32_t n) { return (n + 3u) & ~3u; }
 fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std::vector<uint64_t> *carry_serial) {
     SpawnerHost &sp = ctx->spawners[h];
     ctx->fc_ok = false;
+    ctx->tab_force = true;
     const uint32_t nt = d->n_particle_settings, ne = d->n_emission_settings;
     sp.uid = d->uid;
     sp.starts_enabled = d->starts_enabled;
@@ -662,6 +666,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
 
 fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
     ctx->fc_ok = false;
+    ctx->tab_force = true;
     for (uint32_t si : sp.seg) {
         SegHost &S = ctx->segs[si];
         if (!S.in_use) continue;
@@ -681,7 +686,8 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
 // need leaves the band [need, need * 5/4 + 8], so steady-state frames upload nothing.
 fw_status update_tile_table(fw_ctx *ctx) {
     const uint32_t n_seg = (uint32_t)ctx->segs.size();
-    bool dirty = ctx->tiles_dev.size() != n_seg;
+    bool dirty = ctx->tiles_dev.size() != n_seg || ctx->tab_force;  // descriptors carry per-segment type indices
+    ctx->tab_force = false;
     ctx->tiles_dev.resize(n_seg, 0);
     for (uint32_t i = 0; i < n_seg; i++) {
         const SegHost &S = ctx->segs[i];
@@ -691,7 +697,8 @@ fw_status update_tile_table(fw_ctx *ctx) {
             if (have) have = 0, dirty = true;
             continue;
         }
-        const uint32_t cap_tiles = std::max<uint32_t>(1, (S.capacity + FW_TILE - 1) / FW_TILE);
+        const uint32_t cap_tiles =
+            (S.capacity + FW_TILE - 1) / FW_TILE + (S.frame_spawn + FW_VTILE - 1) / FW_VTILE + 1;
         if (need > have || have > need + need / 4 + 8 || have > cap_tiles) {
             have = std::min(cap_tiles, need + std::max<uint32_t>(2, need / 8));
             dirty = true;
@@ -745,7 +752,8 @@ fw_status update_tile_table(fw_ctx *ctx) {
     ctx->total_tiles_dev = total;
     uint4 *hd = ctx->h_desc[slot];
     for (uint32_t i = 0; i < n_seg; i++)
-        for (uint32_t t = 0; t < ctx->tiles_dev[i]; t++) hd[h[i] + t] = make_uint4(i, h[i], ctx->tiles_dev[i], 0u);
+        for (uint32_t t = 0; t < ctx->tiles_dev[i]; t++)
+            hd[h[i] + t] = make_uint4(i, h[i], ctx->tiles_dev[i], ctx->segs[i].type_idx);
     FW_HIP(ctx, hipMemcpyAsync(ctx->d_tile_first, h, (size_t)(n_seg + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
                                ctx->stream));
     if (total)
@@ -1595,7 +1603,7 @@ fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_
     if (st) return st;
     const uint64_t n = std::min<uint64_t>(max_tiles, ctx->total_tiles_dev);
     if (n_tiles) *n_tiles = n;
-    if (n && out) FW_HIP(ctx, hipMemcpy(out, ctx->g.dbg_ts, n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (n && out) FW_HIP(ctx, hipMemcpy(out, ctx->g.dbg_ts, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return FW_OK;
 }
 

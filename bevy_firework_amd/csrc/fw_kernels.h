@@ -34,7 +34,7 @@ struct FwGlobals {
 
 struct FwUpdateArgs {
     const uint32_t *seg_tile_first;  // [n_seg + 1] first tile of each segment (device)
-    const uint4 *tile_desc;          // [total_tiles] {segment, its first tile, its tile count, 0} (device)
+    const uint4 *tile_desc;          // [total_tiles] {segment, its first tile, its tile count, type index} (device)
     uint32_t n_seg;
     uint32_t total_tiles;
     uint32_t parity;       // read buf[parity], write buf[parity ^ 1]

@@ -100,8 +100,10 @@ __device__ __forceinline__ fw_v3 fw_randvec3(float mag_min, float mag_max, float
     if (spread > 0.0f) {  // cone of half-angle `spread` around `direction` (bevy_utilitarian RandVec3)
         float spread_angle = u_angle * 2.0f * FW_PI;
         float spread_radius = u_radius * spread;
-        float sr = sinf(spread_radius), cr = cosf(spread_radius);
-        fw_v3 local{sr * cosf(spread_angle), cr, sr * sinf(spread_angle)};
+        float sr, cr, sa, ca;
+        sincosf(spread_radius, &sr, &cr);
+        sincosf(spread_angle, &sa, &ca);
+        fw_v3 local{sr * ca, cr, sr * sa};
         d = fw_quat_mul_vec3(fw_q4{arc[0], arc[1], arc[2], arc[3]}, local);
     } else {
         d = fw_v3{dir[0], dir[1], dir[2]};
@@ -126,13 +128,16 @@ __device__ __forceinline__ FwSpawnOut fw_spawn_one(const FwEmit &e, uint32_t see
     fw_v3 off{0.0f, 0.0f, 0.0f};
     if (e.shape_kind == 1) {
         float pitch = u[0] * 2.0f * FW_PI, yaw = u[1] * FW_PI, r = u[2];
-        float cp = cosf(pitch), sp = sinf(pitch);
-        fw_v3 unit{cp * sinf(yaw), sp, cp * cosf(yaw)};
+        float sp, cp, sy, cy;
+        sincosf(pitch, &sp, &cp);
+        sincosf(yaw, &sy, &cy);
+        fw_v3 unit{cp * sy, sp, cp * cy};
         off = fw_v3{unit.x * r * e.shape_radius, unit.y * r * e.shape_radius, unit.z * r * e.shape_radius};
     } else if (e.shape_kind == 2) {
         float ang = u[0] * 2.0f * FW_PI, r = u[1];
-        float h = ang * 0.5f;
-        fw_q4 q2{0.0f, sinf(h), 0.0f, cosf(h)};  // Quat::from_rotation_y
+        float h = ang * 0.5f, sh, ch;
+        sincosf(h, &sh, &ch);
+        fw_q4 q2{0.0f, sh, 0.0f, ch};  // Quat::from_rotation_y
         fw_q4 q = fw_quat_mul(fw_q4{e.shape_arc[0], e.shape_arc[1], e.shape_arc[2], e.shape_arc[3]}, q2);
         off = fw_quat_mul_vec3(q, fw_v3{r * e.shape_radius, 0.0f, 0.0f});
     }
@@ -377,16 +382,29 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned long long ts0 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // workgroup -> (segment, tile in segment): one table read instead of a dependent binary search
-    uint32_t seg, first, seg_tiles;
+    uint32_t seg, first, seg_tiles, type_idx;
     if (a.tile_desc) {
         const uint4 d = a.tile_desc[blockIdx.x];
-        seg = d.x, first = d.y, seg_tiles = d.z;
+        seg = d.x, first = d.y, seg_tiles = d.z, type_idx = d.w;
     } else {
         seg = fw_upper_slot(a.seg_tile_first, a.n_seg, blockIdx.x);
         first = a.seg_tile_first[seg];
         seg_tiles = a.seg_tile_first[seg + 1] - first;
+        type_idx = g.segs[seg].type_idx;
     }
     uint32_t tis = blockIdx.x - first;
+    // Forecast entries of the whole segment: requested now (they depend on the descriptor only), consumed
+    // after the particle loads -- up to FC_U entries per lane in flight, the rest (huge segments) in a loop.
+    constexpr int FC_U = 8;
+    const bool use_fc = FUSED && a.fc_in != nullptr && seg_tiles <= FW_FC_MAX_TILES;
+    uint4 fce[FC_U];
+    if (use_fc) {
+#pragma unroll
+        for (int j = 0; j < FC_U; j++) {
+            const uint32_t t = tid + (uint32_t)j * BLK;
+            fce[j] = t < seg_tiles ? a.fc_in[first + t] : make_uint4(0u, 0u, 0u, a.epoch - 1u);
+        }
+    }
     const uint32_t p = a.parity;
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
     const uint32_t n_in = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
@@ -404,24 +422,25 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         for (uint32_t i = o0; i < o1; i++) n_spawn += a.ops[i].n;
     }
     const uint32_t n_tot = n_in + n_spawn;
-    const uint32_t t_spawn = n_in / FW_TILE;  // first tile that holds a new particle (if any)
-    if (SPAWN != FW_SPAWN_NONE) {
-        // Tiles that hold new particles do ~3k VALU instructions per particle before they can publish their
-        // survivor count.  They are the LAST tiles of the segment; give them the FIRST workgroups so that this
-        // compute overlaps the streaming of everybody else instead of forming the kernel's tail.  At most 64
-        // tiles are front-loaded (they wait for all earlier tiles while holding a slot), so the rest of the
-        // grid -- still dispatched in tile order -- always makes progress.
-        if (n_spawn != 0) {
-            const uint32_t t_last = (n_tot - 1u) / FW_TILE;
-            const uint32_t S = t_last - t_spawn + 1u;
-            if (S <= 64u && t_spawn != 0 && tis <= t_last) tis = tis < S ? t_spawn + tis : tis - S;
-        }
-    }
+    // Tiling of the index space [0, n_tot): the live particles [0, n_in) in tiles of FW_TILE, then the new
+    // ones [n_in, n_tot) in SMALL tiles of FW_VTILE (one round).  A new particle costs ~1-3k VALU instructions
+    // before its tile can even count survivors; small tiles spread that over 4x more workgroups, and those
+    // workgroups are dispatched FIRST (they are the last tiles) so the compute overlaps everybody else's
+    // streaming instead of forming the kernel's tail.  At most FW_VFRONT tiles are front-loaded: they wait for
+    // all earlier tiles while holding a slot, and the rest of the grid, still dispatched in tile order,
+    // always makes progress.
+    const uint32_t t_spawn = (n_in + FW_TILE - 1u) / FW_TILE;  // number of live tiles = first new-particle tile
+    const uint32_t n_vt = (n_spawn + FW_VTILE - 1u) / FW_VTILE;
+    const uint32_t n_act = t_spawn + n_vt;                      // active tiles of this segment
+    if (SPAWN != FW_SPAWN_NONE && n_vt != 0 && n_vt <= FW_VFRONT && t_spawn != 0 && tis < n_act)
+        tis = tis < n_vt ? t_spawn + tis : tis - n_vt;
     const uint32_t tile = first + tis;
-    const uint32_t base = tis * FW_TILE;
+    const bool has_new = tis >= t_spawn;  // block-uniform: a tile is either all live or all new
+    const uint32_t base = has_new ? n_in + (tis - t_spawn) * FW_VTILE : tis * FW_TILE;
+    const uint32_t lim = has_new ? min(base + FW_VTILE, n_tot) : min(base + FW_TILE, n_in);
     uint4 *fc_out = FUSED ? a.fc_out : nullptr;
 
-    if (n_tot == 0 || base >= n_tot) {
+    if (n_tot == 0 || tis >= n_act) {
         if (tid == 0) {
             if (fc_out) fc_out[tile] = make_uint4(0u, 0u, 0u, a.epoch);  // contributes nothing next frame
             if (n_tot == 0 && tis == 0) {  // empty segment: its first tile still owns the bookkeeping
@@ -434,8 +453,8 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         }
         return;
     }
-    const bool is_last = ((n_tot - 1u) / FW_TILE) == tis;
-    if (tis == 0 && tid == 0 && n_tot > seg_tiles * FW_TILE) {
+    const bool is_last = tis + 1u == n_act;
+    if (tis == 0 && tid == 0 && n_act > seg_tiles) {
         atomicOr(g.err, FW_ERR_CAPACITY);
         g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;  // diagnostics
     }
@@ -448,6 +467,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     char *ob = Sp->buf[p ^ 1u];
     char *destroyed = Sp->destroyed;
 
+    const unsigned long long tsA = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (C & 0u)) : 0ull;
     // ---- phase 1: the planes that decide survival: Q0 (age in .w) and Q3 (lifetime in .w); all R loads of
     // both planes are in flight together, then parked in LDS
     {
@@ -455,7 +475,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t idx = base + r * BLK + tid;
-            if (idx < n_in) {
+            if (!has_new && idx < lim) {
                 t0[r] = fw_ld4(ib + FW_OFF_Q0(C), idx);
                 t3[r] = fw_ld4(ib + FW_OFF_Q3(C), idx);
             }
@@ -463,58 +483,59 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t idx = base + r * BLK + tid;
-            if (idx < n_in) s_q0[r * BLK + tid] = t0[r], s_q3[r * BLK + tid] = t3[r];
+            if (!has_new && idx < lim) s_q0[r * BLK + tid] = t0[r], s_q3[r * BLK + tid] = t3[r];
         }
     }
+    const unsigned long long tsB = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // first round's Q1 / Q2 go out now; later rounds are prefetched one round ahead
     float4 q1c = make_float4(0.f, 0.f, 0.f, 0.f), q2c = q1c;
-    if (base + tid < n_in) {
+    if (!has_new && base + tid < lim) {
         q1c = fw_ld4(ib + FW_OFF_Q1(C), base + tid);
         q2c = fw_ld4(ib + FW_OFF_Q2(C), base + tid);
     }
 
     // per-type constants (scalar loads) and curve / gradient keys (staged in LDS) arrive under the loads
-    const FwType T = g.types[Sp->type_idx];
+    const FwType T = g.types[type_idx];
     for (uint32_t i = tid; i < T.keys_len; i += BLK) s_keys[i] = g.keys[T.keys_off + i];
 
-    // ---- forecast prefix: entry t of the table = {survivors landing in output tile A, in A+1, A, tag}
-    const bool use_fc = FUSED && a.fc_in != nullptr && seg_tiles <= FW_FC_MAX_TILES;
+    // ---- forecast prefix: entry t of the table = {survivors landing in output tile A, in A+1, A, tag}.
+    // (`tis` here is the remapped tile index; the loads above used only the descriptor.)
     uint32_t fc_part = 0;
     bool fc_bad = false;
     if (use_fc) {
-        for (uint32_t t = tid; t < seg_tiles; t += BLK) {
+#pragma unroll
+        for (int j = 0; j < FC_U; j++) {
+            const uint4 e = fce[j];
+            fc_bad |= e.w != a.epoch - 1u;
+            fc_part += (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u));
+        }
+        for (uint32_t t = tid + FC_U * BLK; t < seg_tiles; t += BLK) {
             const uint4 e = a.fc_in[first + t];
             fc_bad |= e.w != a.epoch - 1u;
             fc_part += (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u));
         }
     }
 
-    const bool has_new = SPAWN != FW_SPAWN_NONE && base + FW_TILE > n_in;  // block-uniform
-    if (has_new) {
-        // New particles (src/core.rs:437-469) are materialised at their slot of the INPUT buffer -- free space
-        // behind the live ones; the host guarantees count + spawns <= capacity -- and in the LDS planes, after
-        // which they are ordinary inputs of this tile.  One rolled instance of the (large) spawn code.
-#pragma unroll 1
-        for (int r = 0; r < R; r++) {
-            const uint32_t idx = base + r * BLK + tid;
-            if (idx < n_tot && idx >= n_in) {
-                const uint32_t k = idx - n_in;
-                uint32_t oi = o0;
-                for (uint32_t i = o0; i < o1; i++)
-                    if (k >= FW_OP(i).rel_base && k - FW_OP(i).rel_base < FW_OP(i).n) oi = i;
-                const FwOp &op = FW_OP(oi);
-                const FwSpawnOut so = fw_spawn_one(
-                    g.emits[op.emit], g.seed, op.serial_base + (k - op.rel_base),
-                    fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
-                    fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
-                    fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
-                s_q0[r * BLK + tid] = so.q0, s_q3[r * BLK + tid] = so.q3;
-                fw_st4(ib + FW_OFF_Q1(C), idx, so.q1);
-                fw_st4(ib + FW_OFF_Q2(C), idx, so.q2);
-                if (r == 0) q1c = so.q1, q2c = so.q2;
-            }
+    const unsigned long long tsC = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (fc_part & 0u)) : 0ull;
+    if (SPAWN != FW_SPAWN_NONE && has_new) {
+        // New particles (src/core.rs:437-469): a new-particle tile is FW_VTILE = BLK particles, one per lane,
+        // generated in registers from the counter RNG and then treated like loaded ones (spawn runs before
+        // update in the same frame, src/plugin.rs:46-60).
+        const uint32_t idx = base + tid;
+        if (idx < lim) {
+            const uint32_t k = idx - n_in;
+            uint32_t oi = o0;
+            for (uint32_t i = o0; i < o1; i++)
+                if (k >= FW_OP(i).rel_base && k - FW_OP(i).rel_base < FW_OP(i).n) oi = i;
+            const FwOp &op = FW_OP(oi);
+            const FwSpawnOut so = fw_spawn_one(
+                g.emits[op.emit], g.seed, op.serial_base + (k - op.rel_base),
+                fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
+                fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
+                fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
+            s_q0[tid] = so.q0, s_q3[tid] = so.q3;
+            q1c = so.q1, q2c = so.q2;
         }
-        __builtin_amdgcn_s_waitcnt(0);  // the same lane reloads its own Q1/Q2 slots in the round loop
     }
 
     // survivor count of the tile: each lane re-reads what it parked (same lane, no barrier needed yet)
@@ -523,10 +544,10 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     for (int r = 0; r < R; r++) {
         const uint32_t idx = base + r * BLK + tid;
         float an;
-        const bool al = idx < n_tot && fw_survives(s_q0[r * BLK + tid].w, a.dt, s_q3[r * BLK + tid].w, &an);
+        const bool al = idx < lim && fw_survives(s_q0[r * BLK + tid].w, a.dt, s_q3[r * BLK + tid].w, &an);
         const unsigned long long m = __ballot(al);
         if (lane == 0) s_wcnt[r][wave] = (uint32_t)__popcll(m);
-        if (has_new) new_alive += (uint32_t)__popcll(__ballot(al && idx >= n_in));
+        if (has_new) new_alive += (uint32_t)__popcll(m);
     }
     if (use_fc) {
         fc_part = fw_wave_sum(fc_part);
@@ -566,7 +587,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
                 // the earlier particles of this segment (forecast mode: of the earlier NEW particles only).
                 if (tid == 0) atomicOr(g.err, FW_ERR_LOOKBACK_TIMEOUT);
                 uint32_t c = 0;
-                for (uint32_t i = (use_fc ? n_in : 0u) + tid; i < base; i += BLK) {
+                for (uint32_t i = (use_fc ? n_in : 0u) + tid; i < base; i += BLK) {  // base is a particle index
                     float an, ag = 0.0f, lf;
                     if (i < n_in) {
                         ag = fw_ld4(ib + FW_OFF_Q0(C), i).w, lf = fw_ld4(ib + FW_OFF_Q3(C), i).w;
@@ -611,16 +632,11 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         const uint32_t idx = base + r * BLK + tid;
         // prefetch the next round's Q1 / Q2 (new particles were materialised above, so idx < n_tot is enough)
         float4 q1n = make_float4(0.f, 0.f, 0.f, 0.f), q2n = q1n;
-        if (r + 1 < R && idx + BLK < n_in) {
+        if (r + 1 < R && !has_new && idx + BLK < lim) {
             q1n = fw_ld4(ib + FW_OFF_Q1(C), idx + BLK);
             q2n = fw_ld4(ib + FW_OFF_Q2(C), idx + BLK);
-        } else if (SPAWN != FW_SPAWN_NONE && r + 1 < R && idx + BLK < n_tot) {
-            // a slot this lane materialised a moment ago: read it back from L2 (a neighbour's earlier load may
-            // have left the stale line in this CU's L1)
-            q1n = fw_ld4_nt(ib + FW_OFF_Q1(C), idx + BLK);
-            q2n = fw_ld4_nt(ib + FW_OFF_Q2(C), idx + BLK);
         }
-        const bool valid = idx < n_tot, loaded = idx < n_in;
+        const bool valid = idx < lim, loaded = !has_new;
         const float4 q0 = s_q0[r * BLK + tid], q3 = s_q3[r * BLK + tid];
         float age_new;
         const bool alive = valid && fw_survives(q0.w, a.dt, q3.w, &age_new);
@@ -665,8 +681,9 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     }
 
     if ((a.dbg & 8u) && g.dbg_ts && tid == 0) {
-        unsigned long long *d = g.dbg_ts + (size_t)tile * 4;
+        unsigned long long *d = g.dbg_ts + (size_t)tile * 8;
         d[0] = ts0, d[1] = ts1, d[2] = ts2, d[3] = __builtin_amdgcn_s_memrealtime();
+        d[4] = tsA, d[5] = tsB, d[6] = tsC, d[7] = 0;
     }
     if (is_last && tid == 0) {
         const uint32_t nc = excl + cnt;

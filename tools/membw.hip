@@ -112,6 +112,54 @@ __global__ __launch_bounds__(256) void k_planes_occ(const char* __restrict__ in,
     }
 }
 
+// structural twin of fw_k_update v3: planes 0/3 for the whole tile first -> LDS -> barrier -> rolled round loop
+// that reads them back, prefetches planes 1/2 one round ahead and stores 7 planes.  MODE bit0: skip LDS
+// staging (keep regs), bit1: all 16 loads up front, bit2: no barrier
+template <int MODE>
+__global__ __launch_bounds__(256) void k_struct(const char* __restrict__ in, char* __restrict__ out, uint32_t n, uint32_t C) {
+    constexpr int R = 4;
+    __shared__ float4 s0[1024], s3[1024];
+    __shared__ uint32_t s_w[4][4];
+    const uint32_t tid = threadIdx.x, base = blockIdx.x * 1024;
+    const float4* p0 = (const float4*)in; const float4* p1 = (const float4*)(in + (size_t)16 * C);
+    const float4* p2 = (const float4*)(in + (size_t)32 * C); const float4* p3 = (const float4*)(in + (size_t)48 * C);
+    float4 t0[R], t3[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { uint32_t i = base + r * 256 + tid; if (i < n) { t0[r] = p0[i]; t3[r] = p3[i]; } }
+#pragma unroll
+    for (int r = 0; r < R; r++) { uint32_t i = base + r * 256 + tid; if (i < n) { s0[r * 256 + tid] = t0[r]; s3[r * 256 + tid] = t3[r]; } }
+    float4 q1c = make_float4(0,0,0,0), q2c = q1c;
+    if (base + tid < n) { q1c = p1[base + tid]; q2c = p2[base + tid]; }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        unsigned long long m = __ballot(s0[r * 256 + tid].w + 0.016f < s3[r * 256 + tid].w + 1e9f);
+        if ((tid & 63) == 0) s_w[r][tid >> 6] = __popcll(m);
+    }
+    if (!(MODE & 4)) __syncthreads();
+    uint32_t run = 0;
+#pragma unroll 1
+    for (int r = 0; r < R; r++) {
+        uint32_t i = base + r * 256 + tid;
+        float4 q1n = make_float4(0,0,0,0), q2n = q1n;
+        if (r + 1 < R && i + 256 < n) { q1n = p1[i + 256]; q2n = p2[i + 256]; }
+        float4 a = s0[r * 256 + tid], d = s3[r * 256 + tid];
+        for (int w = 0; w < 4; w++) run += s_w[r][w];
+        if (i < n) {
+            uint32_t o = i + (run & 0);
+            float4 e = make_float4(a.x + q1c.x, a.y * q2c.y, d.z, a.w);
+            float4 f = make_float4(q1c.w, q2c.x, d.y, e.x);
+            ((float4*)(out))[o] = a;
+            ((float4*)(out + (size_t)16 * C))[o] = q1c;
+            ((float4*)(out + (size_t)32 * C))[o] = q2c;
+            ((float4*)(out + (size_t)48 * C))[o] = d;
+            ((float4*)(out + (size_t)64 * C))[o] = e;
+            ((float4*)(out + (size_t)80 * C))[o] = f;
+            ((float*)(out + (size_t)96 * C))[o] = e.y;
+        }
+        q1c = q1n; q2c = q2n;
+    }
+}
+
 template <typename F>
 double timeit(F f, int iters) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -158,6 +206,10 @@ int main(int argc, char** argv) {
         printf("planes n=%8u R=1        : %7.2f us  %8.1f GB/s\n", n, t * 1e6, 164.0 * n / t / 1e9);
         t = timeit([&](int i) { hipLaunchKernelGGL((k_planes<8, false>), dim3((n + 2047) / 2048), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
         printf("planes n=%8u R=8        : %7.2f us  %8.1f GB/s\n", n, t * 1e6, 164.0 * n / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_struct<0>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("struct v3 twin n=%8u      : %7.2f us  %8.1f GB/s\n", n, t * 1e6, 164.0 * n / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_struct<4>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("struct v3 twin nobarrier    : %7.2f us  %8.1f GB/s\n", t * 1e6, 164.0 * n / t / 1e9);
         for (int blocks_per_cu : {1, 2, 3, 4, 6, 8}) {
             size_t lds = 160 * 1024 / blocks_per_cu - 1024;
             if (lds > 64 * 1024) { CK(hipFuncSetAttribute((const void*)k_planes_occ, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
