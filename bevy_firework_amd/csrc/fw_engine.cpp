@@ -32,6 +32,7 @@ constexpr int kParamRing = 4;    // per-frame parameter buffers in flight
 constexpr int kSnapRing = 8;     // live-count snapshots in flight
 constexpr int kSnapEvery = 4;    // frames between snapshots
 constexpr int kTabRing = 4;      // staging buffers for tile-table uploads
+constexpr uint64_t kResidentSlots = 1024;  // fw_k_update workgroups resident at once on MI355X (256 CUs x 4)
 constexpr uint32_t kMinCapacity = 4096;
 constexpr uint64_t kMaxSpawnPerOp = 1ull << 30;
 constexpr uint32_t kTimingEvents = 4096;
@@ -143,6 +144,7 @@ struct fw_ctx {
     hipEvent_t ev_tab[kTabRing] = {};
     bool tab_pending[kTabRing] = {};
     uint64_t tab_seq = 0, ring_seq = 0;
+    uint32_t vt_rounds = 1;  // new-particle tile size of the current frame (rounds of 256)
     bool tab_force = false;  // a segment was (re)built: re-send the descriptors even if the tile counts are equal
 
     // survivor forecast tables (fw_k_update): [2][tiles_cap]
@@ -254,11 +256,20 @@ fw_status ensure_max_seg(fw_ctx *ctx, uint32_t need) {
 
 // tiles the update grid must cover for a segment: the live region in tiles of FW_TILE, plus this frame's new
 // particles in tiles of FW_VTILE (fw_k_update's tiling of the index space)
-uint32_t seg_tiles(const SegHost &s) {
-    if (!s.in_use) return 0;
+uint32_t seg_live_tiles(const SegHost &s) {
     const uint32_t live_ub = s.nested_fed ? s.capacity : std::min(s.ub - std::min(s.ub, s.frame_spawn), s.capacity);
-    return std::max<uint32_t>(1, (live_ub + FW_TILE - 1) / FW_TILE + (s.frame_spawn + FW_VTILE - 1) / FW_VTILE + 1);
+    return (live_ub + FW_TILE - 1) / FW_TILE;
 }
+uint32_t seg_tiles(const SegHost &s, uint32_t vt_rounds = 1) {
+    if (!s.in_use) return 0;
+    const uint32_t vtile = vt_rounds * FW_VTILE;
+    return std::max<uint32_t>(1, seg_live_tiles(s) + (s.frame_spawn + vtile - 1) / vtile + 1);
+}
+
+// Size of the new-particle tiles for this frame: the smallest (most parallel) of 1 or 2 rounds for which all
+// ACTIVE tiles of the frame are resident at once (kResidentSlots workgroups: 4 per CU); a second, nearly
+// empty round of workgroups would cost a full tile lifetime.
+uint32_t choose_vt_rounds(const fw_ctx *ctx);
 
 // tile scratch sized for every segment at full capacity
 fw_status ensure_tile_arrays(fw_ctx *ctx) {
@@ -681,17 +692,28 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
     return FW_OK;
 }
 
+uint32_t choose_vt_rounds(const fw_ctx *ctx) {
+    for (uint32_t vr : {1u, 2u}) {  // at most FW_TILE / 2: Q1/Q2 of new particles live in the upper half of the LDS planes
+        uint64_t act = 0;
+        for (const SegHost &S : ctx->segs)
+            if (S.in_use) act += seg_live_tiles(S) + (S.frame_spawn + vr * FW_VTILE - 1) / (vr * FW_VTILE);
+        if (act <= kResidentSlots) return vr;
+    }
+    return 1;
+}
+
 // The update grid covers ceil(bound / FW_TILE) tiles per segment, where `bound` is the host's upper
 // bound of the live count.  The table lives on the device and is re-sent only when a segment's
 // need leaves the band [need, need * 5/4 + 8], so steady-state frames upload nothing.
 fw_status update_tile_table(fw_ctx *ctx) {
     const uint32_t n_seg = (uint32_t)ctx->segs.size();
+    ctx->vt_rounds = choose_vt_rounds(ctx);
     bool dirty = ctx->tiles_dev.size() != n_seg || ctx->tab_force;  // descriptors carry per-segment type indices
     ctx->tab_force = false;
     ctx->tiles_dev.resize(n_seg, 0);
     for (uint32_t i = 0; i < n_seg; i++) {
         const SegHost &S = ctx->segs[i];
-        const uint32_t need = seg_tiles(S);
+        const uint32_t need = seg_tiles(S, ctx->vt_rounds);
         uint32_t &have = ctx->tiles_dev[i];
         if (!S.in_use) {
             if (have) have = 0, dirty = true;
@@ -1160,6 +1182,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     a.dt = dt;
     a.spin_limit = ctx->spin_limit;
     a.dbg = ctx->dbg;
+    a.vt_rounds = ctx->vt_rounds;
+    a.resident_slots = (uint32_t)kResidentSlots;
     uint32_t dt_bits;
     memcpy(&dt_bits, &dt, 4);
     const bool fc_frame = !legacy && ctx->use_forecast && ctx->d_fc != nullptr;

@@ -49,6 +49,8 @@ struct FwUpdateArgs {
     uint32_t n_ops;                // ops this frame (inline form: entries of FwInlineOps used)
     uint32_t dbg;                  // FW_DEBUG (profiling only, results wrong): 1 = no look-back, 2 = no integrate
     // survivor forecast (fw_k_update header): table written last frame / table to write this frame
+    uint32_t vt_rounds;            // new-particle tiles are vt_rounds * (threads per workgroup) particles
+    uint32_t resident_slots;       // fw_k_update workgroups resident at once (256 CUs x 4)
     const uint4 *fc_in;            // null = forecast not applicable this frame -> decoupled look-back
     uint4 *fc_out;
 };

@@ -423,21 +423,28 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     }
     const uint32_t n_tot = n_in + n_spawn;
     // Tiling of the index space [0, n_tot): the live particles [0, n_in) in tiles of FW_TILE, then the new
-    // ones [n_in, n_tot) in SMALL tiles of FW_VTILE (one round).  A new particle costs ~1-3k VALU instructions
+    // ones [n_in, n_tot) in SMALL tiles (1, 2 or 4 rounds, the smallest that keeps all active tiles of the frame
+    // resident at once; chosen by the host).  A new particle costs ~1-3k VALU instructions
     // before its tile can even count survivors; small tiles spread that over 4x more workgroups, and those
     // workgroups are dispatched FIRST (they are the last tiles) so the compute overlaps everybody else's
     // streaming instead of forming the kernel's tail.  At most FW_VFRONT tiles are front-loaded: they wait for
     // all earlier tiles while holding a slot, and the rest of the grid, still dispatched in tile order,
     // always makes progress.
     const uint32_t t_spawn = (n_in + FW_TILE - 1u) / FW_TILE;  // number of live tiles = first new-particle tile
-    const uint32_t n_vt = (n_spawn + FW_VTILE - 1u) / FW_VTILE;
+    // new-particle tile size: one round, or two when that is what keeps every active tile resident at once
+    // (a.resident_slots workgroups).  The host can only bound the live count, so a lone segment decides from
+    // the exact device count; with several segments the host's choice (from its bounds) is used.
+    uint32_t vt_rounds = a.vt_rounds;
+    if (a.n_seg == 1u) vt_rounds = (t_spawn + (n_spawn + BLK - 1u) / BLK <= a.resident_slots) ? 1u : 2u;
+    const uint32_t vtile = vt_rounds * BLK;
+    const uint32_t n_vt = (n_spawn + vtile - 1u) / vtile;
     const uint32_t n_act = t_spawn + n_vt;                      // active tiles of this segment
     if (SPAWN != FW_SPAWN_NONE && n_vt != 0 && n_vt <= FW_VFRONT && t_spawn != 0 && tis < n_act)
         tis = tis < n_vt ? t_spawn + tis : tis - n_vt;
     const uint32_t tile = first + tis;
     const bool has_new = tis >= t_spawn;  // block-uniform: a tile is either all live or all new
-    const uint32_t base = has_new ? n_in + (tis - t_spawn) * FW_VTILE : tis * FW_TILE;
-    const uint32_t lim = has_new ? min(base + FW_VTILE, n_tot) : min(base + FW_TILE, n_in);
+    const uint32_t base = has_new ? n_in + (tis - t_spawn) * vtile : tis * FW_TILE;
+    const uint32_t lim = has_new ? min(base + vtile, n_tot) : min(base + FW_TILE, n_in);
     uint4 *fc_out = FUSED ? a.fc_out : nullptr;
 
     if (n_tot == 0 || tis >= n_act) {
@@ -518,23 +525,28 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
 
     const unsigned long long tsC = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (fc_part & 0u)) : 0ull;
     if (SPAWN != FW_SPAWN_NONE && has_new) {
-        // New particles (src/core.rs:437-469): a new-particle tile is FW_VTILE = BLK particles, one per lane,
-        // generated in registers from the counter RNG and then treated like loaded ones (spawn runs before
-        // update in the same frame, src/plugin.rs:46-60).
-        const uint32_t idx = base + tid;
-        if (idx < lim) {
-            const uint32_t k = idx - n_in;
-            uint32_t oi = o0;
-            for (uint32_t i = o0; i < o1; i++)
-                if (k >= FW_OP(i).rel_base && k - FW_OP(i).rel_base < FW_OP(i).n) oi = i;
-            const FwOp &op = FW_OP(oi);
-            const FwSpawnOut so = fw_spawn_one(
-                g.emits[op.emit], g.seed, op.serial_base + (k - op.rel_base),
-                fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
-                fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
-                fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
-            s_q0[tid] = so.q0, s_q3[tid] = so.q3;
-            q1c = so.q1, q2c = so.q2;
+        // New particles (src/core.rs:437-469), generated from the counter RNG straight into LDS: Q0/Q3 where a
+        // loaded tile parks them, Q1/Q2 in the upper half of the same planes (a new-particle tile is at most
+        // FW_TILE / 2 particles).  From here on they are ordinary inputs: spawn runs before update in the same
+        // frame (src/plugin.rs:46-60).  One rolled instance of the (large) spawn code, in its own loop so its
+        // registers do not add to the round loop's.
+#pragma unroll 1
+        for (int r = 0; r < R / 2; r++) {
+            const uint32_t idx = base + r * BLK + tid;
+            if (idx < lim) {
+                const uint32_t k = idx - n_in;
+                uint32_t oi = o0;
+                for (uint32_t i = o0; i < o1; i++)
+                    if (k >= FW_OP(i).rel_base && k - FW_OP(i).rel_base < FW_OP(i).n) oi = i;
+                const FwOp &op = FW_OP(oi);
+                const FwSpawnOut so = fw_spawn_one(
+                    g.emits[op.emit], g.seed, op.serial_base + (k - op.rel_base),
+                    fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
+                    fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
+                    fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
+                s_q0[r * BLK + tid] = so.q0, s_q3[r * BLK + tid] = so.q3;
+                s_q0[FW_TILE / 2 + r * BLK + tid] = so.q1, s_q3[FW_TILE / 2 + r * BLK + tid] = so.q2;
+            }
         }
     }
 
@@ -638,6 +650,8 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         }
         const bool valid = idx < lim, loaded = !has_new;
         const float4 q0 = s_q0[r * BLK + tid], q3 = s_q3[r * BLK + tid];
+        if (SPAWN != FW_SPAWN_NONE && has_new && valid)
+            q1c = s_q0[FW_TILE / 2 + r * BLK + tid], q2c = s_q3[FW_TILE / 2 + r * BLK + tid];
         float age_new;
         const bool alive = valid && fw_survives(q0.w, a.dt, q3.w, &age_new);
         const unsigned long long m = __ballot(alive);
@@ -1087,11 +1101,9 @@ hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArg
     static const FwInlineOps none{};
     const FwInlineOps &io = inl ? *inl : none;
     if (mode == FW_MODE_SPLIT && spawn_form != FW_SPAWN_NONE) return hipErrorInvalidValue;
-    switch (rounds) {
-        case 1: fw_launch_update_r<1>(s, g, a, io, spawn_form, mode); break;
-        case 2: fw_launch_update_r<2>(s, g, a, io, spawn_form, mode); break;
-        default: fw_launch_update_r<4>(s, g, a, io, spawn_form, mode); break;
-    }
+    // 256 threads x 4 rounds is the measured optimum; the other shapes were dropped
+    (void)rounds;
+    fw_launch_update_r<FW_ROUNDS>(s, g, a, io, spawn_form, mode);
     return hipGetLastError();
 }
 
