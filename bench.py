@@ -140,12 +140,13 @@ def main():
     # Second pass over the same steady state with a hipEvent pair around every fw_k_update launch (on the
     # kernel's own stream).  It is a separate pass because the event markers serialise the queue (~8 us of
     # idle GPU per step): they would distort `value`, and `value` would distort nothing here.
-    ev_ms, ev_launches, ev_particles = (0.0, 0, 0)
+    ev_ms, ev_launches, ev_particles, ev_overhead_us = (0.0, 0, 0, 0.0)
     if not args.no_events and rank == 0:
         ps.kernel_timing(True)
         for _ in range(min(args.steps, 1000)):
             ps.step(dt)
         ev_ms, ev_launches, ev_particles = ps.kernel_timing_read()
+        ev_overhead_us = ps.kernel_timing_overhead_us()
         ps.kernel_timing(False)
     barrier()
 
@@ -189,8 +190,10 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_particle": ALGO_BYTES, "moved_bytes_per_particle": ACTUAL_BYTES,
                 "particles_per_launch": per_launch, "avg_kernel_us": kt * 1e6, "launches": ev_launches,
-                "timing": "hipEvent pair around each launch on the context's stream, second pass over the same "
-                          "steady state (markers serialise the queue, so they are kept out of `value`)",
+                "event_pair_overhead_us": ev_overhead_us,
+                "timing": "hipEvent pair around each launch on the context's stream, minus the calibrated cost of an "
+                          "empty pair; second pass over the same steady state (the markers serialise the queue, so "
+                          "they are kept out of `value`)",
             }
         else:
             out["roofline"] = None

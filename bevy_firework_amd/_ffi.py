@@ -216,6 +216,7 @@ SYMBOLS = [
     ("fw_ctx_last_step_updated", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("fw_ctx_kernel_timing", C.c_int, [_P, C.c_int32]),
     ("fw_ctx_kernel_timing_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("fw_ctx_kernel_timing_overhead", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("fw_ctx_measure_copy_bandwidth", C.c_int, [_P, C.c_uint64, C.c_int32, C.POINTER(C.c_double)]),
     ("fw_compute_emission_count", C.c_uint64,
      [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]),

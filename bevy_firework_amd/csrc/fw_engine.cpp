@@ -164,6 +164,7 @@ struct fw_ctx {
     std::vector<hipEvent_t> tev;
     size_t tev_used = 0;
     uint64_t timing_particles_start = 0;
+    double tev_overhead_ms = 0;  // duration of an empty hipEvent pair on this stream
 
     float *d_aabb = nullptr;
     unsigned long long *d_total = nullptr;
@@ -1184,6 +1185,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     a.dbg = ctx->dbg;
     a.vt_rounds = ctx->vt_rounds;
     a.resident_slots = (uint32_t)kResidentSlots;
+    a.seg0_type = n_seg ? ctx->segs[0].type_idx : 0;
     uint32_t dt_bits;
     memcpy(&dt_bits, &dt, 4);
     const bool fc_frame = !legacy && ctx->use_forecast && ctx->d_fc != nullptr;
@@ -1593,6 +1595,23 @@ fw_status fw_ctx_kernel_timing(fw_ctx *ctx, int32_t enable) {
         ctx->tev.resize(kTimingEvents);
         for (auto &ev : ctx->tev) FW_HIP(ctx, hipEventCreate(&ev));
     }
+    if (enable) {
+        // calibrate the marker cost: a hipEvent pair with nothing between still measures the two markers'
+        // own processing (a few us); that is subtracted per launch so the figure is the kernel's duration
+        const int n = 64;
+        for (int i = 0; i < n; i++) {
+            FW_HIP(ctx, hipEventRecord(ctx->tev[2 * i], ctx->stream));
+            FW_HIP(ctx, hipEventRecord(ctx->tev[2 * i + 1], ctx->stream));
+        }
+        FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        double tot = 0;
+        for (int i = 8; i < n; i++) {
+            float t = 0;
+            FW_HIP(ctx, hipEventElapsedTime(&t, ctx->tev[2 * i], ctx->tev[2 * i + 1]));
+            tot += t;
+        }
+        ctx->tev_overhead_ms = tot / (n - 8);
+    }
     ctx->timing = enable != 0;
     ctx->tev_used = 0;
     unsigned long long now = 0;
@@ -1612,8 +1631,10 @@ fw_status fw_ctx_kernel_timing_read(fw_ctx *ctx, double *ms_total, uint64_t *lau
         FW_HIP(ctx, hipEventElapsedTime(&t, ctx->tev[i], ctx->tev[i + 1]));
         ms += t;
     }
+    const uint64_t nl = ctx->tev_used / 2;
+    ms -= ctx->tev_overhead_ms * (double)nl;  // marker cost, calibrated in fw_ctx_kernel_timing
     if (ms_total) *ms_total = ms;
-    if (launches) *launches = ctx->tev_used / 2;
+    if (launches) *launches = nl;
     unsigned long long now = 0;
     FW_HIP(ctx, hipMemcpy(&now, ctx->g.stats, sizeof now, hipMemcpyDeviceToHost));
     if (particles) *particles = now - ctx->timing_particles_start;
@@ -1628,6 +1649,12 @@ fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_
     const uint64_t n = std::min<uint64_t>(max_tiles, ctx->total_tiles_dev);
     if (n_tiles) *n_tiles = n;
     if (n && out) FW_HIP(ctx, hipMemcpy(out, ctx->g.dbg_ts, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return FW_OK;
+}
+
+fw_status fw_ctx_kernel_timing_overhead(fw_ctx *ctx, double *ms_per_pair) {
+    if (!ctx || !ms_per_pair) return FW_EINVAL;
+    *ms_per_pair = ctx->tev_overhead_ms;
     return FW_OK;
 }
 

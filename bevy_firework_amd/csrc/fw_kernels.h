@@ -51,6 +51,8 @@ struct FwUpdateArgs {
     // survivor forecast (fw_k_update header): table written last frame / table to write this frame
     uint32_t vt_rounds;            // new-particle tiles are vt_rounds * (threads per workgroup) particles
     uint32_t resident_slots;       // fw_k_update workgroups resident at once (256 CUs x 4)
+    uint32_t seg0_type;            // type index of segment 0 (used when n_seg == 1)
+    uint32_t pad2;
     const uint4 *fc_in;            // null = forecast not applicable this frame -> decoupled look-back
     uint4 *fc_out;
 };

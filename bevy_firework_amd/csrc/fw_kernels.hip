@@ -383,7 +383,9 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     const unsigned long long ts0 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // workgroup -> (segment, tile in segment): one table read instead of a dependent binary search
     uint32_t seg, first, seg_tiles, type_idx;
-    if (a.tile_desc) {
+    if (a.n_seg == 1u) {  // a lone segment: everything is in the kernel arguments, no table read on the critical path
+        seg = 0, first = 0, seg_tiles = a.total_tiles, type_idx = a.seg0_type;
+    } else if (a.tile_desc) {
         const uint4 d = a.tile_desc[blockIdx.x];
         seg = d.x, first = d.y, seg_tiles = d.z, type_idx = d.w;
     } else {

@@ -257,6 +257,11 @@ class ParticleSystem:
         self._check(self._lib.fw_ctx_kernel_timing_read(self._ctx, C.byref(ms), C.byref(n), C.byref(parts)))
         return ms.value, int(n.value), int(parts.value)
 
+    def kernel_timing_overhead_us(self) -> float:
+        out = C.c_double()
+        self._check(self._lib.fw_ctx_kernel_timing_overhead(self._ctx, C.byref(out)))
+        return out.value * 1e3
+
     def measure_copy_bandwidth(self, nbytes: int = 1 << 30, iters: int = 20) -> float:
         out = C.c_double()
         self._check(self._lib.fw_ctx_measure_copy_bandwidth(self._ctx, int(nbytes), int(iters), C.byref(out)))

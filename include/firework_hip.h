@@ -191,7 +191,7 @@ fw_status fw_ctx_live_count(fw_ctx *ctx, uint64_t *out);
 /* enqueue a write of the total live count into a caller-owned DEVICE uint64 (no
  * sync): feed for the RCCL all-reduce of live counts across GPUs */
 fw_status fw_ctx_live_count_device(fw_ctx *ctx, void *d_out_u64);
-/* particles that entered update_particles in the last fw_step (after spawn) */
+/* running total of particles that entered update_particles (after spawn) since the context was created */
 fw_status fw_ctx_last_step_updated(fw_ctx *ctx, uint64_t *out);
 
 /* ---- measurement hooks (bench.py / profiles) -------------------------------------- */
@@ -199,6 +199,8 @@ fw_status fw_ctx_last_step_updated(fw_ctx *ctx, uint64_t *out);
  * steps, then read (sum of kernel durations in ms, number of launches). */
 fw_status fw_ctx_kernel_timing(fw_ctx *ctx, int32_t enable);
 fw_status fw_ctx_kernel_timing_read(fw_ctx *ctx, double *ms_total, uint64_t *launches, uint64_t *particles);
+/* cost of an empty hipEvent pair on the stream (calibrated at enable time; already subtracted per launch above) */
+fw_status fw_ctx_kernel_timing_overhead(fw_ctx *ctx, double *ms_per_pair);
 /* device-to-device copy bandwidth probe (bytes moved R+W per second) for the measured-roofline line */
 fw_status fw_ctx_measure_copy_bandwidth(fw_ctx *ctx, uint64_t bytes, int32_t iters, double *bytes_per_s);
 

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""profiles/<round>/pmc_summary.txt -> profiles/pmc_traffic.json (read by bench.py for roofline.traffic).
+
+HBM-side bytes per fw_k_update launch from the rocprofv3 PMC passes (tools/pmc.sh): FETCH_SIZE and WRITE_SIZE are
+reported in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streams, so it is doubled
+(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is used as reported."""
+import json
+import re
+import sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01/pmc_summary.txt"
+txt = open(src).read()
+fetch = float(re.search(r"fw_k_update<true, 1, 4>\s+FETCH_SIZE=([0-9.e+]+)", txt).group(1))
+write = float(re.search(r"fw_k_update<true, 1, 4>\s+WRITE_SIZE=([0-9.e+]+)", txt).group(1))
+out = {
+    "source": src,
+    "kernel": "fw_k_update<true, 1, 4>",
+    "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+    "fetch_bytes_corrected": 2 * fetch * 1024, "write_bytes": write * 1024,
+    "fw_k_update_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
+    "note": "FETCH_SIZE x2 (gfx950 correction for 16 B/lane streams); separate --pmc passes of `bench.py --steps 100`",
+}
+json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+print(out)

@@ -160,6 +160,43 @@ __global__ __launch_bounds__(256) void k_struct(const char* __restrict__ in, cha
     }
 }
 
+// streaming twin: per round, prefetch the next round's 4 planes, then store the 7 output planes of the current one
+template <int R, bool BAR = false>
+__global__ __launch_bounds__(256) void k_stream(const char* __restrict__ in, char* __restrict__ out, uint32_t n, uint32_t C) {
+    __shared__ uint32_t s_c[2][4];
+    const uint32_t tid = threadIdx.x, base = blockIdx.x * 256 * R;
+    uint32_t run = 0;
+    const float4* p0 = (const float4*)in; const float4* p1 = (const float4*)(in + (size_t)16 * C);
+    const float4* p2 = (const float4*)(in + (size_t)32 * C); const float4* p3 = (const float4*)(in + (size_t)48 * C);
+    float4 a = make_float4(0,0,0,0), b = a, c = a, d = a;
+    if (base + tid < n) { a = p0[base + tid]; b = p1[base + tid]; c = p2[base + tid]; d = p3[base + tid]; }
+#pragma unroll 1
+    for (int r = 0; r < R; r++) {
+        uint32_t i = base + r * 256 + tid;
+        float4 an = a, bn = b, cn = c, dn = d;
+        if (r + 1 < R && i + 256 < n) { an = p0[i + 256]; bn = p1[i + 256]; cn = p2[i + 256]; dn = p3[i + 256]; }
+        if (BAR) {  // per-round cross-wave rank exchange (double-buffered LDS, one barrier per round)
+            unsigned long long m = __ballot(i < n && a.w + 0.016f < d.w + 1e9f);
+            if ((tid & 63) == 0) s_c[r & 1][tid >> 6] = __popcll(m);
+            __syncthreads();
+            for (int w = 0; w < 4; w++) run += s_c[r & 1][w];
+        }
+        if (i < n) {
+            i += (run & 0);
+            float4 e = make_float4(a.x + b.x, a.y * c.y, d.z, a.w);
+            float4 f = make_float4(b.w, c.x, d.y, e.x);
+            ((float4*)(out))[i] = a;
+            ((float4*)(out + (size_t)16 * C))[i] = b;
+            ((float4*)(out + (size_t)32 * C))[i] = c;
+            ((float4*)(out + (size_t)48 * C))[i] = d;
+            ((float4*)(out + (size_t)64 * C))[i] = e;
+            ((float4*)(out + (size_t)80 * C))[i] = f;
+            ((float*)(out + (size_t)96 * C))[i] = e.y;
+        }
+        a = an; b = bn; c = cn; d = dn;
+    }
+}
+
 template <typename F>
 double timeit(F f, int iters) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -210,6 +247,16 @@ int main(int argc, char** argv) {
         printf("struct v3 twin n=%8u      : %7.2f us  %8.1f GB/s\n", n, t * 1e6, 164.0 * n / t / 1e9);
         t = timeit([&](int i) { hipLaunchKernelGGL((k_struct<4>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
         printf("struct v3 twin nobarrier    : %7.2f us  %8.1f GB/s\n", t * 1e6, 164.0 * n / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_stream<4>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("stream twin R=4  n=%8u    : %7.2f us  %8.1f GB/s\n", n, t * 1e6, 164.0 * n / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_stream<4, true>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("stream twin R=4 +barrier/round: %7.2f us  %8.1f GB/s\n", t * 1e6, 164.0 * n / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_stream<16, true>), dim3((n + 4095) / 4096), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("stream twin R=16 +barrier/round: %7.2f us  %8.1f GB/s\n", t * 1e6, 164.0 * n / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_stream<8>), dim3((n + 2047) / 2048), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("stream twin R=8               : %7.2f us  %8.1f GB/s\n", t * 1e6, 164.0 * n / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_stream<16>), dim3((n + 4095) / 4096), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("stream twin R=16              : %7.2f us  %8.1f GB/s\n", t * 1e6, 164.0 * n / t / 1e9);
         for (int blocks_per_cu : {1, 2, 3, 4, 6, 8}) {
             size_t lds = 160 * 1024 / blocks_per_cu - 1024;
             if (lds > 64 * 1024) { CK(hipFuncSetAttribute((const void*)k_planes_occ, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
