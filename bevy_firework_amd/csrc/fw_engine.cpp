@@ -67,6 +67,7 @@ struct SegHost {
     uint64_t cum_spawn = 0;     // Global particles ever appended (host-known)
     uint32_t frame_spawn = 0;   // ... this frame
     uint32_t type_idx = 0, n_lplanes = 0;
+    uint32_t keys_off = 0, keys_len = 0;  // key pool window of the segment's type
     int32_t lplane_emission[FW_MAX_EMISSIONS];
     bool nested_fed = false;    // receives Nested children: count not host-predictable
     char *buf[2] = {nullptr, nullptr};
@@ -138,6 +139,8 @@ struct fw_ctx {
     std::vector<uint32_t> tiles_dev;
     uint32_t total_tiles_dev = 0;
     uint32_t *h_tab[kTabRing] = {};
+    uint2 *d_tile_keys = nullptr;  // per segment: {keys_off, keys_len}
+    uint2 *h_keys[kTabRing] = {};
     uint4 *d_tile_desc = nullptr;  // per tile: {segment, first tile, tile count, 0}
     uint4 *h_desc[kTabRing] = {};
     size_t tile_desc_cap = 0;
@@ -153,6 +156,8 @@ struct fw_ctx {
     uint32_t fc_dt_bits = 0;   // ... computed for this dt
     uint64_t fc_tab_seq = 0;   // ... under this tile table
     bool use_forecast = true;  // FW_FORECAST=0 disables (A/B, debugging)
+    uint32_t snap_every = kSnapEvery;  // frames between live-count snapshots (FW_SNAP_EVERY)
+    bool use_stream = true;    // FW_STREAM=0: forecast frames keep the count-park-store kernel (A/B)
 
     uint64_t frame = 0;
     uint32_t parity = 0;
@@ -617,6 +622,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         SegHost &S = ctx->segs[si];
         S = SegHost{};
         S.in_use = true, S.spawner = h, S.type = (int)t, S.type_idx = type_idx;
+        S.keys_off = dt.keys_off, S.keys_len = dt.keys_len;
         for (int k = 0; k < FW_MAX_EMISSIONS; k++) S.lplane_emission[k] = -1;
         for (uint32_t i = 0; i < ne; i++) {
             const fw_emission_settings &e = d->emission_settings[i];
@@ -738,9 +744,13 @@ fw_status update_tile_table(fw_ctx *ctx) {
         const size_t ncap = (size_t)(n_seg + 1) * 2 + 64;
         if (ctx->d_tile_first) hipFree(ctx->d_tile_first);
         FW_HIP(ctx, hipMalloc((void **)&ctx->d_tile_first, ncap * sizeof(uint32_t)));
+        if (ctx->d_tile_keys) hipFree(ctx->d_tile_keys);
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_tile_keys, ncap * sizeof(uint2)));
         for (int i = 0; i < kTabRing; i++) {
             if (ctx->h_tab[i]) hipHostFree(ctx->h_tab[i]);
             FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_tab[i], ncap * sizeof(uint32_t), hipHostMallocDefault));
+            if (ctx->h_keys[i]) hipHostFree(ctx->h_keys[i]);
+            FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_keys[i], ncap * sizeof(uint2), hipHostMallocDefault));
             ctx->tab_pending[i] = false;
         }
         ctx->tile_first_cap = ncap;
@@ -773,6 +783,10 @@ fw_status update_tile_table(fw_ctx *ctx) {
     }
     h[n_seg] = total;
     ctx->total_tiles_dev = total;
+    uint2 *hk = ctx->h_keys[slot];
+    for (uint32_t i = 0; i < n_seg; i++) hk[i] = make_uint2(ctx->segs[i].keys_off, ctx->segs[i].keys_len);
+    if (n_seg)
+        FW_HIP(ctx, hipMemcpyAsync(ctx->d_tile_keys, hk, (size_t)n_seg * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
     uint4 *hd = ctx->h_desc[slot];
     for (uint32_t i = 0; i < n_seg; i++)
         for (uint32_t t = 0; t < ctx->tiles_dev[i]; t++)
@@ -914,6 +928,8 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_UPDATE_MODE")) ctx->update_mode = !strcmp(m, "split") ? FW_MODE_SPLIT : FW_MODE_FUSED;
     if (const char *m = getenv("FW_DEBUG")) ctx->dbg = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_FORECAST")) ctx->use_forecast = atoi(m) != 0;
+    if (const char *m = getenv("FW_STREAM")) ctx->use_stream = atoi(m) != 0;
+    if (const char *m = getenv("FW_SNAP_EVERY")) ctx->snap_every = std::max(1, atoi(m));
     if (const char *m = getenv("FW_UPDATE_ROUNDS")) ctx->update_rounds = atoi(m);
     if (const char *m = getenv("FW_SPIN_LIMIT")) ctx->spin_limit = (uint32_t)strtoul(m, nullptr, 10);
     if (ensure_max_seg(ctx, 1024) != FW_OK) {
@@ -956,6 +972,9 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     }
     if (ctx->d_tile_first) hipFree(ctx->d_tile_first);
     if (ctx->d_tile_desc) hipFree(ctx->d_tile_desc);
+    if (ctx->d_tile_keys) hipFree(ctx->d_tile_keys);
+    for (int i = 0; i < kTabRing; i++)
+        if (ctx->h_keys[i]) hipHostFree(ctx->h_keys[i]);
     if (ctx->d_fc) hipFree(ctx->d_fc);
     if (ctx->h_snap) hipHostFree(ctx->h_snap);
     for (hipEvent_t ev : ctx->tev) hipEventDestroy(ev);
@@ -1186,6 +1205,12 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     a.vt_rounds = ctx->vt_rounds;
     a.resident_slots = (uint32_t)kResidentSlots;
     a.seg0_type = n_seg ? ctx->segs[0].type_idx : 0;
+    a.seg0_keys_off = n_seg ? ctx->segs[0].keys_off : 0;
+    a.seg0_keys_len = n_seg ? ctx->segs[0].keys_len : 0;
+    a.tile_keys = ctx->d_tile_keys;
+    a.use_stream = ctx->use_stream ? 1u : 0u;
+    for (uint32_t i = 0; i < n_seg && a.use_stream; i++)
+        if (ctx->tiles_dev[i] > FW_FC_MAX_TILES) a.use_stream = 0;
     uint32_t dt_bits;
     memcpy(&dt_bits, &dt, 4);
     const bool fc_frame = !legacy && ctx->use_forecast && ctx->d_fc != nullptr;
@@ -1194,8 +1219,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         if (ctx->fc_ok && ctx->fc_dt_bits == dt_bits && ctx->fc_tab_seq == ctx->tab_seq && a.epoch != 1u)
             a.fc_in = ctx->d_fc + (size_t)((ctx->frame + 1u) & 1u) * ctx->tiles_cap;
     }
-    const bool take_snap = (ctx->frame % kSnapEvery) == 0;
-    const int snap = (int)((ctx->frame / kSnapEvery) % kSnapRing);
+    const bool take_snap = (ctx->frame % ctx->snap_every) == 0;
+    const int snap = (int)((ctx->frame / ctx->snap_every) % kSnapRing);
     a.host_counts = take_snap ? ctx->h_snap + (size_t)snap * ctx->max_seg : nullptr;
 
     FwInlineOps inl;

@@ -52,7 +52,9 @@ struct FwUpdateArgs {
     uint32_t vt_rounds;            // new-particle tiles are vt_rounds * (threads per workgroup) particles
     uint32_t resident_slots;       // fw_k_update workgroups resident at once (256 CUs x 4)
     uint32_t seg0_type;            // type index of segment 0 (used when n_seg == 1)
-    uint32_t pad2;
+    uint32_t use_stream;           // forecast frames: run fw_k_update_stream (every segment within FW_FC_MAX_TILES)
+    uint32_t seg0_keys_off, seg0_keys_len;  // key pool window of segment 0's type (n_seg == 1)
+    const uint2 *tile_keys;        // [n_seg] {keys_off, keys_len} of each segment's type (device)
     const uint4 *fc_in;            // null = forecast not applicable this frame -> decoupled look-back
     uint4 *fc_out;
 };

@@ -712,6 +712,336 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     }
 }
 
+// ---------------------------------------------------------------------------------
+// fw_k_update_stream: the update kernel of FORECAST frames (dt repeated, state untouched: the steady state).
+//
+// Same tiling, tables and results as fw_k_update, different schedule.  With the forecast a live tile knows its
+// output offset before it has seen a single particle, so nothing has to be counted ahead of time and nothing
+// has to be parked: each round loads its four input planes (prefetched one round ahead), ranks its survivors
+// (ballot + one LDS exchange per round), integrates and stores.  Loads of round r+1 and stores of round r are
+// in flight together in every workgroup, which is what the memory system wants: the microbenchmark of this
+// exact schedule (tools/membw.hip, "stream twin") moves the 164 B/particle at 8.2 TB/s out of the Infinity
+// Cache at 1M particles and 5.6-5.8 TB/s from HBM at 4M-16M, against 5.8 / 4.8 TB/s for load-count-park-store.
+// A new-particle tile counts its survivors from the lifetime draws alone (one Philox block per particle),
+// looks back among the new-particle tiles only, then generates each particle right before integrating it.
+// ---------------------------------------------------------------------------------
+struct FwRoundOut {
+    uint32_t fa, fb;
+};
+
+// everything a round does once a lane has its particle (q0..q3) and its output slot `o`
+__device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_keys, float dt, uint32_t dbg, float4 q0,
+                                                float4 q1, float4 q2, float4 q3, bool valid, bool alive, bool loaded,
+                                                float age_new, uint32_t idx, uint32_t o, const char *ib, char *ob,
+                                                char *destroyed, bool want_destroyed, uint32_t C, uint32_t n_lplanes,
+                                                bool forecast, uint32_t fc_bnd, FwRoundOut &acc) {
+    if (forecast) {  // will it survive one more step of the same dt?  (same expression as fw_survives)
+        float an2;
+        const bool nx = alive && fw_survives(age_new, dt, q3.w, &an2);
+        acc.fa += (uint32_t)__popcll(__ballot(nx && o < fc_bnd));
+        acc.fb += (uint32_t)__popcll(__ballot(nx && o >= fc_bnd));
+    }
+    if (alive && (dbg & 2u)) {  // profiling only: stream without arithmetic
+        fw_st4(ob + FW_OFF_Q0(C), o, make_float4(q0.x, q0.y, q0.z, age_new)), fw_st4(ob + FW_OFF_Q1(C), o, q1);
+        fw_st4(ob + FW_OFF_Q2(C), o, q2), fw_st4(ob + FW_OFF_Q3(C), o, q3);
+        fw_st4(ob + FW_OFF_Q5(C), o, q0), fw_st4(ob + FW_OFF_Q6(C), o, q1);
+        fw_st1(ob + FW_OFF_S4(C), o, q1.w);
+    } else if (alive) {
+        fw_integrate_store(T, s_keys, dt, q0, q1, q2, q3, age_new, ob, C, o);
+        for (uint32_t k = 0; k < n_lplanes; k++)  // new particles: vec![f32::MIN; n] (core.rs:467)
+            fw_st1(ob + FW_OFF_L(C, k), o, loaded ? fw_ld1(ib + FW_OFF_L(C, k), idx) : FW_F32_MIN);
+    } else if (valid && want_destroyed) {
+        fw_store_destroyed(destroyed, ib, C, idx, loaded, T, s_keys, q0, q1, q2, q3, age_new, idx - o);
+    }
+}
+
+template <int SPAWN>
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUpdateArgs a, FwInlineOps inl) {
+    constexpr int R = FW_ROUNDS;
+    constexpr int BLK = FW_BLOCK;
+    constexpr int NW = BLK / 64;
+    constexpr int LBW = 4;
+    __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
+    __shared__ uint32_t s_c[2][NW];     // survivors per wave of the current round (double-buffered)
+    __shared__ uint32_t s_lb[2 * LBW * NW];
+    __shared__ uint32_t s_part[4][NW];  // per-wave partials: forecast prefix, new survivors, next-frame sums A / B
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned long long ts0 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    uint32_t seg, first, seg_tiles, type_idx, keys_off, keys_len;
+    if (a.n_seg == 1u) {
+        seg = 0, first = 0, seg_tiles = a.total_tiles, type_idx = a.seg0_type;
+        keys_off = a.seg0_keys_off, keys_len = a.seg0_keys_len;
+    } else {
+        const uint4 d = a.tile_desc[blockIdx.x];
+        seg = d.x, first = d.y, seg_tiles = d.z, type_idx = d.w;
+        const uint2 kd = a.tile_keys[seg];
+        keys_off = kd.x, keys_len = kd.y;
+    }
+    // curve / gradient keys -> LDS: requested first, they have the longest way to go (global -> VGPR -> LDS)
+    for (uint32_t i = tid; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
+    uint32_t tis = blockIdx.x - first;
+    // forecast entries of the whole segment, requested before anything else (they depend on the descriptor only)
+    constexpr int FC_U = 8;
+    uint4 fce[FC_U];
+#pragma unroll
+    for (int j = 0; j < FC_U; j++) {
+        const uint32_t t = tid + (uint32_t)j * BLK;
+        fce[j] = t < seg_tiles ? a.fc_in[first + t] : make_uint4(0u, 0u, 0u, a.epoch - 1u);
+    }
+    const uint32_t p = a.parity;
+    const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
+    const uint32_t n_in = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
+    uint32_t o0 = 0, o1 = 0, n_spawn = 0;
+    if (SPAWN == FW_SPAWN_INLINE) {
+        for (uint32_t i = 0; i < a.n_ops; i++) {
+            if (inl.ops[i].seg == seg) {
+                if (o1 == 0) o0 = i;
+                o1 = i + 1;
+                n_spawn += inl.ops[i].n;
+            }
+        }
+    } else if (SPAWN == FW_SPAWN_TABLE) {
+        o0 = a.seg_op_first[seg], o1 = a.seg_op_first[seg + 1];
+        for (uint32_t i = o0; i < o1; i++) n_spawn += a.ops[i].n;
+    }
+    const uint32_t n_tot = n_in + n_spawn;
+    // tiling of [0, n_tot): identical to fw_k_update (live tiles of FW_TILE, then small new-particle tiles)
+    const uint32_t t_spawn = (n_in + FW_TILE - 1u) / FW_TILE;
+    uint32_t vt_rounds = a.vt_rounds;
+    if (a.n_seg == 1u) vt_rounds = (t_spawn + (n_spawn + BLK - 1u) / BLK <= a.resident_slots) ? 1u : 2u;
+    const uint32_t vtile = vt_rounds * BLK;
+    const uint32_t n_vt = (n_spawn + vtile - 1u) / vtile;
+    const uint32_t n_act = t_spawn + n_vt;
+    if (SPAWN != FW_SPAWN_NONE && n_vt != 0 && n_vt <= FW_VFRONT && t_spawn != 0 && tis < n_act)
+        tis = tis < n_vt ? t_spawn + tis : tis - n_vt;
+    const uint32_t tile = first + tis;
+    const bool has_new = tis >= t_spawn;
+    const uint32_t base = has_new ? n_in + (tis - t_spawn) * vtile : tis * FW_TILE;
+    const uint32_t lim = has_new ? min(base + vtile, n_tot) : min(base + FW_TILE, n_in);
+    uint4 *fc_out = a.fc_out;
+
+    if (n_tot == 0 || tis >= n_act) {
+        if (tid == 0) {
+            fc_out[tile] = make_uint4(0u, 0u, 0u, a.epoch);
+            if (n_tot == 0 && tis == 0) {
+                g.count[oidx] = 0;
+                g.spawned[oidx] = 0;
+                g.appended[oidx] = 0;
+                g.ndestroyed[seg] = 0;
+                if (a.host_counts) a.host_counts[seg] = 0;
+            }
+        }
+        return;
+    }
+    const bool is_last = tis + 1u == n_act;
+    if (tis == 0 && tid == 0 && n_act > seg_tiles) {
+        atomicOr(g.err, FW_ERR_CAPACITY);
+        g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;
+    }
+    const FwSeg *Sp = &g.segs[seg];
+    const uint32_t C = Sp->capacity;
+    const uint32_t n_lplanes = Sp->n_lplanes;
+    const char *ib = Sp->buf[p];
+    char *ob = Sp->buf[p ^ 1u];
+    char *destroyed = Sp->destroyed;
+
+    const unsigned long long tsA = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (C & 0u)) : 0ull;
+    // round 0 of a live tile goes out now
+    float4 q0c = make_float4(0.f, 0.f, 0.f, 0.f), q1c = q0c, q2c = q0c, q3c = q0c;
+    if (!has_new && base + tid < lim) {
+        q0c = fw_ld4(ib + FW_OFF_Q0(C), base + tid);
+        q3c = fw_ld4(ib + FW_OFF_Q3(C), base + tid);
+        q1c = fw_ld4(ib + FW_OFF_Q1(C), base + tid);
+        q2c = fw_ld4(ib + FW_OFF_Q2(C), base + tid);
+    }
+    const FwType T = g.types[type_idx];  // scalar loads; first needed in the round loop
+
+    // forecast prefix of this tile
+    uint32_t fc_part = 0;
+    bool fc_bad = false;
+#pragma unroll
+    for (int j = 0; j < FC_U; j++) {
+        const uint4 e = fce[j];
+        fc_bad |= e.w != a.epoch - 1u;
+        fc_part += (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u));
+    }
+    for (uint32_t t = tid + FC_U * BLK; t < seg_tiles; t += BLK) {
+        const uint4 e = a.fc_in[first + t];
+        fc_bad |= e.w != a.epoch - 1u;
+        fc_part += (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u));
+    }
+    // survivors among a new-particle tile's particles: age 0, lifetime = RNG block 2 word 0 (core.rs:455)
+    uint32_t new_alive = 0;
+    if (SPAWN != FW_SPAWN_NONE && has_new) {
+#pragma unroll 1
+        for (uint32_t r = 0; r < vt_rounds; r++) {
+            const uint32_t idx = base + r * BLK + tid;
+            bool al = false;
+            if (idx < lim) {
+                const uint32_t k = idx - n_in;
+                uint32_t oi = o0;
+                for (uint32_t i = o0; i < o1; i++)
+                    if (k >= FW_OP(i).rel_base && k - FW_OP(i).rel_base < FW_OP(i).n) oi = i;
+                const FwOp &op = FW_OP(oi);
+                const FwEmit &e = g.emits[op.emit];
+                const unsigned long long serial = op.serial_base + (k - op.rel_base);
+                const fw_u4 o = fw_philox4x32_10(fw_u4{(uint32_t)serial, (uint32_t)(serial >> 32), e.emission_index, 2u},
+                                                 g.seed, e.uid);
+                float an;
+                al = fw_survives(0.0f, a.dt, fw_unit_f32(o.x) * (e.life_max - e.life_min) + e.life_min, &an);
+            }
+            new_alive += (uint32_t)__popcll(__ballot(al));
+        }
+    }
+    fc_part = fw_wave_sum(fc_part);
+    if (lane == 0) s_part[0][wave] = fc_part, s_part[1][wave] = new_alive;
+    if (__any(fc_bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST);
+    const unsigned long long tsB = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (fc_part & 0u)) : 0ull;
+    __syncthreads();
+    const unsigned long long ts1 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    uint32_t excl = 0, new_cnt = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) excl += s_part[0][w], new_cnt += s_part[1][w];
+
+    if (SPAWN != FW_SPAWN_NONE && has_new) {  // look back among the new-particle tiles only
+        const bool lb_needed = tis > t_spawn;
+        if (lb_needed && tid == 0)
+            __hip_atomic_store(&g.tile_status[tile], fw_pack_status(a.epoch, FW_ST_AGG, new_cnt), RLX, AGENT);
+        uint32_t lb_excl = 0;
+        if (lb_needed) {
+            bool timed_out = false;
+            lb_excl = fw_lookback<BLK, NW, LBW>(g.tile_status, first + t_spawn, tile, a.epoch, a.spin_limit, s_lb, &timed_out);
+            if (timed_out) {  // recount the survivors of the earlier NEW particles (never taken in practice)
+                if (tid == 0) atomicOr(g.err, FW_ERR_LOOKBACK_TIMEOUT);
+                uint32_t c = 0;
+                for (uint32_t i = n_in + tid; i < base; i += BLK) {
+                    const uint32_t k = i - n_in;
+                    uint32_t oi = o0;
+                    for (uint32_t j = o0; j < o1; j++)
+                        if (k >= FW_OP(j).rel_base && k - FW_OP(j).rel_base < FW_OP(j).n) oi = j;
+                    const FwOp &op = FW_OP(oi);
+                    const FwEmit &e = g.emits[op.emit];
+                    const unsigned long long serial = op.serial_base + (k - op.rel_base);
+                    const fw_u4 o = fw_philox4x32_10(
+                        fw_u4{(uint32_t)serial, (uint32_t)(serial >> 32), e.emission_index, 2u}, g.seed, e.uid);
+                    float an;
+                    c += fw_survives(0.0f, a.dt, fw_unit_f32(o.x) * (e.life_max - e.life_min) + e.life_min, &an) ? 1u : 0u;
+                }
+                c = fw_wave_sum(c);
+                __syncthreads();
+                if (lane == 0) s_lb[wave] = c;
+                __syncthreads();
+                lb_excl = 0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) lb_excl += s_lb[w];
+            }
+        }
+        if (tid == 0)
+            __hip_atomic_store(&g.tile_status[tile], fw_pack_status(a.epoch, FW_ST_INCL, lb_excl + new_cnt), RLX, AGENT);
+        excl += lb_excl;
+    }
+
+    const unsigned long long ts2 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long tsR1 = 0;
+    const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
+    const uint32_t fcA = excl / FW_TILE, fc_bnd = (fcA + 1u) * FW_TILE;
+    FwRoundOut acc{0u, 0u};
+    uint32_t run = excl;
+    if (!has_new) {
+        // ---- live tile: stream the rounds
+#pragma unroll 1
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = base + r * BLK + tid;
+            float4 q0n = make_float4(0.f, 0.f, 0.f, 0.f), q1n = q0n, q2n = q0n, q3n = q0n;
+            if (r + 1 < R && idx + BLK < lim) {
+                q0n = fw_ld4(ib + FW_OFF_Q0(C), idx + BLK);
+                q3n = fw_ld4(ib + FW_OFF_Q3(C), idx + BLK);
+                q1n = fw_ld4(ib + FW_OFF_Q1(C), idx + BLK);
+                q2n = fw_ld4(ib + FW_OFF_Q2(C), idx + BLK);
+            }
+            const bool valid = idx < lim;
+            float age_new;
+            const bool alive = valid && fw_survives(q0c.w, a.dt, q3c.w, &age_new);
+            const unsigned long long m = __ballot(alive);
+            if (lane == 0) s_c[r & 1][wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t wbase = run;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const uint32_t c = s_c[r & 1][w];
+                if ((uint32_t)w < wave) wbase += c;
+                run += c;
+            }
+            const uint32_t o = wbase + fw_lane_prefix(m);
+            fw_round_finish(T, s_keys, a.dt, a.dbg, q0c, q1c, q2c, q3c, valid, alive, true, age_new, idx, o, ib, ob,
+                            destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc);
+            q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n;
+            if ((a.dbg & 8u) && r == 0) tsR1 = __builtin_amdgcn_s_memrealtime() + (o & 0u);
+        }
+    } else if (SPAWN != FW_SPAWN_NONE) {
+        // ---- new-particle tile: spawn_particles (src/core.rs:437-469) right before update_particles, per slot
+#pragma unroll 1
+        for (uint32_t r = 0; r < vt_rounds; r++) {
+            const uint32_t idx = base + r * BLK + tid;
+            const bool valid = idx < lim;
+            FwSpawnOut so;
+            so.q0 = so.q1 = so.q2 = so.q3 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) {
+                const uint32_t k = idx - n_in;
+                uint32_t oi = o0;
+                for (uint32_t i = o0; i < o1; i++)
+                    if (k >= FW_OP(i).rel_base && k - FW_OP(i).rel_base < FW_OP(i).n) oi = i;
+                const FwOp &op = FW_OP(oi);
+                so = fw_spawn_one(g.emits[op.emit], g.seed, op.serial_base + (k - op.rel_base),
+                                  fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
+                                  fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
+                                  fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
+            }
+            float age_new;
+            const bool alive = valid && fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);
+            const unsigned long long m = __ballot(alive);
+            if (lane == 0) s_c[r & 1][wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t wbase = run;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const uint32_t c = s_c[r & 1][w];
+                if ((uint32_t)w < wave) wbase += c;
+                run += c;
+            }
+            const uint32_t o = wbase + fw_lane_prefix(m);
+            fw_round_finish(T, s_keys, a.dt, a.dbg, so.q0, so.q1, so.q2, so.q3, valid, alive, false, age_new, idx, o, ib,
+                            ob, destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc);
+        }
+    }
+    if (lane == 0) s_part[2][wave] = acc.fa, s_part[3][wave] = acc.fb;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t sa = 0, sb = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) sa += s_part[2][w], sb += s_part[3][w];
+        fc_out[tile] = make_uint4(sa, sb, fcA, a.epoch);
+    }
+    if ((a.dbg & 8u) && g.dbg_ts && tid == 0) {
+        unsigned long long *d = g.dbg_ts + (size_t)tile * 8;
+        d[0] = ts0, d[1] = ts1, d[2] = ts2, d[3] = __builtin_amdgcn_s_memrealtime();
+        // HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20): which CU / XCD ran this tile
+        const unsigned hwid = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
+        const unsigned xcc = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 20);
+        d[4] = tsA, d[5] = tsB, d[6] = ((unsigned long long)xcc << 32) | hwid, d[7] = tsR1;
+    }
+    if (is_last && tid == 0) {
+        const uint32_t nc = run;  // excl + survivors of this tile
+        g.count[oidx] = nc;
+        g.spawned[oidx] = 0;
+        g.appended[oidx] = 0;
+        g.ndestroyed[seg] = n_tot - nc;
+        if (a.host_counts) a.host_counts[seg] = nc;
+        atomicAdd(g.stats, (unsigned long long)n_tot);
+    }
+}
+
 // split mode, pass 1: survivors per tile
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_count(FwGlobals g, FwUpdateArgs a) {
     __shared__ uint32_t s_c[4];
@@ -1088,6 +1418,13 @@ static void fw_launch_update_r(hipStream_t s, const FwGlobals &g, const FwUpdate
         hipLaunchKernelGGL(fw_k_count, grid, dim3(FW_BLOCK), 0, s, g, a);
         hipLaunchKernelGGL(fw_k_scan, dim3(a.n_seg), dim3(FW_BLOCK), 0, s, g, a);
         hipLaunchKernelGGL((fw_k_update<false, FW_SPAWN_NONE, R>), grid, block, 0, s, g, a, io);
+    } else if (a.use_stream && a.fc_in && a.fc_out) {  // forecast frame: streaming schedule
+        if (spawn_form == FW_SPAWN_INLINE)
+            hipLaunchKernelGGL((fw_k_update_stream<FW_SPAWN_INLINE>), grid, dim3(FW_BLOCK), 0, s, g, a, io);
+        else if (spawn_form == FW_SPAWN_TABLE)
+            hipLaunchKernelGGL((fw_k_update_stream<FW_SPAWN_TABLE>), grid, dim3(FW_BLOCK), 0, s, g, a, io);
+        else
+            hipLaunchKernelGGL((fw_k_update_stream<FW_SPAWN_NONE>), grid, dim3(FW_BLOCK), 0, s, g, a, io);
     } else if (spawn_form == FW_SPAWN_INLINE) {
         hipLaunchKernelGGL((fw_k_update<true, FW_SPAWN_INLINE, R>), grid, block, 0, s, g, a, io);
     } else if (spawn_form == FW_SPAWN_TABLE) {
