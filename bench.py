@@ -186,7 +186,7 @@ def main():
                 except Exception:
                     traffic = None
             out["roofline"] = {
-                "bound": "hbm", "kernel": "fw_k_update<fused>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": "fw_k_update_stream (forecast frames; fw_k_update<fused> when dt changes)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_particle": ALGO_BYTES, "moved_bytes_per_particle": ACTUAL_BYTES,
                 "particles_per_launch": per_launch, "avg_kernel_us": kt * 1e6, "launches": ev_launches,

@@ -10,11 +10,12 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01/pmc_summary.txt"
 txt = open(src).read()
-fetch = float(re.search(r"fw_k_update<true, 1, 4>\s+FETCH_SIZE=([0-9.e+]+)", txt).group(1))
-write = float(re.search(r"fw_k_update<true, 1, 4>\s+WRITE_SIZE=([0-9.e+]+)", txt).group(1))
+kern = "fw_k_update_stream<1>"  # the steady-state kernel of the bench (forecast frames with inline spawn ops)
+fetch = float(re.search(re.escape(kern) + r"\s+FETCH_SIZE=([0-9.e+]+)", txt).group(1))
+write = float(re.search(re.escape(kern) + r"\s+WRITE_SIZE=([0-9.e+]+)", txt).group(1))
 out = {
     "source": src,
-    "kernel": "fw_k_update<true, 1, 4>",
+    "kernel": kern,
     "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
     "fetch_bytes_corrected": 2 * fetch * 1024, "write_bytes": write * 1024,
     "fw_k_update_bytes_per_launch": 2 * fetch * 1024 + write * 1024,

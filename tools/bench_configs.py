@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE.json configs on one GPU (not the bench line; for DESIGN.md / profiles)."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bevy_firework_amd import workloads, sharding
+from bevy_firework_amd.system import ParticleSystem
+
+dt = np.float32(1 / 60)
+
+
+def run(name, spawners, fill, steps, uids=None):
+    ps = ParticleSystem(seed=workloads.SEED)
+    for i, (sp, tf) in enumerate(spawners):
+        ps.spawn(sp, tf, uid=(uids[i] if uids else i))
+    ps.update(dt)
+    for _ in range(fill):
+        ps.step(dt)
+    ps.synchronize()
+    u0 = ps.updated_total()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ps.step(dt)
+    ps.synchronize()
+    el = time.perf_counter() - t0
+    upd = ps.updated_total() - u0
+    live = ps.live_count()
+    print(json.dumps({"config": name, "live": live, "us_per_step": el / steps * 1e6, "particles_per_s": upd / el,
+                      "algorithmic_GBps": upd / el * 156 / 1e9}))
+    ps.close()
+
+
+which = sys.argv[1:] or ["c3", "c4", "c5", "c1"]
+if "c1" in which:
+    run("configs[0] stress_test rate 160000", [workloads.stress_test(160000.0)], 70, 600)
+if "c3" in which:
+    run("configs[2] 256 emitters x 64Ki", workloads.many_emitters(256, 65536), 80, 100)
+if "c5" in which:
+    ems = workloads.many_emitters(4096, 8192)
+    mine = sharding.local_indices(4096, 0, 8)
+    run("configs[4] one GPU's share: 512 of 4096 emitters x 8192", [ems[e] for e in mine], 80, 200, uids=mine)
+if "c4" in which:
+    run("configs[3] nested sparks->smoke ~4M", [workloads.nested(100000.0, 20.0)], 250, 100)
