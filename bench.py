@@ -88,7 +88,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the particle path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("FW_BENCH_FORCE_DIST"):  # the env knob exercises the RCCL path on one GPU
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -109,20 +109,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    counts_ring = torch.zeros(max(args.reduce_every, 1), dtype=torch.int64, device="cuda")
+    # per-frame live totals land in a device ring (written by the update kernel itself, no extra launch); every
+    # --reduce-every frames one RCCL all-reduce carries the whole bucket
+    ring_n = 2 * max(args.reduce_every, 1)
+    counts_ring = torch.zeros(ring_n, dtype=torch.int64, device="cuda")
     global_live = None
+    frames_done = 0
+    if dist is not None:
+        ps.live_count_ring(counts_ring.data_ptr(), ring_n)
 
     def run(n_steps):
-        nonlocal global_live
-        for k in range(n_steps):
+        nonlocal global_live, frames_done
+        for _ in range(n_steps):
             ps.step(dt)
-            if dist is not None:
-                slot = k % args.reduce_every
-                ps.live_count_device(counts_ring.data_ptr() + 8 * slot)
-                if slot == args.reduce_every - 1:
-                    with torch.cuda.stream(stream):
-                        global_live = counts_ring.clone()
-                        dist.all_reduce(global_live)  # RCCL over xGMI: live counts only
+            frames_done += 1
+            if dist is not None and frames_done % args.reduce_every == 0:
+                lo = (frames_done - args.reduce_every) % ring_n
+                with torch.cuda.stream(stream):
+                    global_live = counts_ring[lo:lo + args.reduce_every].clone()
+                    dist.all_reduce(global_live)  # RCCL over xGMI: live counts only
 
     # fill to steady state (setup), then the untimed warm-up
     ps.update(dt)

@@ -213,6 +213,7 @@ SYMBOLS = [
     ("fw_spawner_aabb", C.c_int, [_P, C.c_int32, _F3, _F3, C.POINTER(C.c_int32)]),
     ("fw_ctx_live_count", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("fw_ctx_live_count_device", C.c_int, [_P, _P]),
+    ("fw_ctx_live_count_ring", C.c_int, [_P, _P, C.c_uint32]),
     ("fw_ctx_last_step_updated", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("fw_ctx_kernel_timing", C.c_int, [_P, C.c_int32]),
     ("fw_ctx_kernel_timing_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

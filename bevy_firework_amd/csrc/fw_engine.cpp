@@ -171,6 +171,10 @@ struct fw_ctx {
     uint64_t timing_particles_start = 0;
     double tev_overhead_ms = 0;  // duration of an empty hipEvent pair on this stream
 
+    unsigned long long *live_ring = nullptr;  // caller-owned device ring of per-frame live totals
+    uint32_t live_ring_n = 0;
+    uint64_t live_ring_frames = 0;            // frames written since the ring was registered
+
     float *d_aabb = nullptr;
     unsigned long long *d_total = nullptr;
     uint32_t *d_segids = nullptr;
@@ -1208,6 +1212,11 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     a.seg0_keys_off = n_seg ? ctx->segs[0].keys_off : 0;
     a.seg0_keys_len = n_seg ? ctx->segs[0].keys_len : 0;
     a.tile_keys = ctx->d_tile_keys;
+    if (ctx->live_ring) {
+        a.live_out = ctx->live_ring + (ctx->live_ring_frames % ctx->live_ring_n);
+        a.live_next = ctx->live_ring + ((ctx->live_ring_frames + 1) % ctx->live_ring_n);
+        ctx->live_ring_frames++;
+    }
     a.use_stream = ctx->use_stream ? 1u : 0u;
     for (uint32_t i = 0; i < n_seg && a.use_stream; i++)
         if (ctx->tiles_dev[i] > FW_FC_MAX_TILES) a.use_stream = 0;
@@ -1597,6 +1606,18 @@ fw_status fw_ctx_live_count_device(fw_ctx *ctx, void *d_out_u64) {
     hipSetDevice(ctx->device);
     FW_HIP(ctx, fw_launch_total(ctx->stream, ctx->g.count + (size_t)ctx->parity * ctx->max_seg,
                                 (uint32_t)ctx->segs.size(), (unsigned long long *)d_out_u64));
+    return FW_OK;
+}
+
+fw_status fw_ctx_live_count_ring(fw_ctx *ctx, void *d_ring_u64, uint32_t n_slots) {
+    if (!ctx || (d_ring_u64 && n_slots < 2)) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    fw_status st = sync(ctx);
+    if (st) return st;
+    ctx->live_ring = (unsigned long long *)d_ring_u64;
+    ctx->live_ring_n = d_ring_u64 ? n_slots : 0;
+    ctx->live_ring_frames = 0;
+    if (d_ring_u64) FW_HIP(ctx, hipMemset(d_ring_u64, 0, (size_t)n_slots * sizeof(unsigned long long)));
     return FW_OK;
 }
 

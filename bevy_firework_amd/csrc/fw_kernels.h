@@ -55,6 +55,9 @@ struct FwUpdateArgs {
     uint32_t use_stream;           // forecast frames: run fw_k_update_stream (every segment within FW_FC_MAX_TILES)
     uint32_t seg0_keys_off, seg0_keys_len;  // key pool window of segment 0's type (n_seg == 1)
     const uint2 *tile_keys;        // [n_seg] {keys_off, keys_len} of each segment's type (device)
+    // optional per-frame total of live particles (feed of the RCCL all-reduce): every segment's finalizer adds its
+    // new count to *live_out; workgroup 0 zeroes *live_next (the slot the next frame will use)
+    unsigned long long *live_out, *live_next;
     const uint4 *fc_in;            // null = forecast not applicable this frame -> decoupled look-back
     uint4 *fc_out;
 };

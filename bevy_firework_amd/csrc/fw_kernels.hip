@@ -459,6 +459,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
                 g.ndestroyed[seg] = 0;
                 if (a.host_counts) a.host_counts[seg] = 0;
             }
+            if (blockIdx.x == 0 && a.live_next) *a.live_next = 0ull;
         }
         return;
     }
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         atomicOr(g.err, FW_ERR_CAPACITY);
         g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;  // diagnostics
     }
+    if (blockIdx.x == 0 && tid == 0 && a.live_next) *a.live_next = 0ull;
 
     // field-wise reads (block-uniform -> scalar loads)
     const FwSeg *Sp = &g.segs[seg];
@@ -708,6 +710,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         g.appended[oidx] = 0;
         g.ndestroyed[seg] = n_tot - nc;
         if (a.host_counts) a.host_counts[seg] = nc;
+        if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
         atomicAdd(g.stats, (unsigned long long)n_tot);
     }
 }
@@ -831,6 +834,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
                 g.ndestroyed[seg] = 0;
                 if (a.host_counts) a.host_counts[seg] = 0;
             }
+            if (blockIdx.x == 0 && a.live_next) *a.live_next = 0ull;
         }
         return;
     }
@@ -839,6 +843,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         atomicOr(g.err, FW_ERR_CAPACITY);
         g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;
     }
+    if (blockIdx.x == 0 && tid == 0 && a.live_next) *a.live_next = 0ull;
     const FwSeg *Sp = &g.segs[seg];
     const uint32_t C = Sp->capacity;
     const uint32_t n_lplanes = Sp->n_lplanes;
@@ -1038,6 +1043,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         g.appended[oidx] = 0;
         g.ndestroyed[seg] = n_tot - nc;
         if (a.host_counts) a.host_counts[seg] = nc;
+        if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
         atomicAdd(g.stats, (unsigned long long)n_tot);
     }
 }

@@ -244,6 +244,10 @@ class ParticleSystem:
     def live_count_device(self, device_ptr: int) -> None:
         self._check(self._lib.fw_ctx_live_count_device(self._ctx, C.c_void_p(device_ptr)))
 
+    def live_count_ring(self, device_ptr: int, n_slots: int) -> None:
+        """Every later step leaves its frame's total live count in ring[k % n_slots] (device uint64), no extra launch."""
+        self._check(self._lib.fw_ctx_live_count_ring(self._ctx, C.c_void_p(device_ptr) if device_ptr else None, int(n_slots)))
+
     def updated_total(self) -> int:
         out = C.c_uint64()
         self._check(self._lib.fw_ctx_last_step_updated(self._ctx, C.byref(out)))

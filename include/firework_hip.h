@@ -191,6 +191,10 @@ fw_status fw_ctx_live_count(fw_ctx *ctx, uint64_t *out);
 /* enqueue a write of the total live count into a caller-owned DEVICE uint64 (no
  * sync): feed for the RCCL all-reduce of live counts across GPUs */
 fw_status fw_ctx_live_count_device(fw_ctx *ctx, void *d_out_u64);
+/* register a caller-owned DEVICE ring of n_slots (>= 2) uint64: from now on every fw_step leaves the total live
+ * count of its frame in slot (k mod n_slots), k = frames stepped since registration, at no extra launch
+ * (written by the update kernel itself).  NULL unregisters.  Bucketed RCCL all-reduce feed. */
+fw_status fw_ctx_live_count_ring(fw_ctx *ctx, void *d_ring_u64, uint32_t n_slots);
 /* running total of particles that entered update_particles (after spawn) since the context was created */
 fw_status fw_ctx_last_step_updated(fw_ctx *ctx, uint64_t *out);
 

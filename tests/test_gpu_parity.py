@@ -223,3 +223,83 @@ def test_instances_aabb_and_invalid_settings(system):
     bad = S.ParticleSpawner([S.ParticleSettings()], [S.EmissionSettings(particle_index=3)])
     with pytest.raises(FwError):  # index panic core.rs:392 -> FW_EINVAL
         system.spawn(bad)
+
+
+def test_capacity_growth_on_demand(system):
+    """Vec growth: bursts far beyond the derived capacity (4096 for an OnDemand entry) must grow the device
+    buffers without losing or reordering particles"""
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.2, 0.6))
+    pair = Pair(system, S.ParticleSpawner([ps], [S.EmissionSettings(emission_pacing=S.EmissionPacing.OnDemand())]),
+                seed=SEED, uid=31)
+    for fr in range(30):
+        if fr in (0, 1, 5, 6, 7, 20):
+            pair.queue(30000 + 1000 * fr)
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr % 5 == 4:
+            pair.check(exact_all=True, what=f"growth f{fr}")
+    assert pair.gpu.count(0) > 25000
+
+
+def test_nested_overflow_reports_capacity(system):
+    """children beyond the child type's device capacity are dropped and reported, never written out of bounds"""
+    from bevy_firework_amd.system import FwError
+
+    spawner, tf = workloads.nested(spark_rate=3000.0, smoke_per_spark=20.0)
+    spawner.particle_settings[1].capacity = 2048
+    h = system.spawn(spawner, tf, uid=12)
+    for _ in range(80):
+        system.update(DT)
+    with pytest.raises(FwError) as e:
+        h.counts()
+    assert e.value.status == -4  # FW_ECAPACITY
+    c = h.counts()  # flag is cleared once reported; state stays consistent
+    assert c[1] <= 2048 and c[0] > 3000
+
+
+@pytest.mark.parametrize("env", [{"FW_FORECAST": "0", "FW_SPIN_LIMIT": "0"}, {"FW_UPDATE_MODE": "split"},
+                                 {"FW_STREAM": "0"}])
+def test_alternative_prefix_paths(monkeypatch, env):
+    """the other ways a tile can obtain its output offset must give the same particles: the look-back's
+    recount fallback (spin limit 0 forces it wherever a predecessor has not published yet), the three-launch
+    split mode, and forecast frames on the count-park-store kernel"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    from bevy_firework_amd.system import ParticleSystem
+
+    with ParticleSystem(device=0, seed=SEED) as ps_:
+        ps = S.ParticleSettings(lifetime=S.RandF32(0.05, 1.2), linear_drag=0.3)
+        es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(150000.0),
+                                initial_velocity=S.RandVec3(S.RandF32(0.0, 3.0), (0.0, 1.0, 0.0), 0.0))
+        pair = Pair(ps_, S.ParticleSpawner([ps], [es]), seed=SEED, uid=41)
+        for fr in range(80):
+            ps_.update(DT)
+            pair.step_cpu(DT)
+            if fr % 20 == 19:
+                pair.check(exact_all=True, what=f"{env} f{fr}")
+        assert pair.gpu.count(0) > 60000
+
+
+def test_live_count_ring(system):
+    """per-frame live totals written by the update kernel into a caller-owned device ring (RCCL feed)"""
+    import torch
+
+    spawner, tf = workloads.stress_test(rate=30000.0)
+    pairs = [Pair(system, spawner, tf, seed=SEED, uid=50 + i) for i in range(3)]  # three segments
+    ring = torch.zeros(8, dtype=torch.int64, device="cuda")
+    system.update(DT)
+    for p in pairs:
+        p.step_cpu(DT)
+    system.live_count_ring(ring.data_ptr(), 8)
+    want = []
+    for fr in range(21):
+        system.step(DT)
+        for p in pairs:
+            p.step_cpu(DT)
+        want.append(sum(p.cpu.count(0) for p in pairs))
+    system.synchronize()
+    got = ring.cpu().tolist()
+    for k in range(21 - 7, 21):  # the slot of frame 21 (k % 8 == 5) was zeroed for the next frame
+        assert got[k % 8] == want[k], (k, got, want[-8:])
+    assert system.live_count() == want[-1]
+    system.live_count_ring(0, 0)
