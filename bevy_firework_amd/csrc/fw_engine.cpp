@@ -102,7 +102,6 @@ struct fw_ctx {
     bool own_stream = false;
     std::string err;
     int update_mode = FW_MODE_FUSED;
-    int update_rounds = 4;  // particles per thread in fw_k_update (1, 2 or 4); FW_UPDATE_ROUNDS overrides
     uint32_t spin_limit = 1u << 16;
     uint32_t dbg = 0;  // FW_DEBUG: profiling-only kernel ablations (results are wrong when set)
 
@@ -934,7 +933,6 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_FORECAST")) ctx->use_forecast = atoi(m) != 0;
     if (const char *m = getenv("FW_STREAM")) ctx->use_stream = atoi(m) != 0;
     if (const char *m = getenv("FW_SNAP_EVERY")) ctx->snap_every = std::max(1, atoi(m));
-    if (const char *m = getenv("FW_UPDATE_ROUNDS")) ctx->update_rounds = atoi(m);
     if (const char *m = getenv("FW_SPIN_LIMIT")) ctx->spin_limit = (uint32_t)strtoul(m, nullptr, 10);
     if (ensure_max_seg(ctx, 1024) != FW_OK) {
         g_create_error = ctx->err;
@@ -1340,7 +1338,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     const bool timed = ctx->timing && ctx->tev_used + 2 <= ctx->tev.size();
     if (timed) FW_HIP(ctx, hipEventRecord(ctx->tev[ctx->tev_used], ctx->stream));
     FW_HIP(ctx, fw_launch_update(ctx->stream, ctx->g, a, spawn_form == FW_SPAWN_INLINE ? &inl : nullptr, spawn_form,
-                                 ctx->update_mode, ctx->update_rounds));
+                                 ctx->update_mode));
     if (timed) {
         FW_HIP(ctx, hipEventRecord(ctx->tev[ctx->tev_used + 1], ctx->stream));
         ctx->tev_used += 2;
