@@ -34,6 +34,7 @@ constexpr int kSnapEvery = 4;    // frames between snapshots
 constexpr int kTabRing = 4;      // staging buffers for tile-table uploads
 constexpr uint64_t kResidentSlots = 1024;  // fw_k_update workgroups resident at once on MI355X (256 CUs x 4)
 constexpr uint32_t kMinCapacity = 4096;
+constexpr uint32_t kNoSeg = 0xFFFFFFFFu;  // SpawnerHost::seg entry not built yet
 constexpr uint64_t kMaxSpawnPerOp = 1ull << 30;
 constexpr uint32_t kTimingEvents = 4096;
 
@@ -57,6 +58,7 @@ struct EmissionHost {
     uint64_t serial = 0;      // RNG stream position (Global entries; Nested ones live on the device)
     uint32_t emit_idx = 0;    // -> FwEmit
     uint32_t emit_slot = 0;   // -> device serial counter (Nested)
+    bool assigned = false;    // emit_idx / emit_slot are owned by this entry
 };
 
 struct SegHost {
@@ -108,7 +110,9 @@ struct fw_ctx {
     std::vector<SpawnerHost> spawners;
     std::vector<SegHost> segs;
     uint32_t n_types = 0, n_emits = 0, n_emit_slots = 0;
-    size_t keys_used = 0;
+    // table slots of destroyed / rebuilt spawners, reused by the next build (a type owns the key window
+    // [type_idx * FW_KEYS_MAX, +FW_KEYS_MAX) of the key pool, so windows are recycled with their type)
+    std::vector<uint32_t> free_types, free_emits, free_emit_slots;
 
     FwGlobals g{};
     DevArray<FwSeg> d_segs;
@@ -557,13 +561,14 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
     sp.starts_enabled = d->starts_enabled;
     sp.types.assign(nt, TypeHost{});
     sp.em.assign(ne, EmissionHost{});
-    sp.seg.assign(nt, 0);
+    sp.seg.assign(nt, kNoSeg);
 
     fw_status st;
     if ((st = dev_reserve(ctx, ctx->d_types, ctx->n_types + nt, ctx->n_types))) return st;
     if ((st = dev_reserve(ctx, ctx->d_emits, ctx->n_emits + ne, ctx->n_emits))) return st;
     if ((st = dev_reserve(ctx, ctx->d_emit_serial, ctx->n_emit_slots + ne, ctx->n_emit_slots))) return st;
-    if ((st = dev_reserve(ctx, ctx->d_keys, ctx->keys_used + (size_t)nt * FW_KEYS_MAX, ctx->keys_used))) return st;
+    if ((st = dev_reserve(ctx, ctx->d_keys, (size_t)(ctx->n_types + nt) * FW_KEYS_MAX, (size_t)ctx->n_types * FW_KEYS_MAX)))
+        return st;
     if ((st = dev_reserve(ctx, ctx->d_segs, ctx->segs.size() + nt, ctx->segs.size()))) return st;
     if ((st = ensure_max_seg(ctx, (uint32_t)ctx->segs.size() + nt))) return st;
     ctx->g.types = ctx->d_types.d, ctx->g.emits = ctx->d_emits.d, ctx->g.keys = ctx->d_keys.d;
@@ -606,12 +611,17 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         dt.o_em_t = put(T.emis.times, pad4(T.emis.n));
         dt.o_em_v = put(T.emis.values, 4 * T.emis.n);
         if (keys.size() > FW_KEYS_MAX) return fail(ctx, FW_EINVAL, "curve keys exceed the LDS staging area");
-        dt.keys_off = (uint32_t)ctx->keys_used;
+        uint32_t type_idx;
+        if (!ctx->free_types.empty()) {
+            type_idx = ctx->free_types.back();
+            ctx->free_types.pop_back();
+        } else {
+            type_idx = ctx->n_types++;
+        }
+        dt.keys_off = type_idx * FW_KEYS_MAX;
         dt.keys_len = (uint32_t)keys.size();
-        FW_HIP(ctx, hipMemcpy(ctx->d_keys.d + ctx->keys_used, keys.data(), keys.size() * sizeof(float),
+        FW_HIP(ctx, hipMemcpy(ctx->d_keys.d + dt.keys_off, keys.data(), keys.size() * sizeof(float),
                               hipMemcpyHostToDevice));
-        ctx->keys_used += keys.size();
-        const uint32_t type_idx = ctx->n_types++;
         FW_HIP(ctx, hipMemcpy(ctx->d_types.d + type_idx, &dt, sizeof dt, hipMemcpyHostToDevice));
 
         // segment
@@ -675,8 +685,19 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             for (uint32_t k = 0; k < P.n_lplanes; k++)
                 if (P.lplane_emission[k] == (int32_t)i) de.n_lplane = k;
         }
-        E.emit_idx = ctx->n_emits++;
-        E.emit_slot = ctx->n_emit_slots++;
+        if (!ctx->free_emits.empty()) {
+            E.emit_idx = ctx->free_emits.back();
+            ctx->free_emits.pop_back();
+        } else {
+            E.emit_idx = ctx->n_emits++;
+        }
+        if (!ctx->free_emit_slots.empty()) {
+            E.emit_slot = ctx->free_emit_slots.back();
+            ctx->free_emit_slots.pop_back();
+        } else {
+            E.emit_slot = ctx->n_emit_slots++;
+        }
+        E.assigned = true;
         FW_HIP(ctx, hipMemcpy(ctx->d_emits.d + E.emit_idx, &de, sizeof de, hipMemcpyHostToDevice));
         const unsigned long long s0 = E.serial;
         FW_HIP(ctx, hipMemcpy(ctx->d_emit_serial.d + E.emit_slot, &s0, sizeof s0, hipMemcpyHostToDevice));
@@ -688,9 +709,17 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
 fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
     ctx->fc_ok = false;
     ctx->tab_force = true;
+    for (const EmissionHost &e : sp.em) {
+        if (!e.assigned) continue;  // a build that failed half-way
+        ctx->free_emits.push_back(e.emit_idx);
+        ctx->free_emit_slots.push_back(e.emit_slot);
+    }
+    sp.em.clear();
     for (uint32_t si : sp.seg) {
+        if (si == kNoSeg) continue;
         SegHost &S = ctx->segs[si];
         if (!S.in_use) continue;
+        ctx->free_types.push_back(S.type_idx);
         if (S.buf[0]) FW_HIP(ctx, hipFree(S.buf[0]));
         if (S.destroyed) FW_HIP(ctx, hipFree(S.destroyed));
         S = SegHost{};
@@ -723,7 +752,9 @@ fw_status update_tile_table(fw_ctx *ctx) {
     ctx->tiles_dev.resize(n_seg, 0);
     for (uint32_t i = 0; i < n_seg; i++) {
         const SegHost &S = ctx->segs[i];
-        const uint32_t need = seg_tiles(S, ctx->vt_rounds);
+        // provision for one-round new-particle tiles whatever vt_rounds says: a lone segment picks its tile size on
+        // the device from exact counts and may use the smaller tiles when the host, with looser bounds, would not
+        const uint32_t need = seg_tiles(S, 1);
         uint32_t &have = ctx->tiles_dev[i];
         if (!S.in_use) {
             if (have) have = 0, dirty = true;

@@ -781,8 +781,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         const uint2 kd = a.tile_keys[seg];
         keys_off = kd.x, keys_len = kd.y;
     }
-    // curve / gradient keys -> LDS: requested first, they have the longest way to go (global -> VGPR -> LDS)
-    for (uint32_t i = tid; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
+    // curve / gradient keys: requested first (into a register; they are moved to LDS after the other requests
+    // are out, so nothing waits for them here)
+    const float key0 = tid < keys_len ? g.keys[keys_off + tid] : 0.0f;
     uint32_t tis = blockIdx.x - first;
     // forecast entries of the whole segment, requested before anything else (they depend on the descriptor only)
     constexpr int FC_U = 8;
@@ -861,6 +862,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         q2c = fw_ld4(ib + FW_OFF_Q2(C), base + tid);
     }
     const FwType T = g.types[type_idx];  // scalar loads; first needed in the round loop
+    if (tid < keys_len) s_keys[tid] = key0;
+    for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
 
     // forecast prefix of this tile
     uint32_t fc_part = 0;

@@ -303,3 +303,23 @@ def test_live_count_ring(system):
         assert got[k % 8] == want[k], (k, got, want[-8:])
     assert system.live_count() == want[-1]
     system.live_count_ring(0, 0)
+
+
+def test_settings_churn_does_not_leak_slots(system):
+    """Changed<ParticleSpawner> every few frames and spawn/despawn cycles reuse their table slots"""
+    spawner, tf = workloads.stress_test(rate=8000.0)
+    pair = Pair(system, spawner, tf, seed=SEED, uid=60)
+    for cycle in range(40):
+        for _ in range(3):
+            system.update(DT)
+            pair.step_cpu(DT)
+        pair.gpu.update_settings(spawner)
+        pair.cpu.reset()
+        h = system.spawn(spawner, tf, uid=100 + cycle)
+        system.update(DT)
+        pair.step_cpu(DT)
+        system.despawn(h)
+    for _ in range(20):
+        system.update(DT)
+        pair.step_cpu(DT)
+    pair.check(what="after churn")
