@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "../../include/firework_hip.h"
@@ -74,6 +75,17 @@ struct SegHost {
     bool nested_fed = false;    // receives Nested children: count not host-predictable
     char *buf[2] = {nullptr, nullptr};
     char *destroyed = nullptr;
+    // Lifetime window: a particle is destroyed by the update in which age >= lifetime (core.rs:590-592), and
+    // lifetime <= life_bound, so everything alive was spawned less than life_bound of simulated time ago.  The sum of
+    // the Global spawn counts inside that window bounds the live count without any device feedback.
+    struct Spawned {
+        double t;    // simulated time at the spawn
+        uint64_t n;
+    };
+    std::deque<Spawned> win;
+    uint64_t win_sum = 0;
+    bool win_ok = false;
+    double life_bound = 0.0;
 };
 
 struct SpawnerHost {
@@ -163,6 +175,7 @@ struct fw_ctx {
     bool use_stream = true;    // FW_STREAM=0: forecast frames keep the count-park-store kernel (A/B)
 
     uint64_t frame = 0;
+    double sim_time = 0.0;  // sum of the dt of every step so far (lifetime windows)
     uint32_t parity = 0;
     unsigned long long stats_before_last = 0;
     bool stats_valid = false;
@@ -307,8 +320,8 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_status, ncap * sizeof(unsigned long long)));
         FW_HIP(ctx, hipMemset(ctx->g.tile_status, 0, ncap * sizeof(unsigned long long)));
         if (ctx->g.dbg_ts) hipFree(ctx->g.dbg_ts);
-        FW_HIP(ctx, hipMalloc((void **)&ctx->g.dbg_ts, 8 * ncap * sizeof(unsigned long long)));
-        FW_HIP(ctx, hipMemset(ctx->g.dbg_ts, 0, 8 * ncap * sizeof(unsigned long long)));
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.dbg_ts, (32768 + 8 * ncap) * sizeof(unsigned long long)));
+        FW_HIP(ctx, hipMemset(ctx->g.dbg_ts, 0, (32768 + 8 * ncap) * sizeof(unsigned long long)));
         if (ctx->d_fc) hipFree(ctx->d_fc);
         FW_HIP(ctx, hipMalloc((void **)&ctx->d_fc, 2 * ncap * sizeof(uint4)));
         FW_HIP(ctx, hipMemset(ctx->d_fc, 0, 2 * ncap * sizeof(uint4)));
@@ -643,6 +656,8 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
                 S.lplane_emission[S.n_lplanes++] = (int32_t)i;
             if (e.mode == FW_MODE_NESTED && (uint32_t)e.particle_index == t) S.nested_fed = true;
         }
+        S.life_bound = (double)std::max(p.lifetime.min, p.lifetime.max);  // lifetime = lerp(min, max, u), u in [0, 1)
+        S.win_ok = !S.nested_fed && std::isfinite(S.life_bound);
         if ((st = alloc_seg_buffers(ctx, S, caps[t], p.report_destroyed != 0))) return st;
         sp.seg[t] = si;
         if ((st = upload_seg(ctx, si))) return st;
@@ -1137,6 +1152,20 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     Level levels[FW_MAX_EMISSIONS];
     for (auto &S : ctx->segs) S.frame_spawn = 0;
 
+    // lifetime windows: drop the spawns that must have expired by now and tighten the bounds with what is left.
+    // (ages are fp32 sums of the same dt values on the device; the margin covers the rounding difference)
+    if (!(dt >= 0.0f) || !std::isfinite(dt))
+        for (auto &S : ctx->segs) S.win_ok = false;  // ages would not grow monotonically
+    for (auto &S : ctx->segs) {
+        if (!S.in_use || !S.win_ok) continue;
+        const double horizon = S.life_bound * (1.0 + 1e-3) + 1e-6;
+        while (!S.win.empty() && ctx->sim_time - S.win.front().t >= horizon) {
+            S.win_sum -= S.win.front().n;
+            S.win.pop_front();
+        }
+        if (S.win_sum < S.ub) S.ub = (uint32_t)S.win_sum;
+    }
+
     // spawn_particles, host half (core.rs:377-428): emission clocks and Global counts
     for (size_t h = 0; h < ctx->spawners.size(); h++) {
         SpawnerHost &sp = ctx->spawners[h];
@@ -1200,6 +1229,19 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 S.frame_spawn += (uint32_t)n;
                 S.cum_spawn += n;
                 S.ub = (uint32_t)std::min<uint64_t>((uint64_t)S.ub + n, 0xFFFFFFFFull);
+                if (S.win_ok) {
+                    if (!S.win.empty() && S.win.back().t == ctx->sim_time) {
+                        S.win.back().n += n;
+                    } else {
+                        if (S.win.size() >= 8192) {  // very long lifetimes: fold the two oldest entries into the newer
+                            const uint64_t m = S.win.front().n;
+                            S.win.pop_front();
+                            S.win.front().n += m;
+                        }
+                        S.win.push_back(SegHost::Spawned{ctx->sim_time, n});
+                    }
+                    S.win_sum += n;
+                }
             } else {
                 if (es.pacing_kind != FW_PACING_COUNT_OVER_DURATION) continue;  // warn_once + continue core.rs:474-485
                 const SegHost &P = ctx->segs[sp.seg[es.target_particle_type]];
@@ -1390,6 +1432,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     ctx->fc_tab_seq = ctx->tab_seq;
     ctx->parity ^= 1u;
     ctx->frame++;
+    ctx->sim_time += (double)dt;
     return FW_OK;
 }
 
@@ -1518,6 +1561,7 @@ fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, c
     const uint32_t n32 = (uint32_t)n;
     FW_HIP(ctx, hipMemcpy(ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, &n32, 4, hipMemcpyHostToDevice));
     S.ub = n32;
+    S.win_ok = false;  // ages and lifetimes are now whatever the caller wrote
     for (int i = 0; i < kSnapRing; i++) ctx->snap_pending[i] = false;
     return FW_OK;
 }
@@ -1716,15 +1760,36 @@ fw_status fw_ctx_kernel_timing_read(fw_ctx *ctx, double *ms_total, uint64_t *lau
     return FW_OK;
 }
 
-// profiling hook (not in the public header): per-tile timestamps of the last update when FW_DEBUG & 8
-fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_t max_tiles, uint64_t *n_tiles) {
+// profiling hook (not in the public header): per-tile timestamps of the last update (and, with `prev`, of the one
+// before it: the two are kept apart by launch parity) when FW_DEBUG & 8
+fw_status fw_debug_read_timestamps2(fw_ctx *ctx, unsigned long long *out, unsigned long long *prev, uint64_t max_tiles,
+                                    uint64_t *n_tiles) {
     if (!ctx || !ctx->g.dbg_ts) return FW_EINVAL;
     fw_status st = sync(ctx);
     if (st) return st;
     const uint64_t n = std::min<uint64_t>(max_tiles, ctx->total_tiles_dev);
     if (n_tiles) *n_tiles = n;
-    if (n && out) FW_HIP(ctx, hipMemcpy(out, ctx->g.dbg_ts, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const uint32_t last = (uint32_t)(ctx->frame & 1u);  // epoch of the last launch = frame (after the increment)
+    const size_t stride = (size_t)ctx->total_tiles_dev * 8;
+    if (n && out)
+        FW_HIP(ctx, hipMemcpy(out, ctx->g.dbg_ts + 32768 + last * stride, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (n && prev)
+        FW_HIP(ctx, hipMemcpy(prev, ctx->g.dbg_ts + 32768 + (last ^ 1u) * stride, n * 8 * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost));
     return FW_OK;
+}
+// {~earliest workgroup start [64], latest workgroup end [64]} of the last 256 update launches (slot = epoch & 255);
+// *epoch = the last launch's.  out512: room for 32768 words.
+fw_status fw_debug_read_launches(fw_ctx *ctx, unsigned long long *out512, uint32_t *epoch) {
+    if (!ctx || !ctx->g.dbg_ts || !out512) return FW_EINVAL;
+    fw_status st = sync(ctx);
+    if (st) return st;
+    FW_HIP(ctx, hipMemcpy(out512, ctx->g.dbg_ts, 32768 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (epoch) *epoch = (uint32_t)(ctx->frame & 0x3FFFFFFFu);
+    return FW_OK;
+}
+fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_t max_tiles, uint64_t *n_tiles) {
+    return fw_debug_read_timestamps2(ctx, out, nullptr, max_tiles, n_tiles);
 }
 
 fw_status fw_ctx_kernel_timing_overhead(fw_ctx *ctx, double *ms_per_pair) {

@@ -402,9 +402,9 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     uint4 fce[FC_U];
     if (use_fc) {
 #pragma unroll
-        for (int j = 0; j < FC_U; j++) {
+        for (int j = 0; j < FC_U; j++) {  // unconditional loads at a clamped index: all FC_U in flight at once
             const uint32_t t = tid + (uint32_t)j * BLK;
-            fce[j] = t < seg_tiles ? a.fc_in[first + t] : make_uint4(0u, 0u, 0u, a.epoch - 1u);
+            fce[j] = a.fc_in[first + min(t, seg_tiles - 1u)];
         }
     }
     const uint32_t p = a.parity;
@@ -485,11 +485,10 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         float4 t0[R], t3[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const uint32_t idx = base + r * BLK + tid;
-            if (!has_new && idx < lim) {
-                t0[r] = fw_ld4(ib + FW_OFF_Q0(C), idx);
-                t3[r] = fw_ld4(ib + FW_OFF_Q3(C), idx);
-            }
+            // unconditional, clamped into the tile (a predicated load would be waited for in its own basic block)
+            const uint32_t idx = has_new ? 0u : min(base + r * BLK + tid, lim - 1u);
+            t0[r] = fw_ld4(ib + FW_OFF_Q0(C), idx);
+            t3[r] = fw_ld4(ib + FW_OFF_Q3(C), idx);
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -499,10 +498,11 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     }
     const unsigned long long tsB = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // first round's Q1 / Q2 go out now; later rounds are prefetched one round ahead
-    float4 q1c = make_float4(0.f, 0.f, 0.f, 0.f), q2c = q1c;
-    if (!has_new && base + tid < lim) {
-        q1c = fw_ld4(ib + FW_OFF_Q1(C), base + tid);
-        q2c = fw_ld4(ib + FW_OFF_Q2(C), base + tid);
+    float4 q1c, q2c;
+    {
+        const uint32_t i0 = has_new ? 0u : min(base + tid, lim - 1u);
+        q1c = fw_ld4(ib + FW_OFF_Q1(C), i0);
+        q2c = fw_ld4(ib + FW_OFF_Q2(C), i0);
     }
 
     // per-type constants (scalar loads) and curve / gradient keys (staged in LDS) arrive under the loads
@@ -517,8 +517,9 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
 #pragma unroll
         for (int j = 0; j < FC_U; j++) {
             const uint4 e = fce[j];
-            fc_bad |= e.w != a.epoch - 1u;
-            fc_part += (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u));
+            const bool in = tid + (uint32_t)j * BLK < seg_tiles;  // beyond the table: a clamped duplicate, ignored
+            fc_bad |= in && e.w != a.epoch - 1u;
+            fc_part += in ? (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u)) : 0u;
         }
         for (uint32_t t = tid + FC_U * BLK; t < seg_tiles; t += BLK) {
             const uint4 e = a.fc_in[first + t];
@@ -647,11 +648,9 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     for (int r = 0; r < R; r++) {
         const uint32_t idx = base + r * BLK + tid;
         // prefetch the next round's Q1 / Q2 (new particles were materialised above, so idx < n_tot is enough)
-        float4 q1n = make_float4(0.f, 0.f, 0.f, 0.f), q2n = q1n;
-        if (r + 1 < R && !has_new && idx + BLK < lim) {
-            q1n = fw_ld4(ib + FW_OFF_Q1(C), idx + BLK);
-            q2n = fw_ld4(ib + FW_OFF_Q2(C), idx + BLK);
-        }
+        const uint32_t in_ = has_new ? 0u : min(idx + BLK, lim - 1u);  // clamped, unconditional
+        const float4 q1n = fw_ld4(ib + FW_OFF_Q1(C), in_);
+        const float4 q2n = fw_ld4(ib + FW_OFF_Q2(C), in_);
         const bool valid = idx < lim, loaded = !has_new;
         const float4 q0 = s_q0[r * BLK + tid], q3 = s_q3[r * BLK + tid];
         if (SPAWN != FW_SPAWN_NONE && has_new && valid)
@@ -699,8 +698,15 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     }
 
     if ((a.dbg & 8u) && g.dbg_ts && tid == 0) {
-        unsigned long long *d = g.dbg_ts + (size_t)tile * 8;
-        d[0] = ts0, d[1] = ts1, d[2] = ts2, d[3] = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *d = g.dbg_ts + 32768 + ((size_t)(a.epoch & 1u) * gridDim.x + tile) * 8;  // two launches kept
+        {  // ring of the last 256 launches: earliest start / latest end, spread over 64 words each to keep the atomics apart
+            unsigned long long *rg = g.dbg_ts + (size_t)(a.epoch & 255u) * 128u;
+            atomicMax(&rg[blockIdx.x & 63u], ~ts0);  // max of the complement = min (slots are recycled with 0)
+            atomicMax(&rg[64u + (blockIdx.x & 63u)], __builtin_amdgcn_s_memrealtime());
+            if (blockIdx.x < 128u) g.dbg_ts[(size_t)((a.epoch + 128u) & 255u) * 128u + blockIdx.x] = 0ull;
+        }
+        const unsigned long long tsE = __builtin_amdgcn_s_memrealtime();
+        d[0] = ts0, d[1] = ts1, d[2] = ts2, d[3] = tsE;
         d[4] = tsA, d[5] = tsB, d[6] = tsC, d[7] = 0;
     }
     if (is_last && tid == 0) {
@@ -788,10 +794,12 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     // forecast entries of the whole segment, requested before anything else (they depend on the descriptor only)
     constexpr int FC_U = 8;
     uint4 fce[FC_U];
+    // (unconditional loads at a clamped index: a predicated load would sit in its own basic block and be waited
+    // for before the next one is issued -- eight serial round trips instead of one)
 #pragma unroll
     for (int j = 0; j < FC_U; j++) {
         const uint32_t t = tid + (uint32_t)j * BLK;
-        fce[j] = t < seg_tiles ? a.fc_in[first + t] : make_uint4(0u, 0u, 0u, a.epoch - 1u);
+        fce[j] = a.fc_in[first + min(t, seg_tiles - 1u)];
     }
     const uint32_t p = a.parity;
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
@@ -854,12 +862,18 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
 
     const unsigned long long tsA = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (C & 0u)) : 0ull;
     // round 0 of a live tile goes out now
-    float4 q0c = make_float4(0.f, 0.f, 0.f, 0.f), q1c = q0c, q2c = q0c, q3c = q0c;
-    if (!has_new && base + tid < lim) {
-        q0c = fw_ld4(ib + FW_OFF_Q0(C), base + tid);
-        q3c = fw_ld4(ib + FW_OFF_Q3(C), base + tid);
-        q1c = fw_ld4(ib + FW_OFF_Q1(C), base + tid);
-        q2c = fw_ld4(ib + FW_OFF_Q2(C), base + tid);
+    // (Loads are issued UNCONDITIONALLY at an index clamped into the tile: a load under a lane predicate lives in
+    // its own basic block, and the copy into the merged value at the end of that block makes the compiler wait for
+    // it right there -- the "prefetch" would complete before anything else is issued.  A lane past the end simply
+    // re-reads the tile's last particle and ignores it.)
+    const uint32_t last = lim - 1u;  // lim > base for an active tile
+    float4 q0c, q1c, q2c, q3c;
+    {
+        const uint32_t i0 = has_new ? 0u : min(base + tid, last);
+        q0c = fw_ld4(ib + FW_OFF_Q0(C), i0);
+        q3c = fw_ld4(ib + FW_OFF_Q3(C), i0);
+        q1c = fw_ld4(ib + FW_OFF_Q1(C), i0);
+        q2c = fw_ld4(ib + FW_OFF_Q2(C), i0);
     }
     const FwType T = g.types[type_idx];  // scalar loads; first needed in the round loop
     if (tid < keys_len) s_keys[tid] = key0;
@@ -871,8 +885,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
 #pragma unroll
     for (int j = 0; j < FC_U; j++) {
         const uint4 e = fce[j];
-        fc_bad |= e.w != a.epoch - 1u;
-        fc_part += (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u));
+        const bool in = tid + (uint32_t)j * BLK < seg_tiles;  // beyond the table: a clamped duplicate, ignored
+        fc_bad |= in && e.w != a.epoch - 1u;
+        fc_part += in ? (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u)) : 0u;
     }
     for (uint32_t t = tid + FC_U * BLK; t < seg_tiles; t += BLK) {
         const uint4 e = a.fc_in[first + t];
@@ -961,13 +976,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
 #pragma unroll 1
         for (int r = 0; r < R; r++) {
             const uint32_t idx = base + r * BLK + tid;
-            float4 q0n = make_float4(0.f, 0.f, 0.f, 0.f), q1n = q0n, q2n = q0n, q3n = q0n;
-            if (r + 1 < R && idx + BLK < lim) {
-                q0n = fw_ld4(ib + FW_OFF_Q0(C), idx + BLK);
-                q3n = fw_ld4(ib + FW_OFF_Q3(C), idx + BLK);
-                q1n = fw_ld4(ib + FW_OFF_Q1(C), idx + BLK);
-                q2n = fw_ld4(ib + FW_OFF_Q2(C), idx + BLK);
-            }
+            const uint32_t in_ = min(idx + BLK, last);  // next round's slot (clamped: see above)
+            const float4 q0n = fw_ld4(ib + FW_OFF_Q0(C), in_);
+            const float4 q3n = fw_ld4(ib + FW_OFF_Q3(C), in_);
+            const float4 q1n = fw_ld4(ib + FW_OFF_Q1(C), in_);
+            const float4 q2n = fw_ld4(ib + FW_OFF_Q2(C), in_);
             const bool valid = idx < lim;
             float age_new;
             const bool alive = valid && fw_survives(q0c.w, a.dt, q3c.w, &age_new);
@@ -1032,8 +1045,15 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         fc_out[tile] = make_uint4(sa, sb, fcA, a.epoch);
     }
     if ((a.dbg & 8u) && g.dbg_ts && tid == 0) {
-        unsigned long long *d = g.dbg_ts + (size_t)tile * 8;
-        d[0] = ts0, d[1] = ts1, d[2] = ts2, d[3] = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *d = g.dbg_ts + 32768 + ((size_t)(a.epoch & 1u) * gridDim.x + tile) * 8;  // two launches kept
+        {  // ring of the last 256 launches: earliest start / latest end, spread over 64 words each to keep the atomics apart
+            unsigned long long *rg = g.dbg_ts + (size_t)(a.epoch & 255u) * 128u;
+            atomicMax(&rg[blockIdx.x & 63u], ~ts0);  // max of the complement = min (slots are recycled with 0)
+            atomicMax(&rg[64u + (blockIdx.x & 63u)], __builtin_amdgcn_s_memrealtime());
+            if (blockIdx.x < 128u) g.dbg_ts[(size_t)((a.epoch + 128u) & 255u) * 128u + blockIdx.x] = 0ull;
+        }
+        const unsigned long long tsE = __builtin_amdgcn_s_memrealtime();
+        d[0] = ts0, d[1] = ts1, d[2] = ts2, d[3] = tsE;
         // HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20): which CU / XCD ran this tile
         const unsigned hwid = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
         const unsigned xcc = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 20);

@@ -161,6 +161,40 @@ __global__ __launch_bounds__(256) void k_struct(const char* __restrict__ in, cha
 }
 
 // streaming twin: per round, prefetch the next round's 4 planes, then store the 7 output planes of the current one
+template <int KIND>
+__device__ __forceinline__ void st_kind(float4* p, float4 v) {
+    if (KIND == 0) { *p = v; }
+    else if (KIND == 1) { nt_st(v, p); }
+    else if (KIND == 2) { v4f x = {v.x, v.y, v.z, v.w}; asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory"); }
+    else { v4f x = {v.x, v.y, v.z, v.w}; asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(x) : "memory"); }
+}
+template <int R, int KIND>
+__global__ __launch_bounds__(256) void k_stream_st(const char* __restrict__ in, char* __restrict__ out, uint32_t n, uint32_t C) {
+    const uint32_t tid = threadIdx.x, base = blockIdx.x * 256 * R;
+    const float4* p0 = (const float4*)in; const float4* p1 = (const float4*)(in + (size_t)16 * C);
+    const float4* p2 = (const float4*)(in + (size_t)32 * C); const float4* p3 = (const float4*)(in + (size_t)48 * C);
+    float4 a = make_float4(0,0,0,0), b = a, c = a, d = a;
+    if (base + tid < n) { a = p0[base + tid]; b = p1[base + tid]; c = p2[base + tid]; d = p3[base + tid]; }
+#pragma unroll 1
+    for (int r = 0; r < R; r++) {
+        uint32_t i = base + r * 256 + tid;
+        float4 an = a, bn = b, cn = c, dn = d;
+        if (r + 1 < R && i + 256 < n) { an = p0[i + 256]; bn = p1[i + 256]; cn = p2[i + 256]; dn = p3[i + 256]; }
+        if (i < n) {
+            float4 e = make_float4(a.x + b.x, a.y * c.y, d.z, a.w);
+            float4 f = make_float4(b.w, c.x, d.y, e.x);
+            st_kind<KIND>(&((float4*)(out))[i], a);
+            st_kind<KIND>(&((float4*)(out + (size_t)16 * C))[i], b);
+            st_kind<KIND>(&((float4*)(out + (size_t)32 * C))[i], c);
+            st_kind<KIND>(&((float4*)(out + (size_t)48 * C))[i], d);
+            st_kind<KIND>(&((float4*)(out + (size_t)64 * C))[i], e);
+            st_kind<KIND>(&((float4*)(out + (size_t)80 * C))[i], f);
+            ((float*)(out + (size_t)96 * C))[i] = e.y;
+        }
+        a = an; b = bn; c = cn; d = dn;
+    }
+}
+
 template <int R, bool BAR = false>
 __global__ __launch_bounds__(256) void k_stream(const char* __restrict__ in, char* __restrict__ out, uint32_t n, uint32_t C) {
     __shared__ uint32_t s_c[2][4];
@@ -194,6 +228,44 @@ __global__ __launch_bounds__(256) void k_stream(const char* __restrict__ in, cha
             ((float*)(out + (size_t)96 * C))[i] = e.y;
         }
         a = an; b = bn; c = cn; d = dn;
+    }
+}
+
+// stream twin with the launch-span ring of the real kernel (first workgroup start / last workgroup end per launch)
+template <int R>
+__global__ __launch_bounds__(256) void k_stream_ts(const char* __restrict__ in, char* __restrict__ out, uint32_t n, uint32_t C,
+                                                   unsigned long long* ring, uint32_t epoch) {
+    const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t tid = threadIdx.x, base = blockIdx.x * 256 * R;
+    const float4* p0 = (const float4*)in; const float4* p1 = (const float4*)(in + (size_t)16 * C);
+    const float4* p2 = (const float4*)(in + (size_t)32 * C); const float4* p3 = (const float4*)(in + (size_t)48 * C);
+    float4 a = make_float4(0,0,0,0), b = a, c = a, d = a;
+    if (base + tid < n) { a = p0[base + tid]; b = p1[base + tid]; c = p2[base + tid]; d = p3[base + tid]; }
+    float acc = 0.f;
+#pragma unroll 1
+    for (int r = 0; r < R; r++) {
+        uint32_t i = base + r * 256 + tid;
+        float4 an = a, bn = b, cn = c, dn = d;
+        if (r + 1 < R && i + 256 < n) { an = p0[i + 256]; bn = p1[i + 256]; cn = p2[i + 256]; dn = p3[i + 256]; }
+        if (i < n) {
+            float4 e = make_float4(a.x + b.x, a.y * c.y, d.z, a.w);
+            float4 f = make_float4(b.w, c.x, d.y, e.x);
+            ((float4*)(out))[i] = a;
+            ((float4*)(out + (size_t)16 * C))[i] = b;
+            ((float4*)(out + (size_t)32 * C))[i] = c;
+            ((float4*)(out + (size_t)48 * C))[i] = d;
+            ((float4*)(out + (size_t)64 * C))[i] = e;
+            ((float4*)(out + (size_t)80 * C))[i] = f;
+            ((float*)(out + (size_t)96 * C))[i] = e.y;
+            acc += e.y;
+        }
+        a = an; b = bn; c = cn; d = dn;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long tsE = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(acc != acc ? 1 : 0);
+        atomicMin(&ring[(epoch & 255u) * 2u], ts0);
+        atomicMax(&ring[(epoch & 255u) * 2u + 1u], tsE);
     }
 }
 
@@ -249,6 +321,14 @@ int main(int argc, char** argv) {
         printf("struct v3 twin nobarrier    : %7.2f us  %8.1f GB/s\n", t * 1e6, 164.0 * n / t / 1e9);
         t = timeit([&](int i) { hipLaunchKernelGGL((k_stream<4>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
         printf("stream twin R=4  n=%8u    : %7.2f us  %8.1f GB/s\n", n, t * 1e6, 164.0 * n / t / 1e9);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_stream_st<4, 0>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("stream twin stores plain      : %7.2f us\n", t * 1e6);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_stream_st<4, 1>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("stream twin stores nt         : %7.2f us\n", t * 1e6);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_stream_st<4, 2>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("stream twin stores sc1        : %7.2f us\n", t * 1e6);
+        t = timeit([&](int i) { hipLaunchKernelGGL((k_stream_st<4, 3>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
+        printf("stream twin stores sc0 sc1    : %7.2f us\n", t * 1e6);
         t = timeit([&](int i) { hipLaunchKernelGGL((k_stream<4, true>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
         printf("stream twin R=4 +barrier/round: %7.2f us  %8.1f GB/s\n", t * 1e6, 164.0 * n / t / 1e9);
         t = timeit([&](int i) { hipLaunchKernelGGL((k_stream<16, true>), dim3((n + 4095) / 4096), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
@@ -257,6 +337,18 @@ int main(int argc, char** argv) {
         printf("stream twin R=8               : %7.2f us  %8.1f GB/s\n", t * 1e6, 164.0 * n / t / 1e9);
         t = timeit([&](int i) { hipLaunchKernelGGL((k_stream<16>), dim3((n + 4095) / 4096), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C); }, 50);
         printf("stream twin R=16              : %7.2f us  %8.1f GB/s\n", t * 1e6, 164.0 * n / t / 1e9);
+        {
+            unsigned long long* ring; CK(hipMalloc(&ring, 512 * 8));
+            std::vector<unsigned long long> h(512);
+            for (int i = 0; i < 256; i++) h[2 * i] = ~0ull, h[2 * i + 1] = 0ull;
+            CK(hipMemcpy(ring, h.data(), 512 * 8, hipMemcpyHostToDevice));
+            t = timeit([&](int i) { hipLaunchKernelGGL((k_stream_ts<4>), dim3((n + 1023) / 1024), dim3(256), 0, 0, (i&1)?p1:p0, (i&1)?p0:p1, n, C, ring, (uint32_t)(i + 64)); }, 50);
+            CK(hipMemcpy(h.data(), ring, 512 * 8, hipMemcpyDeviceToHost));
+            double span = 0, gap = 0; int cnt = 0;
+            for (int i = 70; i < 110; i++) { span += (double)(h[2*i+1] - h[2*i]) / 100.0; gap += (double)((long long)h[2*(i+1)] - (long long)h[2*i+1]) / 100.0; cnt++; }
+            printf("stream twin +span ring        : %7.2f us/launch; in-kernel span %.2f us, gap to next launch %.2f us\n", t * 1e6, span / cnt, gap / cnt);
+            CK(hipFree(ring));
+        }
         for (int blocks_per_cu : {1, 2, 3, 4, 6, 8}) {
             size_t lds = 160 * 1024 / blocks_per_cu - 1024;
             if (lds > 64 * 1024) { CK(hipFuncSetAttribute((const void*)k_planes_occ, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
