@@ -143,9 +143,12 @@ struct fw_ctx {
     bool consumed_pending[kParamRing] = {};
 
     // live-count snapshots written by the update kernel into pinned host memory
-    uint32_t *h_snap = nullptr;  // [kSnapRing][max_seg]
-    hipEvent_t ev_snap[kSnapRing] = {};
+    // Live-count snapshots: the update kernel stores {epoch, count} of each segment into a pinned row with one 8-byte
+    // store; the host recognises a finished row by its tag -- no event, no packet between launches.
+    unsigned long long *h_snap = nullptr;  // [kSnapRing][max_seg]
     bool snap_pending[kSnapRing] = {};
+    bool snap_seen[kSnapRing] = {};
+    uint32_t snap_epoch[kSnapRing] = {};
     std::vector<uint64_t> snap_cum[kSnapRing];  // cum_spawn of every segment when the frame was enqueued
 
     // device-resident segment -> tile table
@@ -266,9 +269,9 @@ fw_status ensure_max_seg(fw_ctx *ctx, uint32_t need) {
         ctx->g.ndestroyed = np;
     }
     {
-        uint32_t *nh = nullptr;
-        FW_HIP(ctx, hipHostMalloc((void **)&nh, (size_t)kSnapRing * nmax * sizeof(uint32_t), hipHostMallocDefault));
-        memset(nh, 0, (size_t)kSnapRing * nmax * sizeof(uint32_t));
+        unsigned long long *nh = nullptr;
+        FW_HIP(ctx, hipHostMalloc((void **)&nh, (size_t)kSnapRing * nmax * sizeof(unsigned long long), hipHostMallocDefault));
+        memset(nh, 0, (size_t)kSnapRing * nmax * sizeof(unsigned long long));
         if (ctx->h_snap) FW_HIP(ctx, hipHostFree(ctx->h_snap));
         ctx->h_snap = nh;
         for (int i = 0; i < kSnapRing; i++) ctx->snap_pending[i] = false;
@@ -724,6 +727,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
 fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
     ctx->fc_ok = false;
     ctx->tab_force = true;
+    for (int i = 0; i < kSnapRing; i++) ctx->snap_pending[i] = false;  // rows in flight describe the old segments
     for (const EmissionHost &e : sp.em) {
         if (!e.assigned) continue;  // a build that failed half-way
         ctx->free_emits.push_back(e.emit_idx);
@@ -858,18 +862,33 @@ SpawnerHost *get_spawner(fw_ctx *ctx, fw_spawner h) {
     return &ctx->spawners[h];
 }
 
-// consume finished live-count snapshots to tighten the host upper bounds (no sync)
+// consume finished live-count snapshots to tighten the host upper bounds (no sync, no HIP call)
 void poll_snapshots(fw_ctx *ctx) {
     for (int k = 0; k < kSnapRing; k++) {
         if (!ctx->snap_pending[k]) continue;
-        if (hipEventQuery(ctx->ev_snap[k]) != hipSuccess) continue;
-        ctx->snap_pending[k] = false;
-        const uint32_t *snap = ctx->h_snap + (size_t)k * ctx->max_seg;
+        const volatile unsigned long long *snap = ctx->h_snap + (size_t)k * ctx->max_seg;
         const auto &cum = ctx->snap_cum[k];
-        for (size_t i = 0; i < ctx->segs.size() && i < cum.size(); i++) {
+        const size_t n = std::min(ctx->segs.size(), cum.size());
+        if (!ctx->snap_seen[k]) {
+            // the row is complete once every segment's last tile has stored; look at one segment first and give
+            // the rest one more step
+            size_t probe = n;
+            for (size_t i = 0; i < n && probe == n; i++)
+                if (ctx->segs[i].in_use) probe = i;
+            if (probe == n) {
+                ctx->snap_pending[k] = false;
+            } else if ((uint32_t)(snap[probe] >> 32) == ctx->snap_epoch[k]) {
+                ctx->snap_seen[k] = true;
+            }
+            continue;
+        }
+        ctx->snap_pending[k] = false;
+        for (size_t i = 0; i < n; i++) {
             SegHost &S = ctx->segs[i];
             if (!S.in_use || S.nested_fed) continue;
-            const uint64_t b = (uint64_t)snap[i] + (S.cum_spawn - cum[i]);
+            const unsigned long long v = snap[i];
+            if ((uint32_t)(v >> 32) != ctx->snap_epoch[k]) continue;  // that segment's store has not landed yet
+            const uint64_t b = (uint64_t)(uint32_t)v + (S.cum_spawn - cum[i]);
             if (b < S.ub) S.ub = (uint32_t)b;
         }
     }
@@ -961,9 +980,6 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
         if ((e = hipEventCreateWithFlags(&ctx->ev_consumed[i], hipEventDisableTiming)) != hipSuccess)
             return bail("hipEventCreate", e);
     }
-    for (int i = 0; i < kSnapRing; i++)
-        if ((e = hipEventCreateWithFlags(&ctx->ev_snap[i], hipEventDisableTiming)) != hipSuccess)
-            return bail("hipEventCreate", e);
     for (int i = 0; i < kTabRing; i++)
         if ((e = hipEventCreateWithFlags(&ctx->ev_tab[i], hipEventDisableTiming)) != hipSuccess)
             return bail("hipEventCreate", e);
@@ -1012,7 +1028,6 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
         hipEventDestroy(ctx->ev_copied[i]);
         hipEventDestroy(ctx->ev_consumed[i]);
     }
-    for (int i = 0; i < kSnapRing; i++) hipEventDestroy(ctx->ev_snap[i]);
     for (int i = 0; i < kTabRing; i++) {
         hipEventDestroy(ctx->ev_tab[i]);
         if (ctx->h_tab[i]) hipHostFree(ctx->h_tab[i]);
@@ -1299,8 +1314,13 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         if (ctx->fc_ok && ctx->fc_dt_bits == dt_bits && ctx->fc_tab_seq == ctx->tab_seq && a.epoch != 1u)
             a.fc_in = ctx->d_fc + (size_t)((ctx->frame + 1u) & 1u) * ctx->tiles_cap;
     }
-    const bool take_snap = (ctx->frame % ctx->snap_every) == 0;
-    const int snap = (int)((ctx->frame / ctx->snap_every) % kSnapRing);
+    // a snapshot row stays armed until its stores have been seen (a free-running host can be hundreds of frames
+    // ahead of the device; re-arming by frame number would never catch one)
+    int snap = -1;
+    if ((ctx->frame % ctx->snap_every) == 0)
+        for (int k = 0; k < kSnapRing && snap < 0; k++)
+            if (!ctx->snap_pending[k]) snap = k;
+    const bool take_snap = snap >= 0;
     a.host_counts = take_snap ? ctx->h_snap + (size_t)snap * ctx->max_seg : nullptr;
 
     FwInlineOps inl;
@@ -1421,8 +1441,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         ctx->consumed_pending[slot] = true;
     }
     if (take_snap) {
-        FW_HIP(ctx, hipEventRecord(ctx->ev_snap[snap], ctx->stream));
         ctx->snap_pending[snap] = true;
+        ctx->snap_seen[snap] = false;
+        ctx->snap_epoch[snap] = a.epoch;
         ctx->snap_cum[snap].resize(n_seg);
         for (uint32_t i = 0; i < n_seg; i++) ctx->snap_cum[snap][i] = ctx->segs[i].cum_spawn;
     }

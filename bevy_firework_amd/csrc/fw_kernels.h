@@ -41,7 +41,7 @@ struct FwUpdateArgs {
     uint32_t epoch;        // frame number (look-back tag), never 0
     float dt;
     uint32_t spin_limit;   // look-back polls before the self-computed fallback
-    uint32_t *host_counts; // pinned host snapshot row for this frame (or null)
+    unsigned long long *host_counts;  // pinned host snapshot row for this frame (or null): epoch << 32 | count
     // Global spawn ops fused into the update (virtual particles appended after the live ones);
     // sorted by destination segment, emission order inside a segment
     const FwOp *ops;               // table form (device memory), or null

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
                 g.spawned[oidx] = 0;
                 g.appended[oidx] = 0;
                 g.ndestroyed[seg] = 0;
-                if (a.host_counts) a.host_counts[seg] = 0;
+                if (a.host_counts) a.host_counts[seg] = (unsigned long long)a.epoch << 32;
             }
             if (blockIdx.x == 0 && a.live_next) *a.live_next = 0ull;
         }
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         g.spawned[oidx] = 0;
         g.appended[oidx] = 0;
         g.ndestroyed[seg] = n_tot - nc;
-        if (a.host_counts) a.host_counts[seg] = nc;
+        if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;  // one 8-byte store: tag + count
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
         atomicAdd(g.stats, (unsigned long long)n_tot);
     }
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
                 g.spawned[oidx] = 0;
                 g.appended[oidx] = 0;
                 g.ndestroyed[seg] = 0;
-                if (a.host_counts) a.host_counts[seg] = 0;
+                if (a.host_counts) a.host_counts[seg] = (unsigned long long)a.epoch << 32;
             }
             if (blockIdx.x == 0 && a.live_next) *a.live_next = 0ull;
         }
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         g.spawned[oidx] = 0;
         g.appended[oidx] = 0;
         g.ndestroyed[seg] = n_tot - nc;
-        if (a.host_counts) a.host_counts[seg] = nc;
+        if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;  // one 8-byte store: tag + count
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
         atomicAdd(g.stats, (unsigned long long)n_tot);
     }
