@@ -174,6 +174,7 @@ struct fw_ctx {
     uint32_t fc_dt_bits = 0;   // ... computed for this dt
     uint64_t fc_tab_seq = 0;   // ... under this tile table
     bool use_forecast = true;  // FW_FORECAST=0 disables (A/B, debugging)
+    bool use_static_new = true;  // static output slots for new particles when all of them survive (FW_STATIC_NEW)
     uint32_t snap_every = kSnapEvery;  // frames between live-count snapshots (FW_SNAP_EVERY)
     bool use_stream = true;    // FW_STREAM=0: forecast frames keep the count-park-store kernel (A/B)
 
@@ -994,6 +995,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_DEBUG")) ctx->dbg = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_FORECAST")) ctx->use_forecast = atoi(m) != 0;
     if (const char *m = getenv("FW_STREAM")) ctx->use_stream = atoi(m) != 0;
+    if (const char *m = getenv("FW_STATIC_NEW")) ctx->use_static_new = atoi(m) != 0;  // 0: always count + look back
     if (const char *m = getenv("FW_SNAP_EVERY")) ctx->snap_every = std::max(1, atoi(m));
     if (const char *m = getenv("FW_SPIN_LIMIT")) ctx->spin_limit = (uint32_t)strtoul(m, nullptr, 10);
     if (ensure_max_seg(ctx, 1024) != FW_OK) {
@@ -1166,6 +1168,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     };
     Level levels[FW_MAX_EMISSIONS];
     for (auto &S : ctx->segs) S.frame_spawn = 0;
+    bool new_static = std::isfinite(dt);  // cleared by any Global op whose particles might not survive this step
 
     // lifetime windows: drop the spawns that must have expired by now and tighten the bounds with what is left.
     // (ages are fp32 sums of the same dt values on the device; the margin covers the rounding difference)
@@ -1230,6 +1233,12 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                         if ((st = grow_segment(ctx, dst, (uint32_t)(settled + fs + n)))) return st;
                         for (auto &X : ctx->segs) X.ub += X.frame_spawn;
                     }
+                }
+                {  // does every particle of this op outlive the step?  lifetime = u * (max - min) + min, u in [0, 1)
+                    const fw_particle_settings &tp = sp.types[es.particle_index].ps;
+                    const float lo = std::min(tp.lifetime.min, tp.lifetime.max);
+                    const float lo_safe = std::nextafterf(std::nextafterf(lo, -INFINITY), -INFINITY);  // rounding of the lerp
+                    if (!(std::isfinite(tp.lifetime.min) && std::isfinite(tp.lifetime.max) && dt < lo_safe)) new_static = false;
                 }
                 FwOp op{};
                 op.seg = dst, op.emit = E.emit_idx, op.n = (uint32_t)n;
@@ -1303,6 +1312,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         a.live_next = ctx->live_ring + ((ctx->live_ring_frames + 1) % ctx->live_ring_n);
         ctx->live_ring_frames++;
     }
+    a.new_static = (new_static && ctx->use_static_new) ? 1u : 0u;
     a.use_stream = ctx->use_stream ? 1u : 0u;
     for (uint32_t i = 0; i < n_seg && a.use_stream; i++)
         if (ctx->tiles_dev[i] > FW_FC_MAX_TILES) a.use_stream = 0;

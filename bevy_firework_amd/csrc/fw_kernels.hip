@@ -75,6 +75,38 @@ __device__ __forceinline__ void fw_st1(char *plane, uint32_t i, float v) {
     reinterpret_cast<FW_GLOBAL float *>(reinterpret_cast<uintptr_t>(plane))[i] = v;
 }
 
+// Window addressing: a workgroup reads one contiguous window of each input plane and writes one contiguous window of
+// each output plane.  With the plane pointer advanced to the window start on the scalar unit and a 32-bit byte offset
+// per lane, the access is "SGPR pair + VGPR offset" (the saddr form of global_load / global_store): no 64-bit vector
+// address arithmetic and no address register pairs kept alive per plane.
+__device__ __forceinline__ float4 fw_ld4w(const char *win, uint32_t byte_off) {
+    const fw_f4 v = *reinterpret_cast<const FW_GLOBAL fw_f4 *>(
+        reinterpret_cast<const FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void fw_st4w(char *win, uint32_t byte_off, float4 v) {
+    const fw_f4 x = {v.x, v.y, v.z, v.w};
+    *reinterpret_cast<FW_GLOBAL fw_f4 *>(reinterpret_cast<FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off) = x;
+}
+__device__ __forceinline__ void fw_st1w(char *win, uint32_t byte_off, float v) {
+    *reinterpret_cast<FW_GLOBAL float *>(reinterpret_cast<FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off) = v;
+}
+__device__ __forceinline__ uint4 fw_ld4u(const char *win, uint32_t byte_off) {
+    typedef uint32_t fw_u4v __attribute__((ext_vector_type(4)));
+    const fw_u4v v = *reinterpret_cast<const FW_GLOBAL fw_u4v *>(
+        reinterpret_cast<const FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+struct FwOutWin {  // output planes advanced to slot `first` (workgroup-uniform)
+    char *q0, *q1, *q2, *q3, *q5, *q6, *s4;
+    uint32_t first;
+};
+__device__ __forceinline__ FwOutWin fw_out_window(char *ob, uint32_t C, uint32_t first) {
+    const size_t f16 = (size_t)first * 16u;
+    return FwOutWin{ob + FW_OFF_Q0(C) + f16, ob + FW_OFF_Q1(C) + f16, ob + FW_OFF_Q2(C) + f16, ob + FW_OFF_Q3(C) + f16,
+                    ob + FW_OFF_Q5(C) + f16, ob + FW_OFF_Q6(C) + f16, ob + FW_OFF_S4(C) + (size_t)first * 4u, first};
+}
+
 // alive test of update_particles: `if particle.age >= particle.lifetime { destroyed }` (core.rs:594-599)
 __device__ __forceinline__ bool fw_survives(float age, float dt, float lifetime, float *age_new) {
     float a = age + dt;
@@ -220,8 +252,7 @@ __device__ __forceinline__ unsigned long long fw_pack_status(uint32_t epoch, uin
 
 // integrate one surviving particle and store it at `o` of the output buffer (core.rs:601-657)
 __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float *s_keys, float dt, float4 q0, float4 q1,
-                                                   float4 q2, float4 q3, float age_new, char *ob, uint32_t C,
-                                                   uint32_t o) {
+                                                   float4 q2, float4 q3, float age_new, const FwOutWin &W, uint32_t o) {
     const float lifetime = q3.w;
     const float age_percent = age_new / lifetime;
     const float scale_factor = fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_percent);
@@ -240,13 +271,14 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     float bc[4], em[4];
     fw_gradient_sample(T.bc_kind, T.bc_n, s_keys + T.o_bc_t, s_keys + T.o_bc_v, age_percent, bc);
     fw_gradient_sample(T.em_kind, T.em_n, s_keys + T.o_em_t, s_keys + T.o_em_v, age_percent, em);
-    fw_st4(ob + FW_OFF_Q0(C), o, make_float4(px, py, pz, age_new));
-    fw_st4(ob + FW_OFF_Q1(C), o, make_float4(vx, vy, vz, q1.w));
-    fw_st4(ob + FW_OFF_Q2(C), o, make_float4(nr.x, nr.y, nr.z, nr.w));
-    fw_st4(ob + FW_OFF_Q3(C), o, make_float4(wx, wy, wz, lifetime));
-    fw_st4(ob + FW_OFF_Q5(C), o, make_float4(bc[0], bc[1], bc[2], bc[3]));
-    fw_st4(ob + FW_OFF_Q6(C), o, make_float4(em[0], em[1], em[2], em[3]));
-    fw_st1(ob + FW_OFF_S4(C), o, scale);
+    const uint32_t b16 = (o - W.first) * 16u;  // < 16 KiB + a tile: the window starts at the tile's first output slot
+    fw_st4w(W.q0, b16, make_float4(px, py, pz, age_new));
+    fw_st4w(W.q1, b16, make_float4(vx, vy, vz, q1.w));
+    fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
+    fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
+    fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
+    fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
+    fw_st1w(W.s4, (o - W.first) * 4u, scale);
 }
 
 // destroyed record = the clone with age already advanced, pose of the previous frame (core.rs:596-599)
@@ -641,6 +673,8 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     const unsigned long long ts2 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // ---- phase 3: round loop -- integrate survivors, store them at their compacted slot
     const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
+    excl = __builtin_amdgcn_readfirstlane(excl);  // workgroup-uniform: keep it on the scalar unit
+    const FwOutWin W = fw_out_window(ob, C, excl);
     const uint32_t fcA = excl / FW_TILE, fc_bnd = (fcA + 1u) * FW_TILE;  // output tiles this workgroup feeds
     uint32_t fa = 0, fb = 0;
     uint32_t run = excl;  // output slot of the first survivor of (round r, wave 0)
@@ -673,12 +707,13 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             fb += (uint32_t)__popcll(__ballot(nx && o >= fc_bnd));
         }
         if (alive && (a.dbg & 2u)) {  // profiling only: stream without arithmetic
-            fw_st4(ob + FW_OFF_Q0(C), o, make_float4(q0.x, q0.y, q0.z, age_new)), fw_st4(ob + FW_OFF_Q1(C), o, q1c);
-            fw_st4(ob + FW_OFF_Q2(C), o, q2c), fw_st4(ob + FW_OFF_Q3(C), o, q3);
-            fw_st4(ob + FW_OFF_Q5(C), o, q0), fw_st4(ob + FW_OFF_Q6(C), o, q1c);
-            fw_st1(ob + FW_OFF_S4(C), o, q1c.w);
+            const uint32_t b16 = (o - W.first) * 16u;
+            fw_st4w(W.q0, b16, make_float4(q0.x, q0.y, q0.z, age_new)), fw_st4w(W.q1, b16, q1c);
+            fw_st4w(W.q2, b16, q2c), fw_st4w(W.q3, b16, q3);
+            fw_st4w(W.q5, b16, q0), fw_st4w(W.q6, b16, q1c);
+            fw_st1w(W.s4, (o - W.first) * 4u, q1c.w);
         } else if (alive) {
-            fw_integrate_store(T, s_keys, a.dt, q0, q1c, q2c, q3, age_new, ob, C, o);
+            fw_integrate_store(T, s_keys, a.dt, q0, q1c, q2c, q3, age_new, W, o);
             for (uint32_t k = 0; k < n_lplanes; k++)  // new particles: vec![f32::MIN; n] (core.rs:467)
                 fw_st1(ob + FW_OFF_L(C, k), o, loaded ? fw_ld1(ib + FW_OFF_L(C, k), idx) : FW_F32_MIN);
         } else if (valid && want_destroyed) {
@@ -742,8 +777,8 @@ struct FwRoundOut {
 __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_keys, float dt, uint32_t dbg, float4 q0,
                                                 float4 q1, float4 q2, float4 q3, bool valid, bool alive, bool loaded,
                                                 float age_new, uint32_t idx, uint32_t o, const char *ib, char *ob,
-                                                char *destroyed, bool want_destroyed, uint32_t C, uint32_t n_lplanes,
-                                                bool forecast, uint32_t fc_bnd, FwRoundOut &acc) {
+                                                const FwOutWin &W, char *destroyed, bool want_destroyed, uint32_t C,
+                                                uint32_t n_lplanes, bool forecast, uint32_t fc_bnd, FwRoundOut &acc) {
     if (forecast) {  // will it survive one more step of the same dt?  (same expression as fw_survives)
         float an2;
         const bool nx = alive && fw_survives(age_new, dt, q3.w, &an2);
@@ -751,12 +786,13 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
         acc.fb += (uint32_t)__popcll(__ballot(nx && o >= fc_bnd));
     }
     if (alive && (dbg & 2u)) {  // profiling only: stream without arithmetic
-        fw_st4(ob + FW_OFF_Q0(C), o, make_float4(q0.x, q0.y, q0.z, age_new)), fw_st4(ob + FW_OFF_Q1(C), o, q1);
-        fw_st4(ob + FW_OFF_Q2(C), o, q2), fw_st4(ob + FW_OFF_Q3(C), o, q3);
-        fw_st4(ob + FW_OFF_Q5(C), o, q0), fw_st4(ob + FW_OFF_Q6(C), o, q1);
-        fw_st1(ob + FW_OFF_S4(C), o, q1.w);
+        const uint32_t b16 = (o - W.first) * 16u;
+        fw_st4w(W.q0, b16, make_float4(q0.x, q0.y, q0.z, age_new)), fw_st4w(W.q1, b16, q1);
+        fw_st4w(W.q2, b16, q2), fw_st4w(W.q3, b16, q3);
+        fw_st4w(W.q5, b16, q0), fw_st4w(W.q6, b16, q1);
+        fw_st1w(W.s4, (o - W.first) * 4u, q1.w);
     } else if (alive) {
-        fw_integrate_store(T, s_keys, dt, q0, q1, q2, q3, age_new, ob, C, o);
+        fw_integrate_store(T, s_keys, dt, q0, q1, q2, q3, age_new, W, o);
         for (uint32_t k = 0; k < n_lplanes; k++)  // new particles: vec![f32::MIN; n] (core.rs:467)
             fw_st1(ob + FW_OFF_L(C, k), o, loaded ? fw_ld1(ib + FW_OFF_L(C, k), idx) : FW_F32_MIN);
     } else if (valid && want_destroyed) {
@@ -799,7 +835,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
 #pragma unroll
     for (int j = 0; j < FC_U; j++) {
         const uint32_t t = tid + (uint32_t)j * BLK;
-        fce[j] = a.fc_in[first + min(t, seg_tiles - 1u)];
+        fce[j] = fw_ld4u(reinterpret_cast<const char *>(a.fc_in + first), min(t, seg_tiles - 1u) * 16u);
     }
     const uint32_t p = a.parity;
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
@@ -867,13 +903,17 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     // it right there -- the "prefetch" would complete before anything else is issued.  A lane past the end simply
     // re-reads the tile's last particle and ignores it.)
     const uint32_t last = lim - 1u;  // lim > base for an active tile
+    // input windows: the planes advanced to the tile's first slot (slot 0 for a new-particle tile, which loads nothing real)
+    const size_t ifirst = has_new ? (size_t)0 : (size_t)base * 16u;
+    const char *iw0 = ib + FW_OFF_Q0(C) + ifirst, *iw1 = ib + FW_OFF_Q1(C) + ifirst;
+    const char *iw2 = ib + FW_OFF_Q2(C) + ifirst, *iw3 = ib + FW_OFF_Q3(C) + ifirst;
     float4 q0c, q1c, q2c, q3c;
     {
-        const uint32_t i0 = has_new ? 0u : min(base + tid, last);
-        q0c = fw_ld4(ib + FW_OFF_Q0(C), i0);
-        q3c = fw_ld4(ib + FW_OFF_Q3(C), i0);
-        q1c = fw_ld4(ib + FW_OFF_Q1(C), i0);
-        q2c = fw_ld4(ib + FW_OFF_Q2(C), i0);
+        const uint32_t i0 = has_new ? 0u : min(tid, last - base) * 16u;
+        q0c = fw_ld4w(iw0, i0);
+        q3c = fw_ld4w(iw3, i0);
+        q1c = fw_ld4w(iw1, i0);
+        q2c = fw_ld4w(iw2, i0);
     }
     const FwType T = g.types[type_idx];  // scalar loads; first needed in the round loop
     if (tid < keys_len) s_keys[tid] = key0;
@@ -894,9 +934,12 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         fc_bad |= e.w != a.epoch - 1u;
         fc_part += (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u));
     }
-    // survivors among a new-particle tile's particles: age 0, lifetime = RNG block 2 word 0 (core.rs:455)
+    // survivors among a new-particle tile's particles: age 0, lifetime = RNG block 2 word 0 (core.rs:455).
+    // When the host has established that every particle spawned this frame outlives the step (dt below the smallest
+    // lifetime any of this frame's emitters can draw: a.new_static), nothing has to be counted or looked up: new
+    // particle k lands right after the live survivors, at slot +k.
     uint32_t new_alive = 0;
-    if (SPAWN != FW_SPAWN_NONE && has_new) {
+    if (SPAWN != FW_SPAWN_NONE && has_new && !a.new_static) {
 #pragma unroll 1
         for (uint32_t r = 0; r < vt_rounds; r++) {
             const uint32_t idx = base + r * BLK + tid;
@@ -927,7 +970,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
 #pragma unroll
     for (int w = 0; w < NW; w++) excl += s_part[0][w], new_cnt += s_part[1][w];
 
-    if (SPAWN != FW_SPAWN_NONE && has_new) {  // look back among the new-particle tiles only
+    if (SPAWN != FW_SPAWN_NONE && has_new && a.new_static) {
+        excl += base - n_in;  // every earlier new particle survives
+    } else if (SPAWN != FW_SPAWN_NONE && has_new) {  // look back among the new-particle tiles only
         const bool lb_needed = tis > t_spawn;
         if (lb_needed && tid == 0)
             __hip_atomic_store(&g.tile_status[tile], fw_pack_status(a.epoch, FW_ST_AGG, new_cnt), RLX, AGENT);
@@ -970,17 +1015,19 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
     const uint32_t fcA = excl / FW_TILE, fc_bnd = (fcA + 1u) * FW_TILE;
     FwRoundOut acc{0u, 0u};
+    excl = __builtin_amdgcn_readfirstlane(excl);  // workgroup-uniform (summed from LDS): keep it on the scalar unit
+    const FwOutWin W = fw_out_window(ob, C, excl);
     uint32_t run = excl;
     if (!has_new) {
         // ---- live tile: stream the rounds
 #pragma unroll 1
         for (int r = 0; r < R; r++) {
             const uint32_t idx = base + r * BLK + tid;
-            const uint32_t in_ = min(idx + BLK, last);  // next round's slot (clamped: see above)
-            const float4 q0n = fw_ld4(ib + FW_OFF_Q0(C), in_);
-            const float4 q3n = fw_ld4(ib + FW_OFF_Q3(C), in_);
-            const float4 q1n = fw_ld4(ib + FW_OFF_Q1(C), in_);
-            const float4 q2n = fw_ld4(ib + FW_OFF_Q2(C), in_);
+            const uint32_t in_ = min((r + 1) * BLK + tid, last - base) * 16u;  // next round's slot (clamped: see above)
+            const float4 q0n = fw_ld4w(iw0, in_);
+            const float4 q3n = fw_ld4w(iw3, in_);
+            const float4 q1n = fw_ld4w(iw1, in_);
+            const float4 q2n = fw_ld4w(iw2, in_);
             const bool valid = idx < lim;
             float age_new;
             const bool alive = valid && fw_survives(q0c.w, a.dt, q3c.w, &age_new);
@@ -995,7 +1042,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
                 run += c;
             }
             const uint32_t o = wbase + fw_lane_prefix(m);
-            fw_round_finish(T, s_keys, a.dt, a.dbg, q0c, q1c, q2c, q3c, valid, alive, true, age_new, idx, o, ib, ob,
+            fw_round_finish(T, s_keys, a.dt, a.dbg, q0c, q1c, q2c, q3c, valid, alive, true, age_new, idx, o, ib, ob, W,
                             destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n;
             if ((a.dbg & 8u) && r == 0) tsR1 = __builtin_amdgcn_s_memrealtime() + (o & 0u);
@@ -1033,7 +1080,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
             }
             const uint32_t o = wbase + fw_lane_prefix(m);
             fw_round_finish(T, s_keys, a.dt, a.dbg, so.q0, so.q1, so.q2, so.q3, valid, alive, false, age_new, idx, o, ib,
-                            ob, destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc);
+                            ob, W, destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc);
         }
     }
     if (lane == 0) s_part[2][wave] = acc.fa, s_part[3][wave] = acc.fb;
