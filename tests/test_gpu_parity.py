@@ -258,11 +258,12 @@ def test_nested_overflow_reports_capacity(system):
 
 
 @pytest.mark.parametrize("env", [{"FW_FORECAST": "0", "FW_SPIN_LIMIT": "0"}, {"FW_UPDATE_MODE": "split"},
-                                 {"FW_STREAM": "0"}])
+                                 {"FW_STREAM": "0"}, {"FW_STATIC_NEW": "0"}])
 def test_alternative_prefix_paths(monkeypatch, env):
     """the other ways a tile can obtain its output offset must give the same particles: the look-back's
     recount fallback (spin limit 0 forces it wherever a predecessor has not published yet), the three-launch
-    split mode, and forecast frames on the count-park-store kernel"""
+    split mode, forecast frames on the count-park-store kernel, and new particles counted + looked up even when
+    the host could prove that all of them survive the step"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     from bevy_firework_amd.system import ParticleSystem
@@ -278,6 +279,51 @@ def test_alternative_prefix_paths(monkeypatch, env):
             if fr % 20 == 19:
                 pair.check(exact_all=True, what=f"{env} f{fr}")
         assert pair.gpu.count(0) > 60000
+
+
+def test_new_particles_that_die_in_their_first_step(system):
+    """lifetimes below dt: a particle can be spawned and destroyed by the same frame's update (core.rs:437-469 then
+    594-599), so the slots of the new particles are not static; frames with a tiny dt (all survive) in between
+    switch to the static-slot path and back"""
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.001, 0.04), linear_drag=0.2)
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(400000.0),
+                            initial_velocity=S.RandVec3(S.RandF32(0.0, 2.0), (0.0, 1.0, 0.0), 0.3))
+    pair = Pair(system, S.ParticleSpawner([ps], [es]), seed=SEED, uid=57)
+    dts = [1 / 60] * 12 + [1 / 2000] * 3 + [1 / 60] * 6 + [1 / 2000, 1 / 60, 1 / 2000, 1 / 60] + [1 / 30] * 4
+    for i, dt in enumerate(dts):
+        dt = np.float32(dt)
+        system.update(dt)
+        pair.step_cpu(dt)
+        pair.check(what=f"frame {i} dt={dt}")  # cone spread -> sin/cos: trig tolerance on position / velocity
+    assert pair.gpu.count(0) > 2000
+
+
+def test_lifetime_window_bound_long_run(system):
+    """the host bounds a segment's live count by the spawns of the last `max lifetime` of simulated time and sizes the
+    update grid from it; irregular steps (zero, long, short), a burst of long-lived particles from a second entry and
+    a rewrite of the particle state must never leave a live particle outside the grid"""
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.2, 2.0), linear_drag=0.1)
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(40000.0))
+    burst = S.EmissionSettings(emission_pacing=S.EmissionPacing.OneShot(30000))
+    pair = Pair(system, S.ParticleSpawner([ps], [es, burst]), seed=SEED, uid=63)
+    rng = np.random.default_rng(5)
+    pattern = [1 / 60] * 40 + [0.0, 0.0, 0.25, 1 / 240, 1 / 240, 0.1, 1 / 60, 0.5, 1 / 60, 1 / 60]
+    frames = 0
+    for rep in range(4):
+        for dt in pattern + list(rng.uniform(0.001, 0.05, size=30)):
+            dt = np.float32(dt)
+            system.update(dt)
+            pair.step_cpu(dt)
+            frames += 1
+            if frames % 40 == 0:
+                pair.check(exact_all=True, what=f"frame {frames}")
+        if rep == 1:  # ages and lifetimes rewritten by the caller: the window no longer applies
+            parts = pair.cpu.particles(0)[::2].copy()
+            parts["lifetime"] = parts["lifetime"] + np.float32(3.0)
+            pair.gpu.write_particles(0, parts)
+            pair.cpu.write_particles(0, parts)
+    pair.check(exact_all=True, what="end")
+    assert pair.gpu.count(0) > 20000
 
 
 def test_live_count_ring(system):
