@@ -142,16 +142,15 @@ def main():
     elapsed = time.perf_counter() - t0
     updated = ps.updated_total() - before
     live = ps.live_count()
-    # Second pass over the same steady state with a hipEvent pair around every fw_k_update launch (on the
-    # kernel's own stream).  It is a separate pass because the event markers serialise the queue (~8 us of
-    # idle GPU per step): they would distort `value`, and `value` would distort nothing here.
-    ev_ms, ev_launches, ev_particles, ev_overhead_us, measured_copy = (0.0, 0, 0, 0.0, 0.0)
+    # Second pass over the same steady state with a hipEvent pair attached to every update dispatch on the kernel's
+    # own stream (hipExtLaunchKernel start/stop events: the packet's begin / end timestamps, i.e. the duration
+    # rocprofv3 --kernel-trace reports).  A separate pass so that per-dispatch signals cannot touch `value`.
+    ev_ms, ev_launches, ev_particles, measured_copy = (0.0, 0, 0, 0.0)
     if not args.no_events and rank == 0:
         ps.kernel_timing(True)
         for _ in range(min(args.steps, 1000)):
             ps.step(dt)
         ev_ms, ev_launches, ev_particles = ps.kernel_timing_read()
-        ev_overhead_us = ps.kernel_timing_overhead_us()
         ps.kernel_timing(False)
         measured_copy = ps.measure_copy_bandwidth(1 << 30, 20)  # float4 copy, 1 GiB -> 1 GiB (read + written bytes / s)
     barrier()
@@ -196,12 +195,11 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_particle": ALGO_BYTES, "moved_bytes_per_particle": ACTUAL_BYTES,
                 "particles_per_launch": per_launch, "avg_kernel_us": kt * 1e6, "launches": ev_launches,
-                "event_pair_overhead_us": ev_overhead_us,
                 "measured_hbm_copy_GBps": measured_copy / 1e9,
                 "frac_of_measured_copy": achieved / (measured_copy / 1e9) if measured_copy else None,
-                "timing": "hipEvent pair around each launch on the context's stream, minus the calibrated cost of an "
-                          "empty pair; second pass over the same steady state (the markers serialise the queue, so "
-                          "they are kept out of `value`)",
+                "timing": "hipEvent start/stop attached to each update dispatch on the context's stream "
+                          "(hipExtLaunchKernel: the packet's begin/end timestamps, the same duration rocprofv3 "
+                          "--kernel-trace reports); second pass over the same steady state, kept out of `value`",
             }
         else:
             out["roofline"] = None

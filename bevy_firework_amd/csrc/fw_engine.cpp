@@ -1438,14 +1438,12 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     }
 
     // update_particles + compaction (core.rs:577-670)
+    // timing: the events ride on the dispatch packet (its begin / end timestamps), no marker packets in the stream
     const bool timed = ctx->timing && ctx->tev_used + 2 <= ctx->tev.size();
-    if (timed) FW_HIP(ctx, hipEventRecord(ctx->tev[ctx->tev_used], ctx->stream));
     FW_HIP(ctx, fw_launch_update(ctx->stream, ctx->g, a, spawn_form == FW_SPAWN_INLINE ? &inl : nullptr, spawn_form,
-                                 ctx->update_mode));
-    if (timed) {
-        FW_HIP(ctx, hipEventRecord(ctx->tev[ctx->tev_used + 1], ctx->stream));
-        ctx->tev_used += 2;
-    }
+                                 ctx->update_mode, timed ? ctx->tev[ctx->tev_used] : nullptr,
+                                 timed ? ctx->tev[ctx->tev_used + 1] : nullptr));
+    if (timed) ctx->tev_used += 2;
     if (slot >= 0) {
         FW_HIP(ctx, hipEventRecord(ctx->ev_consumed[slot], ctx->stream));
         ctx->consumed_pending[slot] = true;
@@ -1746,8 +1744,8 @@ fw_status fw_ctx_kernel_timing(fw_ctx *ctx, int32_t enable) {
         for (auto &ev : ctx->tev) FW_HIP(ctx, hipEventCreate(&ev));
     }
     if (enable) {
-        // calibrate the marker cost: a hipEvent pair with nothing between still measures the two markers'
-        // own processing (a few us); that is subtracted per launch so the figure is the kernel's duration
+        // for reference only: what an empty hipEventRecord pair on the stream costs (the timed launches do not use
+        // marker packets: their events are attached to the dispatch, see fw_launch_update)
         const int n = 64;
         for (int i = 0; i < n; i++) {
             FW_HIP(ctx, hipEventRecord(ctx->tev[2 * i], ctx->stream));
@@ -1782,7 +1780,6 @@ fw_status fw_ctx_kernel_timing_read(fw_ctx *ctx, double *ms_total, uint64_t *lau
         ms += t;
     }
     const uint64_t nl = ctx->tev_used / 2;
-    ms -= ctx->tev_overhead_ms * (double)nl;  // marker cost, calibrated in fw_ctx_kernel_timing
     if (ms_total) *ms_total = ms;
     if (launches) *launches = nl;
     unsigned long long now = 0;

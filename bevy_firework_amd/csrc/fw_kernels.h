@@ -76,7 +76,7 @@ enum { FW_MODE_FUSED = 0, FW_MODE_SPLIT = 1 };
 hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *ops, uint32_t n_ops, uint32_t total_blocks,
                            uint32_t parity);
 hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps *inl,
-                            int spawn_form, int mode);
+                            int spawn_form, int mode, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *ops, uint32_t n_ops,
                             uint32_t total_tiles, uint32_t parity);
 // SoA -> AoS gather of `n` particles of one segment buffer into fw_particle records (device)

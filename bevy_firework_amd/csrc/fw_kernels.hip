@@ -16,6 +16,7 @@
 //
 // Arithmetic order is the reference's (fw_math.h); built with -ffp-contract=off.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "fw_kernels.h"
 #include "fw_math.h"
@@ -251,6 +252,30 @@ __device__ __forceinline__ unsigned long long fw_pack_status(uint32_t epoch, uin
 }
 
 // integrate one surviving particle and store it at `o` of the output buffer (core.rs:601-657)
+// Quat::from_scaled_axis(w * dt) for the per-frame rotation step (core.rs:645-647).  glam evaluates
+// (v / |v|) * sin(|v| / 2), cos(|v| / 2); with h = |v| / 2 that is v * (sin(h) / 2h) and cos(h), both even functions
+// of h, so for the small angles of a frame step (h^2 < 0.6, i.e. |w| dt < 89 degrees) two short polynomials in
+// h^2 = |v|^2 / 4 give the quaternion without the square root, the three divisions and the sin/cos range reduction
+// (truncation error < 3e-8 relative, below fp32 rounding; the zero axis comes out as the identity by itself).
+// Rotation is one of the fields compared at 1e-5 (the CPU oracle's libm sin/cos already differs from the device's in
+// the last bit).  Larger angles, NaN and infinities take the reference formula.
+__device__ __forceinline__ fw_q4 fw_quat_step(fw_v3 v) {
+    const float h2 = 0.25f * ((v.x * v.x) + (v.y * v.y) + (v.z * v.z));
+    if (__builtin_expect(__ballot(!(h2 < 0.6f)) == 0ull, 1)) {  // wave-uniform choice
+        float sh = __builtin_fmaf(h2, 2.7557319e-6f, -1.9841270e-4f);   // 1/9!, -1/7!
+        sh = __builtin_fmaf(h2, sh, 8.3333333e-3f);                     // 1/5!
+        sh = __builtin_fmaf(h2, sh, -1.6666667e-1f);                    // -1/3!
+        sh = __builtin_fmaf(h2, sh, 1.0f) * 0.5f;                       // sin(h) / (2 h)
+        float c = __builtin_fmaf(h2, -2.7557319e-7f, 2.4801587e-5f);    // -1/10!, 1/8!
+        c = __builtin_fmaf(h2, c, -1.3888889e-3f);                      // -1/6!
+        c = __builtin_fmaf(h2, c, 4.1666667e-2f);                       // 1/4!
+        c = __builtin_fmaf(h2, c, -0.5f);
+        c = __builtin_fmaf(h2, c, 1.0f);                                // cos(h)
+        return fw_q4{v.x * sh, v.y * sh, v.z * sh, c};
+    }
+    return fw_quat_from_scaled_axis(v);
+}
+
 __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float *s_keys, float dt, float4 q0, float4 q1,
                                                    float4 q2, float4 q3, float age_new, const FwOutWin &W, uint32_t o) {
     const float lifetime = q3.w;
@@ -263,7 +288,7 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     const float vy = q1.y + (T.acc[1] - q1.y * T.lin_drag) * dt;
     const float vz = q1.z + (T.acc[2] - q1.z * T.lin_drag) * dt;
     // rotation = from_scaled_axis(angvel * dt) * rotation, no renormalisation (core.rs:645-647)
-    const fw_q4 dq = fw_quat_from_scaled_axis(fw_v3{q3.x * dt, q3.y * dt, q3.z * dt});
+    const fw_q4 dq = fw_quat_step(fw_v3{q3.x * dt, q3.y * dt, q3.z * dt});
     const fw_q4 nr = fw_quat_mul(dq, fw_q4{q2.x, q2.y, q2.z, q2.w});
     const float wx = q3.x + (T.angacc[0] - T.ang_drag * q3.x) * dt;  // core.rs:648-650
     const float wy = q3.y + (T.angacc[1] - T.ang_drag * q3.y) * dt;
@@ -1486,38 +1511,52 @@ hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *ops, u
     return hipGetLastError();
 }
 
+// Launch with optional timing events attached to the dispatch itself (hipExtLaunchKernel): the events take the
+// packet's own begin / end timestamps, which is what rocprofv3 --kernel-trace reports for the kernel.
+#define FW_LAUNCH_T(kern, grid, block, s, e0, e1, ...)                                          \
+    do {                                                                                          \
+        if ((e0) || (e1))                                                                         \
+            hipExtLaunchKernelGGL(kern, grid, block, 0, s, e0, e1, 0, __VA_ARGS__);               \
+        else                                                                                      \
+            hipLaunchKernelGGL(kern, grid, block, 0, s, __VA_ARGS__);                             \
+    } while (0)
+
 template <int R>
 static void fw_launch_update_r(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps &io,
-                               int spawn_form, int mode) {
+                               int spawn_form, int mode, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(a.total_tiles), block(FW_TILE / R);
     if (mode == FW_MODE_SPLIT) {  // debugging / A-B mode: three launches, no inter-workgroup traffic
-        hipLaunchKernelGGL(fw_k_count, grid, dim3(FW_BLOCK), 0, s, g, a);
+        FW_LAUNCH_T(fw_k_count, grid, dim3(FW_BLOCK), s, e0, (hipEvent_t) nullptr, g, a);
         hipLaunchKernelGGL(fw_k_scan, dim3(a.n_seg), dim3(FW_BLOCK), 0, s, g, a);
-        hipLaunchKernelGGL((fw_k_update<false, FW_SPAWN_NONE, R>), grid, block, 0, s, g, a, io);
+        FW_LAUNCH_T((fw_k_update<false, FW_SPAWN_NONE, R>), grid, block, s, (hipEvent_t) nullptr, e1, g, a, io);
     } else if (a.use_stream && a.fc_in && a.fc_out) {  // forecast frame: streaming schedule
         if (spawn_form == FW_SPAWN_INLINE)
-            hipLaunchKernelGGL((fw_k_update_stream<FW_SPAWN_INLINE>), grid, dim3(FW_BLOCK), 0, s, g, a, io);
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_INLINE>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
         else if (spawn_form == FW_SPAWN_TABLE)
-            hipLaunchKernelGGL((fw_k_update_stream<FW_SPAWN_TABLE>), grid, dim3(FW_BLOCK), 0, s, g, a, io);
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_TABLE>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
         else
-            hipLaunchKernelGGL((fw_k_update_stream<FW_SPAWN_NONE>), grid, dim3(FW_BLOCK), 0, s, g, a, io);
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_NONE>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
     } else if (spawn_form == FW_SPAWN_INLINE) {
-        hipLaunchKernelGGL((fw_k_update<true, FW_SPAWN_INLINE, R>), grid, block, 0, s, g, a, io);
+        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_INLINE, R>), grid, block, s, e0, e1, g, a, io);
     } else if (spawn_form == FW_SPAWN_TABLE) {
-        hipLaunchKernelGGL((fw_k_update<true, FW_SPAWN_TABLE, R>), grid, block, 0, s, g, a, io);
+        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_TABLE, R>), grid, block, s, e0, e1, g, a, io);
     } else {
-        hipLaunchKernelGGL((fw_k_update<true, FW_SPAWN_NONE, R>), grid, block, 0, s, g, a, io);
+        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_NONE, R>), grid, block, s, e0, e1, g, a, io);
     }
 }
 
 hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps *inl,
-                            int spawn_form, int mode) {
-    if (!a.total_tiles) return hipSuccess;
+                            int spawn_form, int mode, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (!a.total_tiles) {
+        if (ev_start) (void)hipEventRecord(ev_start, s);
+        if (ev_stop) (void)hipEventRecord(ev_stop, s);
+        return hipGetLastError();
+    }
     static const FwInlineOps none{};
     const FwInlineOps &io = inl ? *inl : none;
     if (mode == FW_MODE_SPLIT && spawn_form != FW_SPAWN_NONE) return hipErrorInvalidValue;
     // 256 threads x 4 rounds is the measured optimum; 512 x 2 and 1024 x 1 were 25-30 % slower
-    fw_launch_update_r<FW_ROUNDS>(s, g, a, io, spawn_form, mode);
+    fw_launch_update_r<FW_ROUNDS>(s, g, a, io, spawn_form, mode, ev_start, ev_stop);
     return hipGetLastError();
 }
 

@@ -200,10 +200,12 @@ fw_status fw_ctx_last_step_updated(fw_ctx *ctx, uint64_t *out);
 
 /* ---- measurement hooks (bench.py / profiles) -------------------------------------- */
 /* HIP-event timing of the dominant kernel on the context's stream: enable, run
- * steps, then read (sum of kernel durations in ms, number of launches). */
+ * steps, then read (sum of kernel durations in ms, number of launches).  The start / stop
+ * events are attached to the update dispatch itself (hipExtLaunchKernel), so each pair
+ * spans exactly the kernel's begin / end timestamps -- the duration rocprofv3 reports. */
 fw_status fw_ctx_kernel_timing(fw_ctx *ctx, int32_t enable);
 fw_status fw_ctx_kernel_timing_read(fw_ctx *ctx, double *ms_total, uint64_t *launches, uint64_t *particles);
-/* cost of an empty hipEvent pair on the stream (calibrated at enable time; already subtracted per launch above) */
+/* cost of an empty hipEventRecord pair on the stream (informational; nothing is subtracted from the figure above) */
 fw_status fw_ctx_kernel_timing_overhead(fw_ctx *ctx, double *ms_per_pair);
 /* device-to-device copy bandwidth probe (bytes moved R+W per second) for the measured-roofline line */
 fw_status fw_ctx_measure_copy_bandwidth(fw_ctx *ctx, uint64_t bytes, int32_t iters, double *bytes_per_s);
