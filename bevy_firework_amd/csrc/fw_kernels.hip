@@ -1417,15 +1417,33 @@ __global__ void fw_k_scatter(char *buf, uint32_t C, uint32_t n, uint32_t n_lplan
 }
 
 // ParticleInstance packing (reference src/render.rs:95-115): {pos, scale, rot, base, emissive}
-__global__ void fw_k_pack(const char *buf, uint32_t C, const uint32_t *d_count, uint32_t n_upper, float4 *out) {
+// SoA planes -> ParticleInstance records (render.rs:95-115).  Loads are plane-wise coalesced; the 64-byte records are
+// transposed through LDS so that every store instruction of a wave writes 1 KiB of consecutive bytes (a lane writing
+// its own record with four float4 stores would touch 64 lines a quarter at a time).
+__global__ __launch_bounds__(256) void fw_k_pack(const char *buf, uint32_t C, const uint32_t *d_count, uint32_t n_upper,
+                                                 float4 *out) {
+    __shared__ float4 s_rec[256 * 4];
     const uint32_t n = min(*d_count, n_upper);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t b = blockIdx.x * 256u; b < n; b += gridDim.x * 256u) {
+        const uint32_t i = min(b + tid, n - 1u);
         const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i);
-        const float sc = reinterpret_cast<const float *>(buf + FW_OFF_S4(C))[i];
-        out[(size_t)i * 4 + 0] = make_float4(q0.x, q0.y, q0.z, sc);
-        out[(size_t)i * 4 + 1] = fw_ld4(buf + FW_OFF_Q2(C), i);
-        out[(size_t)i * 4 + 2] = fw_ld4(buf + FW_OFF_Q5(C), i);
-        out[(size_t)i * 4 + 3] = fw_ld4(buf + FW_OFF_Q6(C), i);
+        const float sc = fw_ld1(buf + FW_OFF_S4(C), i);
+        const float4 q2 = fw_ld4(buf + FW_OFF_Q2(C), i);
+        const float4 q5 = fw_ld4(buf + FW_OFF_Q5(C), i);
+        const float4 q6 = fw_ld4(buf + FW_OFF_Q6(C), i);
+        s_rec[tid * 4 + 0] = make_float4(q0.x, q0.y, q0.z, sc);
+        s_rec[tid * 4 + 1] = q2;
+        s_rec[tid * 4 + 2] = q5;
+        s_rec[tid * 4 + 3] = q6;
+        __syncthreads();
+        const uint32_t cnt4 = min(256u, n - b) * 4u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t e = k * 256u + tid;
+            if (e < cnt4) out[(size_t)b * 4 + e] = s_rec[e];
+        }
+        __syncthreads();
     }
 }
 
@@ -1587,7 +1605,7 @@ hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t cap
                                     uint32_t n_upper, void *d_out) {
     if (!n_upper) return hipSuccess;
     uint32_t blocks = (n_upper + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(fw_k_pack, dim3(blocks), dim3(256), 0, s, buf, capacity, d_count, n_upper, (float4 *)d_out);
     return hipGetLastError();
 }
