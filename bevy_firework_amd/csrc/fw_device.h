@@ -52,7 +52,9 @@ struct alignas(16) FwSeg {
     uint32_t capacity;    // particles per buffer, multiple of FW_BLOCK
     uint32_t type_idx;    // -> FwType
     uint32_t n_lplanes;   // number of Lk planes
-    uint32_t pad0;
+    uint32_t inst_cap;    // records that fit in `inst`
+    char *inst;           // attached ParticleInstance output (render hand-off fused into the update), or null
+    char *pad1;
 };
 
 // per particle type constants (ParticleSettings, reference src/core.rs:99-142)

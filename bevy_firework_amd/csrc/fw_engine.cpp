@@ -75,6 +75,8 @@ struct SegHost {
     bool nested_fed = false;    // receives Nested children: count not host-predictable
     char *buf[2] = {nullptr, nullptr};
     char *destroyed = nullptr;
+    char *inst = nullptr;       // caller-owned device buffer of ParticleInstance records (fw_spawner_attach_instances)
+    uint32_t inst_cap = 0;
     // Lifetime window: a particle is destroyed by the update in which age >= lifetime (core.rs:590-592), and
     // lifetime <= life_bound, so everything alive was spawned less than life_bound of simulated time ago.  The sum of
     // the Global spawn counts inside that window bounds the live count without any device feedback.
@@ -381,6 +383,7 @@ fw_status upload_seg(fw_ctx *ctx, uint32_t si) {
     d.capacity = s.capacity;
     d.type_idx = s.type_idx;
     d.n_lplanes = s.n_lplanes;
+    d.inst = s.inst, d.inst_cap = s.inst_cap;
     FW_HIP(ctx, hipMemcpy(ctx->d_segs.d + si, &d, sizeof d, hipMemcpyHostToDevice));
     return FW_OK;
 }
@@ -1313,6 +1316,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         ctx->live_ring_frames++;
     }
     a.new_static = (new_static && ctx->use_static_new) ? 1u : 0u;
+    for (const SegHost &S : ctx->segs) a.any_inst |= (S.in_use && S.inst != nullptr) ? 1u : 0u;
     a.use_stream = ctx->use_stream ? 1u : 0u;
     for (uint32_t i = 0; i < n_seg && a.use_stream; i++)
         if (ctx->tiles_dev[i] > FW_FC_MAX_TILES) a.use_stream = 0;
@@ -1640,6 +1644,18 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
     FW_HIP(ctx, fw_launch_pack_instances(ctx->stream, S.buf[ctx->parity], S.capacity,
                                          ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, ub, d_out));
     return FW_OK;
+}
+
+fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || type >= sp->seg.size() || (d_out && !cap)) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    fw_status st = sync(ctx);  // kernels in flight hold the old record
+    if (st) return st;
+    SegHost &S = ctx->segs[sp->seg[type]];
+    S.inst = (char *)d_out;
+    S.inst_cap = d_out ? (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull) : 0u;
+    return upload_seg(ctx, sp->seg[type]);
 }
 
 fw_status fw_spawner_pack_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, fw_particle_instance *out, uint64_t cap,

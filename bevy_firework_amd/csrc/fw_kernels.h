@@ -41,6 +41,7 @@ struct FwUpdateArgs {
     uint32_t epoch;        // frame number (look-back tag), never 0
     float dt;
     uint32_t spin_limit;   // look-back polls before the self-computed fallback
+    uint32_t any_inst;    // some segment has an attached instance buffer: run the kernels that also write the records
     uint32_t new_static;  // 1: every particle spawned this frame survives the step (host-proved), offsets are static
     unsigned long long *host_counts;  // pinned host snapshot row for this frame (or null): epoch << 32 | count
     // Global spawn ops fused into the update (virtual particles appended after the live ones);

@@ -277,7 +277,8 @@ __device__ __forceinline__ fw_q4 fw_quat_step(fw_v3 v) {
 }
 
 __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float *s_keys, float dt, float4 q0, float4 q1,
-                                                   float4 q2, float4 q3, float age_new, const FwOutWin &W, uint32_t o) {
+                                                   float4 q2, float4 q3, float age_new, const FwOutWin &W, uint32_t o,
+                                                   float4 *rec = nullptr) {
     const float lifetime = q3.w;
     const float age_percent = age_new / lifetime;
     const float scale_factor = fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_percent);
@@ -304,7 +305,33 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
     fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
     fw_st1w(W.s4, (o - W.first) * 4u, scale);
+    if (rec) {  // ParticleInstance {pos.xyz, scale, rot, base_color, emissive} (render.rs:95-103); `rec` may be in LDS
+        rec[0] = make_float4(px, py, pz, scale), rec[1] = make_float4(nr.x, nr.y, nr.z, nr.w);
+        rec[2] = make_float4(bc[0], bc[1], bc[2], bc[3]), rec[3] = make_float4(em[0], em[1], em[2], em[3]);
+    }
 }
+
+// Render hand-off fused into the update: the ParticleInstance records of a wave's survivors of one round occupy
+// consecutive slots [wbase, wbase + cnt), i.e. one contiguous run of cnt * 64 bytes.  The lanes park their records in
+// a wave-private LDS area at their rank and the wave then stores the run with fully coalesced float4 stores.
+__device__ __forceinline__ void fw_inst_flush(char *inst, uint32_t inst_cap, const float4 *s_wave, uint32_t lane,
+                                              unsigned long long m, uint32_t wbase) {
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t wb = __builtin_amdgcn_readfirstlane(wbase);
+    const uint32_t room4 = (wb < inst_cap ? min(cnt, inst_cap - wb) : 0u) * 4u;
+    char *dst = inst + (size_t)wb * 64u;
+#pragma unroll 1  // one float4 in registers at a time: the kernel sits at the 128-VGPR occupancy step
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t e = k * 64u + lane;
+        if (e < room4) fw_st4w(dst, e * 16u, s_wave[e]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 
 // destroyed record = the clone with age already advanced, pose of the previous frame (core.rs:596-599)
 __device__ __forceinline__ void fw_store_destroyed(char *dbuf, const char *ib, uint32_t C, uint32_t idx, bool loaded,
@@ -424,7 +451,7 @@ __device__ __forceinline__ uint32_t fw_lookback(const unsigned long long *status
 //     finished a kernel ago) and never waits for a co-resident workgroup.  Only tiles that hold freshly
 //     spawned particles look back -- among themselves -- for the survivors of the new particles.
 //   * otherwise: single-pass decoupled look-back over all earlier tiles of the segment.
-template <bool FUSED, int SPAWN, int R>
+template <bool FUSED, int SPAWN, int R, bool INST>
 __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdateArgs a, FwInlineOps inl) {
     constexpr int BLK = FW_TILE / R;
     constexpr int NW = BLK / 64;
@@ -534,6 +561,8 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     char *ib = Sp->buf[p];  // written only at the slots of this frame's new particles
     char *ob = Sp->buf[p ^ 1u];
     char *destroyed = Sp->destroyed;
+    char *inst = INST ? Sp->inst : nullptr;
+    const uint32_t inst_cap = INST ? Sp->inst_cap : 0u;
 
     const unsigned long long tsA = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (C & 0u)) : 0ull;
     // ---- phase 1: the planes that decide survival: Q0 (age in .w) and Q3 (lifetime in .w); all R loads of
@@ -738,7 +767,12 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             fw_st4w(W.q5, b16, q0), fw_st4w(W.q6, b16, q1c);
             fw_st1w(W.s4, (o - W.first) * 4u, q1c.w);
         } else if (alive) {
-            fw_integrate_store(T, s_keys, a.dt, q0, q1c, q2c, q3, age_new, W, o);
+            float4 rec[4];
+            fw_integrate_store(T, s_keys, a.dt, q0, q1c, q2c, q3, age_new, W, o, INST ? rec : nullptr);
+            if (INST && inst != nullptr && o < inst_cap) {  // this schedule is the rare one: plain per-lane records
+                fw_st4(inst, o * 4u + 0u, rec[0]), fw_st4(inst, o * 4u + 1u, rec[1]);
+                fw_st4(inst, o * 4u + 2u, rec[2]), fw_st4(inst, o * 4u + 3u, rec[3]);
+            }
             for (uint32_t k = 0; k < n_lplanes; k++)  // new particles: vec![f32::MIN; n] (core.rs:467)
                 fw_st1(ob + FW_OFF_L(C, k), o, loaded ? fw_ld1(ib + FW_OFF_L(C, k), idx) : FW_F32_MIN);
         } else if (valid && want_destroyed) {
@@ -803,7 +837,8 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
                                                 float4 q1, float4 q2, float4 q3, bool valid, bool alive, bool loaded,
                                                 float age_new, uint32_t idx, uint32_t o, const char *ib, char *ob,
                                                 const FwOutWin &W, char *destroyed, bool want_destroyed, uint32_t C,
-                                                uint32_t n_lplanes, bool forecast, uint32_t fc_bnd, FwRoundOut &acc) {
+                                                uint32_t n_lplanes, bool forecast, uint32_t fc_bnd, FwRoundOut &acc,
+                                                float4 *rec = nullptr) {
     if (forecast) {  // will it survive one more step of the same dt?  (same expression as fw_survives)
         float an2;
         const bool nx = alive && fw_survives(age_new, dt, q3.w, &an2);
@@ -817,7 +852,7 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
         fw_st4w(W.q5, b16, q0), fw_st4w(W.q6, b16, q1);
         fw_st1w(W.s4, (o - W.first) * 4u, q1.w);
     } else if (alive) {
-        fw_integrate_store(T, s_keys, dt, q0, q1, q2, q3, age_new, W, o);
+        fw_integrate_store(T, s_keys, dt, q0, q1, q2, q3, age_new, W, o, rec);
         for (uint32_t k = 0; k < n_lplanes; k++)  // new particles: vec![f32::MIN; n] (core.rs:467)
             fw_st1(ob + FW_OFF_L(C, k), o, loaded ? fw_ld1(ib + FW_OFF_L(C, k), idx) : FW_F32_MIN);
     } else if (valid && want_destroyed) {
@@ -825,13 +860,14 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
     }
 }
 
-template <int SPAWN>
+template <int SPAWN, bool INST>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUpdateArgs a, FwInlineOps inl) {
     constexpr int R = FW_ROUNDS;
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
     constexpr int LBW = 4;
     __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
+    __shared__ __attribute__((aligned(16))) float4 s_inst[INST ? NW * 256 : 1];  // per wave: 64 records of 4 float4
     __shared__ uint32_t s_c[2][NW];     // survivors per wave of the current round (double-buffered)
     __shared__ uint32_t s_lb[2 * LBW * NW];
     __shared__ uint32_t s_part[4][NW];  // per-wave partials: forecast prefix, new survivors, next-frame sums A / B
@@ -920,6 +956,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     const char *ib = Sp->buf[p];
     char *ob = Sp->buf[p ^ 1u];
     char *destroyed = Sp->destroyed;
+    char *inst = INST ? Sp->inst : nullptr;  // attached ParticleInstance output of this segment (or null)
+    const uint32_t inst_cap = INST ? Sp->inst_cap : 0u;
 
     const unsigned long long tsA = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (C & 0u)) : 0ull;
     // round 0 of a live tile goes out now
@@ -1067,8 +1105,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
                 run += c;
             }
             const uint32_t o = wbase + fw_lane_prefix(m);
+            // the lane's instance record goes to its rank in the wave's LDS area as soon as each part is computed
+            float4 *rec = (INST && inst != nullptr) ? s_inst + wave * 256u + (o - wbase) * 4u : nullptr;
             fw_round_finish(T, s_keys, a.dt, a.dbg, q0c, q1c, q2c, q3c, valid, alive, true, age_new, idx, o, ib, ob, W,
-                            destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc);
+                            destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec);
+            if (INST && inst != nullptr && !(a.dbg & 2u)) fw_inst_flush(inst, inst_cap, s_inst + wave * 256u, lane, m, wbase);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n;
             if ((a.dbg & 8u) && r == 0) tsR1 = __builtin_amdgcn_s_memrealtime() + (o & 0u);
         }
@@ -1104,8 +1145,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
                 run += c;
             }
             const uint32_t o = wbase + fw_lane_prefix(m);
+            float4 *rec = (INST && inst != nullptr) ? s_inst + wave * 256u + (o - wbase) * 4u : nullptr;
             fw_round_finish(T, s_keys, a.dt, a.dbg, so.q0, so.q1, so.q2, so.q3, valid, alive, false, age_new, idx, o, ib,
-                            ob, W, destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc);
+                            ob, W, destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec);
+            if (INST && inst != nullptr && !(a.dbg & 2u)) fw_inst_flush(inst, inst_cap, s_inst + wave * 256u, lane, m, wbase);
         }
     }
     if (lane == 0) s_part[2][wave] = acc.fa, s_part[3][wave] = acc.fb;
@@ -1539,27 +1582,27 @@ hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *ops, u
             hipLaunchKernelGGL(kern, grid, block, 0, s, __VA_ARGS__);                             \
     } while (0)
 
-template <int R>
+template <int R, bool INST>
 static void fw_launch_update_r(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps &io,
                                int spawn_form, int mode, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(a.total_tiles), block(FW_TILE / R);
     if (mode == FW_MODE_SPLIT) {  // debugging / A-B mode: three launches, no inter-workgroup traffic
         FW_LAUNCH_T(fw_k_count, grid, dim3(FW_BLOCK), s, e0, (hipEvent_t) nullptr, g, a);
         hipLaunchKernelGGL(fw_k_scan, dim3(a.n_seg), dim3(FW_BLOCK), 0, s, g, a);
-        FW_LAUNCH_T((fw_k_update<false, FW_SPAWN_NONE, R>), grid, block, s, (hipEvent_t) nullptr, e1, g, a, io);
+        FW_LAUNCH_T((fw_k_update<false, FW_SPAWN_NONE, R, INST>), grid, block, s, (hipEvent_t) nullptr, e1, g, a, io);
     } else if (a.use_stream && a.fc_in && a.fc_out) {  // forecast frame: streaming schedule
         if (spawn_form == FW_SPAWN_INLINE)
-            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_INLINE>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_INLINE, INST>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
         else if (spawn_form == FW_SPAWN_TABLE)
-            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_TABLE>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_TABLE, INST>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
         else
-            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_NONE>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_NONE, INST>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
     } else if (spawn_form == FW_SPAWN_INLINE) {
-        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_INLINE, R>), grid, block, s, e0, e1, g, a, io);
+        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_INLINE, R, INST>), grid, block, s, e0, e1, g, a, io);
     } else if (spawn_form == FW_SPAWN_TABLE) {
-        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_TABLE, R>), grid, block, s, e0, e1, g, a, io);
+        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_TABLE, R, INST>), grid, block, s, e0, e1, g, a, io);
     } else {
-        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_NONE, R>), grid, block, s, e0, e1, g, a, io);
+        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_NONE, R, INST>), grid, block, s, e0, e1, g, a, io);
     }
 }
 
@@ -1574,7 +1617,12 @@ hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArg
     const FwInlineOps &io = inl ? *inl : none;
     if (mode == FW_MODE_SPLIT && spawn_form != FW_SPAWN_NONE) return hipErrorInvalidValue;
     // 256 threads x 4 rounds is the measured optimum; 512 x 2 and 1024 x 1 were 25-30 % slower
-    fw_launch_update_r<FW_ROUNDS>(s, g, a, io, spawn_form, mode, ev_start, ev_stop);
+    // kernels that also write attached ParticleInstance buffers are separate instantiations: the plain ones keep
+    // their register budget
+    if (a.any_inst)
+        fw_launch_update_r<FW_ROUNDS, true>(s, g, a, io, spawn_form, mode, ev_start, ev_stop);
+    else
+        fw_launch_update_r<FW_ROUNDS, false>(s, g, a, io, spawn_form, mode, ev_start, ev_stop);
     return hipGetLastError();
 }
 

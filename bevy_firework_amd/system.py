@@ -129,6 +129,12 @@ class SpawnerData:
                                                          n.value, C.byref(n)))
         return out
 
+    def attach_instances(self, device_ptr: int, capacity: int, particle_type: int = 0) -> None:
+        """From the next step on the update kernel also writes this type's ParticleInstance records (render.rs:95-115)
+        into the caller's device buffer (`capacity` 64-byte records); 0 detaches."""
+        self._sys._check(self._sys._lib.fw_spawner_attach_instances(
+            self._sys._ctx, self.handle, particle_type, C.c_void_p(device_ptr) if device_ptr else None, int(capacity)))
+
     def aabb(self):
         """(any, min, max) of position -/+ scale over all particle types (render.rs:677-703)."""
         mn, mx, any_ = (C.c_float * 3)(), (C.c_float * 3)(), C.c_int32()

@@ -182,6 +182,13 @@ fw_status fw_spawner_pack_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
 /* same, into a DEVICE buffer on the context's stream (no sync): the render hand-off */
 fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap,
                                            uint64_t *n_upper_bound);
+/* Render hand-off fused into the update (render.rs:403 builds these records on the CPU every frame): from the next
+ * fw_step on, the update kernel itself also writes the ParticleInstance record of every particle of (spawner, type) that
+ * survives the step into d_out[0 .. live count) -- device memory, `cap` records, particle order -- so the frame needs
+ * no packing pass.  Records beyond `cap` are dropped.  In frames that run Nested emission entries the children are
+ * appended after the update: use fw_spawner_pack_instances_device for a type that receives Nested children.
+ * d_out = NULL detaches.  Synchronises the context's stream once (the segment record changes). */
+fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap);
 /* update_aabbs reduction (render.rs:677-703), world space; *any = 0 when no particles */
 fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out_max[3], int32_t *any);
 

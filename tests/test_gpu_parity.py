@@ -326,6 +326,56 @@ def test_lifetime_window_bound_long_run(system):
     assert pair.gpu.count(0) > 20000
 
 
+def test_attached_instances_are_the_packed_records(system):
+    """render hand-off fused into the update (render.rs:95-115, :403): the records the update kernel writes into an
+    attached device buffer must be byte-identical to what the packing pass produces from the stored planes, on
+    forecast frames (streaming schedule), on changed-dt frames (look-back schedule) and with new particles in the
+    frame; records beyond the buffer's capacity are dropped, nothing is written past it"""
+    import torch
+
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.3, 1.1), initial_scale=S.RandF32(0.02, 0.08), linear_drag=0.2,
+                            scale_curve=S.FireworkCurve.even_samples([1.0, 2.0, 0.5]),
+                            base_color=S.FireworkGradient.even_samples([(1.0, 1.0, 1.0, 1.0), (0.0, 0.0, 0.0, 0.0)]),
+                            emissive_color=S.FireworkGradient.even_samples([(4.0, 2.0, 0.0, 1.0), (0.0, 0.0, 0.0, 1.0)]))
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(90000.0),
+                            initial_velocity=S.RandVec3(S.RandF32(0.0, 4.0), (0.0, 1.0, 0.0), 0.4),
+                            initial_angular_velocity=S.RandVec3(S.RandF32(0.0, 5.0), (0.0, 1.0, 0.0), 0.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [es]), seed=SEED, uid=71)
+    cap = 120000
+    guard = 64
+    buf = torch.full(((cap + guard) * 16,), float("nan"), dtype=torch.float32, device="cuda")
+    pair.gpu.attach_instances(buf.data_ptr(), cap)
+    dts = [1 / 60] * 30 + [1 / 45, 1 / 60, 1 / 60, 1 / 90] + [1 / 60] * 30
+    for i, dt in enumerate(dts):
+        dt = np.float32(dt)
+        system.update(dt)
+        pair.step_cpu(dt)
+        if i in (0, 5, 29, 30, 31, 33, 34, 40, len(dts) - 1):
+            n = pair.gpu.count(0)
+            ref = pair.gpu.instances(0)  # packing pass over the planes the same update stored
+            got = buf[: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
+            assert np.array_equal(got, ref.view(np.uint32).reshape(n, 16)), f"frame {i}: attached records differ from packed ones"
+            assert bool(torch.isnan(buf[cap * 16:]).all()), "wrote past the attached buffer"
+    pair.check(what="state after attached frames")
+    assert pair.gpu.count(0) > 40000
+    # a buffer smaller than the live count: the first `small` records, nothing beyond
+    small = 10000
+    buf2 = torch.full(((small + guard) * 16,), float("nan"), dtype=torch.float32, device="cuda")
+    pair.gpu.attach_instances(buf2.data_ptr(), small)
+    for _ in range(3):
+        system.update(DT)
+        pair.step_cpu(DT)
+    ref = pair.gpu.instances(0)
+    assert np.array_equal(buf2[: small * 16].cpu().numpy().view(np.uint32), ref.view(np.uint32).reshape(-1, 16)[:small].ravel())
+    assert bool(torch.isnan(buf2[small * 16:]).all())
+    pair.gpu.attach_instances(0, 0)  # detach
+    buf2.fill_(float("nan"))
+    system.update(DT)
+    pair.step_cpu(DT)
+    assert bool(torch.isnan(buf2).all())
+    pair.check(what="after detach")
+
+
 def test_live_count_ring(system):
     """per-frame live totals written by the update kernel into a caller-owned device ring (RCCL feed)"""
     import torch

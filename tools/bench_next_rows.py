@@ -47,7 +47,19 @@ for name, rate in (("1M live", 1.0e6), ("8M live", 8.0e6)):
         L.fw_spawner_pack_instances_device(ps._ctx, h.handle, 0, C.c_void_p(out.data_ptr()), out.numel() // 64, C.byref(ub))
     ps.synchronize()
     t_frame = (time.perf_counter() - t0) / 100
-    print(json.dumps({"config": name, "live": live,
+    # the same frame with the records written by the update kernel itself
+    h.attach_instances(out.data_ptr(), out.numel() // 64)
+    for _ in range(20):
+        ps.step(dt)
+    ps.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        ps.step(dt)
+    ps.synchronize()
+    t_fused = (time.perf_counter() - t0) / 200
+    h.attach_instances(0, 0)
+    print(json.dumps({"config": name, "live": live, "step_with_attached_instances_us": t_fused * 1e6,
+                      "fused_GBps_228B": live * 228 / t_fused / 1e9,
                       "pack_us": t_pack * 1e6, "pack_GBps_132B": live * 132 / t_pack / 1e9,
                       "aabb_call_us (incl. count readback + sync)": t_aabb * 1e6,
                       "step_plus_pack_us": t_frame * 1e6}))
