@@ -133,5 +133,10 @@ struct alignas(16) FwNestOp {
 #define FW_ERR_LOOKBACK_TIMEOUT 2u
 #define FW_ERR_FORECAST 4u          // a forecast entry carried the wrong frame tag (internal error)
 
-// segments longer than this use look-back even when a forecast exists (the prefix is a direct sum)
-#define FW_FC_MAX_TILES 4096u
+// survivor forecast sums (fw_kernels.hip): words between consecutive S entries (spreading them over more lines was
+// measured and changes nothing), words between consecutive group counters S2 (one 64-byte line each: they are hot),
+// and the segment size up to which tiles sum S directly instead of using S2
+#define FW_FC_S_STRIDE 1u
+#define FW_FC_S2_STRIDE 16u
+#define FW_FC_DIRECT 1024u
+

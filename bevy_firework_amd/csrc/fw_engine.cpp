@@ -170,8 +170,11 @@ struct fw_ctx {
     uint32_t vt_rounds = 1;  // new-particle tile size of the current frame (rounds of 256)
     bool tab_force = false;  // a segment was (re)built: re-send the descriptors even if the tile counts are equal
 
-    // survivor forecast tables (fw_k_update): [2][tiles_cap]
-    uint4 *d_fc = nullptr;
+    // survivor forecast sums (update kernels)
+    uint32_t *d_fc = nullptr;   // three rotating buffers of forecast sums: S[tiles_cap] | S2[tiles_cap / 64 + 1] | tag
+    size_t fc_len = 0;          // elements per buffer
+    uint64_t fc_seq = 0;        // forecast-producing frames so far (buffer rotation)
+    bool fc_dirty = false;      // the tile table changed: clear all three buffers before the next forecast frame
     bool fc_ok = false;        // the previous frame left a forecast that still describes the device state
     uint32_t fc_dt_bits = 0;   // ... computed for this dt
     uint64_t fc_tab_seq = 0;   // ... under this tile table
@@ -329,9 +332,11 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.dbg_ts, (32768 + 8 * ncap) * sizeof(unsigned long long)));
         FW_HIP(ctx, hipMemset(ctx->g.dbg_ts, 0, (32768 + 8 * ncap) * sizeof(unsigned long long)));
         if (ctx->d_fc) hipFree(ctx->d_fc);
-        FW_HIP(ctx, hipMalloc((void **)&ctx->d_fc, 2 * ncap * sizeof(uint4)));
-        FW_HIP(ctx, hipMemset(ctx->d_fc, 0, 2 * ncap * sizeof(uint4)));
+        ctx->fc_len = ncap * FW_FC_S_STRIDE + (ncap / 64 + 2) * FW_FC_S2_STRIDE + 8;  // S | S2 | tag
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_fc, 3 * ctx->fc_len * sizeof(uint32_t)));
+        FW_HIP(ctx, hipMemset(ctx->d_fc, 0, 3 * ctx->fc_len * sizeof(uint32_t)));
         ctx->fc_ok = false;
+        ctx->fc_dirty = false;
         ctx->tiles_cap = ncap;
     }
     if (nest_tiles > ctx->nest_tiles_cap) {
@@ -795,6 +800,7 @@ fw_status update_tile_table(fw_ctx *ctx) {
                 (unsigned long long)ctx->frame, (int)dirty, n_seg, n_seg ? ctx->tiles_dev[0] : 0u,
                 n_seg ? ctx->segs[0].ub : 0u);
     if (!dirty && ctx->d_tile_first) return FW_OK;
+    ctx->fc_dirty = true;  // forecast sums are indexed by global tile: a new table invalidates whatever they hold
     if (n_seg + 1 > ctx->tile_first_cap) {
         fw_status st = sync(ctx);
         if (st) return st;
@@ -1318,15 +1324,22 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     a.new_static = (new_static && ctx->use_static_new) ? 1u : 0u;
     for (const SegHost &S : ctx->segs) a.any_inst |= (S.in_use && S.inst != nullptr) ? 1u : 0u;
     a.use_stream = ctx->use_stream ? 1u : 0u;
-    for (uint32_t i = 0; i < n_seg && a.use_stream; i++)
-        if (ctx->tiles_dev[i] > FW_FC_MAX_TILES) a.use_stream = 0;
     uint32_t dt_bits;
     memcpy(&dt_bits, &dt, 4);
     const bool fc_frame = !legacy && ctx->use_forecast && ctx->d_fc != nullptr;
     if (fc_frame) {
-        a.fc_out = ctx->d_fc + (size_t)(ctx->frame & 1u) * ctx->tiles_cap;
-        if (ctx->fc_ok && ctx->fc_dt_bits == dt_bits && ctx->fc_tab_seq == ctx->tab_seq && a.epoch != 1u)
-            a.fc_in = ctx->d_fc + (size_t)((ctx->frame + 1u) & 1u) * ctx->tiles_cap;
+        const bool usable = ctx->fc_ok && ctx->fc_dt_bits == dt_bits && ctx->fc_tab_seq == ctx->tab_seq && a.epoch != 1u;
+        if (ctx->fc_dirty) {
+            // the tile indexing changed: sums left at indices of the old table must not leak into the new one
+            FW_HIP(ctx, hipMemsetAsync(ctx->d_fc, 0, 3 * ctx->fc_len * sizeof(uint32_t), ctx->stream));
+            ctx->fc_dirty = false;
+        }
+        a.fc_s2 = (uint32_t)ctx->tiles_cap * FW_FC_S_STRIDE;
+        a.fc_tag = (uint32_t)(ctx->fc_len - 1);
+        a.fc_out = ctx->d_fc + (size_t)(ctx->fc_seq % 3u) * ctx->fc_len;
+        a.fc_zero = ctx->d_fc + (size_t)((ctx->fc_seq + 1u) % 3u) * ctx->fc_len;
+        if (usable) a.fc_in = ctx->d_fc + (size_t)((ctx->fc_seq + 2u) % 3u) * ctx->fc_len;
+        ctx->fc_seq++;
     }
     // a snapshot row stays armed until its stores have been seen (a free-running host can be hundreds of frames
     // ahead of the device; re-arming by frame number would never catch one)

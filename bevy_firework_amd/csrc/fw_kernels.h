@@ -54,14 +54,21 @@ struct FwUpdateArgs {
     uint32_t vt_rounds;            // new-particle tiles are vt_rounds * (threads per workgroup) particles
     uint32_t resident_slots;       // fw_k_update workgroups resident at once (256 CUs x 4)
     uint32_t seg0_type;            // type index of segment 0 (used when n_seg == 1)
-    uint32_t use_stream;           // forecast frames: run fw_k_update_stream (every segment within FW_FC_MAX_TILES)
+    uint32_t use_stream;           // forecast frames: run fw_k_update_stream 
     uint32_t seg0_keys_off, seg0_keys_len;  // key pool window of segment 0's type (n_seg == 1)
     const uint2 *tile_keys;        // [n_seg] {keys_off, keys_len} of each segment's type (device)
     // optional per-frame total of live particles (feed of the RCCL all-reduce): every segment's finalizer adds its
     // new count to *live_out; workgroup 0 zeroes *live_next (the slot the next frame will use)
     unsigned long long *live_out, *live_next;
-    const uint4 *fc_in;            // null = forecast not applicable this frame -> decoupled look-back
-    uint4 *fc_out;
+    // Survivor forecast, as per-tile sums: S[t] = particles that survive one more step of this dt and will sit in input
+    // tile t of the next frame (global tile index); S2[g] = sum of S over tiles [64 g, 64 g + 64) at offset fc_s2; the
+    // word at fc_tag holds the epoch of the frame that produced the buffer.  Three buffers rotate: read the previous
+    // frame's (fc_in; null = not applicable this frame -> decoupled look-back), accumulate into fc_out with atomics,
+    // clear fc_zero for the frame after.
+    const uint32_t *fc_in;
+    uint32_t *fc_out;
+    uint32_t *fc_zero;
+    uint32_t fc_s2, fc_tag;
 };
 
 // small frames carry their spawn ops in the kernel arguments: no H2D copy, no extra dependency

@@ -98,6 +98,9 @@ __device__ __forceinline__ uint4 fw_ld4u(const char *win, uint32_t byte_off) {
         reinterpret_cast<const FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ uint32_t fw_ld1u(const uint32_t *base, uint32_t idx) {
+    return reinterpret_cast<const FW_GLOBAL uint32_t *>(reinterpret_cast<uintptr_t>(base))[idx];
+}
 struct FwOutWin {  // output planes advanced to slot `first` (workgroup-uniform)
     char *q0, *q1, *q2, *q3, *q5, *q6, *s4;
     uint32_t first;
@@ -432,6 +435,60 @@ __device__ __forceinline__ uint32_t fw_lookback(const unsigned long long *status
     return excl;
 }
 
+// ---- survivor forecast sums (FwUpdateArgs::fc_*) ----------------------------------------------------
+// The sums are accumulated with device-scope atomics, which execute at the memory side and serialise per cache line:
+// the group sums S2 (one word per 64 tiles) would all share a line or two, so each S2 counter has a 64-byte line of its
+// own (stride FW_FC_S2_STRIDE words), and segments of up to FW_FC_DIRECT tiles do not use S2 at all (their tiles sum
+// S directly: at most four loads per lane).
+// this lane's share of sum(S[lo .. hi)), lo = the segment's first tile: whole 64-tile groups come from S2 (large
+// segments only), the ragged ends from S; loads are issued unconditionally at a clamped index
+template <int BLK>
+__device__ __forceinline__ uint32_t fw_fc_prefix_part(const uint32_t *fc, uint32_t s2, uint32_t lo, uint32_t hi,
+                                                      uint32_t seg_tiles) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t nL, nG = 0u, nR = 0u, gl = 0u, gh = 0u;
+    if (seg_tiles <= FW_FC_DIRECT) {
+        nL = hi - lo;
+    } else {
+        gl = (lo + 63u) >> 6, gh = hi >> 6;
+        if (gl >= gh) nL = hi - lo;
+        else nL = gl * 64u - lo, nG = gh - gl, nR = hi - gh * 64u;
+    }
+    const uint32_t n = nL + nG + nR;
+    uint32_t part = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += BLK) {
+        const uint32_t i = i0 + tid;
+        const uint32_t idx = i < nL ? (lo + i) * FW_FC_S_STRIDE
+                                    : (i < nL + nG ? s2 + (gl + (i - nL)) * FW_FC_S2_STRIDE
+                                                   : (gh * 64u + (i - nL - nG)) * FW_FC_S_STRIDE);
+        const uint32_t v = fw_ld1u(fc, i < n ? idx : lo * FW_FC_S_STRIDE);
+        part += i < n ? v : 0u;
+    }
+    return part;
+}
+// a tile's contribution: sa survivors land in output tile A, sb in A + 1 (global tile indices; `limit` = end of segment)
+__device__ __forceinline__ void fw_fc_add(uint32_t *fc, uint32_t s2, uint32_t A, uint32_t sa, uint32_t sb, uint32_t limit,
+                                          uint32_t seg_tiles) {
+    const bool grouped = seg_tiles > FW_FC_DIRECT;
+    if (sa) {
+        atomicAdd(&fc[A * FW_FC_S_STRIDE], sa);
+        if (grouped) atomicAdd(&fc[s2 + (A >> 6) * FW_FC_S2_STRIDE], sa);
+    }
+    if (sb && A + 1u < limit) {
+        atomicAdd(&fc[(A + 1u) * FW_FC_S_STRIDE], sb);
+        if (grouped) atomicAdd(&fc[s2 + ((A + 1u) >> 6) * FW_FC_S2_STRIDE], sb);
+    }
+}
+// every workgroup (active or not) clears its own slot of the buffer the frame after the next will accumulate into
+__device__ __forceinline__ void fw_fc_housekeeping(const FwUpdateArgs &a) {
+    if (threadIdx.x == 0 && a.fc_zero) {
+        a.fc_zero[blockIdx.x * FW_FC_S_STRIDE] = 0u;
+        if ((blockIdx.x & 63u) == 0u) a.fc_zero[a.fc_s2 + (blockIdx.x >> 6) * FW_FC_S2_STRIDE] = 0u;
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0 && a.fc_out) a.fc_out[a.fc_tag] = a.epoch;
+}
+
+
 // R = rounds per tile; the workgroup has FW_TILE / R threads, so a tile is always FW_TILE particles.
 // R = 4 (256 threads) is the measured optimum on MI355X.
 //
@@ -479,18 +536,8 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         type_idx = g.segs[seg].type_idx;
     }
     uint32_t tis = blockIdx.x - first;
-    // Forecast entries of the whole segment: requested now (they depend on the descriptor only), consumed
-    // after the particle loads -- up to FC_U entries per lane in flight, the rest (huge segments) in a loop.
-    constexpr int FC_U = 8;
-    const bool use_fc = FUSED && a.fc_in != nullptr && seg_tiles <= FW_FC_MAX_TILES;
-    uint4 fce[FC_U];
-    if (use_fc) {
-#pragma unroll
-        for (int j = 0; j < FC_U; j++) {  // unconditional loads at a clamped index: all FC_U in flight at once
-            const uint32_t t = tid + (uint32_t)j * BLK;
-            fce[j] = a.fc_in[first + min(t, seg_tiles - 1u)];
-        }
-    }
+    const bool use_fc = FUSED && a.fc_in != nullptr;
+    fw_fc_housekeeping(a);
     const uint32_t p = a.parity;
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
     const uint32_t n_in = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
@@ -531,11 +578,10 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     const bool has_new = tis >= t_spawn;  // block-uniform: a tile is either all live or all new
     const uint32_t base = has_new ? n_in + (tis - t_spawn) * vtile : tis * FW_TILE;
     const uint32_t lim = has_new ? min(base + vtile, n_tot) : min(base + FW_TILE, n_in);
-    uint4 *fc_out = FUSED ? a.fc_out : nullptr;
+    uint32_t *fc_out = FUSED ? a.fc_out : nullptr;
 
     if (n_tot == 0 || tis >= n_act) {
         if (tid == 0) {
-            if (fc_out) fc_out[tile] = make_uint4(0u, 0u, 0u, a.epoch);  // contributes nothing next frame
             if (n_tot == 0 && tis == 0) {  // empty segment: its first tile still owns the bookkeeping
                 g.count[oidx] = 0;
                 g.spawned[oidx] = 0;
@@ -595,23 +641,12 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     const FwType T = g.types[type_idx];
     for (uint32_t i = tid; i < T.keys_len; i += BLK) s_keys[i] = g.keys[T.keys_off + i];
 
-    // ---- forecast prefix: entry t of the table = {survivors landing in output tile A, in A+1, A, tag}.
-    // (`tis` here is the remapped tile index; the loads above used only the descriptor.)
+    // ---- forecast prefix: survivors sitting in the input tiles before this one (all live tiles for a new-particle tile)
     uint32_t fc_part = 0;
     bool fc_bad = false;
     if (use_fc) {
-#pragma unroll
-        for (int j = 0; j < FC_U; j++) {
-            const uint4 e = fce[j];
-            const bool in = tid + (uint32_t)j * BLK < seg_tiles;  // beyond the table: a clamped duplicate, ignored
-            fc_bad |= in && e.w != a.epoch - 1u;
-            fc_part += in ? (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u)) : 0u;
-        }
-        for (uint32_t t = tid + FC_U * BLK; t < seg_tiles; t += BLK) {
-            const uint4 e = a.fc_in[first + t];
-            fc_bad |= e.w != a.epoch - 1u;
-            fc_part += (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u));
-        }
+        fc_part = fw_fc_prefix_part<BLK>(a.fc_in, a.fc_s2, first, first + min(tis, t_spawn), seg_tiles);
+        fc_bad = tid == 0 && fw_ld1u(a.fc_in, a.fc_tag) != a.epoch - 1u;
     }
 
     const unsigned long long tsC = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (fc_part & 0u)) : 0ull;
@@ -787,7 +822,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             uint32_t sa = 0, sb = 0;
 #pragma unroll
             for (int w = 0; w < NW; w++) sa += s_part[2][w], sb += s_part[3][w];
-            fc_out[tile] = make_uint4(sa, sb, fcA, a.epoch);
+            fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, first + seg_tiles, seg_tiles);
         }
     }
 
@@ -888,16 +923,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     // are out, so nothing waits for them here)
     const float key0 = tid < keys_len ? g.keys[keys_off + tid] : 0.0f;
     uint32_t tis = blockIdx.x - first;
-    // forecast entries of the whole segment, requested before anything else (they depend on the descriptor only)
-    constexpr int FC_U = 8;
-    uint4 fce[FC_U];
-    // (unconditional loads at a clamped index: a predicated load would sit in its own basic block and be waited
-    // for before the next one is issued -- eight serial round trips instead of one)
-#pragma unroll
-    for (int j = 0; j < FC_U; j++) {
-        const uint32_t t = tid + (uint32_t)j * BLK;
-        fce[j] = fw_ld4u(reinterpret_cast<const char *>(a.fc_in + first), min(t, seg_tiles - 1u) * 16u);
-    }
+    fw_fc_housekeeping(a);
     const uint32_t p = a.parity;
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
     const uint32_t n_in = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
@@ -928,11 +954,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     const bool has_new = tis >= t_spawn;
     const uint32_t base = has_new ? n_in + (tis - t_spawn) * vtile : tis * FW_TILE;
     const uint32_t lim = has_new ? min(base + vtile, n_tot) : min(base + FW_TILE, n_in);
-    uint4 *fc_out = a.fc_out;
+    uint32_t *fc_out = a.fc_out;
 
     if (n_tot == 0 || tis >= n_act) {
         if (tid == 0) {
-            fc_out[tile] = make_uint4(0u, 0u, 0u, a.epoch);
             if (n_tot == 0 && tis == 0) {
                 g.count[oidx] = 0;
                 g.spawned[oidx] = 0;
@@ -982,21 +1007,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     if (tid < keys_len) s_keys[tid] = key0;
     for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
 
-    // forecast prefix of this tile
-    uint32_t fc_part = 0;
-    bool fc_bad = false;
-#pragma unroll
-    for (int j = 0; j < FC_U; j++) {
-        const uint4 e = fce[j];
-        const bool in = tid + (uint32_t)j * BLK < seg_tiles;  // beyond the table: a clamped duplicate, ignored
-        fc_bad |= in && e.w != a.epoch - 1u;
-        fc_part += in ? (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u)) : 0u;
-    }
-    for (uint32_t t = tid + FC_U * BLK; t < seg_tiles; t += BLK) {
-        const uint4 e = a.fc_in[first + t];
-        fc_bad |= e.w != a.epoch - 1u;
-        fc_part += (e.z + 1u < tis ? e.x + e.y : (e.z < tis ? e.x : 0u));
-    }
+    // forecast prefix of this tile: survivors sitting in the input tiles before it (all live tiles for a new-particle tile)
+    uint32_t fc_part = fw_fc_prefix_part<BLK>(a.fc_in, a.fc_s2, first, first + min(tis, t_spawn), seg_tiles);
+    const bool fc_bad = tid == 0 && fw_ld1u(a.fc_in, a.fc_tag) != a.epoch - 1u;
     // survivors among a new-particle tile's particles: age 0, lifetime = RNG block 2 word 0 (core.rs:455).
     // When the host has established that every particle spawned this frame outlives the step (dt below the smallest
     // lifetime any of this frame's emitters can draw: a.new_static), nothing has to be counted or looked up: new
@@ -1157,7 +1170,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         uint32_t sa = 0, sb = 0;
 #pragma unroll
         for (int w = 0; w < NW; w++) sa += s_part[2][w], sb += s_part[3][w];
-        fc_out[tile] = make_uint4(sa, sb, fcA, a.epoch);
+        fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, first + seg_tiles, seg_tiles);
     }
     if ((a.dbg & 8u) && g.dbg_ts && tid == 0) {
         unsigned long long *d = g.dbg_ts + 32768 + ((size_t)(a.epoch & 1u) * gridDim.x + tile) * 8;  // two launches kept
