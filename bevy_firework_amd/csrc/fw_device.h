@@ -133,10 +133,8 @@ struct alignas(16) FwNestOp {
 #define FW_ERR_LOOKBACK_TIMEOUT 2u
 #define FW_ERR_FORECAST 4u          // a forecast entry carried the wrong frame tag (internal error)
 
-// survivor forecast sums (fw_kernels.hip): words between consecutive S entries (spreading them over more lines was
-// measured and changes nothing), words between consecutive group counters S2 (one 64-byte line each: they are hot),
-// and the segment size up to which tiles sum S directly instead of using S2
-#define FW_FC_S_STRIDE 1u
-#define FW_FC_S2_STRIDE 16u
+// survivor forecast sums (fw_kernels.hip), in 64-bit words: stride between consecutive group counters P2 (one 64-byte
+// line each: they are hot) and the segment size up to which tiles sum P directly instead of using P2
+#define FW_FC_S2_STRIDE 8u
 #define FW_FC_DIRECT 1024u
 

@@ -171,7 +171,7 @@ struct fw_ctx {
     bool tab_force = false;  // a segment was (re)built: re-send the descriptors even if the tile counts are equal
 
     // survivor forecast sums (update kernels)
-    uint32_t *d_fc = nullptr;   // three rotating buffers of forecast sums: S[tiles_cap] | S2[tiles_cap / 64 + 1] | tag
+    unsigned long long *d_fc = nullptr;   // three rotating buffers of forecast sums: S[tiles_cap] | S2[tiles_cap / 64 + 1] | tag
     size_t fc_len = 0;          // elements per buffer
     uint64_t fc_seq = 0;        // forecast-producing frames so far (buffer rotation)
     bool fc_dirty = false;      // the tile table changed: clear all three buffers before the next forecast frame
@@ -332,9 +332,9 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.dbg_ts, (32768 + 8 * ncap) * sizeof(unsigned long long)));
         FW_HIP(ctx, hipMemset(ctx->g.dbg_ts, 0, (32768 + 8 * ncap) * sizeof(unsigned long long)));
         if (ctx->d_fc) hipFree(ctx->d_fc);
-        ctx->fc_len = ncap * FW_FC_S_STRIDE + (ncap / 64 + 2) * FW_FC_S2_STRIDE + 8;  // S | S2 | tag
-        FW_HIP(ctx, hipMalloc((void **)&ctx->d_fc, 3 * ctx->fc_len * sizeof(uint32_t)));
-        FW_HIP(ctx, hipMemset(ctx->d_fc, 0, 3 * ctx->fc_len * sizeof(uint32_t)));
+        ctx->fc_len = ncap + (ncap / 64 + 2) * FW_FC_S2_STRIDE + 8;  // P | P2 | tag (64-bit words)
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_fc, 3 * ctx->fc_len * sizeof(unsigned long long)));
+        FW_HIP(ctx, hipMemset(ctx->d_fc, 0, 3 * ctx->fc_len * sizeof(unsigned long long)));
         ctx->fc_ok = false;
         ctx->fc_dirty = false;
         ctx->tiles_cap = ncap;
@@ -1331,10 +1331,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         const bool usable = ctx->fc_ok && ctx->fc_dt_bits == dt_bits && ctx->fc_tab_seq == ctx->tab_seq && a.epoch != 1u;
         if (ctx->fc_dirty) {
             // the tile indexing changed: sums left at indices of the old table must not leak into the new one
-            FW_HIP(ctx, hipMemsetAsync(ctx->d_fc, 0, 3 * ctx->fc_len * sizeof(uint32_t), ctx->stream));
+            FW_HIP(ctx, hipMemsetAsync(ctx->d_fc, 0, 3 * ctx->fc_len * sizeof(unsigned long long), ctx->stream));
             ctx->fc_dirty = false;
         }
-        a.fc_s2 = (uint32_t)ctx->tiles_cap * FW_FC_S_STRIDE;
+        a.fc_s2 = (uint32_t)ctx->tiles_cap;
         a.fc_tag = (uint32_t)(ctx->fc_len - 1);
         a.fc_out = ctx->d_fc + (size_t)(ctx->fc_seq % 3u) * ctx->fc_len;
         a.fc_zero = ctx->d_fc + (size_t)((ctx->fc_seq + 1u) % 3u) * ctx->fc_len;

@@ -60,14 +60,15 @@ struct FwUpdateArgs {
     // optional per-frame total of live particles (feed of the RCCL all-reduce): every segment's finalizer adds its
     // new count to *live_out; workgroup 0 zeroes *live_next (the slot the next frame will use)
     unsigned long long *live_out, *live_next;
-    // Survivor forecast, as per-tile sums: S[t] = particles that survive one more step of this dt and will sit in input
-    // tile t of the next frame (global tile index); S2[g] = sum of S over tiles [64 g, 64 g + 64) at offset fc_s2; the
+    // Survivor forecast, as per-tile sums: P[t] = {lo: particles that survive one more step of this dt and will sit in
+    // input tile t of the next frame, counted by the tiles whose output starts in t; hi: those that spill into t + 1}
+    // (global tile index); P2[g] = sum of P over tiles [64 g, 64 g + 64), one per 64-byte line from offset fc_s2; the
     // word at fc_tag holds the epoch of the frame that produced the buffer.  Three buffers rotate: read the previous
     // frame's (fc_in; null = not applicable this frame -> decoupled look-back), accumulate into fc_out with atomics,
     // clear fc_zero for the frame after.
-    const uint32_t *fc_in;
-    uint32_t *fc_out;
-    uint32_t *fc_zero;
+    const unsigned long long *fc_in;
+    unsigned long long *fc_out;
+    unsigned long long *fc_zero;
     uint32_t fc_s2, fc_tag;
 };
 

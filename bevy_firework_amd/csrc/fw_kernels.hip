@@ -436,14 +436,22 @@ __device__ __forceinline__ uint32_t fw_lookback(const unsigned long long *status
 }
 
 // ---- survivor forecast sums (FwUpdateArgs::fc_*) ----------------------------------------------------
-// The sums are accumulated with device-scope atomics, which execute at the memory side and serialise per cache line:
-// the group sums S2 (one word per 64 tiles) would all share a line or two, so each S2 counter has a 64-byte line of its
-// own (stride FW_FC_S2_STRIDE words), and segments of up to FW_FC_DIRECT tiles do not use S2 at all (their tiles sum
-// S directly: at most four loads per lane).
-// this lane's share of sum(S[lo .. hi)), lo = the segment's first tile: whole 64-tile groups come from S2 (large
-// segments only), the ragged ends from S; loads are issued unconditionally at a clamped index
+// A tile's survivors-of-the-next-step land in output tile A (sa of them) and A + 1 (sb).  Both go into ONE 64-bit word
+// P[A] = {lo += sa, hi += sb} with a single atomic, so the next frame's count of input tile t is lo(P[t]) + hi(P[t-1])
+// and the prefix a tile needs is   sum_{t < tis} (lo + hi)(P[t])  -  hi(P[tis - 1]).
+// Device-scope atomics execute at the memory side: each costs the kernel about 0.3 ns of wall time at 1M particles
+// (measured by doubling them), and counters sharing a cache line serialise, so the per-group sums P2 (one per 64
+// tiles, large segments only) have a 64-byte line each; segments of up to FW_FC_DIRECT tiles sum P directly.
+typedef unsigned long long fw_u64;
+__device__ __forceinline__ uint2 fw_ld2u(const fw_u64 *base, uint32_t idx) {
+    typedef uint32_t fw_u2v __attribute__((ext_vector_type(2)));
+    const fw_u2v v = reinterpret_cast<const FW_GLOBAL fw_u2v *>(reinterpret_cast<uintptr_t>(base))[idx];
+    return make_uint2(v.x, v.y);
+}
+// this lane's share of the prefix over tiles [lo, hi) (lo = the segment's first tile); the hi(P[hi-1]) correction is
+// applied by the lane that holds it; all loads are issued unconditionally at a clamped index
 template <int BLK>
-__device__ __forceinline__ uint32_t fw_fc_prefix_part(const uint32_t *fc, uint32_t s2, uint32_t lo, uint32_t hi,
+__device__ __forceinline__ uint32_t fw_fc_prefix_part(const fw_u64 *fc, uint32_t s2, uint32_t lo, uint32_t hi,
                                                       uint32_t seg_tiles) {
     const uint32_t tid = threadIdx.x;
     uint32_t nL, nG = 0u, nR = 0u, gl = 0u, gh = 0u;
@@ -455,37 +463,32 @@ __device__ __forceinline__ uint32_t fw_fc_prefix_part(const uint32_t *fc, uint32
         else nL = gl * 64u - lo, nG = gh - gl, nR = hi - gh * 64u;
     }
     const uint32_t n = nL + nG + nR;
+    const uint2 last = fw_ld2u(fc, hi > lo ? hi - 1u : lo);  // every lane loads it (one line), lane 0 uses it
     uint32_t part = 0;
     for (uint32_t i0 = 0; i0 < n; i0 += BLK) {
         const uint32_t i = i0 + tid;
-        const uint32_t idx = i < nL ? (lo + i) * FW_FC_S_STRIDE
-                                    : (i < nL + nG ? s2 + (gl + (i - nL)) * FW_FC_S2_STRIDE
-                                                   : (gh * 64u + (i - nL - nG)) * FW_FC_S_STRIDE);
-        const uint32_t v = fw_ld1u(fc, i < n ? idx : lo * FW_FC_S_STRIDE);
-        part += i < n ? v : 0u;
+        const uint32_t idx = i < nL ? lo + i : (i < nL + nG ? s2 + (gl + (i - nL)) * FW_FC_S2_STRIDE : gh * 64u + (i - nL - nG));
+        const uint2 v = fw_ld2u(fc, i < n ? idx : lo);
+        part += i < n ? v.x + v.y : 0u;
     }
+    if (tid == 0 && hi > lo) part -= last.y;
     return part;
 }
-// a tile's contribution: sa survivors land in output tile A, sb in A + 1 (global tile indices; `limit` = end of segment)
-__device__ __forceinline__ void fw_fc_add(uint32_t *fc, uint32_t s2, uint32_t A, uint32_t sa, uint32_t sb, uint32_t limit,
-                                          uint32_t seg_tiles) {
-    const bool grouped = seg_tiles > FW_FC_DIRECT;
-    if (sa) {
-        atomicAdd(&fc[A * FW_FC_S_STRIDE], sa);
-        if (grouped) atomicAdd(&fc[s2 + (A >> 6) * FW_FC_S2_STRIDE], sa);
-    }
-    if (sb && A + 1u < limit) {
-        atomicAdd(&fc[(A + 1u) * FW_FC_S_STRIDE], sb);
-        if (grouped) atomicAdd(&fc[s2 + ((A + 1u) >> 6) * FW_FC_S2_STRIDE], sb);
+// a tile's contribution (global tile index A; P2 only for large segments)
+__device__ __forceinline__ void fw_fc_add(fw_u64 *fc, uint32_t s2, uint32_t A, uint32_t sa, uint32_t sb, uint32_t seg_tiles) {
+    if (sa | sb) {
+        const fw_u64 v = (fw_u64)sa | ((fw_u64)sb << 32);
+        atomicAdd(&fc[A], v);
+        if (seg_tiles > FW_FC_DIRECT) atomicAdd(&fc[s2 + (A >> 6) * FW_FC_S2_STRIDE], v);
     }
 }
 // every workgroup (active or not) clears its own slot of the buffer the frame after the next will accumulate into
 __device__ __forceinline__ void fw_fc_housekeeping(const FwUpdateArgs &a) {
     if (threadIdx.x == 0 && a.fc_zero) {
-        a.fc_zero[blockIdx.x * FW_FC_S_STRIDE] = 0u;
-        if ((blockIdx.x & 63u) == 0u) a.fc_zero[a.fc_s2 + (blockIdx.x >> 6) * FW_FC_S2_STRIDE] = 0u;
+        a.fc_zero[blockIdx.x] = 0ull;
+        if ((blockIdx.x & 63u) == 0u) a.fc_zero[a.fc_s2 + (blockIdx.x >> 6) * FW_FC_S2_STRIDE] = 0ull;
     }
-    if (threadIdx.x == 0 && blockIdx.x == 0 && a.fc_out) a.fc_out[a.fc_tag] = a.epoch;
+    if (threadIdx.x == 0 && blockIdx.x == 0 && a.fc_out) a.fc_out[a.fc_tag] = (fw_u64)a.epoch;
 }
 
 
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     const bool has_new = tis >= t_spawn;  // block-uniform: a tile is either all live or all new
     const uint32_t base = has_new ? n_in + (tis - t_spawn) * vtile : tis * FW_TILE;
     const uint32_t lim = has_new ? min(base + vtile, n_tot) : min(base + FW_TILE, n_in);
-    uint32_t *fc_out = FUSED ? a.fc_out : nullptr;
+    fw_u64 *fc_out = FUSED ? a.fc_out : nullptr;
 
     if (n_tot == 0 || tis >= n_act) {
         if (tid == 0) {
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     bool fc_bad = false;
     if (use_fc) {
         fc_part = fw_fc_prefix_part<BLK>(a.fc_in, a.fc_s2, first, first + min(tis, t_spawn), seg_tiles);
-        fc_bad = tid == 0 && fw_ld1u(a.fc_in, a.fc_tag) != a.epoch - 1u;
+        fc_bad = tid == 0 && fw_ld2u(a.fc_in, a.fc_tag).x != a.epoch - 1u;
     }
 
     const unsigned long long tsC = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (fc_part & 0u)) : 0ull;
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             uint32_t sa = 0, sb = 0;
 #pragma unroll
             for (int w = 0; w < NW; w++) sa += s_part[2][w], sb += s_part[3][w];
-            fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, first + seg_tiles, seg_tiles);
+            fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, seg_tiles);
         }
     }
 
@@ -954,7 +957,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     const bool has_new = tis >= t_spawn;
     const uint32_t base = has_new ? n_in + (tis - t_spawn) * vtile : tis * FW_TILE;
     const uint32_t lim = has_new ? min(base + vtile, n_tot) : min(base + FW_TILE, n_in);
-    uint32_t *fc_out = a.fc_out;
+    fw_u64 *fc_out = a.fc_out;
 
     if (n_tot == 0 || tis >= n_act) {
         if (tid == 0) {
@@ -1009,7 +1012,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
 
     // forecast prefix of this tile: survivors sitting in the input tiles before it (all live tiles for a new-particle tile)
     uint32_t fc_part = fw_fc_prefix_part<BLK>(a.fc_in, a.fc_s2, first, first + min(tis, t_spawn), seg_tiles);
-    const bool fc_bad = tid == 0 && fw_ld1u(a.fc_in, a.fc_tag) != a.epoch - 1u;
+    const bool fc_bad = tid == 0 && fw_ld2u(a.fc_in, a.fc_tag).x != a.epoch - 1u;
     // survivors among a new-particle tile's particles: age 0, lifetime = RNG block 2 word 0 (core.rs:455).
     // When the host has established that every particle spawned this frame outlives the step (dt below the smallest
     // lifetime any of this frame's emitters can draw: a.new_static), nothing has to be counted or looked up: new
@@ -1170,7 +1173,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         uint32_t sa = 0, sb = 0;
 #pragma unroll
         for (int w = 0; w < NW; w++) sa += s_part[2][w], sb += s_part[3][w];
-        fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, first + seg_tiles, seg_tiles);
+        fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, seg_tiles);
     }
     if ((a.dbg & 8u) && g.dbg_ts && tid == 0) {
         unsigned long long *d = g.dbg_ts + 32768 + ((size_t)(a.epoch & 1u) * gridDim.x + tile) * 8;  // two launches kept
