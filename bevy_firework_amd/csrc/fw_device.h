@@ -136,5 +136,5 @@ struct alignas(16) FwNestOp {
 // survivor forecast sums (fw_kernels.hip), in 64-bit words: stride between consecutive group counters P2 (one 64-byte
 // line each: they are hot) and the segment size up to which tiles sum P directly instead of using P2
 #define FW_FC_S2_STRIDE 8u
-#define FW_FC_DIRECT 1024u
+#define FW_FC_DIRECT 2048u
 

@@ -171,6 +171,8 @@ struct fw_ctx {
     bool tab_force = false;  // a segment was (re)built: re-send the descriptors even if the tile counts are equal
 
     // survivor forecast sums (update kernels)
+    uint32_t fc_sums_prev = 0;    // format of the forecast the last forecast frame produced
+    uint4 *d_fce = nullptr;       // [2][tiles_cap] forecast entries of small segments (double-buffered)
     unsigned long long *d_fc = nullptr;   // three rotating buffers of forecast sums: S[tiles_cap] | S2[tiles_cap / 64 + 1] | tag
     size_t fc_len = 0;          // elements per buffer
     uint64_t fc_seq = 0;        // forecast-producing frames so far (buffer rotation)
@@ -331,6 +333,9 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         if (ctx->g.dbg_ts) hipFree(ctx->g.dbg_ts);
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.dbg_ts, (32768 + 8 * ncap) * sizeof(unsigned long long)));
         FW_HIP(ctx, hipMemset(ctx->g.dbg_ts, 0, (32768 + 8 * ncap) * sizeof(unsigned long long)));
+        if (ctx->d_fce) hipFree(ctx->d_fce);
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_fce, 2 * ncap * sizeof(uint4)));
+        FW_HIP(ctx, hipMemset(ctx->d_fce, 0, 2 * ncap * sizeof(uint4)));
         if (ctx->d_fc) hipFree(ctx->d_fc);
         ctx->fc_len = ncap + (ncap / 64 + 2) * FW_FC_S2_STRIDE + 8;  // P | P2 | tag (64-bit words)
         FW_HIP(ctx, hipMalloc((void **)&ctx->d_fc, 3 * ctx->fc_len * sizeof(unsigned long long)));
@@ -1050,6 +1055,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     for (int i = 0; i < kTabRing; i++)
         if (ctx->h_keys[i]) hipHostFree(ctx->h_keys[i]);
     if (ctx->d_fc) hipFree(ctx->d_fc);
+    if (ctx->d_fce) hipFree(ctx->d_fce);
     if (ctx->h_snap) hipHostFree(ctx->h_snap);
     for (hipEvent_t ev : ctx->tev) hipEventDestroy(ev);
     hipStreamDestroy(ctx->copy_stream);
@@ -1328,7 +1334,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     memcpy(&dt_bits, &dt, 4);
     const bool fc_frame = !legacy && ctx->use_forecast && ctx->d_fc != nullptr;
     if (fc_frame) {
-        const bool usable = ctx->fc_ok && ctx->fc_dt_bits == dt_bits && ctx->fc_tab_seq == ctx->tab_seq && a.epoch != 1u;
+        for (uint32_t i = 0; i < n_seg; i++) a.fc_sums |= ctx->tiles_dev[i] > FW_FC_DIRECT ? 1u : 0u;
+        const bool usable = ctx->fc_ok && ctx->fc_dt_bits == dt_bits && ctx->fc_tab_seq == ctx->tab_seq && a.epoch != 1u &&
+                            ctx->fc_sums_prev == a.fc_sums;  // the previous frame left the other format otherwise
         if (ctx->fc_dirty) {
             // the tile indexing changed: sums left at indices of the old table must not leak into the new one
             FW_HIP(ctx, hipMemsetAsync(ctx->d_fc, 0, 3 * ctx->fc_len * sizeof(unsigned long long), ctx->stream));
@@ -1338,8 +1346,11 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         a.fc_tag = (uint32_t)(ctx->fc_len - 1);
         a.fc_out = ctx->d_fc + (size_t)(ctx->fc_seq % 3u) * ctx->fc_len;
         a.fc_zero = ctx->d_fc + (size_t)((ctx->fc_seq + 1u) % 3u) * ctx->fc_len;
+        a.fce_out = ctx->d_fce + (size_t)(ctx->fc_seq & 1u) * ctx->tiles_cap;
+        a.fce_in = ctx->d_fce + (size_t)((ctx->fc_seq + 1u) & 1u) * ctx->tiles_cap;
         if (usable) a.fc_in = ctx->d_fc + (size_t)((ctx->fc_seq + 2u) % 3u) * ctx->fc_len;
         ctx->fc_seq++;
+        ctx->fc_sums_prev = a.fc_sums;
     }
     // a snapshot row stays armed until its stores have been seen (a free-running host can be hundreds of frames
     // ahead of the device; re-arming by frame number would never catch one)

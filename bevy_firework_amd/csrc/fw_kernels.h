@@ -69,6 +69,12 @@ struct FwUpdateArgs {
     const unsigned long long *fc_in;
     unsigned long long *fc_out;
     unsigned long long *fc_zero;
+    // Segments of up to FW_FC_DIRECT tiles keep the forecast as one plain entry per tile instead: {survivors landing in
+    // output tile A, in A + 1, A, epoch} written with an ordinary store (no atomics: at 1M particles the thousand
+    // atomics cost ~0.7 us of a 25 us kernel), summed by every tile of the segment (at most 4 entries per lane).
+    const uint4 *fce_in;
+    uint4 *fce_out;
+    uint32_t fc_sums;  // 1: some segment exceeds FW_FC_DIRECT tiles -> this launch uses the sums (all segments)
     uint32_t fc_s2, fc_tag;
 };
 

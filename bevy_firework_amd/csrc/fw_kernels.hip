@@ -482,6 +482,34 @@ __device__ __forceinline__ void fw_fc_add(fw_u64 *fc, uint32_t s2, uint32_t A, u
         if (seg_tiles > FW_FC_DIRECT) atomicAdd(&fc[s2 + (A >> 6) * FW_FC_S2_STRIDE], v);
     }
 }
+// small segments: the forecast is one entry per tile {into A, into A + 1, A, epoch}; a tile adds what its predecessors
+// put into the tiles before it.  FW_FC_DIRECT / BLK entries per lane, requested up front (fw_fce_request) at a clamped
+// index, consumed here.
+constexpr int FW_FCE_U = 8;
+template <int BLK>
+__device__ __forceinline__ void fw_fce_request(const uint4 *fce_in, uint32_t first, uint32_t seg_tiles, uint4 (&e)[FW_FCE_U]) {
+    static_assert(FW_FCE_U * BLK >= (int)FW_FC_DIRECT, "entries per lane must cover a small segment");
+#pragma unroll
+    for (int j = 0; j < FW_FCE_U; j++) {
+        const uint32_t t = threadIdx.x + (uint32_t)j * BLK;
+        e[j] = fw_ld4u(reinterpret_cast<const char *>(fce_in + first), min(t, seg_tiles - 1u) * 16u);
+    }
+}
+template <int BLK>
+__device__ __forceinline__ uint32_t fw_fce_prefix_part(const uint4 (&e)[FW_FCE_U], uint32_t seg_tiles, uint32_t tis,
+                                                       uint32_t epoch, bool *bad) {
+    uint32_t part = 0;
+    bool b = false;
+#pragma unroll
+    for (int j = 0; j < FW_FCE_U; j++) {
+        const bool in = threadIdx.x + (uint32_t)j * BLK < seg_tiles;  // beyond the table: a clamped duplicate, ignored
+        b |= in && e[j].w != epoch - 1u;
+        part += in ? (e[j].z + 1u < tis ? e[j].x + e[j].y : (e[j].z < tis ? e[j].x : 0u)) : 0u;
+    }
+    *bad = b;
+    return part;
+}
+
 // every workgroup (active or not) clears its own slot of the buffer the frame after the next will accumulate into
 __device__ __forceinline__ void fw_fc_housekeeping(const FwUpdateArgs &a) {
     if (threadIdx.x == 0 && a.fc_zero) {
@@ -511,7 +539,7 @@ __device__ __forceinline__ void fw_fc_housekeeping(const FwUpdateArgs &a) {
 //     finished a kernel ago) and never waits for a co-resident workgroup.  Only tiles that hold freshly
 //     spawned particles look back -- among themselves -- for the survivors of the new particles.
 //   * otherwise: single-pass decoupled look-back over all earlier tiles of the segment.
-template <bool FUSED, int SPAWN, int R, bool INST>
+template <bool FUSED, int SPAWN, int R, bool INST, bool SUMS>
 __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdateArgs a, FwInlineOps inl) {
     constexpr int BLK = FW_TILE / R;
     constexpr int NW = BLK / 64;
@@ -540,7 +568,10 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     }
     uint32_t tis = blockIdx.x - first;
     const bool use_fc = FUSED && a.fc_in != nullptr;
-    fw_fc_housekeeping(a);
+    constexpr bool fc_small = !SUMS;  // one plain entry per tile (every segment small) instead of atomic sums
+    // (fw_fc_housekeeping runs at the end: a store this early would sit in front of every load in the vmcnt queue)
+    uint4 fce[FW_FCE_U];
+    if (use_fc && fc_small) fw_fce_request<BLK>(a.fce_in, first, seg_tiles, fce);
     const uint32_t p = a.parity;
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
     const uint32_t n_in = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
@@ -585,6 +616,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
 
     if (n_tot == 0 || tis >= n_act) {
         if (tid == 0) {
+            if (fc_out && fc_small) a.fce_out[tile] = make_uint4(0u, 0u, 0u, a.epoch);  // contributes nothing next frame
             if (n_tot == 0 && tis == 0) {  // empty segment: its first tile still owns the bookkeeping
                 g.count[oidx] = 0;
                 g.spawned[oidx] = 0;
@@ -594,6 +626,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             }
             if (blockIdx.x == 0 && a.live_next) *a.live_next = 0ull;
         }
+        if (SUMS) fw_fc_housekeeping(a);
         return;
     }
     const bool is_last = tis + 1u == n_act;
@@ -647,7 +680,9 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     // ---- forecast prefix: survivors sitting in the input tiles before this one (all live tiles for a new-particle tile)
     uint32_t fc_part = 0;
     bool fc_bad = false;
-    if (use_fc) {
+    if (use_fc && fc_small) {
+        fc_part = fw_fce_prefix_part<BLK>(fce, seg_tiles, tis, a.epoch, &fc_bad);
+    } else if (use_fc) {
         fc_part = fw_fc_prefix_part<BLK>(a.fc_in, a.fc_s2, first, first + min(tis, t_spawn), seg_tiles);
         fc_bad = tid == 0 && fw_ld2u(a.fc_in, a.fc_tag).x != a.epoch - 1u;
     }
@@ -825,7 +860,8 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             uint32_t sa = 0, sb = 0;
 #pragma unroll
             for (int w = 0; w < NW; w++) sa += s_part[2][w], sb += s_part[3][w];
-            fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, seg_tiles);
+            if (fc_small) a.fce_out[tile] = make_uint4(sa, sb, fcA, a.epoch);
+            else fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, seg_tiles);
         }
     }
 
@@ -841,6 +877,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         d[0] = ts0, d[1] = ts1, d[2] = ts2, d[3] = tsE;
         d[4] = tsA, d[5] = tsB, d[6] = tsC, d[7] = 0;
     }
+    if (SUMS) fw_fc_housekeeping(a);
     if (is_last && tid == 0) {
         const uint32_t nc = excl + cnt;
         g.count[oidx] = nc;
@@ -898,7 +935,7 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
     }
 }
 
-template <int SPAWN, bool INST>
+template <int SPAWN, bool INST, bool SUMS>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUpdateArgs a, FwInlineOps inl) {
     constexpr int R = FW_ROUNDS;
     constexpr int BLK = FW_BLOCK;
@@ -926,7 +963,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     // are out, so nothing waits for them here)
     const float key0 = tid < keys_len ? g.keys[keys_off + tid] : 0.0f;
     uint32_t tis = blockIdx.x - first;
-    fw_fc_housekeeping(a);
+    // forecast entries of a small segment: requested before anything else (they depend on the descriptor only)
+    constexpr bool fc_small = !SUMS;  // one plain entry per tile (every segment small) instead of atomic sums
+    uint4 fce[FW_FCE_U];
+    if (fc_small) fw_fce_request<BLK>(a.fce_in, first, seg_tiles, fce);
+    // (fw_fc_housekeeping runs at the end: a store this early would sit in front of every load in the vmcnt queue)
     const uint32_t p = a.parity;
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
     const uint32_t n_in = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
@@ -961,6 +1002,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
 
     if (n_tot == 0 || tis >= n_act) {
         if (tid == 0) {
+            if (fc_small) a.fce_out[tile] = make_uint4(0u, 0u, 0u, a.epoch);
             if (n_tot == 0 && tis == 0) {
                 g.count[oidx] = 0;
                 g.spawned[oidx] = 0;
@@ -970,6 +1012,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
             }
             if (blockIdx.x == 0 && a.live_next) *a.live_next = 0ull;
         }
+        if (SUMS) fw_fc_housekeeping(a);
         return;
     }
     const bool is_last = tis + 1u == n_act;
@@ -1011,8 +1054,14 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
 
     // forecast prefix of this tile: survivors sitting in the input tiles before it (all live tiles for a new-particle tile)
-    uint32_t fc_part = fw_fc_prefix_part<BLK>(a.fc_in, a.fc_s2, first, first + min(tis, t_spawn), seg_tiles);
-    const bool fc_bad = tid == 0 && fw_ld2u(a.fc_in, a.fc_tag).x != a.epoch - 1u;
+    uint32_t fc_part;
+    bool fc_bad;
+    if (fc_small) {
+        fc_part = fw_fce_prefix_part<BLK>(fce, seg_tiles, tis, a.epoch, &fc_bad);
+    } else {
+        fc_part = fw_fc_prefix_part<BLK>(a.fc_in, a.fc_s2, first, first + min(tis, t_spawn), seg_tiles);
+        fc_bad = tid == 0 && fw_ld2u(a.fc_in, a.fc_tag).x != a.epoch - 1u;
+    }
     // survivors among a new-particle tile's particles: age 0, lifetime = RNG block 2 word 0 (core.rs:455).
     // When the host has established that every particle spawned this frame outlives the step (dt below the smallest
     // lifetime any of this frame's emitters can draw: a.new_static), nothing has to be counted or looked up: new
@@ -1173,7 +1222,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         uint32_t sa = 0, sb = 0;
 #pragma unroll
         for (int w = 0; w < NW; w++) sa += s_part[2][w], sb += s_part[3][w];
-        fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, seg_tiles);
+        if (fc_small) a.fce_out[tile] = make_uint4(sa, sb, fcA, a.epoch);
+        else fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, seg_tiles);
     }
     if ((a.dbg & 8u) && g.dbg_ts && tid == 0) {
         unsigned long long *d = g.dbg_ts + 32768 + ((size_t)(a.epoch & 1u) * gridDim.x + tile) * 8;  // two launches kept
@@ -1190,6 +1240,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         const unsigned xcc = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 20);
         d[4] = tsA, d[5] = tsB, d[6] = ((unsigned long long)xcc << 32) | hwid, d[7] = tsR1;
     }
+    if (SUMS) fw_fc_housekeeping(a);
     if (is_last && tid == 0) {
         const uint32_t nc = run;  // excl + survivors of this tile
         g.count[oidx] = nc;
@@ -1598,27 +1649,27 @@ hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *ops, u
             hipLaunchKernelGGL(kern, grid, block, 0, s, __VA_ARGS__);                             \
     } while (0)
 
-template <int R, bool INST>
+template <int R, bool INST, bool SUMS>
 static void fw_launch_update_r(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps &io,
                                int spawn_form, int mode, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(a.total_tiles), block(FW_TILE / R);
     if (mode == FW_MODE_SPLIT) {  // debugging / A-B mode: three launches, no inter-workgroup traffic
         FW_LAUNCH_T(fw_k_count, grid, dim3(FW_BLOCK), s, e0, (hipEvent_t) nullptr, g, a);
         hipLaunchKernelGGL(fw_k_scan, dim3(a.n_seg), dim3(FW_BLOCK), 0, s, g, a);
-        FW_LAUNCH_T((fw_k_update<false, FW_SPAWN_NONE, R, INST>), grid, block, s, (hipEvent_t) nullptr, e1, g, a, io);
+        FW_LAUNCH_T((fw_k_update<false, FW_SPAWN_NONE, R, INST, SUMS>), grid, block, s, (hipEvent_t) nullptr, e1, g, a, io);
     } else if (a.use_stream && a.fc_in && a.fc_out) {  // forecast frame: streaming schedule
         if (spawn_form == FW_SPAWN_INLINE)
-            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_INLINE, INST>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_INLINE, INST, SUMS>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
         else if (spawn_form == FW_SPAWN_TABLE)
-            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_TABLE, INST>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_TABLE, INST, SUMS>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
         else
-            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_NONE, INST>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_NONE, INST, SUMS>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
     } else if (spawn_form == FW_SPAWN_INLINE) {
-        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_INLINE, R, INST>), grid, block, s, e0, e1, g, a, io);
+        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_INLINE, R, INST, SUMS>), grid, block, s, e0, e1, g, a, io);
     } else if (spawn_form == FW_SPAWN_TABLE) {
-        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_TABLE, R, INST>), grid, block, s, e0, e1, g, a, io);
+        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_TABLE, R, INST, SUMS>), grid, block, s, e0, e1, g, a, io);
     } else {
-        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_NONE, R, INST>), grid, block, s, e0, e1, g, a, io);
+        FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_NONE, R, INST, SUMS>), grid, block, s, e0, e1, g, a, io);
     }
 }
 
@@ -1635,10 +1686,15 @@ hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArg
     // 256 threads x 4 rounds is the measured optimum; 512 x 2 and 1024 x 1 were 25-30 % slower
     // kernels that also write attached ParticleInstance buffers are separate instantiations: the plain ones keep
     // their register budget
-    if (a.any_inst)
-        fw_launch_update_r<FW_ROUNDS, true>(s, g, a, io, spawn_form, mode, ev_start, ev_stop);
+    // likewise the two forecast formats: plain per-tile entries when every segment is small, atomic sums otherwise
+    if (a.any_inst && a.fc_sums)
+        fw_launch_update_r<FW_ROUNDS, true, true>(s, g, a, io, spawn_form, mode, ev_start, ev_stop);
+    else if (a.any_inst)
+        fw_launch_update_r<FW_ROUNDS, true, false>(s, g, a, io, spawn_form, mode, ev_start, ev_stop);
+    else if (a.fc_sums)
+        fw_launch_update_r<FW_ROUNDS, false, true>(s, g, a, io, spawn_form, mode, ev_start, ev_stop);
     else
-        fw_launch_update_r<FW_ROUNDS, false>(s, g, a, io, spawn_form, mode, ev_start, ev_stop);
+        fw_launch_update_r<FW_ROUNDS, false, false>(s, g, a, io, spawn_form, mode, ev_start, ev_stop);
     return hipGetLastError();
 }
 

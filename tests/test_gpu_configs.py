@@ -133,3 +133,24 @@ def test_config4_nested_mid_size(system):
     assert np.array_equal(pair.gpu.last_emitted(0, 1), pair.cpu.last_emitted(0, 1))
     c = pair.gpu.counts()
     assert c[0] > 35000 and c[1] > 300000
+
+
+def test_single_segment_beyond_the_entry_table(system):
+    """one particle type with more than FW_FC_DIRECT (2048) tiles: the survivor forecast switches from one plain entry
+    per tile to atomic per-tile sums + group sums, and back when enough particles have died; counts, order and
+    state must not notice (2.3M particles burst, lifetimes spread so that deaths hit every tile every frame)"""
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.05, 0.9), linear_drag=0.1, acceleration=(0.0, -9.81, 0.0))
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.OneShot(2_300_000),
+                            initial_velocity=S.RandVec3(S.RandF32(0.0, 3.0), (0.0, 1.0, 0.0), 0.0))
+    trickle = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(30000.0),
+                                 initial_velocity=S.RandVec3(S.RandF32(0.0, 3.0), (0.0, 1.0, 0.0), 0.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [es, trickle]), seed=SEED, uid=77)
+    counts = []
+    for fr in range(34):
+        system.update(DT)
+        pair.step_cpu(DT)
+        counts.append(pair.gpu.count(0))
+        if fr in (1, 4, 9, 14, 20, 27, 33):
+            pair.check(exact_all=True, what=f"frame {fr}")
+    assert counts[0] > 2_200_000 and counts[-1] < 1_200_000  # crossed the 2048-tile boundary on the way down
+    check_properties(pair.gpu.particles(0), "end")
