@@ -187,6 +187,8 @@ class ParticleSpawnerData {
     std::vector<fw_particle> particles(uint32_t particle_type);  // data.particles[i]
     std::vector<fw_particle> destroyed(uint32_t particle_type);
     std::vector<fw_particle_instance> instances(uint32_t particle_type);  // render.rs:95-115
+    // render hand-off fused into the update (fw_spawner_attach_instances): device buffer of `cap` 64-byte records
+    void attach_instances(void *device_buffer, uint64_t cap, uint32_t particle_type = 0);
     bool aabb(Vec3 &mn, Vec3 &mx);                                        // render.rs:677-703
     void set_transform(const Transform &local, const Transform *global = nullptr) {
         transform = local;
@@ -357,6 +359,9 @@ inline std::vector<fw_particle_instance> ParticleSpawnerData::instances(uint32_t
     std::vector<fw_particle_instance> v(n);
     if (n) sys->check(fw_spawner_pack_instances(sys->raw(), handle, t, v.data(), n, &n));
     return v;
+}
+inline void ParticleSpawnerData::attach_instances(void *device_buffer, uint64_t cap, uint32_t t) {
+    sys->check(fw_spawner_attach_instances(sys->raw(), handle, t, device_buffer, cap));
 }
 inline bool ParticleSpawnerData::aabb(Vec3 &mn, Vec3 &mx) {
     float a[3], b[3];
