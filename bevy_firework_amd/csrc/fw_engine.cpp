@@ -202,7 +202,8 @@ struct fw_ctx {
     uint32_t live_ring_n = 0;
     uint64_t live_ring_frames = 0;            // frames written since the ring was registered
 
-    float *d_aabb = nullptr;
+    float *d_aabb = nullptr;   // 256 partial boxes of the AABB query
+    float *h_aabb = nullptr;   // pinned result {min.xyz, any, max.xyz, -}
     unsigned long long *d_total = nullptr;
     uint32_t *d_segids = nullptr;
 };
@@ -1002,7 +1003,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     hipMemset(ctx->g.err, 0, 64);
     if ((e = hipMalloc((void **)&ctx->g.stats, 64)) != hipSuccess) return bail("hipMalloc", e);
     hipMemset(ctx->g.stats, 0, 64);
-    if ((e = hipMalloc((void **)&ctx->d_aabb, 64)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&ctx->d_aabb, 256 * 8 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&ctx->d_total, 64)) != hipSuccess) return bail("hipMalloc", e);
     ctx->g.seed = seed;
     if (const char *m = getenv("FW_UPDATE_MODE")) ctx->update_mode = !strcmp(m, "split") ? FW_MODE_SPLIT : FW_MODE_FUSED;
@@ -1057,6 +1058,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     if (ctx->d_fc) hipFree(ctx->d_fc);
     if (ctx->d_fce) hipFree(ctx->d_fce);
     if (ctx->h_snap) hipHostFree(ctx->h_snap);
+    if (ctx->h_aabb) hipHostFree(ctx->h_aabb);
     for (hipEvent_t ev : ctx->tev) hipEventDestroy(ev);
     hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -1709,24 +1711,16 @@ fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || !out_min || !out_max) return FW_EINVAL;
     hipSetDevice(ctx->device);
-    std::vector<uint32_t> c;
-    fw_status st = read_counts(ctx, c);
+    if (!ctx->h_aabb) FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_aabb, 8 * sizeof(float), hipHostMallocDefault));
+    // two launches, the result lands in pinned memory: one synchronisation, no copies
+    FW_HIP(ctx, fw_launch_aabb(ctx->stream, ctx->g, sp->seg.data(), (uint32_t)sp->seg.size(), ctx->parity, ctx->d_aabb,
+                               ctx->h_aabb));
+    fw_status st = sync(ctx);
+    if (!st) st = check_device_errors(ctx);
     if (st && st != FW_ECAPACITY) return st;
-    bool has = false;
-    for (uint32_t si : sp->seg) has |= c[si] != 0;
-    if (any) *any = has ? 1 : 0;
-    const float init[6] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f, FW_F32_MIN, FW_F32_MIN, FW_F32_MIN};
-    float res[6];
-    memcpy(res, init, sizeof res);
-    if (has) {
-        FW_HIP(ctx, hipMemcpy(ctx->d_aabb, init, sizeof init, hipMemcpyHostToDevice));
-        FW_HIP(ctx, hipMemcpy(ctx->d_segids, sp->seg.data(), sp->seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        FW_HIP(ctx, fw_launch_aabb(ctx->stream, ctx->g, ctx->d_segids, (uint32_t)sp->seg.size(), ctx->parity, ctx->d_aabb));
-        FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        FW_HIP(ctx, hipMemcpy(res, ctx->d_aabb, sizeof res, hipMemcpyDeviceToHost));
-    }
-    memcpy(out_min, res, 3 * sizeof(float));
-    memcpy(out_max, res + 3, 3 * sizeof(float));
+    const volatile float *r = ctx->h_aabb;
+    if (any) *any = r[3] != 0.0f ? 1 : 0;
+    for (int c = 0; c < 3; c++) out_min[c] = r[c], out_max[c] = r[4 + c];
     return st;
 }
 

@@ -100,7 +100,8 @@ hipError_t fw_launch_scatter(hipStream_t s, char *buf, uint32_t capacity, uint32
                              const void *d_in);
 hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, const uint32_t *d_count,
                                     uint32_t n_upper, void *d_out);
+// seg_ids: host array; d_part: device scratch of 256 * 8 floats; h_out8: PINNED host {min.xyz, any, max.xyz, -}
 hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, uint32_t n_segs, uint32_t parity,
-                          float *d_minmax6);
+                          float *d_part, float *h_out8);
 hipError_t fw_launch_total(hipStream_t s, const uint32_t *counts, uint32_t n_seg, unsigned long long *d_out);
 hipError_t fw_launch_copy_probe(hipStream_t s, const void *src, void *dst, size_t bytes);

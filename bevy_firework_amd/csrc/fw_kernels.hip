@@ -1578,19 +1578,29 @@ __device__ __forceinline__ void fw_atomic_maxf(float *addr, float v) {
 
 // update_aabbs reduction (reference src/render.rs:677-703): min/max over position -/+ scale.
 // blockIdx.y = segment of the spawner; out6 = {min xyz, max xyz}, pre-set to {+MAX, -MAX}.
-__global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, const uint32_t *seg_ids, uint32_t parity, float *out6) {
+// update_aabbs (render.rs:677-703) in two launches and no atomics: workgroups reduce position -/+ scale over their slice
+// of every particle type of the spawner into one partial box each; a single workgroup folds the partials and leaves
+// {min.xyz, any, max.xyz, -} in PINNED host memory, so the query costs one stream synchronisation and no copies.
+struct FwSegList {
+    uint32_t n;
+    uint32_t id[8];  // FW_MAX_TYPES
+};
+#define FW_AABB_BLOCKS 256u
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, FwSegList L, uint32_t parity, float *part8) {
     __shared__ float s_m[4][6];
-    const uint32_t seg = seg_ids[blockIdx.y];
-    const FwSeg &S = g.segs[seg];
-    const uint32_t n = g.count[parity * g.max_seg + seg];
-    const char *buf = S.buf[parity];
     float mn[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
     float mx[3] = {FW_F32_MIN, FW_F32_MIN, FW_F32_MIN};
-    for (uint32_t i = blockIdx.x * FW_BLOCK + threadIdx.x; i < n; i += gridDim.x * FW_BLOCK) {
-        const float4 q0 = fw_ld4(buf + FW_OFF_Q0(S.capacity), i);
-        const float sc = reinterpret_cast<const float *>(buf + FW_OFF_S4(S.capacity))[i];
-        mn[0] = fminf(mn[0], q0.x - sc), mn[1] = fminf(mn[1], q0.y - sc), mn[2] = fminf(mn[2], q0.z - sc);
-        mx[0] = fmaxf(mx[0], q0.x + sc), mx[1] = fmaxf(mx[1], q0.y + sc), mx[2] = fmaxf(mx[2], q0.z + sc);
+    for (uint32_t k = 0; k < L.n; k++) {
+        const uint32_t seg = L.id[k];
+        const FwSeg &S = g.segs[seg];
+        const uint32_t n = g.count[parity * g.max_seg + seg];
+        const char *buf = S.buf[parity];
+        for (uint32_t i = blockIdx.x * FW_BLOCK + threadIdx.x; i < n; i += gridDim.x * FW_BLOCK) {
+            const float4 q0 = fw_ld4(buf + FW_OFF_Q0(S.capacity), i);
+            const float sc = fw_ld1(buf + FW_OFF_S4(S.capacity), i);
+            mn[0] = fminf(mn[0], q0.x - sc), mn[1] = fminf(mn[1], q0.y - sc), mn[2] = fminf(mn[2], q0.z - sc);
+            mx[0] = fmaxf(mx[0], q0.x + sc), mx[1] = fmaxf(mx[1], q0.y + sc), mx[2] = fmaxf(mx[2], q0.z + sc);
+        }
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -1604,10 +1614,40 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, const uint32_
     if (lane == 0)
         for (int c = 0; c < 3; c++) s_m[wave][c] = mn[c], s_m[wave][3 + c] = mx[c];
     __syncthreads();
-    if (threadIdx.x < 3) {
-        const int c = threadIdx.x;
-        fw_atomic_minf(&out6[c], fminf(fminf(s_m[0][c], s_m[1][c]), fminf(s_m[2][c], s_m[3][c])));
-        fw_atomic_maxf(&out6[3 + c], fmaxf(fmaxf(s_m[0][3 + c], s_m[1][3 + c]), fmaxf(s_m[2][3 + c], s_m[3][3 + c])));
+    if (threadIdx.x < 6) {
+        const uint32_t c = threadIdx.x;
+        float v = s_m[0][c];
+        for (int w = 1; w < 4; w++) v = c < 3 ? fminf(v, s_m[w][c]) : fmaxf(v, s_m[w][c]);
+        part8[blockIdx.x * 8u + c] = v;
+    }
+}
+__global__ __launch_bounds__(FW_AABB_BLOCKS) void fw_k_aabb_fold(FwGlobals g, FwSegList L, uint32_t parity,
+                                                                 const float *part8, float *host8) {
+    __shared__ float s_m[FW_AABB_BLOCKS / 64][6];
+    float v[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        v[c] = part8[threadIdx.x * 8u + c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_xor(v[c], o, 64);
+            v[c] = c < 3 ? fminf(v[c], other) : fmaxf(v[c], other);
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int c = 0; c < 6; c++) s_m[wave][c] = v[c];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const uint32_t c = threadIdx.x;
+        float r = s_m[0][c];
+        for (uint32_t w = 1; w < FW_AABB_BLOCKS / 64; w++) r = c < 3 ? fminf(r, s_m[w][c]) : fmaxf(r, s_m[w][c]);
+        host8[c < 3 ? c : c + 1u] = r;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t any = 0;
+        for (uint32_t k = 0; k < L.n; k++) any |= g.count[parity * g.max_seg + L.id[k]];
+        host8[3] = any ? 1.0f : 0.0f;
     }
 }
 
@@ -1731,9 +1771,13 @@ hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t cap
 }
 
 hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, uint32_t n_segs, uint32_t parity,
-                          float *d_minmax6) {
-    if (!n_segs) return hipSuccess;
-    hipLaunchKernelGGL(fw_k_aabb, dim3(512, n_segs), dim3(FW_BLOCK), 0, s, g, seg_ids, parity, d_minmax6);
+                          float *d_part, float *h_out8) {
+    if (!n_segs || n_segs > 8u) return hipErrorInvalidValue;  // FW_MAX_TYPES
+    FwSegList L{};
+    L.n = n_segs;
+    for (uint32_t i = 0; i < n_segs; i++) L.id[i] = seg_ids[i];
+    hipLaunchKernelGGL(fw_k_aabb, dim3(FW_AABB_BLOCKS), dim3(FW_BLOCK), 0, s, g, L, parity, d_part);
+    hipLaunchKernelGGL(fw_k_aabb_fold, dim3(1), dim3(FW_AABB_BLOCKS), 0, s, g, L, parity, (const float *)d_part, h_out8);
     return hipGetLastError();
 }
 
