@@ -1286,6 +1286,12 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             } else {
                 if (es.pacing_kind != FW_PACING_COUNT_OVER_DURATION) continue;  // warn_once + continue core.rs:474-485
                 const SegHost &P = ctx->segs[sp.seg[es.target_particle_type]];
+                {  // children are born with age 0 like any new particle: do they all outlive this step?
+                    const fw_particle_settings &tp = sp.types[es.particle_index].ps;
+                    const float lo = std::min(tp.lifetime.min, tp.lifetime.max);
+                    const float lo_safe = std::nextafterf(std::nextafterf(lo, -INFINITY), -INFINITY);
+                    if (!(std::isfinite(tp.lifetime.min) && std::isfinite(tp.lifetime.max) && dt < lo_safe)) new_static = false;
+                }
                 FwNestOp op{};
                 op.parent_seg = sp.seg[es.target_particle_type], op.child_seg = dst;
                 op.emit = E.emit_idx, op.emit_slot = E.emit_slot;
@@ -1334,11 +1340,15 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     a.use_stream = ctx->use_stream ? 1u : 0u;
     uint32_t dt_bits;
     memcpy(&dt_bits, &dt, 4);
-    const bool fc_frame = !legacy && ctx->use_forecast && ctx->d_fc != nullptr;
+    // Frames with Nested entries materialise their new particles before the update; the streaming kernel takes them as
+    // loaded new-particle tiles with static slots, which needs every one of them to survive the step (new_static).
+    const bool split = ctx->update_mode == FW_MODE_SPLIT;
+    const bool fc_frame = !split && ctx->use_forecast && ctx->d_fc != nullptr;
     if (fc_frame) {
         for (uint32_t i = 0; i < n_seg; i++) a.fc_sums |= ctx->tiles_dev[i] > FW_FC_DIRECT ? 1u : 0u;
         const bool usable = ctx->fc_ok && ctx->fc_dt_bits == dt_bits && ctx->fc_tab_seq == ctx->tab_seq && a.epoch != 1u &&
-                            ctx->fc_sums_prev == a.fc_sums;  // the previous frame left the other format otherwise
+                            ctx->fc_sums_prev == a.fc_sums &&  // the previous frame left the other format otherwise
+                            (!legacy || (a.use_stream && a.new_static));
         if (ctx->fc_dirty) {
             // the tile indexing changed: sums left at indices of the old table must not leak into the new one
             FW_HIP(ctx, hipMemsetAsync(ctx->d_fc, 0, 3 * ctx->fc_len * sizeof(unsigned long long), ctx->stream));

@@ -970,8 +970,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     // (fw_fc_housekeeping runs at the end: a store this early would sit in front of every load in the vmcnt queue)
     const uint32_t p = a.parity;
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
-    const uint32_t n_in = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
-    uint32_t o0 = 0, o1 = 0, n_spawn = 0;
+    // SPAWN_NONE frames may have had this frame's new particles MATERIALISED behind the live ones (Global ops of a frame
+    // with Nested entries by fw_k_spawn, Nested children by fw_k_nest_spawn): they form the new-particle tiles here
+    // too, loaded instead of generated; the forecast only ever describes the live part [0, count).
+    const uint32_t n_in = SPAWN == FW_SPAWN_NONE ? g.count[sidx] : g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
+    uint32_t o0 = 0, o1 = 0, n_spawn = SPAWN == FW_SPAWN_NONE ? g.spawned[sidx] + g.appended[sidx] : 0u;
     if (SPAWN == FW_SPAWN_INLINE) {
         for (uint32_t i = 0; i < a.n_ops; i++) {
             if (inl.ops[i].seg == seg) {
@@ -989,7 +992,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     const uint32_t t_spawn = (n_in + FW_TILE - 1u) / FW_TILE;
     uint32_t vt_rounds = a.vt_rounds;
     if (a.n_seg == 1u) vt_rounds = (t_spawn + (n_spawn + BLK - 1u) / BLK <= a.resident_slots) ? 1u : 2u;
-    const uint32_t vtile = vt_rounds * BLK;
+    const uint32_t vtile = SPAWN == FW_SPAWN_NONE ? (uint32_t)FW_TILE : vt_rounds * BLK;  // materialised: full tiles
     const uint32_t n_vt = (n_spawn + vtile - 1u) / vtile;
     const uint32_t n_act = t_spawn + n_vt;
     if (SPAWN != FW_SPAWN_NONE && n_vt != 0 && n_vt <= FW_VFRONT && t_spawn != 0 && tis < n_act)
@@ -1038,12 +1041,13 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     // re-reads the tile's last particle and ignores it.)
     const uint32_t last = lim - 1u;  // lim > base for an active tile
     // input windows: the planes advanced to the tile's first slot (slot 0 for a new-particle tile, which loads nothing real)
-    const size_t ifirst = has_new ? (size_t)0 : (size_t)base * 16u;
+    const bool loaded_tile = !has_new || SPAWN == FW_SPAWN_NONE;  // block-uniform
+    const size_t ifirst = loaded_tile ? (size_t)base * 16u : (size_t)0;
     const char *iw0 = ib + FW_OFF_Q0(C) + ifirst, *iw1 = ib + FW_OFF_Q1(C) + ifirst;
     const char *iw2 = ib + FW_OFF_Q2(C) + ifirst, *iw3 = ib + FW_OFF_Q3(C) + ifirst;
     float4 q0c, q1c, q2c, q3c;
     {
-        const uint32_t i0 = has_new ? 0u : min(tid, last - base) * 16u;
+        const uint32_t i0 = loaded_tile ? min(tid, last - base) * 16u : 0u;
         q0c = fw_ld4w(iw0, i0);
         q3c = fw_ld4w(iw3, i0);
         q1c = fw_ld4w(iw1, i0);
@@ -1098,8 +1102,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
 #pragma unroll
     for (int w = 0; w < NW; w++) excl += s_part[0][w], new_cnt += s_part[1][w];
 
-    if (SPAWN != FW_SPAWN_NONE && has_new && a.new_static) {
+    if (has_new && (a.new_static || SPAWN == FW_SPAWN_NONE)) {
         excl += base - n_in;  // every earlier new particle survives
+        // (materialised new particles come here only when the host has shown that: it does not schedule this kernel
+        // for such a frame otherwise)
+        if (SPAWN == FW_SPAWN_NONE && !a.new_static && tid == 0) atomicOr(g.err, FW_ERR_FORECAST);
     } else if (SPAWN != FW_SPAWN_NONE && has_new) {  // look back among the new-particle tiles only
         const bool lb_needed = tis > t_spawn;
         if (lb_needed && tid == 0)
@@ -1146,8 +1153,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     excl = __builtin_amdgcn_readfirstlane(excl);  // workgroup-uniform (summed from LDS): keep it on the scalar unit
     const FwOutWin W = fw_out_window(ob, C, excl);
     uint32_t run = excl;
-    if (!has_new) {
-        // ---- live tile: stream the rounds
+    if (loaded_tile) {
+        // ---- live tile (or a tile of materialised new particles): stream the rounds
 #pragma unroll 1
         for (int r = 0; r < R; r++) {
             const uint32_t idx = base + r * BLK + tid;

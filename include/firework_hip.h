@@ -187,7 +187,8 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
  * survives the step into d_out[0 .. live count) -- device memory, `cap` records, particle order -- so the frame needs
  * no packing pass.  Records beyond `cap` are dropped.  In frames that run Nested emission entries the children are
  * appended after the update: use fw_spawner_pack_instances_device for a type that receives Nested children.
- * d_out = NULL detaches.  Synchronises the context's stream once (the segment record changes). */
+ * d_out = NULL detaches; fw_spawner_update_settings (which rebuilds the particle types) detaches too.
+ * Synchronises the context's stream once (the segment record changes). */
 fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap);
 /* update_aabbs reduction (render.rs:677-703), world space; *any = 0 when no particles */
 fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out_max[3], int32_t *any);
