@@ -11,7 +11,7 @@ def main(d, tail=60):
         rows = list(csv.DictReader(open(path)))
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in rows:
-            per[r["Kernel_Name"].split("(")[0][-34:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            per[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
         print(path.split("/")[-1])
         for k, cs in per.items():
             if "fw_k" not in k:

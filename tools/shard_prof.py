@@ -1,0 +1,21 @@
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from bevy_firework_amd import workloads, sharding
+from bevy_firework_amd.system import ParticleSystem
+ps = ParticleSystem(seed=workloads.SEED)
+ems = workloads.many_emitters(4096, 8192)
+mine = sharding.local_indices(4096, 0, 8)
+for e in mine:
+    ps.spawn(ems[e][0], ems[e][1], uid=e)
+dt = np.float32(1 / 60)
+ps.update(dt)
+for _ in range(80):
+    ps.step(dt)
+ps.synchronize()
+t0 = time.perf_counter()
+for _ in range(200):
+    ps.step(dt)
+t1 = time.perf_counter()
+ps.synchronize()
+print("us/step", (time.perf_counter() - t0) / 200 * 1e6, "host submit us/step", (t1 - t0) / 200 * 1e6, "live", ps.live_count())
