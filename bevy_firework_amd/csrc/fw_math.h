@@ -194,6 +194,13 @@ FW_HD float fw_clampf(float x, float lo, float hi) {
 // FireworkCurve<f32>::sample_clamped (curve.rs:26-32): clamp to the domain, lerp a + (b - a) * s
 FW_HD float fw_curve_sample(int kind, int n, const float *times, const float *vals, float t) {
     if (kind == 0 || n == 1) return vals[0];
+    if (kind == 1 && n == 2) {
+        // two evenly spaced keys (the linear fade every example uses): EvenCore with one subdivision is
+        // steps_taken = t, lo = 0, s = t - trunc(t) = t inside (0, 1) -- the same values without the index arithmetic
+        t = fw_clampf(t, 0.0f, 1.0f);
+        const float a = vals[0], b = vals[1];
+        return t <= 0.0f ? a : (t >= 1.0f ? b : a + (b - a) * t);
+    }
     int lo;
     float s = 0.0f;
     bool between;
@@ -212,6 +219,16 @@ FW_HD float fw_curve_sample(int kind, int n, const float *times, const float *va
 
 // FireworkGradient<LinearRgba>::sample_clamped (curve.rs:111-114,156-158); Mix: a*(1-f) + b*f
 FW_HD void fw_gradient_sample(int kind, int n, const float *times, const float *rgba, float t, float out[4]) {
+    if (kind == 1 && n == 2) {  // two evenly spaced keys: see fw_curve_sample (no clamp here: the ends select a key)
+        const bool lo_end = t <= 0.0f, hi_end = t >= 1.0f;
+        const float nf = 1.0f - t;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float a = rgba[c], b = rgba[4 + c];
+            out[c] = lo_end ? a : (hi_end ? b : a * nf + b * t);
+        }
+        return;
+    }
     int lo = 0;
     float s = 0.0f;
     bool between = false;
