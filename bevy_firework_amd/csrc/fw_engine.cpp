@@ -81,8 +81,9 @@ struct SegHost {
     // lifetime <= life_bound, so everything alive was spawned less than life_bound of simulated time ago.  The sum of
     // the Global spawn counts inside that window bounds the live count without any device feedback.
     struct Spawned {
-        double t;    // simulated time at the spawn
+        double t;        // simulated time at the spawn
         uint64_t n;
+        uint64_t frame;  // frame of the spawn (the device's ages are fp32 sums: the error grows with the steps taken)
     };
     std::deque<Spawned> win;
     uint64_t win_sum = 0;
@@ -1193,8 +1194,11 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         for (auto &S : ctx->segs) S.win_ok = false;  // ages would not grow monotonically
     for (auto &S : ctx->segs) {
         if (!S.in_use || !S.win_ok) continue;
-        const double horizon = S.life_bound * (1.0 + 1e-3) + 1e-6;
-        while (!S.win.empty() && ctx->sim_time - S.win.front().t >= horizon) {
+        // an age is an fp32 running sum of the dt values: up to half an ulp of the age per step taken, i.e. a relative
+        // error below steps * 6e-8; the horizon carries that (with a factor 4) on top of a fixed 1e-3
+        while (!S.win.empty() &&
+               ctx->sim_time - S.win.front().t >=
+                   S.life_bound * (1.0 + 1e-3 + 2.4e-7 * (double)(ctx->frame - S.win.front().frame)) + 1e-6) {
             S.win_sum -= S.win.front().n;
             S.win.pop_front();
         }
@@ -1279,7 +1283,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                             S.win.pop_front();
                             S.win.front().n += m;
                         }
-                        S.win.push_back(SegHost::Spawned{ctx->sim_time, n});
+                        S.win.push_back(SegHost::Spawned{ctx->sim_time, n, ctx->frame});
                     }
                     S.win_sum += n;
                 }
