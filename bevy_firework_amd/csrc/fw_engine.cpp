@@ -29,7 +29,7 @@
 
 namespace {
 
-constexpr int kParamRing = 4;    // per-frame parameter buffers in flight
+constexpr int kParamRing = 8;    // per-frame parameter buffers in flight
 constexpr int kSnapRing = 8;     // live-count snapshots in flight
 constexpr int kSnapEvery = 4;    // frames between snapshots
 constexpr int kTabRing = 4;      // staging buffers for tile-table uploads
@@ -144,6 +144,12 @@ struct fw_ctx {
     char *d_param[kParamRing] = {};
     hipEvent_t ev_copied[kParamRing] = {}, ev_consumed[kParamRing] = {};
     bool consumed_pending[kParamRing] = {};
+    // Global-only frames with more ops than fit the kernel arguments: the kernel reads the op table straight from the
+    // pinned ring slot (no copy, no events); a slot is free again once the launch after its frame has started, which
+    // that launch reports through a pinned word (FwUpdateArgs::done_tag).  FW_OPS_ZEROCOPY=0: staged copy + events.
+    bool ops_zerocopy = true;
+    unsigned long long *h_done = nullptr;      // pinned; written by workgroup 0 of every update launch
+    uint64_t slot_frame[kParamRing] = {};      // frame that last used the slot through the zero-copy path (+1; 0 = free)
 
     // live-count snapshots written by the update kernel into pinned host memory
     // Live-count snapshots: the update kernel stores {epoch, count} of each segment into a pinned row with one 8-byte
@@ -1000,6 +1006,8 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     for (int i = 0; i < kTabRing; i++)
         if ((e = hipEventCreateWithFlags(&ctx->ev_tab[i], hipEventDisableTiming)) != hipSuccess)
             return bail("hipEventCreate", e);
+    if ((e = hipHostMalloc((void **)&ctx->h_done, 64, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    *ctx->h_done = 0ull;
     if ((e = hipMalloc((void **)&ctx->g.err, 64)) != hipSuccess) return bail("hipMalloc", e);
     hipMemset(ctx->g.err, 0, 64);
     if ((e = hipMalloc((void **)&ctx->g.stats, 64)) != hipSuccess) return bail("hipMalloc", e);
@@ -1011,6 +1019,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_DEBUG")) ctx->dbg = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_FORECAST")) ctx->use_forecast = atoi(m) != 0;
     if (const char *m = getenv("FW_STREAM")) ctx->use_stream = atoi(m) != 0;
+    if (const char *m = getenv("FW_OPS_ZEROCOPY")) ctx->ops_zerocopy = atoi(m) != 0;
     if (const char *m = getenv("FW_STATIC_NEW")) ctx->use_static_new = atoi(m) != 0;  // 0: always count + look back
     if (const char *m = getenv("FW_SNAP_EVERY")) ctx->snap_every = std::max(1, atoi(m));
     if (const char *m = getenv("FW_SPIN_LIMIT")) ctx->spin_limit = (uint32_t)strtoul(m, nullptr, 10);
@@ -1060,6 +1069,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     if (ctx->d_fce) hipFree(ctx->d_fce);
     if (ctx->h_snap) hipHostFree(ctx->h_snap);
     if (ctx->h_aabb) hipHostFree(ctx->h_aabb);
+    if (ctx->h_done) hipHostFree(ctx->h_done);
     for (hipEvent_t ev : ctx->tev) hipEventDestroy(ev);
     hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -1463,6 +1473,12 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 FW_HIP(ctx, hipEventSynchronize(ctx->ev_consumed[slot]));
                 ctx->consumed_pending[slot] = false;
             }
+            if (ctx->slot_frame[slot]) {  // zero-copy use: wait until a launch AFTER that frame has started
+                const volatile unsigned long long *tag = ctx->h_done;
+                for (int spin = 0; *tag < ctx->slot_frame[slot] && spin < 200000; spin++) __builtin_ia32_pause();
+                if (*tag < ctx->slot_frame[slot]) FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                ctx->slot_frame[slot] = 0;
+            }
             char *hp = ctx->h_param[slot];
             char *dp = ctx->d_param[slot];
             uint32_t *sof = (uint32_t *)hp;
@@ -1473,13 +1489,22 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             }
             sof[n_seg] = (uint32_t)ops.size();
             memcpy(hp + off_ops, ops.data(), ops.size() * sizeof(FwOp));
-            FW_HIP(ctx, hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-            FW_HIP(ctx, hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
-            FW_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
-            a.seg_op_first = (const uint32_t *)dp;
-            a.ops = (const FwOp *)(dp + off_ops);
+            if (ctx->ops_zerocopy) {
+                // pinned host memory is device-visible: the tiles read their few ops over the bus (tens of bytes each)
+                a.seg_op_first = (const uint32_t *)hp;
+                a.ops = (const FwOp *)(hp + off_ops);
+                ctx->slot_frame[slot] = ctx->frame + 1;  // free once done_tag >= frame + 1
+                slot = -1;                                // no consumed-event for this slot
+            } else {
+                FW_HIP(ctx, hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+                FW_HIP(ctx, hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
+                FW_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
+                a.seg_op_first = (const uint32_t *)dp;
+                a.ops = (const FwOp *)(dp + off_ops);
+            }
         }
     }
+    if (ctx->h_done) a.done_tag = ctx->h_done, a.done_value = ctx->frame;
 
     // update_particles + compaction (core.rs:577-670)
     // timing: the events ride on the dispatch packet (its begin / end timestamps), no marker packets in the stream

@@ -42,6 +42,10 @@ struct FwUpdateArgs {
     float dt;
     uint32_t spin_limit;   // look-back polls before the self-computed fallback
     uint32_t any_inst;    // some segment has an attached instance buffer: run the kernels that also write the records
+    // pinned host word: workgroup 0 stores done_value at its START.  Launches of a stream run in order, so the host
+    // reads "every launch before frame done_value has finished" without an event (recycling of per-frame host rings)
+    unsigned long long *done_tag;
+    unsigned long long done_value;
     uint32_t new_static;  // 1: every particle spawned this frame survives the step (host-proved), offsets are static
     unsigned long long *host_counts;  // pinned host snapshot row for this frame (or null): epoch << 32 | count
     // Global spawn ops fused into the update (virtual particles appended after the live ones);

@@ -625,6 +625,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
                 if (a.host_counts) a.host_counts[seg] = (unsigned long long)a.epoch << 32;
             }
             if (blockIdx.x == 0 && a.live_next) *a.live_next = 0ull;
+            if (blockIdx.x == 0 && a.done_tag) *a.done_tag = a.done_value;
         }
         if (SUMS) fw_fc_housekeeping(a);
         return;
@@ -635,6 +636,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;  // diagnostics
     }
     if (blockIdx.x == 0 && tid == 0 && a.live_next) *a.live_next = 0ull;
+    if (blockIdx.x == 0 && tid == 0 && a.done_tag) *a.done_tag = a.done_value;
 
     // field-wise reads (block-uniform -> scalar loads)
     const FwSeg *Sp = &g.segs[seg];
@@ -1014,6 +1016,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
                 if (a.host_counts) a.host_counts[seg] = (unsigned long long)a.epoch << 32;
             }
             if (blockIdx.x == 0 && a.live_next) *a.live_next = 0ull;
+            if (blockIdx.x == 0 && a.done_tag) *a.done_tag = a.done_value;
         }
         if (SUMS) fw_fc_housekeeping(a);
         return;
@@ -1024,6 +1027,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;
     }
     if (blockIdx.x == 0 && tid == 0 && a.live_next) *a.live_next = 0ull;
+    if (blockIdx.x == 0 && tid == 0 && a.done_tag) *a.done_tag = a.done_value;
     const FwSeg *Sp = &g.segs[seg];
     const uint32_t C = Sp->capacity;
     const uint32_t n_lplanes = Sp->n_lplanes;
