@@ -1402,8 +1402,15 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             FW_HIP(ctx, hipEventSynchronize(ctx->ev_consumed[slot]));
             ctx->consumed_pending[slot] = false;
         }
+        if (ctx->slot_frame[slot]) {  // zero-copy use: wait until a launch AFTER that frame has started
+            const volatile unsigned long long *tag = ctx->h_done;
+            for (int spin = 0; *tag < ctx->slot_frame[slot] && spin < 200000; spin++) __builtin_ia32_pause();
+            if (*tag < ctx->slot_frame[slot]) FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->slot_frame[slot] = 0;
+        }
         char *hp = ctx->h_param[slot];
-        char *dp = ctx->d_param[slot];
+        char *dp = ctx->d_param[slot];  // staged copy here: the few workgroups of the small spawn / nest kernels would
+                                        // wait for the bus on their critical path (measured: no gain from reading in place)
         struct Launch {
             bool nested;
             size_t first, count;
