@@ -185,8 +185,8 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
 /* Render hand-off fused into the update (render.rs:403 builds these records on the CPU every frame): from the next
  * fw_step on, the update kernel itself also writes the ParticleInstance record of every particle of (spawner, type) that
  * survives the step into d_out[0 .. live count) -- device memory, `cap` records, particle order -- so the frame needs
- * no packing pass.  Records beyond `cap` are dropped.  In frames that run Nested emission entries the children are
- * appended after the update: use fw_spawner_pack_instances_device for a type that receives Nested children.
+ * no packing pass.  Records beyond `cap` are dropped.  Types that receive Nested children work too: children are spawned
+ * before the update of the same frame (plugin.rs:46-60), so they are among the records.
  * d_out = NULL detaches; fw_spawner_update_settings (which rebuilds the particle types) detaches too.
  * Synchronises the context's stream once (the segment record changes). */
 fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap);

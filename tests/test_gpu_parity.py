@@ -376,6 +376,30 @@ def test_attached_instances_are_the_packed_records(system):
     pair.check(what="after detach")
 
 
+def test_attached_instances_of_a_nested_child_type(system):
+    """frames with Nested entries spawn the children before the update of the same frame (plugin.rs:46-60), so the
+    records the update writes for the child type cover the new children too; sparks -> smoke, both types attached"""
+    import torch
+
+    spawner, tf = workloads.nested(spark_rate=4000.0, smoke_per_spark=20.0)
+    pair = Pair(system, spawner, tf, seed=SEED, uid=13)
+    cap = [20000, 200000]
+    bufs = [torch.full((c * 16,), float("nan"), dtype=torch.float32, device="cuda") for c in cap]
+    for t in (0, 1):
+        pair.gpu.attach_instances(bufs[t].data_ptr(), cap[t], particle_type=t)
+    for fr in range(90):
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr in (0, 3, 30, 60, 89):
+            for t in (0, 1):
+                n = pair.gpu.count(t)
+                ref = pair.gpu.instances(t)
+                got = bufs[t][: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
+                assert np.array_equal(got, ref.view(np.uint32).reshape(n, 16)), f"frame {fr} type {t}"
+    pair.check(what="nested with attached buffers")
+    assert pair.gpu.count(1) > 50000
+
+
 def test_live_count_ring(system):
     """per-frame live totals written by the update kernel into a caller-owned device ring (RCCL feed)"""
     import torch
