@@ -12,5 +12,11 @@ python profiles/analyze_trace.py $OUT/${TAG}_stats_kernel_trace.csv 600 > $OUT/t
 python profiles/analyze_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
 # 4. memory microbenchmark (measured roofline of the kernel's load/store shape)
 ./tools/membw 64 > $OUT/membw.txt 2>&1
+# 5. in-kernel timelines, launch period, the rows ranked next, size sweep, feature twins
+timeout 200 python tools/launch_gaps.py > $OUT/launch_gaps.txt 2>&1
+timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline.txt 2>&1
+timeout 300 python tools/bench_next_rows.py > $OUT/next_rows.txt 2>&1
+timeout 300 python tools/fused_sizes.py > $OUT/fused_sizes.txt 2>&1
+[ -x tools/launchgap ] && timeout 200 ./tools/launchgap > $OUT/launchgap.txt 2>&1
 rm -f $OUT/${TAG}_stats_kernel_trace.csv $OUT/pmc/*kernel_trace.csv   # large; the summaries are what is kept
 ls $OUT
