@@ -1,0 +1,146 @@
+"""Randomised parity: random spawner settings (curve kinds and key counts, shapes, pacings with offsets, several
+emission entries per type, Nested entries, drag / acceleration, modifiers, transforms) and irregular step sequences,
+HIP path against the CPU oracle through the C ABI.  Sizes are kept where the oracle finishes in about a second per case.
+Needs an MI355X."""
+import math
+
+import numpy as np
+import pytest
+
+from bevy_firework_amd import settings as S
+from parity import Pair
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED
+
+
+def _curve(rng):
+    k = rng.integers(0, 3)
+    if k == 0:
+        return S.FireworkCurve.constant(float(rng.uniform(0.2, 2.0)))
+    n = int(rng.integers(2, 6))
+    vals = [float(v) for v in rng.uniform(0.0, 3.0, size=n)]
+    if k == 1:
+        return S.FireworkCurve.even_samples(vals)
+    ts = np.sort(rng.uniform(0.0, 1.0, size=n))
+    ts[0], ts[-1] = (0.0, 1.0) if rng.random() < 0.7 else (ts[0], ts[-1])
+    ts = np.unique(ts.astype(np.float32))
+    return S.FireworkCurve.uneven_samples([(float(t), vals[i]) for i, t in enumerate(ts)]) if len(ts) >= 2 \
+        else S.FireworkCurve.constant(vals[0])
+
+
+def _gradient(rng):
+    k = rng.integers(0, 3)
+    col = lambda: tuple(float(c) for c in rng.uniform(0.0, 4.0, size=4))
+    if k == 0:
+        return S.FireworkGradient.constant(col())
+    n = int(rng.integers(2, 6))
+    if k == 1:
+        return S.FireworkGradient.even_samples([col() for _ in range(n)])
+    ts = np.unique(np.sort(rng.uniform(0.0, 1.0, size=n)).astype(np.float32))
+    if len(ts) < 2:
+        return S.FireworkGradient.constant(col())
+    return S.FireworkGradient.uneven_samples([(float(t), col()) for t in ts])
+
+
+def _unit(rng):
+    v = rng.normal(size=3)
+    v /= np.linalg.norm(v)
+    return tuple(float(c) for c in v)
+
+
+def _randvec(rng, mag_hi):
+    if rng.random() < 0.25:
+        return S.RandVec3.constant(tuple(float(c) for c in rng.uniform(-1.0, 1.0, size=3)))
+    lo = float(rng.uniform(0.0, mag_hi * 0.5))
+    return S.RandVec3(S.RandF32(lo, float(lo + rng.uniform(0.0, mag_hi))), _unit(rng), float(rng.uniform(0.0, math.pi)))
+
+
+def _pacing(rng, scale):
+    k = rng.integers(0, 4)
+    if k == 0:
+        return S.EmissionPacing.rate(float(rng.uniform(2000.0, 40000.0) * scale))
+    if k == 1:
+        dur = float(rng.uniform(0.2, 1.5))
+        a, b = sorted(rng.uniform(0.0, 1.0, size=2))
+        if b - a < 0.05:
+            a, b = 0.0, 1.0
+        return S.EmissionPacing.CountOverDuration(float(rng.uniform(500.0, 20000.0) * scale), dur, float(a), float(b))
+    if k == 2:
+        return S.EmissionPacing.OneShot(int(rng.integers(1, 30000) * scale) + 1)
+    return S.EmissionPacing.OnDemand()
+
+
+def _spawner(rng, scale=1.0):
+    n_types = int(rng.integers(1, 3))
+    types = []
+    for _ in range(n_types):
+        lo = float(rng.uniform(0.01, 0.6))
+        types.append(S.ParticleSettings(
+            lifetime=S.RandF32(lo, float(lo + rng.uniform(0.0, 1.2))) if rng.random() < 0.8 else S.RandF32.constant(lo + 0.3),
+            scale_curve=_curve(rng), initial_scale=S.RandF32(0.01, float(rng.uniform(0.02, 0.2))),
+            acceleration=tuple(float(c) for c in rng.uniform(-10.0, 10.0, size=3)),
+            angular_acceleration=tuple(float(c) for c in rng.uniform(-2.0, 2.0, size=3)),
+            linear_drag=float(rng.uniform(0.0, 1.0)), angular_drag=float(rng.uniform(0.0, 1.0)),
+            base_color=_gradient(rng), emissive_color=_gradient(rng), pbr=bool(rng.random() < 0.5)))
+    emissions = []
+    for _ in range(int(rng.integers(1, 4))):
+        shape = [S.EmissionShape.Point(), S.EmissionShape.Sphere(float(rng.uniform(0.1, 2.0))),
+                 S.EmissionShape.Circle(_unit(rng), float(rng.uniform(0.1, 2.0)))][int(rng.integers(0, 3))]
+        emissions.append(S.EmissionSettings(
+            particle_index=int(rng.integers(0, n_types)), emission_pacing=_pacing(rng, scale), emission_shape=shape,
+            initial_velocity=_randvec(rng, 6.0), initial_velocity_radial=S.RandF32(0.0, float(rng.uniform(0.0, 3.0))),
+            inherit_parent_velocity=bool(rng.random() < 0.5),
+            initial_rotation=tuple(float(c) for c in (lambda q: q / np.linalg.norm(q))(rng.normal(size=4))),
+            initial_angular_velocity=_randvec(rng, 8.0)))
+    if n_types == 2 and rng.random() < 0.6:  # one Nested entry: type 1 particles born on type 0 particles
+        emissions.append(S.EmissionSettings(
+            particle_index=1, emission_mode=S.EmissionMode.Nested(0),
+            emission_pacing=S.EmissionPacing.CountOverDuration(float(rng.uniform(1.0, 8.0)), 1.0, 0.0, float(rng.uniform(0.3, 1.0))),
+            inherit_parent_velocity=bool(rng.random() < 0.5), initial_velocity=_randvec(rng, 2.0)))
+    return S.ParticleSpawner(types, emissions)
+
+
+def _steps(rng, n):
+    base = float(rng.choice([1 / 60, 1 / 30, 1 / 144, 0.011]))
+    out = []
+    for i in range(n):
+        r = rng.random()
+        out.append(base if r < 0.8 else (0.0 if r < 0.83 else float(rng.uniform(0.002, 0.05))))
+    return out
+
+
+@pytest.mark.parametrize("case", range(40))
+def test_random_spawner_matches_the_oracle(case):
+    from bevy_firework_amd.system import ParticleSystem
+
+    rng = np.random.default_rng(1000 + case)
+    spawner = _spawner(rng, scale=1.0 if case % 4 else 6.0)  # every fourth case is several tiles per type
+    tf = S.Transform(tuple(float(c) for c in rng.uniform(-2.0, 2.0, size=3)),
+                     tuple(float(c) for c in (lambda q: q / np.linalg.norm(q))(rng.normal(size=4))))
+    mod = S.EffectModifier(float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.5, 2.0))) if rng.random() < 0.5 else None
+    with ParticleSystem(device=0, seed=SEED) as system:
+        pair = Pair(system, spawner, tf, seed=SEED, uid=100 + case, modifier=mod)
+        on_demand = any(e.emission_pacing.kind == S.PACING_ONDEMAND for e in spawner.emission_settings)
+        for i, dt in enumerate(_steps(rng, 36)):
+            dt = np.float32(dt)
+            if on_demand and i % 5 == 0:
+                pair.queue(int(rng.integers(0, 4000)))
+            system.update(dt)
+            pair.step_cpu(dt)
+            if i % 6 == 5 or i == 35:
+                pair.check(what=f"case {case} frame {i} dt={dt}")
+        test_random_spawner_matches_the_oracle.sizes[case] = pair.gpu.counts()
+
+
+test_random_spawner_matches_the_oracle.sizes = {}
+
+
+def test_random_cases_were_not_trivial():
+    """bookkeeping for the cases above: enough of them must have held a meaningful number of particles at the end"""
+    sizes = test_random_spawner_matches_the_oracle.sizes
+    if not sizes:
+        pytest.skip("the random cases did not run in this session")
+    totals = [sum(c) for c in sizes.values()]
+    assert sum(t > 2000 for t in totals) >= len(totals) // 2, totals
+    assert max(totals) > 50000, totals
