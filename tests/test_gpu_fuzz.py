@@ -144,3 +144,27 @@ def test_random_cases_were_not_trivial():
     totals = [sum(c) for c in sizes.values()]
     assert sum(t > 2000 for t in totals) >= len(totals) // 2, totals
     assert max(totals) > 50000, totals
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_random_multi_spawner_system(case):
+    """a dozen random spawners in one context: many segments in one launch, more spawn ops than fit the kernel
+    arguments (op table read from the pinned ring), per-segment forecast entries; every spawner against its own oracle"""
+    from bevy_firework_amd.system import ParticleSystem
+
+    rng = np.random.default_rng(5000 + case)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        pairs = []
+        for k in range(12):
+            spawner = _spawner(rng, scale=0.5)
+            tf = S.Transform(tuple(float(c) for c in rng.uniform(-3.0, 3.0, size=3)))
+            pairs.append(Pair(system, spawner, tf, seed=SEED, uid=200 + 16 * case + k))
+        for i, dt in enumerate(_steps(rng, 30)):
+            dt = np.float32(dt)
+            system.update(dt)
+            for p in pairs:
+                p.step_cpu(dt)
+            if i % 10 == 9:
+                for k, p in enumerate(pairs):
+                    p.check(what=f"case {case} spawner {k} frame {i}")
+        assert sum(sum(p.gpu.counts()) for p in pairs) > 5000
