@@ -112,7 +112,14 @@ struct DevArray {
 
 }  // namespace
 
+struct FwLevel {  // ops of one emission index (spawn order inside a frame: core.rs:377-428)
+    std::vector<FwOp> g;
+    std::vector<FwNestOp> n;
+};
+
 struct fw_ctx {
+    FwLevel levels[FW_MAX_EMISSIONS];  // per-frame scratch of fw_step
+    std::vector<FwOp> ops_scratch;
     int device = 0;
     uint32_t seed = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr;
@@ -1190,11 +1197,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     hipSetDevice(ctx->device);
     poll_snapshots(ctx);
 
-    struct Level {
-        std::vector<FwOp> g;
-        std::vector<FwNestOp> n;
-    };
-    Level levels[FW_MAX_EMISSIONS];
+    // per-frame scratch lives in the context: with thousands of emitters the allocations were a visible part of the
+    // host's ~60 ns per emitter
+    auto &levels = ctx->levels;
+    for (auto &L : levels) L.g.clear(), L.n.clear();
     for (auto &S : ctx->segs) S.frame_spawn = 0;
     bool new_static = std::isfinite(dt);  // cleared by any Global op whose particles might not survive this step
 
@@ -1462,10 +1468,14 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     } else {
         // Global-only frame: spawn is fused into the update kernel (virtual particles).  Ops sorted by segment;
         // the order inside a segment stays the emission order (rel_base was assigned in that order).
-        std::vector<FwOp> ops;
+        std::vector<FwOp> &ops = ctx->ops_scratch;
+        ops.clear();
         ops.reserve(n_g);
         for (auto &L : levels) ops.insert(ops.end(), L.g.begin(), L.g.end());
-        std::stable_sort(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; });
+        // sorted by segment, emission order kept inside a segment; a single emission level is already in spawner
+        // (= segment creation) order most of the time: skip the sort then
+        if (!std::is_sorted(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; }))
+            std::stable_sort(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; });
         a.n_ops = (uint32_t)ops.size();
         if (ops.size() <= FW_INLINE_OPS) {
             spawn_form = ops.empty() ? FW_SPAWN_NONE : FW_SPAWN_INLINE;
