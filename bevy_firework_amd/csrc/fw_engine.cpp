@@ -503,6 +503,34 @@ fw_status grow_segment(fw_ctx *ctx, uint32_t si, uint32_t need) {
     return ensure_tile_arrays(ctx);
 }
 
+// A parent type grew: the types its particles emit onto (Nested entries targeting it) were sized from the parent's
+// capacity (derive_capacity) and cannot grow on demand themselves -- their counts are only known on the device -- so
+// they follow the parent now, by the same rule.  Types with a caller-given capacity are left alone.
+fw_status grow_nested_children(fw_ctx *ctx, SpawnerHost &sp, uint32_t parent_type, int depth = 0) {
+    if (depth > FW_MAX_TYPES) return FW_OK;
+    const double pcap = ctx->segs[sp.seg[parent_type]].capacity;
+    for (const EmissionHost &E : sp.em) {
+        const fw_emission_settings &es = E.es;
+        if (es.mode != FW_MODE_NESTED || (uint32_t)es.target_particle_type != parent_type) continue;
+        if (es.pacing_kind != FW_PACING_COUNT_OVER_DURATION || !(es.count > 0)) continue;
+        const uint32_t ct = (uint32_t)es.particle_index;
+        if (ct == parent_type) continue;
+        const fw_particle_settings &cp = sp.types[ct].ps, &pp = sp.types[parent_type].ps;
+        if (cp.capacity) continue;
+        const double life = std::max(0.0, (double)std::max(cp.lifetime.min, cp.lifetime.max));
+        const double plife = std::max(1e-3, (double)std::min(pp.lifetime.min, pp.lifetime.max));
+        double need = pcap * (double)es.count * std::max(1.0, life / plife + 0.1) * 1.25 + kMinCapacity;
+        if (need > 3.0e9) need = 3.0e9;
+        SegHost &C = ctx->segs[sp.seg[ct]];
+        if (need > (double)C.capacity) {
+            fw_status st = grow_segment(ctx, sp.seg[ct], (uint32_t)need);
+            if (st) return st;
+            if ((st = grow_nested_children(ctx, sp, ct, depth + 1))) return st;
+        }
+    }
+    return FW_OK;
+}
+
 void copy_curve(CurveCopy &dst, int32_t kind, int32_t n, const float *times, const float *values, int stride) {
     dst.kind = kind;
     dst.n = n;
@@ -1268,6 +1296,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                         S.ub -= fs;
                         const uint32_t settled = S.ub;
                         if ((st = grow_segment(ctx, dst, (uint32_t)(settled + fs + n)))) return st;
+                        if ((st = grow_nested_children(ctx, sp, (uint32_t)es.particle_index))) return st;
                         for (auto &X : ctx->segs) X.ub += X.frame_spawn;
                     }
                 }

@@ -110,7 +110,7 @@ def _steps(rng, n):
     return out
 
 
-@pytest.mark.parametrize("case", range(40))
+@pytest.mark.parametrize("case", list(range(40)) + [339])  # 339: OnDemand parents outgrow the derived capacity of their Nested children
 def test_random_spawner_matches_the_oracle(case):
     from bevy_firework_amd.system import ParticleSystem
 
