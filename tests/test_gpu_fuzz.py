@@ -168,3 +168,64 @@ def test_random_multi_spawner_system(case):
                 for k, p in enumerate(pairs):
                     p.check(what=f"case {case} spawner {k} frame {i}")
         assert sum(sum(p.gpu.counts()) for p in pairs) > 5000
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_scenario_with_api_calls_between_frames(case):
+    """the calls a host makes between frames -- moving the origin, parent velocity, modifier, queueing, rewriting the
+    particles, the destroyed-particle stream, AABB and instance reads, attaching an instance buffer -- in random order
+    on a random spawner; state, destroyed records, bounds and instance records against the oracle after every call"""
+    import torch
+    from bevy_firework_amd.system import ParticleSystem
+
+    rng = np.random.default_rng(9000 + case)
+    spawner = _spawner(rng, scale=1.0 if case % 3 else 4.0)
+    for p in spawner.particle_settings:  # the destroyed stream only exists for types that register a handler
+        p.particles_destroyed = (lambda dead: None) if rng.random() < 0.6 else None
+    with ParticleSystem(device=0, seed=SEED) as system:
+        pair = Pair(system, spawner, S.Transform(), seed=SEED, uid=300 + case)
+        buf = None
+        for i, dt in enumerate(_steps(rng, 30)):
+            dt = np.float32(dt)
+            a = int(rng.integers(0, 8))
+            if a == 0:
+                tf = S.Transform(tuple(float(c) for c in rng.uniform(-3.0, 3.0, size=3)),
+                                 tuple(float(c) for c in (lambda q: q / np.linalg.norm(q))(rng.normal(size=4))))
+                pair.gpu.set_transform(tf)
+                pair.cpu.set_origin(tf.translation, tf.rotation)
+            elif a == 1:
+                v = tuple(float(c) for c in rng.uniform(-2.0, 2.0, size=3))
+                pair.gpu.set_parent_velocity(v)
+                pair.cpu.set_parent_velocity(v)
+            elif a == 2:
+                m = S.EffectModifier(float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.5, 2.0)))
+                pair.gpu.set_modifier(m)
+                pair.cpu.set_modifier(m)
+            elif a == 3:
+                pair.queue(int(rng.integers(0, 3000)))
+            elif a == 4 and i > 4:
+                t = int(rng.integers(0, pair.n_types))
+                parts = pair.cpu.particles(t)[:: int(rng.integers(1, 4))].copy()
+                pair.gpu.write_particles(t, parts)
+                pair.cpu.write_particles(t, parts)
+            elif a == 5 and buf is None:
+                buf = torch.full((60000 * 16,), float("nan"), dtype=torch.float32, device="cuda")
+                pair.gpu.attach_instances(buf.data_ptr(), 60000, particle_type=0)
+            system.update(dt)
+            pair.step_cpu(dt)
+            if i % 3 == 2:
+                pair.check(what=f"case {case} frame {i}")
+                for t in range(pair.n_types):
+                    if spawner.particle_settings[t].particles_destroyed is not None:
+                        from parity import assert_particles_match
+                        assert_particles_match(pair.gpu.destroyed(t), pair.cpu.destroyed(t), False, f"destroyed type {t} frame {i}")
+                any_g, mn_g, mx_g = pair.gpu.aabb()
+                any_c, mn_c, mx_c = pair.cpu.aabb()
+                assert any_g == any_c
+                if any_g:
+                    assert np.allclose(mn_g, mn_c, rtol=1e-5, atol=1e-4) and np.allclose(mx_g, mx_c, rtol=1e-5, atol=1e-4)
+                if buf is not None:
+                    n = min(pair.gpu.count(0), 60000)
+                    ref = pair.gpu.instances(0)[:n]
+                    got = buf[: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
+                    assert np.array_equal(got, ref.view(np.uint32).reshape(n, 16)), f"case {case} frame {i}: instance records"
