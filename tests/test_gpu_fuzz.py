@@ -211,6 +211,11 @@ def test_random_scenario_with_api_calls_between_frames(case):
             elif a == 5 and buf is None:
                 buf = torch.full((60000 * 16,), float("nan"), dtype=torch.float32, device="cuda")
                 pair.gpu.attach_instances(buf.data_ptr(), 60000, particle_type=0)
+            elif a == 6 and i > 8 and rng.random() < 0.4:  # Changed<ParticleSpawner>: state reset (core.rs:343-365)
+                pair.gpu.update_settings(spawner)
+                pair.cpu.reset()
+                if buf is not None:  # the rebuilt types start detached
+                    pair.gpu.attach_instances(buf.data_ptr(), 60000, particle_type=0)
             system.update(dt)
             pair.step_cpu(dt)
             if i % 3 == 2:
