@@ -159,12 +159,20 @@ def test_random_multi_spawner_system(case):
             spawner = _spawner(rng, scale=0.5)
             tf = S.Transform(tuple(float(c) for c in rng.uniform(-3.0, 3.0, size=3)))
             pairs.append(Pair(system, spawner, tf, seed=SEED, uid=200 + 16 * case + k))
+        next_uid = 200 + 16 * case + 12
         for i, dt in enumerate(_steps(rng, 30)):
             dt = np.float32(dt)
+            if i in (7, 13, 21):  # entities come and go: a spawner is despawned, another takes its slots
+                k = int(rng.integers(0, len(pairs)))
+                system.despawn(pairs[k].gpu)
+                pairs[k].cpu.close()
+                pairs[k] = Pair(system, _spawner(rng, scale=0.5), S.Transform(tuple(float(c) for c in rng.uniform(-3.0, 3.0, size=3))),
+                                seed=SEED, uid=1000 * (case + 1) + next_uid)
+                next_uid += 1
             system.update(dt)
             for p in pairs:
                 p.step_cpu(dt)
-            if i % 10 == 9:
+            if i % 10 == 9 or i in (8, 14, 22):
                 for k, p in enumerate(pairs):
                     p.check(what=f"case {case} spawner {k} frame {i}")
         assert sum(sum(p.gpu.counts()) for p in pairs) > 5000
