@@ -838,8 +838,10 @@ fw_status update_tile_table(fw_ctx *ctx) {
         }
         const uint32_t cap_tiles =
             (S.capacity + FW_TILE - 1) / FW_TILE + (S.frame_spawn + FW_VTILE - 1) / FW_VTILE + 1;
-        if (need > have || have > need + need / 4 + 8 || have > cap_tiles) {
-            have = std::min(cap_tiles, need + std::max<uint32_t>(2, need / 8));
+        // slack: an eighth for large segments; a small segment (thousands of small emitters) gets one spare tile --
+        // idle workgroups are cheap one by one, but two per segment doubled such a grid
+        if (need > have || have > need + need / 4 + (need >= 16 ? 8u : 2u) || have > cap_tiles) {
+            have = std::min(cap_tiles, need + (need >= 16 ? std::max<uint32_t>(2, need / 8) : 1u));
             dirty = true;
         }
     }

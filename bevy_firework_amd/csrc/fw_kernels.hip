@@ -807,8 +807,9 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     const uint32_t fcA = excl / FW_TILE, fc_bnd = (fcA + 1u) * FW_TILE;  // output tiles this workgroup feeds
     uint32_t fa = 0, fb = 0;
     uint32_t run = excl;  // output slot of the first survivor of (round r, wave 0)
+    const int n_rounds = (int)((lim - base + BLK - 1u) / BLK);  // a partial tile runs only the rounds that hold particles
 #pragma unroll 1
-    for (int r = 0; r < R; r++) {
+    for (int r = 0; r < n_rounds; r++) {
         const uint32_t idx = base + r * BLK + tid;
         // prefetch the next round's Q1 / Q2 (new particles were materialised above, so idx < n_tot is enough)
         const uint32_t in_ = has_new ? 0u : min(idx + BLK, lim - 1u);  // clamped, unconditional
@@ -939,7 +940,6 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
 
 template <int SPAWN, bool INST, bool SUMS>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUpdateArgs a, FwInlineOps inl) {
-    constexpr int R = FW_ROUNDS;
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
     constexpr int LBW = 4;
@@ -1158,9 +1158,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
     const FwOutWin W = fw_out_window(ob, C, excl);
     uint32_t run = excl;
     if (loaded_tile) {
-        // ---- live tile (or a tile of materialised new particles): stream the rounds
+        // ---- live tile (or a tile of materialised new particles): stream the rounds that hold particles (a segment's
+        // last tile is partial; with thousands of small emitters that is every tile)
+        const int n_rounds = (int)((lim - base + BLK - 1u) / BLK);
 #pragma unroll 1
-        for (int r = 0; r < R; r++) {
+        for (int r = 0; r < n_rounds; r++) {
             const uint32_t idx = base + r * BLK + tid;
             const uint32_t in_ = min((r + 1) * BLK + tid, last - base) * 16u;  // next round's slot (clamped: see above)
             const float4 q0n = fw_ld4w(iw0, in_);
