@@ -73,6 +73,8 @@ struct SegHost {
     uint32_t keys_off = 0, keys_len = 0;  // key pool window of the segment's type
     int32_t lplane_emission[FW_MAX_EMISSIONS];
     bool nested_fed = false;    // receives Nested children: count not host-predictable
+    bool auto_capacity = false; // capacity was derived (fw_particle_settings.capacity == 0): the library may grow it
+    uint32_t dev_count = 0;     // nested_fed: live count of the latest snapshot row (growth trigger)
     char *buf[2] = {nullptr, nullptr};
     char *destroyed = nullptr;
     char *inst = nullptr;       // caller-owned device buffer of ParticleInstance records (fw_spawner_attach_instances)
@@ -120,6 +122,20 @@ struct FwLevel {  // ops of one emission index (spawn order inside a frame: core
 struct fw_ctx {
     FwLevel levels[FW_MAX_EMISSIONS];  // per-frame scratch of fw_step
     std::vector<FwOp> ops_scratch;
+    // undo log of fw_step's host half: spawn_particles is all-or-nothing per frame in the reference, so a frame that
+    // cannot be enqueued (limit exceeded, allocation failure) must leave clocks, queues and RNG serials untouched
+    struct EmUndo {
+        uint32_t spawner, entry;
+        float last_emission, time_passed_in_cycle;
+        bool enabled;
+        uint64_t serial;
+    };
+    struct SpUndo {
+        uint32_t spawner;
+        uint64_t manual_queued_count;
+    };
+    std::vector<EmUndo> undo_em;
+    std::vector<SpUndo> undo_sp;
     int device = 0;
     uint32_t seed = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr;
@@ -573,6 +589,19 @@ fw_status validate_desc(fw_ctx *ctx, const fw_spawner_desc *d) {
             if (ns[k] > FW_MAX_KEYS) return fail(ctx, FW_EINVAL, "curve has more than FW_MAX_KEYS keys");
             if (ks[k] < 0 || ks[k] > 2 || !vs[k]) return fail(ctx, FW_EINVAL, "bad curve kind / null values");
             if (ks[k] == FW_CURVE_UNEVEN && !ts[k]) return fail(ctx, FW_EINVAL, "uneven curve without times");
+            if (ks[k] == FW_CURVE_UNEVEN && ns[k] >= 2) {
+                // UnevenCore::new drops non-finite times and duplicates; with fewer than two left it returns
+                // Err(NotEnoughSamples) and the reference's `.unwrap()` panics (curve.rs:50,67,217,232)
+                const float *tt = (const float *)ts[k];
+                int distinct = 0;
+                for (int a = 0; a < ns[k]; a++) {
+                    if (!std::isfinite(tt[a])) continue;
+                    bool dup = false;
+                    for (int b = 0; b < a; b++) dup |= std::isfinite(tt[b]) && tt[b] == tt[a];
+                    distinct += dup ? 0 : 1;
+                }
+                if (distinct < 2) return fail(ctx, FW_EINVAL, "uneven curve needs at least 2 distinct finite times");
+            }
         }
     }
     for (uint32_t i = 0; i < d->n_emission_settings; i++) {
@@ -693,11 +722,8 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         }
         dt.keys_off = type_idx * FW_KEYS_MAX;
         dt.keys_len = (uint32_t)keys.size();
-        FW_HIP(ctx, hipMemcpy(ctx->d_keys.d + dt.keys_off, keys.data(), keys.size() * sizeof(float),
-                              hipMemcpyHostToDevice));
-        FW_HIP(ctx, hipMemcpy(ctx->d_types.d + type_idx, &dt, sizeof dt, hipMemcpyHostToDevice));
-
-        // segment
+        // segment: the slot, its type index and the spawner's reference to it are recorded BEFORE anything that can
+        // fail, so that release_spawner_segments undoes a build that stops half-way (nothing leaks, nothing dangles)
         uint32_t si = (uint32_t)ctx->segs.size();
         for (uint32_t k = 0; k < ctx->segs.size(); k++)
             if (!ctx->segs[k].in_use) {
@@ -709,6 +735,10 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         S = SegHost{};
         S.in_use = true, S.spawner = h, S.type = (int)t, S.type_idx = type_idx;
         S.keys_off = dt.keys_off, S.keys_len = dt.keys_len;
+        sp.seg[t] = si;
+        FW_HIP(ctx, hipMemcpy(ctx->d_keys.d + dt.keys_off, keys.data(), keys.size() * sizeof(float),
+                              hipMemcpyHostToDevice));
+        FW_HIP(ctx, hipMemcpy(ctx->d_types.d + type_idx, &dt, sizeof dt, hipMemcpyHostToDevice));
         for (int k = 0; k < FW_MAX_EMISSIONS; k++) S.lplane_emission[k] = -1;
         for (uint32_t i = 0; i < ne; i++) {
             const fw_emission_settings &e = d->emission_settings[i];
@@ -716,10 +746,10 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
                 S.lplane_emission[S.n_lplanes++] = (int32_t)i;
             if (e.mode == FW_MODE_NESTED && (uint32_t)e.particle_index == t) S.nested_fed = true;
         }
+        S.auto_capacity = p.capacity == 0;
         S.life_bound = (double)std::max(p.lifetime.min, p.lifetime.max);  // lifetime = lerp(min, max, u), u in [0, 1)
         S.win_ok = !S.nested_fed && std::isfinite(S.life_bound);
         if ((st = alloc_seg_buffers(ctx, S, caps[t], p.report_destroyed != 0))) return st;
-        sp.seg[t] = si;
         if ((st = upload_seg(ctx, si))) return st;
         const uint32_t zero2[2] = {0, 0};
         for (int r = 0; r < 2; r++) {
@@ -945,9 +975,13 @@ void poll_snapshots(fw_ctx *ctx) {
         ctx->snap_pending[k] = false;
         for (size_t i = 0; i < n; i++) {
             SegHost &S = ctx->segs[i];
-            if (!S.in_use || S.nested_fed) continue;
+            if (!S.in_use) continue;
             const unsigned long long v = snap[i];
             if ((uint32_t)(v >> 32) != ctx->snap_epoch[k]) continue;  // that segment's store has not landed yet
+            if (S.nested_fed) {
+                S.dev_count = (uint32_t)v;  // no host-side bound exists; the count only drives capacity growth
+                continue;
+            }
             const uint64_t b = (uint64_t)(uint32_t)v + (S.cum_spawn - cum[i]);
             if (b < S.ub) S.ub = (uint32_t)b;
         }
@@ -1177,6 +1211,15 @@ fw_status fw_spawner_update_settings(fw_ctx *ctx, fw_spawner h, const fw_spawner
     memcpy(sp->parent_vel, keep.parent_vel, sizeof keep.parent_vel);
     sp->mod_scale = keep.mod_scale, sp->mod_speed = keep.mod_speed;
     st = build_spawner(ctx, h, desc, &serials);
+    if (st) {
+        // the old particle types are gone and the new ones could not be built: the handle dies (every later call on
+        // it returns FW_EINVAL) instead of pointing at segments that do not exist
+        const std::string why = ctx->err;
+        release_spawner_segments(ctx, ctx->spawners[h]);
+        ctx->spawners[h] = SpawnerHost{};
+        ctx->err = why + " (spawner destroyed: its settings could not be rebuilt)";
+        return st;
+    }
     ctx->spawners[h].finished_notified = finished_notified;
     return st;
 }
@@ -1251,6 +1294,34 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         if (S.win_sum < S.ub) S.ub = (uint32_t)S.win_sum;
     }
 
+    // Types fed by Nested entries cannot be bounded by the host (children are counted per parent on the device), so
+    // they cannot grow exactly when needed the way Global-fed ones do (the reference's Vec::push, core.rs:523).  Their
+    // derived capacity follows the live count seen in the snapshot rows instead: past half full, it doubles -- well
+    // before the device-side clamp (FW_ECAPACITY) could drop a particle.  Caller-given capacities are left alone.
+    for (uint32_t si = 0; si < ctx->segs.size(); si++) {
+        SegHost &S = ctx->segs[si];
+        if (!S.in_use || !S.nested_fed || !S.auto_capacity || S.dev_count <= S.capacity / 2) continue;
+        if (S.capacity >= 0x70000000u) continue;
+        S.dev_count = 0;
+        fw_status gst = grow_segment(ctx, si, S.capacity * 2u);
+        if (!gst) gst = grow_nested_children(ctx, ctx->spawners[S.spawner], (uint32_t)S.type);
+        if (gst) return gst;
+    }
+
+    // Everything the host half changes before the frame is known to be enqueueable goes through this log; `rollback`
+    // restores it (the per-segment live-count bounds only ever get looser, which is harmless).
+    ctx->undo_em.clear(), ctx->undo_sp.clear();
+    auto rollback = [&](fw_status why) {
+        for (const auto &u : ctx->undo_em) {
+            EmissionHost &E = ctx->spawners[u.spawner].em[u.entry];
+            E.last_emission = u.last_emission, E.time_passed_in_cycle = u.time_passed_in_cycle;
+            E.enabled = u.enabled, E.serial = u.serial;
+        }
+        for (const auto &u : ctx->undo_sp) ctx->spawners[u.spawner].manual_queued_count = u.manual_queued_count;
+        for (auto &S : ctx->segs) S.ub -= std::min(S.ub, S.frame_spawn), S.frame_spawn = 0;
+        return why;
+    };
+
     // spawn_particles, host half (core.rs:377-428): emission clocks and Global counts
     for (size_t h = 0; h < ctx->spawners.size(); h++) {
         SpawnerHost &sp = ctx->spawners[h];
@@ -1268,11 +1339,14 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             const uint32_t dst = sp.seg[es.particle_index];
             if (es.mode == FW_MODE_GLOBAL) {
                 uint64_t n = 0;
+                ctx->undo_em.push_back(fw_ctx::EmUndo{(uint32_t)h, (uint32_t)i, E.last_emission, E.time_passed_in_cycle,
+                                                      E.enabled, E.serial});
                 if (es.pacing_kind == FW_PACING_ONESHOT) {
                     E.enabled = false;  // core.rs:397-400
                     n = es.oneshot_count;
                 } else if (es.pacing_kind == FW_PACING_ONDEMAND) {
                     n = sp.manual_queued_count;  // core.rs:401-405
+                    if (n) ctx->undo_sp.push_back(fw_ctx::SpUndo{(uint32_t)h, n});
                     sp.manual_queued_count = 0;
                 } else {
                     E.time_passed_in_cycle = fw_rem_euclid(E.time_passed_in_cycle + dt, es.duration);  // core.rs:412-414
@@ -1283,23 +1357,25 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 }
                 if (!n) continue;
                 if (n > kMaxSpawnPerOp)
-                    return fail(ctx, FW_ECAPACITY, "emission count exceeds 2^30 particles in one frame");
+                    return rollback(fail(ctx, FW_ECAPACITY, "emission count exceeds 2^30 particles in one frame"));
                 SegHost &S = ctx->segs[dst];
                 if (!S.nested_fed && (uint64_t)S.ub + n > S.capacity) {
                     fw_status st = refresh_counts_exact(ctx);
-                    if (st) return st;
+                    if (st) return rollback(st);
                     // the refresh dropped this frame's earlier appends from ub: add them back
                     for (auto &X : ctx->segs) X.ub += X.frame_spawn;
                     if ((uint64_t)S.ub + n > S.capacity) {
-                        if ((uint64_t)S.ub + n > 0xF0000000ull) return fail(ctx, FW_ECAPACITY, "particle type too large");
+                        if ((uint64_t)S.ub + n > 0xF0000000ull)
+                            return rollback(fail(ctx, FW_ECAPACITY, "particle type too large"));
                         // grow_segment copies `ub - frame_spawn` settled particles; appended ones are not on the
                         // device yet (spawn kernels of this frame have not been enqueued)
                         const uint32_t fs = S.frame_spawn;
                         S.ub -= fs;
                         const uint32_t settled = S.ub;
-                        if ((st = grow_segment(ctx, dst, (uint32_t)(settled + fs + n)))) return st;
-                        if ((st = grow_nested_children(ctx, sp, (uint32_t)es.particle_index))) return st;
+                        st = grow_segment(ctx, dst, (uint32_t)(settled + fs + n));
+                        if (!st) st = grow_nested_children(ctx, sp, (uint32_t)es.particle_index);
                         for (auto &X : ctx->segs) X.ub += X.frame_spawn;
+                        if (st) return rollback(st);
                     }
                 }
                 {  // does every particle of this op outlive the step?  lifetime = u * (max - min) + min, u in [0, 1)
@@ -1319,21 +1395,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 levels[i].g.push_back(op);
                 E.serial += n;
                 S.frame_spawn += (uint32_t)n;
-                S.cum_spawn += n;
                 S.ub = (uint32_t)std::min<uint64_t>((uint64_t)S.ub + n, 0xFFFFFFFFull);
-                if (S.win_ok) {
-                    if (!S.win.empty() && S.win.back().t == ctx->sim_time) {
-                        S.win.back().n += n;
-                    } else {
-                        if (S.win.size() >= 8192) {  // very long lifetimes: fold the two oldest entries into the newer
-                            const uint64_t m = S.win.front().n;
-                            S.win.pop_front();
-                            S.win.front().n += m;
-                        }
-                        S.win.push_back(SegHost::Spawned{ctx->sim_time, n, ctx->frame});
-                    }
-                    S.win_sum += n;
-                }
+                // (cum_spawn and the lifetime window are committed below, once nothing can fail any more)
             } else {
                 if (es.pacing_kind != FW_PACING_COUNT_OVER_DURATION) continue;  // warn_once + continue core.rs:474-485
                 const SegHost &P = ctx->segs[sp.seg[es.target_particle_type]];
@@ -1356,11 +1419,34 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // ---- segment -> tile table (device resident, re-uploaded only when a bound moves out of its band)
     const uint32_t n_seg = (uint32_t)ctx->segs.size();
     fw_status st = update_tile_table(ctx);
-    if (st) return st;
+    if (st) return rollback(st);
     const uint32_t total_tiles = ctx->total_tiles_dev;
 
     size_t n_g = 0, n_n = 0;
     for (auto &L : levels) n_g += L.g.size(), n_n += L.n.size();
+    // last thing that can fail before the frame is enqueued: room for the op tables of either form
+    if ((st = ensure_param_ring(ctx, round_up((n_seg + 1) * sizeof(uint32_t), 16) + n_g * sizeof(FwOp) +
+                                         n_n * sizeof(FwNestOp) + 16)))
+        return rollback(st);
+    // ---- commit: the frame will run
+    for (auto &L : levels)
+        for (const FwOp &op : L.g) {
+            SegHost &S = ctx->segs[op.seg];
+            const uint64_t n = op.n;
+            S.cum_spawn += n;
+            if (!S.win_ok) continue;
+            if (!S.win.empty() && S.win.back().t == ctx->sim_time) {
+                S.win.back().n += n;
+            } else {
+                if (S.win.size() >= 8192) {  // very long lifetimes: fold the two oldest entries into the newer
+                    const uint64_t m = S.win.front().n;
+                    S.win.pop_front();
+                    S.win.front().n += m;
+                }
+                S.win.push_back(SegHost::Spawned{ctx->sim_time, n, ctx->frame});
+            }
+            S.win_sum += n;
+        }
     const uint32_t p = ctx->parity;
     const bool legacy = n_n != 0 || ctx->update_mode == FW_MODE_SPLIT;
 

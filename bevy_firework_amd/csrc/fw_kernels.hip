@@ -232,13 +232,16 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_spawn(FwGlobals g, const FwOp *
     const uint32_t sidx = parity * g.max_seg + op.seg;
     const FwSeg &S = g.segs[op.seg];
     const uint32_t base = g.count[sidx] + g.appended[sidx] + op.rel_base;
-    if (k == 0) atomicAdd(&g.spawned[sidx], op.n);
-    if (k >= op.n) return;
-    const uint32_t slot = base + k;
-    if (slot >= S.capacity) {
-        atomicOr(g.err, FW_ERR_CAPACITY);
-        return;
+    // Only what fits is counted: the update sizes its input from count + spawned + appended and must never see more
+    // than `capacity` particles (types that also receive Nested children cannot be grown by the host: their count is
+    // only known on the device).  Ops of one launch own disjoint slot ranges [base, base + n), so the clamps add up.
+    const uint32_t room = base < S.capacity ? S.capacity - base : 0u;
+    if (k == 0) {
+        atomicAdd(&g.spawned[sidx], min(op.n, room));
+        if (op.n > room) atomicOr(g.err, FW_ERR_CAPACITY);
     }
+    if (k >= op.n || k >= room) return;
+    const uint32_t slot = base + k;
     const FwEmit &e = g.emits[op.emit];
     FwSpawnOut o = fw_spawn_one(e, g.seed, op.serial_base + k, fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
                                 fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
@@ -588,6 +591,11 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         o0 = a.seg_op_first[seg], o1 = a.seg_op_first[seg + 1];
         for (uint32_t i = o0; i < o1; i++) n_spawn += a.ops[i].n;
     }
+    // virtual spawns beyond the segment's capacity are dropped (and reported): nothing may be read or written past it
+    const uint32_t seg_cap = g.segs[seg].capacity;
+    const uint32_t spawn_room = seg_cap - min(n_in, seg_cap);
+    const bool spawn_clamped = n_spawn > spawn_room;
+    n_spawn = min(n_spawn, spawn_room);
     const uint32_t n_tot = n_in + n_spawn;
     // Tiling of the index space [0, n_tot): the live particles [0, n_in) in tiles of FW_TILE, then the new
     // ones [n_in, n_tot) in SMALL tiles (1, 2 or 4 rounds, the smallest that keeps all active tiles of the frame
@@ -631,7 +639,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         return;
     }
     const bool is_last = tis + 1u == n_act;
-    if (tis == 0 && tid == 0 && n_act > seg_tiles) {
+    if (tis == 0 && tid == 0 && (n_act > seg_tiles || spawn_clamped)) {
         atomicOr(g.err, FW_ERR_CAPACITY);
         g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;  // diagnostics
     }
@@ -640,7 +648,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
 
     // field-wise reads (block-uniform -> scalar loads)
     const FwSeg *Sp = &g.segs[seg];
-    const uint32_t C = Sp->capacity;
+    const uint32_t C = seg_cap;
     const uint32_t n_lplanes = Sp->n_lplanes;
     char *ib = Sp->buf[p];  // written only at the slots of this frame's new particles
     char *ob = Sp->buf[p ^ 1u];
@@ -989,6 +997,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         o0 = a.seg_op_first[seg], o1 = a.seg_op_first[seg + 1];
         for (uint32_t i = o0; i < o1; i++) n_spawn += a.ops[i].n;
     }
+    const uint32_t seg_cap = g.segs[seg].capacity;  // virtual spawns beyond the capacity are dropped (and reported)
+    const uint32_t spawn_room = seg_cap - min(n_in, seg_cap);
+    const bool spawn_clamped = SPAWN != FW_SPAWN_NONE && n_spawn > spawn_room;
+    if (SPAWN != FW_SPAWN_NONE) n_spawn = min(n_spawn, spawn_room);
     const uint32_t n_tot = n_in + n_spawn;
     // tiling of [0, n_tot): identical to fw_k_update (live tiles of FW_TILE, then small new-particle tiles)
     const uint32_t t_spawn = (n_in + FW_TILE - 1u) / FW_TILE;
@@ -1022,14 +1034,14 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         return;
     }
     const bool is_last = tis + 1u == n_act;
-    if (tis == 0 && tid == 0 && n_act > seg_tiles) {
+    if (tis == 0 && tid == 0 && (n_act > seg_tiles || spawn_clamped)) {
         atomicOr(g.err, FW_ERR_CAPACITY);
-        g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;
+        g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;  // diagnostics
     }
     if (blockIdx.x == 0 && tid == 0 && a.live_next) *a.live_next = 0ull;
     if (blockIdx.x == 0 && tid == 0 && a.done_tag) *a.done_tag = a.done_value;
     const FwSeg *Sp = &g.segs[seg];
-    const uint32_t C = Sp->capacity;
+    const uint32_t C = seg_cap;
     const uint32_t n_lplanes = Sp->n_lplanes;
     const char *ib = Sp->buf[p];
     char *ob = Sp->buf[p ^ 1u];

@@ -191,7 +191,8 @@ FW_HD float fw_clampf(float x, float lo, float hi) {
     return x;
 }
 
-// FireworkCurve<f32>::sample_clamped (curve.rs:26-32): clamp to the domain, lerp a + (b - a) * s
+// FireworkCurve<f32>::sample_clamped (curve.rs:26-32): clamp to the domain, then VectorSpace::lerp a * (1 - s) + b * s
+// (bevy_math's StableInterpolate for NormedVectorSpace types; not glam's a + (b - a) * s)
 FW_HD float fw_curve_sample(int kind, int n, const float *times, const float *vals, float t) {
     if (kind == 0 || n == 1) return vals[0];
     if (kind == 1 && n == 2) {
@@ -199,7 +200,7 @@ FW_HD float fw_curve_sample(int kind, int n, const float *times, const float *va
         // steps_taken = t, lo = 0, s = t - trunc(t) = t inside (0, 1) -- the same values without the index arithmetic
         t = fw_clampf(t, 0.0f, 1.0f);
         const float a = vals[0], b = vals[1];
-        return t <= 0.0f ? a : (t >= 1.0f ? b : a + (b - a) * t);
+        return t <= 0.0f ? a : (t >= 1.0f ? b : a * (1.0f - t) + b * t);
     }
     int lo;
     float s = 0.0f;
@@ -214,7 +215,7 @@ FW_HD float fw_curve_sample(int kind, int n, const float *times, const float *va
     float a = vals[lo];
     if (!between) return a;
     float b = vals[lo + 1];
-    return a + (b - a) * s;
+    return a * (1.0f - s) + b * s;
 }
 
 // FireworkGradient<LinearRgba>::sample_clamped (curve.rs:111-114,156-158); Mix: a*(1-f) + b*f

@@ -110,7 +110,10 @@ static int uneven_interp(const float *times, int n, float t, int *lo, float *s) 
 }
 
 /* FireworkCurve<f32>::sample_clamped: Curve default = clamp to domain, then
- * sample_unchecked (curve.rs:26-32); f32 interpolation = a + (b - a) * s. */
+ * sample_unchecked (curve.rs:26-32).  f32 interpolation: bevy_math 0.19 implements
+ * StableInterpolate for every NormedVectorSpace as `self.lerp(*other, t)`, and inside that generic
+ * impl `lerp` is VectorSpace::lerp = self * (1. - t) + rhs * t (NOT glam's FloatExt::lerp
+ * a + (b - a) * t, which is not a candidate for a generic V).  Same form as Mix below. */
 float fwo_curve_sample_clamped(const fwo_curve *c, float t) {
     int lo;
     float s = 0.0f;
@@ -123,7 +126,7 @@ float fwo_curve_sample_clamped(const fwo_curve *c, float t) {
         if (!uneven_interp(c->times, c->n, t, &lo, &s)) return c->values[lo];
     }
     float a = c->values[lo], b = c->values[lo + 1];
-    return a + (b - a) * s;
+    return a * (1.0f - s) + b * s;
 }
 
 /* FireworkGradient<LinearRgba>::sample_clamped (curve.rs:111-114,156-158);

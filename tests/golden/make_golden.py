@@ -196,7 +196,38 @@ def update_kat():
     return {"source": "reference src/core.rs:591-658 (hand-derived, numpy float32)", "cases": cases}
 
 
+def trajectories():
+    """Multi-frame trajectories of the array-oriented numpy restatement (np_sim.py) over scenarios.py: particle
+    state of every type at the checkpoint frames, stored as raw float32 (bit patterns preserved) in one .npz."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import np_sim
+    import scenarios
+
+    out = {}
+    summary = {}
+    for name, make in scenarios.ALL.items():
+        sc = make()
+        sim = np_sim.Spawner(sc["spawner"], scenarios.SEED, sc["uid"], sc["transform"], sc["modifier"])
+        sim.parent_velocity = np.asarray(sc["parent_velocity"], dtype=f32)
+        counts = []
+        for fr in range(sc["frames"]):
+            sim.step(f32(sc["dts"][fr % len(sc["dts"])]))
+            if fr in sc["checkpoints"]:
+                for t, p in enumerate(sim.particles):
+                    for k, v in p.items():
+                        out[f"{name}/f{fr}/t{t}/{k}"] = np.ascontiguousarray(v, dtype=f32)
+                    d = sim.destroyed[t]
+                    out[f"{name}/f{fr}/t{t}/destroyed_age"] = np.ascontiguousarray(d["age"], dtype=f32)
+                    out[f"{name}/f{fr}/t{t}/destroyed_position"] = np.ascontiguousarray(d["position"], dtype=f32)
+                counts.append([fr] + [sim.count(t) for t in range(len(sim.particles))])
+        summary[name] = counts
+    np.savez_compressed(os.path.join(HERE, "trajectories.npz"), **out)
+    print("wrote trajectories.npz", {k: v[-1] for k, v in summary.items()})
+    return {"source": "tests/golden/np_sim.py over tests/golden/scenarios.py", "counts_at_checkpoints": summary}
+
+
 if __name__ == "__main__":
+    dump("trajectories.json", trajectories())
     dump("emission_kat.json", emission_kat())
     dump("emission_wrap.json", emission_wrap())
     dump("nested_count_kat.json", nested_count_kat())

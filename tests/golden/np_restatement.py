@@ -104,7 +104,7 @@ def curve_sample(kind, values, times, t):
     if s is None:
         return values[lo]
     a, b = values[lo], values[lo + 1]
-    return f32(a + f32(f32(b - a) * s))
+    return f32(f32(a * f32(f32(1) - s)) + f32(b * s))  # VectorSpace::lerp: self * (1. - t) + rhs * t
 
 
 def gradient_sample(kind, colors, times, t):

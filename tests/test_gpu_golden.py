@@ -1,0 +1,218 @@
+"""The HIP path against the committed golden vectors DIRECTLY -- no C oracle in between.
+
+tests/golden/trajectories.npz holds multi-frame trajectories produced by the independent numpy restatement
+(tests/golden/np_sim.py: array-oriented, written from the reference lines, numpy's libm).  A misreading of glam /
+bevy_math shared by oracle/fw_oracle.c and csrc/fw_math.h (same author) passes test_gpu_parity.py; it does not pass
+here.  Also: the reference-held vectors (core.rs:806-834, curve.rs:246-258) re-run on the GPU box, against the oracle
+.so loaded there, against the product's host helper and against the device kernels.  Needs an MI355X."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import parity
+from bevy_firework_amd import settings as S
+
+pytestmark = pytest.mark.gpu
+G = parity.GOLDEN_DIR
+sys.path.insert(0, G)
+import scenarios  # noqa: E402
+
+DT = np.float32(1.0 / 60.0)
+
+
+@pytest.fixture()
+def system():
+    from bevy_firework_amd.system import ParticleSystem
+
+    with ParticleSystem(device=0, seed=scenarios.SEED) as ps:
+        yield ps
+
+
+@pytest.mark.parametrize("env", [{}, {"FW_FORECAST": "0"}])
+@pytest.mark.parametrize("name", list(scenarios.ALL))
+def test_hip_follows_the_numpy_trajectories(monkeypatch, name, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    from bevy_firework_amd.system import ParticleSystem
+
+    sc = scenarios.ALL[name]()
+    for p in sc["spawner"].particle_settings:
+        p.particles_destroyed = lambda dead: None  # report_destroyed on: the destroyed stream is compared too
+    n_types = len(sc["spawner"].particle_settings)
+    n_em = len(sc["spawner"].emission_settings)
+    g = parity.golden()
+    with ParticleSystem(device=0, seed=scenarios.SEED) as system:
+        h = system.spawn(sc["spawner"], sc["transform"], uid=sc["uid"], modifier=sc["modifier"])
+        h.set_parent_velocity(sc["parent_velocity"])
+
+        def check(fr):
+            for t in range(n_types):
+                want = parity.golden_particles(name, fr, t)
+                got = h.particles(t)
+                parity.assert_particles_match(got, want, exact_all=bool(sc.get("exact")),
+                                              what=f"{name} {env} frame {fr} type {t}")
+                lea = g[f"{name}/f{fr}/t{t}/last_emitted_age"]
+                for i in range(n_em):
+                    assert np.array_equal(h.last_emitted(t, i), lea[:, i]), (name, fr, t, i)
+                dead = h.destroyed(t)
+                assert np.array_equal(dead["age"], g[f"{name}/f{fr}/t{t}/destroyed_age"]), (name, fr, t)
+                if len(dead):
+                    ok, _ = parity.trig_field_errors(dead["position"], g[f"{name}/f{fr}/t{t}/destroyed_position"])
+                    assert ok.all()
+
+        parity.run_scenario(sc, lambda: system.update, check)
+        assert sum(h.counts()) > 500
+
+
+# ---- the reference-held vectors, on the GPU box -----------------------------------------------------------------
+def test_reference_pins_hold_for_the_oracle_loaded_here():
+    """the GPU lease proves by itself that the oracle .so it loaded is the pinned one"""
+    import test_oracle_golden as tg
+
+    tg.test_reference_emission_unit_test()
+    tg.test_reference_gradient_unit_test()
+    tg.test_philox_published_kat_and_uniform_stream()
+    tg.test_nested_count_kat()
+
+
+def test_reference_emission_unit_test_through_the_product_library():
+    """reference src/core.rs:806-834 through libfirework_hip.so's own arithmetic (fw_compute_emission_count is the
+    function fw_step evaluates for Global entries)"""
+    from bevy_firework_amd.system import compute_emission_count
+
+    d = json.load(open(os.path.join(G, "emission_kat.json")))
+    f = lambda bits: np.array([bits], dtype=np.uint32).view(np.float32)[0]
+    total = 0
+    for age_b, last_b, n, next_b in d["steps"]:
+        got_n, got_next = compute_emission_count(f(age_b), f(last_b), 3.0, 0.0, 1.0, 23.0)
+        assert got_n == n and int(np.float32(got_next).view(np.uint32)) == next_b
+        total += got_n
+    assert total in (22, 23)
+
+
+def test_reference_gradient_unit_test_on_the_device(system):
+    """reference src/curve.rs:246-258 (three even keys; t = 0 and t = 0.5 select keys exactly) evaluated by the
+    kernels: t = 0 is the colour a particle is spawned with (core.rs:460), t = 0.5 the colour update_particles stores
+    for age / lifetime = 0.5 (core.rs:652-655).  t = 1 cannot be sampled by a live particle (age >= lifetime)."""
+    red, green, blue = (1.0, 0.0, 0.0, 1.0), (0.0, 1.0, 0.0, 1.0), (0.0, 0.0, 1.0, 1.0)
+    ps = S.ParticleSettings(lifetime=S.RandF32.constant(1.0), base_color=S.FireworkGradient.even_samples([red, green, blue]),
+                            emissive_color=S.FireworkGradient.even_samples([blue, red, green]))
+    h = system.spawn(S.ParticleSpawner([ps], [S.EmissionSettings(emission_pacing=S.EmissionPacing.OnDemand())]))
+    h.queue_particles(3)
+    system.update(np.float32(0.0))  # spawned with gradient(0), then updated at age / lifetime = 0 -> the first key
+    p = h.particles(0)
+    assert [tuple(c) for c in p["base_color"]] == [red] * 3 and [tuple(c) for c in p["emissive_color"]] == [blue] * 3
+    p["age"] = np.float32(0.25)
+    h.write_particles(0, p)
+    system.update(np.float32(0.25))  # age 0.5 of lifetime 1.0 -> exactly the middle key
+    p = h.particles(0)
+    assert [tuple(c) for c in p["base_color"]] == [green] * 3 and [tuple(c) for c in p["emissive_color"]] == [red] * 3
+
+
+def test_nested_count_kat_on_the_device(system):
+    """tests/golden/nested_count_kat.json (numpy restatement of core.rs:490-500): one parent per case, counted by the
+    Nested kernels frame by frame; children per frame and the parent's last_emitted_age must match bit for bit"""
+    d = json.load(open(os.path.join(G, "nested_count_kat.json")))
+    for case in d["cases"]:
+        parent = S.ParticleSettings(lifetime=S.RandF32.constant(case["lifetime"]))
+        child = S.ParticleSettings(lifetime=S.RandF32.constant(1000.0))
+        e0 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.OnDemand())
+        e1 = S.EmissionSettings(particle_index=1, emission_mode=S.EmissionMode.Nested(0),
+                                emission_pacing=S.EmissionPacing.CountOverDuration(case["count"], 0.0, case["offset_start"],
+                                                                                   case["offset_end"]))
+        h = system.spawn(S.ParticleSpawner([parent, child], [e0, e1]))
+        h.queue_particles(1)
+        children = 0
+        for age_b, n, last_b in case["rows"]:
+            system.update(DT)
+            c = h.counts()
+            assert c[1] - children == n, (case["count"], age_b, c, children, n)
+            children = c[1]
+            if c[0]:
+                assert int(h.last_emitted(0, 1)[0].view(np.uint32)) == last_b
+        assert children == case["total"]
+        system.despawn(h)
+
+
+def test_global_burst_into_a_nested_fed_type_stays_in_bounds(system):
+    """a Global (OnDemand) entry and a Nested entry feed the same particle type with a caller-given capacity: the
+    burst is clamped to the capacity on the device and reported, nothing is read or written past the buffers
+    (neighbouring spawners stay intact), and the state stays usable"""
+    from bevy_firework_amd.system import FwError
+
+    sparks = S.ParticleSettings(lifetime=S.RandF32.constant(1.0))
+    mixed = S.ParticleSettings(lifetime=S.RandF32.constant(0.5), capacity=4096)
+    e0 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(600.0))
+    e1 = S.EmissionSettings(particle_index=1, emission_mode=S.EmissionMode.Nested(0),
+                            emission_pacing=S.EmissionPacing.CountOverDuration(4.0, 0.0, 0.0, 1.0))
+    e2 = S.EmissionSettings(particle_index=1, emission_pacing=S.EmissionPacing.OnDemand())
+    # a neighbour allocated right after: an out-of-bounds write would land in its planes
+    h = system.spawn(S.ParticleSpawner([sparks, mixed], [e0, e1, e2]), uid=1)
+    nb = parity.Pair(system, S.ParticleSpawner([S.ParticleSettings(lifetime=S.RandF32.constant(2.0))],
+                                               [S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(20000.0))]),
+                     seed=scenarios.SEED, uid=2)
+    for fr in range(40):
+        if fr in (5, 6, 20):
+            h.queue_particles(30000)  # far beyond the 4096 slots
+        system.update(DT)
+        nb.step_cpu(DT)
+    with pytest.raises(FwError) as e:
+        h.counts()
+    assert e.value.status == -4  # FW_ECAPACITY
+    c = h.counts()
+    assert c[1] <= 4096 and c[0] > 300
+    p = h.particles(1)
+    assert np.isfinite(p["position"]).all() and (p["age"] < p["lifetime"]).all()
+    nb.check(exact_all=True, what="neighbour of the overflowing type")
+    for _ in range(40):  # everything of the burst expires; the type keeps working
+        system.update(DT)
+        nb.step_cpu(DT)
+    assert h.counts()[1] < 4096
+    nb.check(exact_all=True, what="neighbour, later")
+
+
+def test_nested_fed_type_with_derived_capacity_grows(system):
+    """the reference pushes children onto a Vec (core.rs:523); a Nested-fed type whose capacity was derived follows
+    the live count seen in the snapshot rows and doubles before it can overflow: OnDemand parents far beyond what
+    the capacity was derived from, no FW_ECAPACITY, counts identical to the oracle"""
+    parent = S.ParticleSettings(lifetime=S.RandF32.constant(1.5))
+    child = S.ParticleSettings(lifetime=S.RandF32.constant(0.6))
+    e0 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.OnDemand())
+    e1 = S.EmissionSettings(particle_index=1, emission_mode=S.EmissionMode.Nested(0),
+                            emission_pacing=S.EmissionPacing.CountOverDuration(30.0, 0.0, 0.0, 1.0))
+    pair = parity.Pair(system, S.ParticleSpawner([parent, child], [e0, e1]), seed=scenarios.SEED, uid=8)
+    for fr in range(120):
+        if fr % 10 == 0 and fr < 60:
+            pair.queue(600 * (1 + fr // 10))  # 600, 1200, ... parents per burst: ramps up gradually
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr % 20 == 19:
+            pair.check(exact_all=True, what=f"frame {fr}")
+    assert max(pair.gpu.counts()) > 20000
+
+
+def test_rotation_does_not_drift_from_the_oracle_over_2000_frames(system):
+    """rotation = from_scaled_axis(w dt) * rotation is never renormalised (core.rs:645-647), so per-step differences
+    (the kernels use two short polynomials for small angles, the oracle glibc's sinf/cosf) compound; 2000 frames of
+    spinning particles, angular drag 0 so they never slow down, compared with the oracle at the usual tolerance"""
+    import oracle
+
+    ps = S.ParticleSettings(lifetime=S.RandF32.constant(1000.0), angular_drag=0.0, angular_acceleration=(0.0, 0.0, 0.0),
+                            linear_drag=1.0, acceleration=(0.0, 0.0, 0.0))
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.OneShot(3000),
+                            initial_angular_velocity=S.RandVec3(S.RandF32(0.5, 12.0), (0.3, 0.9, -0.3), 1.2))
+    pair = parity.Pair(system, S.ParticleSpawner([ps], [es]), seed=scenarios.SEED, uid=77)
+    worst = 0.0
+    for fr in range(2000):
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr % 250 == 249:
+            got, want = pair.gpu.particles(0)["rotation"], pair.cpu.particles(0)["rotation"]
+            ok, w = parity.trig_field_errors(got, want)
+            worst = max(worst, w)
+            assert ok.all(), f"frame {fr}: rotation drifted to {w:.2f}x the allowance"
+    print(f"rotation drift after 2000 frames: worst {worst:.3f} of the allowance (rtol {parity.RTOL})")
+    pair.check(what="after 2000 frames")

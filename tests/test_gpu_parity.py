@@ -4,10 +4,11 @@ import math
 import numpy as np
 import pytest
 
-import oracle
+import oracle  # noqa: F401
 from bevy_firework_amd import settings as S
 from bevy_firework_amd import workloads
 from parity import Pair, assert_particles_match
+from parity import trig_field_errors as parity_trig
 
 pytestmark = pytest.mark.gpu
 DT = np.float32(1.0 / 60.0)
@@ -211,6 +212,10 @@ def test_instances_aabb_and_invalid_settings(system):
     assert np.array_equal(inst["position"], parts["position"]) and np.array_equal(inst["scale"], parts["scale"])
     assert np.array_equal(inst["rotation"], parts["rotation"])
     assert np.array_equal(inst["base_color"], parts["base_color"])
+    assert np.array_equal(inst["emissive_color"], parts["emissive_color"])
+    cpu_parts = pair.cpu.particles(0)  # and against the oracle's own state: the record is {pos, scale, rot, base, emissive}
+    for k in ("scale", "base_color", "emissive_color"):
+        assert np.array_equal(inst[k], cpu_parts[k]), k
     any_g, mn_g, mx_g = pair.gpu.aabb()
     cp = pair.cpu.particles(0)
     assert any_g
@@ -358,6 +363,15 @@ def test_attached_instances_are_the_packed_records(system):
             assert bool(torch.isnan(buf[cap * 16:]).all()), "wrote past the attached buffer"
     pair.check(what="state after attached frames")
     assert pair.gpu.count(0) > 40000
+    # ... and the records against the ORACLE's state (not only against the packing pass of the same library): scale and
+    # both colours involve no libm call, so they are bit-identical; this gradient pair has a non-constant emissive
+    n = pair.gpu.count(0)
+    rec = buf[: n * 16].cpu().numpy().view(S.INSTANCE_DTYPE).reshape(n)
+    cp = pair.cpu.particles(0)
+    for k in ("scale", "base_color", "emissive_color"):
+        assert np.array_equal(rec[k], cp[k]), k
+    ok, _ = parity_trig(rec["position"], cp["position"])
+    assert ok.all()
     # a buffer smaller than the live count: the first `small` records, nothing beyond
     small = 10000
     buf2 = torch.full(((small + guard) * 16,), float("nan"), dtype=torch.float32, device="cuda")
