@@ -194,25 +194,126 @@ def test_nested_fed_type_with_derived_capacity_grows(system):
     assert max(pair.gpu.counts()) > 20000
 
 
-def test_rotation_does_not_drift_from_the_oracle_over_2000_frames(system):
-    """rotation = from_scaled_axis(w dt) * rotation is never renormalised (core.rs:645-647), so per-step differences
-    (the kernels use two short polynomials for small angles, the oracle glibc's sinf/cosf) compound; 2000 frames of
-    spinning particles, angular drag 0 so they never slow down, compared with the oracle at the usual tolerance"""
-    import oracle
+def _exact_rotation(w32, dt32, rot0, steps):
+    """float64 ground truth of `steps` applications of from_scaled_axis(w dt) * rotation with a constant w"""
+    v = w32.astype(np.float64) * np.float64(dt32)
+    ln = np.linalg.norm(v, axis=1)
+    safe = np.where(ln == 0, 1.0, ln)
+    dq = np.concatenate([v / safe[:, None] * np.sin(ln / 2)[:, None], np.cos(ln / 2)[:, None]], axis=1)
+    q = rot0.astype(np.float64).copy()
+    for _ in range(steps):
+        x0, y0, z0, w0 = dq.T
+        x1, y1, z1, w1 = q.T
+        q = np.stack([w0 * x1 + x0 * w1 + y0 * z1 - z0 * y1, w0 * y1 - x0 * z1 + y0 * w1 + z0 * x1,
+                      w0 * z1 + x0 * y1 - y0 * x1 + z0 * w1, w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1], axis=1)
+    return q
 
+
+def test_rotation_drift_over_2000_frames_is_no_worse_than_the_oracles(system):
+    """rotation = from_scaled_axis(w dt) * rotation is never renormalised (core.rs:645-647).  With a CONSTANT angular
+    velocity (drag 0) the same rounded step quaternion is applied every frame, so its half-ulp norm / angle error
+    compounds linearly and ANY two implementations that differ in one rounding drift apart (numpy's sin/cos, 99.2 %
+    bit-identical to glibc's, is 1e-4 away from the oracle after 2000 frames; the oracle itself is 6e-5 away from the
+    float64 truth).  What can be asked of the kernels (small-angle polynomials instead of sinf/cosf + divisions) is
+    that they are as close to the TRUTH as the oracle is: checked here against a float64 recurrence."""
     ps = S.ParticleSettings(lifetime=S.RandF32.constant(1000.0), angular_drag=0.0, angular_acceleration=(0.0, 0.0, 0.0),
                             linear_drag=1.0, acceleration=(0.0, 0.0, 0.0))
     es = S.EmissionSettings(emission_pacing=S.EmissionPacing.OneShot(3000),
                             initial_angular_velocity=S.RandVec3(S.RandF32(0.5, 12.0), (0.3, 0.9, -0.3), 1.2))
     pair = parity.Pair(system, S.ParticleSpawner([ps], [es]), seed=scenarios.SEED, uid=77)
+    w = rot0 = None
+    for fr in range(2000):
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr == 0:
+            w = pair.cpu.particles(0)["angular_velocity"].copy()  # constant from here on (no drag, no acceleration)
+            assert np.array_equal(pair.gpu.particles(0)["angular_velocity"], w) or parity.trig_field_errors(
+                pair.gpu.particles(0)["angular_velocity"], w)[0].all()
+        if fr + 1 in (250, 1000, 2000):
+            truth = _exact_rotation(w, DT, np.tile(np.array([0, 0, 0, 1.0]), (len(w), 1)), fr + 1)
+            got, want = pair.gpu.particles(0)["rotation"], pair.cpu.particles(0)["rotation"]
+            e_hip, e_cpu = np.abs(got - truth).max(), np.abs(want - truth).max()
+            print(f"frame {fr + 1}: |HIP - truth| {e_hip:.3g}  |oracle - truth| {e_cpu:.3g}  |HIP - oracle| {np.abs(got - want).max():.3g}")
+            assert e_hip <= 1.5 * e_cpu + 1e-6, (fr, e_hip, e_cpu)
+            assert e_hip < 4e-8 * (fr + 1) + 1e-6  # half an ulp per step, linear: 8e-5 at 2000 frames
+
+
+def test_rotation_with_default_drag_stays_inside_the_tolerance_for_2000_frames(system):
+    """the default angular_drag 0.2 (core.rs:203): the angular velocity changes every frame, the per-step roundings do
+    not repeat, and HIP and oracle stay inside the usual 1e-5 for 2000 frames (33 s)"""
+    ps = S.ParticleSettings(lifetime=S.RandF32.constant(1000.0), linear_drag=1.0, acceleration=(0.0, 0.0, 0.0))
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.OneShot(3000),
+                            initial_rotation=(0.0, float(np.sin(0.4)), 0.0, float(np.cos(0.4))),
+                            initial_angular_velocity=S.RandVec3(S.RandF32(0.5, 12.0), (0.3, 0.9, -0.3), 1.2))
+    pair = parity.Pair(system, S.ParticleSpawner([ps], [es]), seed=scenarios.SEED, uid=78)
     worst = 0.0
     for fr in range(2000):
         system.update(DT)
         pair.step_cpu(DT)
         if fr % 250 == 249:
-            got, want = pair.gpu.particles(0)["rotation"], pair.cpu.particles(0)["rotation"]
-            ok, w = parity.trig_field_errors(got, want)
-            worst = max(worst, w)
-            assert ok.all(), f"frame {fr}: rotation drifted to {w:.2f}x the allowance"
-    print(f"rotation drift after 2000 frames: worst {worst:.3f} of the allowance (rtol {parity.RTOL})")
+            ok, wst = parity.trig_field_errors(pair.gpu.particles(0)["rotation"], pair.cpu.particles(0)["rotation"])
+            worst = max(worst, wst)
+            assert ok.all(), f"frame {fr}: rotation at {wst:.2f}x the allowance"
+    print(f"rotation, default drag, 2000 frames: worst {worst:.3f} of the allowance (rtol {parity.RTOL})")
     pair.check(what="after 2000 frames")
+
+
+def test_sharded_system_feeds_the_exchange_from_the_device_ring():
+    """bevy_firework_amd/sharding.py on the real backend: per-frame totals come from the ring the update kernel
+    writes (no live_count() synchronisation in the frame), buckets incl. a partial one and a wrapped window"""
+    import torch
+
+    from bevy_firework_amd import sharding, workloads
+    from bevy_firework_amd.system import ParticleSystem
+
+    ems = workloads.many_emitters(6, live_per_emitter=3000)
+    stream = torch.cuda.Stream()
+    sh = sharding.ShardedParticleSystem(lambda: ParticleSystem(device=0, seed=workloads.SEED, stream=stream.cuda_stream),
+                                        ems, rank=0, world=1, reduce_every=8, torch_stream=stream, exchange=True)
+    assert sh._device_ring
+    want = []
+    import oracle
+
+    cpu = [oracle.OracleSpawner(s, seed=workloads.SEED, uid=e, transform=tf) for e, (s, tf) in enumerate(ems)]
+    for fr in range(45):
+        sh.update(DT)
+        for o in cpu:
+            o.step(DT)
+        want.append(sum(o.count(0) for o in cpu))
+        if fr == 19:
+            sh.flush()  # moves the bucket boundary: later windows wrap around the ring
+    sh.flush()
+    assert sh.global_live_history == want
+    assert sh.global_live_count() == want[-1]
+    sh.system.close()
+
+
+def test_sharded_system_over_a_one_rank_rccl_group():
+    """the same class with the nccl (= RCCL) backend: device buckets all-reduced on the GPU; run in a subprocess with
+    a timeout so that a communicator problem cannot hang the suite"""
+    import subprocess
+
+    code = r'''
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from bevy_firework_amd import sharding, workloads
+from bevy_firework_amd.system import ParticleSystem
+stream = torch.cuda.Stream()
+sh = sharding.ShardedParticleSystem(lambda: ParticleSystem(device=0, seed=workloads.SEED, stream=stream.cuda_stream),
+                                    workloads.many_emitters(4, 2000), 0, 1, process_group=dist.group.WORLD,
+                                    reduce_every=4, torch_stream=stream)
+dt = np.float32(1 / 60)
+local = []
+for fr in range(24):
+    sh.update(dt)
+    local.append(sh.local_live_count())
+assert all(b.is_cuda for b in sh._buckets), "buckets must stay on the device with the nccl backend"
+assert sh.global_live_history == local, (sh.global_live_history, local)
+sh.system.close(); dist.destroy_process_group(); print("RCCL_OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=240)
+    assert "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -19,7 +19,7 @@ import oracle  # noqa: E402
 from bevy_firework_amd import sharding, workloads  # noqa: E402
 
 DT = np.float32(1.0 / 60.0)
-FRAMES = 40
+FRAMES = 43  # five full buckets of 8 frames + a partial one (flush)
 N_EMITTERS = 6
 
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -32,6 +33,27 @@ __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ src, fl
         for (int u = 0; u < U; u++) {
             size_t j = i + (size_t)u * 256;
             if (j < n4) { if (NT) nt_st(v[u], &dst[j]); else dst[j] = v[u]; }
+        }
+    }
+}
+
+// contiguous chunk per workgroup (each workgroup streams its own region front to back) instead of a grid-strided
+// interleave: fewer DRAM pages open at once
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_copy_chunk(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    const size_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
+    for (size_t i = lo + threadIdx.x; i < hi; i += (size_t)256 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t j = i + (size_t)u * 256;
+            if (j < hi) v[u] = NT ? nt_ld(&src[j]) : src[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t j = i + (size_t)u * 256;
+            if (j < hi) { if (NT) nt_st(v[u], &dst[j]); else dst[j] = v[u]; }
         }
     }
 }
@@ -286,6 +308,31 @@ int main(int argc, char** argv) {
     char *a, *b; CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
     CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 0, bytes));
     size_t n4 = bytes / 16;
+    if (argc > 2 && !strcmp(argv[2], "copy")) {  // copy sweep only (what fw_ctx_measure_copy_bandwidth should use)
+        printf("copy sweep %zu MiB -> %zu MiB (GB/s = read+write bytes)\n", mb, mb);
+        for (int blocks : {256, 512, 1024, 2048, 4096, 8192, 16384}) {
+            double t;
+#define RUNK(K, tag) t = timeit([&](int i) { hipLaunchKernelGGL((K), dim3(blocks), dim3(256), 0, 0, (const float4*)((i&1)?b:a), (float4*)((i&1)?a:b), n4); }, 20); \
+            printf("  %-22s blocks=%5d : %8.1f GB/s\n", tag, blocks, 2.0 * bytes / t / 1e9);
+            RUNK((k_copy<1, false>), "stride U=1")
+            RUNK((k_copy<4, false>), "stride U=4")
+            RUNK((k_copy<4, true>), "stride U=4 nt")
+            RUNK((k_copy_chunk<1, false>), "chunk U=1")
+            RUNK((k_copy_chunk<4, false>), "chunk U=4")
+            RUNK((k_copy_chunk<4, true>), "chunk U=4 nt")
+            RUNK((k_copy_chunk<8, false>), "chunk U=8")
+        }
+        {
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            for (int i = 0; i < 3; i++) CK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0));
+            hipEventRecord(e0, 0);
+            for (int i = 0; i < 10; i++) CK(hipMemcpyAsync((i&1)?a:b, (i&1)?b:a, bytes, hipMemcpyDeviceToDevice, 0));
+            hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("  hipMemcpyAsync D2D                 : %8.1f GB/s\n", 2.0 * bytes * 10 / (ms * 1e-3) / 1e9);
+        }
+        return 0;
+    }
     printf("copy %zu MiB -> %zu MiB (GB/s = read+write bytes)\n", mb, mb);
     for (int blocks : {1024, 2048, 4096, 8192}) {
         double t;
