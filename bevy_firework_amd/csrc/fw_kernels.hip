@@ -1687,10 +1687,27 @@ __global__ void fw_k_total(const uint32_t *counts, uint32_t n_seg, unsigned long
     if (threadIdx.x == 0) *out = s[0] + s[1] + s[2] + s[3];
 }
 
-// float4 streaming copy: the measured-roofline probe (bytes read + written per second)
+// float4 streaming copy: the measured-roofline probe (bytes read + written per second).  Shape chosen by a sweep on
+// MI355X at 1 GiB -> 1 GiB (tools/membw <MiB> copy, profiles/r02/copy_sweep.txt): grid-strided, four float4 per lane in
+// flight, non-temporal loads and stores, 16384 workgroups: 6.34 TB/s (plain one-float4 grid-stride: 4.9; hipMemcpy D2D: 5.0).
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_copy(const float4 *src, float4 *dst, size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * FW_BLOCK + threadIdx.x; i < n4; i += (size_t)gridDim.x * FW_BLOCK)
-        dst[i] = src[i];
+    constexpr int U = 4;
+    const size_t stride = (size_t)gridDim.x * FW_BLOCK * U;
+    const FW_GLOBAL fw_f4 *s = reinterpret_cast<const FW_GLOBAL fw_f4 *>(reinterpret_cast<uintptr_t>(src));
+    FW_GLOBAL fw_f4 *d = reinterpret_cast<FW_GLOBAL fw_f4 *>(reinterpret_cast<uintptr_t>(dst));
+    for (size_t i = (size_t)blockIdx.x * FW_BLOCK * U + threadIdx.x; i < n4; i += stride) {
+        fw_f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t j = i + (size_t)u * FW_BLOCK;
+            if (j < n4) v[u] = __builtin_nontemporal_load(&s[j]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t j = i + (size_t)u * FW_BLOCK;
+            if (j < n4) __builtin_nontemporal_store(v[u], &d[j]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1812,6 +1829,6 @@ hipError_t fw_launch_total(hipStream_t s, const uint32_t *counts, uint32_t n_seg
 }
 
 hipError_t fw_launch_copy_probe(hipStream_t s, const void *src, void *dst, size_t bytes) {
-    hipLaunchKernelGGL(fw_k_copy, dim3(2048), dim3(FW_BLOCK), 0, s, (const float4 *)src, (float4 *)dst, bytes / 16);
+    hipLaunchKernelGGL(fw_k_copy, dim3(16384), dim3(FW_BLOCK), 0, s, (const float4 *)src, (float4 *)dst, bytes / 16);
     return hipGetLastError();
 }
