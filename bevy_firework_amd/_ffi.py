@@ -44,6 +44,27 @@ class Gradient(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("times", C.POINTER(C.c_float)), ("rgba", C.POINTER(C.c_float))]
 
 
+class CollisionSettings(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("restitution", C.c_float), ("friction", C.c_float),
+                ("destroy_on_collision", C.c_int32), ("filter_mask", C.c_uint32)]
+
+
+class Collider(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("layers", C.c_uint32), ("position", C.c_float * 3), ("rotation", C.c_float * 4),
+                ("normal", C.c_float * 3), ("radius", C.c_float), ("half_extents", C.c_float * 3)]
+
+
+def make_colliders(colliders):
+    arr = (Collider * max(len(colliders), 1))()
+    for d, c in zip(arr, colliders):
+        d.kind, d.layers, d.radius = int(c.kind), int(c.layers) & 0xFFFFFFFF, float(c.radius)
+        d.position[:] = [float(x) for x in c.position]
+        d.rotation[:] = [float(x) for x in c.rotation]
+        d.normal[:] = [float(x) for x in c.normal]
+        d.half_extents[:] = [float(x) for x in c.half_extents]
+    return arr
+
+
 class ParticleSettings(C.Structure):
     _fields_ = [
         ("lifetime", RandF32),
@@ -58,6 +79,7 @@ class ParticleSettings(C.Structure):
         ("pbr", C.c_int32),
         ("report_destroyed", C.c_int32),
         ("capacity", C.c_uint32),
+        ("collision", CollisionSettings),
     ]
 
 
@@ -169,6 +191,12 @@ def make_desc(spawner: S.ParticleSpawner, uid: int):
         d.pbr = 1 if p.pbr else 0
         d.report_destroyed = 1 if p.particles_destroyed is not None else 0
         d.capacity = int(p.capacity)
+        cs = p.collision_settings
+        d.collision.enabled = 1 if cs is not None else 0
+        if cs is not None:
+            d.collision.restitution, d.collision.friction = float(cs.restitution), float(cs.friction)
+            d.collision.destroy_on_collision = 1 if cs.destroy_on_collision else 0
+            d.collision.filter_mask = int(cs.filter_mask) & 0xFFFFFFFF
     for i, e in enumerate(spawner.emission_settings):
         fill_emission(es[i], e)
     desc = SpawnerDesc()
@@ -192,6 +220,7 @@ SYMBOLS = [
     ("fw_last_error", C.c_char_p, [_P]),
     ("fw_ctx_stream", _P, [_P]),
     ("fw_ctx_synchronize", C.c_int, [_P]),
+    ("fw_ctx_set_colliders", C.c_int, [_P, C.POINTER(Collider), C.c_uint32]),
     ("fw_spawner_create", C.c_int, [_P, C.POINTER(SpawnerDesc), C.POINTER(C.c_int32)]),
     ("fw_spawner_update_settings", C.c_int, [_P, C.c_int32, C.POINTER(SpawnerDesc)]),
     ("fw_spawner_destroy", C.c_int, [_P, C.c_int32]),
@@ -242,7 +271,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.fw_abi_version() != 1:
+    if lib.fw_abi_version() != 2:
         raise ImportError("libfirework_hip.so ABI version mismatch")
     _lib = lib
     return lib

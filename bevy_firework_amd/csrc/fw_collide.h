@@ -1,0 +1,177 @@
+// fw_collide.h -- particle_collision (reference src/core.rs:744-800, feature physics_avian) against the context's
+// device-resident analytic colliders (include/firework_hip.h: fw_collider).  fp32, operation order of the reference
+// line by line; built with -ffp-contract=off like everything else.
+//
+// The reference casts its rays through avian's SpatialQuery (parry shapes behind a CPU broadphase).  That world does
+// not exist on the device; the ray cast below is this backend's own definition (header comment of fw_collider),
+// modelled on parry's `solid = true` casts: a ray starting inside a solid reports distance 0 with a zero normal.
+#pragma once
+#include "fw_math.h"
+
+struct alignas(16) FwCollider {
+    int32_t kind;
+    uint32_t layers;
+    float radius;
+    float pad0;
+    float position[4];
+    float rotation[4];     // xyzw (BOX)
+    float normal[4];       // PLANE
+    float half_extents[4]; // BOX
+};
+
+struct FwRayHit {
+    float distance;
+    fw_v3 normal;
+};
+
+FW_HD float fw_len3(fw_v3 a) { return sqrtf(fw_dot3(a, a)); }
+FW_HD fw_v3 fw_scale3(fw_v3 a, float s) { return fw_v3{a.x * s, a.y * s, a.z * s}; }
+FW_HD fw_v3 fw_add3(fw_v3 a, fw_v3 b) { return fw_v3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+FW_HD fw_v3 fw_sub3(fw_v3 a, fw_v3 b) { return fw_v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+// glam Vec3::normalize: self * length_recip()
+FW_HD fw_v3 fw_normalize3(fw_v3 a) { return fw_scale3(a, 1.0f / fw_len3(a)); }
+// glam Vec3::project_onto(rhs): rhs * self.dot(rhs) * rhs.dot(rhs).recip()
+FW_HD fw_v3 fw_project_onto(fw_v3 a, fw_v3 rhs) {
+    const float rcp = 1.0f / fw_dot3(rhs, rhs);
+    return fw_scale3(fw_scale3(rhs, fw_dot3(a, rhs)), rcp);
+}
+
+// one collider; returns true and fills *hit when the ray origin + t dir, t in [0, max_distance], meets it
+FW_HD bool fw_ray_collider(const FwCollider &c, fw_v3 origin, fw_v3 dir, float max_distance, FwRayHit *hit) {
+    const fw_v3 cpos{c.position[0], c.position[1], c.position[2]};
+    if (c.kind == 0) {  // PLANE: the half-space n.(x - p) <= 0
+        const fw_v3 n{c.normal[0], c.normal[1], c.normal[2]};
+        const float dot_normal_dpos = fw_dot3(n, fw_sub3(cpos, origin));
+        if (dot_normal_dpos > 0.0f) {  // inside the solid half-space
+            *hit = FwRayHit{0.0f, fw_v3{0.0f, 0.0f, 0.0f}};
+            return true;
+        }
+        const float t = dot_normal_dpos / fw_dot3(n, dir);
+        if (t >= 0.0f && t <= max_distance) {
+            *hit = FwRayHit{t, n};
+            return true;
+        }
+        return false;
+    }
+    if (c.kind == 1) {  // SPHERE
+        const fw_v3 dcenter = fw_sub3(origin, cpos);
+        const float a = fw_dot3(dir, dir);
+        const float b = fw_dot3(dcenter, dir);
+        const float cc = fw_dot3(dcenter, dcenter) - c.radius * c.radius;
+        if (cc <= 0.0f) {  // inside (or on) the ball
+            *hit = FwRayHit{0.0f, fw_v3{0.0f, 0.0f, 0.0f}};
+            return true;
+        }
+        if (b > 0.0f) return false;  // outside and moving away
+        const float delta = b * b - a * cc;
+        if (!(delta >= 0.0f)) return false;
+        const float t = (-b - sqrtf(delta)) / a;
+        if (!(t >= 0.0f && t <= max_distance)) return false;
+        const fw_v3 p = fw_sub3(fw_add3(origin, fw_scale3(dir, t)), cpos);
+        *hit = FwRayHit{t, fw_normalize3(p)};
+        return true;
+    }
+    // BOX: slabs in the box's own frame
+    const fw_q4 q{c.rotation[0], c.rotation[1], c.rotation[2], c.rotation[3]};
+    const fw_q4 qi{-q.x, -q.y, -q.z, q.w};  // conjugate = inverse of a unit quaternion
+    const fw_v3 ol = fw_quat_mul_vec3(qi, fw_sub3(origin, cpos));
+    const fw_v3 dl = fw_quat_mul_vec3(qi, dir);
+    const float o3[3] = {ol.x, ol.y, ol.z}, d3[3] = {dl.x, dl.y, dl.z};
+    bool inside = true;
+    for (int i = 0; i < 3; i++) inside = inside && fabsf(o3[i]) <= c.half_extents[i];
+    if (inside) {
+        *hit = FwRayHit{0.0f, fw_v3{0.0f, 0.0f, 0.0f}};
+        return true;
+    }
+    float tnear = -INFINITY, tfar = INFINITY;
+    int axis = 0;
+    float sign = 0.0f;
+    for (int i = 0; i < 3; i++) {
+        const float h = c.half_extents[i];
+        if (d3[i] == 0.0f) {
+            if (fabsf(o3[i]) > h) return false;
+            continue;
+        }
+        const float inv = 1.0f / d3[i];
+        float t1 = (-h - o3[i]) * inv, t2 = (h - o3[i]) * inv;
+        float s = -1.0f;  // entering through the -h face: outward normal -e_i
+        if (t1 > t2) {
+            const float tmp = t1;
+            t1 = t2, t2 = tmp, s = 1.0f;
+        }
+        if (t1 > tnear) tnear = t1, axis = i, sign = s;
+        if (t2 < tfar) tfar = t2;
+        if (tnear > tfar) return false;
+    }
+    if (!(tnear >= 0.0f && tnear <= max_distance)) return false;
+    fw_v3 nl{0.0f, 0.0f, 0.0f};
+    if (axis == 0) nl.x = sign;
+    else if (axis == 1) nl.y = sign;
+    else nl.z = sign;
+    *hit = FwRayHit{tnear, fw_quat_mul_vec3(q, nl)};
+    return true;
+}
+
+// SpatialQuery::cast_ray(origin, dir, max_distance, solid = true, filter): nearest hit, lowest index on ties
+FW_HD bool fw_cast_ray(const FwCollider *colliders, uint32_t n, uint32_t mask, fw_v3 origin, fw_v3 dir, float max_distance,
+                       FwRayHit *best) {
+    bool any = false;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!(colliders[i].layers & mask)) continue;
+        FwRayHit h;
+        if (fw_ray_collider(colliders[i], origin, dir, max_distance, &h) && (!any || h.distance < best->distance)) {
+            *best = h;
+            any = true;
+        }
+    }
+    return any;
+}
+
+// particle_collision (src/core.rs:744-800).  Returns should_destroy; *pos / *vel are updated in place.
+FW_HD bool fw_particle_collision(fw_v3 *pos_io, fw_v3 *vel_io, float delta, float restitution, float friction,
+                                 bool destroy_on_collision, uint32_t mask, const FwCollider *colliders, uint32_t n) {
+    fw_v3 pos = *pos_io, vel = *vel_io;
+    const float orig_delta = delta;
+    int n_steps = 0;
+    bool should_destroy = false;
+    while (delta > 0.0f && n_steps < 4) {
+        // Dir3::try_from(vel): value / length when the length is finite and > 0, else Dir3::Y (core.rs:758-761)
+        const float len = fw_len3(vel);
+        const fw_v3 dir = (len < INFINITY && len > 0.0f) ? fw_v3{vel.x / len, vel.y / len, vel.z / len} : fw_v3{0.0f, 1.0f, 0.0f};
+        FwRayHit hit;
+        if (fw_cast_ray(colliders, n, mask, pos, dir, fw_len3(vel) * delta, &hit)) {
+            if (hit.distance == 0.0f) {  // core.rs:766-776
+                fw_v3 normal = hit.normal;
+                if (normal.x == 0.0f && normal.y == 0.0f && normal.z == 0.0f) {
+                    if (vel.x != 0.0f || vel.y != 0.0f || vel.z != 0.0f)
+                        normal = fw_normalize3(vel);
+                    else
+                        normal = fw_v3{0.0f, 1.0f, 0.0f};
+                }
+                const float k = fmaxf(fw_len3(vel), 1.0f);
+                pos = fw_add3(pos, fw_scale3(fw_scale3(normal, k), delta));  // vel.length().max(1.) * normal * delta
+            } else {  // core.rs:777-787
+                pos = fw_add3(pos, fw_scale3(fw_normalize_or_zero(vel), hit.distance));
+                const fw_v3 vel_project0 = fw_project_onto(vel, hit.normal);
+                const fw_v3 vel_reject = fw_sub3(vel, vel_project0);          // reject_from = self - project_onto
+                const fw_v3 vel_project = fw_project_onto(vel, hit.normal);
+                const float friction_dv = fminf(fw_len3(vel_project), fw_len3(vel_reject)) * friction;
+                vel = fw_sub3(fw_sub3(vel_reject, fw_scale3(fw_normalize_or_zero(vel_reject), friction_dv)),
+                              fw_scale3(vel_project, restitution));
+                pos = fw_add3(pos, fw_scale3(hit.normal, 0.0001f));
+                float nd = delta - hit.distance;  // (delta - hit.distance).clamp(0., orig_delta): the reference's units
+                if (nd < 0.0f) nd = 0.0f;
+                if (nd > orig_delta) nd = orig_delta;
+                delta = nd;
+            }
+            should_destroy = destroy_on_collision;
+            if (should_destroy) break;
+        } else {
+            pos = fw_add3(pos, fw_scale3(vel, delta));
+            delta = 0.0f;
+        }
+        n_steps++;
+    }
+    *pos_io = pos, *vel_io = vel;
+    return should_destroy;
+}

@@ -72,6 +72,14 @@ struct alignas(16) FwType {
     uint32_t keys_off, keys_len;
     uint32_t o_sc_v, o_bc_t, o_bc_v, o_em_t, o_em_v, pad0;
 };
+// collision_settings of a particle type (core.rs:137-138, 240-248), in a table of its own next to FwType: only the
+// collision kernels read it, the streaming kernels' per-type record (and their scalar-register budget) stays as it was
+struct alignas(16) FwTypeColl {
+    uint32_t coll_flags, coll_mask;  // bit 0 = Some(..), bit 1 = destroy_on_collision
+    float coll_restitution, coll_friction;
+};
+#define FW_COLL_ENABLED 1u
+#define FW_COLL_DESTROY 2u
 
 // static settings of one emission entry (EmissionSettings, src/core.rs:144-162)
 // plus the spawn-relevant ranges of its particle type

@@ -73,6 +73,7 @@ struct SegHost {
     uint32_t keys_off = 0, keys_len = 0;  // key pool window of the segment's type
     int32_t lplane_emission[FW_MAX_EMISSIONS];
     bool nested_fed = false;    // receives Nested children: count not host-predictable
+    bool collides = false;      // the type has collision settings (core.rs:137-138): frames run the collision path
     bool auto_capacity = false; // capacity was derived (fw_particle_settings.capacity == 0): the library may grow it
     uint32_t dev_count = 0;     // nested_fed: live count of the latest snapshot row (growth trigger)
     char *buf[2] = {nullptr, nullptr};
@@ -155,6 +156,7 @@ struct fw_ctx {
     FwGlobals g{};
     DevArray<FwSeg> d_segs;
     DevArray<FwType> d_types;
+    DevArray<FwTypeColl> d_type_coll;
     DevArray<float> d_keys;
     DevArray<FwEmit> d_emits;
     DevArray<unsigned long long> d_emit_serial;
@@ -232,6 +234,8 @@ struct fw_ctx {
     uint32_t live_ring_n = 0;
     uint64_t live_ring_frames = 0;            // frames written since the ring was registered
 
+    FwCollider *d_colliders = nullptr;  // device-resident analytic colliders (fw_ctx_set_colliders)
+    uint32_t n_colliders = 0;
     float *d_aabb = nullptr;   // 256 partial boxes of the AABB query
     float *h_aabb = nullptr;   // pinned result {min.xyz, any, max.xyz, -}
     unsigned long long *d_total = nullptr;
@@ -667,12 +671,14 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
 
     fw_status st;
     if ((st = dev_reserve(ctx, ctx->d_types, ctx->n_types + nt, ctx->n_types))) return st;
+    if ((st = dev_reserve(ctx, ctx->d_type_coll, ctx->n_types + nt, ctx->n_types))) return st;
     if ((st = dev_reserve(ctx, ctx->d_emits, ctx->n_emits + ne, ctx->n_emits))) return st;
     if ((st = dev_reserve(ctx, ctx->d_emit_serial, ctx->n_emit_slots + ne, ctx->n_emit_slots))) return st;
     if ((st = dev_reserve(ctx, ctx->d_keys, (size_t)(ctx->n_types + nt) * FW_KEYS_MAX, (size_t)ctx->n_types * FW_KEYS_MAX)))
         return st;
     if ((st = dev_reserve(ctx, ctx->d_segs, ctx->segs.size() + nt, ctx->segs.size()))) return st;
     if ((st = ensure_max_seg(ctx, (uint32_t)ctx->segs.size() + nt))) return st;
+    ctx->g.type_coll = ctx->d_type_coll.d;
     ctx->g.types = ctx->d_types.d, ctx->g.emits = ctx->d_emits.d, ctx->g.keys = ctx->d_keys.d;
     ctx->g.segs = ctx->d_segs.d, ctx->g.emit_serial = ctx->d_emit_serial.d;
 
@@ -699,6 +705,11 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         dt.bc_kind = T.base.kind, dt.bc_n = T.base.n;
         dt.em_kind = T.emis.kind, dt.em_n = T.emis.n;
         dt.pbr = p.pbr, dt.report_destroyed = p.report_destroyed;
+        FwTypeColl dc{};
+        dc.coll_flags = (p.collision.enabled ? FW_COLL_ENABLED : 0u) |
+                        (p.collision.enabled && p.collision.destroy_on_collision ? FW_COLL_DESTROY : 0u);
+        dc.coll_mask = p.collision.filter_mask;
+        dc.coll_restitution = p.collision.restitution, dc.coll_friction = p.collision.friction;
         std::vector<float> keys;
         auto put = [&](const std::vector<float> &v, uint32_t padded) {
             uint32_t off = (uint32_t)keys.size();
@@ -739,6 +750,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         FW_HIP(ctx, hipMemcpy(ctx->d_keys.d + dt.keys_off, keys.data(), keys.size() * sizeof(float),
                               hipMemcpyHostToDevice));
         FW_HIP(ctx, hipMemcpy(ctx->d_types.d + type_idx, &dt, sizeof dt, hipMemcpyHostToDevice));
+        FW_HIP(ctx, hipMemcpy(ctx->d_type_coll.d + type_idx, &dc, sizeof dc, hipMemcpyHostToDevice));
         for (int k = 0; k < FW_MAX_EMISSIONS; k++) S.lplane_emission[k] = -1;
         for (uint32_t i = 0; i < ne; i++) {
             const fw_emission_settings &e = d->emission_settings[i];
@@ -747,6 +759,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             if (e.mode == FW_MODE_NESTED && (uint32_t)e.particle_index == t) S.nested_fed = true;
         }
         S.auto_capacity = p.capacity == 0;
+        S.collides = p.collision.enabled != 0;
         S.life_bound = (double)std::max(p.lifetime.min, p.lifetime.max);  // lifetime = lerp(min, max, u), u in [0, 1)
         S.win_ok = !S.nested_fed && std::isfinite(S.life_bound);
         if ((st = alloc_seg_buffers(ctx, S, caps[t], p.report_destroyed != 0))) return st;
@@ -1112,12 +1125,13 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
         if (S.buf[0]) hipFree(S.buf[0]);
         if (S.destroyed) hipFree(S.destroyed);
     }
-    void *frees[] = {ctx->d_segs.d,       ctx->d_types.d,       ctx->d_keys.d,        ctx->d_emits.d,
+    void *frees[] = {ctx->d_type_coll.d, ctx->d_segs.d,       ctx->d_types.d,       ctx->d_keys.d,        ctx->d_emits.d,
                      ctx->d_emit_serial.d, ctx->g.count,        ctx->g.spawned,       ctx->g.appended,
                      ctx->g.ndestroyed,   ctx->g.tile_cnt,      ctx->g.tile_off,      ctx->g.tile_status,
                      ctx->g.err,          ctx->g.stats,         ctx->g.nest_tile_cnt, ctx->g.nest_tile_off,
                      ctx->g.nest_op_npar, ctx->g.nest_op_base,  ctx->g.nest_op_total, ctx->g.nest_op_serial,
-                     ctx->d_aabb,         ctx->d_total,         ctx->d_segids,        ctx->g.dbg_ts};
+                     ctx->d_aabb,         ctx->d_total,         ctx->d_segids,        ctx->g.dbg_ts,
+                     ctx->d_colliders};
     for (void *p : frees)
         if (p) hipFree(p);
     for (int i = 0; i < kParamRing; i++) {
@@ -1155,6 +1169,33 @@ fw_status fw_ctx_synchronize(fw_ctx *ctx) {
     fw_status st = sync(ctx);
     if (st) return st;
     return check_device_errors(ctx);
+}
+
+fw_status fw_ctx_set_colliders(fw_ctx *ctx, const fw_collider *colliders, uint32_t n) {
+    if (!ctx || (n && !colliders) || n > FW_MAX_COLLIDERS) return fail(ctx, FW_EINVAL, "bad collider set (at most FW_MAX_COLLIDERS)");
+    hipSetDevice(ctx->device);
+    for (uint32_t i = 0; i < n; i++)
+        if (colliders[i].kind < FW_COLLIDER_PLANE || colliders[i].kind > FW_COLLIDER_BOX)
+            return fail(ctx, FW_EINVAL, "unknown collider kind");
+    fw_status st = sync(ctx);  // kernels in flight read the old set
+    if (st) return st;
+    if (!ctx->d_colliders) FW_HIP(ctx, hipMalloc((void **)&ctx->d_colliders, FW_MAX_COLLIDERS * sizeof(FwCollider)));
+    std::vector<FwCollider> h(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const fw_collider &c = colliders[i];
+        FwCollider &d = h[i];
+        d = FwCollider{};
+        d.kind = c.kind, d.layers = c.layers, d.radius = c.radius;
+        memcpy(d.position, c.position, sizeof c.position);
+        memcpy(d.rotation, c.rotation, sizeof c.rotation);
+        memcpy(d.normal, c.normal, sizeof c.normal);
+        memcpy(d.half_extents, c.half_extents, sizeof c.half_extents);
+    }
+    if (n) FW_HIP(ctx, hipMemcpy(ctx->d_colliders, h.data(), n * sizeof(FwCollider), hipMemcpyHostToDevice));
+    ctx->n_colliders = n;
+    ctx->g.colliders = ctx->d_colliders, ctx->g.n_colliders = n;
+    ctx->fc_ok = false;
+    return FW_OK;
 }
 
 fw_status fw_spawner_create(fw_ctx *ctx, const fw_spawner_desc *desc, fw_spawner *out) {
@@ -1448,7 +1489,12 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             S.win_sum += n;
         }
     const uint32_t p = ctx->parity;
-    const bool legacy = n_n != 0 || ctx->update_mode == FW_MODE_SPLIT;
+    // Particle types with collision settings (core.rs:607-624) run the count / scan / update-with-collisions launches
+    // (everything materialised first, like FW_UPDATE_MODE=split); the streaming kernels never see a collider.
+    bool any_coll = false;
+    for (const SegHost &S : ctx->segs) any_coll |= S.in_use && S.collides;
+    const int frame_mode = any_coll ? FW_MODE_SPLIT_COLL : ctx->update_mode;
+    const bool legacy = n_n != 0 || frame_mode != FW_MODE_FUSED;
 
     FwUpdateArgs a{};
     a.seg_tile_first = ctx->d_tile_first;
@@ -1479,7 +1525,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     memcpy(&dt_bits, &dt, 4);
     // Frames with Nested entries materialise their new particles before the update; the streaming kernel takes them as
     // loaded new-particle tiles with static slots, which needs every one of them to survive the step (new_static).
-    const bool split = ctx->update_mode == FW_MODE_SPLIT;
+    const bool split = frame_mode != FW_MODE_FUSED;
     const bool fc_frame = !split && ctx->use_forecast && ctx->d_fc != nullptr;
     if (fc_frame) {
         for (uint32_t i = 0; i < n_seg; i++) a.fc_sums |= ctx->tiles_dev[i] > FW_FC_DIRECT ? 1u : 0u;
@@ -1644,7 +1690,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // timing: the events ride on the dispatch packet (its begin / end timestamps), no marker packets in the stream
     const bool timed = ctx->timing && ctx->tev_used + 2 <= ctx->tev.size();
     FW_HIP(ctx, fw_launch_update(ctx->stream, ctx->g, a, spawn_form == FW_SPAWN_INLINE ? &inl : nullptr, spawn_form,
-                                 ctx->update_mode, timed ? ctx->tev[ctx->tev_used] : nullptr,
+                                 frame_mode, timed ? ctx->tev[ctx->tev_used] : nullptr,
                                  timed ? ctx->tev[ctx->tev_used + 1] : nullptr));
     if (timed) ctx->tev_used += 2;
     if (slot >= 0) {

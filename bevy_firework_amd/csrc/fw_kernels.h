@@ -4,11 +4,13 @@
 #include <hip/hip_runtime.h>
 
 #include "fw_device.h"
+#include "fw_collide.h"
 
 // pointers to the context's persistent device state (passed by value as a kernel argument)
 struct FwGlobals {
     FwSeg *segs;
     FwType *types;
+    FwTypeColl *type_coll;  // [like types] collision settings per particle type
     float *keys;
     FwEmit *emits;
     uint32_t *count;     // [2][max_seg]  live particles per segment, by buffer parity
@@ -30,6 +32,8 @@ struct FwGlobals {
     uint32_t *nest_op_base;          // [n_ops] first child slot in the child segment
     uint32_t *nest_op_total;         // [n_ops] children spawned (after clamping)
     unsigned long long *nest_op_serial;  // [n_ops] RNG serial of the first child
+    const FwCollider *colliders;         // the world particle_collision casts its rays into (fw_ctx_set_colliders)
+    uint32_t n_colliders;
 };
 
 struct FwUpdateArgs {
@@ -90,7 +94,7 @@ struct FwInlineOps {
 
 enum { FW_SPAWN_NONE = 0, FW_SPAWN_INLINE = 1, FW_SPAWN_TABLE = 2 };
 
-enum { FW_MODE_FUSED = 0, FW_MODE_SPLIT = 1 };
+enum { FW_MODE_FUSED = 0, FW_MODE_SPLIT = 1, FW_MODE_SPLIT_COLL = 2 };  // SPLIT_COLL: frames with colliding particle types
 
 hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *ops, uint32_t n_ops, uint32_t total_blocks,
                            uint32_t parity);

@@ -284,16 +284,20 @@ __device__ __forceinline__ fw_q4 fw_quat_step(fw_v3 v) {
 
 __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float *s_keys, float dt, float4 q0, float4 q1,
                                                    float4 q2, float4 q3, float age_new, const FwOutWin &W, uint32_t o,
-                                                   float4 *rec = nullptr) {
+                                                   float4 *rec = nullptr, const fw_v3 *cpos = nullptr,
+                                                   const fw_v3 *cvel = nullptr) {
     const float lifetime = q3.w;
     const float age_percent = age_new / lifetime;
     const float scale_factor = fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_percent);
     const float scale = q1.w * scale_factor;
-    // explicit Euler with the OLD velocity (core.rs:626-631, 641-643)
-    const float px = q0.x + q1.x * dt, py = q0.y + q1.y * dt, pz = q0.z + q1.z * dt;
-    const float vx = q1.x + (T.acc[0] - q1.x * T.lin_drag) * dt;
-    const float vy = q1.y + (T.acc[1] - q1.y * T.lin_drag) * dt;
-    const float vz = q1.z + (T.acc[2] - q1.z * T.lin_drag) * dt;
+    // explicit Euler with the OLD velocity (core.rs:626-631, 641-643); cpos / cvel: what particle_collision returned
+    // for a type with collision settings (core.rs:607-624) -- the velocity update then starts from the new velocity
+    const float ux = cvel ? cvel->x : q1.x, uy = cvel ? cvel->y : q1.y, uz = cvel ? cvel->z : q1.z;
+    const float px = cpos ? cpos->x : q0.x + q1.x * dt, py = cpos ? cpos->y : q0.y + q1.y * dt,
+                pz = cpos ? cpos->z : q0.z + q1.z * dt;
+    const float vx = ux + (T.acc[0] - ux * T.lin_drag) * dt;
+    const float vy = uy + (T.acc[1] - uy * T.lin_drag) * dt;
+    const float vz = uz + (T.acc[2] - uz * T.lin_drag) * dt;
     // rotation = from_scaled_axis(angvel * dt) * rotation, no renormalisation (core.rs:645-647)
     const fw_q4 dq = fw_quat_step(fw_v3{q3.x * dt, q3.y * dt, q3.z * dt});
     const fw_q4 nr = fw_quat_mul(dq, fw_q4{q2.x, q2.y, q2.z, q2.w});
@@ -593,9 +597,13 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     }
     // virtual spawns beyond the segment's capacity are dropped (and reported): nothing may be read or written past it
     const uint32_t seg_cap = g.segs[seg].capacity;
-    const uint32_t spawn_room = seg_cap - min(n_in, seg_cap);
-    const bool spawn_clamped = n_spawn > spawn_room;
-    n_spawn = min(n_spawn, spawn_room);
+    if (SPAWN != FW_SPAWN_NONE) {
+        const uint32_t spawn_room = seg_cap - min(n_in, seg_cap);
+        if (n_spawn > spawn_room) {  // (reported here: nothing about it has to stay live through the kernel)
+            n_spawn = spawn_room;
+            if (blockIdx.x == first && threadIdx.x == 0) atomicOr(g.err, FW_ERR_CAPACITY);
+        }
+    }
     const uint32_t n_tot = n_in + n_spawn;
     // Tiling of the index space [0, n_tot): the live particles [0, n_in) in tiles of FW_TILE, then the new
     // ones [n_in, n_tot) in SMALL tiles (1, 2 or 4 rounds, the smallest that keeps all active tiles of the frame
@@ -639,7 +647,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         return;
     }
     const bool is_last = tis + 1u == n_act;
-    if (tis == 0 && tid == 0 && (n_act > seg_tiles || spawn_clamped)) {
+    if (tis == 0 && tid == 0 && n_act > seg_tiles) {
         atomicOr(g.err, FW_ERR_CAPACITY);
         g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;  // diagnostics
     }
@@ -947,7 +955,7 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
 }
 
 template <int SPAWN, bool INST, bool SUMS>
-__global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUpdateArgs a, FwInlineOps inl) {
+__global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void fw_k_update_stream(FwGlobals g, FwUpdateArgs a, FwInlineOps inl) {
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
     constexpr int LBW = 4;
@@ -998,9 +1006,13 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         for (uint32_t i = o0; i < o1; i++) n_spawn += a.ops[i].n;
     }
     const uint32_t seg_cap = g.segs[seg].capacity;  // virtual spawns beyond the capacity are dropped (and reported)
-    const uint32_t spawn_room = seg_cap - min(n_in, seg_cap);
-    const bool spawn_clamped = SPAWN != FW_SPAWN_NONE && n_spawn > spawn_room;
-    if (SPAWN != FW_SPAWN_NONE) n_spawn = min(n_spawn, spawn_room);
+    if (SPAWN != FW_SPAWN_NONE) {
+        const uint32_t spawn_room = seg_cap - min(n_in, seg_cap);
+        if (n_spawn > spawn_room) {
+            n_spawn = spawn_room;
+            if (blockIdx.x == first && threadIdx.x == 0) atomicOr(g.err, FW_ERR_CAPACITY);
+        }
+    }
     const uint32_t n_tot = n_in + n_spawn;
     // tiling of [0, n_tot): identical to fw_k_update (live tiles of FW_TILE, then small new-particle tiles)
     const uint32_t t_spawn = (n_in + FW_TILE - 1u) / FW_TILE;
@@ -1034,7 +1046,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_stream(FwGlobals g, FwUp
         return;
     }
     const bool is_last = tis + 1u == n_act;
-    if (tis == 0 && tid == 0 && (n_act > seg_tiles || spawn_clamped)) {
+    if (tis == 0 && tid == 0 && n_act > seg_tiles) {
         atomicOr(g.err, FW_ERR_CAPACITY);
         g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;  // diagnostics
     }
@@ -1291,14 +1303,21 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_count(FwGlobals g, FwUpdateArgs
     if (base < n_tot) {
         const FwSeg &S = g.segs[seg];
         const char *ib = S.buf[a.parity];
+        const FwTypeColl &T = g.type_coll[S.type_idx];
+        const bool coll_kill = (T.coll_flags & (FW_COLL_ENABLED | FW_COLL_DESTROY)) == (FW_COLL_ENABLED | FW_COLL_DESTROY);
         for (int r = 0; r < FW_ROUNDS; r++) {
             const uint32_t idx = base + r * FW_BLOCK + tid;
             if (idx < n_tot) {
                 float an;
-                c += fw_survives(fw_ld4(ib + FW_OFF_Q0(S.capacity), idx).w, a.dt,
-                                 fw_ld4(ib + FW_OFF_Q3(S.capacity), idx).w, &an)
-                         ? 1u
-                         : 0u;
+                const float4 q0 = fw_ld4(ib + FW_OFF_Q0(S.capacity), idx);
+                bool al = fw_survives(q0.w, a.dt, fw_ld4(ib + FW_OFF_Q3(S.capacity), idx).w, &an);
+                if (al && coll_kill) {  // destroy_on_collision removes particles too (core.rs:636-639)
+                    const float4 q1 = fw_ld4(ib + FW_OFF_Q1(S.capacity), idx);
+                    fw_v3 pos{q0.x, q0.y, q0.z}, vel{q1.x, q1.y, q1.z};
+                    al = !fw_particle_collision(&pos, &vel, a.dt, T.coll_restitution, T.coll_friction, true, T.coll_mask,
+                                                g.colliders, g.n_colliders);
+                }
+                c += al ? 1u : 0u;
             }
         }
     }
@@ -1306,6 +1325,110 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_count(FwGlobals g, FwUpdateArgs
     if ((tid & 63u) == 0) s_c[tid >> 6] = c;
     __syncthreads();
     if (tid == 0) g.tile_cnt[tile] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+
+// split mode, pass 3 for frames with colliding particle types (FW_MODE_SPLIT_COLL): update_particles with the
+// physics_avian arm (core.rs:607-624, 633-639, 744-800).  Same tiling as fw_k_count (tiles of FW_TILE over
+// [0, count + spawned + appended), everything materialised), output offset from fw_k_scan; per round: load, age test,
+// particle_collision for types that have collision settings, rank, integrate, store.  This is the feature path, not
+// the tuned one: no forecast, no fused spawn (the streaming kernels never run collisions and keep their registers).
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpdateArgs a) {
+    constexpr int NW = FW_BLOCK / 64;
+    __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
+    __shared__ uint32_t s_c[2][NW];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t seg = fw_upper_slot(a.seg_tile_first, a.n_seg, tile);
+    const uint32_t tis = tile - a.seg_tile_first[seg];
+    const uint32_t p = a.parity;
+    const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
+    const uint32_t n_tot = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
+    const uint32_t base = tis * FW_TILE;
+    if (blockIdx.x == 0 && tid == 0 && a.live_next) *a.live_next = 0ull;
+    if (blockIdx.x == 0 && tid == 0 && a.done_tag) *a.done_tag = a.done_value;
+    if (base >= n_tot) {
+        if (tid == 0 && n_tot == 0 && tis == 0) {  // empty segment: its first tile still owns the bookkeeping
+            g.count[oidx] = 0, g.spawned[oidx] = 0, g.appended[oidx] = 0, g.ndestroyed[seg] = 0;
+            if (a.host_counts) a.host_counts[seg] = (unsigned long long)a.epoch << 32;
+        }
+        return;
+    }
+    const FwSeg *Sp = &g.segs[seg];
+    const uint32_t C = Sp->capacity, n_lplanes = Sp->n_lplanes;
+    const char *ib = Sp->buf[p];
+    char *ob = Sp->buf[p ^ 1u];
+    char *destroyed = Sp->destroyed;
+    char *inst = Sp->inst;
+    const uint32_t inst_cap = Sp->inst_cap;
+    const FwType T = g.types[Sp->type_idx];
+    for (uint32_t i = tid; i < T.keys_len; i += FW_BLOCK) s_keys[i] = g.keys[T.keys_off + i];
+    __syncthreads();
+    const FwTypeColl TC = g.type_coll[Sp->type_idx];
+    const bool coll = (TC.coll_flags & FW_COLL_ENABLED) != 0u, coll_kill = (TC.coll_flags & FW_COLL_DESTROY) != 0u;
+    const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
+    const uint32_t excl = g.tile_off[tile];
+    const FwOutWin W = fw_out_window(ob, C, excl);
+    uint32_t run = excl;
+    const uint32_t lim = min(base + FW_TILE, n_tot);
+    const int n_rounds = (int)((lim - base + FW_BLOCK - 1u) / FW_BLOCK);
+#pragma unroll 1
+    for (int r = 0; r < n_rounds; r++) {
+        const uint32_t idx = base + r * FW_BLOCK + tid;
+        const bool valid = idx < lim;
+        const uint32_t li = min(idx, lim - 1u);
+        const float4 q0 = fw_ld4(ib + FW_OFF_Q0(C), li), q1 = fw_ld4(ib + FW_OFF_Q1(C), li),
+                     q2 = fw_ld4(ib + FW_OFF_Q2(C), li), q3 = fw_ld4(ib + FW_OFF_Q3(C), li);
+        float age_new;
+        const bool young = valid && fw_survives(q0.w, a.dt, q3.w, &age_new);
+        fw_v3 cpos{q0.x, q0.y, q0.z}, cvel{q1.x, q1.y, q1.z};
+        bool killed = false;
+        if (young && coll)
+            killed = fw_particle_collision(&cpos, &cvel, a.dt, TC.coll_restitution, TC.coll_friction, coll_kill, TC.coll_mask,
+                                           g.colliders, g.n_colliders);
+        const bool alive = young && !killed;
+        const unsigned long long m = __ballot(alive);
+        if (lane == 0) s_c[r & 1][wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t wbase = run;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t c = s_c[r & 1][w];
+            if ((uint32_t)w < wave) wbase += c;
+            run += c;
+        }
+        const uint32_t o = wbase + fw_lane_prefix(m);
+        if (alive) {
+            float4 rec[4];
+            fw_integrate_store(T, s_keys, a.dt, q0, q1, q2, q3, age_new, W, o, inst ? rec : nullptr, coll ? &cpos : nullptr,
+                               coll ? &cvel : nullptr);
+            if (inst != nullptr && o < inst_cap) {
+                fw_st4(inst, o * 4u + 0u, rec[0]), fw_st4(inst, o * 4u + 1u, rec[1]);
+                fw_st4(inst, o * 4u + 2u, rec[2]), fw_st4(inst, o * 4u + 3u, rec[3]);
+            }
+            for (uint32_t k = 0; k < n_lplanes; k++) fw_st1(ob + FW_OFF_L(C, k), o, fw_ld1(ib + FW_OFF_L(C, k), idx));
+        } else if (valid && want_destroyed) {
+            if (!killed) {  // died of age: the clone with the advanced age, pose of the previous frame (core.rs:596-599)
+                fw_store_destroyed(destroyed, ib, C, idx, true, T, s_keys, q0, q1, q2, q3, age_new, idx - o);
+            } else {  // destroyed by a collision (core.rs:633-639): new position, velocity and scale; the rest as loaded
+                const float sc = q1.w * fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_new / q3.w);
+                float *rec = reinterpret_cast<float *>(destroyed) + (size_t)(idx - o) * 26;
+                const float4 bc = fw_ld4(ib + FW_OFF_Q5(C), idx), em = fw_ld4(ib + FW_OFF_Q6(C), idx);
+                rec[0] = cpos.x, rec[1] = cpos.y, rec[2] = cpos.z, rec[3] = cvel.x, rec[4] = cvel.y, rec[5] = cvel.z;
+                rec[6] = q2.x, rec[7] = q2.y, rec[8] = q2.z, rec[9] = q2.w, rec[10] = q3.x, rec[11] = q3.y, rec[12] = q3.z;
+                rec[13] = q1.w, rec[14] = sc, rec[15] = age_new, rec[16] = q3.w;
+                rec[17] = bc.x, rec[18] = bc.y, rec[19] = bc.z, rec[20] = bc.w;
+                rec[21] = em.x, rec[22] = em.y, rec[23] = em.z, rec[24] = em.w;
+                reinterpret_cast<int32_t *>(rec)[25] = T.pbr;
+            }
+        }
+    }
+    if (lim == n_tot && tid == 0) {  // the segment's last tile
+        const uint32_t nc = run;
+        g.count[oidx] = nc, g.spawned[oidx] = 0, g.appended[oidx] = 0;
+        g.ndestroyed[seg] = n_tot - nc;
+        if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;
+        if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
+        atomicAdd(g.stats, (unsigned long long)n_tot);
+    }
 }
 
 // split mode, pass 2: one workgroup per segment scans its tiles
@@ -1735,7 +1858,11 @@ template <int R, bool INST, bool SUMS>
 static void fw_launch_update_r(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps &io,
                                int spawn_form, int mode, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(a.total_tiles), block(FW_TILE / R);
-    if (mode == FW_MODE_SPLIT) {  // debugging / A-B mode: three launches, no inter-workgroup traffic
+    if (mode == FW_MODE_SPLIT_COLL) {  // frames with colliding particle types: count (with collisions), scan, update
+        FW_LAUNCH_T(fw_k_count, grid, dim3(FW_BLOCK), s, e0, (hipEvent_t) nullptr, g, a);
+        hipLaunchKernelGGL(fw_k_scan, dim3(a.n_seg), dim3(FW_BLOCK), 0, s, g, a);
+        FW_LAUNCH_T(fw_k_update_coll, grid, dim3(FW_BLOCK), s, (hipEvent_t) nullptr, e1, g, a);
+    } else if (mode == FW_MODE_SPLIT) {  // debugging / A-B mode: three launches, no inter-workgroup traffic
         FW_LAUNCH_T(fw_k_count, grid, dim3(FW_BLOCK), s, e0, (hipEvent_t) nullptr, g, a);
         hipLaunchKernelGGL(fw_k_scan, dim3(a.n_seg), dim3(FW_BLOCK), 0, s, g, a);
         FW_LAUNCH_T((fw_k_update<false, FW_SPAWN_NONE, R, INST, SUMS>), grid, block, s, (hipEvent_t) nullptr, e1, g, a, io);
@@ -1764,7 +1891,7 @@ hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArg
     }
     static const FwInlineOps none{};
     const FwInlineOps &io = inl ? *inl : none;
-    if (mode == FW_MODE_SPLIT && spawn_form != FW_SPAWN_NONE) return hipErrorInvalidValue;
+    if (mode != FW_MODE_FUSED && spawn_form != FW_SPAWN_NONE) return hipErrorInvalidValue;
     // 256 threads x 4 rounds is the measured optimum; 512 x 2 and 1024 x 1 were 25-30 % slower
     // kernels that also write attached ParticleInstance buffers are separate instantiations: the plain ones keep
     // their register budget

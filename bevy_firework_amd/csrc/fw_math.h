@@ -198,7 +198,8 @@ FW_HD float fw_curve_sample(int kind, int n, const float *times, const float *va
     if (kind == 1 && n == 2) {
         // two evenly spaced keys (the linear fade every example uses): EvenCore with one subdivision is
         // steps_taken = t, lo = 0, s = t - trunc(t) = t inside (0, 1) -- the same values without the index arithmetic
-        t = fw_clampf(t, 0.0f, 1.0f);
+        // (the clamp to [0, 1] changes nothing here: outside (0, 1) a key is selected, inside the clamp is the identity,
+        // and a NaN passes through both; without it `1 - t` is the same value the two-key gradients use)
         const float a = vals[0], b = vals[1];
         return t <= 0.0f ? a : (t >= 1.0f ? b : a * (1.0f - t) + b * t);
     }

@@ -215,6 +215,51 @@ class SpawnTransformMode:
     Local = 1
 
 
+@dataclass(frozen=True)
+class ParticleCollisionSettings:
+    """ParticleCollisionSettings (core.rs:240-248, feature physics_avian).  ``filter_mask`` stands in for the
+    SpatialQueryFilter: a collider takes part when ``filter_mask & collider.layers`` is non-zero."""
+
+    restitution: float = 0.0
+    friction: float = 0.0
+    destroy_on_collision: bool = False
+    filter_mask: int = 0xFFFFFFFF
+
+
+COLLIDER_PLANE, COLLIDER_SPHERE, COLLIDER_BOX = 0, 1, 2
+
+
+@dataclass(frozen=True)
+class Collider:
+    """One analytic collider of the world particle_collision casts its rays into (core.rs:744-800).  The reference
+    asks avian's SpatialQuery; this backend keeps a device-resident set of planes / spheres / boxes instead
+    (include/firework_hip.h: fw_collider has the ray-cast semantics)."""
+
+    kind: int
+    position: Vec3 = (0.0, 0.0, 0.0)
+    rotation: Quat = QUAT_IDENTITY
+    normal: Vec3 = (0.0, 1.0, 0.0)
+    radius: float = 0.0
+    half_extents: Vec3 = (0.0, 0.0, 0.0)
+    layers: int = 1
+
+    @staticmethod
+    def Plane(point: Vec3, normal: Vec3, layers: int = 1) -> "Collider":
+        n = np.asarray(normal, dtype=np.float64)
+        n = n / np.linalg.norm(n)
+        return Collider(COLLIDER_PLANE, tuple(float(c) for c in point), normal=tuple(float(c) for c in n.astype(np.float32)),
+                        layers=layers)
+
+    @staticmethod
+    def Sphere(center: Vec3, radius: float, layers: int = 1) -> "Collider":
+        return Collider(COLLIDER_SPHERE, tuple(float(c) for c in center), radius=float(radius), layers=layers)
+
+    @staticmethod
+    def Box(center: Vec3, half_extents: Vec3, rotation: Quat = QUAT_IDENTITY, layers: int = 1) -> "Collider":
+        return Collider(COLLIDER_BOX, tuple(float(c) for c in center), tuple(float(c) for c in rotation),
+                        half_extents=tuple(float(c) for c in half_extents), layers=layers)
+
+
 @dataclass
 class ParticleSettings:
     """ParticleSettings (core.rs:99-142); defaults core.rs:187-211.
@@ -239,6 +284,7 @@ class ParticleSettings:
     blend_mode: str = "Blend"
     pbr: bool = False
     particles_destroyed: Optional[object] = None
+    collision_settings: Optional[ParticleCollisionSettings] = None  # core.rs:137-138
     capacity: int = 0  # backend knob: device slots for this type (0 = derived)
 
 

@@ -189,6 +189,11 @@ class ParticleSystem:
     def synchronize(self) -> None:
         self._check(self._lib.fw_ctx_synchronize(self._ctx))
 
+    def set_colliders(self, colliders) -> None:
+        """The world particle_collision casts its rays into (core.rs:744-800): a device-resident set of analytic
+        colliders (settings.Collider) standing in for avian's SpatialQuery."""
+        self._check(self._lib.fw_ctx_set_colliders(self._ctx, _ffi.make_colliders(colliders), len(colliders)))
+
     # -- ECS-like surface ------------------------------------------------------------------------
     def spawn(self, spawner: S.ParticleSpawner, transform: Optional[S.Transform] = None,
               global_transform: Optional[S.Transform] = None, modifier: Optional[S.EffectModifier] = None,

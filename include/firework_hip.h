@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 1
+#define FW_ABI_VERSION 2
 #define FW_MAX_KEYS 32          /* keys per curve / gradient */
 #define FW_MAX_TYPES 8          /* particle_settings entries per spawner */
 #define FW_MAX_EMISSIONS 8      /* emission_settings entries per spawner */
@@ -61,6 +61,15 @@ enum { FW_CURVE_CONSTANT = 0, FW_CURVE_EVEN = 1, FW_CURVE_UNEVEN = 2 };
 typedef struct fw_curve { int32_t kind; int32_t n; const float *times; const float *values; } fw_curve;
 typedef struct fw_gradient { int32_t kind; int32_t n; const float *times; const float *rgba; } fw_gradient;
 
+/* ParticleCollisionSettings (core.rs:240-248, feature physics_avian): `enabled` = the Option is Some.
+ * `filter_mask` stands in for SpatialQueryFilter: a collider takes part when (filter_mask & collider.layers) != 0. */
+typedef struct fw_collision_settings {
+    int32_t enabled;
+    float restitution, friction;
+    int32_t destroy_on_collision;
+    uint32_t filter_mask;
+} fw_collision_settings;
+
 /* ParticleSettings (core.rs:99-142), simulation-relevant fields only; textures,
  * fade_*, blend_mode stay on the host (they never enter update_particles). */
 typedef struct fw_particle_settings {
@@ -74,7 +83,29 @@ typedef struct fw_particle_settings {
     int32_t pbr;
     int32_t report_destroyed; /* event_handlers.particles_destroyed.is_some() (core.rs:164-167) */
     uint32_t capacity;        /* device slots for this type; 0 = derive from the emitters */
+    fw_collision_settings collision; /* collision_settings: Option<ParticleCollisionSettings> (core.rs:137-138) */
 } fw_particle_settings;
+
+/* The world particle_collision (core.rs:744-800) casts its rays into.  The reference asks avian's SpatialQuery
+ * (arbitrary colliders, CPU broadphase); this backend keeps a DEVICE-RESIDENT set of analytic colliders instead and
+ * casts against them inside the update.  Ray-cast semantics (ours, modelled on parry's `solid = true` casts):
+ *   PLANE   the half-space n.(x - position) <= 0 is solid; `normal` must be a unit vector
+ *   SPHERE  |x - position| <= radius is solid
+ *   BOX     |R^-1 (x - position)|_i <= half_extents_i is solid (R = rotation, xyzw)
+ *   a ray that starts inside a solid hits it at distance 0 with a ZERO normal (core.rs:762-771 handles that case);
+ *   otherwise the hit is the entry point, its normal the outward surface normal; the nearest hit over all colliders
+ *   that pass the filter wins (lowest index on ties). */
+enum { FW_COLLIDER_PLANE = 0, FW_COLLIDER_SPHERE = 1, FW_COLLIDER_BOX = 2 };
+typedef struct fw_collider {
+    int32_t kind;
+    uint32_t layers;        /* collision layers (membership bits) */
+    float position[3];
+    float rotation[4];      /* xyzw; BOX only */
+    float normal[3];        /* PLANE only */
+    float radius;           /* SPHERE only */
+    float half_extents[3];  /* BOX only */
+} fw_collider;
+#define FW_MAX_COLLIDERS 64
 
 enum { FW_PACING_ONESHOT = 0, FW_PACING_ONDEMAND = 1, FW_PACING_COUNT_OVER_DURATION = 2 }; /* core.rs:12-29 */
 enum { FW_MODE_GLOBAL = 0, FW_MODE_NESTED = 1 };                                           /* core.rs:47-54 */
@@ -140,6 +171,10 @@ fw_status fw_ctx_destroy(fw_ctx *ctx);
 const char *fw_last_error(const fw_ctx *ctx); /* ctx may be NULL: last create error */
 void *fw_ctx_stream(const fw_ctx *ctx);       /* the hipStream_t in use */
 fw_status fw_ctx_synchronize(fw_ctx *ctx);
+
+/* replaces the context's collider set (copied; n <= FW_MAX_COLLIDERS; n = 0 clears it).  Takes effect at the next
+ * fw_step; synchronises the stream. */
+fw_status fw_ctx_set_colliders(fw_ctx *ctx, const fw_collider *colliders, uint32_t n);
 
 /* ---- spawners ----------------------------------------------------------------- */
 /* ParticleSpawner insertion + first sync_spawner_data (core.rs:343-365) */

@@ -57,7 +57,28 @@ class _ParticleSettings(C.Structure):
         ("base_color", _Gradient),
         ("emissive_color", _Gradient),
         ("pbr", C.c_int32),
+        ("coll_enabled", C.c_int32),
+        ("coll_restitution", C.c_float),
+        ("coll_friction", C.c_float),
+        ("coll_destroy_on_collision", C.c_int32),
+        ("coll_filter_mask", C.c_uint32),
     ]
+
+
+class _Collider(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("layers", C.c_uint32), ("position", C.c_float * 3), ("rotation", C.c_float * 4),
+                ("normal", C.c_float * 3), ("radius", C.c_float), ("half_extents", C.c_float * 3)]
+
+
+def make_colliders(colliders):
+    arr = (_Collider * max(len(colliders), 1))()
+    for d, c in zip(arr, colliders):
+        d.kind, d.layers, d.radius = int(c.kind), int(c.layers) & 0xFFFFFFFF, float(c.radius)
+        d.position[:] = [float(x) for x in c.position]
+        d.rotation[:] = [float(x) for x in c.rotation]
+        d.normal[:] = [float(x) for x in c.normal]
+        d.half_extents[:] = [float(x) for x in c.half_extents]
+    return arr
 
 
 class _EmissionSettings(C.Structure):
@@ -119,6 +140,11 @@ def lib() -> C.CDLL:
     for name in ("fwo_quat_mul", "fwo_quat_mul_vec3", "fwo_quat_from_rotation_arc"):
         getattr(L, name).restype = None
         getattr(L, name).argtypes = [_FP, _FP, _FP]
+    L.fwo_particle_collision.restype = C.c_int32
+    L.fwo_particle_collision.argtypes = [_FP, _FP, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_uint32,
+                                         C.POINTER(_Collider), C.c_int32]
+    L.fwo_spawner_set_colliders.restype = None
+    L.fwo_spawner_set_colliders.argtypes = [_VP, C.POINTER(_Collider), C.c_int32]
     L.fwo_spawner_create.restype = _VP
     L.fwo_spawner_create.argtypes = [
         C.POINTER(_ParticleSettings), C.c_int32, C.POINTER(_EmissionSettings), C.c_int32, C.c_int32, C.c_uint32,
@@ -298,6 +324,15 @@ def randvec3_generate(r: S.RandVec3, ua, ur, um) -> np.ndarray:
     return np.array(out[:], dtype=np.float32)
 
 
+def particle_collision(pos, vel, delta, settings: S.ParticleCollisionSettings, colliders):
+    """core.rs:744-800 -> (pos, vel, should_destroy)"""
+    p, v = _farr(pos), _farr(vel)
+    d = lib().fwo_particle_collision(p, v, float(delta), float(settings.restitution), float(settings.friction),
+                                     1 if settings.destroy_on_collision else 0, int(settings.filter_mask) & 0xFFFFFFFF,
+                                     make_colliders(colliders), len(colliders))
+    return np.array(p[:], dtype=np.float32), np.array(v[:], dtype=np.float32), bool(d)
+
+
 # ---- spawner ------------------------------------------------------------------------
 
 class OracleSpawner:
@@ -321,6 +356,12 @@ class OracleSpawner:
             d.base_color = make_gradient(p.base_color, keep)
             d.emissive_color = make_gradient(p.emissive_color, keep)
             d.pbr = 1 if p.pbr else 0
+            cs = p.collision_settings
+            d.coll_enabled = 1 if cs is not None else 0
+            if cs is not None:
+                d.coll_restitution, d.coll_friction = float(cs.restitution), float(cs.friction)
+                d.coll_destroy_on_collision = 1 if cs.destroy_on_collision else 0
+                d.coll_filter_mask = int(cs.filter_mask) & 0xFFFFFFFF
         for i, e in enumerate(spawner.emission_settings):
             es[i] = make_emission(e)
         self.n_types, self.n_emissions = n_ps, n_es
@@ -350,6 +391,9 @@ class OracleSpawner:
 
     def set_modifier(self, m: S.EffectModifier):
         lib().fwo_spawner_set_modifier(self._h, float(m.scale), float(m.speed))
+
+    def set_colliders(self, colliders):
+        lib().fwo_spawner_set_colliders(self._h, make_colliders(colliders), len(colliders))
 
     def queue_particles(self, n: int):
         lib().fwo_spawner_queue(self._h, int(n))

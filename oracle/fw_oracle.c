@@ -341,6 +341,158 @@ void fwo_shape_generate(const fwo_emission_settings *e, const float u[3], float 
 }
 
 /* ------------------------------------------------------------------------- */
+/* particle_collision (core.rs:744-800) with an analytic ray cast               */
+/* ------------------------------------------------------------------------- */
+
+static float v3_length(const float a[3]) { return sqrtf(v3_dot(a, a)); }
+/* glam Vec3::normalize = self * length_recip() */
+static void v3_normalize(const float a[3], float o[3]) {
+    float r = 1.0f / v3_length(a);
+    o[0] = a[0] * r, o[1] = a[1] * r, o[2] = a[2] * r;
+}
+/* glam Vec3::project_onto(rhs) = rhs * self.dot(rhs) * rhs.dot(rhs).recip() */
+static void v3_project_onto(const float a[3], const float rhs[3], float o[3]) {
+    float rcp = 1.0f / v3_dot(rhs, rhs);
+    float d = v3_dot(a, rhs);
+    for (int i = 0; i < 3; i++) o[i] = (rhs[i] * d) * rcp;
+}
+
+/* one collider, `solid = true` semantics (include/firework_hip.h: fw_collider): inside -> distance 0, zero normal */
+static int ray_collider(const fwo_collider *c, const float o[3], const float d[3], float max_distance, float *dist,
+                        float normal[3]) {
+    if (c->kind == FWO_COLLIDER_PLANE) {
+        float dpos[3] = {c->position[0] - o[0], c->position[1] - o[1], c->position[2] - o[2]};
+        float dot_normal_dpos = v3_dot(c->normal, dpos);
+        if (dot_normal_dpos > 0.0f) {
+            *dist = 0.0f, normal[0] = normal[1] = normal[2] = 0.0f;
+            return 1;
+        }
+        float t = dot_normal_dpos / v3_dot(c->normal, d);
+        if (t >= 0.0f && t <= max_distance) {
+            *dist = t;
+            memcpy(normal, c->normal, 3 * sizeof(float));
+            return 1;
+        }
+        return 0;
+    }
+    if (c->kind == FWO_COLLIDER_SPHERE) {
+        float dc[3] = {o[0] - c->position[0], o[1] - c->position[1], o[2] - c->position[2]};
+        float a = v3_dot(d, d), b = v3_dot(dc, d);
+        float cc = v3_dot(dc, dc) - c->radius * c->radius;
+        if (cc <= 0.0f) {
+            *dist = 0.0f, normal[0] = normal[1] = normal[2] = 0.0f;
+            return 1;
+        }
+        if (b > 0.0f) return 0;
+        float delta = b * b - a * cc;
+        if (!(delta >= 0.0f)) return 0;
+        float t = (-b - sqrtf(delta)) / a;
+        if (!(t >= 0.0f && t <= max_distance)) return 0;
+        float p[3];
+        for (int i = 0; i < 3; i++) p[i] = (o[i] + d[i] * t) - c->position[i];
+        v3_normalize(p, normal);
+        *dist = t;
+        return 1;
+    }
+    /* BOX: slab test in the box frame */
+    float qi[4] = {-c->rotation[0], -c->rotation[1], -c->rotation[2], c->rotation[3]};
+    float rel[3] = {o[0] - c->position[0], o[1] - c->position[1], o[2] - c->position[2]}, ol[3], dl[3];
+    fwo_quat_mul_vec3(qi, rel, ol);
+    fwo_quat_mul_vec3(qi, d, dl);
+    int inside = 1;
+    for (int i = 0; i < 3; i++) inside = inside && fabsf(ol[i]) <= c->half_extents[i];
+    if (inside) {
+        *dist = 0.0f, normal[0] = normal[1] = normal[2] = 0.0f;
+        return 1;
+    }
+    float tnear = -INFINITY, tfar = INFINITY, sign = 0.0f;
+    int axis = 0;
+    for (int i = 0; i < 3; i++) {
+        float h = c->half_extents[i];
+        if (dl[i] == 0.0f) {
+            if (fabsf(ol[i]) > h) return 0;
+            continue;
+        }
+        float inv = 1.0f / dl[i];
+        float t1 = (-h - ol[i]) * inv, t2 = (h - ol[i]) * inv, sg = -1.0f;
+        if (t1 > t2) {
+            float tmp = t1;
+            t1 = t2, t2 = tmp, sg = 1.0f;
+        }
+        if (t1 > tnear) tnear = t1, axis = i, sign = sg;
+        if (t2 < tfar) tfar = t2;
+        if (tnear > tfar) return 0;
+    }
+    if (!(tnear >= 0.0f && tnear <= max_distance)) return 0;
+    float nl[3] = {0.0f, 0.0f, 0.0f};
+    nl[axis] = sign;
+    fwo_quat_mul_vec3(c->rotation, nl, normal);
+    *dist = tnear;
+    return 1;
+}
+
+/* SpatialQuery::cast_ray(origin, dir, max_distance, true, filter): the nearest hit */
+static int cast_ray(const fwo_collider *cs, int n, uint32_t mask, const float o[3], const float d[3], float max_distance,
+                    float *dist, float normal[3]) {
+    int any = 0;
+    for (int i = 0; i < n; i++) {
+        if (!(cs[i].layers & mask)) continue;
+        float t, nn[3];
+        if (ray_collider(&cs[i], o, d, max_distance, &t, nn) && (!any || t < *dist)) {
+            *dist = t;
+            memcpy(normal, nn, sizeof nn);
+            any = 1;
+        }
+    }
+    return any;
+}
+
+/* core.rs:744-800 */
+int32_t fwo_particle_collision(float pos[3], float vel[3], float delta, float restitution, float friction,
+                               int32_t destroy_on_collision, uint32_t filter_mask, const fwo_collider *colliders,
+                               int32_t n) {
+    const float orig_delta = delta;
+    int n_steps = 0, should_destroy = 0;
+    while (delta > 0.0f && n_steps < 4) {
+        float len = v3_length(vel), dir[3] = {0.0f, 1.0f, 0.0f}; /* Dir3::try_from(vel) else Dir3::Y */
+        if (isfinite(len) && len > 0.0f)
+            for (int i = 0; i < 3; i++) dir[i] = vel[i] / len;
+        float dist, normal[3];
+        if (cast_ray(colliders, n, filter_mask, pos, dir, v3_length(vel) * delta, &dist, normal)) {
+            if (dist == 0.0f) {
+                if (normal[0] == 0.0f && normal[1] == 0.0f && normal[2] == 0.0f) {
+                    if (vel[0] != 0.0f || vel[1] != 0.0f || vel[2] != 0.0f) {
+                        v3_normalize(vel, normal);
+                    } else {
+                        normal[0] = 0.0f, normal[1] = 1.0f, normal[2] = 0.0f;
+                    }
+                }
+                float k = fmaxf(v3_length(vel), 1.0f);
+                for (int i = 0; i < 3; i++) pos[i] += (k * normal[i]) * delta;
+            } else {
+                float nv[3], rej[3], proj[3], nrej[3];
+                v3_normalize_or_zero(vel, nv);
+                for (int i = 0; i < 3; i++) pos[i] += nv[i] * dist;
+                v3_project_onto(vel, normal, proj);
+                for (int i = 0; i < 3; i++) rej[i] = vel[i] - proj[i]; /* reject_from */
+                float friction_dv = fminf(v3_length(proj), v3_length(rej)) * friction;
+                v3_normalize_or_zero(rej, nrej);
+                for (int i = 0; i < 3; i++) vel[i] = (rej[i] - friction_dv * nrej[i]) - restitution * proj[i];
+                for (int i = 0; i < 3; i++) pos[i] += normal[i] * 0.0001f;
+                delta = f32_clamp(delta - dist, 0.0f, orig_delta);
+            }
+            should_destroy = destroy_on_collision;
+            if (should_destroy) return 1;
+        } else {
+            for (int i = 0; i < 3; i++) pos[i] += vel[i] * delta;
+            delta = 0.0f;
+        }
+        n_steps++;
+    }
+    return should_destroy;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Spawner state: AoS, one heap vector per particle, like the reference        */
 /* ------------------------------------------------------------------------- */
 
@@ -379,6 +531,8 @@ struct fwo_spawner {
     /* per-frame inputs the ECS would provide */
     float origin_translation[3], origin_rotation[4];
     float modifier_scale, modifier_speed;
+    fwo_collider *colliders; /* the SpatialQuery world (analytic stand-in) */
+    int32_t n_colliders;
 };
 
 static void pvec_push(pvec *v, const particle *p) {
@@ -505,6 +659,7 @@ void fwo_spawner_destroy(fwo_spawner *s) {
         free((void *)s->ps[i].emissive_color.times);
         free((void *)s->ps[i].emissive_color.rgba);
     }
+    free(s->colliders);
     free(s->particles), free(s->destroyed), free(s->emission), free(s->ps), free(s->es), free(s);
 }
 
@@ -531,6 +686,15 @@ void fwo_spawner_set_parent_velocity(fwo_spawner *s, const float v[3]) { memcpy(
 void fwo_spawner_set_modifier(fwo_spawner *s, float scale, float speed) { s->modifier_scale = scale, s->modifier_speed = speed; }
 /* ParticleSpawnerData::queue_particles core.rs:284-286 */
 void fwo_spawner_queue(fwo_spawner *s, uint64_t n) { s->manual_queued_count += n; }
+void fwo_spawner_set_colliders(fwo_spawner *s, const fwo_collider *colliders, int32_t n) {
+    free(s->colliders);
+    s->colliders = NULL, s->n_colliders = 0;
+    if (n > 0) {
+        s->colliders = (fwo_collider *)malloc(sizeof(fwo_collider) * (size_t)n);
+        memcpy(s->colliders, colliders, sizeof(fwo_collider) * (size_t)n);
+        s->n_colliders = n;
+    }
+}
 
 /* ParticleSpawnerData::active core.rs:288-302 */
 int32_t fwo_spawner_active(const fwo_spawner *s) {
@@ -640,7 +804,7 @@ void fwo_spawner_spawn(fwo_spawner *s, float dt) {
     }
 }
 
-/* update_particles core.rs:577-670, non-avian arm (core.rs:626-631) */
+/* update_particles core.rs:577-670; the physics_avian arm (core.rs:607-624) when the type has collision settings */
 void fwo_spawner_update(fwo_spawner *s, float dt) {
     for (int i = 0; i < s->n_ps; i++) {
         const fwo_particle_settings *ps = &s->ps[i];
@@ -660,9 +824,19 @@ void fwo_spawner_update(fwo_spawner *s, float dt) {
             p.scale = p.initial_scale * scale_factor;
 
             float sa[3];
+            if (ps->coll_enabled) { /* core.rs:607-624 (feature physics_avian) */
+                int destroy = fwo_particle_collision(p.position, p.velocity, dt, ps->coll_restitution, ps->coll_friction,
+                                                     ps->coll_destroy_on_collision, ps->coll_filter_mask, s->colliders,
+                                                     s->n_colliders);
+                if (destroy) { /* core.rs:636-639: the record carries the new position / velocity / scale */
+                    pvec_push(&destroyed, &p);
+                    continue;
+                }
+            } else {
+                for (int c = 0; c < 3; c++) p.position[c] = p.position[c] + p.velocity[c] * dt;
+            }
             for (int c = 0; c < 3; c++) {
                 float v = p.velocity[c];
-                p.position[c] = p.position[c] + v * dt;
                 p.velocity[c] = v + (ps->acceleration[c] - v * ps->linear_drag) * dt;
                 sa[c] = p.angular_velocity[c] * dt;
             }

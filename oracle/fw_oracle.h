@@ -70,7 +70,25 @@ typedef struct {
     float linear_drag, angular_drag;
     fwo_gradient base_color, emissive_color;
     int32_t pbr;
+    /* collision_settings: Option<ParticleCollisionSettings> (core.rs:137-138, 240-248; feature physics_avian) */
+    int32_t coll_enabled;
+    float coll_restitution, coll_friction;
+    int32_t coll_destroy_on_collision;
+    uint32_t coll_filter_mask;
 } fwo_particle_settings;
+
+/* the analytic collider set the oracle's ray cast runs against (stands in for avian's SpatialQuery; semantics in
+ * include/firework_hip.h: fw_collider).  "Parity unpinned": the reference's world is arbitrary parry shapes. */
+enum { FWO_COLLIDER_PLANE = 0, FWO_COLLIDER_SPHERE = 1, FWO_COLLIDER_BOX = 2 };
+typedef struct {
+    int32_t kind;
+    uint32_t layers;
+    float position[3];
+    float rotation[4];
+    float normal[3];
+    float radius;
+    float half_extents[3];
+} fwo_collider;
 
 enum { FWO_PACING_ONESHOT = 0, FWO_PACING_ONDEMAND = 1, FWO_PACING_COUNT_OVER_DURATION = 2 };
 enum { FWO_MODE_GLOBAL = 0, FWO_MODE_NESTED = 1 };
@@ -128,6 +146,11 @@ void fwo_quat_mul(const float a[4], const float b[4], float out[4]);
 void fwo_quat_mul_vec3(const float q[4], const float v[3], float out[3]);
 void fwo_quat_from_rotation_arc(const float from[3], const float to[3], float out[4]);
 
+/* particle_collision (core.rs:744-800) against `n` colliders; pos / vel updated in place; returns should_destroy */
+int32_t fwo_particle_collision(float pos[3], float vel[3], float delta, float restitution, float friction,
+                               int32_t destroy_on_collision, uint32_t filter_mask, const fwo_collider *colliders,
+                               int32_t n);
+
 /* ---- spawner lifecycle ----------------------------------------------------- */
 fwo_spawner *fwo_spawner_create(const fwo_particle_settings *ps, int32_t n_ps, const fwo_emission_settings *es,
                                 int32_t n_es, int32_t starts_enabled, uint32_t seed, uint32_t uid);
@@ -138,6 +161,8 @@ void fwo_spawner_set_origin(fwo_spawner *s, const float translation[3], const fl
 void fwo_spawner_set_parent_velocity(fwo_spawner *s, const float v[3]);
 void fwo_spawner_set_modifier(fwo_spawner *s, float scale, float speed);
 void fwo_spawner_queue(fwo_spawner *s, uint64_t n);
+/* the world the spawner's particles collide with (copied) */
+void fwo_spawner_set_colliders(fwo_spawner *s, const fwo_collider *colliders, int32_t n);
 int32_t fwo_spawner_active(const fwo_spawner *s);
 /* returns 1 exactly once, like notify_finished_particle_spawners (core.rs:674-688) */
 int32_t fwo_spawner_poll_finished(fwo_spawner *s);

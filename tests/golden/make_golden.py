@@ -209,6 +209,7 @@ def trajectories():
         sc = make()
         sim = np_sim.Spawner(sc["spawner"], scenarios.SEED, sc["uid"], sc["transform"], sc["modifier"])
         sim.parent_velocity = np.asarray(sc["parent_velocity"], dtype=f32)
+        sim.colliders = sc.get("colliders", [])
         counts = []
         for fr in range(sc["frames"]):
             sim.step(f32(sc["dts"][fr % len(sc["dts"])]))
@@ -219,6 +220,8 @@ def trajectories():
                     d = sim.destroyed[t]
                     out[f"{name}/f{fr}/t{t}/destroyed_age"] = np.ascontiguousarray(d["age"], dtype=f32)
                     out[f"{name}/f{fr}/t{t}/destroyed_position"] = np.ascontiguousarray(d["position"], dtype=f32)
+                    out[f"{name}/f{fr}/t{t}/destroyed_velocity"] = np.ascontiguousarray(d["velocity"], dtype=f32)
+                    out[f"{name}/f{fr}/t{t}/destroyed_scale"] = np.ascontiguousarray(d["scale"], dtype=f32)
                 counts.append([fr] + [sim.count(t) for t in range(len(sim.particles))])
         summary[name] = counts
     np.savez_compressed(os.path.join(HERE, "trajectories.npz"), **out)

@@ -311,6 +311,152 @@ def gradient_sample(grad, t):
     return np.where(between[..., None], mixed, a).astype(f32)
 
 
+# ---------------------------------------------------------------- particle_collision (core.rs:744-800)
+def _len3(v):
+    return np.sqrt(dot3(v, v)).astype(f32)
+
+
+def _normalize3(v):  # glam Vec3::normalize = self * length_recip()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (v * (ONE / _len3(v)).astype(f32)[..., None]).astype(f32)
+
+
+def _project_onto(a, rhs):  # glam: rhs * self.dot(rhs) * rhs.dot(rhs).recip()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rcp = (ONE / dot3(rhs, rhs)).astype(f32)
+    return ((rhs * dot3(a, rhs)[..., None]).astype(f32) * rcp[..., None]).astype(f32)
+
+
+def cast_ray(colliders, mask, origin, d, max_distance):
+    """nearest `solid = true` hit of the rays origin + t d over the analytic colliders (include/firework_hip.h:
+    fw_collider) -> (hit mask, distance, normal); a ray starting inside a solid hits at 0 with a zero normal"""
+    n = len(origin)
+    best_t = np.full(n, np.inf, dtype=f32)
+    best_n = np.zeros((n, 3), dtype=f32)
+    found = np.zeros(n, dtype=bool)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        for c in colliders:
+            if not (int(c.layers) & int(mask)):
+                continue
+            cpos = _a(c.position)
+            hit = np.zeros(n, dtype=bool)
+            t = np.zeros(n, dtype=f32)
+            nrm = np.zeros((n, 3), dtype=f32)
+            if c.kind == 0:  # plane
+                nn = np.broadcast_to(_a(c.normal), (n, 3))
+                dnd = dot3(nn, (cpos - origin).astype(f32))
+                inside = dnd > 0
+                tt = (dnd / dot3(nn, d)).astype(f32)
+                ok = ~inside & (tt >= 0) & (tt <= max_distance)
+                hit = inside | ok
+                t = np.where(inside, ZERO, tt).astype(f32)
+                nrm = np.where(ok[:, None], nn, ZERO).astype(f32)
+            elif c.kind == 1:  # sphere
+                dc = (origin - cpos).astype(f32)
+                a_, b_ = dot3(d, d), dot3(dc, d)
+                cc = (dot3(dc, dc) - f32(f32(c.radius) * f32(c.radius))).astype(f32)
+                inside = cc <= 0
+                delta = ((b_ * b_).astype(f32) - (a_ * cc).astype(f32)).astype(f32)
+                tt = (((-b_).astype(f32) - np.sqrt(np.maximum(delta, ZERO)).astype(f32)).astype(f32) / a_).astype(f32)
+                ok = ~inside & ~(b_ > 0) & (delta >= 0) & (tt >= 0) & (tt <= max_distance)
+                p_ = ((origin + (d * tt[:, None]).astype(f32)).astype(f32) - cpos).astype(f32)
+                hit = inside | ok
+                t = np.where(inside, ZERO, tt).astype(f32)
+                nrm = np.where(ok[:, None], _normalize3(p_), ZERO).astype(f32)
+            else:  # box
+                q = _a(c.rotation)
+                qi = np.broadcast_to(np.array([-q[0], -q[1], -q[2], q[3]], dtype=f32), (n, 4))
+                ol = quat_mul_vec3(qi, (origin - cpos).astype(f32))
+                dl = quat_mul_vec3(qi, d)
+                h = _a(c.half_extents)
+                inside = (np.abs(ol) <= h).all(axis=1)
+                tnear = np.full(n, -np.inf, dtype=f32)
+                tfar = np.full(n, np.inf, dtype=f32)
+                axis = np.zeros(n, dtype=np.int64)
+                sign = np.zeros(n, dtype=f32)
+                dead = np.zeros(n, dtype=bool)
+                for i in range(3):
+                    par = dl[:, i] == 0
+                    dead |= ~dead & par & (np.abs(ol[:, i]) > h[i])
+                    inv = (ONE / dl[:, i]).astype(f32)
+                    t1 = ((-h[i] - ol[:, i]).astype(f32) * inv).astype(f32)
+                    t2 = ((h[i] - ol[:, i]).astype(f32) * inv).astype(f32)
+                    sw = t1 > t2
+                    lo_, hi_ = np.where(sw, t2, t1), np.where(sw, t1, t2)
+                    sg = np.where(sw, ONE, f32(-1.0)).astype(f32)
+                    live = ~dead & ~par
+                    upd = live & (lo_ > tnear)
+                    tnear = np.where(upd, lo_, tnear).astype(f32)
+                    axis = np.where(upd, i, axis)
+                    sign = np.where(upd, sg, sign).astype(f32)
+                    tfar = np.where(live & (hi_ < tfar), hi_, tfar).astype(f32)
+                    dead |= live & (tnear > tfar)
+                ok = ~inside & ~dead & (tnear >= 0) & (tnear <= max_distance)
+                nl = np.zeros((n, 3), dtype=f32)
+                nl[np.arange(n), axis] = sign
+                hit = inside | ok
+                t = np.where(inside, ZERO, tnear).astype(f32)
+                nrm = np.where(ok[:, None], quat_mul_vec3(np.broadcast_to(q, (n, 4)), nl), ZERO).astype(f32)
+            better = hit & (~found | (t < best_t))
+            best_t = np.where(better, t, best_t).astype(f32)
+            best_n = np.where(better[:, None], nrm, best_n).astype(f32)
+            found |= hit
+    return found, best_t, best_n
+
+
+def particle_collision(pos, vel, delta, cs, colliders):
+    """core.rs:744-800 for arrays of particles -> (pos, vel, should_destroy)"""
+    n = len(pos)
+    pos, vel = pos.astype(f32).copy(), vel.astype(f32).copy()
+    orig = f32(delta)
+    delta = np.full(n, orig, dtype=f32)
+    steps = np.zeros(n, dtype=np.int64)
+    destroy = np.zeros(n, dtype=bool)
+    returned = np.zeros(n, dtype=bool)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        for _ in range(4):
+            act = ~returned & (delta > 0) & (steps < 4)
+            if not act.any():
+                break
+            ln = _len3(vel)
+            okdir = np.isfinite(ln) & (ln > 0)
+            d = np.where(okdir[:, None], (vel / np.where(okdir, ln, ONE)[:, None]).astype(f32), _a((0.0, 1.0, 0.0))).astype(f32)
+            found, dist, normal = cast_ray(colliders, cs.filter_mask, pos, d, (ln * delta).astype(f32))
+            hit = act & found
+            miss = act & ~found
+            # ---- distance == 0 (core.rs:766-776)
+            z = hit & (dist == 0)
+            nz = (normal == 0).all(axis=1)
+            vz = (vel == 0).all(axis=1)
+            nfix = np.where((nz & ~vz)[:, None], _normalize3(vel), np.where((nz & vz)[:, None], _a((0.0, 1.0, 0.0)), normal)).astype(f32)
+            k = np.fmax(ln, ONE).astype(f32)
+            push = ((nfix * k[:, None]).astype(f32) * delta[:, None]).astype(f32)
+            pos = np.where(z[:, None], (pos + push).astype(f32), pos).astype(f32)
+            # ---- a real hit (core.rs:777-787)
+            r = hit & ~z
+            pos_r = (pos + (normalize_or_zero(vel) * dist[:, None]).astype(f32)).astype(f32)
+            proj = _project_onto(vel, normal)
+            rej = (vel - proj).astype(f32)
+            fdv = (np.fmin(_len3(proj), _len3(rej)).astype(f32) * f32(cs.friction)).astype(f32)
+            vel_r = ((rej - (normalize_or_zero(rej) * fdv[:, None]).astype(f32)).astype(f32)
+                     - (proj * f32(cs.restitution)).astype(f32)).astype(f32)
+            pos_r = (pos_r + (normal * f32(0.0001)).astype(f32)).astype(f32)
+            nd = (delta - dist).astype(f32)
+            nd = np.where(nd < 0, ZERO, nd).astype(f32)
+            nd = np.where(nd > orig, orig, nd).astype(f32)
+            pos = np.where(r[:, None], pos_r, pos).astype(f32)
+            vel = np.where(r[:, None], vel_r, vel).astype(f32)
+            delta = np.where(r, nd, delta).astype(f32)
+            if cs.destroy_on_collision:
+                destroy |= hit
+                returned |= hit
+            # ---- no hit
+            pos = np.where(miss[:, None], (pos + (vel * delta[:, None]).astype(f32)).astype(f32), pos).astype(f32)
+            delta = np.where(miss, ZERO, delta).astype(f32)
+            steps = steps + act
+    return pos, vel, destroy
+
+
 # ---------------------------------------------------------------- the spawner
 FIELDS = {"position": 3, "velocity": 3, "rotation": 4, "angular_velocity": 3, "initial_scale": 0, "scale": 0, "age": 0,
           "lifetime": 0, "base_color": 4, "emissive_color": 4}
@@ -343,6 +489,7 @@ class Spawner:
         self.mod_scale = f32(modifier.scale if modifier else 1.0)
         self.mod_speed = f32(modifier.speed if modifier else 1.0)
         self.queued = 0
+        self.colliders = []
         self.serial = [0] * self.n_em
         self.reset()
 
@@ -433,8 +580,17 @@ class Spawner:
             q["age"] = age[~dead]
             pct = (q["age"] / q["lifetime"]).astype(f32)
             q["scale"] = (q["initial_scale"] * curve_sample(ps.scale_curve, pct)).astype(f32)
-            vel = q["velocity"]
-            q["position"] = (q["position"] + (vel * dt).astype(f32)).astype(f32)
+            if ps.collision_settings is not None:  # the physics_avian arm (core.rs:607-624, 633-639)
+                npos, nvel, kill = particle_collision(q["position"], q["velocity"], dt, ps.collision_settings, self.colliders)
+                q["position"], q["velocity"] = npos, nvel
+                hit = _take(q, kill)  # destroyed with the NEW position / velocity / scale, old rotation and colours
+                self.destroyed[t] = self._merge_destroyed(gone, hit, dead, kill)
+                q = _take(q, ~kill)
+                pct = pct[~kill]
+                vel = q["velocity"]
+            else:
+                vel = q["velocity"]
+                q["position"] = (q["position"] + (vel * dt).astype(f32)).astype(f32)
             acc = _a(ps.acceleration)
             q["velocity"] = (vel + ((acc - (vel * f32(ps.linear_drag)).astype(f32)).astype(f32) * dt).astype(f32)).astype(f32)
             w = q["angular_velocity"]
@@ -444,6 +600,23 @@ class Spawner:
             q["base_color"] = gradient_sample(ps.base_color, pct)
             q["emissive_color"] = gradient_sample(ps.emissive_color, pct)
             self.particles[t] = q
+
+    @staticmethod
+    def _merge_destroyed(gone, hit, dead, kill):
+        """the reference pushes destroyed particles in iteration order: age deaths and collision deaths interleaved"""
+        n = len(dead)
+        order = np.zeros(n, dtype=np.int64)  # 1 = died of age, 2 = destroyed by a collision, 0 = alive
+        order[dead] = 1
+        alive_idx = np.flatnonzero(~dead)
+        order[alive_idx[kill]] = 2
+        out = {}
+        for k in gone:
+            width = gone[k].shape[1:]
+            buf = np.zeros((n,) + width, dtype=f32)
+            buf[order == 1] = gone[k]
+            buf[order == 2] = hit[k]
+            out[k] = buf[order != 0]
+        return out
 
     def step(self, dt):  # plugin.rs:46-60: spawn_particles then update_particles
         self.spawn(dt)

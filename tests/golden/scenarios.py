@@ -102,4 +102,32 @@ def deaths_everywhere():
                 checkpoints=[0, 30, 95, 149], exact=True)
 
 
-ALL = {f.__name__: f for f in (rotation_cone_sphere, two_types_circle_oneshot, nested_sparks_smoke, deaths_everywhere)}
+def bouncing_colliders():
+    """particle_collision (core.rs:607-624, 744-800) against the analytic collider set: a tilted ground plane, a sphere
+    and a rotated box; type 0 bounces (restitution, friction), type 1 is destroyed on contact, type 2 only collides
+    with layer 2 (the small sphere high up); fast particles take several bounce sub-steps per frame.  No libm call
+    anywhere in the collision arithmetic (sqrt and division are correctly rounded everywhere): bit-exact."""
+    bounce = S.ParticleSettings(lifetime=S.RandF32(1.5, 3.0), linear_drag=0.05, initial_scale=S.RandF32(0.02, 0.05),
+                                collision_settings=S.ParticleCollisionSettings(restitution=0.6, friction=0.3))
+    fragile = S.ParticleSettings(lifetime=S.RandF32(2.0, 3.0), linear_drag=0.0,
+                                 collision_settings=S.ParticleCollisionSettings(0.2, 0.9, destroy_on_collision=True))
+    picky = S.ParticleSettings(lifetime=S.RandF32.constant(2.5), acceleration=(0.0, 2.0, 0.0), linear_drag=0.0,
+                               collision_settings=S.ParticleCollisionSettings(1.0, 0.0, False, filter_mask=2))
+    e0 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(600.0),
+                            emission_shape=S.EmissionShape.Point(),
+                            initial_velocity=S.RandVec3(S.RandF32(2.0, 14.0), (0.3, -1.0, 0.1), 0.0),
+                            initial_velocity_radial=S.RandF32(0.0, 0.0))
+    e1 = S.EmissionSettings(particle_index=1, emission_pacing=S.EmissionPacing.rate(400.0),
+                            initial_velocity=S.RandVec3(S.RandF32(1.0, 6.0), (-0.5, -1.0, 0.2), 0.0))
+    e2 = S.EmissionSettings(particle_index=2, emission_pacing=S.EmissionPacing.rate(150.0),
+                            initial_velocity=S.RandVec3(S.RandF32(0.5, 3.0), (0.0, 1.0, 0.0), 0.0))
+    colliders = [S.Collider.Plane((0.0, -1.0, 0.0), (0.1, 1.0, 0.05)), S.Collider.Sphere((1.0, 0.0, 0.2), 0.8),
+                 S.Collider.Box((-1.2, -0.2, 0.3), (0.7, 0.4, 0.9), (0.0, math.sin(0.35), 0.0, math.cos(0.35))),
+                 S.Collider.Sphere((0.0, 4.5, 0.0), 0.6, layers=2)]
+    return dict(spawner=S.ParticleSpawner([bounce, fragile, picky], [e0, e1, e2]), transform=S.Transform((0.0, 2.0, 0.0)),
+                modifier=None, parent_velocity=(0.0, 0.0, 0.0), uid=21, dts=[1 / 60] * 30 + [1 / 30, 1 / 120, 0.05],
+                frames=160, checkpoints=[0, 25, 80, 159], exact=True, colliders=colliders)
+
+
+ALL = {f.__name__: f for f in (rotation_cone_sphere, two_types_circle_oneshot, nested_sparks_smoke, deaths_everywhere,
+                               bouncing_colliders)}

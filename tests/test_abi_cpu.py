@@ -33,11 +33,22 @@ def test_library_exports_every_declared_symbol():
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.fw_abi_version() == 1
+    assert lib.fw_abi_version() == 2
 
 
-def test_struct_sizes_match_header():
-    assert C.sizeof(_ffi.ParticleSettings) == 8 + 24 + 8 + 12 + 12 + 8 + 24 + 24 + 12 + 4  # incl. tail padding
+def test_struct_sizes_match_header(tmp_path):
+    """the ctypes mirrors against the C compiler's layout of include/firework_hip.h"""
+    import subprocess
+
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "firework_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   "sizeof(fw_particle_settings),sizeof(fw_emission_settings),sizeof(fw_spawner_desc),sizeof(fw_collider),"
+                   "sizeof(fw_particle),sizeof(fw_particle_instance));return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [C.sizeof(_ffi.ParticleSettings), C.sizeof(_ffi.EmissionSettings), C.sizeof(_ffi.SpawnerDesc),
+                   C.sizeof(_ffi.Collider), S.PARTICLE_DTYPE.itemsize, S.INSTANCE_DTYPE.itemsize], got
     assert S.PARTICLE_DTYPE.itemsize == 104 and S.INSTANCE_DTYPE.itemsize == 64
 
 

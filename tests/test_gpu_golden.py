@@ -47,6 +47,7 @@ def test_hip_follows_the_numpy_trajectories(monkeypatch, name, env):
     with ParticleSystem(device=0, seed=scenarios.SEED) as system:
         h = system.spawn(sc["spawner"], sc["transform"], uid=sc["uid"], modifier=sc["modifier"])
         h.set_parent_velocity(sc["parent_velocity"])
+        system.set_colliders(sc.get("colliders", []))
 
         def check(fr):
             for t in range(n_types):
@@ -60,8 +61,11 @@ def test_hip_follows_the_numpy_trajectories(monkeypatch, name, env):
                 dead = h.destroyed(t)
                 assert np.array_equal(dead["age"], g[f"{name}/f{fr}/t{t}/destroyed_age"]), (name, fr, t)
                 if len(dead):
-                    ok, _ = parity.trig_field_errors(dead["position"], g[f"{name}/f{fr}/t{t}/destroyed_position"])
-                    assert ok.all()
+                    for k in ("position", "velocity"):  # collision deaths carry the NEW position / velocity
+                        want_k = g[f"{name}/f{fr}/t{t}/destroyed_{k}"]
+                        ok, _ = parity.trig_field_errors(dead[k], want_k)
+                        assert ok.all() and (not sc.get("exact") or np.array_equal(dead[k], want_k)), (name, fr, t, k)
+                    assert np.array_equal(dead["scale"], g[f"{name}/f{fr}/t{t}/destroyed_scale"])
 
         parity.run_scenario(sc, lambda: system.update, check)
         assert sum(h.counts()) > 500
@@ -317,3 +321,57 @@ sh.system.close(); dist.destroy_process_group(); print("RCCL_OK")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=240)
     assert "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_collisions_against_the_oracle_with_nested_and_attached_instances(system):
+    """the collision path (count / scan / update-with-collisions launches) together with everything else a frame can
+    hold: a Nested entry (children of bouncing parents), a non-colliding neighbour in the same context, an attached
+    instance buffer on the colliding type, colliders replaced mid-run, destroyed streams of both death causes"""
+    import torch
+
+    bounce = S.ParticleSettings(lifetime=S.RandF32(0.8, 1.6), linear_drag=0.1,
+                                collision_settings=S.ParticleCollisionSettings(0.7, 0.2))
+    bounce.particles_destroyed = lambda d: None
+    trail = S.ParticleSettings(lifetime=S.RandF32(0.2, 0.5), acceleration=(0.0, 0.0, 0.0),
+                               collision_settings=S.ParticleCollisionSettings(0.0, 0.0, destroy_on_collision=True))
+    trail.particles_destroyed = lambda d: None
+    e0 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(3000.0),
+                            emission_shape=S.EmissionShape.Sphere(0.3),
+                            initial_velocity=S.RandVec3(S.RandF32(1.0, 9.0), (0.2, -1.0, 0.0), 0.6))
+    e1 = S.EmissionSettings(particle_index=1, emission_mode=S.EmissionMode.Nested(0),
+                            emission_pacing=S.EmissionPacing.CountOverDuration(12.0, 0.0, 0.0, 1.0),
+                            initial_velocity=S.RandVec3(S.RandF32(0.0, 2.0), (0.0, -1.0, 0.0), 1.0))
+    pair = parity.Pair(system, S.ParticleSpawner([bounce, trail], [e0, e1]), S.Transform((0.0, 2.5, 0.0)),
+                       seed=scenarios.SEED, uid=31)
+    plain = parity.Pair(system, S.ParticleSpawner([S.ParticleSettings(lifetime=S.RandF32(0.3, 0.9))],
+                                                  [S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(20000.0))]),
+                        seed=scenarios.SEED, uid=32)
+    world_a = [S.Collider.Plane((0, 0, 0), (0, 1, 0)), S.Collider.Sphere((0.8, 0.6, 0.0), 0.5)]
+    world_b = world_a + [S.Collider.Box((-0.9, 0.5, 0.2), (0.5, 0.5, 0.5), (0.0, 0.0, float(np.sin(0.2)), float(np.cos(0.2))))]
+    system.set_colliders(world_a)
+    pair.cpu.set_colliders(world_a)
+    cap = 60000
+    buf = torch.full((cap * 16,), float("nan"), dtype=torch.float32, device="cuda")
+    pair.gpu.attach_instances(buf.data_ptr(), cap, particle_type=0)
+    for fr in range(120):
+        if fr == 60:
+            system.set_colliders(world_b)
+            pair.cpu.set_colliders(world_b)
+        system.update(DT)
+        pair.step_cpu(DT)
+        plain.step_cpu(DT)
+        if fr % 20 == 19:
+            pair.check(what=f"colliding spawner, frame {fr}")
+            plain.check(exact_all=True, what=f"neighbour, frame {fr}")
+            for t in (0, 1):
+                gd, cd = pair.gpu.destroyed(t), pair.cpu.destroyed(t)
+                assert len(gd) == len(cd) and np.array_equal(gd["age"], cd["age"]) and np.array_equal(gd["scale"], cd["scale"])
+                if len(gd):
+                    assert parity.trig_field_errors(gd["position"], cd["position"])[0].all()
+            n = pair.gpu.count(0)
+            rec = buf[: n * 16].cpu().numpy().view(S.INSTANCE_DTYPE).reshape(n)
+            assert np.array_equal(rec["position"], pair.gpu.particles(0)["position"])
+    c = pair.gpu.counts()
+    assert c[0] > 2000 and c[1] > 3000, c
+    # bounced particles really are above the ground plane, and some were slowed by it
+    assert (pair.gpu.particles(0)["position"][:, 1] > -1e-3).all()

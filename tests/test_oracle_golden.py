@@ -184,7 +184,7 @@ def _scenarios():
 
 
 @pytest.mark.parametrize("name", ["rotation_cone_sphere", "two_types_circle_oneshot", "nested_sparks_smoke",
-                                  "deaths_everywhere"])
+                                  "deaths_everywhere", "bouncing_colliders"])
 def test_oracle_follows_the_numpy_trajectories(name):
     """tests/golden/trajectories.npz was produced by np_sim.py -- array-oriented numpy, written from the reference
     lines, a different libm -- over scenarios.py.  The C oracle, run over the same inputs, must give the same counts
@@ -199,6 +199,7 @@ def test_oracle_follows_the_numpy_trajectories(name):
     if sc["modifier"] is not None:
         o.set_modifier(sc["modifier"])
     o.set_parent_velocity(sc["parent_velocity"])
+    o.set_colliders(sc.get("colliders", []))
     n_types = len(sc["spawner"].particle_settings)
     n_em = len(sc["spawner"].emission_settings)
     g = parity.golden()
@@ -214,8 +215,10 @@ def test_oracle_follows_the_numpy_trajectories(name):
             dead = o.destroyed(t)
             assert np.array_equal(dead["age"], g[f"{name}/f{fr}/t{t}/destroyed_age"])
             if len(dead):
-                ok, _ = parity.trig_field_errors(dead["position"], g[f"{name}/f{fr}/t{t}/destroyed_position"])
-                assert ok.all()
+                for k in ("position", "velocity"):  # collision deaths carry the NEW position / velocity (core.rs:633-639)
+                    ok, _ = parity.trig_field_errors(dead[k], g[f"{name}/f{fr}/t{t}/destroyed_{k}"])
+                    assert ok.all() and (not sc.get("exact") or np.array_equal(dead[k], g[f"{name}/f{fr}/t{t}/destroyed_{k}"]))
+                assert np.array_equal(dead["scale"], g[f"{name}/f{fr}/t{t}/destroyed_scale"])
 
     parity.run_scenario(sc, lambda: o.step, check)
     assert sum(o.counts()) > 500
@@ -240,3 +243,40 @@ def test_fixtures_are_reproducible():
     for t, p in enumerate(sim.particles):
         for k, v in p.items():
             assert np.array_equal(v.view(np.uint32), g[f"{name}/f{fr}/t{t}/{k}"].view(np.uint32)), (t, k)
+
+
+def test_particle_collision_against_the_numpy_restatement():
+    """particle_collision (core.rs:744-800) + the analytic ray cast: the C oracle and the vectorised numpy restatement
+    agree bit for bit on random rays against every collider kind, inside-solid starts, grazing rays, zero velocity,
+    the 4-sub-step cap and destroy_on_collision"""
+    import math
+    import sys
+
+    sys.path.insert(0, G)
+    import np_sim
+
+    rng = np.random.default_rng(11)
+    cols = [S.Collider.Plane((0, -1, 0), (0.1, 1, 0.05)), S.Collider.Sphere((1, 0.5, 0), 0.8),
+            S.Collider.Box((-1.5, 0.3, 0.5), (0.6, 0.4, 0.9), (0.0, math.sin(0.35), 0.0, math.cos(0.35))),
+            S.Collider.Sphere((0, 3, 0), 0.5, layers=2)]
+    n = 6000
+    pos = rng.uniform(-3, 3, size=(n, 3)).astype(np.float32)
+    vel = (rng.normal(size=(n, 3)) * rng.choice([0, 0.5, 5, 30], size=(n, 1))).astype(np.float32)
+    hits = 0
+    for cs in (S.ParticleCollisionSettings(0.6, 0.3), S.ParticleCollisionSettings(0.2, 0.9, True),
+               S.ParticleCollisionSettings(1.0, 0.0, False, 2)):
+        for dt in (1 / 60, 0.25, 0.0):
+            p2, v2, k2 = np_sim.particle_collision(pos, vel, np.float32(dt), cs, cols)
+            for i in range(0, n, 5):
+                p, v, k = oracle.particle_collision(pos[i], vel[i], np.float32(dt), cs, cols)
+                assert np.array_equal(p, p2[i]) and np.array_equal(v, v2[i]) and k == bool(k2[i]), (cs, dt, i)
+            hits += int((np.abs(p2 - (pos + vel * np.float32(dt))) > 1e-6).any(axis=1).sum())
+    assert hits > 5000
+    # hand-checkable: straight down onto the plane y = 0 with restitution 0.5, friction 0.2
+    p, v, k = oracle.particle_collision((0, 1, 0), (0, -10, 1), 0.2, S.ParticleCollisionSettings(0.5, 0.2),
+                                        [S.Collider.Plane((0, 0, 0), (0, 1, 0))])
+    assert np.allclose(v, (0, 5, 0.8), atol=1e-6) and abs(p[1] - 1e-4) < 1e-6 and not k
+    # 4-sub-step cap: inside the half-space every sub-step pushes along the velocity, delta is never consumed
+    p, v, k = oracle.particle_collision((0, -1, 0), (0, -10, 1), 0.2, S.ParticleCollisionSettings(0.5, 0.2),
+                                        [S.Collider.Plane((0, 0, 0), (0, 1, 0))])
+    assert np.allclose(p, (0, -9, 0.8), atol=1e-5) and np.array_equal(v, np.float32((0, -10, 1)))
