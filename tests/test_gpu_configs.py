@@ -137,20 +137,20 @@ def test_config4_nested_mid_size(system):
 
 def test_config4_nested_full_rate_beyond_the_entry_table(system):
     """configs[3] at its full emission rates (100 000 sparks/s, 20 smoke per spark -> 3.9M live in steady state),
-    followed until the smoke type holds 2.9M particles: beyond FW_FC_DIRECT (2048) tiles the survivor forecast of the
-    child segment switches to the per-tile SUMS format while this frame's children are MATERIALISED new-particle tiles
-    (SPAWN_NONE) -- the kernel instantiation no smaller case reaches.  The whole state of both types is compared with
+    followed for 110 frames (2.4M smoke particles).  The child segment is sized for the steady state (> FW_FC_DIRECT =
+    2048 tiles), so its survivor forecast uses the per-tile SUMS format while this frame's children are MATERIALISED
+    new-particle tiles (SPAWN_NONE) -- the kernel instantiation no smaller case reaches.  The whole state of both types is compared with
     the oracle (counts, order, exact fields bit for bit, last_emitted_age), plus the size-independent properties."""
     spawner, tf = workloads.nested(spark_rate=100000.0, smoke_per_spark=20.0)
     pair = Pair(system, spawner, tf, seed=SEED, uid=2)
-    frames = 100
+    frames = 110
     for fr in range(frames):
         system.update(DT)
         pair.step_cpu(DT)
-        if fr in (69, 84):  # around the switch of formats (2.1M smoke at frame ~73)
+        if fr in (69, 84):
             assert pair.gpu.counts() == pair.cpu.counts(), fr
     c = pair.gpu.counts()
-    assert c[1] > 2_500_000 and c[0] > 150_000, c  # > 2048 tiles of 1024 in the child segment
+    assert c[1] > 2_300_000 and c[0] > 150_000, c  # > 2048 tiles of 1024 in the child segment
     pair.check(what="nested, full rate")
     assert np.array_equal(pair.gpu.last_emitted(0, 1), pair.cpu.last_emitted(0, 1))
     for t in (0, 1):

@@ -335,13 +335,15 @@ def test_collisions_against_the_oracle_with_nested_and_attached_instances(system
     trail = S.ParticleSettings(lifetime=S.RandF32(0.2, 0.5), acceleration=(0.0, 0.0, 0.0),
                                collision_settings=S.ParticleCollisionSettings(0.0, 0.0, destroy_on_collision=True))
     trail.particles_destroyed = lambda d: None
-    e0 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(3000.0),
-                            emission_shape=S.EmissionShape.Sphere(0.3),
-                            initial_velocity=S.RandVec3(S.RandF32(1.0, 9.0), (0.2, -1.0, 0.0), 0.6))
+    # no libm call anywhere (Point shape, zero spread; directions vary through three entries and a parent velocity that
+    # changes every frame): a bounce amplifies differences, so this test is bit-exact or nothing
+    dirs = [(0.2, -1.0, 0.0), (-0.6, -0.8, 0.3), (0.5, -0.2, -0.7)]
+    e0 = [S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(1000.0),
+                             initial_velocity=S.RandVec3(S.RandF32(1.0, 9.0), d, 0.0)) for d in dirs]
     e1 = S.EmissionSettings(particle_index=1, emission_mode=S.EmissionMode.Nested(0),
                             emission_pacing=S.EmissionPacing.CountOverDuration(12.0, 0.0, 0.0, 1.0),
-                            initial_velocity=S.RandVec3(S.RandF32(0.0, 2.0), (0.0, -1.0, 0.0), 1.0))
-    pair = parity.Pair(system, S.ParticleSpawner([bounce, trail], [e0, e1]), S.Transform((0.0, 2.5, 0.0)),
+                            initial_velocity=S.RandVec3(S.RandF32(0.0, 2.0), (0.0, -1.0, 0.0), 0.0))
+    pair = parity.Pair(system, S.ParticleSpawner([bounce, trail], e0 + [e1]), S.Transform((0.0, 2.5, 0.0)),
                        seed=scenarios.SEED, uid=31)
     plain = parity.Pair(system, S.ParticleSpawner([S.ParticleSettings(lifetime=S.RandF32(0.3, 0.9))],
                                                   [S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(20000.0))]),
@@ -357,21 +359,25 @@ def test_collisions_against_the_oracle_with_nested_and_attached_instances(system
         if fr == 60:
             system.set_colliders(world_b)
             pair.cpu.set_colliders(world_b)
+        pv = (float(np.float32(((fr * 37) % 23) / 11.0 - 1.0)), 0.0, float(np.float32(((fr * 17) % 13) / 6.0 - 1.0)))
+        pair.gpu.set_parent_velocity(pv)
+        pair.cpu.set_parent_velocity(pv)
         system.update(DT)
         pair.step_cpu(DT)
         plain.step_cpu(DT)
         if fr % 20 == 19:
-            pair.check(what=f"colliding spawner, frame {fr}")
+            pair.check(exact_all=True, what=f"colliding spawner, frame {fr}")
             plain.check(exact_all=True, what=f"neighbour, frame {fr}")
             for t in (0, 1):
                 gd, cd = pair.gpu.destroyed(t), pair.cpu.destroyed(t)
                 assert len(gd) == len(cd) and np.array_equal(gd["age"], cd["age"]) and np.array_equal(gd["scale"], cd["scale"])
-                if len(gd):
-                    assert parity.trig_field_errors(gd["position"], cd["position"])[0].all()
+                assert np.array_equal(gd["position"], cd["position"]) and np.array_equal(gd["velocity"], cd["velocity"])
             n = pair.gpu.count(0)
             rec = buf[: n * 16].cpu().numpy().view(S.INSTANCE_DTYPE).reshape(n)
             assert np.array_equal(rec["position"], pair.gpu.particles(0)["position"])
     c = pair.gpu.counts()
-    assert c[0] > 2000 and c[1] > 3000, c
-    # bounced particles really are above the ground plane, and some were slowed by it
-    assert (pair.gpu.particles(0)["position"][:, 1] > -1e-3).all()
+    assert c[0] > 2000 and c[1] > 1000, c
+    # the ground really acts (without it nearly everything would be far below y = 0 by now); a few particles do end up
+    # below it, as in the reference: a particle that starts a frame inside a solid is pushed along its velocity
+    # (core.rs:766-776), and `delta - hit.distance` mixes a time with a length (core.rs:786)
+    assert (pair.gpu.particles(0)["position"][:, 1] > -1e-3).mean() > 0.8
