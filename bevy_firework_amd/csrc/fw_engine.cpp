@@ -1513,6 +1513,12 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     a.seg0_keys_off = n_seg ? ctx->segs[0].keys_off : 0;
     a.seg0_keys_len = n_seg ? ctx->segs[0].keys_len : 0;
     a.tile_keys = ctx->d_tile_keys;
+    if (n_seg == 1 && ctx->segs[0].in_use) {
+        const SegHost &S0 = ctx->segs[0];
+        a.seg0_ib = S0.buf[p], a.seg0_ob = S0.buf[p ^ 1u];
+        a.seg0_destroyed = S0.destroyed, a.seg0_inst = S0.inst;
+        a.seg0_capacity = S0.capacity, a.seg0_n_lplanes = S0.n_lplanes, a.seg0_inst_cap = S0.inst_cap;
+    }
     if (ctx->live_ring) {
         a.live_out = ctx->live_ring + (ctx->live_ring_frames % ctx->live_ring_n);
         a.live_next = ctx->live_ring + ((ctx->live_ring_frames + 1) % ctx->live_ring_n);

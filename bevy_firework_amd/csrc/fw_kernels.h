@@ -64,6 +64,11 @@ struct FwUpdateArgs {
     uint32_t seg0_type;            // type index of segment 0 (used when n_seg == 1)
     uint32_t use_stream;           // forecast frames: run fw_k_update_stream 
     uint32_t seg0_keys_off, seg0_keys_len;  // key pool window of segment 0's type (n_seg == 1)
+    // n_seg == 1: the lone segment's record (FwSeg) for THIS frame's parity, so that a tile can address its input from
+    // the kernel arguments alone (fw_k_update_stream<.., LONE>); seg0_ib == null: not provided
+    const char *seg0_ib;
+    char *seg0_ob, *seg0_destroyed, *seg0_inst;
+    uint32_t seg0_capacity, seg0_n_lplanes, seg0_inst_cap;
     const uint2 *tile_keys;        // [n_seg] {keys_off, keys_len} of each segment's type (device)
     // optional per-frame total of live particles (feed of the RCCL all-reduce): every segment's finalizer adds its
     // new count to *live_out; workgroup 0 zeroes *live_next (the slot the next frame will use)

@@ -617,8 +617,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     // new-particle tile size: one round, or two when that is what keeps every active tile resident at once
     // (a.resident_slots workgroups).  The host can only bound the live count, so a lone segment decides from
     // the exact device count; with several segments the host's choice (from its bounds) is used.
-    uint32_t vt_rounds = a.vt_rounds;
-    if (a.n_seg == 1u) vt_rounds = (t_spawn + (n_spawn + BLK - 1u) / BLK <= a.resident_slots) ? 1u : 2u;
+    const uint32_t vt_rounds = a.vt_rounds;  // the host's choice (from its bounds), for every segment
     const uint32_t vtile = vt_rounds * BLK;
     const uint32_t n_vt = (n_spawn + vtile - 1u) / vtile;
     const uint32_t n_act = t_spawn + n_vt;                      // active tiles of this segment
@@ -954,8 +953,17 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
     }
 }
 
-template <int SPAWN, bool INST, bool SUMS>
+// LONE: the context holds a single segment (the 1M-particle headline case).  Everything a tile needs to ADDRESS its
+// input then comes with the kernel arguments (buffers, capacity: FwUpdateArgs::seg0_*) and the tile -> particle-range
+// mapping of a live tile does not depend on the live count (new-particle tiles are dispatched first and their number
+// follows from the spawn ops in the arguments), so round 0 of the four input planes is requested SPECULATIVELY right
+// after the arguments arrive -- in parallel with the counters, the forecast entries and the per-type constants
+// instead of one dependent memory round trip (~1 us at launch, when every workgroup asks at once) after them.  Lanes
+// past the live count read stale slots of the buffer and are masked; a tile whose role turns out different (a
+// new-particle tile of materialised children, a clamped spawn) reloads.
+template <int SPAWN, bool INST, bool SUMS, bool LONE>
 __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void fw_k_update_stream(FwGlobals g, FwUpdateArgs a, FwInlineOps inl) {
+    static_assert(!LONE || SPAWN != FW_SPAWN_TABLE, "a lone segment with a table of ops takes the general kernel");
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
     constexpr int LBW = 4;
@@ -968,7 +976,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned long long ts0 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t seg, first, seg_tiles, type_idx, keys_off, keys_len;
-    if (a.n_seg == 1u) {
+    if (LONE) {
         seg = 0, first = 0, seg_tiles = a.total_tiles, type_idx = a.seg0_type;
         keys_off = a.seg0_keys_off, keys_len = a.seg0_keys_len;
     } else {
@@ -987,6 +995,37 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     if (fc_small) fw_fce_request<BLK>(a.fce_in, first, seg_tiles, fce);
     // (fw_fc_housekeeping runs at the end: a store this early would sit in front of every load in the vmcnt queue)
     const uint32_t p = a.parity;
+    // the segment record: kernel arguments for a lone segment, memory otherwise
+    const FwSeg *Sp = &g.segs[seg];
+    const uint32_t seg_cap = LONE ? a.seg0_capacity : Sp->capacity;
+    const uint32_t C = seg_cap;
+    const uint32_t n_lplanes = LONE ? a.seg0_n_lplanes : Sp->n_lplanes;
+    const char *ib = LONE ? a.seg0_ib : Sp->buf[p];
+    char *ob = LONE ? a.seg0_ob : Sp->buf[p ^ 1u];
+    char *destroyed = LONE ? a.seg0_destroyed : Sp->destroyed;
+    char *inst = INST ? (LONE ? a.seg0_inst : Sp->inst) : nullptr;  // attached ParticleInstance output (or null)
+    const uint32_t inst_cap = INST ? (LONE ? a.seg0_inst_cap : Sp->inst_cap) : 0u;
+    const uint32_t vt_rounds = a.vt_rounds;  // new-particle tile size: the host's choice (from its bounds)
+    // ---- LONE: round 0 requested now, for the particle range this workgroup has if it is a live tile
+    float4 q0c, q1c, q2c, q3c;
+    uint32_t spec_base = 0xFFFFFFFFu;  // first particle of the speculative request (none: 0xFFFFFFFF)
+    if (LONE) {
+        uint32_t ks = 0;  // spawns of this frame, known from the arguments (every inline op belongs to the lone segment)
+        if (SPAWN == FW_SPAWN_INLINE)
+            for (uint32_t i = 0; i < a.n_ops; i++) ks += inl.ops[i].n;
+        const uint32_t kvt = SPAWN == FW_SPAWN_INLINE ? (ks + vt_rounds * BLK - 1u) / (vt_rounds * BLK) : 0u;
+        const bool kfront = SPAWN == FW_SPAWN_INLINE && kvt != 0u && kvt <= FW_VFRONT;  // new-particle tiles go first
+        const bool is_front = kfront && blockIdx.x < kvt;
+        const uint32_t sb = (blockIdx.x - (kfront && !is_front ? kvt : 0u)) * FW_TILE;
+        // (capacity and sb are multiples of FW_TILE: sb < C leaves room for a whole tile)
+        if (!is_front && sb < C) spec_base = sb;
+        const size_t sfirst = spec_base != 0xFFFFFFFFu ? (size_t)spec_base * 16u : (size_t)0;
+        const uint32_t i0 = tid * 16u;
+        q0c = fw_ld4w(ib + FW_OFF_Q0(C) + sfirst, i0);
+        q3c = fw_ld4w(ib + FW_OFF_Q3(C) + sfirst, i0);
+        q1c = fw_ld4w(ib + FW_OFF_Q1(C) + sfirst, i0);
+        q2c = fw_ld4w(ib + FW_OFF_Q2(C) + sfirst, i0);
+    }
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
     // SPAWN_NONE frames may have had this frame's new particles MATERIALISED behind the live ones (Global ops of a frame
     // with Nested entries by fw_k_spawn, Nested children by fw_k_nest_spawn): they form the new-particle tiles here
@@ -1005,8 +1044,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         o0 = a.seg_op_first[seg], o1 = a.seg_op_first[seg + 1];
         for (uint32_t i = o0; i < o1; i++) n_spawn += a.ops[i].n;
     }
-    const uint32_t seg_cap = g.segs[seg].capacity;  // virtual spawns beyond the capacity are dropped (and reported)
-    if (SPAWN != FW_SPAWN_NONE) {
+    if (SPAWN != FW_SPAWN_NONE) {  // virtual spawns beyond the capacity are dropped (and reported)
         const uint32_t spawn_room = seg_cap - min(n_in, seg_cap);
         if (n_spawn > spawn_room) {
             n_spawn = spawn_room;
@@ -1014,10 +1052,10 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         }
     }
     const uint32_t n_tot = n_in + n_spawn;
-    // tiling of [0, n_tot): identical to fw_k_update (live tiles of FW_TILE, then small new-particle tiles)
+    // tiling of [0, n_tot): identical to fw_k_update (live tiles of FW_TILE, then small new-particle tiles).  With
+    // front-loading (at most FW_VFRONT new-particle tiles) workgroup b < n_vt is new-particle tile b and workgroup
+    // b >= n_vt is live tile b - n_vt, whatever the live count is.
     const uint32_t t_spawn = (n_in + FW_TILE - 1u) / FW_TILE;
-    uint32_t vt_rounds = a.vt_rounds;
-    if (a.n_seg == 1u) vt_rounds = (t_spawn + (n_spawn + BLK - 1u) / BLK <= a.resident_slots) ? 1u : 2u;
     const uint32_t vtile = SPAWN == FW_SPAWN_NONE ? (uint32_t)FW_TILE : vt_rounds * BLK;  // materialised: full tiles
     const uint32_t n_vt = (n_spawn + vtile - 1u) / vtile;
     const uint32_t n_act = t_spawn + n_vt;
@@ -1052,17 +1090,9 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     }
     if (blockIdx.x == 0 && tid == 0 && a.live_next) *a.live_next = 0ull;
     if (blockIdx.x == 0 && tid == 0 && a.done_tag) *a.done_tag = a.done_value;
-    const FwSeg *Sp = &g.segs[seg];
-    const uint32_t C = seg_cap;
-    const uint32_t n_lplanes = Sp->n_lplanes;
-    const char *ib = Sp->buf[p];
-    char *ob = Sp->buf[p ^ 1u];
-    char *destroyed = Sp->destroyed;
-    char *inst = INST ? Sp->inst : nullptr;  // attached ParticleInstance output of this segment (or null)
-    const uint32_t inst_cap = INST ? Sp->inst_cap : 0u;
 
     const unsigned long long tsA = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (C & 0u)) : 0ull;
-    // round 0 of a live tile goes out now
+    // round 0 of a live tile goes out now (unless the speculative request above already covers it)
     // (Loads are issued UNCONDITIONALLY at an index clamped into the tile: a load under a lane predicate lives in
     // its own basic block, and the copy into the merged value at the end of that block makes the compiler wait for
     // it right there -- the "prefetch" would complete before anything else is issued.  A lane past the end simply
@@ -1073,8 +1103,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     const size_t ifirst = loaded_tile ? (size_t)base * 16u : (size_t)0;
     const char *iw0 = ib + FW_OFF_Q0(C) + ifirst, *iw1 = ib + FW_OFF_Q1(C) + ifirst;
     const char *iw2 = ib + FW_OFF_Q2(C) + ifirst, *iw3 = ib + FW_OFF_Q3(C) + ifirst;
-    float4 q0c, q1c, q2c, q3c;
-    {
+    if (!LONE || (loaded_tile && base != spec_base)) {  // LONE: only a tile whose role differs from the guess reloads
         const uint32_t i0 = loaded_tile ? min(tid, last - base) * 16u : 0u;
         q0c = fw_ld4w(iw0, i0);
         q3c = fw_ld4w(iw3, i0);
@@ -1119,6 +1148,12 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             }
             new_alive += (uint32_t)__popcll(__ballot(al));
         }
+    }
+    if (fc_small && (a.dbg & 16u)) {  // FW_DEBUG 16 (profiling): read the table a second time -- what does the read cost?
+        uint4 e2[FW_FCE_U];
+        fw_fce_request<BLK>(a.fce_out, first, seg_tiles, e2);
+#pragma unroll
+        for (int j = 0; j < FW_FCE_U; j++) asm volatile("" ::"v"(e2[j].x), "v"(e2[j].w));
     }
     fc_part = fw_wave_sum(fc_part);
     if (lane == 0) s_part[0][wave] = fc_part, s_part[1][wave] = new_alive;
@@ -1867,12 +1902,17 @@ static void fw_launch_update_r(hipStream_t s, const FwGlobals &g, const FwUpdate
         hipLaunchKernelGGL(fw_k_scan, dim3(a.n_seg), dim3(FW_BLOCK), 0, s, g, a);
         FW_LAUNCH_T((fw_k_update<false, FW_SPAWN_NONE, R, INST, SUMS>), grid, block, s, (hipEvent_t) nullptr, e1, g, a, io);
     } else if (a.use_stream && a.fc_in && a.fc_out) {  // forecast frame: streaming schedule
-        if (spawn_form == FW_SPAWN_INLINE)
-            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_INLINE, INST, SUMS>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
+        const bool lone = a.n_seg == 1u && a.seg0_ib != nullptr;  // a single segment: its record rides in the arguments
+        if (spawn_form == FW_SPAWN_INLINE && lone)
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_INLINE, INST, SUMS, true>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
+        else if (spawn_form == FW_SPAWN_INLINE)
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_INLINE, INST, SUMS, false>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
         else if (spawn_form == FW_SPAWN_TABLE)
-            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_TABLE, INST, SUMS>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_TABLE, INST, SUMS, false>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
+        else if (lone)
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_NONE, INST, SUMS, true>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
         else
-            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_NONE, INST, SUMS>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
+            FW_LAUNCH_T((fw_k_update_stream<FW_SPAWN_NONE, INST, SUMS, false>), grid, dim3(FW_BLOCK), s, e0, e1, g, a, io);
     } else if (spawn_form == FW_SPAWN_INLINE) {
         FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_INLINE, R, INST, SUMS>), grid, block, s, e0, e1, g, a, io);
     } else if (spawn_form == FW_SPAWN_TABLE) {
