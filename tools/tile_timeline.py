@@ -16,8 +16,9 @@ sp, tf = workloads.one_million()
 ps.spawn(sp, tf, uid=0)
 dt = np.float32(1 / 60)
 ps.update(dt)
-for _ in range(100):
-    ps.step(dt)
+jitter = os.environ.get("FW_TL_JITTER") == "1"  # a dt that changes every frame (the look-back / death-threshold schedule)
+for k in range(100):
+    ps.step(np.float32((1.0 / 60.0) * (1.0 + 0.1 * np.sin(0.7 * k))) if jitter else dt)
 ps.synchronize()
 lib = ps._lib
 lib.fw_debug_read_timestamps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
