@@ -31,6 +31,8 @@
 #define FW_ROUNDS 4           // particles per thread per tile
 #define FW_TILE (FW_BLOCK * FW_ROUNDS)
 #define FW_VTILE FW_BLOCK     // tile size of the new-particle region (fw_k_update)
+#define FW_NEST_TILE FW_BLOCK  // parents per workgroup of fw_k_nest: one per lane (spawning a child is ~2.5k instructions:
+                              // small tiles = several waves per SIMD to hide them; 1024-parent tiles ran one wave per SIMD)
 #define FW_VFRONT 256u        // at most this many new-particle tiles are dispatched first
 #define FW_KEYS_MAX 400       // floats of curve keys staged in LDS per type
 #define FW_DEV_MAX_EMISSIONS 8
@@ -130,6 +132,14 @@ struct alignas(16) FwNestOp {
     uint32_t n_tiles;     // parent tiles launched (upper bound)
     uint32_t emit_slot;   // index into the device serial counters
     float speed, scale;
+    // what a tile needs to ADDRESS its parents, so that their loads depend on the op record only (kernel arguments
+    // for short op lists) and go out together with the counter loads: the launch is latency-bound (a few hundred
+    // small workgroups), every dependent memory level costs ~1 us
+    char *parent_buf;        // parent segment buffer of this frame's parity
+    uint32_t parent_cap;     // its capacity (plane stride)
+    uint32_t parent_lplane;  // which last_emitted_age plane of the parent type belongs to this entry
+    float n_count, n_start, n_end;  // CountOverDuration of the entry (core.rs:474-481)
+    uint32_t pad0;
 };
 
 // decoupled look-back status word: {epoch:30 | state:2 | value:32}

@@ -217,6 +217,7 @@ struct fw_ctx {
     uint32_t snap_every = kSnapEvery;  // frames between live-count snapshots (FW_SNAP_EVERY)
     bool use_stream = true;    // FW_STREAM=0: forecast frames keep the count-park-store kernel (A/B)
 
+    uint32_t nest_seq = 0;  // launches of fw_k_nest so far (tag of their look-back words)
     uint64_t frame = 0;
     double sim_time = 0.0;  // sum of the dt of every step so far (lifetime windows)
     uint32_t parity = 0;
@@ -352,7 +353,7 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         if (!sp.alive) continue;
         for (auto &e : sp.em)
             if (e.es.mode == FW_MODE_NESTED) {
-                nest_tiles += (ctx->segs[sp.seg[e.es.target_particle_type]].capacity + FW_TILE - 1) / FW_TILE + 1;
+                nest_tiles += (ctx->segs[sp.seg[e.es.target_particle_type]].capacity + FW_NEST_TILE - 1) / FW_NEST_TILE + 1;
                 nest_ops++;
             }
     }
@@ -383,22 +384,18 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         fw_status st = sync(ctx);
         if (st) return st;
         size_t ncap = nest_tiles * 2;
-        if (ctx->g.nest_tile_cnt) hipFree(ctx->g.nest_tile_cnt), hipFree(ctx->g.nest_tile_off);
-        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_tile_cnt, ncap * sizeof(uint32_t)));
-        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_tile_off, ncap * sizeof(uint32_t)));
+        if (ctx->g.nest_status) hipFree(ctx->g.nest_status);
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_status, ncap * sizeof(unsigned long long)));
+        FW_HIP(ctx, hipMemset(ctx->g.nest_status, 0, ncap * sizeof(unsigned long long)));
         ctx->nest_tiles_cap = ncap;
     }
     if (nest_ops > ctx->nest_ops_cap) {
         fw_status st = sync(ctx);
         if (st) return st;
         size_t ncap = nest_ops * 2 + 16;
-        if (ctx->g.nest_op_npar)
-            hipFree(ctx->g.nest_op_npar), hipFree(ctx->g.nest_op_base), hipFree(ctx->g.nest_op_total),
-                hipFree(ctx->g.nest_op_serial);
-        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_op_npar, ncap * sizeof(uint32_t)));
-        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_op_base, ncap * sizeof(uint32_t)));
-        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_op_total, ncap * sizeof(uint32_t)));
-        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_op_serial, ncap * sizeof(unsigned long long)));
+        if (ctx->g.nest_ticket) hipFree(ctx->g.nest_ticket);
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_ticket, ncap * sizeof(unsigned long long)));
+        FW_HIP(ctx, hipMemset(ctx->g.nest_ticket, 0, ncap * sizeof(unsigned long long)));
         ctx->nest_ops_cap = ncap;
     }
     return FW_OK;
@@ -1128,8 +1125,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     void *frees[] = {ctx->d_type_coll.d, ctx->d_segs.d,       ctx->d_types.d,       ctx->d_keys.d,        ctx->d_emits.d,
                      ctx->d_emit_serial.d, ctx->g.count,        ctx->g.spawned,       ctx->g.appended,
                      ctx->g.ndestroyed,   ctx->g.tile_cnt,      ctx->g.tile_off,      ctx->g.tile_status,
-                     ctx->g.err,          ctx->g.stats,         ctx->g.nest_tile_cnt, ctx->g.nest_tile_off,
-                     ctx->g.nest_op_npar, ctx->g.nest_op_base,  ctx->g.nest_op_total, ctx->g.nest_op_serial,
+                     ctx->g.err,          ctx->g.stats,         ctx->g.nest_status,   ctx->g.nest_ticket,
                      ctx->d_aabb,         ctx->d_total,         ctx->d_segids,        ctx->g.dbg_ts,
                      ctx->d_colliders};
     for (void *p : frees)
@@ -1450,8 +1446,16 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 FwNestOp op{};
                 op.parent_seg = sp.seg[es.target_particle_type], op.child_seg = dst;
                 op.emit = E.emit_idx, op.emit_slot = E.emit_slot;
-                op.n_tiles = seg_tiles(P);
+                {  // parent tiles of the launch: from the host's bound of the parent count (exact counts live on the device)
+                    const uint32_t par_ub = P.nested_fed ? P.capacity : std::min(P.ub, P.capacity);
+                    op.n_tiles = (par_ub + FW_NEST_TILE - 1) / FW_NEST_TILE + 1;
+                }
                 op.speed = sp.mod_speed, op.scale = sp.mod_scale;
+                // (parent_buf / parent_cap are filled in when the launch is built: a later entry of this frame may
+                // still grow the parent segment)
+                for (uint32_t k = 0; k < P.n_lplanes; k++)
+                    if (P.lplane_emission[k] == (int32_t)i) op.parent_lplane = k;
+                op.n_count = es.count, op.n_start = es.offset_start, op.n_end = es.offset_end;
                 levels[i].n.push_back(op);
             }
         }
@@ -1614,26 +1618,38 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 for (FwNestOp op : L.n) {
                     op.first_tile = tiles;
                     tiles += op.n_tiles;
+                    op.parent_buf = ctx->segs[op.parent_seg].buf[p];
+                    op.parent_cap = ctx->segs[op.parent_seg].capacity;
                     h_nops[ni++] = op;
                 }
                 launches.push_back(Launch{true, first, ni - first, tiles});
             }
         }
         flush_global();
-        if (!launches.empty()) {
+        // launches with at most FW_INLINE_OPS ops carry them in their kernel arguments; only longer lists (many
+        // spawners with Nested entries) are staged through the copy stream
+        bool staged = false;
+        for (const Launch &L : launches) staged |= L.count > FW_INLINE_OPS;
+        if (staged) {
             FW_HIP(ctx, hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
             FW_HIP(ctx, hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
             FW_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
         }
         for (const Launch &L : launches) {
-            if (!L.nested)
-                FW_HIP(ctx, fw_launch_spawn(ctx->stream, ctx->g, (const FwOp *)dp + L.first, (uint32_t)L.count,
-                                            L.blocks, p));
-            else
-                FW_HIP(ctx, fw_launch_nested(ctx->stream, ctx->g, (const FwNestOp *)(dp + off_nops) + L.first,
-                                             (uint32_t)L.count, L.blocks, p));
+            const bool inl_ops = L.count <= FW_INLINE_OPS;
+            if (!L.nested) {
+                FW_HIP(ctx, fw_launch_spawn(ctx->stream, ctx->g, inl_ops ? nullptr : (const FwOp *)dp + L.first,
+                                            h_ops + L.first, (uint32_t)L.count, L.blocks, p));
+            } else {
+                ctx->nest_seq = (ctx->nest_seq + 1u) & 0x3FFFFFFFu;
+                if (!ctx->nest_seq) ctx->nest_seq = 1u;
+                FW_HIP(ctx, fw_launch_nested(ctx->stream, ctx->g,
+                                             inl_ops ? nullptr : (const FwNestOp *)(dp + off_nops) + L.first,
+                                             h_nops + L.first, (uint32_t)L.count, L.blocks, p, ctx->nest_seq,
+                                             ctx->spin_limit, ctx->dbg));
+            }
         }
-        if (launches.empty()) slot = -1;
+        if (!staged) slot = -1;  // nothing in the ring slot is read by the device: no consumed-event needed
     } else {
         // Global-only frame: spawn is fused into the update kernel (virtual particles).  Ops sorted by segment;
         // the order inside a segment stays the emission order (rel_base was assigned in that order).

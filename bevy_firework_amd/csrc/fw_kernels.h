@@ -26,12 +26,8 @@ struct FwGlobals {
     unsigned long long *stats;       // [0] particles that entered update (running total)
     unsigned long long *dbg_ts;      // FW_DEBUG & 8: 4 timestamps per tile of the last update (profiling)
     unsigned long long *emit_serial; // RNG serials of Nested emission entries
-    uint32_t *nest_tile_cnt;         // children per parent tile
-    uint32_t *nest_tile_off;         // exclusive prefix of the above, per op
-    uint32_t *nest_op_npar;          // [n_ops] parents visible to the op (bound fixed once, core.rs:488)
-    uint32_t *nest_op_base;          // [n_ops] first child slot in the child segment
-    uint32_t *nest_op_total;         // [n_ops] children spawned (after clamping)
-    unsigned long long *nest_op_serial;  // [n_ops] RNG serial of the first child
+    unsigned long long *nest_status; // [nested tiles] look-back words of fw_k_nest, tagged with the launch's sequence number
+    unsigned long long *nest_ticket; // [n_ops] {workgroups of the op that have finished, children of the op}: the last one commits, then zeroes
     const FwCollider *colliders;         // the world particle_collision casts its rays into (fw_ctx_set_colliders)
     uint32_t n_colliders;
 };
@@ -101,12 +97,13 @@ enum { FW_SPAWN_NONE = 0, FW_SPAWN_INLINE = 1, FW_SPAWN_TABLE = 2 };
 
 enum { FW_MODE_FUSED = 0, FW_MODE_SPLIT = 1, FW_MODE_SPLIT_COLL = 2 };  // SPLIT_COLL: frames with colliding particle types
 
-hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *ops, uint32_t n_ops, uint32_t total_blocks,
-                           uint32_t parity);
+// d_ops: device table, or null -> the (at most FW_INLINE_OPS) ops at h_ops travel in the kernel arguments
+hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *d_ops, const FwOp *h_ops, uint32_t n_ops,
+                           uint32_t total_blocks, uint32_t parity);
 hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps *inl,
                             int spawn_form, int mode, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *ops, uint32_t n_ops,
-                            uint32_t total_tiles, uint32_t parity);
+hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d_ops, const FwNestOp *h_ops, uint32_t n_ops,
+                            uint32_t total_tiles, uint32_t parity, uint32_t tag, uint32_t spin_limit, uint32_t dbg = 0);
 // SoA -> AoS gather of `n` particles of one segment buffer into fw_particle records (device)
 hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t n, int32_t pbr, void *d_out);
 hipError_t fw_launch_scatter(hipStream_t s, char *buf, uint32_t capacity, uint32_t n, uint32_t n_lplanes,

@@ -218,16 +218,23 @@ __device__ __forceinline__ void fw_store_new(const FwGlobals &g, const FwSeg &S,
 
 // Global emission: ops[] lists this frame's (segment, entry, count) triples; op i owns
 // workgroups [first_block_i, first_block_{i+1}).
-__global__ __launch_bounds__(FW_BLOCK) void fw_k_spawn(FwGlobals g, const FwOp *ops, uint32_t n_ops, uint32_t parity) {
+// (`ops` = device table, or null: the ops ride in the kernel arguments -- no staging copy, no event in the stream)
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_spawn(FwGlobals g, FwInlineOps inl, const FwOp *ops, uint32_t n_ops,
+                                                      uint32_t parity) {
     uint32_t lo = 0, hi = n_ops;  // op lookup (block-uniform)
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (ops[mid].first_block <= blockIdx.x)
-            lo = mid;
-        else
-            hi = mid;
+    if (ops) {
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (ops[mid].first_block <= blockIdx.x)
+                lo = mid;
+            else
+                hi = mid;
+        }
+    } else {
+        for (uint32_t i = 1; i < n_ops; i++)
+            if (inl.ops[i].first_block <= blockIdx.x) lo = i;
     }
-    const FwOp &op = ops[lo];
+    const FwOp &op = ops ? ops[lo] : inl.ops[lo];
     const uint32_t k = (blockIdx.x - op.first_block) * FW_BLOCK + threadIdx.x;
     const uint32_t sidx = parity * g.max_seg + op.seg;
     const FwSeg &S = g.segs[op.seg];
@@ -1520,154 +1527,187 @@ __device__ __forceinline__ uint32_t fw_find_nest_op(const FwNestOp *ops, uint32_
     return lo;
 }
 
-// pass 1: children per parent tile (reads age, lifetime, last_emitted_age: 12 B / parent)
-__global__ __launch_bounds__(FW_BLOCK) void fw_k_nest_count(FwGlobals g, const FwNestOp *ops, uint32_t n_ops,
-                                                            uint32_t parity) {
-    __shared__ uint32_t s_c[4];
-    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
-    const uint32_t oi = fw_find_nest_op(ops, n_ops, tile);
-    const FwNestOp &op = ops[oi];
-    const uint32_t sidx = parity * g.max_seg + op.parent_seg;
-    const uint32_t n_par = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];  // bound fixed once (core.rs:488)
-    const uint32_t base = (tile - op.first_tile) * FW_TILE;
-    if (tile == op.first_tile && tid == 0) g.nest_op_npar[oi] = n_par;  // pass 3 must not see this op's own children
-    const FwSeg &P = g.segs[op.parent_seg];
-    const FwEmit &e = g.emits[op.emit];
-    const char *ib = P.buf[parity];
-    const uint32_t C = P.capacity;
-    unsigned long long c = 0;
-    for (int r = 0; r < FW_ROUNDS; r++) {
-        const uint32_t idx = base + r * FW_BLOCK + tid;
-        if (idx < n_par) {
-            float next;
-            const float age = fw_ld4(ib + FW_OFF_Q0(C), idx).w, life = fw_ld4(ib + FW_OFF_Q3(C), idx).w;
-            const float lea = reinterpret_cast<const float *>(ib + FW_OFF_L(C, e.n_lplane))[idx];
-            c += fw_nest_children(e, age, lea, life, &next);
-        }
-    }
-    uint32_t c32 = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
-    // saturating block sum
-    unsigned long long s = c32;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((tid & 63u) == 0) s_c[tid >> 6] = s > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)s;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long t = (unsigned long long)s_c[0] + s_c[1] + s_c[2] + s_c[3];
-        g.nest_tile_cnt[tile] = t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
-    }
-}
+// Nested emission in ONE launch per emission level (was: count, scan, spawn = three latency-bound launches).
+// A workgroup owns a tile of FW_NEST_TILE parents of one op:
+//   1. per parent: compute_emission_count from (age, last_emitted_age, lifetime) -- device fp32, IEEE divide, fmodf,
+//      truncf, contraction off: bit-exact -- and store the advanced last_emitted_age (core.rs:490-500);
+//   2. the tile's child total is published and the exclusive prefix over the earlier tiles of the op comes from a
+//      decoupled look-back (status words tagged with the launch's sequence number: no memset between launches).  The
+//      launch runs alone in the stream, a few hundred tiles at most, so the hop costs ~1 us here, not the ~3 us it
+//      costs under a streaming update;
+//   3. children are written WAVE-COOPERATIVELY: a wave's parents of one round have their counts prefix-summed; lane l
+//      of the wave then takes child c = 64 m + l of the wave (binary search of c in the prefix finds its parent, whose
+//      pose sits in LDS), so consecutive lanes write consecutive child slots -- seven coalesced plane stores per 64
+//      children instead of one lane walking through up to `count` children with scattered stores.  Child order stays
+//      parent-major (core.rs:488-544): slot = base + prefix(parent) + k.
+//   4. the LAST workgroup to finish (a ticket per op) adds the op's total to the child segment's `appended` count and
+//      to the entry's RNG serial: nobody can still be reading the counters that fix the parent bound (core.rs:488).
+struct FwNestInline {
+    FwNestOp ops[FW_INLINE_OPS];
+};
 
-// pass 2: one workgroup per op: scan the parent tiles, reserve child slots + RNG serials
-__global__ __launch_bounds__(FW_BLOCK) void fw_k_nest_scan(FwGlobals g, const FwNestOp *ops, uint32_t n_ops,
-                                                           uint32_t parity) {
-    __shared__ unsigned long long s_w[4];
-    __shared__ unsigned long long s_run;
-    const uint32_t oi = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const FwNestOp &op = ops[oi];
-    if (tid == 0) s_run = 0;
-    __syncthreads();
-    for (uint32_t t0 = 0; t0 < op.n_tiles; t0 += FW_BLOCK) {
-        const uint32_t t = t0 + tid;
-        const unsigned long long v = t < op.n_tiles ? g.nest_tile_cnt[op.first_tile + t] : 0ull;
-        unsigned long long inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long u = __shfl_up(inc, o, 64);
-            if (lane >= (uint32_t)o) inc += u;
-        }
-        if (lane == 63) s_w[wave] = inc;
-        __syncthreads();
-        unsigned long long woff = 0;
-        for (uint32_t w = 0; w < wave; w++) woff += s_w[w];
-        const unsigned long long run = s_run;
-        const unsigned long long ex = run + woff + inc - v;
-        if (t < op.n_tiles) g.nest_tile_off[op.first_tile + t] = ex > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ex;
-        __syncthreads();
-        if (tid == FW_BLOCK - 1) s_run = run + woff + inc;
-        __syncthreads();
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline inl, const FwNestOp *ops, uint32_t n_ops,
+                                                     uint32_t parity, uint32_t tag, uint32_t spin_limit, uint32_t dbg) {
+    constexpr int NW = FW_BLOCK / 64;
+    constexpr int LBW = 4;
+    constexpr int NR = FW_NEST_TILE / FW_BLOCK;  // rounds per tile
+    __shared__ uint32_t s_w[NR][NW];
+    __shared__ uint32_t s_lb[2 * LBW * NW];
+    __shared__ uint32_t s_inc[NW][64];
+    __shared__ __attribute__((aligned(16))) float4 s_par[NW][3][64];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t oi = 0;
+    FwNestOp op = inl.ops[0];
+    if (ops) {
+        oi = fw_find_nest_op(ops, n_ops, tile);
+        op = ops[oi];
+    } else {
+#pragma unroll  // constant indices: the record stays in scalar registers (a dynamic index would go through scratch)
+        for (uint32_t i = 1; i < FW_INLINE_OPS; i++)
+            if (i < n_ops && inl.ops[i].first_tile <= tile) oi = i, op = inl.ops[i];
     }
-    if (tid == 0) {
-        const unsigned long long total = s_run;
-        const uint32_t cidx = parity * g.max_seg + op.child_seg;
-        const uint32_t cap = g.segs[op.child_seg].capacity;
-        const uint32_t cbase = g.count[cidx] + g.spawned[cidx] + g.appended[cidx];
-        const unsigned long long room = cbase < cap ? (unsigned long long)(cap - cbase) : 0ull;
+    // the parents' counting inputs: requested now, at an index clamped into the buffer, together with the counters below
+    const uint32_t pbase = (tile - op.first_tile) * FW_NEST_TILE;
+    float p_age[FW_NEST_TILE / FW_BLOCK], p_life[FW_NEST_TILE / FW_BLOCK], p_lea[FW_NEST_TILE / FW_BLOCK];
+#pragma unroll
+    for (int r = 0; r < FW_NEST_TILE / FW_BLOCK; r++) {
+        const uint32_t ci = min(pbase + r * FW_BLOCK + tid, op.parent_cap - 1u);
+        p_age[r] = fw_ld4(op.parent_buf + FW_OFF_Q0(op.parent_cap), ci).w;
+        p_life[r] = fw_ld4(op.parent_buf + FW_OFF_Q3(op.parent_cap), ci).w;
+        p_lea[r] = fw_ld1(op.parent_buf + FW_OFF_L(op.parent_cap, op.parent_lplane), ci);
+    }
+    const uint32_t sidx = parity * g.max_seg + op.parent_seg, cidx = parity * g.max_seg + op.child_seg;
+    const uint32_t n_par = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];  // bound fixed once (core.rs:488)
+    const uint32_t cbase = g.count[cidx] + g.spawned[cidx] + g.appended[cidx];  // first child slot of the op
+    const unsigned long long serial0 = g.emit_serial[op.emit_slot];
+    const uint32_t base = (tile - op.first_tile) * FW_NEST_TILE;
+    const FwSeg &Cs = g.segs[op.child_seg];
+    const uint32_t ccap = Cs.capacity;
+    uint32_t op_total = 0;  // non-zero only in the op's last active tile
+    if (base < n_par) {
+        const FwEmit &e = g.emits[op.emit];
+        char *pb = op.parent_buf;
+        const uint32_t PC = op.parent_cap;
+        uint32_t n[NR], inc[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const uint32_t idx = base + r * FW_BLOCK + tid;
+            n[r] = 0;
+            if (idx < n_par) {
+                float next;
+                const uint64_t cnt = fw_emission_count(p_age[r], p_lea[r], p_life[r], op.n_start, op.n_end, op.n_count, &next);
+                n[r] = cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cnt;  // core.rs:490-498
+                fw_st1(pb + FW_OFF_L(PC, op.parent_lplane), idx, next);  // other_particle.last_emitted_age[i] = next (core.rs:500)
+            }
+            uint32_t x = n[r];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(x, o, 64);
+                if (lane >= (uint32_t)o) x = (x + u < x) ? 0xFFFFFFFFu : x + u;  // saturating
+            }
+            inc[r] = x;
+            if (lane == 63) s_w[r][wave] = x;
+        }
+        __syncthreads();
+        unsigned long long tot64 = 0;
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+#pragma unroll
+            for (int w = 0; w < NW; w++) tot64 += s_w[r][w];
+        const uint32_t tile_total = tot64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot64;
+        // ---- exclusive prefix over the earlier parent tiles of this op
+        const bool lb_needed = tile > op.first_tile;
+        if (lb_needed && tid == 0)
+            __hip_atomic_store(&g.nest_status[tile], fw_pack_status(tag, FW_ST_AGG, tile_total), RLX, AGENT);
+        uint32_t excl = 0;
+        if (lb_needed && !(dbg & 64u)) {  // (FW_DEBUG 64: profiling only, no look-back)
+            bool timed_out = false;
+            excl = fw_lookback<FW_BLOCK, NW, LBW>(g.nest_status, op.first_tile, tile, tag, spin_limit * 64u + 1024u, s_lb,
+                                                   &timed_out);
+            // (no recount is possible here: the earlier tiles have already advanced their parents' last_emitted_age.
+            // Workgroups are dispatched in index order, so every predecessor is resident or done: the wait is bounded.)
+            if (timed_out && tid == 0) atomicOr(g.err, FW_ERR_FORECAST);
+        }
+        const unsigned long long incl64 = (unsigned long long)excl + tile_total;
+        const uint32_t incl = incl64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)incl64;
+        if (tid == 0) __hip_atomic_store(&g.nest_status[tile], fw_pack_status(tag, FW_ST_INCL, incl), RLX, AGENT);
+        if (base + FW_NEST_TILE >= n_par) op_total = incl;  // the op's last active tile knows the total
+        // ---- children, wave-cooperatively (parent-major order)
+        uint32_t run = excl;  // children of the tile before (round r, wave 0)
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            uint32_t woff = run;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                if ((uint32_t)w < wave) woff += s_w[r][w];
+                run += s_w[r][w];
+            }
+            const uint32_t tw = (dbg & 32u) ? 0u : s_w[r][wave];  // wave-uniform (FW_DEBUG 32: profiling only, no children)
+            if (tw == 0) continue;
+            const uint32_t idx = base + r * FW_BLOCK + tid;
+            s_inc[wave][lane] = inc[r];
+            if (n[r] != 0) {
+                s_par[wave][0][lane] = fw_ld4(pb + FW_OFF_Q0(PC), idx);
+                s_par[wave][1][lane] = fw_ld4(pb + FW_OFF_Q1(PC), idx);
+                s_par[wave][2][lane] = fw_ld4(pb + FW_OFF_Q2(PC), idx);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t c0 = 0; c0 < tw; c0 += 64u) {
+                const uint32_t c = c0 + lane;
+                if (c < tw) {
+                    uint32_t lo = 0, hi = 63;  // first lane whose inclusive prefix exceeds c
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_inc[wave][mid] > c) hi = mid;
+                        else lo = mid + 1;
+                    }
+                    const unsigned long long j = (unsigned long long)woff + c;  // child index within the op
+                    const unsigned long long slot = (unsigned long long)cbase + j;
+                    if (slot < ccap) {
+                        const float4 pq0 = s_par[wave][0][lo], pq1 = s_par[wave][1][lo], pq2 = s_par[wave][2][lo];
+                        FwSpawnOut o = fw_spawn_one(e, g.seed, serial0 + j, fw_v3{pq0.x, pq0.y, pq0.z},
+                                                    fw_q4{pq2.x, pq2.y, pq2.z, pq2.w}, fw_v3{pq1.x, pq1.y, pq1.z}, op.speed,
+                                                    op.scale);
+                        fw_store_new(g, Cs, Cs.buf[parity], (uint32_t)slot, o);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the wave's LDS rows are reused by the next round
+        }
+    }
+    // ---- commit the op's totals (children appended to the child segment, RNG serial of the entry).
+    // Normally by the op's last ACTIVE tile: once its look-back is done every earlier tile has started, i.e. has read
+    // the counters that fix its parent bound and child base, and the later tiles hold no parents and read nothing that
+    // changes.  Only when particles emit onto their OWN type (parent segment == child segment) would a late workgroup
+    // see the new children as parents: such ops commit through a ticket instead -- the last workgroup to FINISH does it.
+    // The ticket word carries the total ({finished workgroups : 32 | children : 32}, one relaxed 64-bit atomic each): no
+    // fence (a device-scope release writes back the XCD's whole L2; 800 of them cost 10 us), nothing to order.  (All
+    // workgroups hitting one word serialise at the memory side -- 10 ns each -- which is why this is not the normal path.)
+    const bool self_nested = op.parent_seg == op.child_seg;
+    auto commit = [&](unsigned long long total) {
+        const unsigned long long room = cbase < ccap ? (unsigned long long)(ccap - cbase) : 0ull;
         unsigned long long take = total;
         if (take > room) {
             take = room;
             atomicOr(g.err, FW_ERR_CAPACITY);
         }
-        g.nest_op_base[oi] = cbase;
-        g.nest_op_total[oi] = (uint32_t)take;
-        g.nest_op_serial[oi] = g.emit_serial[op.emit_slot];
-        g.emit_serial[op.emit_slot] += total;
+        g.emit_serial[op.emit_slot] = serial0 + total;
         g.appended[cidx] += (uint32_t)take;
-    }
-}
-
-// pass 3: per parent, recompute the count, advance last_emitted_age, write the children
-// (parent-major, emission-minor order: core.rs:488-544)
-__global__ __launch_bounds__(FW_BLOCK) void fw_k_nest_spawn(FwGlobals g, const FwNestOp *ops, uint32_t n_ops,
-                                                            uint32_t parity) {
-    __shared__ uint32_t s_w[FW_ROUNDS][4];
-    const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t oi = fw_find_nest_op(ops, n_ops, tile);
-    const FwNestOp &op = ops[oi];
-    const uint32_t n_par = g.nest_op_npar[oi];
-    const uint32_t base = (tile - op.first_tile) * FW_TILE;
-    if (base >= n_par) return;
-    const FwSeg &P = g.segs[op.parent_seg];
-    const FwSeg &Cs = g.segs[op.child_seg];
-    const FwEmit &e = g.emits[op.emit];
-    char *pb = P.buf[parity];
-    const uint32_t PC = P.capacity;
-    uint32_t n[FW_ROUNDS], inc[FW_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < FW_ROUNDS; r++) {
-        const uint32_t idx = base + r * FW_BLOCK + tid;
-        n[r] = 0;
-        if (idx < n_par) {
-            float next;
-            const float age = fw_ld4(pb + FW_OFF_Q0(PC), idx).w, life = fw_ld4(pb + FW_OFF_Q3(PC), idx).w;
-            float *lp = reinterpret_cast<float *>(pb + FW_OFF_L(PC, e.n_lplane)) + idx;
-            n[r] = fw_nest_children(e, age, *lp, life, &next);
-            *lp = next;  // other_particle.last_emitted_age[i] = next (core.rs:500)
-        }
-        uint32_t x = n[r];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t u = __shfl_up(x, o, 64);
-            if (lane >= (uint32_t)o) x += u;
-        }
-        inc[r] = x;
-        if (lane == 63) s_w[r][wave] = x;
-    }
-    __syncthreads();
-    const uint32_t tile_off = g.nest_tile_off[tile];
-    const uint32_t total = g.nest_op_total[oi], cbase = g.nest_op_base[oi];
-    const unsigned long long serial0 = g.nest_op_serial[oi];
-    uint32_t run = 0;
-#pragma unroll
-    for (int r = 0; r < FW_ROUNDS; r++) {
-        uint32_t my = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            if ((uint32_t)w == wave) my = run;
-            run += s_w[r][w];
-        }
-        if (n[r] == 0) continue;
-        const uint32_t idx = base + r * FW_BLOCK + tid;
-        const uint32_t j0 = tile_off + my + inc[r] - n[r];
-        const float4 pq0 = fw_ld4(pb + FW_OFF_Q0(PC), idx), pq1 = fw_ld4(pb + FW_OFF_Q1(PC), idx),
-                     pq2 = fw_ld4(pb + FW_OFF_Q2(PC), idx);
-        for (uint32_t k = 0; k < n[r]; k++) {
-            const uint32_t j = j0 + k;
-            if (j >= total) break;
-            FwSpawnOut o = fw_spawn_one(e, g.seed, serial0 + j, fw_v3{pq0.x, pq0.y, pq0.z},
-                                        fw_q4{pq2.x, pq2.y, pq2.z, pq2.w}, fw_v3{pq1.x, pq1.y, pq1.z}, op.speed,
-                                        op.scale);
-            fw_store_new(g, Cs, Cs.buf[parity], cbase + j, o);
+    };
+    if (!self_nested) {
+        if (tid == 0 && base < n_par && base + FW_NEST_TILE >= n_par) commit(op_total);
+    } else {
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long mine = (1ull << 32) | (unsigned long long)op_total;
+            const unsigned long long seen = __hip_atomic_fetch_add(&g.nest_ticket[oi], mine, RLX, AGENT) + mine;
+            if ((uint32_t)(seen >> 32) == op.n_tiles) {
+                commit((uint32_t)seen);
+                __hip_atomic_store(&g.nest_ticket[oi], 0ull, RLX, AGENT);  // ready for the next launch
+            }
         }
     }
 }
@@ -1872,10 +1912,13 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_copy(const float4 *src, float4 
 // launch wrappers
 // ---------------------------------------------------------------------------------
 
-hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *ops, uint32_t n_ops, uint32_t total_blocks,
-                           uint32_t parity) {
+hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *d_ops, const FwOp *h_ops, uint32_t n_ops,
+                           uint32_t total_blocks, uint32_t parity) {
     if (!n_ops || !total_blocks) return hipSuccess;
-    hipLaunchKernelGGL(fw_k_spawn, dim3(total_blocks), dim3(FW_BLOCK), 0, s, g, ops, n_ops, parity);
+    static FwInlineOps io;  // (calls on a context are serialised by the caller; the launch copies its arguments)
+    if (!d_ops)
+        for (uint32_t i = 0; i < n_ops && i < FW_INLINE_OPS; i++) io.ops[i] = h_ops[i];
+    hipLaunchKernelGGL(fw_k_spawn, dim3(total_blocks), dim3(FW_BLOCK), 0, s, g, io, d_ops, n_ops, parity);
     return hipGetLastError();
 }
 
@@ -1947,12 +1990,13 @@ hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArg
     return hipGetLastError();
 }
 
-hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *ops, uint32_t n_ops,
-                            uint32_t total_tiles, uint32_t parity) {
+hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d_ops, const FwNestOp *h_ops, uint32_t n_ops,
+                            uint32_t total_tiles, uint32_t parity, uint32_t tag, uint32_t spin_limit, uint32_t dbg) {
     if (!n_ops || !total_tiles) return hipSuccess;
-    hipLaunchKernelGGL(fw_k_nest_count, dim3(total_tiles), dim3(FW_BLOCK), 0, s, g, ops, n_ops, parity);
-    hipLaunchKernelGGL(fw_k_nest_scan, dim3(n_ops), dim3(FW_BLOCK), 0, s, g, ops, n_ops, parity);
-    hipLaunchKernelGGL(fw_k_nest_spawn, dim3(total_tiles), dim3(FW_BLOCK), 0, s, g, ops, n_ops, parity);
+    static FwNestInline io;
+    if (!d_ops)
+        for (uint32_t i = 0; i < n_ops && i < FW_INLINE_OPS; i++) io.ops[i] = h_ops[i];
+    hipLaunchKernelGGL(fw_k_nest, dim3(total_tiles), dim3(FW_BLOCK), 0, s, g, io, d_ops, n_ops, parity, tag, spin_limit, dbg);
     return hipGetLastError();
 }
 

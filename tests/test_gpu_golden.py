@@ -381,3 +381,25 @@ def test_collisions_against_the_oracle_with_nested_and_attached_instances(system
     # below it, as in the reference: a particle that starts a frame inside a solid is pushed along its velocity
     # (core.rs:766-776), and `delta - hit.distance` mixes a time with a length (core.rs:786)
     assert (pair.gpu.particles(0)["position"][:, 1] > -1e-3).mean() > 0.8
+
+
+def test_particles_that_emit_onto_their_own_type(system):
+    """Nested { target_particle_type } == particle_index: the parent bound `0..particles[t].len()` is fixed when the
+    entry starts (core.rs:488), the children are appended behind it and become parents only in the NEXT frame.  On the
+    device such an op commits its totals through the ticket path of fw_k_nest (a late workgroup must not see this
+    frame's children as parents); several parent tiles, counts and state against the oracle, last_emitted_age too."""
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.3, 0.6), linear_drag=0.4)
+    seedling = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(2500.0),
+                                  initial_velocity=S.RandVec3(S.RandF32(0.5, 3.0), (0.0, 1.0, 0.0), 0.0))
+    budding = S.EmissionSettings(particle_index=0, emission_mode=S.EmissionMode.Nested(0),
+                                 emission_pacing=S.EmissionPacing.CountOverDuration(1.6, 0.0, 0.3, 0.95),
+                                 initial_velocity=S.RandVec3(S.RandF32(0.2, 1.0), (1.0, 0.0, 0.0), 0.0),
+                                 inherit_parent_velocity=True)
+    pair = parity.Pair(system, S.ParticleSpawner([ps], [seedling, budding]), seed=scenarios.SEED, uid=41)
+    for fr in range(150):
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr % 15 == 14:
+            pair.check(exact_all=True, what=f"self-nested frame {fr}")
+            assert np.array_equal(pair.gpu.last_emitted(0, 1), pair.cpu.last_emitted(0, 1))
+    assert pair.gpu.count(0) > 3000  # well beyond what the Global entry alone sustains (2500/s x 0.45 s)
