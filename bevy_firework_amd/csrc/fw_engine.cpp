@@ -336,6 +336,14 @@ uint32_t seg_live_tiles(const SegHost &s) {
 uint32_t seg_tiles(const SegHost &s, uint32_t vt_rounds = 1) {
     if (!s.in_use) return 0;
     const uint32_t vtile = vt_rounds * FW_VTILE;
+    if (!s.nested_fed && s.frame_spawn <= FW_VTILE) {
+        // At most one round of new particles: they ride in the last live tile whenever it has room for them (both
+        // update kernels apply the same rule), otherwise they take one tile of their own right behind it -- either
+        // way ceil((live + new) / FW_TILE) tiles, for any live count up to the bound.  Thousands of small emitters
+        // then cost ONE workgroup each instead of three (every workgroup pays ~5 us of launch-time latencies).
+        const uint64_t live_ub = std::min(s.ub - std::min(s.ub, s.frame_spawn), s.capacity);
+        return std::max<uint32_t>(1, (uint32_t)((live_ub + s.frame_spawn + FW_TILE - 1) / FW_TILE));
+    }
     return std::max<uint32_t>(1, seg_live_tiles(s) + (s.frame_spawn + vtile - 1) / vtile + 1);
 }
 
@@ -881,7 +889,7 @@ fw_status update_tile_table(fw_ctx *ctx) {
         // slack: an eighth for large segments; a small segment (thousands of small emitters) gets one spare tile --
         // idle workgroups are cheap one by one, but two per segment doubled such a grid
         if (need > have || have > need + need / 4 + (need >= 16 ? 8u : 2u) || have > cap_tiles) {
-            have = std::min(cap_tiles, need + (need >= 16 ? std::max<uint32_t>(2, need / 8) : 1u));
+            have = std::min(cap_tiles, need + (need >= 16 ? std::max<uint32_t>(2, need / 8) : (need >= 4 ? 1u : 0u)));
             dirty = true;
         }
     }

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     __shared__ __attribute__((aligned(16))) float4 s_q0[FW_TILE];  // Q0 / Q3 of the tile (virtual particles included)
     __shared__ __attribute__((aligned(16))) float4 s_q3[FW_TILE];
     __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
-    __shared__ uint32_t s_wcnt[R][NW];
+    __shared__ uint32_t s_wcnt[R + 1][NW];  // row R: the extra round of a tile that carries its segment's few new particles
     __shared__ uint32_t s_lb[2 * LBW * NW];
     __shared__ uint32_t s_part[4][NW];  // per-wave partials: forecast prefix, new survivors, next-frame sums A / B
 
@@ -626,12 +626,17 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     // the exact device count; with several segments the host's choice (from its bounds) is used.
     const uint32_t vt_rounds = a.vt_rounds;  // the host's choice (from its bounds), for every segment
     const uint32_t vtile = vt_rounds * BLK;
-    const uint32_t n_vt = (n_spawn + vtile - 1u) / vtile;
+    // a handful of new particles ride along in the segment's last live tile when it has room (same rule as in
+    // fw_k_update_stream: the host sizes the grid counting on it)
+    const bool merge_new = SPAWN != FW_SPAWN_NONE && n_spawn != 0u && n_spawn <= BLK && t_spawn != 0u &&
+                           n_tot <= t_spawn * FW_TILE;
+    const uint32_t n_vt = merge_new ? 0u : (n_spawn + vtile - 1u) / vtile;
     const uint32_t n_act = t_spawn + n_vt;                      // active tiles of this segment
     if (SPAWN != FW_SPAWN_NONE && n_vt != 0 && n_vt <= FW_VFRONT && t_spawn != 0 && tis < n_act)
         tis = tis < n_vt ? t_spawn + tis : tis - n_vt;
     const uint32_t tile = first + tis;
-    const bool has_new = tis >= t_spawn;  // block-uniform: a tile is either all live or all new
+    const bool has_new = tis >= t_spawn;  // block-uniform: a tile is either all live or all new (tail_new: see above)
+    const bool tail_new = merge_new && tis + 1u == t_spawn;
     const uint32_t base = has_new ? n_in + (tis - t_spawn) * vtile : tis * FW_TILE;
     const uint32_t lim = has_new ? min(base + vtile, n_tot) : min(base + FW_TILE, n_in);
     fw_u64 *fc_out = FUSED ? a.fc_out : nullptr;
@@ -749,6 +754,24 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         if (lane == 0) s_wcnt[r][wave] = (uint32_t)__popcll(m);
         if (has_new) new_alive += (uint32_t)__popcll(m);
     }
+    {  // row R: survivors among the new particles this (live) tile carries: age 0, lifetime = RNG block 2 word 0
+        bool al = false;
+        if (SPAWN != FW_SPAWN_NONE && tail_new && tid < n_spawn) {
+            const uint32_t k = tid;
+            uint32_t oi = o0;
+            for (uint32_t i = o0; i < o1; i++)
+                if (k >= FW_OP(i).rel_base && k - FW_OP(i).rel_base < FW_OP(i).n) oi = i;
+            const FwOp &op = FW_OP(oi);
+            const FwEmit &e = g.emits[op.emit];
+            const unsigned long long serial = op.serial_base + (k - op.rel_base);
+            const fw_u4 o = fw_philox4x32_10(fw_u4{(uint32_t)serial, (uint32_t)(serial >> 32), e.emission_index, 2u}, g.seed,
+                                             e.uid);
+            float an;
+            al = fw_survives(0.0f, a.dt, fw_unit_f32(o.x) * (e.life_max - e.life_min) + e.life_min, &an);
+        }
+        const unsigned long long m = __ballot(al);
+        if (lane == 0) s_wcnt[R][wave] = (uint32_t)__popcll(m);
+    }
     if (use_fc) {
         fc_part = fw_wave_sum(fc_part);
         if (lane == 0) s_part[0][wave] = fc_part, s_part[1][wave] = new_alive;
@@ -758,7 +781,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     const unsigned long long ts1 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t cnt = 0;
 #pragma unroll
-    for (int r = 0; r < R; r++) {
+    for (int r = 0; r <= R; r++) {
 #pragma unroll
         for (int w = 0; w < NW; w++) cnt += s_wcnt[r][w];
     }
@@ -878,6 +901,50 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         }
         q1c = q1n, q2c = q2n;
     }
+    if (SPAWN != FW_SPAWN_NONE && tail_new) {
+        // ---- the extra round: this segment's few new particles, spawned (src/core.rs:437-469) and updated right
+        // behind the tile's live survivors
+        const uint32_t idx = n_in + tid;
+        const bool valid = tid < n_spawn;
+        FwSpawnOut so;
+        so.q0 = so.q1 = so.q2 = so.q3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            const uint32_t k = tid;
+            uint32_t oi = o0;
+            for (uint32_t i = o0; i < o1; i++)
+                if (k >= FW_OP(i).rel_base && k - FW_OP(i).rel_base < FW_OP(i).n) oi = i;
+            const FwOp &op = FW_OP(oi);
+            so = fw_spawn_one(g.emits[op.emit], g.seed, op.serial_base + (k - op.rel_base),
+                              fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
+                              fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
+                              fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
+        }
+        float age_new;
+        const bool alive = valid && fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);
+        const unsigned long long m = __ballot(alive);
+        uint32_t wbase = run;
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+            if ((uint32_t)w < wave) wbase += s_wcnt[R][w];
+        const uint32_t o = wbase + fw_lane_prefix(m);
+        if (fc_out) {
+            float an2;
+            const bool nx = alive && fw_survives(age_new, a.dt, so.q3.w, &an2);
+            fa += (uint32_t)__popcll(__ballot(nx && o < fc_bnd));
+            fb += (uint32_t)__popcll(__ballot(nx && o >= fc_bnd));
+        }
+        if (alive) {
+            float4 rec[4];
+            fw_integrate_store(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, o, INST ? rec : nullptr);
+            if (INST && inst != nullptr && o < inst_cap) {
+                fw_st4(inst, o * 4u + 0u, rec[0]), fw_st4(inst, o * 4u + 1u, rec[1]);
+                fw_st4(inst, o * 4u + 2u, rec[2]), fw_st4(inst, o * 4u + 3u, rec[3]);
+            }
+            for (uint32_t k = 0; k < n_lplanes; k++) fw_st1(ob + FW_OFF_L(C, k), o, FW_F32_MIN);  // core.rs:467
+        } else if (valid && want_destroyed) {
+            fw_store_destroyed(destroyed, ib, C, idx, false, T, s_keys, so.q0, so.q1, so.q2, so.q3, age_new, idx - o);
+        }
+    }
     if (fc_out) {
         if (lane == 0) s_part[2][wave] = fa, s_part[3][wave] = fb;
         __syncthreads();
@@ -911,7 +978,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         g.ndestroyed[seg] = n_tot - nc;
         if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;  // one 8-byte store: tag + count
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        atomicAdd(g.stats, (unsigned long long)n_tot);
+        if (!(a.dbg & 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
     }
 }
 
@@ -1064,14 +1131,23 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     // b >= n_vt is live tile b - n_vt, whatever the live count is.
     const uint32_t t_spawn = (n_in + FW_TILE - 1u) / FW_TILE;
     const uint32_t vtile = SPAWN == FW_SPAWN_NONE ? (uint32_t)FW_TILE : vt_rounds * BLK;  // materialised: full tiles
-    const uint32_t n_vt = (n_spawn + vtile - 1u) / vtile;
+    // A handful of new particles (at most one round) whose segment's last live tile has room for them ride along in
+    // THAT tile, as one more round after its live ones: their slots follow its live survivors by construction, so they
+    // need no tile of their own (no counting, no look-back).  With thousands of small emitters this halves the number
+    // of workgroups -- each of which pays the same ~5 us of launch-time latencies however few particles it holds.
+    // (materialised new particles -- SPAWN_NONE -- sit right behind the live ones in the input buffer: for them
+    // "riding along" just means that the last live tile's range extends over them)
+    const bool merge_new = n_spawn != 0u && n_spawn <= BLK && t_spawn != 0u && n_tot <= t_spawn * FW_TILE;
+    const uint32_t n_vt = merge_new ? 0u : (n_spawn + vtile - 1u) / vtile;
     const uint32_t n_act = t_spawn + n_vt;
     if (SPAWN != FW_SPAWN_NONE && n_vt != 0 && n_vt <= FW_VFRONT && t_spawn != 0 && tis < n_act)
         tis = tis < n_vt ? t_spawn + tis : tis - n_vt;
     const uint32_t tile = first + tis;
     const bool has_new = tis >= t_spawn;
+    const bool tail_new = merge_new && tis + 1u == t_spawn;  // this live tile also spawns + updates the new particles
     const uint32_t base = has_new ? n_in + (tis - t_spawn) * vtile : tis * FW_TILE;
-    const uint32_t lim = has_new ? min(base + vtile, n_tot) : min(base + FW_TILE, n_in);
+    const uint32_t lim = has_new ? min(base + vtile, n_tot)
+                                 : min(base + FW_TILE, (SPAWN == FW_SPAWN_NONE && tail_new) ? n_tot : n_in);
     fw_u64 *fc_out = a.fc_out;
 
     if (n_tot == 0 || tis >= n_act) {
@@ -1223,10 +1299,12 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     excl = __builtin_amdgcn_readfirstlane(excl);  // workgroup-uniform (summed from LDS): keep it on the scalar unit
     const FwOutWin W = fw_out_window(ob, C, excl);
     uint32_t run = excl;
+    int rr = 0;  // rounds done so far (the wave-count exchange area is double-buffered by round parity)
     if (loaded_tile) {
         // ---- live tile (or a tile of materialised new particles): stream the rounds that hold particles (a segment's
         // last tile is partial; with thousands of small emitters that is every tile)
         const int n_rounds = (int)((lim - base + BLK - 1u) / BLK);
+        rr = n_rounds;
 #pragma unroll 1
         for (int r = 0; r < n_rounds; r++) {
             const uint32_t idx = base + r * BLK + tid;
@@ -1257,12 +1335,17 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n;
             if ((a.dbg & 8u) && r == 0) tsR1 = __builtin_amdgcn_s_memrealtime() + (o & 0u);
         }
-    } else if (SPAWN != FW_SPAWN_NONE) {
-        // ---- new-particle tile: spawn_particles (src/core.rs:437-469) right before update_particles, per slot
+    }
+    if (SPAWN != FW_SPAWN_NONE && (!loaded_tile || tail_new)) {
+        // ---- new-particle tile (or the one extra round of a live tile that carries its segment's few new particles):
+        // spawn_particles (src/core.rs:437-469) right before update_particles, per slot
+        const uint32_t sbase = tail_new ? n_in : base, slim = tail_new ? n_tot : lim;
+        const uint32_t srounds = tail_new ? 1u : vt_rounds;
 #pragma unroll 1
-        for (uint32_t r = 0; r < vt_rounds; r++) {
-            const uint32_t idx = base + r * BLK + tid;
-            const bool valid = idx < lim;
+        for (uint32_t r = 0; r < srounds; r++) {
+            const uint32_t idx = sbase + r * BLK + tid;
+            const bool valid = idx < slim;
+            const uint32_t cb = (uint32_t)(rr + (int)r) & 1u;
             FwSpawnOut so;
             so.q0 = so.q1 = so.q2 = so.q3 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (valid) {
@@ -1279,12 +1362,12 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             float age_new;
             const bool alive = valid && fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);
             const unsigned long long m = __ballot(alive);
-            if (lane == 0) s_c[r & 1][wave] = (uint32_t)__popcll(m);
+            if (lane == 0) s_c[cb][wave] = (uint32_t)__popcll(m);
             __syncthreads();
             uint32_t wbase = run;
 #pragma unroll
             for (int w = 0; w < NW; w++) {
-                const uint32_t c = s_c[r & 1][w];
+                const uint32_t c = s_c[cb][w];
                 if ((uint32_t)w < wave) wbase += c;
                 run += c;
             }
@@ -1328,7 +1411,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         g.ndestroyed[seg] = n_tot - nc;
         if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;  // one 8-byte store: tag + count
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        atomicAdd(g.stats, (unsigned long long)n_tot);
+        if (!(a.dbg & 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
     }
 }
 
@@ -1469,7 +1552,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpda
         g.ndestroyed[seg] = n_tot - nc;
         if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        atomicAdd(g.stats, (unsigned long long)n_tot);
+        if (!(a.dbg & 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
     }
 }
 
