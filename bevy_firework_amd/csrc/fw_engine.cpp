@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -49,6 +50,9 @@ struct CurveCopy {
 struct TypeHost {
     fw_particle_settings ps{};
     CurveCopy scale, base, emis;
+    // every particle of this type outlives a step of dt < life_lo_safe: lifetime = u * (max - min) + min, u in [0, 1),
+    // two ulps of margin for the rounding of the lerp; NaN when the range is not finite (never provably safe)
+    float life_lo_safe = 0.f;
 };
 
 struct EmissionHost {
@@ -218,6 +222,10 @@ struct fw_ctx {
     bool use_stream = true;    // FW_STREAM=0: forecast frames keep the count-park-store kernel (A/B)
 
     uint32_t nest_seq = 0;  // launches of fw_k_nest so far (tag of their look-back words)
+    // FW_HOST_PROF=1: time spent in the sections of fw_step's host half (printed when the context is destroyed)
+    bool host_prof = false;
+    double prof_ns[10] = {};
+    uint64_t prof_frames = 0;
     uint64_t frame = 0;
     double sim_time = 0.0;  // sum of the dt of every step so far (lifetime windows)
     uint32_t parity = 0;
@@ -698,6 +706,9 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         copy_curve(T.scale, p.scale_curve.kind, p.scale_curve.n, p.scale_curve.times, p.scale_curve.values, 1);
         copy_curve(T.base, p.base_color.kind, p.base_color.n, p.base_color.times, p.base_color.rgba, 4);
         copy_curve(T.emis, p.emissive_color.kind, p.emissive_color.n, p.emissive_color.times, p.emissive_color.rgba, 4);
+        T.life_lo_safe = (std::isfinite(p.lifetime.min) && std::isfinite(p.lifetime.max))
+                             ? std::nextafterf(std::nextafterf(std::min(p.lifetime.min, p.lifetime.max), -INFINITY), -INFINITY)
+                             : NAN;
         T.ps.scale_curve.times = T.ps.scale_curve.values = nullptr;  // descriptors are copied, never kept
         T.ps.base_color.times = T.ps.base_color.rgba = nullptr;
         T.ps.emissive_color.times = T.ps.emissive_color.rgba = nullptr;
@@ -856,13 +867,16 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
 }
 
 uint32_t choose_vt_rounds(const fw_ctx *ctx) {
-    for (uint32_t vr : {1u, 2u}) {  // at most FW_TILE / 2: Q1/Q2 of new particles live in the upper half of the LDS planes
-        uint64_t act = 0;
-        for (const SegHost &S : ctx->segs)
-            if (S.in_use) act += seg_live_tiles(S) + (S.frame_spawn + vr * FW_VTILE - 1) / (vr * FW_VTILE);
-        if (act <= kResidentSlots) return vr;
+    // at most FW_TILE / 2: Q1/Q2 of new particles live in the upper half of the LDS planes
+    uint64_t act1 = 0, act2 = 0;
+    for (const SegHost &S : ctx->segs) {
+        if (!S.in_use) continue;
+        const uint32_t live = seg_live_tiles(S);
+        act1 += live + (S.frame_spawn + FW_VTILE - 1) / FW_VTILE;
+        act2 += live + (S.frame_spawn + 2 * FW_VTILE - 1) / (2 * FW_VTILE);
+        if (act2 > kResidentSlots) return 1;  // neither size keeps the frame resident: the smaller (more parallel) one
     }
-    return 1;
+    return act1 <= kResidentSlots ? 1 : 2;
 }
 
 // The update grid covers ceil(bound / FW_TILE) tiles per segment, where `bound` is the host's upper
@@ -1112,6 +1126,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_STATIC_NEW")) ctx->use_static_new = atoi(m) != 0;  // 0: always count + look back
     if (const char *m = getenv("FW_SNAP_EVERY")) ctx->snap_every = std::max(1, atoi(m));
     if (const char *m = getenv("FW_SPIN_LIMIT")) ctx->spin_limit = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_HOST_PROF")) ctx->host_prof = atoi(m) != 0;
     if (ensure_max_seg(ctx, 1024) != FW_OK) {
         g_create_error = ctx->err;
         delete ctx;
@@ -1123,6 +1138,12 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
 
 fw_status fw_ctx_destroy(fw_ctx *ctx) {
     if (!ctx) return FW_EINVAL;
+    if (ctx->host_prof && ctx->prof_frames) {
+        static const char *names[10] = {"windows+reset", "spawner loop", "tile table", "commit", "args", "op tables", "launch", "post", "", ""};
+        fprintf(stderr, "[fw] host half of fw_step over %llu frames (ns per frame):", (unsigned long long)ctx->prof_frames);
+        for (int i = 0; i < 8; i++) fprintf(stderr, "  %s %.0f", names[i], ctx->prof_ns[i] / (double)ctx->prof_frames);
+        fprintf(stderr, "\n");
+    }
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->copy_stream);
@@ -1313,6 +1334,13 @@ fw_status fw_spawner_queue(fw_ctx *ctx, fw_spawner h, uint64_t count) {
 fw_status fw_step(fw_ctx *ctx, float dt) {
     if (!ctx) return FW_EINVAL;
     hipSetDevice(ctx->device);
+    auto prof_t = std::chrono::steady_clock::now();
+    auto prof = [&](int i) {
+        if (!ctx->host_prof) return;
+        const auto now = std::chrono::steady_clock::now();
+        ctx->prof_ns[i] += std::chrono::duration<double, std::nano>(now - prof_t).count();
+        prof_t = now;
+    };
     poll_snapshots(ctx);
 
     // per-frame scratch lives in the context: with thousands of emitters the allocations were a visible part of the
@@ -1367,6 +1395,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         return why;
     };
 
+    prof(0);
     // spawn_particles, host half (core.rs:377-428): emission clocks and Global counts
     for (size_t h = 0; h < ctx->spawners.size(); h++) {
         SpawnerHost &sp = ctx->spawners[h];
@@ -1423,12 +1452,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                         if (st) return rollback(st);
                     }
                 }
-                {  // does every particle of this op outlive the step?  lifetime = u * (max - min) + min, u in [0, 1)
-                    const fw_particle_settings &tp = sp.types[es.particle_index].ps;
-                    const float lo = std::min(tp.lifetime.min, tp.lifetime.max);
-                    const float lo_safe = std::nextafterf(std::nextafterf(lo, -INFINITY), -INFINITY);  // rounding of the lerp
-                    if (!(std::isfinite(tp.lifetime.min) && std::isfinite(tp.lifetime.max) && dt < lo_safe)) new_static = false;
-                }
+                // does every particle of this op outlive the step?  (TypeHost::life_lo_safe; false for NaN)
+                if (!(dt < sp.types[es.particle_index].life_lo_safe)) new_static = false;
                 FwOp op{};
                 op.seg = dst, op.emit = E.emit_idx, op.n = (uint32_t)n;
                 op.rel_base = S.frame_spawn;
@@ -1445,12 +1470,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             } else {
                 if (es.pacing_kind != FW_PACING_COUNT_OVER_DURATION) continue;  // warn_once + continue core.rs:474-485
                 const SegHost &P = ctx->segs[sp.seg[es.target_particle_type]];
-                {  // children are born with age 0 like any new particle: do they all outlive this step?
-                    const fw_particle_settings &tp = sp.types[es.particle_index].ps;
-                    const float lo = std::min(tp.lifetime.min, tp.lifetime.max);
-                    const float lo_safe = std::nextafterf(std::nextafterf(lo, -INFINITY), -INFINITY);
-                    if (!(std::isfinite(tp.lifetime.min) && std::isfinite(tp.lifetime.max) && dt < lo_safe)) new_static = false;
-                }
+                // children are born with age 0 like any new particle: do they all outlive this step?
+                if (!(dt < sp.types[es.particle_index].life_lo_safe)) new_static = false;
                 FwNestOp op{};
                 op.parent_seg = sp.seg[es.target_particle_type], op.child_seg = dst;
                 op.emit = E.emit_idx, op.emit_slot = E.emit_slot;
@@ -1470,8 +1491,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     }
 
     // ---- segment -> tile table (device resident, re-uploaded only when a bound moves out of its band)
+    prof(1);
     const uint32_t n_seg = (uint32_t)ctx->segs.size();
     fw_status st = update_tile_table(ctx);
+    prof(2);
     if (st) return rollback(st);
     const uint32_t total_tiles = ctx->total_tiles_dev;
 
@@ -1500,6 +1523,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             }
             S.win_sum += n;
         }
+    prof(3);
     const uint32_t p = ctx->parity;
     // Particle types with collision settings (core.rs:607-624) run the count / scan / update-with-collisions launches
     // (everything materialised first, like FW_UPDATE_MODE=split); the streaming kernels never see a collider.
@@ -1577,6 +1601,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     FwInlineOps inl;
     int spawn_form = FW_SPAWN_NONE;
     int slot = -1;
+    prof(4);
 
     if (legacy) {
         // Frames with Nested entries: parents spawned earlier in the frame must exist in memory before the
@@ -1715,6 +1740,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         }
     }
     if (ctx->h_done) a.done_tag = ctx->h_done, a.done_value = ctx->frame;
+    prof(5);
 
     // update_particles + compaction (core.rs:577-670)
     // timing: the events ride on the dispatch packet (its begin / end timestamps), no marker packets in the stream
@@ -1723,6 +1749,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                                  frame_mode, timed ? ctx->tev[ctx->tev_used] : nullptr,
                                  timed ? ctx->tev[ctx->tev_used + 1] : nullptr));
     if (timed) ctx->tev_used += 2;
+    prof(6);
     if (slot >= 0) {
         FW_HIP(ctx, hipEventRecord(ctx->ev_consumed[slot], ctx->stream));
         ctx->consumed_pending[slot] = true;
@@ -1741,6 +1768,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     ctx->parity ^= 1u;
     ctx->frame++;
     ctx->sim_time += (double)dt;
+    prof(7);
+    ctx->prof_frames++;
     return FW_OK;
 }
 

@@ -22,12 +22,19 @@ FW_HD fw_v3 fw_cross(fw_v3 a, fw_v3 b) {
 }
 
 // f32::div_euclid / rem_euclid (reference src/core.rs:412-414,569)
+// (a % b carries the sign of a, so it can only be negative when a is: the remainder is not evaluated otherwise)
 FW_HD float fw_div_euclid(float a, float b) {
     float q = truncf(a / b);
-    if (fmodf(a, b) < 0.0f) return (b > 0.0f) ? q - 1.0f : q + 1.0f;
+    if (a < 0.0f && fmodf(a, b) < 0.0f) return (b > 0.0f) ? q - 1.0f : q + 1.0f;
     return q;
 }
+// (the two common cases of the emission clock, 0 <= a < b and b <= a < 2b, have exact closed forms: a itself, and
+// a - b, which fp32 subtracts exactly for b <= a <= 2b -- the same values fmodf returns, without its loop)
 FW_HD float fw_rem_euclid(float a, float b) {
+    if (b > 0.0f && a >= 0.0f) {
+        if (a < b) return a;
+        if (a - b < b) return a - b;
+    }
     float r = fmodf(a, b);
     return (r < 0.0f) ? r + fabsf(b) : r;
 }
