@@ -4,7 +4,9 @@
 // overlay shows (stress_test.rs:178-201): particle count and frames per second.
 //
 //   make -C examples        (g++ -std=c++17 -Iinclude ... -lfirework_hip)
-//   ./examples/stress_test [rate] [frames]
+//   ./examples/stress_test [rate] [frames] [collision]
+// With a third argument the particle type gets the collision settings of examples/stress_test_collision.rs:110-115
+// (restitution 0.6, friction 0.2) and the world holds that example's 8 x 1 x 8 cuboid base (:85-90) as a box collider.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +18,7 @@ using namespace firework;
 int main(int argc, char **argv) {
     const float rate = argc > 1 ? (float)atof(argv[1]) : 160000.0f;
     const int frames = argc > 2 ? atoi(argv[2]) : 600;
+    const bool collision = argc > 3;
     const float PI = 3.14159265358979f;
     try {
         ParticleSystemPlugin app(0, /*seed*/ 0x00C0FFEE);
@@ -30,6 +33,11 @@ int main(int argc, char **argv) {
                                                           {0.9f, {0.3f, 0.3f, 0.3f, 1}},
                                                           {1.0f, {0.1f, 0.1f, 0.1f, 0}}});
         ps.linear_drag = 0.1f;
+        if (collision) {
+            ps.has_collision_settings = true;
+            ps.collision_settings = ParticleCollisionSettings{0.6f, 0.2f, false, 0xFFFFFFFFu};
+            app.set_colliders({Collider::Box({0.0f, -0.5f, 0.0f}, {4.0f, 0.5f, 4.0f})});
+        }
         EmissionSettings &es = sp.emission_settings[0];
         es.emission_pacing = EmissionPacing::rate(rate);
         es.emission_shape = EmissionShape::Circle({0, 1, 0}, 0.3f);

@@ -15,6 +15,7 @@
 //   ParticleSpawnerData        src/core.rs:269-303  firework::ParticleSpawnerData (queue_particles, active, particles)
 //   ParticleData               src/core.rs:305-321  fw_particle
 //   EffectModifier             src/core.rs:323-336  firework::EffectModifier
+//   ParticleCollisionSettings  src/core.rs:240-248  firework::ParticleCollisionSettings (+ firework::Collider, set_colliders)
 //
 // Header-only; link with -lfirework_hip.  No simulation arithmetic lives here.
 #pragma once
@@ -138,6 +139,36 @@ struct EmissionShape {
 
 enum class SpawnTransformMode { Global, Local };  // core.rs:66-73
 
+// ParticleCollisionSettings (core.rs:240-248, feature physics_avian).  filter_mask stands in for the
+// SpatialQueryFilter: a collider takes part when (filter_mask & collider.layers) != 0.
+struct ParticleCollisionSettings {
+    float restitution = 0, friction = 0;
+    bool destroy_on_collision = false;
+    uint32_t filter_mask = 0xFFFFFFFFu;
+};
+
+// One analytic collider of the world particle_collision casts its rays into (core.rs:744-800): the backend keeps a
+// device-resident set of these instead of asking avian's SpatialQuery (semantics: fw_collider in firework_hip.h).
+struct Collider {
+    int32_t kind = FW_COLLIDER_PLANE;
+    Vec3 position{};
+    Quat rotation{};
+    Vec3 normal{0, 1, 0};
+    float radius = 0;
+    Vec3 half_extents{};
+    uint32_t layers = 1;
+    static Collider Plane(Vec3 point, Vec3 unit_normal, uint32_t layers = 1) {
+        Collider c; c.kind = FW_COLLIDER_PLANE, c.position = point, c.normal = unit_normal, c.layers = layers; return c;
+    }
+    static Collider Sphere(Vec3 center, float radius, uint32_t layers = 1) {
+        Collider c; c.kind = FW_COLLIDER_SPHERE, c.position = center, c.radius = radius, c.layers = layers; return c;
+    }
+    static Collider Box(Vec3 center, Vec3 half_extents, Quat rotation = {}, uint32_t layers = 1) {
+        Collider c; c.kind = FW_COLLIDER_BOX, c.position = center, c.half_extents = half_extents, c.rotation = rotation;
+        c.layers = layers; return c;
+    }
+};
+
 struct ParticleSettings {  // core.rs:99-142, defaults core.rs:187-211
     RandF32 lifetime = RandF32::constant(5.0f);
     FireworkCurve scale_curve = FireworkCurve::constant(1.0f);
@@ -151,6 +182,8 @@ struct ParticleSettings {  // core.rs:99-142, defaults core.rs:187-211
     bool pbr = false;
     // event_handlers.particles_destroyed (core.rs:164-167)
     std::function<void(const std::vector<fw_particle> &)> particles_destroyed;
+    bool has_collision_settings = false;            // collision_settings: Option<..> (core.rs:137-138)
+    ParticleCollisionSettings collision_settings{};
     uint32_t capacity = 0;  // backend knob
 };
 
@@ -243,6 +276,10 @@ class ParticleSystemPlugin {
                                 p.emissive_color.times.empty() ? nullptr : p.emissive_color.times.data(),
                                 p.emissive_color.rgba.data()};
             d.pbr = p.pbr, d.report_destroyed = p.particles_destroyed ? 1 : 0, d.capacity = p.capacity;
+            d.collision.enabled = p.has_collision_settings ? 1 : 0;
+            d.collision.restitution = p.collision_settings.restitution, d.collision.friction = p.collision_settings.friction;
+            d.collision.destroy_on_collision = p.collision_settings.destroy_on_collision ? 1 : 0;
+            d.collision.filter_mask = p.collision_settings.filter_mask;
         }
         for (size_t i = 0; i < es.size(); i++) {
             const EmissionSettings &e = s.emission_settings[i];
@@ -279,6 +316,22 @@ class ParticleSystemPlugin {
         d->handle = h, d->sys = this, d->settings = s, d->transform = t;
         spawners_.push_back(d);
         return d;
+    }
+
+    // the world particles collide with (stands in for avian's SpatialQuery; core.rs:581, 744-800)
+    void set_colliders(const std::vector<Collider> &cs) {
+        std::vector<fw_collider> v(cs.size());
+        for (size_t i = 0; i < cs.size(); i++) {
+            const Collider &c = cs[i];
+            fw_collider &d = v[i];
+            d = fw_collider{};
+            d.kind = c.kind, d.layers = c.layers, d.radius = c.radius;
+            d.position[0] = c.position.x, d.position[1] = c.position.y, d.position[2] = c.position.z;
+            d.rotation[0] = c.rotation.x, d.rotation[1] = c.rotation.y, d.rotation[2] = c.rotation.z, d.rotation[3] = c.rotation.w;
+            d.normal[0] = c.normal.x, d.normal[1] = c.normal.y, d.normal[2] = c.normal.z;
+            d.half_extents[0] = c.half_extents.x, d.half_extents[1] = c.half_extents.y, d.half_extents[2] = c.half_extents.z;
+        }
+        check(fw_ctx_set_colliders(ctx_, v.data(), (uint32_t)v.size()));
     }
 
     // one run of the chained systems (plugin.rs:46-60)

@@ -8,10 +8,10 @@ import json
 import re
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01/pmc_summary.txt"
+src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r02/pmc_summary.txt"
 txt = open(src).read()
-kern = "fw_k_update_stream<1, false, false>"  # the steady-state kernel of the bench: forecast frames, inline spawn ops,
-# no attached instance buffers, per-tile forecast entries
+kern = "fw_k_update_stream<1, false, false, true>"  # the steady-state kernel of the bench: forecast frames, inline spawn
+# ops, no attached instance buffers, per-tile forecast entries, lone segment (its record in the kernel arguments)
 fetch = float(re.search(re.escape(kern) + r"\s+FETCH_SIZE=([0-9.e+]+)", txt).group(1))
 write = float(re.search(re.escape(kern) + r"\s+WRITE_SIZE=([0-9.e+]+)", txt).group(1))
 out = {

@@ -1,22 +1,35 @@
 #!/bin/bash
-# Produce the committed profile artefacts of a round (run on the GPU box):  tools/profile_round.sh r01
-TAG=${1:-r01}
+# Produce the committed profile artefacts of a round (run on the GPU box):  tools/profile_round.sh r02
+TAG=${1:-r02}
 R=$PWD; OUT=gpurun_out/profile_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 # 1. the bench line itself (default flags)
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-# 2. rocprofv3 kernel trace + stats of the same command
-cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT -o ${TAG}_stats --output-format csv -- python $R/bench.py --no-cpu > $R/$OUT/stats_bench.json 2>/dev/null; cd $R
+# 2. rocprofv3 kernel trace + stats of the same command (without the CPU baseline and the extra workloads: the
+#    kernel of the headline configuration only)
+cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT -o ${TAG}_stats --output-format csv -- python $R/bench.py --no-cpu --no-extras > $R/$OUT/stats_bench.json 2>/dev/null; cd $R
 python profiles/analyze_trace.py $OUT/${TAG}_stats_kernel_trace.csv 600 > $OUT/trace_summary.txt
 # 3. PMC passes (own runs, kernel-trace only)
 ./tools/pmc.sh $OUT/pmc > /dev/null 2>&1
 python profiles/analyze_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
-# 4. memory microbenchmark (measured roofline of the kernel's load/store shape)
+# 4. memory microbenchmarks (measured roofline of the kernel's load/store shape; copy sweep at 1 GiB)
 ./tools/membw 64 > $OUT/membw.txt 2>&1
-# 5. in-kernel timelines, launch period, the rows ranked next, size sweep, feature twins
+./tools/membw 1024 copy > $OUT/copy_sweep.txt 2>&1
+# 5. in-kernel timelines, launch period, the rows ranked next, size sweep, ablations
 timeout 200 python tools/launch_gaps.py > $OUT/launch_gaps.txt 2>&1
 timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline.txt 2>&1
+FW_TL_JITTER=1 timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline_variable_dt.txt 2>&1
 timeout 300 python tools/bench_next_rows.py > $OUT/next_rows.txt 2>&1
 timeout 300 python tools/fused_sizes.py > $OUT/fused_sizes.txt 2>&1
+timeout 300 python tools/dbg_modes.py > $OUT/dbg_modes.txt 2>&1
+timeout 300 python tools/var_dt.py 400 > $OUT/var_dt.txt 2>&1
+# 6. the other BASELINE configs on one GPU, the small-emitter regime and the host half of fw_step
+timeout 600 python tools/bench_configs.py > $OUT/configs.txt 2>&1
+timeout 300 python tools/small_emitters_gpu.py > $OUT/small_emitters.txt 2>&1
+FW_HOST_PROF=1 timeout 300 python tools/small_emitters.py >> $OUT/small_emitters.txt 2>&1
+# 7. configs[3] (Nested): rocprofv3 kernel stats of the steady state
+cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/nested -o nested --output-format csv -- python $R/tools/nested_prof.py > $R/$OUT/nested_step.txt 2>/dev/null; cd $R
+python profiles/analyze_trace.py $OUT/nested/nested_kernel_trace.csv 400 > $OUT/nested_trace_summary.txt 2>&1
+cp $OUT/nested/nested_kernel_stats.csv $OUT/configs3_nested_kernel_stats.csv 2>/dev/null
 [ -x tools/launchgap ] && timeout 200 ./tools/launchgap > $OUT/launchgap.txt 2>&1
-rm -f $OUT/${TAG}_stats_kernel_trace.csv $OUT/pmc/*kernel_trace.csv   # large; the summaries are what is kept
+rm -rf $OUT/${TAG}_stats_kernel_trace.csv $OUT/pmc/*kernel_trace.csv $OUT/nested   # large; the summaries are what is kept
 ls $OUT
