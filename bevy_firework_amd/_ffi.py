@@ -249,6 +249,9 @@ SYMBOLS = [
     ("fw_ctx_kernel_timing_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("fw_ctx_kernel_timing_overhead", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("fw_ctx_measure_copy_bandwidth", C.c_int, [_P, C.c_uint64, C.c_int32, C.POINTER(C.c_double)]),
+    ("fw_debug_read_timestamps", C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("fw_debug_read_timestamps2", C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("fw_debug_read_launches", C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
     ("fw_compute_emission_count", C.c_uint64,
      [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]),
 ]

@@ -253,6 +253,14 @@ fw_status fw_ctx_kernel_timing_overhead(fw_ctx *ctx, double *ms_per_pair);
 /* device-to-device copy bandwidth probe (bytes moved R+W per second) for the measured-roofline line */
 fw_status fw_ctx_measure_copy_bandwidth(fw_ctx *ctx, uint64_t bytes, int32_t iters, double *bytes_per_s);
 
+/* in-kernel timestamps of the update kernel when the context was created under FW_DEBUG=8 (tools/tile_timeline.py,
+ * tools/launch_gaps.py): per tile {entry, after the count barrier, after the prefix, end, 4 more phase marks} of the
+ * last launch (and of the one before it: `prev`); {~earliest start [64], latest end [64]} of the last 256 launches */
+fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_t max_tiles, uint64_t *n_tiles);
+fw_status fw_debug_read_timestamps2(fw_ctx *ctx, unsigned long long *out, unsigned long long *prev, uint64_t max_tiles,
+                                    uint64_t *n_tiles);
+fw_status fw_debug_read_launches(fw_ctx *ctx, unsigned long long *out32768, uint32_t *epoch);
+
 /* ---- pure host helpers (no GPU needed; the bit-exact count arithmetic) ------------ */
 /* compute_emission_count (core.rs:553-575) exactly as fw_step's host side evaluates it */
 uint64_t fw_compute_emission_count(float time_passed_in_cycle, float last_emission, float cycle_duration,

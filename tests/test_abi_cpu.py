@@ -34,6 +34,14 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.fw_abi_version() == 2
+    # the Rust `extern "C"` block of INTEGRATION.md lists the same functions (three mirrors of one header: keep them in step)
+    rust = set(re.findall(r"pub fn (fw_[a-z0-9_]+)\(", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
+    assert rust == declared, rust ^ declared
+    # ... and the library exports no fw_* function the header does not declare
+    import subprocess
+
+    exported = set(re.findall(r" T (fw_[a-z0-9_]+)$", subprocess.check_output(["nm", "-D", "--defined-only", _ffi.LIB_PATH], text=True), re.M))
+    assert exported == declared, exported ^ declared
 
 
 def test_struct_sizes_match_header(tmp_path):
