@@ -64,25 +64,33 @@ struct EmissionHost {
     uint32_t emit_idx = 0;    // -> FwEmit
     uint32_t emit_slot = 0;   // -> device serial counter (Nested)
     bool assigned = false;    // emit_idx / emit_slot are owned by this entry
+    uint32_t dst_seg = 0;     // segment of es.particle_index (cached: the frame loop then touches only this record)
+    float life_lo_safe = 0.f; // TypeHost::life_lo_safe of es.particle_index
 };
 
-struct SegHost {
+struct alignas(64) SegHost {
+    // ---- what the per-frame loops of fw_step touch, in ONE cache line (with thousands of segments those loops are
+    // bound by how many lines they stream, not by their arithmetic)
     bool in_use = false;
-    int spawner = -1, type = -1;
-    uint32_t capacity = 0;
-    uint32_t ub = 0;            // upper bound of the device count (after this frame's spawns)
-    uint64_t cum_spawn = 0;     // Global particles ever appended (host-known)
-    uint32_t frame_spawn = 0;   // ... this frame
-    uint32_t type_idx = 0, n_lplanes = 0;
-    uint32_t keys_off = 0, keys_len = 0;  // key pool window of the segment's type
-    int32_t lplane_emission[FW_MAX_EMISSIONS];
     bool nested_fed = false;    // receives Nested children: count not host-predictable
     bool collides = false;      // the type has collision settings (core.rs:137-138): frames run the collision path
     bool auto_capacity = false; // capacity was derived (fw_particle_settings.capacity == 0): the library may grow it
+    bool win_ok = false;
+    uint32_t capacity = 0;
+    uint32_t ub = 0;            // upper bound of the device count (after this frame's spawns)
+    uint32_t frame_spawn = 0;   // Global particles appended this frame
     uint32_t dev_count = 0;     // nested_fed: live count of the latest snapshot row (growth trigger)
+    uint64_t cum_spawn = 0;     // Global particles ever appended (host-known)
+    uint64_t win_sum = 0;
+    double life_bound = 0.0;
+    char *inst = nullptr;       // caller-owned device buffer of ParticleInstance records (fw_spawner_attach_instances)
+    // ---- the rest
+    int spawner = -1, type = -1;
+    uint32_t type_idx = 0, n_lplanes = 0;
+    uint32_t keys_off = 0, keys_len = 0;  // key pool window of the segment's type
+    int32_t lplane_emission[FW_MAX_EMISSIONS];
     char *buf[2] = {nullptr, nullptr};
     char *destroyed = nullptr;
-    char *inst = nullptr;       // caller-owned device buffer of ParticleInstance records (fw_spawner_attach_instances)
     uint32_t inst_cap = 0;
     // Lifetime window: a particle is destroyed by the update in which age >= lifetime (core.rs:590-592), and
     // lifetime <= life_bound, so everything alive was spawned less than life_bound of simulated time ago.  The sum of
@@ -92,10 +100,25 @@ struct SegHost {
         uint64_t n;
         uint64_t frame;  // frame of the spawn (the device's ages are fp32 sums: the error grows with the steps taken)
     };
-    std::deque<Spawned> win;
-    uint64_t win_sum = 0;
-    bool win_ok = false;
-    double life_bound = 0.0;
+    // (a ring in one allocation: in the steady state every frame pops one entry and pushes one per segment; a
+    // std::deque pays its chunk bookkeeping for each -- 30 us per frame with 2048 emitters)
+    struct Window {
+        std::vector<Spawned> v;
+        uint32_t head = 0, n = 0;
+        bool empty() const { return n == 0; }
+        size_t size() const { return n; }
+        Spawned &front() { return v[head]; }
+        Spawned &back() { return v[(head + n - 1) & (uint32_t)(v.size() - 1)]; }
+        void pop_front() { head = (head + 1) & (uint32_t)(v.size() - 1), n--; }
+        void push_back(const Spawned &x) {
+            if (n == v.size()) {  // grow to the next power of two, oldest entry first
+                std::vector<Spawned> w(v.empty() ? 64 : v.size() * 2);
+                for (uint32_t i = 0; i < n; i++) w[i] = v[(head + i) & (uint32_t)(v.size() - 1)];
+                v.swap(w), head = 0;
+            }
+            v[(head + n) & (uint32_t)(v.size() - 1)] = x, n++;
+        }
+    } win;
 };
 
 struct SpawnerHost {
@@ -224,6 +247,7 @@ struct fw_ctx {
     uint32_t nest_seq = 0;  // launches of fw_k_nest so far (tag of their look-back words)
     // FW_HOST_PROF=1: time spent in the sections of fw_step's host half (printed when the context is destroyed)
     bool host_prof = false;
+    uint64_t host_prof_skip = 0;  // FW_HOST_PROF=n (n > 1): frames to skip first (fill, table uploads)
     double prof_ns[10] = {};
     uint64_t prof_frames = 0;
     uint64_t frame = 0;
@@ -796,6 +820,8 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         E.last_emission = 0.f, E.time_passed_in_cycle = 0.f;  // sync_spawner_data core.rs:350-358
         E.enabled = d->starts_enabled != 0;
         E.emits_on_other_particles = e.mode == FW_MODE_NESTED;
+        E.dst_seg = sp.seg[e.particle_index];
+        E.life_lo_safe = sp.types[e.particle_index].life_lo_safe;
         E.serial = carry_serial && i < carry_serial->size() ? (*carry_serial)[i] : 0;
         const fw_particle_settings &p = d->particle_settings[e.particle_index];
         FwEmit de{};
@@ -1126,7 +1152,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_STATIC_NEW")) ctx->use_static_new = atoi(m) != 0;  // 0: always count + look back
     if (const char *m = getenv("FW_SNAP_EVERY")) ctx->snap_every = std::max(1, atoi(m));
     if (const char *m = getenv("FW_SPIN_LIMIT")) ctx->spin_limit = (uint32_t)strtoul(m, nullptr, 10);
-    if (const char *m = getenv("FW_HOST_PROF")) ctx->host_prof = atoi(m) != 0;
+    if (const char *m = getenv("FW_HOST_PROF")) ctx->host_prof = atoi(m) != 0, ctx->host_prof_skip = atoi(m) > 1 ? (uint64_t)atoi(m) : 0;
     if (ensure_max_seg(ctx, 1024) != FW_OK) {
         g_create_error = ctx->err;
         delete ctx;
@@ -1338,6 +1364,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     auto prof = [&](int i) {
         if (!ctx->host_prof) return;
         const auto now = std::chrono::steady_clock::now();
+        if (ctx->frame < ctx->host_prof_skip) {
+            prof_t = now;
+            return;
+        }
         ctx->prof_ns[i] += std::chrono::duration<double, std::nano>(now - prof_t).count();
         prof_t = now;
     };
@@ -1347,14 +1377,20 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // host's ~60 ns per emitter
     auto &levels = ctx->levels;
     for (auto &L : levels) L.g.clear(), L.n.clear();
-    for (auto &S : ctx->segs) S.frame_spawn = 0;
+    // (frame_spawn is reset in the lifetime-window pass below: one pass over the segments instead of two)
     bool new_static = std::isfinite(dt);  // cleared by any Global op whose particles might not survive this step
 
     // lifetime windows: drop the spawns that must have expired by now and tighten the bounds with what is left.
     // (ages are fp32 sums of the same dt values on the device; the margin covers the rounding difference)
     if (!(dt >= 0.0f) || !std::isfinite(dt))
         for (auto &S : ctx->segs) S.win_ok = false;  // ages would not grow monotonically
-    for (auto &S : ctx->segs) {
+    for (size_t si = 0, ns = ctx->segs.size(); si < ns; si++) {
+        SegHost &S = ctx->segs[si];
+        if (si + 8 < ns) {  // the oldest window entry of a later segment: a heap line of its own, fetched ahead of time
+            const SegHost &N = ctx->segs[si + 8];
+            if (N.win.n) __builtin_prefetch(&N.win.v[N.win.head]);
+        }
+        S.frame_spawn = 0;
         if (!S.in_use || !S.win_ok) continue;
         // an age is an fp32 running sum of the dt values: up to half an ulp of the age per step taken, i.e. a relative
         // error below steps * 6e-8; the horizon carries that (with a factor 4) on top of a fixed 1e-3
@@ -1399,6 +1435,13 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // spawn_particles, host half (core.rs:377-428): emission clocks and Global counts
     for (size_t h = 0; h < ctx->spawners.size(); h++) {
         SpawnerHost &sp = ctx->spawners[h];
+        if (h + 8 < ctx->spawners.size()) {  // the entries of a later spawner live on the heap: fetch them ahead of time
+            const SpawnerHost &nx = ctx->spawners[h + 8];
+            if (!nx.em.empty()) {
+                __builtin_prefetch(nx.em.data());
+                __builtin_prefetch((const char *)nx.em.data() + 128);
+            }
+        }
         if (!sp.alive) continue;
         // `if data.active()` (core.rs:378): an entry that emits on other particles contributes only when
         // some particle exists; with no particle at all the Nested arm below is a no-op anyway, so the
@@ -1410,7 +1453,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             EmissionHost &E = sp.em[i];
             if (!E.enabled) continue;
             const fw_emission_settings &es = E.es;
-            const uint32_t dst = sp.seg[es.particle_index];
+            const uint32_t dst = E.dst_seg;
             if (es.mode == FW_MODE_GLOBAL) {
                 uint64_t n = 0;
                 ctx->undo_em.push_back(fw_ctx::EmUndo{(uint32_t)h, (uint32_t)i, E.last_emission, E.time_passed_in_cycle,
@@ -1453,7 +1496,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     }
                 }
                 // does every particle of this op outlive the step?  (TypeHost::life_lo_safe; false for NaN)
-                if (!(dt < sp.types[es.particle_index].life_lo_safe)) new_static = false;
+                if (!(dt < E.life_lo_safe)) new_static = false;
                 FwOp op{};
                 op.seg = dst, op.emit = E.emit_idx, op.n = (uint32_t)n;
                 op.rel_base = S.frame_spawn;
@@ -1471,7 +1514,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 if (es.pacing_kind != FW_PACING_COUNT_OVER_DURATION) continue;  // warn_once + continue core.rs:474-485
                 const SegHost &P = ctx->segs[sp.seg[es.target_particle_type]];
                 // children are born with age 0 like any new particle: do they all outlive this step?
-                if (!(dt < sp.types[es.particle_index].life_lo_safe)) new_static = false;
+                if (!(dt < E.life_lo_safe)) new_static = false;
                 FwNestOp op{};
                 op.parent_seg = sp.seg[es.target_particle_type], op.child_seg = dst;
                 op.emit = E.emit_idx, op.emit_slot = E.emit_slot;
@@ -1506,7 +1549,12 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         return rollback(st);
     // ---- commit: the frame will run
     for (auto &L : levels)
-        for (const FwOp &op : L.g) {
+        for (size_t oi = 0, no = L.g.size(); oi < no; oi++) {
+            const FwOp &op = L.g[oi];
+            if (oi + 8 < no) {
+                const SegHost &N = ctx->segs[L.g[oi + 8].seg];
+                if (!N.win.v.empty()) __builtin_prefetch(&N.win.v[(N.win.head + N.win.n) & (uint32_t)(N.win.v.size() - 1)]);
+            }
             SegHost &S = ctx->segs[op.seg];
             const uint64_t n = op.n;
             S.cum_spawn += n;
@@ -1769,7 +1817,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     ctx->frame++;
     ctx->sim_time += (double)dt;
     prof(7);
-    ctx->prof_frames++;
+    if (ctx->frame > ctx->host_prof_skip) ctx->prof_frames++;
     return FW_OK;
 }
 

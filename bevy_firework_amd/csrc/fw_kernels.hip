@@ -17,6 +17,7 @@
 // Arithmetic order is the reference's (fw_math.h); built with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <cstdlib>
 
 #include "fw_kernels.h"
 #include "fw_math.h"
@@ -80,14 +81,25 @@ __device__ __forceinline__ void fw_st1(char *plane, uint32_t i, float v) {
 // each output plane.  With the plane pointer advanced to the window start on the scalar unit and a 32-bit byte offset
 // per lane, the access is "SGPR pair + VGPR offset" (the saddr form of global_load / global_store): no 64-bit vector
 // address arithmetic and no address register pairs kept alive per plane.
+// (FW_NT_LOADS / FW_NT_STORES: experiment builds with non-temporal plane accesses, tools/ab.sh)
 __device__ __forceinline__ float4 fw_ld4w(const char *win, uint32_t byte_off) {
-    const fw_f4 v = *reinterpret_cast<const FW_GLOBAL fw_f4 *>(
+    const FW_GLOBAL fw_f4 *p = reinterpret_cast<const FW_GLOBAL fw_f4 *>(
         reinterpret_cast<const FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off);
+#ifdef FW_NT_LOADS
+    const fw_f4 v = __builtin_nontemporal_load(p);
+#else
+    const fw_f4 v = *p;
+#endif
     return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void fw_st4w(char *win, uint32_t byte_off, float4 v) {
     const fw_f4 x = {v.x, v.y, v.z, v.w};
-    *reinterpret_cast<FW_GLOBAL fw_f4 *>(reinterpret_cast<FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off) = x;
+    FW_GLOBAL fw_f4 *p = reinterpret_cast<FW_GLOBAL fw_f4 *>(reinterpret_cast<FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off);
+#ifdef FW_NT_STORES
+    __builtin_nontemporal_store(x, p);
+#else
+    *p = x;
+#endif
 }
 __device__ __forceinline__ void fw_st1w(char *win, uint32_t byte_off, float v) {
     *reinterpret_cast<FW_GLOBAL float *>(reinterpret_cast<FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off) = v;
@@ -2007,12 +2019,15 @@ hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *d_ops,
 
 // Launch with optional timing events attached to the dispatch itself (hipExtLaunchKernel): the events take the
 // packet's own begin / end timestamps, which is what rocprofv3 --kernel-trace reports for the kernel.
+// (fw_dyn_lds: experiment knob FW_DYN_LDS -- unused dynamic LDS per workgroup lowers the number of resident workgroups
+// per CU; measured on the HBM-resident configurations)
+static unsigned fw_dyn_lds = getenv("FW_DYN_LDS") ? (unsigned)atoi(getenv("FW_DYN_LDS")) : 0u;
 #define FW_LAUNCH_T(kern, grid, block, s, e0, e1, ...)                                          \
     do {                                                                                          \
         if ((e0) || (e1))                                                                         \
-            hipExtLaunchKernelGGL(kern, grid, block, 0, s, e0, e1, 0, __VA_ARGS__);               \
+            hipExtLaunchKernelGGL(kern, grid, block, fw_dyn_lds, s, e0, e1, 0, __VA_ARGS__);      \
         else                                                                                      \
-            hipLaunchKernelGGL(kern, grid, block, 0, s, __VA_ARGS__);                             \
+            hipLaunchKernelGGL(kern, grid, block, fw_dyn_lds, s, __VA_ARGS__);                    \
     } while (0)
 
 template <int R, bool INST, bool SUMS>
