@@ -241,6 +241,7 @@ SYMBOLS = [
     ("fw_spawner_pack_instances_device", C.c_int, [_P, C.c_int32, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("fw_spawner_attach_instances", C.c_int, [_P, C.c_int32, C.c_uint32, _P, C.c_uint64]),
     ("fw_spawner_aabb", C.c_int, [_P, C.c_int32, _F3, _F3, C.POINTER(C.c_int32)]),
+    ("fw_ctx_track_aabbs", C.c_int, [_P, C.c_int32]),
     ("fw_ctx_live_count", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("fw_ctx_live_count_device", C.c_int, [_P, _P]),
     ("fw_ctx_live_count_ring", C.c_int, [_P, _P, C.c_uint32]),

@@ -243,6 +243,10 @@ struct fw_ctx {
     bool use_static_new = true;  // static output slots for new particles when all of them survive (FW_STATIC_NEW)
     uint32_t snap_every = kSnapEvery;  // frames between live-count snapshots (FW_SNAP_EVERY)
     bool use_stream = true;    // FW_STREAM=0: forecast frames keep the count-park-store kernel (A/B)
+    // AABB fused into the update (fw_ctx_track_aabbs): per-tile boxes of the last update, valid while nothing touched
+    // the state or the tile table since
+    bool track_aabb = false;
+    uint32_t boxes_epoch = 0;  // epoch of the update that left valid boxes (0 = none)
 
     uint32_t nest_seq = 0;  // launches of fw_k_nest so far (tag of their look-back words)
     // FW_HOST_PROF=1: time spent in the sections of fw_step's host half (printed when the context is destroyed)
@@ -406,6 +410,10 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_off, ncap * sizeof(uint32_t)));
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_status, ncap * sizeof(unsigned long long)));
         FW_HIP(ctx, hipMemset(ctx->g.tile_status, 0, ncap * sizeof(unsigned long long)));
+        if (ctx->g.tile_box) hipFree(ctx->g.tile_box);
+        FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_box, ncap * 8 * sizeof(float)));
+        FW_HIP(ctx, hipMemset(ctx->g.tile_box, 0, ncap * 8 * sizeof(float)));
+        ctx->boxes_epoch = 0;
         if (ctx->g.dbg_ts) hipFree(ctx->g.dbg_ts);
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.dbg_ts, (32768 + 8 * ncap) * sizeof(unsigned long long)));
         FW_HIP(ctx, hipMemset(ctx->g.dbg_ts, 0, (32768 + 8 * ncap) * sizeof(unsigned long long)));
@@ -416,7 +424,7 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         ctx->fc_len = ncap + (ncap / 64 + 2) * FW_FC_S2_STRIDE + 8;  // P | P2 | tag (64-bit words)
         FW_HIP(ctx, hipMalloc((void **)&ctx->d_fc, 3 * ctx->fc_len * sizeof(unsigned long long)));
         FW_HIP(ctx, hipMemset(ctx->d_fc, 0, 3 * ctx->fc_len * sizeof(unsigned long long)));
-        ctx->fc_ok = false;
+        ctx->fc_ok = false, ctx->boxes_epoch = 0;
         ctx->fc_dirty = false;
         ctx->tiles_cap = ncap;
     }
@@ -527,7 +535,7 @@ fw_status check_device_errors(fw_ctx *ctx) {
 
 fw_status grow_segment(fw_ctx *ctx, uint32_t si, uint32_t need) {
     SegHost &s = ctx->segs[si];
-    ctx->fc_ok = false;
+    ctx->fc_ok = false, ctx->boxes_epoch = 0;
     fw_status st = refresh_counts_exact(ctx);
     if (st) return st;
     uint32_t ncap = round_up(std::max<uint32_t>((uint32_t)std::min<uint64_t>((uint64_t)need * 5 / 4, 0xFFFF0000ull),
@@ -697,7 +705,7 @@ uint32_t pad4(uint32_t n) { return (n + 3u) & ~3u; }
 // builds the device tables (types, keys, emits, segments) of one spawner
 fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std::vector<uint64_t> *carry_serial) {
     SpawnerHost &sp = ctx->spawners[h];
-    ctx->fc_ok = false;
+    ctx->fc_ok = false, ctx->boxes_epoch = 0;
     ctx->tab_force = true;
     const uint32_t nt = d->n_particle_settings, ne = d->n_emission_settings;
     sp.uid = d->uid;
@@ -867,7 +875,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
 }
 
 fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
-    ctx->fc_ok = false;
+    ctx->fc_ok = false, ctx->boxes_epoch = 0;
     ctx->tab_force = true;
     for (int i = 0; i < kSnapRing; i++) ctx->snap_pending[i] = false;  // rows in flight describe the old segments
     for (const EmissionHost &e : sp.em) {
@@ -1148,6 +1156,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_DEBUG")) ctx->dbg = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_FORECAST")) ctx->use_forecast = atoi(m) != 0;
     if (const char *m = getenv("FW_STREAM")) ctx->use_stream = atoi(m) != 0;
+    if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
     if (const char *m = getenv("FW_OPS_ZEROCOPY")) ctx->ops_zerocopy = atoi(m) != 0;
     if (const char *m = getenv("FW_STATIC_NEW")) ctx->use_static_new = atoi(m) != 0;  // 0: always count + look back
     if (const char *m = getenv("FW_SNAP_EVERY")) ctx->snap_every = std::max(1, atoi(m));
@@ -1182,7 +1191,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
                      ctx->g.ndestroyed,   ctx->g.tile_cnt,      ctx->g.tile_off,      ctx->g.tile_status,
                      ctx->g.err,          ctx->g.stats,         ctx->g.nest_status,   ctx->g.nest_ticket,
                      ctx->d_aabb,         ctx->d_total,         ctx->d_segids,        ctx->g.dbg_ts,
-                     ctx->d_colliders};
+                     ctx->d_colliders,   ctx->g.tile_box};
     for (void *p : frees)
         if (p) hipFree(p);
     for (int i = 0; i < kParamRing; i++) {
@@ -1245,7 +1254,7 @@ fw_status fw_ctx_set_colliders(fw_ctx *ctx, const fw_collider *colliders, uint32
     if (n) FW_HIP(ctx, hipMemcpy(ctx->d_colliders, h.data(), n * sizeof(FwCollider), hipMemcpyHostToDevice));
     ctx->n_colliders = n;
     ctx->g.colliders = ctx->d_colliders, ctx->g.n_colliders = n;
-    ctx->fc_ok = false;
+    ctx->fc_ok = false, ctx->boxes_epoch = 0;
     return FW_OK;
 }
 
@@ -1609,6 +1618,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         ctx->live_ring_frames++;
     }
     a.new_static = (new_static && ctx->use_static_new) ? 1u : 0u;
+    a.boxes = (ctx->track_aabb && frame_mode == FW_MODE_FUSED) ? 1u : 0u;
     for (const SegHost &S : ctx->segs) a.any_inst |= (S.in_use && S.inst != nullptr) ? 1u : 0u;
     a.use_stream = ctx->use_stream ? 1u : 0u;
     uint32_t dt_bits;
@@ -1811,6 +1821,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     }
 
     ctx->fc_ok = fc_frame;
+    ctx->boxes_epoch = a.boxes ? a.epoch : 0u;
     ctx->fc_dt_bits = dt_bits;
     ctx->fc_tab_seq = ctx->tab_seq;
     ctx->parity ^= 1u;
@@ -1926,7 +1937,7 @@ fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, c
     fw_status st = sync(ctx);
     if (st) return st;
     const uint32_t si = sp->seg[type];
-    ctx->fc_ok = false;
+    ctx->fc_ok = false, ctx->boxes_epoch = 0;
     if (n > ctx->segs[si].capacity) {
         ctx->segs[si].ub = 0;
         const uint32_t zero = 0;
@@ -2038,9 +2049,15 @@ fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out
     if (!sp || !out_min || !out_max) return FW_EINVAL;
     hipSetDevice(ctx->device);
     if (!ctx->h_aabb) FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_aabb, 8 * sizeof(float), hipHostMallocDefault));
-    // two launches, the result lands in pinned memory: one synchronisation, no copies
-    FW_HIP(ctx, fw_launch_aabb(ctx->stream, ctx->g, sp->seg.data(), (uint32_t)sp->seg.size(), ctx->parity, ctx->d_aabb,
-                               ctx->h_aabb));
+    if (ctx->boxes_epoch && ctx->d_tile_first) {
+        // the last update left the box of every tile's survivors (fw_ctx_track_aabbs): fold those -- one small launch
+        FW_HIP(ctx, fw_launch_aabb_from_tiles(ctx->stream, ctx->g, sp->seg.data(), (uint32_t)sp->seg.size(), ctx->parity,
+                                              ctx->boxes_epoch, ctx->d_tile_first, ctx->h_aabb));
+    } else {
+        // two launches over the particles, the result lands in pinned memory: one synchronisation, no copies
+        FW_HIP(ctx, fw_launch_aabb(ctx->stream, ctx->g, sp->seg.data(), (uint32_t)sp->seg.size(), ctx->parity, ctx->d_aabb,
+                                   ctx->h_aabb));
+    }
     fw_status st = sync(ctx);
     if (!st) st = check_device_errors(ctx);
     if (st && st != FW_ECAPACITY) return st;
@@ -2048,6 +2065,13 @@ fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out
     if (any) *any = r[3] != 0.0f ? 1 : 0;
     for (int c = 0; c < 3; c++) out_min[c] = r[c], out_max[c] = r[4 + c];
     return st;
+}
+
+fw_status fw_ctx_track_aabbs(fw_ctx *ctx, int32_t enable) {
+    if (!ctx) return FW_EINVAL;
+    ctx->track_aabb = enable != 0;
+    if (!enable) ctx->boxes_epoch = 0;
+    return FW_OK;
 }
 
 fw_status fw_ctx_live_count(fw_ctx *ctx, uint64_t *out) {

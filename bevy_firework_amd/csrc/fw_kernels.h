@@ -22,6 +22,7 @@ struct FwGlobals {
     uint32_t *tile_cnt;              // split mode: survivors per tile
     uint32_t *tile_off;              // split mode: exclusive prefix per tile
     unsigned long long *tile_status; // fused mode: decoupled look-back words
+    float *tile_box;                 // [tiles][8] {min.xyz, epoch, max.xyz, -} of the survivors each tile stored (FwUpdateArgs::boxes)
     uint32_t *err;                   // sticky FW_ERR_* flags
     unsigned long long *stats;       // [0] particles that entered update (running total)
     unsigned long long *dbg_ts;      // FW_DEBUG & 8: 4 timestamps per tile of the last update (profiling)
@@ -83,6 +84,7 @@ struct FwUpdateArgs {
     // atomics cost ~0.7 us of a 25 us kernel), summed by every tile of the segment (at most 4 entries per lane).
     const uint4 *fce_in;
     uint4 *fce_out;
+    uint32_t boxes;    // 1: every tile also leaves the box of position -/+ scale of its survivors in FwGlobals::tile_box
     uint32_t fc_sums;  // 1: some segment exceeds FW_FC_DIRECT tiles -> this launch uses the sums (all segments)
     uint32_t fc_s2, fc_tag;
 };
@@ -113,5 +115,8 @@ hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t cap
 // seg_ids: host array; d_part: device scratch of 256 * 8 floats; h_out8: PINNED host {min.xyz, any, max.xyz, -}
 hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, uint32_t n_segs, uint32_t parity,
                           float *d_part, float *h_out8);
+// the same query answered from the per-tile boxes of the last update (epoch = that update's)
+hipError_t fw_launch_aabb_from_tiles(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, uint32_t n_segs,
+                                     uint32_t parity, uint32_t epoch, const uint32_t *d_seg_tile_first, float *h_out8);
 hipError_t fw_launch_total(hipStream_t s, const uint32_t *counts, uint32_t n_seg, unsigned long long *d_out);
 hipError_t fw_launch_copy_probe(hipStream_t s, const void *src, void *dst, size_t bytes);

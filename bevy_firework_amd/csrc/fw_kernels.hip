@@ -304,7 +304,8 @@ __device__ __forceinline__ fw_q4 fw_quat_step(fw_v3 v) {
 __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float *s_keys, float dt, float4 q0, float4 q1,
                                                    float4 q2, float4 q3, float age_new, const FwOutWin &W, uint32_t o,
                                                    float4 *rec = nullptr, const fw_v3 *cpos = nullptr,
-                                                   const fw_v3 *cvel = nullptr) {
+                                                   const fw_v3 *cvel = nullptr, float *box = nullptr,
+                                                   bool box_on = false) {
     const float lifetime = q3.w;
     const float age_percent = age_new / lifetime;
     const float scale_factor = fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_percent);
@@ -334,6 +335,12 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
     fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
     fw_st1w(W.s4, (o - W.first) * 4u, scale);
+    if (box_on) {  // update_aabbs (render.rs:677-703): running min / max of position -/+ scale, per lane
+        // (`box` always points at the caller's local array when box_on can be true: never selected against null, so it
+        // stays in registers)
+        box[0] = fminf(box[0], px - scale), box[1] = fminf(box[1], py - scale), box[2] = fminf(box[2], pz - scale);
+        box[3] = fmaxf(box[3], px + scale), box[4] = fmaxf(box[4], py + scale), box[5] = fmaxf(box[5], pz + scale);
+    }
     if (rec) {  // ParticleInstance {pos.xyz, scale, rot, base_color, emissive} (render.rs:95-103); `rec` may be in LDS
         rec[0] = make_float4(px, py, pz, scale), rec[1] = make_float4(nr.x, nr.y, nr.z, nr.w);
         rec[2] = make_float4(bc[0], bc[1], bc[2], bc[3]), rec[3] = make_float4(em[0], em[1], em[2], em[3]);
@@ -388,6 +395,43 @@ __device__ __forceinline__ void fw_store_destroyed(char *dbuf, const char *ib, u
     rec[17] = bc.x, rec[18] = bc.y, rec[19] = bc.z, rec[20] = bc.w;
     rec[21] = em.x, rec[22] = em.y, rec[23] = em.z, rec[24] = em.w;
     reinterpret_cast<int32_t *>(rec)[25] = pbr;
+}
+
+// AABB fused into the update (render.rs:677-703 reads every particle twice on the CPU each frame): the
+// lanes keep a running box of position -/+ scale over the survivors they store, the workgroup folds the lane boxes once
+// at the end of the tile and leaves {min.xyz, epoch, max.xyz, -} in its slot of a per-tile array.  fw_spawner_aabb then
+// folds a few hundred 32-byte tile boxes instead of re-reading 20 bytes of every particle.  min / max are exact and
+// order-independent: the result is bit-identical to the two-pass query.  `s_box`: NW x 6 floats of LDS.
+template <int NW>
+__device__ __forceinline__ void fw_tile_box_flush(float *tile_box, uint32_t tile, uint32_t epoch, const float (&box)[6],
+                                                  float (*s_box)[6]) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    float v[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        v[c] = box[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_xor(v[c], o, 64);
+            v[c] = c < 3 ? fminf(v[c], other) : fmaxf(v[c], other);
+        }
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int c = 0; c < 6; c++) s_box[wave][c] = v[c];
+    __syncthreads();
+    if (tid == 0) {
+        float r[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            r[c] = s_box[0][c];
+#pragma unroll
+            for (int w = 1; w < NW; w++) r[c] = c < 3 ? fminf(r[c], s_box[w][c]) : fmaxf(r[c], s_box[w][c]);
+        }
+        float4 *dst = reinterpret_cast<float4 *>(tile_box) + (size_t)tile * 2;
+        dst[0] = make_float4(r[0], r[1], r[2], __uint_as_float(epoch));
+        dst[1] = make_float4(r[3], r[4], r[5], 0.0f);
+    }
 }
 
 // SPAWN selects where this frame's Global spawn ops come from: none (already materialised by
@@ -863,6 +907,8 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     const FwOutWin W = fw_out_window(ob, C, excl);
     const uint32_t fcA = excl / FW_TILE, fc_bnd = (fcA + 1u) * FW_TILE;  // output tiles this workgroup feeds
     uint32_t fa = 0, fb = 0;
+    float box[6] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f, FW_F32_MIN, FW_F32_MIN, FW_F32_MIN};
+    const bool box_on = a.boxes != 0u;  // workgroup-uniform
     uint32_t run = excl;  // output slot of the first survivor of (round r, wave 0)
     const int n_rounds = (int)((lim - base + BLK - 1u) / BLK);  // a partial tile runs only the rounds that hold particles
 #pragma unroll 1
@@ -901,7 +947,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             fw_st1w(W.s4, (o - W.first) * 4u, q1c.w);
         } else if (alive) {
             float4 rec[4];
-            fw_integrate_store(T, s_keys, a.dt, q0, q1c, q2c, q3, age_new, W, o, INST ? rec : nullptr);
+            fw_integrate_store(T, s_keys, a.dt, q0, q1c, q2c, q3, age_new, W, o, INST ? rec : nullptr, nullptr, nullptr, box, box_on);
             if (INST && inst != nullptr && o < inst_cap) {  // this schedule is the rare one: plain per-lane records
                 fw_st4(inst, o * 4u + 0u, rec[0]), fw_st4(inst, o * 4u + 1u, rec[1]);
                 fw_st4(inst, o * 4u + 2u, rec[2]), fw_st4(inst, o * 4u + 3u, rec[3]);
@@ -947,7 +993,8 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         }
         if (alive) {
             float4 rec[4];
-            fw_integrate_store(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, o, INST ? rec : nullptr);
+            fw_integrate_store(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, o, INST ? rec : nullptr, nullptr, nullptr,
+                               box, box_on);
             if (INST && inst != nullptr && o < inst_cap) {
                 fw_st4(inst, o * 4u + 0u, rec[0]), fw_st4(inst, o * 4u + 1u, rec[1]);
                 fw_st4(inst, o * 4u + 2u, rec[2]), fw_st4(inst, o * 4u + 3u, rec[3]);
@@ -967,6 +1014,10 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             if (fc_small) a.fce_out[tile] = make_uint4(sa, sb, fcA, a.epoch);
             else fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, seg_tiles);
         }
+    }
+    if (a.boxes) {
+        __syncthreads();  // (s_lb doubles as the exchange area of the box fold)
+        fw_tile_box_flush<NW>(g.tile_box, tile, a.epoch, box, reinterpret_cast<float (*)[6]>(s_lb));
     }
 
     if ((a.dbg & 8u) && g.dbg_ts && tid == 0) {
@@ -1017,7 +1068,7 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
                                                 float age_new, uint32_t idx, uint32_t o, const char *ib, char *ob,
                                                 const FwOutWin &W, char *destroyed, bool want_destroyed, uint32_t C,
                                                 uint32_t n_lplanes, bool forecast, uint32_t fc_bnd, FwRoundOut &acc,
-                                                float4 *rec = nullptr) {
+                                                float4 *rec = nullptr, float *box = nullptr, bool box_on = false) {
     if (forecast) {  // will it survive one more step of the same dt?  (same expression as fw_survives)
         float an2;
         const bool nx = alive && fw_survives(age_new, dt, q3.w, &an2);
@@ -1031,7 +1082,7 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
         fw_st4w(W.q5, b16, q0), fw_st4w(W.q6, b16, q1);
         fw_st1w(W.s4, (o - W.first) * 4u, q1.w);
     } else if (alive) {
-        fw_integrate_store(T, s_keys, dt, q0, q1, q2, q3, age_new, W, o, rec);
+        fw_integrate_store(T, s_keys, dt, q0, q1, q2, q3, age_new, W, o, rec, nullptr, nullptr, box, box_on);
         for (uint32_t k = 0; k < n_lplanes; k++)  // new particles: vec![f32::MIN; n] (core.rs:467)
             fw_st1(ob + FW_OFF_L(C, k), o, loaded ? fw_ld1(ib + FW_OFF_L(C, k), idx) : FW_F32_MIN);
     } else if (valid && want_destroyed) {
@@ -1308,6 +1359,8 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
     const uint32_t fcA = excl / FW_TILE, fc_bnd = (fcA + 1u) * FW_TILE;
     FwRoundOut acc{0u, 0u};
+    float box[6] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f, FW_F32_MIN, FW_F32_MIN, FW_F32_MIN};
+    const bool box_on = a.boxes != 0u;  // workgroup-uniform
     excl = __builtin_amdgcn_readfirstlane(excl);  // workgroup-uniform (summed from LDS): keep it on the scalar unit
     const FwOutWin W = fw_out_window(ob, C, excl);
     uint32_t run = excl;
@@ -1342,7 +1395,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             // the lane's instance record goes to its rank in the wave's LDS area as soon as each part is computed
             float4 *rec = (INST && inst != nullptr) ? s_inst + wave * 256u + (o - wbase) * 4u : nullptr;
             fw_round_finish(T, s_keys, a.dt, a.dbg, q0c, q1c, q2c, q3c, valid, alive, true, age_new, idx, o, ib, ob, W,
-                            destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec);
+                            destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec, box, box_on);
             if (INST && inst != nullptr && !(a.dbg & 2u)) fw_inst_flush(inst, inst_cap, s_inst + wave * 256u, lane, m, wbase);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n;
             if ((a.dbg & 8u) && r == 0) tsR1 = __builtin_amdgcn_s_memrealtime() + (o & 0u);
@@ -1386,7 +1439,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             const uint32_t o = wbase + fw_lane_prefix(m);
             float4 *rec = (INST && inst != nullptr) ? s_inst + wave * 256u + (o - wbase) * 4u : nullptr;
             fw_round_finish(T, s_keys, a.dt, a.dbg, so.q0, so.q1, so.q2, so.q3, valid, alive, false, age_new, idx, o, ib,
-                            ob, W, destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec);
+                            ob, W, destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec, box, box_on);
             if (INST && inst != nullptr && !(a.dbg & 2u)) fw_inst_flush(inst, inst_cap, s_inst + wave * 256u, lane, m, wbase);
         }
     }
@@ -1399,6 +1452,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         if (fc_small) a.fce_out[tile] = make_uint4(sa, sb, fcA, a.epoch);
         else fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, seg_tiles);
     }
+    if (a.boxes) fw_tile_box_flush<NW>(g.tile_box, tile, a.epoch, box, reinterpret_cast<float (*)[6]>(s_lb));
     if ((a.dbg & 8u) && g.dbg_ts && tid == 0) {
         unsigned long long *d = g.dbg_ts + 32768 + ((size_t)(a.epoch & 1u) * gridDim.x + tile) * 8;  // two launches kept
         {  // ring of the last 256 launches: earliest start / latest end, spread over 64 words each to keep the atomics apart
@@ -1969,6 +2023,48 @@ __global__ __launch_bounds__(FW_AABB_BLOCKS) void fw_k_aabb_fold(FwGlobals g, Fw
     }
 }
 
+// fw_spawner_aabb from the per-tile boxes the last update left (fw_tile_box_flush): one workgroup folds the boxes of the
+// spawner's segments -- a few hundred 32-byte records -- and leaves {min.xyz, any, max.xyz, -} in pinned host memory.
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb_from_tiles(FwGlobals g, FwSegList L, uint32_t parity, uint32_t epoch,
+                                                                 const uint32_t *seg_tile_first, float *host8) {
+    __shared__ float s_m[FW_BLOCK / 64][6];
+    float v[6] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f, FW_F32_MIN, FW_F32_MIN, FW_F32_MIN};
+    const float4 *boxes = reinterpret_cast<const float4 *>(g.tile_box);
+    for (uint32_t k = 0; k < L.n; k++) {
+        const uint32_t seg = L.id[k];
+        const uint32_t t0 = seg_tile_first[seg], t1 = seg_tile_first[seg + 1];
+        for (uint32_t t = t0 + threadIdx.x; t < t1; t += FW_BLOCK) {
+            const float4 lo = boxes[(size_t)t * 2], hi = boxes[(size_t)t * 2 + 1];
+            if (__float_as_uint(lo.w) != epoch) continue;  // a tile that held no particles in the last update
+            v[0] = fminf(v[0], lo.x), v[1] = fminf(v[1], lo.y), v[2] = fminf(v[2], lo.z);
+            v[3] = fmaxf(v[3], hi.x), v[4] = fmaxf(v[4], hi.y), v[5] = fmaxf(v[5], hi.z);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_xor(v[c], o, 64);
+            v[c] = c < 3 ? fminf(v[c], other) : fmaxf(v[c], other);
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int c = 0; c < 6; c++) s_m[wave][c] = v[c];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const uint32_t c = threadIdx.x;
+        float r = s_m[0][c];
+        for (uint32_t w = 1; w < FW_BLOCK / 64; w++) r = c < 3 ? fminf(r, s_m[w][c]) : fmaxf(r, s_m[w][c]);
+        host8[c < 3 ? c : c + 1u] = r;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t any = 0;
+        for (uint32_t k = 0; k < L.n; k++) any |= g.count[parity * g.max_seg + L.id[k]];
+        host8[3] = any ? 1.0f : 0.0f;
+    }
+}
+
 __global__ void fw_k_total(const uint32_t *counts, uint32_t n_seg, unsigned long long *out) {
     __shared__ unsigned long long s[4];
     unsigned long long t = 0;
@@ -2129,6 +2225,16 @@ hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg
     for (uint32_t i = 0; i < n_segs; i++) L.id[i] = seg_ids[i];
     hipLaunchKernelGGL(fw_k_aabb, dim3(FW_AABB_BLOCKS), dim3(FW_BLOCK), 0, s, g, L, parity, d_part);
     hipLaunchKernelGGL(fw_k_aabb_fold, dim3(1), dim3(FW_AABB_BLOCKS), 0, s, g, L, parity, (const float *)d_part, h_out8);
+    return hipGetLastError();
+}
+
+hipError_t fw_launch_aabb_from_tiles(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, uint32_t n_segs,
+                                     uint32_t parity, uint32_t epoch, const uint32_t *d_seg_tile_first, float *h_out8) {
+    if (!n_segs || n_segs > 8u) return hipErrorInvalidValue;  // FW_MAX_TYPES
+    FwSegList L{};
+    L.n = n_segs;
+    for (uint32_t i = 0; i < n_segs; i++) L.id[i] = seg_ids[i];
+    hipLaunchKernelGGL(fw_k_aabb_from_tiles, dim3(1), dim3(FW_BLOCK), 0, s, g, L, parity, epoch, d_seg_tile_first, h_out8);
     return hipGetLastError();
 }
 

@@ -246,6 +246,11 @@ class ParticleSystem:
                 for fn in d.on_finished:
                     fn(d)
 
+    def track_aabbs(self, enable: bool = True) -> None:
+        """AABB fused into the update (render.rs:677-703): every tile leaves the box of its survivors; `aabb()` folds
+        those instead of re-reading the particles."""
+        self._check(self._lib.fw_ctx_track_aabbs(self._ctx, 1 if enable else 0))
+
     # -- statistics / measurement ----------------------------------------------------------------
     def live_count(self) -> int:
         out = C.c_uint64()

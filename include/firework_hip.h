@@ -227,6 +227,12 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
 fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap);
 /* update_aabbs reduction (render.rs:677-703), world space; *any = 0 when no particles */
 fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out_max[3], int32_t *any);
+/* AABB fused into the update: from the next fw_step on, every tile of the update kernel also leaves the box of
+ * position -/+ scale of the survivors it stored (no extra pass over the particles, no extra launch in the frame);
+ * fw_spawner_aabb then folds a few hundred 32-byte tile boxes instead of re-reading every particle.  Same result bit for
+ * bit.  Frames with colliding particle types, and queries after the state was touched outside fw_step, fall back to the
+ * two-pass reduction. */
+fw_status fw_ctx_track_aabbs(fw_ctx *ctx, int32_t enable);
 
 /* ---- whole-context statistics ---------------------------------------------------- */
 /* total live particles over all spawners (host value; synchronises) */

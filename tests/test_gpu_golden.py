@@ -403,3 +403,45 @@ def test_particles_that_emit_onto_their_own_type(system):
             pair.check(exact_all=True, what=f"self-nested frame {fr}")
             assert np.array_equal(pair.gpu.last_emitted(0, 1), pair.cpu.last_emitted(0, 1))
     assert pair.gpu.count(0) > 3000  # well beyond what the Global entry alone sustains (2500/s x 0.45 s)
+
+
+def test_aabb_fused_into_the_update_matches_the_two_pass_query(system):
+    """fw_ctx_track_aabbs: the update kernels leave the box of position -/+ scale of every tile's survivors and
+    fw_spawner_aabb folds those tile boxes; the two-pass reduction over the stored planes (and numpy over the read-back
+    particles) must give the same box bit for bit -- forecast frames, a changed dt (look-back kernel), a Nested spawner
+    (materialised tiles), thousands of particles in several tiles, a tiny spawner (new particles riding in the live tile),
+    an empty one, and the fallback after the state was touched outside fw_step"""
+    from bevy_firework_amd import workloads
+
+    big, tf = workloads.stress_test(rate=40000.0)
+    nest, tfn = workloads.nested(spark_rate=2000.0, smoke_per_spark=10.0)
+    tiny = S.ParticleSpawner([S.ParticleSettings(lifetime=S.RandF32(0.2, 0.5))],
+                             [S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(300.0),
+                                                 emission_shape=S.EmissionShape.Sphere(0.4))])
+    idle = S.ParticleSpawner([S.ParticleSettings()], [S.EmissionSettings(emission_pacing=S.EmissionPacing.OnDemand())])
+    hs = [system.spawn(big, tf, uid=1), system.spawn(nest, tfn, uid=2), system.spawn(tiny, S.Transform((5.0, 0.0, 1.0)), uid=3),
+          system.spawn(idle, uid=4)]
+    system.track_aabbs(True)
+    dts = [1 / 60] * 20 + [1 / 45, 1 / 60, 1 / 75] + [1 / 60] * 15
+    for i, dt in enumerate(dts):
+        system.update(np.float32(dt))
+        if i % 4 == 3 or i in (20, 21, 22):
+            fused = [h.aabb() for h in hs]
+            system.track_aabbs(False)  # drops the tile boxes: the same query now re-reads the particles
+            twopass = [h.aabb() for h in hs]
+            system.track_aabbs(True)
+            for h, (a1, mn1, mx1), (a2, mn2, mx2) in zip(hs, fused, twopass):
+                assert a1 == a2 and np.array_equal(mn1, mn2) and np.array_equal(mx1, mx2), (i, h.handle, mn1, mn2, mx1, mx2)
+                if a1:
+                    p = np.concatenate([h.particles(t) for t in range(len(h.settings.particle_settings))])
+                    assert np.array_equal(mn1, (p["position"] - p["scale"][:, None]).min(axis=0))
+                    assert np.array_equal(mx1, (p["position"] + p["scale"][:, None]).max(axis=0))
+            # (tracking was re-enabled after a frame without boxes: the next query must not use stale ones)
+            assert hs[0].aabb()[0]
+    assert not hs[3].aabb()[0] and hs[1].counts()[1] > 1000
+    # state rewritten by the caller: the boxes of the last update no longer describe it
+    p = hs[0].particles(0)[:100].copy()
+    p["position"] += np.float32(100.0)
+    hs[0].write_particles(0, p)
+    a, mn, mx = hs[0].aabb()
+    assert a and mn[0] > 90.0

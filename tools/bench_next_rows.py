@@ -39,6 +39,15 @@ for name, rate in (("1M live", 1.0e6), ("8M live", 8.0e6)):
     for _ in range(20):
         h.aabb()
     t_aabb = (time.perf_counter() - t0) / 20
+    # the same query with the boxes fused into the update (fw_ctx_track_aabbs): one frame to produce them, then fold
+    ps.track_aabbs(True)
+    ps.step(dt)
+    ps.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        h.aabb()
+    t_aabb_fused = (time.perf_counter() - t0) / 20
+    ps.track_aabbs(False)
     # a frame as the renderer sees it: step + pack
     ps.synchronize()
     t0 = time.perf_counter()
@@ -62,5 +71,6 @@ for name, rate in (("1M live", 1.0e6), ("8M live", 8.0e6)):
                       "fused_GBps_228B": live * 228 / t_fused / 1e9,
                       "pack_us": t_pack * 1e6, "pack_GBps_132B": live * 132 / t_pack / 1e9,
                       "aabb_call_us (incl. count readback + sync)": t_aabb * 1e6,
+                      "aabb_call_us with boxes fused into the update": t_aabb_fused * 1e6,
                       "step_plus_pack_us": t_frame * 1e6}))
     ps.close()
