@@ -119,6 +119,10 @@ struct alignas(64) SegHost {
             v[(head + n) & (uint32_t)(v.size() - 1)] = x, n++;
         }
     } win;
+    // colours of the type at age 0: what both colour planes are filled with when the buffers are allocated, so that a
+    // constant gradient's plane never has to be written by the update (FwOutWin::wr5 / wr6)
+    float fill_bc[4] = {0, 0, 0, 0}, fill_em[4] = {0, 0, 0, 0};
+    bool colors_dirty = false;  // the caller wrote particles (any colours) into the current buffer
 };
 
 struct SpawnerHost {
@@ -247,6 +251,7 @@ struct fw_ctx {
     // the state or the tile table since
     bool track_aabb = false;
     uint32_t boxes_epoch = 0;  // epoch of the update that left valid boxes (0 = none)
+    bool colors_dirty = false; // some SegHost::colors_dirty is set
 
     uint32_t nest_seq = 0;  // launches of fw_k_nest so far (tag of their look-back words)
     // FW_HOST_PROF=1: time spent in the sections of fw_step's host half (printed when the context is destroyed)
@@ -491,6 +496,8 @@ fw_status alloc_seg_buffers(fw_ctx *ctx, SegHost &s, uint32_t capacity, bool wan
         e = hipMalloc((void **)&s.destroyed, (size_t)capacity * sizeof(fw_particle));
         if (e != hipSuccess) return fail(ctx, FW_ENOMEM, "hipMalloc destroyed buffer");
     }
+    FW_HIP(ctx, fw_launch_fill_colors(ctx->stream, s.buf[0], s.buf[1], capacity, s.fill_bc, s.fill_em));
+    FW_HIP(ctx, hipStreamSynchronize(ctx->stream));  // callers go on with blocking copies on the null stream
     return FW_OK;
 }
 
@@ -810,6 +817,11 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         S.collides = p.collision.enabled != 0;
         S.life_bound = (double)std::max(p.lifetime.min, p.lifetime.max);  // lifetime = lerp(min, max, u), u in [0, 1)
         S.win_ok = !S.nested_fed && std::isfinite(S.life_bound);
+        for (int c = 0; c < 4; c++) {  // the first key is the colour at age 0 (and, for one key, at every age)
+            S.fill_bc[c] = T.base.values.empty() ? 0.f : T.base.values[c];
+            S.fill_em[c] = T.emis.values.empty() ? 0.f : T.emis.values[c];
+        }
+        S.colors_dirty = false;
         if ((st = alloc_seg_buffers(ctx, S, caps[t], p.report_destroyed != 0))) return st;
         if ((st = upload_seg(ctx, si))) return st;
         const uint32_t zero2[2] = {0, 0};
@@ -1619,6 +1631,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     }
     a.new_static = (new_static && ctx->use_static_new) ? 1u : 0u;
     a.boxes = (ctx->track_aabb && frame_mode == FW_MODE_FUSED) ? 1u : 0u;
+    a.force_colors = ctx->colors_dirty ? 1u : 0u;
     for (const SegHost &S : ctx->segs) a.any_inst |= (S.in_use && S.inst != nullptr) ? 1u : 0u;
     a.use_stream = ctx->use_stream ? 1u : 0u;
     uint32_t dt_bits;
@@ -1807,6 +1820,17 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                                  frame_mode, timed ? ctx->tev[ctx->tev_used] : nullptr,
                                  timed ? ctx->tev[ctx->tev_used + 1] : nullptr));
     if (timed) ctx->tev_used += 2;
+    if (ctx->colors_dirty) {
+        // that update wrote every colour of its output; the buffer it read (next frame's output) may still hold the
+        // caller's colours past the survivors: back to the fill value, after which constant planes are skipped again
+        for (uint32_t i = 0; i < n_seg; i++) {
+            SegHost &S = ctx->segs[i];
+            if (!S.in_use || !S.colors_dirty) continue;
+            FW_HIP(ctx, fw_launch_fill_colors(ctx->stream, S.buf[ctx->parity], nullptr, S.capacity, S.fill_bc, S.fill_em));
+            S.colors_dirty = false;
+        }
+        ctx->colors_dirty = false;
+    }
     prof(6);
     if (slot >= 0) {
         FW_HIP(ctx, hipEventRecord(ctx->ev_consumed[slot], ctx->stream));
@@ -1958,6 +1982,7 @@ fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, c
     FW_HIP(ctx, hipMemcpy(ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, &n32, 4, hipMemcpyHostToDevice));
     S.ub = n32;
     S.win_ok = false;  // ages and lifetimes are now whatever the caller wrote
+    S.colors_dirty = true, ctx->colors_dirty = true;  // and so are the colours: the next update writes them all
     for (int i = 0; i < kSnapRing; i++) ctx->snap_pending[i] = false;
     return FW_OK;
 }

@@ -84,6 +84,7 @@ struct FwUpdateArgs {
     // atomics cost ~0.7 us of a 25 us kernel), summed by every tile of the segment (at most 4 entries per lane).
     const uint4 *fce_in;
     uint4 *fce_out;
+    uint32_t force_colors;  // 1: write base / emissive colour even for constant gradients (the caller rewrote particles)
     uint32_t boxes;    // 1: every tile also leaves the box of position -/+ scale of its survivors in FwGlobals::tile_box
     uint32_t fc_sums;  // 1: some segment exceeds FW_FC_DIRECT tiles -> this launch uses the sums (all segments)
     uint32_t fc_s2, fc_tag;
@@ -110,6 +111,8 @@ hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d
 hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t n, int32_t pbr, void *d_out);
 hipError_t fw_launch_scatter(hipStream_t s, char *buf, uint32_t capacity, uint32_t n, uint32_t n_lplanes,
                              const void *d_in);
+// fills the base / emissive colour planes of one (buf1 == nullptr) or both buffers of a segment (capacity slots each)
+hipError_t fw_launch_fill_colors(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, const float bc[4], const float em[4]);
 hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, const uint32_t *d_count,
                                     uint32_t n_upper, void *d_out);
 // seg_ids: host array; d_part: device scratch of 256 * 8 floats; h_out8: PINNED host {min.xyz, any, max.xyz, -}

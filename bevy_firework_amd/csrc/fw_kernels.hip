@@ -116,11 +116,17 @@ __device__ __forceinline__ uint32_t fw_ld1u(const uint32_t *base, uint32_t idx) 
 struct FwOutWin {  // output planes advanced to slot `first` (workgroup-uniform)
     char *q0, *q1, *q2, *q3, *q5, *q6, *s4;
     uint32_t first;
+    // A gradient with a single key (the reference's default emissive colour, core.rs:205) gives every particle of the
+    // type the same colour for ever: both buffers of the segment are filled with it once (fw_k_fill_colors) and the
+    // update does not write that plane again -- 16 of its 164 bytes per particle per constant gradient.  wr5 / wr6:
+    // this launch writes base_color / emissive_color (always true for a few frames after the caller rewrote particles).
+    bool wr5, wr6;
 };
-__device__ __forceinline__ FwOutWin fw_out_window(char *ob, uint32_t C, uint32_t first) {
+__device__ __forceinline__ FwOutWin fw_out_window(char *ob, uint32_t C, uint32_t first, const FwType &T, uint32_t force_colors) {
     const size_t f16 = (size_t)first * 16u;
     return FwOutWin{ob + FW_OFF_Q0(C) + f16, ob + FW_OFF_Q1(C) + f16, ob + FW_OFF_Q2(C) + f16, ob + FW_OFF_Q3(C) + f16,
-                    ob + FW_OFF_Q5(C) + f16, ob + FW_OFF_Q6(C) + f16, ob + FW_OFF_S4(C) + (size_t)first * 4u, first};
+                    ob + FW_OFF_Q5(C) + f16, ob + FW_OFF_Q6(C) + f16, ob + FW_OFF_S4(C) + (size_t)first * 4u, first,
+                    T.bc_kind != 0 || force_colors != 0u, T.em_kind != 0 || force_colors != 0u};
 }
 
 // alive test of update_particles: `if particle.age >= particle.lifetime { destroyed }` (core.rs:594-599)
@@ -332,8 +338,8 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     fw_st4w(W.q1, b16, make_float4(vx, vy, vz, q1.w));
     fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
     fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
-    fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
-    fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
+    if (W.wr5) fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));  // workgroup-uniform branches
+    if (W.wr6) fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
     fw_st1w(W.s4, (o - W.first) * 4u, scale);
     if (box_on) {  // update_aabbs (render.rs:677-703): running min / max of position -/+ scale, per lane
         // (`box` always points at the caller's local array when box_on can be true: never selected against null, so it
@@ -904,7 +910,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     // ---- phase 3: round loop -- integrate survivors, store them at their compacted slot
     const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
     excl = __builtin_amdgcn_readfirstlane(excl);  // workgroup-uniform: keep it on the scalar unit
-    const FwOutWin W = fw_out_window(ob, C, excl);
+    const FwOutWin W = fw_out_window(ob, C, excl, T, a.force_colors);
     const uint32_t fcA = excl / FW_TILE, fc_bnd = (fcA + 1u) * FW_TILE;  // output tiles this workgroup feeds
     uint32_t fa = 0, fb = 0;
     float box[6] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f, FW_F32_MIN, FW_F32_MIN, FW_F32_MIN};
@@ -1362,7 +1368,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     float box[6] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f, FW_F32_MIN, FW_F32_MIN, FW_F32_MIN};
     const bool box_on = a.boxes != 0u;  // workgroup-uniform
     excl = __builtin_amdgcn_readfirstlane(excl);  // workgroup-uniform (summed from LDS): keep it on the scalar unit
-    const FwOutWin W = fw_out_window(ob, C, excl);
+    const FwOutWin W = fw_out_window(ob, C, excl, T, a.force_colors);
     uint32_t run = excl;
     int rr = 0;  // rounds done so far (the wave-count exchange area is double-buffered by round parity)
     if (loaded_tile) {
@@ -1557,7 +1563,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpda
     const bool coll = (TC.coll_flags & FW_COLL_ENABLED) != 0u, coll_kill = (TC.coll_flags & FW_COLL_DESTROY) != 0u;
     const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
     const uint32_t excl = g.tile_off[tile];
-    const FwOutWin W = fw_out_window(ob, C, excl);
+    const FwOutWin W = fw_out_window(ob, C, excl, T, a.force_colors);
     uint32_t run = excl;
     const uint32_t lim = min(base + FW_TILE, n_tot);
     const int n_rounds = (int)((lim - base + FW_BLOCK - 1u) / FW_BLOCK);
@@ -1898,6 +1904,15 @@ __global__ void fw_k_scatter(char *buf, uint32_t C, uint32_t n, uint32_t n_lplan
     for (uint32_t k = 0; k < n_lplanes; k++) reinterpret_cast<float *>(buf + FW_OFF_L(C, k))[i] = FW_F32_MIN;
 }
 
+// both colour planes of a fresh buffer pair filled with the type's colours at age 0: for a constant gradient that is
+// the colour of every particle for ever (FwOutWin::wr5 / wr6), for any other it is simply overwritten
+__global__ void fw_k_fill_colors(char *buf0, char *buf1, uint32_t C, float4 bc, float4 em) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    fw_st4(buf0 + FW_OFF_Q5(C), i, bc), fw_st4(buf0 + FW_OFF_Q6(C), i, em);
+    if (buf1) fw_st4(buf1 + FW_OFF_Q5(C), i, bc), fw_st4(buf1 + FW_OFF_Q6(C), i, em);
+}
+
 // ParticleInstance packing (reference src/render.rs:95-115): {pos, scale, rot, base, emissive}
 // SoA planes -> ParticleInstance records (render.rs:95-115).  Loads are plane-wise coalesced; the 64-byte records are
 // transposed through LDS so that every store instruction of a wave writes 1 KiB of consecutive bytes (a lane writing
@@ -2205,6 +2220,13 @@ hipError_t fw_launch_scatter(hipStream_t s, char *buf, uint32_t capacity, uint32
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(fw_k_scatter, dim3((n + 255) / 256), dim3(256), 0, s, buf, capacity, n, n_lplanes,
                        (const float *)d_in);
+    return hipGetLastError();
+}
+
+hipError_t fw_launch_fill_colors(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, const float bc[4], const float em[4]) {
+    if (!capacity) return hipSuccess;
+    hipLaunchKernelGGL(fw_k_fill_colors, dim3((capacity + 255) / 256), dim3(256), 0, s, buf0, buf1, capacity,
+                       make_float4(bc[0], bc[1], bc[2], bc[3]), make_float4(em[0], em[1], em[2], em[3]));
     return hipGetLastError();
 }
 

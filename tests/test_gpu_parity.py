@@ -153,6 +153,33 @@ def test_variable_dt_switches_between_forecast_and_lookback(system):
     assert pair.gpu.count(0) > 20000
 
 
+def test_constant_colour_planes_survive_caller_written_colours(system):
+    """a one-key gradient's colour plane is filled once and not written by the update (FwOutWin::wr5 / wr6); particles
+    the caller writes may carry ANY colour, in slots later reused by new particles: every colour must still be the
+    reference's (the gradient sampled each update, core.rs:640-646), on both buffers, with and without the forecast"""
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.05, 0.5), base_color=S.FireworkGradient.constant((0.25, 0.5, 0.75, 1.0)))
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(60000.0),
+                            initial_velocity=S.RandVec3(S.RandF32(0.0, 3.0), (0.0, 1.0, 0.0), 0.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [es]), seed=SEED, uid=77)
+    run(system, pair, 20, check_every=20, exact_all=True)
+    rng = np.random.default_rng(5)
+    for rep in range(3):
+        parts = pair.cpu.particles(0).copy()
+        parts = np.concatenate([parts, parts, parts])[: 40000 + 1000 * rep]   # more than are live: slots past the survivors
+        parts["base_color"] = rng.uniform(0.0, 9.0, size=(len(parts), 4)).astype(np.float32)
+        parts["emissive_color"] = rng.uniform(0.0, 9.0, size=(len(parts), 4)).astype(np.float32)
+        parts["age"][::2] = parts["lifetime"][::2]                             # half of them die in the next update
+        pair.gpu.write_particles(0, parts)
+        pair.cpu.write_particles(0, parts)
+        got = pair.gpu.particles(0)                                            # until then they read back as written
+        assert np.array_equal(got["base_color"], parts["base_color"]) and np.array_equal(got["emissive_color"], parts["emissive_color"])
+        for i in range(5 + rep):
+            system.update(DT)
+            pair.step_cpu(DT)
+            pair.check(exact_all=True, what=f"rep {rep} after write {i}")
+    assert pair.gpu.count(0) > 10000
+
+
 def test_two_types_two_emitters_and_modifier(system):
     p0 = S.ParticleSettings(lifetime=S.RandF32(0.5, 0.7), linear_drag=0.5)
     p1 = S.ParticleSettings(lifetime=S.RandF32.constant(0.25), acceleration=(0.0, 1.0, 0.0),
