@@ -39,6 +39,8 @@ constexpr uint32_t kMinCapacity = 4096;
 constexpr uint32_t kNoSeg = 0xFFFFFFFFu;  // SpawnerHost::seg entry not built yet
 constexpr uint64_t kMaxSpawnPerOp = 1ull << 30;
 constexpr uint32_t kTimingEvents = 4096;
+constexpr uint32_t kMaxFifoSegs = FW_FIFO_PER_LAUNCH;  // FIFO segments per context: one launch (beyond: the general path)
+constexpr size_t kMaxCohorts = 16384;    // spawn cohorts a FIFO segment tracks before it gives the mode up (tiny dt)
 
 std::string g_create_error;
 
@@ -123,6 +125,19 @@ struct alignas(64) SegHost {
     // constant gradient's plane never has to be written by the update (FwOutWin::wr5 / wr6)
     float fill_bc[4] = {0, 0, 0, 0}, fill_em[4] = {0, 0, 0, 0};
     bool colors_dirty = false;  // the caller wrote particles (any colours) into the current buffer
+    // FIFO ring (fw_kernels.h: FwFifoSeg): a type with a single lifetime value, Global emission only, no collisions.
+    // ONE buffer (buf[0] == buf[1]); logical particle i sits in slot (head + i) mod capacity; `ub` is the EXACT live
+    // count.  The host replays the fp32 age of every spawn cohort (same additions as the device), which tells it how
+    // many particles each update destroys -- always the oldest ones.
+    bool fifo = false;
+    uint32_t head = 0;
+    float fifo_life = 0.f;  // the lifetime every particle of the type gets (core.rs:455 with min == max)
+    int32_t fifo_wm = 0;    // FwFifoArgs::write_mask of the type
+    struct Cohort {
+        uint32_t n;
+        float age;
+    };
+    std::deque<Cohort> coh;  // oldest first
 };
 
 struct SpawnerHost {
@@ -252,6 +267,14 @@ struct fw_ctx {
     bool track_aabb = false;
     uint32_t boxes_epoch = 0;  // epoch of the update that left valid boxes (0 = none)
     bool colors_dirty = false; // some SegHost::colors_dirty is set
+    bool use_fifo = true;      // FW_FIFO=0: constant-lifetime types take the general (compacting) path too (A/B, tests)
+    uint32_t fifo_rounds = 4;  // ring tile of the FIFO launch in rounds of FW_BLOCK (FW_FIFO_ROUNDS: 1, 2, 4)
+    // smallest (derived or given) capacity that makes a type a FIFO ring: the mode costs a launch of its own next to the
+    // general one, which only large segments repay (FW_FIFO_MIN; tests set 0)
+    uint32_t fifo_min = 131072;
+    uint32_t n_fifo = 0;       // FIFO segments in use (at most kMaxFifoSegs: their records travel in kernel arguments)
+    std::vector<FwOp> fifo_ops;  // this frame's Global ops that feed FIFO segments
+    uint64_t tev_frames = 0;   // frames timed so far (a frame may take several update launches)
 
     uint32_t nest_seq = 0;  // launches of fw_k_nest so far (tag of their look-back words)
     // FW_HOST_PROF=1: time spent in the sections of fw_step's host half (printed when the context is destroyed)
@@ -375,7 +398,7 @@ uint32_t seg_live_tiles(const SegHost &s) {
     return (live_ub + FW_TILE - 1) / FW_TILE;
 }
 uint32_t seg_tiles(const SegHost &s, uint32_t vt_rounds = 1) {
-    if (!s.in_use) return 0;
+    if (!s.in_use || s.fifo) return 0;  // (FIFO segments have their own launch: fw_k_update_fifo)
     const uint32_t vtile = vt_rounds * FW_VTILE;
     if (!s.nested_fed && s.frame_spawn <= FW_VTILE) {
         // At most one round of new particles: they ride in the last live tile whenever it has room for them (both
@@ -397,7 +420,7 @@ uint32_t choose_vt_rounds(const fw_ctx *ctx);
 fw_status ensure_tile_arrays(fw_ctx *ctx) {
     size_t tiles = 0, nest_tiles = 0, nest_ops = 0;
     for (auto &s : ctx->segs)
-        if (s.in_use) tiles += (s.capacity + FW_VTILE - 1) / FW_VTILE + 2;  // worst case: every slot a new particle
+        if (s.in_use && !s.fifo) tiles += (s.capacity + FW_VTILE - 1) / FW_VTILE + 2;  // worst case: every slot a new particle
     for (auto &sp : ctx->spawners) {
         if (!sp.alive) continue;
         for (auto &e : sp.em)
@@ -486,17 +509,17 @@ fw_status upload_seg(fw_ctx *ctx, uint32_t si) {
 fw_status alloc_seg_buffers(fw_ctx *ctx, SegHost &s, uint32_t capacity, bool want_destroyed) {
     const size_t bytes = FW_BUF_BYTES((size_t)capacity, s.n_lplanes);
     char *b = nullptr;
-    hipError_t e = hipMalloc((void **)&b, bytes * 2);
+    hipError_t e = hipMalloc((void **)&b, bytes * (s.fifo ? 1 : 2));  // a FIFO ring is updated in place: one buffer
     if (e != hipSuccess) return fail(ctx, FW_ENOMEM, std::string("hipMalloc particle buffers: ") + hipGetErrorString(e));
     s.buf[0] = b;
-    s.buf[1] = b + bytes;
+    s.buf[1] = s.fifo ? b : b + bytes;
     s.capacity = capacity;
     s.destroyed = nullptr;
     if (want_destroyed) {
         e = hipMalloc((void **)&s.destroyed, (size_t)capacity * sizeof(fw_particle));
         if (e != hipSuccess) return fail(ctx, FW_ENOMEM, "hipMalloc destroyed buffer");
     }
-    FW_HIP(ctx, fw_launch_fill_colors(ctx->stream, s.buf[0], s.buf[1], capacity, s.fill_bc, s.fill_em));
+    FW_HIP(ctx, fw_launch_fill_colors(ctx->stream, s.buf[0], s.fifo ? nullptr : s.buf[1], capacity, s.fill_bc, s.fill_em));
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));  // callers go on with blocking copies on the null stream
     return FW_OK;
 }
@@ -540,25 +563,36 @@ fw_status check_device_errors(fw_ctx *ctx) {
     return FW_OK;  // FW_ERR_LOOKBACK_TIMEOUT is informational: the fallback path produced the same result
 }
 
-fw_status grow_segment(fw_ctx *ctx, uint32_t si, uint32_t need) {
+// moves a segment into freshly allocated buffers of `ncap` slots: its live particles, in order, from slot 0 (a FIFO ring
+// is unwrapped); make_general: a FIFO segment leaves that mode (two buffers, compacting update) on the way
+fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_general) {
     SegHost &s = ctx->segs[si];
     ctx->fc_ok = false, ctx->boxes_epoch = 0;
     fw_status st = refresh_counts_exact(ctx);
     if (st) return st;
-    uint32_t ncap = round_up(std::max<uint32_t>((uint32_t)std::min<uint64_t>((uint64_t)need * 5 / 4, 0xFFFF0000ull),
-                                                s.capacity * 2),
-                             FW_TILE);
     SegHost old = s;
+    if (make_general && s.fifo) {
+        s.fifo = false, s.coh.clear();
+        ctx->n_fifo--;
+        ctx->tab_force = true;
+    }
     st = alloc_seg_buffers(ctx, s, ncap, old.destroyed != nullptr);
     if (st) {
+        if (old.fifo && !s.fifo) ctx->n_fifo++;
         s = old;
         return st;
     }
+    s.head = 0;
     const uint32_t p = ctx->parity;
     const uint32_t n = old.ub;  // exact after the refresh
+    const uint32_t h = old.fifo ? old.head : 0u;
+    const uint32_t n1 = std::min<uint32_t>(n, old.capacity - h);  // up to the end of the old buffer, then from its slot 0
     auto cp = [&](size_t noff, size_t ooff, size_t elem) -> hipError_t {
-        if (!n) return hipSuccess;
-        return hipMemcpy(s.buf[p] + noff, old.buf[p] + ooff, (size_t)n * elem, hipMemcpyDeviceToDevice);
+        hipError_t e = hipSuccess;
+        if (n1) e = hipMemcpy(s.buf[p] + noff, old.buf[p] + ooff + (size_t)h * elem, (size_t)n1 * elem, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess && n > n1)
+            e = hipMemcpy(s.buf[p] + noff + (size_t)n1 * elem, old.buf[p] + ooff, (size_t)(n - n1) * elem, hipMemcpyDeviceToDevice);
+        return e;
     };
     const size_t OC = old.capacity, NC = ncap;
     FW_HIP(ctx, cp(FW_OFF_Q0(NC), FW_OFF_Q0(OC), 16));
@@ -569,10 +603,32 @@ fw_status grow_segment(fw_ctx *ctx, uint32_t si, uint32_t need) {
     FW_HIP(ctx, cp(FW_OFF_Q6(NC), FW_OFF_Q6(OC), 16));
     FW_HIP(ctx, cp(FW_OFF_S4(NC), FW_OFF_S4(OC), 4));
     for (uint32_t k = 0; k < s.n_lplanes; k++) FW_HIP(ctx, cp(FW_OFF_L(NC, k), FW_OFF_L(OC, k), 4));
+    if (old.destroyed)  // the records of the last update stay readable (fw_spawner_read_destroyed)
+        FW_HIP(ctx, hipMemcpy(s.destroyed, old.destroyed, (size_t)std::min(old.capacity, ncap) * sizeof(fw_particle),
+                              hipMemcpyDeviceToDevice));
     FW_HIP(ctx, hipFree(old.buf[0]));
     if (old.destroyed) FW_HIP(ctx, hipFree(old.destroyed));
     if ((st = upload_seg(ctx, si))) return st;
     return ensure_tile_arrays(ctx);
+}
+
+fw_status grow_segment(fw_ctx *ctx, uint32_t si, uint32_t need) {
+    const SegHost &s = ctx->segs[si];
+    const uint32_t ncap = round_up(std::max<uint32_t>((uint32_t)std::min<uint64_t>((uint64_t)need * 5 / 4, 0xFFFF0000ull),
+                                                      s.capacity * 2),
+                                   FW_TILE);
+    return realloc_segment(ctx, si, ncap, false);
+}
+
+// a FIFO segment whose premise no longer holds (the caller wrote particles, dt went negative or non-finite, ...)
+// continues as an ordinary segment
+fw_status fifo_to_general(fw_ctx *ctx, uint32_t si) {
+    if (!ctx->segs[si].fifo) return FW_OK;
+    fw_status st = realloc_segment(ctx, si, ctx->segs[si].capacity, true);
+    if (st) return st;
+    SegHost &s = ctx->segs[si];
+    s.win_ok = false;  // no lifetime window was kept: the bound follows the snapshots from here on
+    return FW_OK;
 }
 
 // A parent type grew: the types its particles emit onto (Nested entries targeting it) were sized from the parent's
@@ -817,6 +873,18 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         S.collides = p.collision.enabled != 0;
         S.life_bound = (double)std::max(p.lifetime.min, p.lifetime.max);  // lifetime = lerp(min, max, u), u in [0, 1)
         S.win_ok = !S.nested_fed && std::isfinite(S.life_bound);
+        {  // FIFO ring (SegHost::fifo): one lifetime value, fed by Global entries only, no collisions
+            bool any_nested = false;
+            for (uint32_t i = 0; i < ne; i++) any_nested |= d->emission_settings[i].mode == FW_MODE_NESTED;
+            S.fifo = ctx->use_fifo && !any_nested && !S.collides && p.lifetime.min == p.lifetime.max &&
+                     std::isfinite(p.lifetime.min) && ctx->n_fifo < kMaxFifoSegs && caps[t] >= ctx->fifo_min;
+            if (S.fifo) {
+                ctx->n_fifo++;
+                S.win_ok = false;
+                S.fifo_life = 0.0f * (p.lifetime.max - p.lifetime.min) + p.lifetime.min;  // u * (max - min) + min, any u
+                S.fifo_wm = (T.base.kind != 0 ? 1 : 0) | (T.emis.kind != 0 ? 2 : 0) | (T.scale.kind != 0 ? 4 : 0);
+            }
+        }
         for (int c = 0; c < 4; c++) {  // the first key is the colour at age 0 (and, for one key, at every age)
             S.fill_bc[c] = T.base.values.empty() ? 0.f : T.base.values[c];
             S.fill_em[c] = T.emis.values.empty() ? 0.f : T.emis.values[c];
@@ -901,6 +969,7 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
         SegHost &S = ctx->segs[si];
         if (!S.in_use) continue;
         ctx->free_types.push_back(S.type_idx);
+        if (S.fifo) ctx->n_fifo--;
         if (S.buf[0]) FW_HIP(ctx, hipFree(S.buf[0]));
         if (S.destroyed) FW_HIP(ctx, hipFree(S.destroyed));
         S = SegHost{};
@@ -916,7 +985,7 @@ uint32_t choose_vt_rounds(const fw_ctx *ctx) {
     // at most FW_TILE / 2: Q1/Q2 of new particles live in the upper half of the LDS planes
     uint64_t act1 = 0, act2 = 0;
     for (const SegHost &S : ctx->segs) {
-        if (!S.in_use) continue;
+        if (!S.in_use || S.fifo) continue;
         const uint32_t live = seg_live_tiles(S);
         act1 += live + (S.frame_spawn + FW_VTILE - 1) / FW_VTILE;
         act2 += live + (S.frame_spawn + 2 * FW_VTILE - 1) / (2 * FW_VTILE);
@@ -940,7 +1009,7 @@ fw_status update_tile_table(fw_ctx *ctx) {
         // the device from exact counts and may use the smaller tiles when the host, with looser bounds, would not
         const uint32_t need = seg_tiles(S, 1);
         uint32_t &have = ctx->tiles_dev[i];
-        if (!S.in_use) {
+        if (!S.in_use || S.fifo) {
             if (have) have = 0, dirty = true;
             continue;
         }
@@ -1056,6 +1125,7 @@ void poll_snapshots(fw_ctx *ctx) {
             if (!S.in_use) continue;
             const unsigned long long v = snap[i];
             if ((uint32_t)(v >> 32) != ctx->snap_epoch[k]) continue;  // that segment's store has not landed yet
+            if (S.fifo) continue;  // the host's count is exact
             if (S.nested_fed) {
                 S.dev_count = (uint32_t)v;  // no host-side bound exists; the count only drives capacity growth
                 continue;
@@ -1168,6 +1238,9 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_DEBUG")) ctx->dbg = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_FORECAST")) ctx->use_forecast = atoi(m) != 0;
     if (const char *m = getenv("FW_STREAM")) ctx->use_stream = atoi(m) != 0;
+    if (const char *m = getenv("FW_FIFO")) ctx->use_fifo = atoi(m) != 0;
+    if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_FIFO_ROUNDS")) ctx->fifo_rounds = atoi(m) == 1 ? 1u : (atoi(m) == 2 ? 2u : 4u);
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
     if (const char *m = getenv("FW_OPS_ZEROCOPY")) ctx->ops_zerocopy = atoi(m) != 0;
     if (const char *m = getenv("FW_STATIC_NEW")) ctx->use_static_new = atoi(m) != 0;  // 0: always count + look back
@@ -1398,6 +1471,18 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // host's ~60 ns per emitter
     auto &levels = ctx->levels;
     for (auto &L : levels) L.g.clear(), L.n.clear();
+    ctx->fifo_ops.clear();
+    if (ctx->n_fifo) {
+        // the FIFO order rests on ages that never decrease: a negative or non-finite dt ends the mode (as does a dt so
+        // small that the cohort list grows without bound)
+        const bool dt_ok = dt >= 0.0f && std::isfinite(dt);
+        for (uint32_t si = 0; si < ctx->segs.size(); si++) {
+            SegHost &S = ctx->segs[si];
+            if (!S.in_use || !S.fifo || (dt_ok && S.coh.size() < kMaxCohorts)) continue;
+            fw_status cst = fifo_to_general(ctx, si);
+            if (cst) return cst;
+        }
+    }
     // (frame_spawn is reset in the lifetime-window pass below: one pass over the segments instead of two)
     bool new_static = std::isfinite(dt);  // cleared by any Global op whose particles might not survive this step
 
@@ -1517,7 +1602,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     }
                 }
                 // does every particle of this op outlive the step?  (TypeHost::life_lo_safe; false for NaN)
-                if (!(dt < E.life_lo_safe)) new_static = false;
+                if (!S.fifo && !(dt < E.life_lo_safe)) new_static = false;
                 FwOp op{};
                 op.seg = dst, op.emit = E.emit_idx, op.n = (uint32_t)n;
                 op.rel_base = S.frame_spawn;
@@ -1526,7 +1611,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 memcpy(op.origin_rot, sp.origin_rot, sizeof sp.origin_rot);
                 memcpy(op.parent_vel, sp.parent_vel, sizeof sp.parent_vel);
                 op.speed = sp.mod_speed, op.scale = sp.mod_scale;
-                levels[i].g.push_back(op);
+                if (S.fifo)
+                    ctx->fifo_ops.push_back(op);  // spawned inside fw_k_update_fifo, whatever else the frame holds
+                else
+                    levels[i].g.push_back(op);
                 E.serial += n;
                 S.frame_spawn += (uint32_t)n;
                 S.ub = (uint32_t)std::min<uint64_t>((uint64_t)S.ub + n, 0xFFFFFFFFull);
@@ -1592,6 +1680,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             }
             S.win_sum += n;
         }
+    for (const FwOp &op : ctx->fifo_ops) ctx->segs[op.seg].cum_spawn += op.n;
     prof(3);
     const uint32_t p = ctx->parity;
     // Particle types with collision settings (core.rs:607-624) run the count / scan / update-with-collisions launches
@@ -1618,7 +1707,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     a.seg0_keys_off = n_seg ? ctx->segs[0].keys_off : 0;
     a.seg0_keys_len = n_seg ? ctx->segs[0].keys_len : 0;
     a.tile_keys = ctx->d_tile_keys;
-    if (n_seg == 1 && ctx->segs[0].in_use) {
+    if (n_seg == 1 && ctx->segs[0].in_use && !ctx->segs[0].fifo) {
         const SegHost &S0 = ctx->segs[0];
         a.seg0_ib = S0.buf[p], a.seg0_ob = S0.buf[p ^ 1u];
         a.seg0_destroyed = S0.destroyed, a.seg0_inst = S0.inst;
@@ -1632,7 +1721,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     a.new_static = (new_static && ctx->use_static_new) ? 1u : 0u;
     a.boxes = (ctx->track_aabb && frame_mode == FW_MODE_FUSED) ? 1u : 0u;
     a.force_colors = ctx->colors_dirty ? 1u : 0u;
-    for (const SegHost &S : ctx->segs) a.any_inst |= (S.in_use && S.inst != nullptr) ? 1u : 0u;
+    for (const SegHost &S : ctx->segs) a.any_inst |= (S.in_use && !S.fifo && S.inst != nullptr) ? 1u : 0u;
     a.use_stream = ctx->use_stream ? 1u : 0u;
     uint32_t dt_bits;
     memcpy(&dt_bits, &dt, 4);
@@ -1815,11 +1904,90 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
 
     // update_particles + compaction (core.rs:577-670)
     // timing: the events ride on the dispatch packet (its begin / end timestamps), no marker packets in the stream
-    const bool timed = ctx->timing && ctx->tev_used + 2 <= ctx->tev.size();
-    FW_HIP(ctx, fw_launch_update(ctx->stream, ctx->g, a, spawn_form == FW_SPAWN_INLINE ? &inl : nullptr, spawn_form,
-                                 frame_mode, timed ? ctx->tev[ctx->tev_used] : nullptr,
-                                 timed ? ctx->tev[ctx->tev_used + 1] : nullptr));
-    if (timed) ctx->tev_used += 2;
+    bool timed_frame = false;
+    auto next_timing_pair = [&](hipEvent_t *e0, hipEvent_t *e1) {
+        *e0 = *e1 = nullptr;
+        if (!ctx->timing || ctx->tev_used + 2 > ctx->tev.size()) return;
+        *e0 = ctx->tev[ctx->tev_used], *e1 = ctx->tev[ctx->tev_used + 1];
+        ctx->tev_used += 2;
+        timed_frame = true;
+    };
+    // ---- FIFO segments: in place, everything they need in the kernel arguments (fw_kernels.h: FwFifoSeg)
+    bool fifo_launched = false;
+    if (ctx->n_fifo) {
+        FwFifoArgs fa{};
+        FwInlineOps fio;
+        uint32_t f_ops = 0, f_tiles = 0;
+        auto flush = [&]() -> hipError_t {
+            if (!fa.n_segs) return hipSuccess;
+            fa.parity = p, fa.epoch = a.epoch, fa.dbg = ctx->dbg, fa.dt = dt, fa.rounds = ctx->fifo_rounds;
+            fa.done_tag = a.done_tag, fa.done_value = a.done_value;
+            fa.host_counts = a.host_counts;
+            fa.live_out = a.live_out, fa.live_next = a.live_next;
+            hipEvent_t e0, e1;
+            next_timing_pair(&e0, &e1);
+            const hipError_t e = fw_launch_update_fifo(ctx->stream, ctx->g, fa, fio, f_tiles, e0, e1);
+            fa = FwFifoArgs{};
+            f_ops = f_tiles = 0;
+            fifo_launched = true;
+            return e;
+        };
+        for (uint32_t si = 0; si < n_seg; si++) {
+            SegHost &S = ctx->segs[si];
+            if (!S.in_use || !S.fifo) continue;
+            uint32_t k_ops = 0;
+            for (const FwOp &op : ctx->fifo_ops) k_ops += op.seg == si ? 1u : 0u;  // (at most FW_MAX_EMISSIONS)
+            if (fa.n_segs == FW_FIFO_PER_LAUNCH || f_ops + k_ops > FW_INLINE_OPS) FW_HIP(ctx, flush());
+            if (!fa.n_segs) fa.write_mask = S.fifo_wm;
+            else if (fa.write_mask != S.fifo_wm) fa.write_mask = -1;
+            const uint32_t n_spawn = S.frame_spawn, n_in = S.ub - n_spawn, n_tot = S.ub;
+            // the cohorts age by this dt exactly as their particles do (fp32 additions, fw_survives); the oldest die first
+            if (n_spawn) {
+                if (!S.coh.empty() && S.coh.back().age == 0.0f && !std::signbit(S.coh.back().age))
+                    S.coh.back().n += n_spawn;
+                else
+                    S.coh.push_back(SegHost::Cohort{n_spawn, 0.0f});
+            }
+            for (auto &c : S.coh) c.age = c.age + dt;
+            uint32_t dead = 0;
+            while (!S.coh.empty() && S.coh.front().age >= S.fifo_life) dead += S.coh.front().n, S.coh.pop_front();
+            FwFifoSeg &F = fa.s[fa.n_segs++];
+            F.buf = S.buf[0], F.destroyed = S.destroyed, F.inst = S.inst;
+            F.inst_cap = S.inst_cap, F.capacity = S.capacity, F.seg = si, F.type_idx = S.type_idx;
+            F.keys_off = S.keys_off, F.keys_len = S.keys_len;
+            F.head = S.head, F.n_in = n_in, F.n_spawn = n_spawn, F.dead = dead;
+            F.op0 = f_ops;
+            for (const FwOp &op : ctx->fifo_ops)
+                if (op.seg == si) fio.ops[f_ops++] = op;
+            F.op1 = f_ops;
+            // workgroups: the new particles first, FW_BLOCK each, in two groups of consecutive slots (up to the end of the
+            // buffer / from slot 0); then the ring tiles from the first slot the update touches (the first destroyed particle
+            // when their records are wanted, the first survivor otherwise) to the last old particle; at least one in all
+            // (it publishes the counts)
+            const uint32_t lo = std::min(S.destroyed ? 0u : dead, n_in), cnt = n_in - lo;
+            const uint32_t ftile = ctx->fifo_rounds * FW_BLOCK;
+            const uint32_t ps = (uint32_t)(((uint64_t)S.head + lo) % S.capacity), ring_tiles = S.capacity / ftile;
+            const uint32_t ns0 = (uint32_t)(((uint64_t)S.head + n_in) % S.capacity);  // slot of the first new particle
+            F.spawn_a = std::min(n_spawn, S.capacity - ns0);
+            F.n_vt_a = (F.spawn_a + FW_BLOCK - 1) / FW_BLOCK, F.n_vt_b = (n_spawn - F.spawn_a + FW_BLOCK - 1) / FW_BLOCK;
+            F.tile0 = ps / ftile;
+            const uint32_t live_tiles = cnt ? std::min<uint32_t>(ring_tiles, (ps % ftile + cnt + ftile - 1) / ftile) : 0u;
+            F.n_tiles = std::max(1u, F.n_vt_a + F.n_vt_b + live_tiles);
+            F.tile_first = f_tiles;
+            f_tiles += F.n_tiles;
+            fa.any_inst |= S.inst != nullptr ? 1u : 0u;
+            S.head = (uint32_t)(((uint64_t)S.head + std::min(dead, n_tot)) % S.capacity);
+            S.ub = n_tot - std::min(dead, n_tot);
+        }
+        FW_HIP(ctx, flush());
+    }
+    if (total_tiles || !fifo_launched) {
+        hipEvent_t e0, e1;
+        next_timing_pair(&e0, &e1);
+        FW_HIP(ctx, fw_launch_update(ctx->stream, ctx->g, a, spawn_form == FW_SPAWN_INLINE ? &inl : nullptr, spawn_form,
+                                     frame_mode, e0, e1));
+    }
+    if (timed_frame) ctx->tev_frames++;
     if (ctx->colors_dirty) {
         // that update wrote every colour of its output; the buffer it read (next frame's output) may still hold the
         // caller's colours past the survivors: back to the fill value, after which constant planes are skipped again
@@ -1897,7 +2065,7 @@ fw_status fw_spawner_poll_finished(fw_ctx *ctx, fw_spawner h, int32_t *out) {
 }
 
 static fw_status read_records(fw_ctx *ctx, const char *buf, uint32_t cap_seg, uint32_t n, int32_t pbr, bool aos,
-                              fw_particle *out, uint64_t cap) {
+                              fw_particle *out, uint64_t cap, uint32_t head = 0) {
     const uint64_t m = std::min<uint64_t>(n, cap);
     if (!m || !out) return FW_OK;
     if (aos) {
@@ -1906,7 +2074,7 @@ static fw_status read_records(fw_ctx *ctx, const char *buf, uint32_t cap_seg, ui
     }
     void *tmp = nullptr;
     FW_HIP(ctx, hipMalloc(&tmp, m * sizeof(fw_particle)));
-    hipError_t e = fw_launch_gather(ctx->stream, buf, cap_seg, (uint32_t)m, pbr, tmp);
+    hipError_t e = fw_launch_gather(ctx->stream, buf, cap_seg, head, (uint32_t)m, pbr, tmp);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(out, tmp, m * sizeof(fw_particle), hipMemcpyDeviceToHost);
     hipFree(tmp);
@@ -1925,7 +2093,8 @@ fw_status fw_spawner_read_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
     const SegHost &S = ctx->segs[sp->seg[type]];
     const uint32_t n = c[sp->seg[type]];
     if (n_out) *n_out = n;
-    fw_status st2 = read_records(ctx, S.buf[ctx->parity], S.capacity, n, sp->types[type].ps.pbr, false, out, cap);
+    fw_status st2 = read_records(ctx, S.buf[ctx->parity], S.capacity, n, sp->types[type].ps.pbr, false, out, cap,
+                                 S.fifo ? S.head : 0u);
     return st2 ? st2 : st;
 }
 
@@ -1962,6 +2131,7 @@ fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, c
     if (st) return st;
     const uint32_t si = sp->seg[type];
     ctx->fc_ok = false, ctx->boxes_epoch = 0;
+    if ((st = fifo_to_general(ctx, si))) return st;  // ages and lifetimes will be whatever the caller writes
     if (n > ctx->segs[si].capacity) {
         ctx->segs[si].ub = 0;
         const uint32_t zero = 0;
@@ -2029,7 +2199,7 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
     const SegHost &S = ctx->segs[si];
     const uint32_t ub = (uint32_t)std::min<uint64_t>(S.nested_fed ? S.capacity : std::min(S.ub, S.capacity), cap);
     if (n_upper_bound) *n_upper_bound = ub;
-    FW_HIP(ctx, fw_launch_pack_instances(ctx->stream, S.buf[ctx->parity], S.capacity,
+    FW_HIP(ctx, fw_launch_pack_instances(ctx->stream, S.buf[ctx->parity], S.capacity, S.fifo ? S.head : 0u,
                                          ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, ub, d_out));
     return FW_OK;
 }
@@ -2074,14 +2244,21 @@ fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out
     if (!sp || !out_min || !out_max) return FW_EINVAL;
     hipSetDevice(ctx->device);
     if (!ctx->h_aabb) FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_aabb, 8 * sizeof(float), hipHostMallocDefault));
-    if (ctx->boxes_epoch && ctx->d_tile_first) {
+    bool any_fifo = false;  // FIFO segments leave no per-tile boxes: the two-pass query reads their rings
+    uint32_t heads[FW_MAX_TYPES] = {};
+    for (size_t t = 0; t < sp->seg.size() && t < FW_MAX_TYPES; t++) {
+        const SegHost &S = ctx->segs[sp->seg[t]];
+        any_fifo |= S.fifo;
+        heads[t] = S.fifo ? S.head : 0u;
+    }
+    if (ctx->boxes_epoch && ctx->d_tile_first && !any_fifo) {
         // the last update left the box of every tile's survivors (fw_ctx_track_aabbs): fold those -- one small launch
         FW_HIP(ctx, fw_launch_aabb_from_tiles(ctx->stream, ctx->g, sp->seg.data(), (uint32_t)sp->seg.size(), ctx->parity,
                                               ctx->boxes_epoch, ctx->d_tile_first, ctx->h_aabb));
     } else {
         // two launches over the particles, the result lands in pinned memory: one synchronisation, no copies
-        FW_HIP(ctx, fw_launch_aabb(ctx->stream, ctx->g, sp->seg.data(), (uint32_t)sp->seg.size(), ctx->parity, ctx->d_aabb,
-                                   ctx->h_aabb));
+        FW_HIP(ctx, fw_launch_aabb(ctx->stream, ctx->g, sp->seg.data(), heads, (uint32_t)sp->seg.size(), ctx->parity,
+                                   ctx->d_aabb, ctx->h_aabb));
     }
     fw_status st = sync(ctx);
     if (!st) st = check_device_errors(ctx);
@@ -2170,7 +2347,7 @@ fw_status fw_ctx_kernel_timing(fw_ctx *ctx, int32_t enable) {
         ctx->tev_overhead_ms = tot / (n - 8);
     }
     ctx->timing = enable != 0;
-    ctx->tev_used = 0;
+    ctx->tev_used = 0, ctx->tev_frames = 0;
     unsigned long long now = 0;
     FW_HIP(ctx, hipMemcpy(&now, ctx->g.stats, sizeof now, hipMemcpyDeviceToHost));
     ctx->timing_particles_start = now;
@@ -2188,7 +2365,7 @@ fw_status fw_ctx_kernel_timing_read(fw_ctx *ctx, double *ms_total, uint64_t *lau
         FW_HIP(ctx, hipEventElapsedTime(&t, ctx->tev[i], ctx->tev[i + 1]));
         ms += t;
     }
-    const uint64_t nl = ctx->tev_used / 2;
+    const uint64_t nl = ctx->tev_frames;  // frames: a frame's update may be several launches (FIFO + general), all summed
     if (ms_total) *ms_total = ms;
     if (launches) *launches = nl;
     unsigned long long now = 0;
@@ -2223,6 +2400,24 @@ fw_status fw_debug_read_launches(fw_ctx *ctx, unsigned long long *out512, uint32
     if (st) return st;
     FW_HIP(ctx, hipMemcpy(out512, ctx->g.dbg_ts, 32768 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (epoch) *epoch = (uint32_t)(ctx->frame & 0x3FFFFFFFu);
+    return FW_OK;
+}
+// which update path a particle type is on: *mode = 1 FIFO ring (in place), 0 general (compacting); *bytes_per_particle =
+// the bytes one update of a live particle reads and writes on that path (planes the type never changes are not written)
+fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t *mode, uint32_t *bytes_per_particle) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || type >= sp->seg.size()) return FW_EINVAL;
+    const SegHost &S = ctx->segs[sp->seg[type]];
+    const TypeHost &T = sp->types[type];
+    if (mode) *mode = S.fifo ? 1 : 0;
+    if (bytes_per_particle) {
+        const uint32_t colours = (T.base.kind != 0 ? 16u : 0u) + (T.emis.kind != 0 ? 16u : 0u);
+        // general: read Q0..Q3 (+ the last_emitted planes), write Q0..Q3 + scale + the non-constant colour planes
+        // FIFO: read Q0..Q3, write Q0 Q1 + scale unless its curve is constant + the non-constant colour planes
+        // (+ rotation / angular velocity where they change: not counted)
+        *bytes_per_particle = S.fifo ? 64u + 32u + (T.scale.kind != 0 ? 4u : 0u) + colours
+                                     : 64u + 64u + 4u + colours + 8u * S.n_lplanes;
+    }
     return FW_OK;
 }
 fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_t max_tiles, uint64_t *n_tiles) {

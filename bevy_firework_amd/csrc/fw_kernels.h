@@ -96,6 +96,49 @@ struct FwInlineOps {
     FwOp ops[FW_INLINE_OPS];
 };
 
+// ---- FIFO (ring) segments ----------------------------------------------------------------------------------------
+// A particle type whose lifetime range is a single value destroys its particles in the order it received them: ages
+// grow by the same dt for everybody (fp32 addition is monotone), new particles start at 0, so at every update the
+// destroyed particles are a PREFIX of the list (reference order, core.rs:590-600 keeps survivors in order).  Nothing
+// ever has to move: such a segment lives in ONE buffer used as a ring -- logical particle i sits in slot
+// (head + i) mod capacity -- the update works in place (a particle is read and written by the same lane, planes that
+// did not change are not written), and the host, which knows every spawn count and replays the fp32 age of each spawn
+// cohort, knows head / live count / destroyed count of every frame exactly: no counting pass, no look-back, no
+// forecast, whatever dt does.  One record per segment per frame, in the kernel arguments:
+struct FwFifoSeg {
+    char *buf;               // the ring (FwSeg::buf[0] == buf[1])
+    char *destroyed, *inst;  // FwSeg::destroyed / inst (or null)
+    uint32_t inst_cap, capacity, seg, type_idx;
+    uint32_t keys_off, keys_len;
+    uint32_t head;     // slot of logical particle 0 BEFORE this update
+    uint32_t n_in;     // live particles before this frame's spawns
+    uint32_t n_spawn;  // Global particles spawned this frame (logical indices [n_in, n_in + n_spawn))
+    uint32_t dead;     // logical indices [0, dead) are destroyed by this update (may reach into the new ones)
+    uint32_t op0, op1; // this segment's spawn ops in FwInlineOps
+    // workgroups [tile_first, tile_first + n_tiles) of the launch: first n_vt_a + n_vt_b of FW_BLOCK new particles each
+    // (new particles [0, spawn_a) occupy the slots up to the end of the buffer, [spawn_a, n_spawn) those from slot 0),
+    // then one per ring tile (FwFifoArgs::rounds * FW_BLOCK slots) from tile0 on, covering the particles that were there before
+    uint32_t tile0;
+    uint32_t tile_first, n_tiles;
+    uint32_t spawn_a, n_vt_a, n_vt_b;
+};
+#define FW_FIFO_PER_LAUNCH 8
+struct FwFifoArgs {
+    FwFifoSeg s[FW_FIFO_PER_LAUNCH];
+    uint32_t n_segs, parity, epoch, dbg;
+    uint32_t rounds;  // a ring tile is rounds * FW_BLOCK slots (1, 2 or 4: capacities are multiples of FW_TILE)
+    float dt;
+    uint32_t any_inst;
+    // which optional planes the particle types of this launch write: bit 0 base colour (gradient not constant), bit 1
+    // emissive colour, bit 2 scale (curve not constant) when all its segments agree -- the kernel is then compiled for
+    // exactly that set of stores; -1: they differ, read the flags from each type
+    int32_t write_mask;
+    unsigned long long *done_tag;      // as in FwUpdateArgs
+    unsigned long long done_value;
+    unsigned long long *host_counts;
+    unsigned long long *live_out, *live_next;
+};
+
 enum { FW_SPAWN_NONE = 0, FW_SPAWN_INLINE = 1, FW_SPAWN_TABLE = 2 };
 
 enum { FW_MODE_FUSED = 0, FW_MODE_SPLIT = 1, FW_MODE_SPLIT_COLL = 2 };  // SPLIT_COLL: frames with colliding particle types
@@ -105,19 +148,24 @@ hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *d_ops,
                            uint32_t total_blocks, uint32_t parity);
 hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps *inl,
                             int spawn_form, int mode, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// in-place update of up to FW_FIFO_PER_LAUNCH FIFO segments (their spawn ops in `inl`)
+hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifoArgs &a, const FwInlineOps &inl,
+                                 uint32_t total_tiles, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d_ops, const FwNestOp *h_ops, uint32_t n_ops,
                             uint32_t total_tiles, uint32_t parity, uint32_t tag, uint32_t spin_limit, uint32_t dbg = 0);
 // SoA -> AoS gather of `n` particles of one segment buffer into fw_particle records (device)
-hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t n, int32_t pbr, void *d_out);
+// (head: slot of particle 0 -- 0 for every segment but a FIFO ring)
+hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, uint32_t n, int32_t pbr, void *d_out);
 hipError_t fw_launch_scatter(hipStream_t s, char *buf, uint32_t capacity, uint32_t n, uint32_t n_lplanes,
                              const void *d_in);
 // fills the base / emissive colour planes of one (buf1 == nullptr) or both buffers of a segment (capacity slots each)
 hipError_t fw_launch_fill_colors(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, const float bc[4], const float em[4]);
-hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, const uint32_t *d_count,
+hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, const uint32_t *d_count,
                                     uint32_t n_upper, void *d_out);
 // seg_ids: host array; d_part: device scratch of 256 * 8 floats; h_out8: PINNED host {min.xyz, any, max.xyz, -}
-hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, uint32_t n_segs, uint32_t parity,
-                          float *d_part, float *h_out8);
+// seg_heads: ring heads of the segments (host array, or null = all 0)
+hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, const uint32_t *seg_heads, uint32_t n_segs,
+                          uint32_t parity, float *d_part, float *h_out8);
 // the same query answered from the per-tile boxes of the last update (epoch = that update's)
 hipError_t fw_launch_aabb_from_tiles(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, uint32_t n_segs,
                                      uint32_t parity, uint32_t epoch, const uint32_t *d_seg_tile_first, float *h_out8);

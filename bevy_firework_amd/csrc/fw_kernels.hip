@@ -92,6 +92,22 @@ __device__ __forceinline__ float4 fw_ld4w(const char *win, uint32_t byte_off) {
 #endif
     return make_float4(v.x, v.y, v.z, v.w);
 }
+// Prefetch whose completion the KERNEL tracks, not the compiler.  The memory counter (vmcnt) is in-order and counts
+// stores too; the compiler's wait for a loaded register allows as many younger operations to stay outstanding as it
+// can PROVE were issued after the load.  In the round loops the stores of the current round sit between the prefetch
+// and its use, mostly under lane predicates or wave-uniform conditions, so the provable number is small and the wave
+// ends up waiting for the acknowledgement of its own stores every round -- 4 x ~2 us per tile at 1M particles.  These
+// loads are invisible to that analysis; fw_prefetch_wait<K> is the matching wait, K = stores the round is KNOWN to
+// have issued after them.  (The compiler's own waits stay correct: not knowing about these loads it can only wait
+// for more, never less.)
+__device__ __forceinline__ void fw_ld4w_async(fw_f4 &dst, const char *win, uint32_t byte_off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(byte_off), "s"(win) : "memory");
+}
+template <int K>
+__device__ __forceinline__ void fw_prefetch_wait(fw_f4 &a, fw_f4 &b, fw_f4 &c, fw_f4 &d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(K) : "memory");
+}
+__device__ __forceinline__ float4 fw_f4_to_float4(const fw_f4 &v) { return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void fw_st4w(char *win, uint32_t byte_off, float4 v) {
     const fw_f4 x = {v.x, v.y, v.z, v.w};
     FW_GLOBAL fw_f4 *p = reinterpret_cast<FW_GLOBAL fw_f4 *>(reinterpret_cast<FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off);
@@ -307,11 +323,17 @@ __device__ __forceinline__ fw_q4 fw_quat_step(fw_v3 v) {
     return fw_quat_from_scaled_axis(v);
 }
 
+// INPLACE (FIFO segments, fw_k_update_fifo): the output slot is the input slot, so a plane whose new value is
+// bit-identical to the loaded one for every lane of the wave is not written (rotation and angular velocity of particles
+// that do not spin, the scale under a constant curve); `full` marks a lane whose slot holds nothing yet (a particle
+// spawned this frame): it writes everything.
+// WM >= 0: which of the optional planes the launch writes is a compile-time fact (bit 0 base colour, 1 emissive, 2 scale)
+template <bool INPLACE = false, int WM = -1>
 __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float *s_keys, float dt, float4 q0, float4 q1,
                                                    float4 q2, float4 q3, float age_new, const FwOutWin &W, uint32_t o,
                                                    float4 *rec = nullptr, const fw_v3 *cpos = nullptr,
                                                    const fw_v3 *cvel = nullptr, float *box = nullptr,
-                                                   bool box_on = false) {
+                                                   bool box_on = false, bool full = false) {
     const float lifetime = q3.w;
     const float age_percent = age_new / lifetime;
     const float scale_factor = fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_percent);
@@ -336,11 +358,23 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     const uint32_t b16 = (o - W.first) * 16u;  // < 16 KiB + a tile: the window starts at the tile's first output slot
     fw_st4w(W.q0, b16, make_float4(px, py, pz, age_new));
     fw_st4w(W.q1, b16, make_float4(vx, vy, vz, q1.w));
-    fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
-    fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
-    if (W.wr5) fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));  // workgroup-uniform branches
-    if (W.wr6) fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
-    fw_st1w(W.s4, (o - W.first) * 4u, scale);
+    if (INPLACE) {
+        const uint32_t d2 = (__float_as_uint(nr.x) ^ __float_as_uint(q2.x)) | (__float_as_uint(nr.y) ^ __float_as_uint(q2.y)) |
+                            (__float_as_uint(nr.z) ^ __float_as_uint(q2.z)) | (__float_as_uint(nr.w) ^ __float_as_uint(q2.w));
+        const uint32_t d3 = (__float_as_uint(wx) ^ __float_as_uint(q3.x)) | (__float_as_uint(wy) ^ __float_as_uint(q3.y)) |
+                            (__float_as_uint(wz) ^ __float_as_uint(q3.z));
+        if (__any(full || d2 != 0u)) fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));  // wave-uniform branches
+        if (__any(full || d3 != 0u)) fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
+        if ((WM >= 0 ? (WM & 1) != 0 : W.wr5) || full) fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
+        if ((WM >= 0 ? (WM & 2) != 0 : W.wr6) || full) fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
+        if ((WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) || full) fw_st1w(W.s4, (o - W.first) * 4u, scale);
+    } else {
+        fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
+        fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
+        if (W.wr5) fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));  // workgroup-uniform branches
+        if (W.wr6) fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
+        fw_st1w(W.s4, (o - W.first) * 4u, scale);
+    }
     if (box_on) {  // update_aabbs (render.rs:677-703): running min / max of position -/+ scale, per lane
         // (`box` always points at the caller's local array when box_on can be true: never selected against null, so it
         // stays in registers)
@@ -1487,6 +1521,191 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     }
 }
 
+// ---------------------------------------------------------------------------------
+// FIFO (ring) segments: update_particles in place (fw_kernels.h: FwFifoSeg).  One workgroup per ring tile of FW_TILE
+// slots that holds a live or a new particle; a lane owns the same slot from load to store, so there is no compaction,
+// no cross-wave exchange and no barrier in the round loop -- the waves of a workgroup drift apart and the loads of one
+// overlap the arithmetic and the stores of another.  What the host says about each slot (destroyed / live / spawned
+// this frame) is re-derived from the particle itself and a disagreement raises FW_ERR_FORECAST.
+// Per live particle the kernel reads the four state planes (64 B) and writes position+age and velocity (32 B), the
+// colour planes whose gradient is not constant, the scale unless its curve is constant, and rotation / angular
+// velocity only in waves where they changed: 132 B for the linear 2-key curves of configs[1] instead of 164.
+// ---------------------------------------------------------------------------------
+// the ParticleInstance records of a wave's survivors: consecutive in the output unless the wave straddles the ring's head
+template <bool INST>
+__device__ __forceinline__ void fw_fifo_inst_out(const FwFifoSeg &F, char *inst, const float4 *s_inst_wave, const float4 *rec,
+                                                 uint32_t lane, unsigned long long m, bool alive, uint32_t o) {
+    if (!INST || inst == nullptr || m == 0ull) return;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    const uint32_t o_first = __builtin_amdgcn_readlane(o, __ffsll((long long)m) - 1);
+    const uint32_t o_last = __builtin_amdgcn_readlane(o, 63 - __clzll((long long)m));
+    if (o_last - o_first + 1u == cnt) {
+        fw_inst_flush(inst, F.inst_cap, s_inst_wave, lane, m, o_first);
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (alive && o < F.inst_cap)
+            for (uint32_t k = 0; k < 4; k++) fw_st4(inst + (size_t)o * 64u, k, rec[k]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// WM: the optional planes this launch's particle types write (fw_integrate_store), or -1 = read from the type
+template <bool INST, int WM>
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifoArgs a, FwInlineOps inl) {
+    constexpr int BLK = FW_BLOCK;
+    constexpr int NW = BLK / 64;
+    const int R = (int)a.rounds;                   // rounds per ring tile (the host's choice: 1, 2 or 4)
+    const uint32_t TILE = a.rounds * BLK;
+    __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
+    __shared__ __attribute__((aligned(16))) float4 s_inst[INST ? NW * 256 : 1];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t j = 0;  // this workgroup's segment (block-uniform; the records ride in the kernel arguments)
+    for (uint32_t i = 1; i < a.n_segs; i++)
+        if (a.s[i].tile_first <= blockIdx.x) j = i;
+    const FwFifoSeg &F = a.s[j];
+    const uint32_t C = F.capacity, ring_tiles = C / TILE;
+    const uint32_t tis = blockIdx.x - F.tile_first;
+    const uint32_t n_vt = F.n_vt_a + F.n_vt_b;
+    const bool spawner = tis < n_vt;  // a workgroup of new particles (they come first: the longest job starts earliest)
+    uint32_t pt = F.tile0 + (tis - n_vt);
+    if (pt >= ring_tiles) pt -= ring_tiles;
+    const uint32_t head = F.head, n_in = F.n_in, n_dead = F.dead;
+    const uint32_t n_tot = n_in + F.n_spawn;
+    // first slot of the workgroup: a ring tile, or the slot of the first new particle of its group (the groups [0, a) and
+    // [a, n_spawn) of the new particles each occupy consecutive slots: a is where the ring wraps, FwFifoSeg::spawn_a)
+    const uint32_t k0 = spawner ? (tis < F.n_vt_a ? tis * BLK : F.spawn_a + (tis - F.n_vt_a) * BLK) : 0u;
+    uint32_t sbase = spawner ? head + n_in + k0 : pt * TILE;
+    if (sbase >= C) sbase -= C;
+    if (spawner && sbase >= C) sbase -= C;  // (head + n_in + k0 < 3 C)
+    const float key0 = tid < F.keys_len ? g.keys[F.keys_off + tid] : 0.0f;
+    char *buf = F.buf;
+    const size_t sfirst = (size_t)sbase * 16u;
+    const char *iw0 = buf + FW_OFF_Q0(C) + sfirst, *iw1 = buf + FW_OFF_Q1(C) + sfirst;
+    const char *iw2 = buf + FW_OFF_Q2(C) + sfirst, *iw3 = buf + FW_OFF_Q3(C) + sfirst;
+    // round 0 of a live tile (every slot of a tile exists -- the capacity is a multiple of FW_TILE -- so the loads
+    // need no bounds; a spawning workgroup loads nothing)
+    float4 q0c, q1c, q2c, q3c, q0n, q1n, q2n, q3n;  // rounds 0 and 1: the loop keeps two rounds of loads in flight
+    q0c = q1c = q2c = q3c = q0n = q1n = q2n = q3n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!spawner) {
+        q0c = fw_ld4w(iw0, tid * 16u), q3c = fw_ld4w(iw3, tid * 16u);
+        q1c = fw_ld4w(iw1, tid * 16u), q2c = fw_ld4w(iw2, tid * 16u);
+        const uint32_t i1 = (uint32_t)(min(1, R - 1) * BLK + (int)tid) * 16u;
+        q0n = fw_ld4w(iw0, i1), q3n = fw_ld4w(iw3, i1);
+        q1n = fw_ld4w(iw1, i1), q2n = fw_ld4w(iw2, i1);
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        if (a.live_next) *a.live_next = 0ull;
+        if (a.done_tag) *a.done_tag = a.done_value;
+    }
+    const FwType T = g.types[F.type_idx];
+    if (tid < F.keys_len) s_keys[tid] = key0;
+    for (uint32_t i = tid + BLK; i < F.keys_len; i += BLK) s_keys[i] = g.keys[F.keys_off + i];
+    __syncthreads();
+    const bool want_destroyed = T.report_destroyed && F.destroyed != nullptr;
+    char *inst = INST ? F.inst : nullptr;
+    float4 *s_inst_wave = s_inst + (INST ? wave * 256u : 0u);
+    const FwOutWin W = fw_out_window(buf, C, sbase, T, 0u);
+    bool bad = false;
+    if (spawner) {
+        // ---- this frame's new particles: spawn_particles (core.rs:437-469) right before update_particles, each in the
+        // slot it will live in.  One round per workgroup: spawning is ~5x the arithmetic of an update.
+        const uint32_t k = k0 + tid;
+        const uint32_t k_end = tis < F.n_vt_a ? F.spawn_a : F.n_spawn;
+        const bool is_new = k < k_end;
+        const uint32_t i = n_in + k, s = sbase + tid;
+        FwSpawnOut so;
+        so.q0 = so.q1 = so.q2 = so.q3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (is_new) {
+            uint32_t oi = F.op0;
+            for (uint32_t x = F.op0; x < F.op1; x++)
+                if (k >= inl.ops[x].rel_base && k - inl.ops[x].rel_base < inl.ops[x].n) oi = x;
+            const FwOp &op = inl.ops[oi];
+            so = fw_spawn_one(g.emits[op.emit], g.seed, op.serial_base + (k - op.rel_base),
+                              fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
+                              fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
+                              fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
+        }
+        float age_new;
+        const bool surv = fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);
+        const bool dead = i < n_dead;
+        bad |= is_new && surv == dead;
+        const bool alive = is_new && !dead;
+        const unsigned long long m = __ballot(alive);
+        float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(m) * 4u : nullptr;
+        if (alive)
+            fw_integrate_store<true, -1>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, nullptr, nullptr,
+                                         nullptr, false, true);
+        else if (is_new && want_destroyed)  // born and destroyed in the same frame (dt >= lifetime)
+            fw_store_destroyed(F.destroyed, buf, C, s, false, T, s_keys, so.q0, so.q1, so.q2, so.q3, age_new, i);
+        fw_fifo_inst_out<INST>(F, inst, s_inst_wave, rec, lane, m, alive, i - n_dead);
+    } else {
+        // ---- (1) records of the particles this update destroys (core.rs:596-599).  Kept out of the streaming loop:
+        // memory reads inside a divergent branch make the compiler drain every outstanding load -- the prefetch
+        // included -- where the branches join.
+        if (want_destroyed && n_dead != 0u) {
+#pragma unroll 1
+            for (int r = 0; r < R; r++) {
+                const uint32_t s = sbase + r * BLK + tid;
+                uint32_t i = s - head;
+                if (s < head) i += C;
+                if (i < n_dead && i < n_in) {
+                    const uint32_t b16 = (uint32_t)(r * BLK + (int)tid) * 16u;
+                    const float4 q0 = fw_ld4w(iw0, b16), q1 = fw_ld4w(iw1, b16), q2 = fw_ld4w(iw2, b16), q3 = fw_ld4w(iw3, b16);
+                    fw_store_destroyed(F.destroyed, buf, C, s, true, T, s_keys, q0, q1, q2, q3, q0.w + a.dt, i);
+                }
+            }
+        }
+        // ---- (2) the particles that were here before this frame: a streaming loop, next round's loads in flight while
+        // this one is integrated and stored.  No barrier, no exchange between lanes: the waves of a workgroup drift apart.
+#pragma unroll 1
+        for (int r = 0; r < R; r++) {
+            const uint32_t s = sbase + r * BLK + tid;
+            const uint32_t in_ = (uint32_t)(min(r + 2, R - 1) * BLK + (int)tid) * 16u;  // two rounds ahead (the last re-read)
+            const float4 q0f = fw_ld4w(iw0, in_), q3f = fw_ld4w(iw3, in_);
+            const float4 q1f = fw_ld4w(iw1, in_), q2f = fw_ld4w(iw2, in_);
+            uint32_t i = s - head;  // logical index of the slot
+            if (s < head) i += C;
+            float age_new;
+            const bool surv = fw_survives(q0c.w, a.dt, q3c.w, &age_new);
+            const bool mine = i < n_in, dead = i < n_dead;
+            bad |= mine && surv == dead;  // the host's cohort ages and the particle disagree
+            const bool alive = mine && !dead;
+            const unsigned long long m = INST ? __ballot(alive) : 0ull;
+            float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(m) * 4u : nullptr;
+            if (alive) {
+                if (a.dbg & 2u) {  // profiling only: stream without arithmetic
+                    const uint32_t b16 = (s - W.first) * 16u;
+                    fw_st4w(W.q0, b16, make_float4(q0c.x, q0c.y, q0c.z, age_new)), fw_st4w(W.q1, b16, q1c);
+                    if (WM >= 0 ? (WM & 1) != 0 : W.wr5) fw_st4w(W.q5, b16, q0c);
+                    if (WM >= 0 ? (WM & 2) != 0 : W.wr6) fw_st4w(W.q6, b16, q1c);
+                    if (WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) fw_st1w(W.s4, (s - W.first) * 4u, q1c.w);
+                } else {
+                    fw_integrate_store<true, WM>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec);
+                }
+            }
+            fw_fifo_inst_out<INST>(F, inst, s_inst_wave, rec, lane, m, alive, i - n_dead);
+            q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n;
+            q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f;
+        }
+    }
+    if (__any(bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST);
+    if (tis == 0 && tid == 0) {
+        const uint32_t sidx = a.parity * g.max_seg + F.seg, oidx = (a.parity ^ 1u) * g.max_seg + F.seg;
+        if (g.count[sidx] != n_in) atomicOr(g.err, FW_ERR_FORECAST);
+        const uint32_t nc = n_tot - min(n_dead, n_tot);
+        g.count[oidx] = nc;
+        g.spawned[oidx] = 0;
+        g.appended[oidx] = 0;
+        g.ndestroyed[F.seg] = n_tot - nc;
+        if (a.host_counts) a.host_counts[F.seg] = ((unsigned long long)a.epoch << 32) | nc;
+        if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
+        if (!(a.dbg & 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);
+    }
+}
+
 // split mode, pass 1: survivors per tile
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_count(FwGlobals g, FwUpdateArgs a) {
     __shared__ uint32_t s_c[4];
@@ -1872,14 +2091,21 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
 // ---------------------------------------------------------------------------------
 
 // SoA planes -> fw_particle records (26 x 4 B)
-__global__ void fw_k_gather(const char *buf, uint32_t C, uint32_t n, int32_t pbr, float *out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// slot of logical particle i of a segment whose particle 0 sits in slot `head` (0 unless the segment is a FIFO ring)
+__device__ __forceinline__ uint32_t fw_ring_slot(uint32_t head, uint32_t i, uint32_t C) {
+    const uint32_t s = head + i;  // head < C, i < C <= 0xFFFF0000 / 2 ... no overflow: capacities stay below 2^31
+    return s >= C ? s - C : s;
+}
+
+__global__ void fw_k_gather(const char *buf, uint32_t C, uint32_t head, uint32_t n, int32_t pbr, float *out) {
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n) return;
+    const uint32_t i = fw_ring_slot(head, li, C);
     const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i), q1 = fw_ld4(buf + FW_OFF_Q1(C), i),
                  q2 = fw_ld4(buf + FW_OFF_Q2(C), i), q3 = fw_ld4(buf + FW_OFF_Q3(C), i),
                  bc = fw_ld4(buf + FW_OFF_Q5(C), i), em = fw_ld4(buf + FW_OFF_Q6(C), i);
     const float sc = reinterpret_cast<const float *>(buf + FW_OFF_S4(C))[i];
-    float *r = out + (size_t)i * 26;
+    float *r = out + (size_t)li * 26;
     r[0] = q0.x, r[1] = q0.y, r[2] = q0.z;
     r[3] = q1.x, r[4] = q1.y, r[5] = q1.z;
     r[6] = q2.x, r[7] = q2.y, r[8] = q2.z, r[9] = q2.w;
@@ -1917,13 +2143,13 @@ __global__ void fw_k_fill_colors(char *buf0, char *buf1, uint32_t C, float4 bc, 
 // SoA planes -> ParticleInstance records (render.rs:95-115).  Loads are plane-wise coalesced; the 64-byte records are
 // transposed through LDS so that every store instruction of a wave writes 1 KiB of consecutive bytes (a lane writing
 // its own record with four float4 stores would touch 64 lines a quarter at a time).
-__global__ __launch_bounds__(256) void fw_k_pack(const char *buf, uint32_t C, const uint32_t *d_count, uint32_t n_upper,
-                                                 float4 *out) {
+__global__ __launch_bounds__(256) void fw_k_pack(const char *buf, uint32_t C, uint32_t head, const uint32_t *d_count,
+                                                 uint32_t n_upper, float4 *out) {
     __shared__ float4 s_rec[256 * 4];
     const uint32_t n = min(*d_count, n_upper);
     const uint32_t tid = threadIdx.x;
     for (uint32_t b = blockIdx.x * 256u; b < n; b += gridDim.x * 256u) {
-        const uint32_t i = min(b + tid, n - 1u);
+        const uint32_t i = fw_ring_slot(head, min(b + tid, n - 1u), C);
         const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i);
         const float sc = fw_ld1(buf + FW_OFF_S4(C), i);
         const float4 q2 = fw_ld4(buf + FW_OFF_Q2(C), i);
@@ -1970,7 +2196,8 @@ __device__ __forceinline__ void fw_atomic_maxf(float *addr, float v) {
 // {min.xyz, any, max.xyz, -} in PINNED host memory, so the query costs one stream synchronisation and no copies.
 struct FwSegList {
     uint32_t n;
-    uint32_t id[8];  // FW_MAX_TYPES
+    uint32_t id[8];    // FW_MAX_TYPES
+    uint32_t head[8];  // slot of each segment's particle 0 (FIFO rings; 0 otherwise)
 };
 #define FW_AABB_BLOCKS 256u
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, FwSegList L, uint32_t parity, float *part8) {
@@ -1982,7 +2209,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, FwSegList L, 
         const FwSeg &S = g.segs[seg];
         const uint32_t n = g.count[parity * g.max_seg + seg];
         const char *buf = S.buf[parity];
-        for (uint32_t i = blockIdx.x * FW_BLOCK + threadIdx.x; i < n; i += gridDim.x * FW_BLOCK) {
+        for (uint32_t li = blockIdx.x * FW_BLOCK + threadIdx.x; li < n; li += gridDim.x * FW_BLOCK) {
+            const uint32_t i = fw_ring_slot(L.head[k], li, S.capacity);
             const float4 q0 = fw_ld4(buf + FW_OFF_Q0(S.capacity), i);
             const float sc = fw_ld1(buf + FW_OFF_S4(S.capacity), i);
             mn[0] = fminf(mn[0], q0.x - sc), mn[1] = fminf(mn[1], q0.y - sc), mn[2] = fminf(mn[2], q0.z - sc);
@@ -2199,6 +2427,30 @@ hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArg
     return hipGetLastError();
 }
 
+hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifoArgs &a, const FwInlineOps &inl,
+                                 uint32_t total_tiles, hipEvent_t e0, hipEvent_t e1) {
+    if (!total_tiles || !a.n_segs) return hipErrorInvalidValue;
+    const dim3 grid(total_tiles), block(FW_BLOCK);
+#define FW_FIFO_CASE(wm)                                                                   \
+    case wm:                                                                               \
+        if (a.any_inst)                                                                    \
+            FW_LAUNCH_T((fw_k_update_fifo<true, wm>), grid, block, s, e0, e1, g, a, inl);  \
+        else                                                                               \
+            FW_LAUNCH_T((fw_k_update_fifo<false, wm>), grid, block, s, e0, e1, g, a, inl); \
+        break;
+    switch (a.write_mask) {
+        FW_FIFO_CASE(0) FW_FIFO_CASE(1) FW_FIFO_CASE(2) FW_FIFO_CASE(3) FW_FIFO_CASE(4) FW_FIFO_CASE(5) FW_FIFO_CASE(6)
+        FW_FIFO_CASE(7)
+        default:
+            if (a.any_inst)
+                FW_LAUNCH_T((fw_k_update_fifo<true, -1>), grid, block, s, e0, e1, g, a, inl);
+            else
+                FW_LAUNCH_T((fw_k_update_fifo<false, -1>), grid, block, s, e0, e1, g, a, inl);
+    }
+#undef FW_FIFO_CASE
+    return hipGetLastError();
+}
+
 hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d_ops, const FwNestOp *h_ops, uint32_t n_ops,
                             uint32_t total_tiles, uint32_t parity, uint32_t tag, uint32_t spin_limit, uint32_t dbg) {
     if (!n_ops || !total_tiles) return hipSuccess;
@@ -2209,9 +2461,9 @@ hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d
     return hipGetLastError();
 }
 
-hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t n, int32_t pbr, void *d_out) {
+hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, uint32_t n, int32_t pbr, void *d_out) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(fw_k_gather, dim3((n + 255) / 256), dim3(256), 0, s, buf, capacity, n, pbr, (float *)d_out);
+    hipLaunchKernelGGL(fw_k_gather, dim3((n + 255) / 256), dim3(256), 0, s, buf, capacity, head, n, pbr, (float *)d_out);
     return hipGetLastError();
 }
 
@@ -2230,21 +2482,21 @@ hipError_t fw_launch_fill_colors(hipStream_t s, char *buf0, char *buf1, uint32_t
     return hipGetLastError();
 }
 
-hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, const uint32_t *d_count,
+hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, const uint32_t *d_count,
                                     uint32_t n_upper, void *d_out) {
     if (!n_upper) return hipSuccess;
     uint32_t blocks = (n_upper + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(fw_k_pack, dim3(blocks), dim3(256), 0, s, buf, capacity, d_count, n_upper, (float4 *)d_out);
+    hipLaunchKernelGGL(fw_k_pack, dim3(blocks), dim3(256), 0, s, buf, capacity, head, d_count, n_upper, (float4 *)d_out);
     return hipGetLastError();
 }
 
-hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, uint32_t n_segs, uint32_t parity,
-                          float *d_part, float *h_out8) {
+hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, const uint32_t *seg_heads, uint32_t n_segs,
+                          uint32_t parity, float *d_part, float *h_out8) {
     if (!n_segs || n_segs > 8u) return hipErrorInvalidValue;  // FW_MAX_TYPES
     FwSegList L{};
     L.n = n_segs;
-    for (uint32_t i = 0; i < n_segs; i++) L.id[i] = seg_ids[i];
+    for (uint32_t i = 0; i < n_segs; i++) L.id[i] = seg_ids[i], L.head[i] = seg_heads ? seg_heads[i] : 0u;
     hipLaunchKernelGGL(fw_k_aabb, dim3(FW_AABB_BLOCKS), dim3(FW_BLOCK), 0, s, g, L, parity, d_part);
     hipLaunchKernelGGL(fw_k_aabb_fold, dim3(1), dim3(FW_AABB_BLOCKS), 0, s, g, L, parity, (const float *)d_part, h_out8);
     return hipGetLastError();

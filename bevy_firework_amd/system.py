@@ -135,6 +135,13 @@ class SpawnerData:
         self._sys._check(self._sys._lib.fw_spawner_attach_instances(
             self._sys._ctx, self.handle, particle_type, C.c_void_p(device_ptr) if device_ptr else None, int(capacity)))
 
+    def update_path(self, particle_type: int = 0):
+        """("fifo" | "general", bytes one update of a live particle moves) -- which kernel family updates this type"""
+        mode, nbytes = C.c_int32(), C.c_uint32()
+        self._sys._check(self._sys._lib.fw_debug_update_path(self._sys._ctx, self.handle, particle_type, C.byref(mode),
+                                                             C.byref(nbytes)))
+        return ("fifo" if mode.value else "general"), int(nbytes.value)
+
     def aabb(self):
         """(any, min, max) of position -/+ scale over all particle types (render.rs:677-703)."""
         mn, mx, any_ = (C.c_float * 3)(), (C.c_float * 3)(), C.c_int32()

@@ -28,3 +28,22 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# Every GPU test runs twice: with constant-lifetime particle types on the in-place FIFO ring path (whatever their size:
+# FW_FIFO_MIN=0) and with that path switched off (FW_FIFO=0: everything on the general, compacting path).  The knobs are
+# read when a context is created, so setting the environment before the test body is enough.
+def pytest_generate_tests(metafunc):
+    if metafunc.definition.get_closest_marker("gpu") and "fw_path" in metafunc.fixturenames:
+        metafunc.parametrize("fw_path", ["fifo", "general"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def fw_path(request, monkeypatch):
+    mode = getattr(request, "param", None)
+    if mode == "fifo":
+        monkeypatch.setenv("FW_FIFO", "1")
+        monkeypatch.setenv("FW_FIFO_MIN", "0")
+    elif mode == "general":
+        monkeypatch.setenv("FW_FIFO", "0")
+    return mode

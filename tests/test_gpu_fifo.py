@@ -1,0 +1,234 @@
+"""The in-place FIFO ring path (fw_k_update_fifo: particle types with one lifetime value) against the CPU oracle: the ring
+wraps, grows while wrapped, falls back to the general path when its premise breaks, and everything the ABI can observe
+(order, state, destroyed records, instance records, AABB) stays the reference's.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+import oracle  # noqa: F401
+from bevy_firework_amd import settings as S
+from bevy_firework_amd import workloads
+from parity import Pair, assert_particles_match
+
+pytestmark = pytest.mark.gpu
+DT = np.float32(1.0 / 60.0)
+SEED = workloads.SEED
+
+
+@pytest.fixture()
+def system(fw_path):
+    from bevy_firework_amd.system import ParticleSystem
+
+    with ParticleSystem(device=0, seed=SEED) as ps:
+        ps.path = fw_path
+        yield ps
+
+
+def _expect_path(system, pair, t=0, fifo=True):
+    want = "fifo" if (fifo and system.path == "fifo") else "general"
+    assert pair.gpu.update_path(t)[0] == want, (pair.gpu.update_path(t), want)
+
+
+def _ring_settings(**kw):
+    base = dict(lifetime=S.RandF32.constant(0.25), initial_scale=S.RandF32(0.5, 2.0), linear_drag=0.2,
+                scale_curve=S.FireworkCurve.even_samples([1.0, 2.0, 0.5]),
+                base_color=S.FireworkGradient.uneven_samples(workloads.STRESS_GRADIENT))
+    base.update(kw)
+    return S.ParticleSettings(**base)
+
+
+def test_ring_wraps_many_times_bit_exact(system):
+    """a small ring (capacity 4096) turns over every ~0.3 s: the head crosses the end of the buffer again and again,
+    tiles and the new-particle groups straddle it; no trig anywhere -> the whole state bit-exact every frame"""
+    ps = _ring_settings(capacity=4096)
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(11000.0),
+                            initial_velocity=S.RandVec3(S.RandF32(1.0, 6.0), (0.0, 1.0, 0.0), 0.0),
+                            initial_velocity_radial=S.RandF32(0.0, 1.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [es]), S.Transform((1.0, 2.0, 3.0)), seed=SEED, uid=3)
+    _expect_path(system, pair)
+    for fr in range(200):
+        system.update(DT)
+        pair.step_cpu(DT)
+        pair.check(exact_all=True, what=f"frame {fr}")
+    assert 2500 < pair.gpu.count(0) < 3000
+    _expect_path(system, pair)
+
+
+def test_irregular_dt_needs_no_forecast(system):
+    """any sequence of dt >= 0 (the plugin's wall-clock delta, plugin.rs:26-31): the host replays the cohort ages, so the
+    destroyed count is exact every frame; zero steps and a step longer than the lifetime (everything dies, the particles
+    spawned in that very frame included) are part of it"""
+    ps = _ring_settings(lifetime=S.RandF32.constant(0.2), particles_destroyed=lambda dead: None)
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(40000.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [es]), seed=SEED, uid=4)
+    _expect_path(system, pair)
+    rng = np.random.default_rng(11)
+    dts = list(rng.uniform(0.0, 0.03, size=60)) + [0.0, 0.0, 0.016, 0.25, 0.016, 0.016, 0.5, 0.001] + list(rng.uniform(0.001, 0.02, size=30))
+    for fr, dt in enumerate(dts):
+        dt = np.float32(dt)
+        system.update(dt)
+        pair.step_cpu(dt)
+        pair.check(exact_all=True, what=f"frame {fr} dt={dt}")
+        assert_particles_match(pair.gpu.destroyed(0), pair.cpu.destroyed(0), True, f"destroyed frame {fr}")
+    _expect_path(system, pair)
+    assert pair.gpu.count(0) > 1000
+
+
+def test_growth_while_wrapped(system):
+    """bursts far beyond the capacity while the head sits in the middle of the buffer: the ring is unwrapped into the
+    larger allocation (Vec growth, core.rs:523) without losing or reordering a particle"""
+    ps = _ring_settings(lifetime=S.RandF32.constant(0.3), capacity=4096)
+    pair = Pair(system, S.ParticleSpawner([ps], [S.EmissionSettings(emission_pacing=S.EmissionPacing.OnDemand())]),
+                seed=SEED, uid=31)
+    _expect_path(system, pair)
+    for fr in range(70):
+        pair.queue(150 if fr % 3 else 900)          # keeps the ring turning
+        if fr in (25, 26, 40, 58):
+            pair.queue(9000 + 1500 * (fr % 7))      # ... and bursts through the capacity
+        system.update(DT)
+        pair.step_cpu(DT)
+        pair.check(exact_all=True, what=f"growth f{fr}")
+    _expect_path(system, pair)
+    assert pair.gpu.count(0) > 3000
+
+
+def test_caller_written_particles_end_the_mode(system):
+    """fw_spawner_write_particles may hand over any ages and lifetimes: the segment continues on the general path, from
+    exactly the state the caller wrote (ring unwrapped first)"""
+    ps = _ring_settings(capacity=8192)
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(20000.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [es]), seed=SEED, uid=8)
+    for fr in range(40):
+        system.update(DT)
+        pair.step_cpu(DT)
+    pair.check(exact_all=True, what="before write")
+    _expect_path(system, pair)
+    parts = pair.cpu.particles(0)[::2].copy()
+    parts["lifetime"] = np.linspace(0.05, 0.6, len(parts)).astype(np.float32)   # no longer one lifetime
+    pair.gpu.write_particles(0, parts)
+    pair.cpu.write_particles(0, parts)
+    assert pair.gpu.update_path(0)[0] == "general"
+    for fr in range(40):
+        system.update(DT)
+        pair.step_cpu(DT)
+        pair.check(exact_all=True, what=f"after write {fr}")
+    assert pair.gpu.count(0) > 3000
+
+
+def test_negative_dt_ends_the_mode(system):
+    """ages must never decrease for the oldest-first order to hold: a negative step moves the type to the general path,
+    which then does whatever the reference's arithmetic does with it"""
+    ps = _ring_settings(lifetime=S.RandF32.constant(0.3))
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(15000.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [es]), seed=SEED, uid=9)
+    dts = [1 / 60] * 30 + [-1 / 120, 1 / 60, -1 / 60] + [1 / 60] * 30
+    for fr, dt in enumerate(dts):
+        if fr == 30:
+            _expect_path(system, pair)
+        dt = np.float32(dt)
+        system.update(dt)
+        pair.step_cpu(dt)
+        pair.check(exact_all=True, what=f"frame {fr} dt={dt}")
+    assert pair.gpu.update_path(0)[0] == "general"
+    assert pair.gpu.count(0) > 3000
+
+
+def test_more_ring_types_than_one_launch_holds(system):
+    """FW_FIFO_PER_LAUNCH (8) ring segments per context; further constant-lifetime types simply take the general path.
+    Two-type spawners, one of the two with a lifetime range, so both launches run in every frame."""
+    pairs = []
+    for k in range(6):
+        p0 = _ring_settings(lifetime=S.RandF32.constant(0.2 + 0.02 * k), capacity=4096)
+        p1 = S.ParticleSettings(lifetime=S.RandF32(0.1, 0.4) if k % 2 else S.RandF32.constant(0.15), linear_drag=0.1 * k)
+        e0 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(3000.0 + 500 * k),
+                                emission_shape=S.EmissionShape.Sphere(0.5 + 0.1 * k))
+        e1 = S.EmissionSettings(particle_index=1, emission_pacing=S.EmissionPacing.rate(2000.0))
+        e2 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.CountOverDuration(300.0, 0.5, 0.1, 0.9))
+        pairs.append(Pair(system, S.ParticleSpawner([p0, p1], [e0, e1, e2]), S.Transform((float(k), 0.0, 0.0)), seed=SEED, uid=k))
+    modes = [p.gpu.update_path(t)[0] for p in pairs for t in (0, 1)]
+    if system.path == "fifo":
+        assert modes.count("fifo") == 8 and modes[:2] == ["fifo", "fifo"], modes
+    else:
+        assert modes.count("fifo") == 0
+    for fr in range(60):
+        system.update(DT)
+        for p in pairs:
+            p.step_cpu(DT)
+        if fr % 6 == 5:
+            for k, p in enumerate(pairs):
+                p.check(what=f"frame {fr} spawner {k}")
+
+
+def test_instances_destroyed_and_aabb_on_a_wrapped_ring(system):
+    """the render hand-off of a ring: records in particle order whatever the head is (a wave that straddles the head
+    writes its records one by one), destroyed records of the update that wrapped, AABB of a wrapped live range"""
+    import torch
+
+    ps = _ring_settings(lifetime=S.RandF32.constant(0.2), capacity=4096, particles_destroyed=lambda dead: None,
+                        emissive_color=S.FireworkGradient.even_samples([(4.0, 2.0, 0.0, 1.0), (0.0, 0.0, 0.0, 1.0)]))
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(17000.0),
+                            initial_velocity=S.RandVec3(S.RandF32(0.0, 4.0), (0.0, 1.0, 0.0), 0.0),
+                            initial_angular_velocity=S.RandVec3(S.RandF32(0.0, 5.0), (0.0, 1.0, 0.0), 0.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [es]), seed=SEED, uid=71)
+    _expect_path(system, pair)
+    cap, guard = 4000, 64
+    buf = torch.full(((cap + guard) * 16,), float("nan"), dtype=torch.float32, device="cuda")
+    pair.gpu.attach_instances(buf.data_ptr(), cap)
+    for fr in range(120):
+        system.update(DT)
+        pair.step_cpu(DT)
+        n = pair.gpu.count(0)
+        ref = pair.gpu.instances(0)  # packing pass over the ring
+        got = buf[: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
+        assert np.array_equal(got, ref.view(np.uint32).reshape(n, 16)), f"frame {fr}: attached records differ from packed ones"
+        assert bool(torch.isnan(buf[cap * 16:]).all()), "wrote past the attached buffer"
+        cp = pair.cpu.particles(0)
+        rec = got.view(np.float32).reshape(n, 16)
+        assert np.array_equal(rec[:, 3], cp["scale"]) and np.array_equal(rec[:, 8:12], cp["base_color"])
+        assert np.array_equal(rec[:, 12:16], cp["emissive_color"])
+        assert_particles_match(pair.gpu.destroyed(0), pair.cpu.destroyed(0), False, f"destroyed frame {fr}")
+        if fr % 10 == 9:
+            pair.check(what=f"frame {fr}")
+            any_g, mn_g, mx_g = pair.gpu.aabb()
+            parts = pair.gpu.particles(0)
+            assert any_g and np.array_equal(mn_g, (parts["position"] - parts["scale"][:, None]).min(axis=0))
+            assert np.array_equal(mx_g, (parts["position"] + parts["scale"][:, None]).max(axis=0))
+    assert 3000 < pair.gpu.count(0) < 4000
+
+
+def test_unchanged_planes_are_not_written_but_changed_ones_are(system):
+    """the in-place update skips rotation / angular velocity / scale / constant colours where their bits do not change;
+    a type whose particles DO spin and scale must still get every plane (trig -> tolerance of tests/parity.py)"""
+    still = S.ParticleSettings(lifetime=S.RandF32.constant(0.5), scale_curve=S.FireworkCurve.constant(1.5), capacity=16384)
+    spin = S.ParticleSettings(lifetime=S.RandF32.constant(0.5), angular_acceleration=(0.1, 0.0, -0.2), angular_drag=0.3,
+                              scale_curve=S.FireworkCurve.uneven_samples([(0.0, 1.0), (0.8, 1.2), (1.0, 0.0)]), capacity=16384)
+    e0 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(9000.0))
+    e1 = S.EmissionSettings(particle_index=1, emission_pacing=S.EmissionPacing.rate(9000.0),
+                            initial_angular_velocity=S.RandVec3(S.RandF32(1.0, 9.0), (0.0, 0.6, 0.8), 0.5))
+    pair = Pair(system, S.ParticleSpawner([still, spin], [e0, e1]), seed=SEED, uid=5)
+    _expect_path(system, pair, 0), _expect_path(system, pair, 1)
+    if system.path == "fifo":
+        # (default colours are one-key gradients: never rewritten; so is a constant scale curve)
+        assert pair.gpu.update_path(0)[1] == 64 + 32 and pair.gpu.update_path(1)[1] == 64 + 32 + 4
+    for fr in range(90):
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr % 9 == 8:
+            pair.check(what=f"frame {fr}")
+    assert pair.gpu.count(0) > 4000 and pair.gpu.count(1) > 4000
+
+
+def test_settings_rebuild_and_despawn_release_the_ring_slots(system):
+    """update_settings / despawn give the (at most 8) ring slots of a context back"""
+    sp = S.ParticleSpawner([_ring_settings(capacity=4096)], [S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(5000.0))])
+    for rep in range(20):
+        hs = [system.spawn(sp, uid=rep * 10 + k) for k in range(4)]
+        if system.path == "fifo":
+            assert all(h.update_path(0)[0] == "fifo" for h in hs), rep
+        for _ in range(5):
+            system.update(DT)
+        hs[0].update_settings(sp)
+        system.update(DT)
+        if system.path == "fifo":
+            assert hs[0].update_path(0)[0] == "fifo"
+        for h in hs:
+            system.despawn(h)

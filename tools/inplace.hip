@@ -1,0 +1,91 @@
+// inplace.hip -- what an in-place (ring) update of a FIFO segment could reach, against the ping-pong shape.
+// Planes as in fw_device.h: Q0 Q1 Q2 Q3 (float4, read), Q5 Q6 (float4) + S4 (float), capacity C slots per plane.
+//   hipcc --offload-arch=gfx950 -O3 tools/inplace.hip -o tools/inplace
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+__device__ __forceinline__ float work(float x, int K) {
+#pragma unroll 1
+    for (int k = 0; k < K; k++) x = x * 1.0001f + 0.5f;
+    return x;
+}
+
+// RD: bit i = read plane i (0..3);  WR: bit i = write plane i (0..3), bit 4 = Q5, bit 5 = Q6, bit 6 = S4.
+// in == out for in-place; shift: out slot j reads in slot j + shift (aligned stores, misaligned loads)
+template <int R, int RD, int WR, bool STSHIFT = false>
+__global__ __launch_bounds__(256) void k_upd(const char* __restrict__ in, char* __restrict__ out, uint32_t n, uint32_t C, uint32_t shift, int K) {
+    const uint32_t base = blockIdx.x * 256 * R;
+    float4 q[4][R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = base + r * 256 + threadIdx.x;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            q[p][r] = make_float4(1.f, 2.f, 3.f, 4.f);
+            if ((RD >> p & 1) && i < n) q[p][r] = ((const float4*)(in + (size_t)16 * p * C))[i + (STSHIFT ? 0u : shift)];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        uint32_t i = base + r * 256 + threadIdx.x;
+        if (i < n) {
+            if (STSHIFT) i += shift;
+            float4 a = q[0][r], b = q[1][r], c = q[2][r], d = q[3][r];
+            a.x = work(a.x + b.x, K);
+            float4 e = make_float4(a.x + b.x, a.y * c.y, d.z, a.w);
+            float4 f = make_float4(b.w, c.x, d.y, e.x);
+            if (WR & 1) ((float4*)(out))[i] = a;
+            if (WR & 2) ((float4*)(out + (size_t)16 * C))[i] = b;
+            if (WR & 4) ((float4*)(out + (size_t)32 * C))[i] = c;
+            if (WR & 8) ((float4*)(out + (size_t)48 * C))[i] = d;
+            if (WR & 16) ((float4*)(out + (size_t)64 * C))[i] = e;
+            if (WR & 32) ((float4*)(out + (size_t)80 * C))[i] = f;
+            if (WR & 64) ((float*)(out + (size_t)96 * C))[i] = e.y;
+        }
+    }
+}
+
+template <typename F>
+double timeit(F f, int iters) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) f(i);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) f(i);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e-3 / iters;
+}
+
+int main() {
+    for (uint32_t n : {1000000u, 4000000u, 16000000u}) {
+        const uint32_t C = (n + 1023) / 1024 * 1024 + 262144;
+        const size_t pb = (size_t)100 * C;
+        char *p0, *p1; CK(hipMalloc(&p0, pb)); CK(hipMalloc(&p1, pb));
+        CK(hipMemset(p0, 0, pb)); CK(hipMemset(p1, 0, pb));
+        const dim3 g((n + 1023) / 1024), b(256);
+        for (int K : {0, 150}) {
+            double t;
+#define RUN(RD, WR, inplace, shift, bytes, tag) \
+            t = timeit([&](int i) { char* a = (i & 1) ? p1 : p0; char* o = (inplace) ? a : ((i & 1) ? p0 : p1); \
+                hipLaunchKernelGGL((k_upd<4, RD, WR>), g, b, 0, 0, a, o, n, C, shift, K); }, 50); \
+            printf("n=%8u K=%3d %-44s: %8.2f us  %7.1f GB/s moved\n", n, K, tag, t * 1e6, (double)(bytes) * n / t / 1e9);
+            RUN(15, 127, false, 0u, 164, "ping-pong r4 w7 (164 B)")
+            RUN(15, 127, false, 16667u, 164, "ping-pong shifted loads, aligned stores")
+            for (uint32_t sh : {1u, 3u, 4u, 8u, 16667u}) {
+                t = timeit([&](int i) { char* a = (i & 1) ? p1 : p0; char* o = (i & 1) ? p0 : p1;
+                    hipLaunchKernelGGL((k_upd<4, 15, 127, true>), g, b, 0, 0, a, o, n, C, sh, K); }, 50);
+                printf("n=%8u K=%3d ping-pong aligned loads, stores shifted by %5u : %8.2f us  %7.1f GB/s moved\n", n, K, sh, t * 1e6, 164.0 * n / t / 1e9);
+            }
+            RUN(15, 127, true, 0u, 164, "in place r4 w7 (164 B)")
+            RUN(15, 115, true, 0u, 132, "in place r4 w Q0 Q1 Q5 Q6 S4 (132 B)")
+            RUN(15, 83, true, 0u, 116, "in place r4 w Q0 Q1 Q5 S4 (116 B)")
+            RUN(3, 115, true, 0u, 100, "in place r Q0 Q1 w Q0 Q1 Q5 Q6 S4 (100 B)")
+            RUN(3, 83, true, 0u, 84, "in place r Q0 Q1 w Q0 Q1 Q5 S4 (84 B)")
+            RUN(3, 3, true, 0u, 64, "in place r Q0 Q1 w Q0 Q1 (64 B)")
+        }
+        CK(hipFree(p0)); CK(hipFree(p1));
+    }
+    return 0;
+}
