@@ -38,9 +38,19 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES = 156  # 64 B read + 92 B written per particle-update
-ACTUAL_BYTES = 164  # what the kernel moves: +8 B (initial_scale, lifetime re-written by the ping-pong compaction)
+SURVEY_BYTES = 156  # 64 B read + 92 B written per particle-update (every plane rewritten)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def path_bytes(ps):
+    """(update path, algorithmic B / particle-update, moved B / particle-update) of the system's first spawner, from the
+    library (fw_debug_update_path).  General (compacting, ping-pong) path: every plane is rewritten at the particle's new
+    slot -- 64 B read + 100 B written, of which 8 B (initial_scale, lifetime: unchanged values) are not in SURVEY.md's
+    156 B; a colour plane with a one-key gradient is not written at all (-16 B each, algorithmic and moved alike).
+    FIFO ring path (one lifetime value: particles never move): 64 B read + only the planes the update changes."""
+    h = next(iter(ps.spawners.values()))
+    mode, moved, algo = h.update_path(0)
+    return mode, algo, moved
 
 
 def cpu_baseline(args, dt):
@@ -107,9 +117,13 @@ def kernel_roofline(ps, step, frames, label):
         return None
     kt = ev_ms * 1e-3 / launches
     per_launch = particles / launches
-    achieved = per_launch * ALGO_BYTES / kt / 1e9
+    mode, algo, moved = path_bytes(ps)
+    achieved = per_launch * algo / kt / 1e9
     return {"workload": label, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "particles_per_launch": per_launch, "avg_kernel_us": kt * 1e6, "launches": launches}
+            "particles_per_launch": per_launch, "avg_kernel_us": kt * 1e6, "launches": launches, "update_path": mode,
+            "algorithmic_bytes_per_particle": algo, "moved_bytes_per_particle": moved,
+            "at_survey_156B_per_particle": {"achieved": per_launch * SURVEY_BYTES / kt / 1e9,
+                                            "frac": per_launch * SURVEY_BYTES / kt / 1e9 / HBM_PEAK_GBS}}
 
 
 def main():
@@ -266,7 +280,7 @@ def main():
         value = updated / elapsed
         if workload == "configs1":
             wl = ("configs[1]: 1 emitter x rate 1e6/s x lifetime 1 s per GPU (983 333 live), Point emission, linear 2-key "
-                  "scale/colour curves, dt=1/60, spawn+update+stable compaction every step")
+                  "scale/colour curves, dt=1/60, spawn + update + removal of the dead (order kept) every step")
             scaling, em_total = "weak", world
         else:
             wl = (f"configs[4]: {args.emitters} Sphere emitters x {args.live_per_emitter} live (radial velocity, lifetimes "
@@ -286,7 +300,7 @@ def main():
                 "allreduced_live_count_last_frame": hist[-1] if hist else None,
                 "update_mode": os.environ.get("FW_UPDATE_MODE", "fused"),
             },
-            "hbm_gbs_algorithmic_whole_step": value * ALGO_BYTES / 1e9,
+            "hbm_gbs_algorithmic_whole_step": value * (roof["algorithmic_bytes_per_particle"] if roof else SURVEY_BYTES) / 1e9,
         }
         if roof:
             traffic = None
@@ -296,12 +310,18 @@ def main():
                     traffic = json.load(open(tp)).get("fw_k_update_bytes_per_launch")
                 except Exception:
                     traffic = None
+            fifo = roof.get("update_path") == "fifo"
             roof.update({
-                "bound": "hbm", "kernel": "fw_k_update_stream (forecast frames; fw_k_update<fused> when dt changes)",
-                "traffic": traffic, "algorithmic_bytes_per_particle": ALGO_BYTES, "moved_bytes_per_particle": ACTUAL_BYTES,
+                "bound": "hbm",
+                "kernel": ("fw_k_update_fifo (in-place ring update of a one-lifetime particle type, any dt)" if fifo else
+                           "fw_k_update_stream (forecast frames; fw_k_update<fused> when dt changes)"),
+                "traffic": traffic,
                 "measured_hbm_copy_GBps": measured_copy / 1e9,
-                "note": "at 1M particles the 200 MB ping-pong working set sits in the 256 MiB Infinity Cache; "
-                        "`hbm_resident` is the same kernel on a 16.8M-particle working set",
+                "note": ("at 1M particles the 100 MB ring sits in the 256 MiB Infinity Cache; `hbm_resident` is the general "
+                         "(compacting) kernel on a 16.8M-particle working set -- configs[2]'s lifetimes are a range, so its "
+                         "particles do not die in order" if fifo else
+                         "at 1M particles the 200 MB ping-pong working set sits in the 256 MiB Infinity Cache; "
+                         "`hbm_resident` is the same kernel on a 16.8M-particle working set"),
                 "timing": "hipEvent start/stop attached to each update dispatch on the context's stream "
                           "(hipExtLaunchKernel: the packet's begin/end timestamps, the same duration rocprofv3 "
                           "--kernel-trace reports); second pass over the same steady state, kept out of `value`",

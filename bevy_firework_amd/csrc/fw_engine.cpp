@@ -268,7 +268,6 @@ struct fw_ctx {
     uint32_t boxes_epoch = 0;  // epoch of the update that left valid boxes (0 = none)
     bool colors_dirty = false; // some SegHost::colors_dirty is set
     bool use_fifo = true;      // FW_FIFO=0: constant-lifetime types take the general (compacting) path too (A/B, tests)
-    uint32_t fifo_rounds = 4;  // ring tile of the FIFO launch in rounds of FW_BLOCK (FW_FIFO_ROUNDS: 1, 2, 4)
     // smallest (derived or given) capacity that makes a type a FIFO ring: the mode costs a launch of its own next to the
     // general one, which only large segments repay (FW_FIFO_MIN; tests set 0)
     uint32_t fifo_min = 131072;
@@ -1240,7 +1239,6 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_STREAM")) ctx->use_stream = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO")) ctx->use_fifo = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
-    if (const char *m = getenv("FW_FIFO_ROUNDS")) ctx->fifo_rounds = atoi(m) == 1 ? 1u : (atoi(m) == 2 ? 2u : 4u);
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
     if (const char *m = getenv("FW_OPS_ZEROCOPY")) ctx->ops_zerocopy = atoi(m) != 0;
     if (const char *m = getenv("FW_STATIC_NEW")) ctx->use_static_new = atoi(m) != 0;  // 0: always count + look back
@@ -1920,7 +1918,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         uint32_t f_ops = 0, f_tiles = 0;
         auto flush = [&]() -> hipError_t {
             if (!fa.n_segs) return hipSuccess;
-            fa.parity = p, fa.epoch = a.epoch, fa.dbg = ctx->dbg, fa.dt = dt, fa.rounds = ctx->fifo_rounds;
+            fa.parity = p, fa.epoch = a.epoch, fa.dbg = ctx->dbg, fa.dt = dt;
             fa.done_tag = a.done_tag, fa.done_value = a.done_value;
             fa.host_counts = a.host_counts;
             fa.live_out = a.live_out, fa.live_next = a.live_next;
@@ -1965,7 +1963,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             // when their records are wanted, the first survivor otherwise) to the last old particle; at least one in all
             // (it publishes the counts)
             const uint32_t lo = std::min(S.destroyed ? 0u : dead, n_in), cnt = n_in - lo;
-            const uint32_t ftile = ctx->fifo_rounds * FW_BLOCK;
+            const uint32_t ftile = FW_TILE;
             const uint32_t ps = (uint32_t)(((uint64_t)S.head + lo) % S.capacity), ring_tiles = S.capacity / ftile;
             const uint32_t ns0 = (uint32_t)(((uint64_t)S.head + n_in) % S.capacity);  // slot of the first new particle
             F.spawn_a = std::min(n_spawn, S.capacity - ns0);
@@ -2402,22 +2400,38 @@ fw_status fw_debug_read_launches(fw_ctx *ctx, unsigned long long *out512, uint32
     if (epoch) *epoch = (uint32_t)(ctx->frame & 0x3FFFFFFFu);
     return FW_OK;
 }
-// which update path a particle type is on: *mode = 1 FIFO ring (in place), 0 general (compacting); *bytes_per_particle =
-// the bytes one update of a live particle reads and writes on that path (planes the type never changes are not written)
-fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t *mode, uint32_t *bytes_per_particle) {
+// which update path a particle type is on: *mode = 1 FIFO ring (in place), 0 general (compacting); *moved_bytes = the
+// bytes one update of a live particle reads and writes on that path; *algorithmic_bytes = the part of them that carries
+// state the update needs or changes (SURVEY.md 8(d)'s convention: a float4 plane rewritten for three changed components
+// moves 4 bytes -- initial_scale, lifetime -- that are not algorithmic)
+fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t *mode, uint32_t *moved_bytes,
+                               uint32_t *algorithmic_bytes) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || type >= sp->seg.size()) return FW_EINVAL;
     const SegHost &S = ctx->segs[sp->seg[type]];
     const TypeHost &T = sp->types[type];
     if (mode) *mode = S.fifo ? 1 : 0;
-    if (bytes_per_particle) {
-        const uint32_t colours = (T.base.kind != 0 ? 16u : 0u) + (T.emis.kind != 0 ? 16u : 0u);
-        // general: read Q0..Q3 (+ the last_emitted planes), write Q0..Q3 + scale + the non-constant colour planes
-        // FIFO: read Q0..Q3, write Q0 Q1 + scale unless its curve is constant + the non-constant colour planes
-        // (+ rotation / angular velocity where they change: not counted)
-        *bytes_per_particle = S.fifo ? 64u + 32u + (T.scale.kind != 0 ? 4u : 0u) + colours
-                                     : 64u + 64u + 4u + colours + 8u * S.n_lplanes;
+    const uint32_t colours = (T.base.kind != 0 ? 16u : 0u) + (T.emis.kind != 0 ? 16u : 0u);  // one-key gradients: never rewritten
+    uint32_t moved, algo;
+    if (S.fifo) {
+        // in place: position+age and velocity always; rotation only where some emitter makes the particles spin (or the
+        // type accelerates them), angular velocity only if it then changes; scale unless its curve is constant
+        bool spins = false;
+        for (const EmissionHost &E : sp->em)
+            if ((uint32_t)E.es.particle_index == type)
+                spins |= !(E.es.initial_angular_velocity.magnitude.min == 0.f && E.es.initial_angular_velocity.magnitude.max == 0.f);
+        const float *aa = T.ps.angular_acceleration;
+        const bool acc = aa[0] != 0.f || aa[1] != 0.f || aa[2] != 0.f;
+        const uint32_t q2 = (spins || acc) ? 16u : 0u, q3 = ((spins && T.ps.angular_drag != 0.f) || acc) ? 16u : 0u;
+        moved = 64u + 32u + q2 + q3 + (T.scale.kind != 0 ? 4u : 0u) + colours;
+        algo = moved - 4u - (q3 ? 4u : 0u);
+    } else {
+        // compacting: every state plane lands at a new slot (+ the last_emitted planes of a Nested parent, read and written)
+        moved = 64u + 64u + 4u + colours + 8u * S.n_lplanes;
+        algo = moved - 8u;
     }
+    if (moved_bytes) *moved_bytes = moved;
+    if (algorithmic_bytes) *algorithmic_bytes = algo;
     return FW_OK;
 }
 fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_t max_tiles, uint64_t *n_tiles) {

@@ -117,7 +117,7 @@ struct FwFifoSeg {
     uint32_t op0, op1; // this segment's spawn ops in FwInlineOps
     // workgroups [tile_first, tile_first + n_tiles) of the launch: first n_vt_a + n_vt_b of FW_BLOCK new particles each
     // (new particles [0, spawn_a) occupy the slots up to the end of the buffer, [spawn_a, n_spawn) those from slot 0),
-    // then one per ring tile (FwFifoArgs::rounds * FW_BLOCK slots) from tile0 on, covering the particles that were there before
+    // then one per ring tile (FW_TILE slots) from tile0 on, covering the particles that were there before
     uint32_t tile0;
     uint32_t tile_first, n_tiles;
     uint32_t spawn_a, n_vt_a, n_vt_b;
@@ -126,7 +126,6 @@ struct FwFifoSeg {
 struct FwFifoArgs {
     FwFifoSeg s[FW_FIFO_PER_LAUNCH];
     uint32_t n_segs, parity, epoch, dbg;
-    uint32_t rounds;  // a ring tile is rounds * FW_BLOCK slots (1, 2 or 4: capacities are multiples of FW_TILE)
     float dt;
     uint32_t any_inst;
     // which optional planes the particle types of this launch write: bit 0 base colour (gradient not constant), bit 1

@@ -92,22 +92,6 @@ __device__ __forceinline__ float4 fw_ld4w(const char *win, uint32_t byte_off) {
 #endif
     return make_float4(v.x, v.y, v.z, v.w);
 }
-// Prefetch whose completion the KERNEL tracks, not the compiler.  The memory counter (vmcnt) is in-order and counts
-// stores too; the compiler's wait for a loaded register allows as many younger operations to stay outstanding as it
-// can PROVE were issued after the load.  In the round loops the stores of the current round sit between the prefetch
-// and its use, mostly under lane predicates or wave-uniform conditions, so the provable number is small and the wave
-// ends up waiting for the acknowledgement of its own stores every round -- 4 x ~2 us per tile at 1M particles.  These
-// loads are invisible to that analysis; fw_prefetch_wait<K> is the matching wait, K = stores the round is KNOWN to
-// have issued after them.  (The compiler's own waits stay correct: not knowing about these loads it can only wait
-// for more, never less.)
-__device__ __forceinline__ void fw_ld4w_async(fw_f4 &dst, const char *win, uint32_t byte_off) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(byte_off), "s"(win) : "memory");
-}
-template <int K>
-__device__ __forceinline__ void fw_prefetch_wait(fw_f4 &a, fw_f4 &b, fw_f4 &c, fw_f4 &d) {
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(K) : "memory");
-}
-__device__ __forceinline__ float4 fw_f4_to_float4(const fw_f4 &v) { return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void fw_st4w(char *win, uint32_t byte_off, float4 v) {
     const fw_f4 x = {v.x, v.y, v.z, v.w};
     FW_GLOBAL fw_f4 *p = reinterpret_cast<FW_GLOBAL fw_f4 *>(reinterpret_cast<FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off);
@@ -1553,12 +1537,15 @@ __device__ __forceinline__ void fw_fifo_inst_out(const FwFifoSeg &F, char *inst,
 }
 
 // WM: the optional planes this launch's particle types write (fw_integrate_store), or -1 = read from the type
+#ifndef FW_FIFO_UNROLL
+#define FW_FIFO_UNROLL 4
+#endif
 template <bool INST, int WM>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifoArgs a, FwInlineOps inl) {
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
-    const int R = (int)a.rounds;                   // rounds per ring tile (the host's choice: 1, 2 or 4)
-    const uint32_t TILE = a.rounds * BLK;
+    constexpr int R = FW_TILE / BLK;  // (smaller ring tiles were measured: 2 rounds 26.7 us, 1 round 26.2 us, 4 rounds 24.6 us)
+    constexpr uint32_t TILE = FW_TILE;
     __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
     __shared__ __attribute__((aligned(16))) float4 s_inst[INST ? NW * 256 : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1660,7 +1647,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         }
         // ---- (2) the particles that were here before this frame: a streaming loop, next round's loads in flight while
         // this one is integrated and stored.  No barrier, no exchange between lanes: the waves of a workgroup drift apart.
-#pragma unroll 1
+#pragma unroll FW_FIFO_UNROLL
         for (int r = 0; r < R; r++) {
             const uint32_t s = sbase + r * BLK + tid;
             const uint32_t in_ = (uint32_t)(min(r + 2, R - 1) * BLK + (int)tid) * 16u;  // two rounds ahead (the last re-read)

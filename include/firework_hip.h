@@ -266,9 +266,10 @@ fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_
 fw_status fw_debug_read_timestamps2(fw_ctx *ctx, unsigned long long *out, unsigned long long *prev, uint64_t max_tiles,
                                     uint64_t *n_tiles);
 fw_status fw_debug_read_launches(fw_ctx *ctx, unsigned long long *out32768, uint32_t *epoch);
-/* which update path a particle type is on (1 = FIFO ring updated in place, 0 = general compacting path) and the bytes
- * one update of a live particle moves on it */
-fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner spawner, uint32_t type, int32_t *mode, uint32_t *bytes_per_particle);
+/* which update path a particle type is on (1 = FIFO ring updated in place, 0 = general compacting path), the bytes one
+ * update of a live particle moves on it, and how many of those are algorithmic (bench.py's roofline accounting) */
+fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner spawner, uint32_t type, int32_t *mode, uint32_t *moved_bytes,
+                               uint32_t *algorithmic_bytes);
 
 /* ---- pure host helpers (no GPU needed; the bit-exact count arithmetic) ------------ */
 /* compute_emission_count (core.rs:553-575) exactly as fw_step's host side evaluates it */

@@ -4,6 +4,7 @@ TAG=${1:-r02}
 R=$PWD; OUT=gpurun_out/profile_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 # 1. the bench line itself (default flags)
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+FW_FIFO=0 timeout 900 python bench.py --no-cpu > $OUT/bench_general_path.json 2>> $OUT/bench.err   # the same line with every type on the compacting path
 # 2. rocprofv3 kernel trace + stats of the same command (without the CPU baseline and the extra workloads: the
 #    kernel of the headline configuration only)
 cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT -o ${TAG}_stats --output-format csv -- python $R/bench.py --no-cpu --no-extras > $R/$OUT/stats_bench.json 2>/dev/null; cd $R
@@ -14,14 +15,17 @@ python profiles/analyze_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
 # 4. memory microbenchmarks (measured roofline of the kernel's load/store shape; copy sweep at 1 GiB)
 ./tools/membw 64 > $OUT/membw.txt 2>&1
 ./tools/membw 1024 copy > $OUT/copy_sweep.txt 2>&1
+[ -x tools/inplace ] && ./tools/inplace > $OUT/inplace.txt 2>&1   # what in-place ring updates of various plane sets can reach
 # 5. in-kernel timelines, launch period, the rows ranked next, size sweep, ablations
 timeout 200 python tools/launch_gaps.py > $OUT/launch_gaps.txt 2>&1
-timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline.txt 2>&1
-FW_TL_JITTER=1 timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline_variable_dt.txt 2>&1
+FW_FIFO=0 timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline.txt 2>&1   # (instrumentation of the general path's kernels)
+FW_FIFO=0 FW_TL_JITTER=1 timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline_variable_dt.txt 2>&1
 timeout 300 python tools/bench_next_rows.py > $OUT/next_rows.txt 2>&1
 timeout 300 python tools/fused_sizes.py > $OUT/fused_sizes.txt 2>&1
+FW_FIFO=0 timeout 300 python tools/fused_sizes.py > $OUT/fused_sizes_general_path.txt 2>&1
 timeout 300 python tools/dbg_modes.py > $OUT/dbg_modes.txt 2>&1
 timeout 300 python tools/var_dt.py 400 > $OUT/var_dt.txt 2>&1
+FW_FIFO=0 timeout 300 python tools/var_dt.py 400 > $OUT/var_dt_general_path.txt 2>&1
 # 6. the other BASELINE configs on one GPU, the small-emitter regime and the host half of fw_step
 timeout 600 python tools/bench_configs.py > $OUT/configs.txt 2>&1
 timeout 300 python tools/small_emitters_gpu.py > $OUT/small_emitters.txt 2>&1
