@@ -223,6 +223,12 @@ class ParticleSpawnerData {
     // render hand-off fused into the update (fw_spawner_attach_instances): device buffer of `cap` 64-byte records
     void attach_instances(void *device_buffer, uint64_t cap, uint32_t particle_type = 0);
     bool aabb(Vec3 &mn, Vec3 &mx);                                        // render.rs:677-703
+    // which kernel family updates a particle type: true = in-place FIFO ring (types with one lifetime value)
+    bool on_fifo_path(uint32_t particle_type = 0) {
+        int32_t mode = 0;
+        check_(fw_debug_update_path(raw_(), handle, particle_type, &mode, nullptr, nullptr));
+        return mode != 0;
+    }
     void set_transform(const Transform &local, const Transform *global = nullptr) {
         transform = local;
         has_global = global != nullptr;
@@ -235,6 +241,8 @@ class ParticleSpawnerData {
 
   private:
     friend class ParticleSystemPlugin;
+    fw_ctx *raw_();
+    void check_(fw_status st);
     ParticleSystemPlugin *sys = nullptr;
     ParticleSpawner settings;
     Transform transform, global_transform;
@@ -334,6 +342,10 @@ class ParticleSystemPlugin {
         check(fw_ctx_set_colliders(ctx_, v.data(), (uint32_t)v.size()));
     }
 
+    // update_aabbs (render.rs:677-703) fused into the update: every frame leaves per-tile boxes, ParticleSpawnerData::aabb
+    // folds them instead of re-reading the particles
+    void track_aabbs(bool enable) { check(fw_ctx_track_aabbs(ctx_, enable ? 1 : 0)); }
+
     // one run of the chained systems (plugin.rs:46-60)
     void update(float dt) {
         for (auto *d : spawners_) {
@@ -381,6 +393,8 @@ class ParticleSystemPlugin {
     uint32_t next_uid_ = 0;
 };
 
+inline fw_ctx *ParticleSpawnerData::raw_() { return sys->raw(); }
+inline void ParticleSpawnerData::check_(fw_status st) { sys->check(st); }
 inline void ParticleSpawnerData::queue_particles(uint64_t n) { sys->check(fw_spawner_queue(sys->raw(), handle, n)); }
 inline bool ParticleSpawnerData::active() {
     int32_t a = 0;

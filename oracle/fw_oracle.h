@@ -30,9 +30,15 @@
  *     core.rs:806-834 (total in {22,23}) and cross-checked bit-for-bit against
  *     an independent numpy-float32 restatement (tests/golden/).
  *   - even gradient + Mix: pinned by curve.rs:246-258.
- *   - update_particles, uneven cores, f32 curves, quaternion path: the
- *     reference holds no test for them -> "parity unpinned"; anchored on the
- *     reference source lines above plus hand-derived KATs.
+ *   - update_particles, uneven cores, f32 curves (VectorSpace::lerp:
+ *     a * (1 - t) + b * t), quaternion path, particle_collision
+ *     (core.rs:744-800 over this backend's analytic ray cast): the reference
+ *     holds no test for them -> "parity unpinned"; anchored on the reference
+ *     source lines above, on hand-derived KATs and on a second, independent
+ *     array-oriented numpy restatement of the whole path
+ *     (tests/golden/np_sim.py) whose multi-frame trajectories this oracle
+ *     reproduces (tests/test_oracle_golden.py) and which the HIP path is
+ *     compared with directly (tests/test_gpu_golden.py).
  *   - spawn ATTRIBUTES (RandF32/RandVec3/PitchYaw/shapes): the reference uses
  *     an unseeded thread-local RNG (rand::random), so they are unpinnable in
  *     principle; this oracle defines a Philox4x32-10 counter stream with the

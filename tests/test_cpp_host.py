@@ -31,3 +31,77 @@ def test_cpp_stress_test_counts():
     assert out.returncode == 0, out.stderr
     n = int(re.search(r"Particles: (\d+)", out.stdout).group(1))
     assert n in (157333, 157334, 157335)  # examples/stress_test.rs load: 157 334 per 1 s cycle
+
+
+def _fnv(b: bytes) -> int:
+    h = 1469598103934665603
+    for x in b:
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_and_python_mirror_drive_the_library_identically():
+    """examples/mirror_check.cpp (three particle types, Global / OnDemand / OneShot / Nested entries, all curve kinds,
+    modifier, transforms, parent velocity, destroyed handler, colliders, fused AABB) through include/firework.hpp, and
+    the same scenario through bevy_firework_amd/: the same library, so every digest must be identical -- a field either
+    mirror marshals differently (or forgets) shows up here"""
+    import numpy as np
+
+    from bevy_firework_amd import settings as S
+    from bevy_firework_amd.system import ParticleSystem
+
+    build()
+    out = subprocess.run([os.path.join(ROOT, "examples", "mirror_check")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    cpp_lines = out.stdout.strip().splitlines()
+
+    seen = [0]
+    p0 = S.ParticleSettings(lifetime=S.RandF32.constant(0.4), initial_scale=S.RandF32(0.5, 2.0),
+                            scale_curve=S.FireworkCurve.even_samples([1.0, 2.0, 0.5]),
+                            base_color=S.FireworkGradient.uneven_samples([(0.0, (10, 7, 1, 1)), (0.7, (3, 1, 1, 1)),
+                                                                          (1.0, (0.1, 0.1, 0.1, 0))]),
+                            linear_drag=0.3, particles_destroyed=lambda dead: seen.__setitem__(0, seen[0] + len(dead)))
+    p1 = S.ParticleSettings(lifetime=S.RandF32(0.2, 0.6), acceleration=(0.0, 0.5, 0.0),
+                            scale_curve=S.FireworkCurve.uneven_samples([(0.0, 1.0), (0.8, 1.2), (1.0, 0.0)]),
+                            emissive_color=S.FireworkGradient.even_samples([(4, 2, 0, 1), (0, 0, 0, 1)]),
+                            angular_drag=0.1, angular_acceleration=(0.1, 0.0, -0.2))
+    p2 = S.ParticleSettings(lifetime=S.RandF32(0.5, 0.9), pbr=True,
+                            collision_settings=S.ParticleCollisionSettings(0.6, 0.2, False, 3))
+    e0 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(5000.0),
+                            emission_shape=S.EmissionShape.Sphere(0.5),
+                            initial_velocity=S.RandVec3(S.RandF32(1.0, 6.0), (0.0, 1.0, 0.0), 0.0),
+                            initial_velocity_radial=S.RandF32(1.0, 2.0))
+    e1 = S.EmissionSettings(particle_index=1, emission_pacing=S.EmissionPacing.CountOverDuration(8.0, 1.0, 0.1, 0.9),
+                            emission_mode=S.EmissionMode.Nested(0), inherit_parent_velocity=False)
+    e2 = S.EmissionSettings(particle_index=2, emission_pacing=S.EmissionPacing.OnDemand(),
+                            emission_shape=S.EmissionShape.Circle((0.0, 0.0, 1.0), 2.0),
+                            initial_velocity=S.RandVec3(S.RandF32(0.0, 3.0), (0.0, -1.0, 0.0), 0.0),
+                            initial_rotation=(0.0, 0.38941834, 0.0, 0.92106099))
+    e3 = S.EmissionSettings(particle_index=2, emission_pacing=S.EmissionPacing.OneShot(700))
+    lines = []
+    with ParticleSystem(device=0, seed=0x00C0FFEE) as ps:
+        ps.track_aabbs(True)
+        ps.set_colliders([S.Collider.Plane((0.0, -1.0, 0.0), (0.0, 1.0, 0.0)), S.Collider.Sphere((1.0, 0.5, 0.0), 0.75, 2),
+                          S.Collider.Box((-2.0, 0.0, 0.0), (0.5, 1.0, 0.5), (0.0, 0.38268343, 0.0, 0.92387953))])
+        d = ps.spawn(S.ParticleSpawner([p0, p1, p2], [e0, e1, e2, e3]), S.Transform((0.0, 1.0, 0.0)), uid=42,
+                     modifier=S.EffectModifier(2.0, 0.5))
+        d.set_parent_velocity((0.5, 0.0, -0.25))
+        dt = np.float32(1.0 / 60.0)
+        for fr in range(60):
+            if fr in (0, 7, 8, 31):
+                d.queue_particles(500 + 10 * fr)
+            if fr == 20:
+                d.set_transform(S.Transform((1.0, 2.0, 3.0), (0.0, 0.0, 0.38268343, 0.92387953)))
+            ps.update(dt)
+            if fr % 10 != 9:
+                continue
+            c = d.counts()
+            digests = " ".join(f"{_fnv(d.particles(t).tobytes()):016x}" for t in range(3))
+            any_, mn, mx = d.aabb()
+            box = np.concatenate([mn, mx]).astype(np.float32).tobytes()
+            lines.append(f"frame {fr} counts {c[0]} {c[1]} {c[2]} {digests} aabb {int(any_)} {_fnv(box):016x} "
+                         f"active {int(d.active())}")
+    lines.append(f"destroyed reported {seen[0]}")
+    assert cpp_lines == lines, "\n".join(["C++:"] + cpp_lines + ["Python:"] + lines)
+    assert int(cpp_lines[-2].split()[3]) > 1000 and seen[0] > 2000
