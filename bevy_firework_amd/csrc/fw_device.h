@@ -116,7 +116,7 @@ struct alignas(16) FwOp {
     uint32_t rel_base;    // slots already taken this frame by earlier Global ops on `seg`
     uint64_t serial_base; // RNG serial of the first particle
     uint32_t first_block; // first workgroup of this op in the spawn launch
-    uint32_t pad0;
+    uint32_t head;        // ring head of `seg` when it is a FIFO ring (slot of its particle 0), else 0
     float origin_pos[4];
     float origin_rot[4];
     float parent_vel[4];
@@ -139,7 +139,9 @@ struct alignas(16) FwNestOp {
     uint32_t parent_cap;     // its capacity (plane stride)
     uint32_t parent_lplane;  // which last_emitted_age plane of the parent type belongs to this entry
     float n_count, n_start, n_end;  // CountOverDuration of the entry (core.rs:474-481)
-    uint32_t pad0;
+    uint32_t parent_head;    // ring heads of the two segments (FIFO rings; 0 otherwise): particle i sits in slot
+    uint32_t child_head;     // (head + i) mod capacity
+    uint32_t pad0[3];
 };
 
 // decoupled look-back status word: {epoch:30 | state:2 | value:32}

@@ -41,6 +41,7 @@ constexpr uint64_t kMaxSpawnPerOp = 1ull << 30;
 constexpr uint32_t kTimingEvents = 4096;
 constexpr uint32_t kMaxFifoSegs = FW_FIFO_PER_LAUNCH;  // FIFO segments per context: one launch (beyond: the general path)
 constexpr size_t kMaxCohorts = 16384;    // spawn cohorts a FIFO segment tracks before it gives the mode up (tiny dt)
+constexpr uint32_t kReportRing = 32768;  // pinned per-frame cohort sizes of a ring that receives Nested children (> kMaxCohorts)
 
 std::string g_create_error;
 
@@ -136,8 +137,17 @@ struct alignas(64) SegHost {
     struct Cohort {
         uint32_t n;
         float age;
+        uint64_t frame = 0;  // frame the cohort was added in
+        bool known = true;   // false: a cohort of Nested children whose size the device has not been asked for yet
     };
     std::deque<Cohort> coh;  // oldest first
+    // A ring in a spawner WITH Nested entries: in frames that run the Nested pass its new particles are materialised in
+    // the ring before the update (fw_k_spawn / fw_k_nest address it through the head) and fw_k_update_fifo gives them
+    // their first update (FwFifoSeg::mat).  fifo_dev: the type receives Nested children -- its live count is known to the
+    // device only, and the size of each frame's cohort reaches the host through a pinned ring (h_report[frame %
+    // kReportRing] = {epoch, added}) long before the host needs it: when the cohort's age reaches the lifetime.
+    bool fifo_mat = false, fifo_dev = false;
+    unsigned long long *h_report = nullptr;
 };
 
 struct SpawnerHost {
@@ -268,11 +278,14 @@ struct fw_ctx {
     uint32_t boxes_epoch = 0;  // epoch of the update that left valid boxes (0 = none)
     bool colors_dirty = false; // some SegHost::colors_dirty is set
     bool use_fifo = true;      // FW_FIFO=0: constant-lifetime types take the general (compacting) path too (A/B, tests)
+    bool fifo_nested = true;   // FW_FIFO_NESTED=0: ... those of spawners with Nested entries do (A/B)
     // smallest (derived or given) capacity that makes a type a FIFO ring: the mode costs a launch of its own next to the
     // general one, which only large segments repay (FW_FIFO_MIN; tests set 0)
     uint32_t fifo_min = 131072;
     uint32_t n_fifo = 0;       // FIFO segments in use (at most kMaxFifoSegs: their records travel in kernel arguments)
-    std::vector<FwOp> fifo_ops;  // this frame's Global ops that feed FIFO segments
+    std::vector<FwOp> fifo_ops;  // this frame's Global ops that feed FIFO segments (spawned inside fw_k_update_fifo)
+    std::vector<std::pair<uint32_t, FwOp>> fifo_mat_ops;  // {emission index, op}: rings of spawners with Nested entries -- the
+                                                         // Nested pass of the frame, if there is one, must find them in memory
     uint64_t tev_frames = 0;   // frames timed so far (a frame may take several update launches)
 
     uint32_t nest_seq = 0;  // launches of fw_k_nest so far (tag of their look-back words)
@@ -571,7 +584,7 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
     if (st) return st;
     SegHost old = s;
     if (make_general && s.fifo) {
-        s.fifo = false, s.coh.clear();
+        s.fifo = false, s.fifo_mat = s.fifo_dev = false, s.coh.clear();
         ctx->n_fifo--;
         ctx->tab_force = true;
     }
@@ -581,6 +594,7 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
         s = old;
         return st;
     }
+    if (old.fifo && !s.fifo && s.h_report) hipHostFree(s.h_report), s.h_report = nullptr;
     s.head = 0;
     const uint32_t p = ctx->parity;
     const uint32_t n = old.ub;  // exact after the refresh
@@ -872,14 +886,29 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         S.collides = p.collision.enabled != 0;
         S.life_bound = (double)std::max(p.lifetime.min, p.lifetime.max);  // lifetime = lerp(min, max, u), u in [0, 1)
         S.win_ok = !S.nested_fed && std::isfinite(S.life_bound);
-        {  // FIFO ring (SegHost::fifo): one lifetime value, fed by Global entries only, no collisions
-            bool any_nested = false;
-            for (uint32_t i = 0; i < ne; i++) any_nested |= d->emission_settings[i].mode == FW_MODE_NESTED;
-            S.fifo = ctx->use_fifo && !any_nested && !S.collides && p.lifetime.min == p.lifetime.max &&
-                     std::isfinite(p.lifetime.min) && ctx->n_fifo < kMaxFifoSegs && caps[t] >= ctx->fifo_min;
+        {  // FIFO ring (SegHost::fifo): one lifetime value, no collisions; spawners whose particles emit onto their own
+            // type stay on the general path (a parent would see this frame's children as parents)
+            // ... and so does a type that receives Nested children AND Global particles (its Global particles would have to be
+            // placed behind a live count only the device knows)
+            bool any_nested = false, self_nested = false, mixed_feed = false;
+            for (uint32_t i = 0; i < ne; i++) {
+                const fw_emission_settings &e = d->emission_settings[i];
+                any_nested |= e.mode == FW_MODE_NESTED;
+                self_nested |= e.mode == FW_MODE_NESTED && e.target_particle_type == e.particle_index;
+                mixed_feed |= S.nested_fed && e.mode == FW_MODE_GLOBAL && (uint32_t)e.particle_index == t;
+            }
+            S.fifo = ctx->use_fifo && !self_nested && !mixed_feed && !S.collides && p.lifetime.min == p.lifetime.max &&
+                     std::isfinite(p.lifetime.min) && ctx->n_fifo < kMaxFifoSegs && caps[t] >= ctx->fifo_min &&
+                     (!any_nested || ctx->fifo_nested);
             if (S.fifo) {
                 ctx->n_fifo++;
                 S.win_ok = false;
+                S.fifo_mat = any_nested;
+                S.fifo_dev = S.nested_fed;
+                if (S.fifo_dev) {
+                    FW_HIP(ctx, hipHostMalloc((void **)&S.h_report, (size_t)kReportRing * sizeof(unsigned long long), hipHostMallocDefault));
+                    memset(S.h_report, 0, (size_t)kReportRing * sizeof(unsigned long long));
+                }
                 S.fifo_life = 0.0f * (p.lifetime.max - p.lifetime.min) + p.lifetime.min;  // u * (max - min) + min, any u
                 S.fifo_wm = (T.base.kind != 0 ? 1 : 0) | (T.emis.kind != 0 ? 2 : 0) | (T.scale.kind != 0 ? 4 : 0);
             }
@@ -969,6 +998,7 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
         if (!S.in_use) continue;
         ctx->free_types.push_back(S.type_idx);
         if (S.fifo) ctx->n_fifo--;
+        if (S.h_report) hipHostFree(S.h_report);
         if (S.buf[0]) FW_HIP(ctx, hipFree(S.buf[0]));
         if (S.destroyed) FW_HIP(ctx, hipFree(S.destroyed));
         S = SegHost{};
@@ -1238,6 +1268,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_FORECAST")) ctx->use_forecast = atoi(m) != 0;
     if (const char *m = getenv("FW_STREAM")) ctx->use_stream = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO")) ctx->use_fifo = atoi(m) != 0;
+    if (const char *m = getenv("FW_FIFO_NESTED")) ctx->fifo_nested = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
     if (const char *m = getenv("FW_OPS_ZEROCOPY")) ctx->ops_zerocopy = atoi(m) != 0;
@@ -1268,6 +1299,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     for (auto &S : ctx->segs) {
         if (S.buf[0]) hipFree(S.buf[0]);
         if (S.destroyed) hipFree(S.destroyed);
+        if (S.h_report) hipHostFree(S.h_report);
     }
     void *frees[] = {ctx->d_type_coll.d, ctx->d_segs.d,       ctx->d_types.d,       ctx->d_keys.d,        ctx->d_emits.d,
                      ctx->d_emit_serial.d, ctx->g.count,        ctx->g.spawned,       ctx->g.appended,
@@ -1469,14 +1501,16 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // host's ~60 ns per emitter
     auto &levels = ctx->levels;
     for (auto &L : levels) L.g.clear(), L.n.clear();
-    ctx->fifo_ops.clear();
+    ctx->fifo_ops.clear(), ctx->fifo_mat_ops.clear();
     if (ctx->n_fifo) {
         // the FIFO order rests on ages that never decrease: a negative or non-finite dt ends the mode (as does a dt so
         // small that the cohort list grows without bound)
         const bool dt_ok = dt >= 0.0f && std::isfinite(dt);
         for (uint32_t si = 0; si < ctx->segs.size(); si++) {
             SegHost &S = ctx->segs[si];
-            if (!S.in_use || !S.fifo || (dt_ok && S.coh.size() < kMaxCohorts)) continue;
+            // (a type that receives Nested children: a step as long as its lifetime would destroy children whose number only
+            // this frame's Nested pass will know)
+            if (!S.in_use || !S.fifo || (dt_ok && S.coh.size() < kMaxCohorts && !(S.fifo_dev && dt >= S.fifo_life))) continue;
             fw_status cst = fifo_to_general(ctx, si);
             if (cst) return cst;
         }
@@ -1609,7 +1643,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 memcpy(op.origin_rot, sp.origin_rot, sizeof sp.origin_rot);
                 memcpy(op.parent_vel, sp.parent_vel, sizeof sp.parent_vel);
                 op.speed = sp.mod_speed, op.scale = sp.mod_scale;
-                if (S.fifo)
+                if (S.fifo && S.fifo_mat)
+                    ctx->fifo_mat_ops.push_back({(uint32_t)i, op});  // routed below, once the frame's Nested ops are known
+                else if (S.fifo)
                     ctx->fifo_ops.push_back(op);  // spawned inside fw_k_update_fifo, whatever else the frame holds
                 else
                     levels[i].g.push_back(op);
@@ -1640,6 +1676,21 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         }
     }
 
+    // Rings of spawners with Nested entries: a frame that runs a Nested pass (anywhere in the context: the launches are
+    // per emission level) materialises their new particles with fw_k_spawn, at their level, so that the per-parent pass
+    // finds them in memory (core.rs:488); any other frame spawns them inside fw_k_update_fifo like every other ring's.
+    bool nested_frame = false;
+    {
+        for (auto &L : levels) nested_frame |= !L.n.empty();
+        for (auto &io : ctx->fifo_mat_ops) {
+            if (nested_frame) {
+                io.second.head = ctx->segs[io.second.seg].head;
+                levels[io.first].g.push_back(io.second);
+            } else {
+                ctx->fifo_ops.push_back(io.second);
+            }
+        }
+    }
     // ---- segment -> tile table (device resident, re-uploaded only when a bound moves out of its band)
     prof(1);
     const uint32_t n_seg = (uint32_t)ctx->segs.size();
@@ -1811,6 +1862,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     tiles += op.n_tiles;
                     op.parent_buf = ctx->segs[op.parent_seg].buf[p];
                     op.parent_cap = ctx->segs[op.parent_seg].capacity;
+                    op.parent_head = ctx->segs[op.parent_seg].fifo ? ctx->segs[op.parent_seg].head : 0u;
+                    op.child_head = ctx->segs[op.child_seg].fifo ? ctx->segs[op.child_seg].head : 0u;
                     h_nops[ni++] = op;
                 }
                 launches.push_back(Launch{true, first, ni - first, tiles});
@@ -1938,34 +1991,59 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             if (fa.n_segs == FW_FIFO_PER_LAUNCH || f_ops + k_ops > FW_INLINE_OPS) FW_HIP(ctx, flush());
             if (!fa.n_segs) fa.write_mask = S.fifo_wm;
             else if (fa.write_mask != S.fifo_wm) fa.write_mask = -1;
-            const uint32_t n_spawn = S.frame_spawn, n_in = S.ub - n_spawn, n_tot = S.ub;
+            // frames that materialise (Nested pass): the segment's Global particles of this frame already sit in the ring
+            const bool mat_frame = S.fifo_mat && nested_frame;
+            const bool mat = S.fifo_dev || mat_frame;
+            const uint32_t n_spawn = mat_frame ? 0u : S.frame_spawn;  // spawned by fw_k_update_fifo itself
+            // live particles before fw_k_update_fifo's own spawns (a type that receives children: only the device knows)
+            const uint32_t n_in = S.fifo_dev ? 0xFFFFFFFFu : S.ub - n_spawn;
             // the cohorts age by this dt exactly as their particles do (fp32 additions, fw_survives); the oldest die first
-            if (n_spawn) {
+            if (S.fifo_dev) {
+                S.coh.push_back(SegHost::Cohort{0u, 0.0f, ctx->frame, false});  // size: whatever the device appends
+            } else if (S.frame_spawn) {
                 if (!S.coh.empty() && S.coh.back().age == 0.0f && !std::signbit(S.coh.back().age))
-                    S.coh.back().n += n_spawn;
+                    S.coh.back().n += S.frame_spawn;
                 else
-                    S.coh.push_back(SegHost::Cohort{n_spawn, 0.0f});
+                    S.coh.push_back(SegHost::Cohort{S.frame_spawn, 0.0f, ctx->frame, true});
             }
             for (auto &c : S.coh) c.age = c.age + dt;
             uint32_t dead = 0;
-            while (!S.coh.empty() && S.coh.front().age >= S.fifo_life) dead += S.coh.front().n, S.coh.pop_front();
+            while (!S.coh.empty() && S.coh.front().age >= S.fifo_life) {
+                SegHost::Cohort &c = S.coh.front();
+                if (!c.known && c.frame != ctx->frame) {
+                    // children added `lifetime` ago: the update of that frame left their number in the pinned ring
+                    const uint32_t ep = (uint32_t)((c.frame + 1) & 0x3FFFFFFFu) ? (uint32_t)((c.frame + 1) & 0x3FFFFFFFu) : 1u;
+                    const volatile unsigned long long *row = S.h_report + (c.frame % kReportRing);
+                    for (int spin = 0; (uint32_t)(*row >> 32) != ep && spin < 100000; spin++) __builtin_ia32_pause();
+                    if ((uint32_t)(*row >> 32) != ep) FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    if ((uint32_t)(*row >> 32) != ep) return fail(ctx, FW_EHIP, "internal error: cohort report missing");
+                    c.n = (uint32_t)*row, c.known = true;
+                }
+                dead += c.n;
+                S.coh.pop_front();
+            }
+            const uint32_t n_tot = S.fifo_dev ? S.capacity : n_in + n_spawn;  // (fifo_dev: upper bound, tiles only)
             FwFifoSeg &F = fa.s[fa.n_segs++];
             F.buf = S.buf[0], F.destroyed = S.destroyed, F.inst = S.inst;
             F.inst_cap = S.inst_cap, F.capacity = S.capacity, F.seg = si, F.type_idx = S.type_idx;
             F.keys_off = S.keys_off, F.keys_len = S.keys_len;
             F.head = S.head, F.n_in = n_in, F.n_spawn = n_spawn, F.dead = dead;
+            F.mat = mat ? 1u : 0u;
+            F.report = S.fifo_dev ? S.h_report + (ctx->frame % kReportRing) : nullptr;
             F.op0 = f_ops;
-            for (const FwOp &op : ctx->fifo_ops)
-                if (op.seg == si) fio.ops[f_ops++] = op;
+            if (!mat_frame)
+                for (const FwOp &op : ctx->fifo_ops)
+                    if (op.seg == si) fio.ops[f_ops++] = op;
             F.op1 = f_ops;
             // workgroups: the new particles first, FW_BLOCK each, in two groups of consecutive slots (up to the end of the
             // buffer / from slot 0); then the ring tiles from the first slot the update touches (the first destroyed particle
-            // when their records are wanted, the first survivor otherwise) to the last old particle; at least one in all
-            // (it publishes the counts)
-            const uint32_t lo = std::min(S.destroyed ? 0u : dead, n_in), cnt = n_in - lo;
+            // when their records are wanted, the first survivor otherwise) to the last old particle (a type whose count
+            // only the device knows: the whole ring, empty tiles leave at once); at least one in all (it publishes the counts)
+            const uint32_t n_old = S.fifo_dev ? S.capacity : n_in;
+            const uint32_t lo = std::min(S.destroyed ? 0u : dead, n_old), cnt = n_old - lo;
             const uint32_t ftile = FW_TILE;
             const uint32_t ps = (uint32_t)(((uint64_t)S.head + lo) % S.capacity), ring_tiles = S.capacity / ftile;
-            const uint32_t ns0 = (uint32_t)(((uint64_t)S.head + n_in) % S.capacity);  // slot of the first new particle
+            const uint32_t ns0 = (uint32_t)(((uint64_t)S.head + (S.fifo_dev ? 0u : n_in)) % S.capacity);  // slot of the first new particle
             F.spawn_a = std::min(n_spawn, S.capacity - ns0);
             F.n_vt_a = (F.spawn_a + FW_BLOCK - 1) / FW_BLOCK, F.n_vt_b = (n_spawn - F.spawn_a + FW_BLOCK - 1) / FW_BLOCK;
             F.tile0 = ps / ftile;
@@ -1974,8 +2052,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             F.tile_first = f_tiles;
             f_tiles += F.n_tiles;
             fa.any_inst |= S.inst != nullptr ? 1u : 0u;
-            S.head = (uint32_t)(((uint64_t)S.head + std::min(dead, n_tot)) % S.capacity);
-            S.ub = n_tot - std::min(dead, n_tot);
+            S.head = (uint32_t)(((uint64_t)S.head + dead) % S.capacity);
+            if (!S.fifo_dev) S.ub = n_tot - std::min(dead, n_tot);
+            (void)n_tot;
         }
         FW_HIP(ctx, flush());
     }
@@ -2116,8 +2195,11 @@ fw_status fw_spawner_read_last_emitted(fw_ctx *ctx, fw_spawner h, uint32_t type,
         for (uint64_t i = 0; i < m; i++) out[i] = FW_F32_MIN;  // never touched: still vec![f32::MIN; n] (core.rs:467)
         return st;
     }
-    FW_HIP(ctx, hipMemcpy(out, S.buf[ctx->parity] + FW_OFF_L((size_t)S.capacity, plane), m * sizeof(float),
-                          hipMemcpyDeviceToHost));
+    const char *pl = S.buf[ctx->parity] + FW_OFF_L((size_t)S.capacity, plane);
+    const uint32_t h0 = S.fifo ? S.head : 0u;  // a ring: from the head to the end of the buffer, then from slot 0
+    const uint64_t m1 = std::min<uint64_t>(m, S.capacity - h0);
+    FW_HIP(ctx, hipMemcpy(out, pl + (size_t)h0 * sizeof(float), m1 * sizeof(float), hipMemcpyDeviceToHost));
+    if (m > m1) FW_HIP(ctx, hipMemcpy(out + m1, pl, (m - m1) * sizeof(float), hipMemcpyDeviceToHost));
     return st;
 }
 
@@ -2162,6 +2244,7 @@ fw_status fw_spawner_write_last_emitted(fw_ctx *ctx, fw_spawner h, uint32_t type
     hipSetDevice(ctx->device);
     fw_status st = sync(ctx);
     if (st) return st;
+    if ((st = fifo_to_general(ctx, sp->seg[type]))) return st;  // (caller-written state: the general path takes over)
     const SegHost &S = ctx->segs[sp->seg[type]];
     int plane = -1;
     for (uint32_t k = 0; k < S.n_lplanes; k++)

@@ -121,6 +121,14 @@ struct FwFifoSeg {
     uint32_t tile0;
     uint32_t tile_first, n_tiles;
     uint32_t spawn_a, n_vt_a, n_vt_b;
+    // mat = 1: this frame's new particles of the segment were MATERIALISED in the ring before the update (frames with
+    // Nested entries: Global ops by fw_k_spawn, children by fw_k_nest) -- n_spawn is 0, the live count is read from the
+    // device counters (count + spawned + appended; n_in is the host's value, or 0xFFFFFFFF when only the device knows:
+    // a type that receives Nested children) and the particles from index `count` on get their first update (every
+    // plane written).  report (or null): pinned host word that receives {epoch << 32 | particles added this frame} --
+    // how the host learns the size of each cohort of children, long before it needs it (when the cohort dies)
+    uint32_t mat;
+    unsigned long long *report;
 };
 #define FW_FIFO_PER_LAUNCH 8
 struct FwFifoArgs {

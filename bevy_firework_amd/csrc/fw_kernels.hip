@@ -129,6 +129,12 @@ __device__ __forceinline__ FwOutWin fw_out_window(char *ob, uint32_t C, uint32_t
                     T.bc_kind != 0 || force_colors != 0u, T.em_kind != 0 || force_colors != 0u};
 }
 
+// slot of logical particle i of a segment whose particle 0 sits in slot `head` (0 unless the segment is a FIFO ring)
+__device__ __forceinline__ uint32_t fw_ring_slot(uint32_t head, uint32_t i, uint32_t C) {
+    const uint32_t s = head + i;  // head < C, i < C <= 0xFFFF0000 / 2 ... no overflow: capacities stay below 2^31
+    return s >= C ? s - C : s;
+}
+
 // alive test of update_particles: `if particle.age >= particle.lifetime { destroyed }` (core.rs:594-599)
 __device__ __forceinline__ bool fw_survives(float age, float dt, float lifetime, float *age_new) {
     float a = age + dt;
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_spawn(FwGlobals g, FwInlineOps 
         if (op.n > room) atomicOr(g.err, FW_ERR_CAPACITY);
     }
     if (k >= op.n || k >= room) return;
-    const uint32_t slot = base + k;
+    const uint32_t slot = fw_ring_slot(op.head, base + k, S.capacity);  // (base + k < capacity)
     const FwEmit &e = g.emits[op.emit];
     FwSpawnOut o = fw_spawn_one(e, g.seed, op.serial_base + k, fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
                                 fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
@@ -1559,7 +1565,14 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
     const bool spawner = tis < n_vt;  // a workgroup of new particles (they come first: the longest job starts earliest)
     uint32_t pt = F.tile0 + (tis - n_vt);
     if (pt >= ring_tiles) pt -= ring_tiles;
-    const uint32_t head = F.head, n_in = F.n_in, n_dead = F.dead;
+    const uint32_t head = F.head, n_dead = F.dead;
+    const uint32_t sidx = a.parity * g.max_seg + F.seg;
+    // materialised new particles (FwFifoSeg::mat): the counters are requested now and used after the barrier below
+    uint32_t c_cnt = 0, c_new = 0;
+    if (F.mat) c_cnt = g.count[sidx], c_new = g.spawned[sidx] + g.appended[sidx];
+    // (uniform values: kept on the scalar unit)
+    const uint32_t n_in = F.mat ? __builtin_amdgcn_readfirstlane(c_cnt + c_new) : F.n_in;
+    const uint32_t full_from = F.mat ? __builtin_amdgcn_readfirstlane(c_cnt) : 0xFFFFFFFFu;  // first-update particles
     const uint32_t n_tot = n_in + F.n_spawn;
     // first slot of the workgroup: a ring tile, or the slot of the first new particle of its group (the groups [0, a) and
     // [a, n_spawn) of the new particles each occupy consecutive slots: a is where the ring wraps, FwFifoSeg::spawn_a)
@@ -1592,6 +1605,12 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
     for (uint32_t i = tid + BLK; i < F.keys_len; i += BLK) s_keys[i] = g.keys[F.keys_off + i];
     __syncthreads();
     const bool want_destroyed = T.report_destroyed && F.destroyed != nullptr;
+    if (!spawner && tis != 0u) {
+        // a tile without a single particle (the grid of a segment whose count only the device knows covers its ring)
+        uint32_t i0 = sbase - head;
+        if (sbase < head) i0 += C;
+        if (!(i0 < n_tot || (i0 + TILE > C && n_tot != 0u))) return;
+    }
     char *inst = INST ? F.inst : nullptr;
     float4 *s_inst_wave = s_inst + (INST ? wave * 256u : 0u);
     const FwOutWin W = fw_out_window(buf, C, sbase, T, 0u);
@@ -1641,6 +1660,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
                 if (i < n_dead && i < n_in) {
                     const uint32_t b16 = (uint32_t)(r * BLK + (int)tid) * 16u;
                     const float4 q0 = fw_ld4w(iw0, b16), q1 = fw_ld4w(iw1, b16), q2 = fw_ld4w(iw2, b16), q3 = fw_ld4w(iw3, b16);
+                    // (a materialised particle that dies in its first update: its planes hold the spawn-time colours and
+                    // scale, which is what the record of a particle born and destroyed in one frame carries)
                     fw_store_destroyed(F.destroyed, buf, C, s, true, T, s_keys, q0, q1, q2, q3, q0.w + a.dt, i);
                 }
             }
@@ -1670,7 +1691,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
                     if (WM >= 0 ? (WM & 2) != 0 : W.wr6) fw_st4w(W.q6, b16, q1c);
                     if (WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) fw_st1w(W.s4, (s - W.first) * 4u, q1c.w);
                 } else {
-                    fw_integrate_store<true, WM>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec);
+                    fw_integrate_store<true, WM>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, nullptr, nullptr, nullptr,
+                                                 false, i >= full_from);
                 }
             }
             fw_fifo_inst_out<INST>(F, inst, s_inst_wave, rec, lane, m, alive, i - n_dead);
@@ -1680,8 +1702,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
     }
     if (__any(bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST);
     if (tis == 0 && tid == 0) {
-        const uint32_t sidx = a.parity * g.max_seg + F.seg, oidx = (a.parity ^ 1u) * g.max_seg + F.seg;
-        if (g.count[sidx] != n_in) atomicOr(g.err, FW_ERR_FORECAST);
+        const uint32_t oidx = (a.parity ^ 1u) * g.max_seg + F.seg;
+        if (F.mat ? (F.n_in != 0xFFFFFFFFu && F.n_in != n_in) : g.count[sidx] != n_in) atomicOr(g.err, FW_ERR_FORECAST);
+        if (F.report) *F.report = ((unsigned long long)a.epoch << 32) | c_new;
         const uint32_t nc = n_tot - min(n_dead, n_tot);
         g.count[oidx] = nc;
         g.spawned[oidx] = 0;
@@ -1932,7 +1955,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
     float p_age[FW_NEST_TILE / FW_BLOCK], p_life[FW_NEST_TILE / FW_BLOCK], p_lea[FW_NEST_TILE / FW_BLOCK];
 #pragma unroll
     for (int r = 0; r < FW_NEST_TILE / FW_BLOCK; r++) {
-        const uint32_t ci = min(pbase + r * FW_BLOCK + tid, op.parent_cap - 1u);
+        const uint32_t ci = fw_ring_slot(op.parent_head, min(pbase + r * FW_BLOCK + tid, op.parent_cap - 1u), op.parent_cap);
         p_age[r] = fw_ld4(op.parent_buf + FW_OFF_Q0(op.parent_cap), ci).w;
         p_life[r] = fw_ld4(op.parent_buf + FW_OFF_Q3(op.parent_cap), ci).w;
         p_lea[r] = fw_ld1(op.parent_buf + FW_OFF_L(op.parent_cap, op.parent_lplane), ci);
@@ -1958,7 +1981,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
                 float next;
                 const uint64_t cnt = fw_emission_count(p_age[r], p_lea[r], p_life[r], op.n_start, op.n_end, op.n_count, &next);
                 n[r] = cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cnt;  // core.rs:490-498
-                fw_st1(pb + FW_OFF_L(PC, op.parent_lplane), idx, next);  // other_particle.last_emitted_age[i] = next (core.rs:500)
+                fw_st1(pb + FW_OFF_L(PC, op.parent_lplane), fw_ring_slot(op.parent_head, idx, PC), next);  // other_particle.last_emitted_age[i] = next (core.rs:500)
             }
             uint32_t x = n[r];
 #pragma unroll
@@ -2008,9 +2031,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
             const uint32_t idx = base + r * FW_BLOCK + tid;
             s_inc[wave][lane] = inc[r];
             if (n[r] != 0) {
-                s_par[wave][0][lane] = fw_ld4(pb + FW_OFF_Q0(PC), idx);
-                s_par[wave][1][lane] = fw_ld4(pb + FW_OFF_Q1(PC), idx);
-                s_par[wave][2][lane] = fw_ld4(pb + FW_OFF_Q2(PC), idx);
+                const uint32_t ps = fw_ring_slot(op.parent_head, idx, PC);
+                s_par[wave][0][lane] = fw_ld4(pb + FW_OFF_Q0(PC), ps);
+                s_par[wave][1][lane] = fw_ld4(pb + FW_OFF_Q1(PC), ps);
+                s_par[wave][2][lane] = fw_ld4(pb + FW_OFF_Q2(PC), ps);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -2031,7 +2055,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
                         FwSpawnOut o = fw_spawn_one(e, g.seed, serial0 + j, fw_v3{pq0.x, pq0.y, pq0.z},
                                                     fw_q4{pq2.x, pq2.y, pq2.z, pq2.w}, fw_v3{pq1.x, pq1.y, pq1.z}, op.speed,
                                                     op.scale);
-                        fw_store_new(g, Cs, Cs.buf[parity], (uint32_t)slot, o);
+                        fw_store_new(g, Cs, Cs.buf[parity], fw_ring_slot(op.child_head, (uint32_t)slot, ccap), o);
                     }
                 }
             }
@@ -2078,12 +2102,6 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
 // ---------------------------------------------------------------------------------
 
 // SoA planes -> fw_particle records (26 x 4 B)
-// slot of logical particle i of a segment whose particle 0 sits in slot `head` (0 unless the segment is a FIFO ring)
-__device__ __forceinline__ uint32_t fw_ring_slot(uint32_t head, uint32_t i, uint32_t C) {
-    const uint32_t s = head + i;  // head < C, i < C <= 0xFFFF0000 / 2 ... no overflow: capacities stay below 2^31
-    return s >= C ? s - C : s;
-}
-
 __global__ void fw_k_gather(const char *buf, uint32_t C, uint32_t head, uint32_t n, int32_t pbr, float *out) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;

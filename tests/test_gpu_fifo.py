@@ -233,3 +233,68 @@ def test_settings_rebuild_and_despawn_release_the_ring_slots(system):
             assert hs[0].update_path(0)[0] == "fifo"
         for h in hs:
             system.despawn(h)
+
+
+def _nested_rings(spark_rate=3000.0, per_spark=20.0, spark_life=0.5, smoke_life=0.4, **smoke_kw):
+    sparks = S.ParticleSettings(lifetime=S.RandF32.constant(spark_life), initial_scale=S.RandF32(0.01, 0.03), linear_drag=0.3,
+                                base_color=S.FireworkGradient.even_samples([(8.0, 4.0, 1.0, 1.0), (1.0, 0.2, 0.0, 0.0)]))
+    kw = dict(lifetime=S.RandF32.constant(smoke_life), initial_scale=S.RandF32(0.05, 0.1), acceleration=(0.0, 0.5, 0.0),
+              base_color=S.FireworkGradient.uneven_samples([(0.0, (0.1, 0.1, 0.1, 0.0)), (0.1, (0.1, 0.1, 0.1, 0.15)),
+                                                            (1.0, (0.1, 0.1, 0.1, 0.0))]))
+    kw.update(smoke_kw)
+    smoke = S.ParticleSettings(**kw)
+    e0 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(spark_rate),
+                            initial_velocity=S.RandVec3(S.RandF32(2.0, 6.0), (0.0, 1.0, 0.0), 0.0))
+    e1 = S.EmissionSettings(particle_index=1, emission_pacing=S.EmissionPacing.rate(per_spark),
+                            emission_mode=S.EmissionMode.Nested(0), inherit_parent_velocity=False)
+    return S.ParticleSpawner([sparks, smoke], [e0, e1])
+
+
+def test_nested_spawner_on_rings_bit_exact(system):
+    """sparks -> smoke with one lifetime value each: both types are rings.  The sparks are materialised in their ring by
+    fw_k_spawn, the per-parent pass reads them through the head and appends the children into the smoke ring, whose live
+    count only the device knows (the host learns each frame's cohort size through the pinned report ring, in time for the
+    frame in which that cohort dies); small capacities so that both rings wrap and the smoke ring grows"""
+    sp = _nested_rings(particles_destroyed=lambda dead: None)
+    pair = Pair(system, sp, S.Transform((0.0, 1.0, 0.0)), seed=SEED, uid=11)
+    _expect_path(system, pair, 0), _expect_path(system, pair, 1)
+    rng = np.random.default_rng(3)
+    for fr in range(150):
+        dt = np.float32(DT if fr < 60 else rng.uniform(0.004, 0.03))
+        system.update(dt)
+        pair.step_cpu(dt)
+        if fr % 3 == 2 or fr < 5:
+            pair.check(exact_all=True, what=f"frame {fr}")
+            assert_particles_match(pair.gpu.destroyed(1), pair.cpu.destroyed(1), True, f"destroyed smoke frame {fr}")
+            assert np.array_equal(pair.gpu.last_emitted(0, 1), pair.cpu.last_emitted(0, 1)), f"last_emitted frame {fr}"
+    _expect_path(system, pair, 0), _expect_path(system, pair, 1)
+    assert pair.gpu.count(0) > 1000 and pair.gpu.count(1) > 10000
+
+
+def test_nested_rings_with_attached_instances_and_idle_frames(system):
+    """the child ring's render hand-off (records in particle order from a count the kernel reads on the device) and a step
+    longer than both lifetimes: every spark dies, this frame's included (the host knows their number); the smoke type,
+    whose newest cohort only this frame's Nested pass can size, leaves the ring mode for it"""
+    import torch
+
+    sp = _nested_rings(spark_rate=4000.0)
+    pair = Pair(system, sp, S.Transform((0.0, 1.0, 0.0)), seed=SEED, uid=13)
+    cap = [8000, 60000]
+    bufs = [torch.full((c * 16,), float("nan"), dtype=torch.float32, device="cuda") for c in cap]
+    for t in (0, 1):
+        pair.gpu.attach_instances(bufs[t].data_ptr(), cap[t], particle_type=t)
+    for fr in range(100):
+        dt = np.float32(0.5 if fr == 80 else DT)
+        system.update(dt)
+        pair.step_cpu(dt)
+        if fr % 7 == 6 or fr in (80, 81):
+            pair.check(exact_all=True, what=f"frame {fr}")
+            for t in (0, 1):
+                n = pair.gpu.count(t)
+                ref = pair.gpu.instances(t)
+                got = bufs[t][: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
+                assert np.array_equal(got, ref.view(np.uint32).reshape(n, 16)), f"frame {fr} type {t}"
+        if fr == 79:
+            _expect_path(system, pair, 0), _expect_path(system, pair, 1)
+    assert pair.gpu.update_path(1)[0] == "general"  # the 0.5 s step was longer than the smoke lives
+    assert pair.gpu.count(1) > 5000
