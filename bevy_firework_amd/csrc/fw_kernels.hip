@@ -1589,10 +1589,22 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
     // need no bounds; a spawning workgroup loads nothing)
     float4 q0c, q1c, q2c, q3c, q0n, q1n, q2n, q3n;  // rounds 0 and 1: the loop keeps two rounds of loads in flight
     q0c = q1c = q2c = q3c = q0n = q1n = q2n = q3n = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!spawner) {
+    // (a ring whose live count only the device knows is launched over its whole capacity: its tiles look at the counters
+    // first and the empty ones leave without having asked for a byte of particle data)
+    const bool defer = F.mat != 0u && F.n_in == 0xFFFFFFFFu;
+    const uint32_t i1 = (uint32_t)(min(1, R - 1) * BLK + (int)tid) * 16u;
+    if (!spawner && !defer) {
         q0c = fw_ld4w(iw0, tid * 16u), q3c = fw_ld4w(iw3, tid * 16u);
         q1c = fw_ld4w(iw1, tid * 16u), q2c = fw_ld4w(iw2, tid * 16u);
-        const uint32_t i1 = (uint32_t)(min(1, R - 1) * BLK + (int)tid) * 16u;
+        q0n = fw_ld4w(iw0, i1), q3n = fw_ld4w(iw3, i1);
+        q1n = fw_ld4w(iw1, i1), q2n = fw_ld4w(iw2, i1);
+    }
+    if (defer) {
+        uint32_t i0 = sbase - head;
+        if (sbase < head) i0 += C;
+        if (tis != 0u && !(i0 < n_tot || (i0 + TILE > C && n_tot != 0u))) return;
+        q0c = fw_ld4w(iw0, tid * 16u), q3c = fw_ld4w(iw3, tid * 16u);
+        q1c = fw_ld4w(iw1, tid * 16u), q2c = fw_ld4w(iw2, tid * 16u);
         q0n = fw_ld4w(iw0, i1), q3n = fw_ld4w(iw3, i1);
         q1n = fw_ld4w(iw1, i1), q2n = fw_ld4w(iw2, i1);
     }
