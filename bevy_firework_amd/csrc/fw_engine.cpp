@@ -1154,7 +1154,7 @@ void poll_snapshots(fw_ctx *ctx) {
             if (!S.in_use) continue;
             const unsigned long long v = snap[i];
             if ((uint32_t)(v >> 32) != ctx->snap_epoch[k]) continue;  // that segment's store has not landed yet
-            if (S.fifo) continue;  // the host's count is exact
+            if (S.fifo && !S.fifo_dev) continue;  // the host's count is exact
             if (S.nested_fed) {
                 S.dev_count = (uint32_t)v;  // no host-side bound exists; the count only drives capacity growth
                 continue;

@@ -17,7 +17,7 @@ python profiles/analyze_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
 ./tools/membw 1024 copy > $OUT/copy_sweep.txt 2>&1
 [ -x tools/inplace ] && ./tools/inplace > $OUT/inplace.txt 2>&1   # what in-place ring updates of various plane sets can reach
 # 5. in-kernel timelines, launch period, the rows ranked next, size sweep, ablations
-timeout 200 python tools/launch_gaps.py > $OUT/launch_gaps.txt 2>&1
+FW_FIFO=0 timeout 200 python tools/launch_gaps.py > $OUT/launch_gaps.txt 2>&1   # (in-kernel timestamps exist in the general path's kernels)
 FW_FIFO=0 timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline.txt 2>&1   # (instrumentation of the general path's kernels)
 FW_FIFO=0 FW_TL_JITTER=1 timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline_variable_dt.txt 2>&1
 timeout 300 python tools/bench_next_rows.py > $OUT/next_rows.txt 2>&1
@@ -33,6 +33,7 @@ FW_HOST_PROF=1 timeout 300 python tools/small_emitters.py >> $OUT/small_emitters
 # 7. configs[3] (Nested): rocprofv3 kernel stats of the steady state
 cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/nested -o nested --output-format csv -- python $R/tools/nested_prof.py > $R/$OUT/nested_step.txt 2>/dev/null; cd $R
 python profiles/analyze_trace.py $OUT/nested/nested_kernel_trace.csv 400 > $OUT/nested_trace_summary.txt 2>&1
+(timeout 200 python tools/nested_ab.py; echo 'FW_FIFO_NESTED=0:'; FW_FIFO_NESTED=0 timeout 200 python tools/nested_ab.py) > $OUT/nested_ab.txt 2>&1   # configs[3] on rings / on the general path
 cp $OUT/nested/nested_kernel_stats.csv $OUT/configs3_nested_kernel_stats.csv 2>/dev/null
 [ -x tools/launchgap ] && timeout 200 ./tools/launchgap > $OUT/launchgap.txt 2>&1
 rm -rf $OUT/${TAG}_stats_kernel_trace.csv $OUT/pmc/*kernel_trace.csv $OUT/nested   # large; the summaries are what is kept
