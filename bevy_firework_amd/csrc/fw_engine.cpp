@@ -2022,7 +2022,6 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 dead += c.n;
                 S.coh.pop_front();
             }
-            const uint32_t n_tot = S.fifo_dev ? S.capacity : n_in + n_spawn;  // (fifo_dev: upper bound, tiles only)
             FwFifoSeg &F = fa.s[fa.n_segs++];
             F.buf = S.buf[0], F.destroyed = S.destroyed, F.inst = S.inst;
             F.inst_cap = S.inst_cap, F.capacity = S.capacity, F.seg = si, F.type_idx = S.type_idx;
@@ -2053,8 +2052,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             f_tiles += F.n_tiles;
             fa.any_inst |= S.inst != nullptr ? 1u : 0u;
             S.head = (uint32_t)(((uint64_t)S.head + dead) % S.capacity);
-            if (!S.fifo_dev) S.ub = n_tot - std::min(dead, n_tot);
-            (void)n_tot;
+            if (!S.fifo_dev) S.ub = n_in + n_spawn - std::min(dead, n_in + n_spawn);  // exact
         }
         FW_HIP(ctx, flush());
     }

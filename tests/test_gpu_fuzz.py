@@ -71,13 +71,14 @@ def _pacing(rng, scale):
     return S.EmissionPacing.OnDemand()
 
 
-def _spawner(rng, scale=1.0):
+def _spawner(rng, scale=1.0, const_p=0.2):
+    """const_p: probability that a particle type has ONE lifetime value (the in-place ring path when it is switched on)"""
     n_types = int(rng.integers(1, 3))
     types = []
     for _ in range(n_types):
         lo = float(rng.uniform(0.01, 0.6))
         types.append(S.ParticleSettings(
-            lifetime=S.RandF32(lo, float(lo + rng.uniform(0.0, 1.2))) if rng.random() < 0.8 else S.RandF32.constant(lo + 0.3),
+            lifetime=S.RandF32(lo, float(lo + rng.uniform(0.0, 1.2))) if rng.random() < 1.0 - const_p else S.RandF32.constant(lo + 0.3),
             scale_curve=_curve(rng), initial_scale=S.RandF32(0.01, float(rng.uniform(0.02, 0.2))),
             acceleration=tuple(float(c) for c in rng.uniform(-10.0, 10.0, size=3)),
             angular_acceleration=tuple(float(c) for c in rng.uniform(-2.0, 2.0, size=3)),
@@ -110,17 +111,16 @@ def _steps(rng, n):
     return out
 
 
-@pytest.mark.parametrize("case", list(range(40)) + [339])  # 339: OnDemand parents outgrow the derived capacity of their Nested children
-def test_random_spawner_matches_the_oracle(case):
+def _random_spawner_case(case, seed_base, const_p, sizes):
     from bevy_firework_amd.system import ParticleSystem
 
-    rng = np.random.default_rng(1000 + case)
-    spawner = _spawner(rng, scale=1.0 if case % 4 else 6.0)  # every fourth case is several tiles per type
+    rng = np.random.default_rng(seed_base + case)
+    spawner = _spawner(rng, scale=1.0 if case % 4 else 6.0, const_p=const_p)  # every fourth case is several tiles per type
     tf = S.Transform(tuple(float(c) for c in rng.uniform(-2.0, 2.0, size=3)),
                      tuple(float(c) for c in (lambda q: q / np.linalg.norm(q))(rng.normal(size=4))))
     mod = S.EffectModifier(float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.5, 2.0))) if rng.random() < 0.5 else None
     with ParticleSystem(device=0, seed=SEED) as system:
-        pair = Pair(system, spawner, tf, seed=SEED, uid=100 + case, modifier=mod)
+        pair = Pair(system, spawner, tf, seed=SEED, uid=(seed_base // 10) + case, modifier=mod)
         on_demand = any(e.emission_pacing.kind == S.PACING_ONDEMAND for e in spawner.emission_settings)
         for i, dt in enumerate(_steps(rng, 36)):
             dt = np.float32(dt)
@@ -130,10 +130,26 @@ def test_random_spawner_matches_the_oracle(case):
             pair.step_cpu(dt)
             if i % 6 == 5 or i == 35:
                 pair.check(what=f"case {case} frame {i} dt={dt}")
-        test_random_spawner_matches_the_oracle.sizes[case] = pair.gpu.counts()
+        sizes[case] = pair.gpu.counts()
+
+
+@pytest.mark.parametrize("case", list(range(40)) + [339])  # 339: OnDemand parents outgrow the derived capacity of their Nested children
+def test_random_spawner_matches_the_oracle(case):
+    _random_spawner_case(case, 1000, 0.2, test_random_spawner_matches_the_oracle.sizes)
 
 
 test_random_spawner_matches_the_oracle.sizes = {}
+
+
+@pytest.mark.parametrize("case", range(30))
+def test_random_spawner_with_single_lifetimes_matches_the_oracle(case):
+    """the same generator with nine types in ten on ONE lifetime value: rings that wrap and grow, rings of spawners with
+    Nested entries (materialised spawns, children counted on the device), types that receive both kinds of particles
+    (not eligible) -- whatever the draw gives, on both update paths"""
+    _random_spawner_case(case, 21000, 0.9, test_random_spawner_with_single_lifetimes_matches_the_oracle.sizes)
+
+
+test_random_spawner_with_single_lifetimes_matches_the_oracle.sizes = {}
 
 
 def test_random_cases_were_not_trivial():
@@ -183,15 +199,25 @@ def test_random_scenario_with_api_calls_between_frames(case):
     """the calls a host makes between frames -- moving the origin, parent velocity, modifier, queueing, rewriting the
     particles, the destroyed-particle stream, AABB and instance reads, attaching an instance buffer -- in random order
     on a random spawner; state, destroyed records, bounds and instance records against the oracle after every call"""
+    _api_scenario(case, 9000, 0.2)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_scenario_with_api_calls_on_single_lifetime_types(case):
+    """... with nine types in ten on one lifetime value (rings; a rewritten type continues on the general path)"""
+    _api_scenario(case, 23000, 0.9)
+
+
+def _api_scenario(case, seed_base, const_p):
     import torch
     from bevy_firework_amd.system import ParticleSystem
 
-    rng = np.random.default_rng(9000 + case)
-    spawner = _spawner(rng, scale=1.0 if case % 3 else 4.0)
+    rng = np.random.default_rng(seed_base + case)
+    spawner = _spawner(rng, scale=1.0 if case % 3 else 4.0, const_p=const_p)
     for p in spawner.particle_settings:  # the destroyed stream only exists for types that register a handler
         p.particles_destroyed = (lambda dead: None) if rng.random() < 0.6 else None
     with ParticleSystem(device=0, seed=SEED) as system:
-        pair = Pair(system, spawner, S.Transform(), seed=SEED, uid=300 + case)
+        pair = Pair(system, spawner, S.Transform(), seed=SEED, uid=(seed_base // 30) + case)
         buf = None
         for i, dt in enumerate(_steps(rng, 30)):
             dt = np.float32(dt)
