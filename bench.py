@@ -256,6 +256,16 @@ def main():
                                                      "configs[2]: 256 emitters x 65 536 live (16.8M particles)")
             extras["hbm_resident"]["whole_step_particles_per_s"] = whole
             extras["hbm_resident"]["whole_step_ms"] = el / 100 * 1e3
+        # (b') the ring path far beyond the Infinity Cache: configs[1]'s emitter at 16x the rate (16.4M particles in one ring)
+        with ParticleSystem(device=local_rank, seed=workloads.SEED, stream=stream.cuda_stream) as p3:
+            s_, tf_ = workloads.one_million(rate=16.0 * args.rate)
+            p3.spawn(s_, tf_, uid=0)
+            p3.update(dt)
+            for _ in range(62 + 20):
+                p3.step(dt)
+            torch.cuda.synchronize()
+            extras["hbm_resident_ring"] = kernel_roofline(p3, lambda k: p3.step(dt), 100,
+                                                          "configs[1] at 16x the rate: one ring of 15.7M live particles")
         # (c) configs[4] on this one GPU: the base point of the multi-GPU curve
         with ParticleSystem(device=local_rank, seed=workloads.SEED, stream=stream.cuda_stream) as p4:
             for e, (s_, tf_) in enumerate(workloads.many_emitters(args.emitters, args.live_per_emitter)):

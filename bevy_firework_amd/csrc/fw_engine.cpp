@@ -279,9 +279,13 @@ struct fw_ctx {
     bool colors_dirty = false; // some SegHost::colors_dirty is set
     bool use_fifo = true;      // FW_FIFO=0: constant-lifetime types take the general (compacting) path too (A/B, tests)
     bool fifo_nested = true;   // FW_FIFO_NESTED=0: ... those of spawners with Nested entries do (A/B)
-    // smallest (derived or given) capacity that makes a type a FIFO ring: the mode costs a launch of its own next to the
-    // general one, which only large segments repay (FW_FIFO_MIN; tests set 0)
-    uint32_t fifo_min = 131072;
+    // Smallest (derived or given) capacity that makes a type a FIFO ring.  The ring launch runs next to the general one,
+    // which costs ~5 us when a context holds both kinds of segment and only pays from a few hundred thousand particles
+    // on (tools/fifo_threshold.py: 500k compacting particles + X ring particles; X = 131k: 23.7 us against 18.0 on the
+    // general path, X = 524k: 26.4 against 28.9); in a context whose segments are ALL rings there is no second launch
+    // and a ring wins at any size (the reference's stress test, 157k particles: 11.4 against 16 us).  FW_FIFO_MIN /
+    // FW_FIFO_MIN_PURE; the tests set 0.
+    uint32_t fifo_min = 393216, fifo_min_pure = 32768;
     uint32_t n_fifo = 0;       // FIFO segments in use (at most kMaxFifoSegs: their records travel in kernel arguments)
     std::vector<FwOp> fifo_ops;  // this frame's Global ops that feed FIFO segments (spawned inside fw_k_update_fifo)
     std::vector<std::pair<uint32_t, FwOp>> fifo_mat_ops;  // {emission index, op}: rings of spawners with Nested entries -- the
@@ -897,9 +901,11 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
                 self_nested |= e.mode == FW_MODE_NESTED && e.target_particle_type == e.particle_index;
                 mixed_feed |= S.nested_fed && e.mode == FW_MODE_GLOBAL && (uint32_t)e.particle_index == t;
             }
+            bool pure = true;  // every other segment of the context is a ring
+            for (uint32_t k = 0; k < ctx->segs.size(); k++) pure &= k == si || !ctx->segs[k].in_use || ctx->segs[k].fifo;
             S.fifo = ctx->use_fifo && !self_nested && !mixed_feed && !S.collides && p.lifetime.min == p.lifetime.max &&
-                     std::isfinite(p.lifetime.min) && ctx->n_fifo < kMaxFifoSegs && caps[t] >= ctx->fifo_min &&
-                     (!any_nested || ctx->fifo_nested);
+                     std::isfinite(p.lifetime.min) && ctx->n_fifo < kMaxFifoSegs &&
+                     (caps[t] >= ctx->fifo_min || (pure && caps[t] >= ctx->fifo_min_pure)) && (!any_nested || ctx->fifo_nested);
             if (S.fifo) {
                 ctx->n_fifo++;
                 S.win_ok = false;
@@ -979,7 +985,16 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         FW_HIP(ctx, hipMemcpy(ctx->d_emit_serial.d + E.emit_slot, &s0, sizeof s0, hipMemcpyHostToDevice));
     }
     sp.initialized = true;
-    return ensure_tile_arrays(ctx);
+    if ((st = ensure_tile_arrays(ctx))) return st;
+    // a context that now holds a compacting segment pays a second launch for its rings: the small ones are not worth it
+    // (SegHost: fifo_min)
+    bool any_general = false;
+    for (const SegHost &S : ctx->segs) any_general |= S.in_use && !S.fifo;
+    if (any_general)
+        for (uint32_t k = 0; k < ctx->segs.size(); k++)
+            if (ctx->segs[k].in_use && ctx->segs[k].fifo && ctx->segs[k].capacity < ctx->fifo_min)
+                if ((st = fifo_to_general(ctx, k))) return st;
+    return FW_OK;
 }
 
 fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
@@ -1269,7 +1284,11 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_STREAM")) ctx->use_stream = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO")) ctx->use_fifo = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_NESTED")) ctx->fifo_nested = atoi(m) != 0;
-    if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_FIFO_MIN_PURE")) ctx->fifo_min_pure = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_FIFO_MIN")) {
+        ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
+        ctx->fifo_min_pure = std::min(ctx->fifo_min_pure, ctx->fifo_min);
+    }
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
     if (const char *m = getenv("FW_OPS_ZEROCOPY")) ctx->ops_zerocopy = atoi(m) != 0;
     if (const char *m = getenv("FW_STATIC_NEW")) ctx->use_static_new = atoi(m) != 0;  // 0: always count + look back
