@@ -196,6 +196,19 @@ struct fw_ctx {
     int device = 0;
     uint32_t seed = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr;
+    // Rings next to compacting segments: the ring launch and the general launch of a frame touch disjoint segments, so the
+    // ring launch goes to a stream of its own and the two run concurrently (in one stream the second launch waits for the
+    // first to drain: 1M ring particles + one small compacting emitter cost 39.8 us per frame, 29.4 with everything on the
+    // general path).  Each chain is in order on its own stream; they are joined where the other stream (or the caller's
+    // work on it) looks at ring data -- no event in a steady-state frame.  Not used while a ring has an attached instance
+    // buffer, belongs to a spawner with Nested entries (fw_k_spawn / fw_k_nest on the main stream feed it) or a live-count
+    // ring is registered.  FW_FIFO_STREAM=0: everything on the one stream.
+    hipStream_t fifo_stream = nullptr;
+    hipEvent_t ev_side = nullptr, ev_main = nullptr;
+    bool use_fifo_stream = true;
+    bool side_dirty = false;      // ring launches on the side stream that the main stream has not waited for
+    bool fifo_last_side = false;  // where the previous frame's ring launch went
+    bool main_reads_ring = false; // work enqueued on the main stream since then reads ring data (must finish first)
     bool own_stream = false;
     std::string err;
     int update_mode = FW_MODE_FUSED;
@@ -279,13 +292,12 @@ struct fw_ctx {
     bool colors_dirty = false; // some SegHost::colors_dirty is set
     bool use_fifo = true;      // FW_FIFO=0: constant-lifetime types take the general (compacting) path too (A/B, tests)
     bool fifo_nested = true;   // FW_FIFO_NESTED=0: ... those of spawners with Nested entries do (A/B)
-    // Smallest (derived or given) capacity that makes a type a FIFO ring.  The ring launch runs next to the general one,
-    // which costs ~5 us when a context holds both kinds of segment and only pays from a few hundred thousand particles
-    // on (tools/fifo_threshold.py: 500k compacting particles + X ring particles; X = 131k: 23.7 us against 18.0 on the
-    // general path, X = 524k: 26.4 against 28.9); in a context whose segments are ALL rings there is no second launch
-    // and a ring wins at any size (the reference's stress test, 157k particles: 11.4 against 16 us).  FW_FIFO_MIN /
-    // FW_FIFO_MIN_PURE; the tests set 0.
-    uint32_t fifo_min = 393216, fifo_min_pure = 32768;
+    // Smallest (derived or given) capacity that makes a type a FIFO ring (FW_FIFO_MIN; the tests set 0).  Below a few
+    // tens of thousands of particles a frame is launch latency whatever the path.  Next to compacting segments the ring
+    // launch runs on its own stream (fifo_stream) and wins at any size (tools/fifo_threshold.py, tools/mixed_context.py);
+    // where it cannot -- attached instance buffers, Nested spawners, a registered live-count ring -- the two launches of
+    // a mixed context run one after the other and a small ring costs a few microseconds more than it saves.
+    uint32_t fifo_min = 32768;
     uint32_t n_fifo = 0;       // FIFO segments in use (at most kMaxFifoSegs: their records travel in kernel arguments)
     std::vector<FwOp> fifo_ops;  // this frame's Global ops that feed FIFO segments (spawned inside fw_k_update_fifo)
     std::vector<std::pair<uint32_t, FwOp>> fifo_mat_ops;  // {emission index, op}: rings of spawners with Nested entries -- the
@@ -357,6 +369,23 @@ fw_status dev_reserve(fw_ctx *ctx, DevArray<T> &a, size_t need, size_t used) {
 
 fw_status sync(fw_ctx *ctx) {
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->side_dirty) {
+        FW_HIP(ctx, hipStreamSynchronize(ctx->fifo_stream));
+        ctx->side_dirty = false;
+    }
+    ctx->main_reads_ring = false;
+    return FW_OK;
+}
+
+// before work that reads ring data is enqueued on the main stream without a synchronisation: the main stream waits for
+// the ring launches on the side stream (and the next ring launch will wait for that work)
+fw_status join_side(fw_ctx *ctx) {
+    if (ctx->side_dirty) {
+        FW_HIP(ctx, hipEventRecord(ctx->ev_side, ctx->fifo_stream));
+        FW_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+        ctx->side_dirty = false;
+    }
+    ctx->main_reads_ring = true;
     return FW_OK;
 }
 
@@ -901,11 +930,9 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
                 self_nested |= e.mode == FW_MODE_NESTED && e.target_particle_type == e.particle_index;
                 mixed_feed |= S.nested_fed && e.mode == FW_MODE_GLOBAL && (uint32_t)e.particle_index == t;
             }
-            bool pure = true;  // every other segment of the context is a ring
-            for (uint32_t k = 0; k < ctx->segs.size(); k++) pure &= k == si || !ctx->segs[k].in_use || ctx->segs[k].fifo;
             S.fifo = ctx->use_fifo && !self_nested && !mixed_feed && !S.collides && p.lifetime.min == p.lifetime.max &&
                      std::isfinite(p.lifetime.min) && ctx->n_fifo < kMaxFifoSegs &&
-                     (caps[t] >= ctx->fifo_min || (pure && caps[t] >= ctx->fifo_min_pure)) && (!any_nested || ctx->fifo_nested);
+                     caps[t] >= ctx->fifo_min && (!any_nested || ctx->fifo_nested);
             if (S.fifo) {
                 ctx->n_fifo++;
                 S.win_ok = false;
@@ -985,16 +1012,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         FW_HIP(ctx, hipMemcpy(ctx->d_emit_serial.d + E.emit_slot, &s0, sizeof s0, hipMemcpyHostToDevice));
     }
     sp.initialized = true;
-    if ((st = ensure_tile_arrays(ctx))) return st;
-    // a context that now holds a compacting segment pays a second launch for its rings: the small ones are not worth it
-    // (SegHost: fifo_min)
-    bool any_general = false;
-    for (const SegHost &S : ctx->segs) any_general |= S.in_use && !S.fifo;
-    if (any_general)
-        for (uint32_t k = 0; k < ctx->segs.size(); k++)
-            if (ctx->segs[k].in_use && ctx->segs[k].fifo && ctx->segs[k].capacity < ctx->fifo_min)
-                if ((st = fifo_to_general(ctx, k))) return st;
-    return FW_OK;
+    return ensure_tile_arrays(ctx);
 }
 
 fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
@@ -1260,6 +1278,11 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     }
     if ((e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate(copy)", e);
+    if ((e = hipStreamCreateWithFlags(&ctx->fifo_stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate(rings)", e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming)) != hipSuccess)
+        return bail("hipEventCreate", e);
     for (int i = 0; i < kParamRing; i++) {
         if ((e = hipEventCreateWithFlags(&ctx->ev_copied[i], hipEventDisableTiming)) != hipSuccess)
             return bail("hipEventCreate", e);
@@ -1284,11 +1307,8 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_STREAM")) ctx->use_stream = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO")) ctx->use_fifo = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_NESTED")) ctx->fifo_nested = atoi(m) != 0;
-    if (const char *m = getenv("FW_FIFO_MIN_PURE")) ctx->fifo_min_pure = (uint32_t)strtoul(m, nullptr, 10);
-    if (const char *m = getenv("FW_FIFO_MIN")) {
-        ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
-        ctx->fifo_min_pure = std::min(ctx->fifo_min_pure, ctx->fifo_min);
-    }
+    if (const char *m = getenv("FW_FIFO_STREAM")) ctx->use_fifo_stream = atoi(m) != 0;
+    if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
     if (const char *m = getenv("FW_OPS_ZEROCOPY")) ctx->ops_zerocopy = atoi(m) != 0;
     if (const char *m = getenv("FW_STATIC_NEW")) ctx->use_static_new = atoi(m) != 0;  // 0: always count + look back
@@ -1315,6 +1335,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->fifo_stream) hipStreamSynchronize(ctx->fifo_stream);
     for (auto &S : ctx->segs) {
         if (S.buf[0]) hipFree(S.buf[0]);
         if (S.destroyed) hipFree(S.destroyed);
@@ -1351,6 +1372,9 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     if (ctx->h_done) hipHostFree(ctx->h_done);
     for (hipEvent_t ev : ctx->tev) hipEventDestroy(ev);
     hipStreamDestroy(ctx->copy_stream);
+    if (ctx->fifo_stream) hipStreamDestroy(ctx->fifo_stream);
+    if (ctx->ev_side) hipEventDestroy(ctx->ev_side);
+    if (ctx->ev_main) hipEventDestroy(ctx->ev_main);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return FW_OK;
@@ -1985,18 +2009,36 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // ---- FIFO segments: in place, everything they need in the kernel arguments (fw_kernels.h: FwFifoSeg)
     bool fifo_launched = false;
     if (ctx->n_fifo) {
+        // the ring launch(es) of this frame: on the side stream when a general launch runs next to them (fw_ctx: fifo_stream)
+        bool side = ctx->use_fifo_stream && total_tiles != 0 && ctx->live_ring == nullptr;
+        for (const SegHost &S : ctx->segs) side &= !(S.in_use && S.fifo && (S.fifo_mat || S.inst != nullptr));
+        if (side && (!ctx->fifo_last_side || ctx->main_reads_ring)) {
+            // the previous ring launch, or a reader of ring data, sits on the main stream: this launch comes after it
+            FW_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+            FW_HIP(ctx, hipStreamWaitEvent(ctx->fifo_stream, ctx->ev_main, 0));
+            ctx->main_reads_ring = false;
+        } else if (!side && ctx->fifo_last_side && ctx->side_dirty) {
+            FW_HIP(ctx, hipEventRecord(ctx->ev_side, ctx->fifo_stream));
+            FW_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+            ctx->side_dirty = false;
+        }
+        ctx->fifo_last_side = side;
+        const hipStream_t fstream = side ? ctx->fifo_stream : ctx->stream;
         FwFifoArgs fa{};
         FwInlineOps fio;
         uint32_t f_ops = 0, f_tiles = 0;
         auto flush = [&]() -> hipError_t {
             if (!fa.n_segs) return hipSuccess;
             fa.parity = p, fa.epoch = a.epoch, fa.dbg = ctx->dbg, fa.dt = dt;
-            fa.done_tag = a.done_tag, fa.done_value = a.done_value;
+            // (the pinned "frame F has started" word recycles host buffers the GENERAL launch reads: when the two launches
+            // run on different streams only that one reports)
+            fa.done_tag = side ? nullptr : a.done_tag, fa.done_value = a.done_value;
             fa.host_counts = a.host_counts;
             fa.live_out = a.live_out, fa.live_next = a.live_next;
             hipEvent_t e0, e1;
             next_timing_pair(&e0, &e1);
-            const hipError_t e = fw_launch_update_fifo(ctx->stream, ctx->g, fa, fio, f_tiles, e0, e1);
+            const hipError_t e = fw_launch_update_fifo(fstream, ctx->g, fa, fio, f_tiles, e0, e1);
+            if (side) ctx->side_dirty = true;
             fa = FwFifoArgs{};
             f_ops = f_tiles = 0;
             fifo_launched = true;
@@ -2297,6 +2339,10 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
     const SegHost &S = ctx->segs[si];
     const uint32_t ub = (uint32_t)std::min<uint64_t>(S.nested_fed ? S.capacity : std::min(S.ub, S.capacity), cap);
     if (n_upper_bound) *n_upper_bound = ub;
+    if (S.fifo) {
+        fw_status jst = join_side(ctx);
+        if (jst) return jst;
+    }
     FW_HIP(ctx, fw_launch_pack_instances(ctx->stream, S.buf[ctx->parity], S.capacity, S.fifo ? S.head : 0u,
                                          ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, ub, d_out));
     return FW_OK;
@@ -2342,6 +2388,10 @@ fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out
     if (!sp || !out_min || !out_max) return FW_EINVAL;
     hipSetDevice(ctx->device);
     if (!ctx->h_aabb) FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_aabb, 8 * sizeof(float), hipHostMallocDefault));
+    {
+        fw_status jst = join_side(ctx);  // (the query kernels run on the main stream and may read rings)
+        if (jst) return jst;
+    }
     bool any_fifo = false;  // FIFO segments leave no per-tile boxes: the two-pass query reads their rings
     uint32_t heads[FW_MAX_TYPES] = {};
     for (size_t t = 0; t < sp->seg.size() && t < FW_MAX_TYPES; t++) {
@@ -2390,6 +2440,8 @@ fw_status fw_ctx_live_count(fw_ctx *ctx, uint64_t *out) {
 fw_status fw_ctx_live_count_device(fw_ctx *ctx, void *d_out_u64) {
     if (!ctx || !d_out_u64) return FW_EINVAL;
     hipSetDevice(ctx->device);
+    fw_status jst = join_side(ctx);  // the counts of ring segments are written by the side stream's launches
+    if (jst) return jst;
     FW_HIP(ctx, fw_launch_total(ctx->stream, ctx->g.count + (size_t)ctx->parity * ctx->max_seg,
                                 (uint32_t)ctx->segs.size(), (unsigned long long *)d_out_u64));
     return FW_OK;
