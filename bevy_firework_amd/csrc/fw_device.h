@@ -72,8 +72,21 @@ struct alignas(16) FwType {
     // key pool layout (floats, each sub-array padded to a multiple of 4):
     //  [sc_times | sc_vals | bc_times | bc_rgba | em_times | em_rgba]
     uint32_t keys_off, keys_len;
-    uint32_t o_sc_v, o_bc_t, o_bc_v, o_em_t, o_em_v, pad0;
+    uint32_t o_sc_v, o_bc_t, o_bc_v, o_em_t, o_em_v;
+    // FW_TYPE_NOSPIN: no particle of the type can ever turn -- every emission entry that feeds it has an angular-velocity
+    // magnitude range of exactly {0, 0} and the same initial_rotation, and the type's angular_acceleration is zero.  Then
+    // angular_velocity stays (+-0, +-0, +-0) (core.rs:648-650) and rotation = from_scaled_axis(0) * rotation stays the
+    // entries' initial_rotation (core.rs:645-647; numerically: signs of zero components aside), for every particle, for
+    // ever: the update neither reads nor writes the rotation plane (32 of the 164 bytes a compacting update moves per
+    // particle), readers get const_rot instead.  Cleared for good when the caller rewrites the type's particles or a
+    // non-finite dt is stepped (the plane is filled with const_rot first).
+    uint32_t flags;
+    float const_rot[4];
 };
+#define FW_TYPE_NOSPIN 1u
+// (the update kernels of the general path learn the flag before the type record arrives -- their loads depend on it --
+// from bit 31 of the type index in the tile descriptor / FwUpdateArgs::seg0_type / FwFifoSeg::type_idx)
+#define FW_TYPE_IDX_NOSPIN 0x80000000u
 // collision_settings of a particle type (core.rs:137-138, 240-248), in a table of its own next to FwType: only the
 // collision kernels read it, the streaming kernels' per-type record (and their scalar-register budget) stays as it was
 struct alignas(16) FwTypeColl {
@@ -141,7 +154,9 @@ struct alignas(16) FwNestOp {
     float n_count, n_start, n_end;  // CountOverDuration of the entry (core.rs:474-481)
     uint32_t parent_head;    // ring heads of the two segments (FIFO rings; 0 otherwise): particle i sits in slot
     uint32_t child_head;     // (head + i) mod capacity
-    uint32_t pad0[3];
+    uint32_t parent_nospin;  // the parent type cannot turn (FW_TYPE_NOSPIN): its rotation is parent_rot, not in the plane
+    uint32_t pad0[2];
+    float parent_rot[4];
 };
 
 // decoupled look-back status word: {epoch:30 | state:2 | value:32}

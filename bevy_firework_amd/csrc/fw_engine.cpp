@@ -134,6 +134,9 @@ struct alignas(64) SegHost {
     uint32_t head = 0;
     float fifo_life = 0.f;  // the lifetime every particle of the type gets (core.rs:455 with min == max)
     int32_t fifo_wm = 0;    // FwFifoArgs::write_mask of the type
+    // FW_TYPE_NOSPIN (fw_device.h): no particle of the type can turn; the rotation plane is neither read nor written
+    bool nospin = false;
+    float const_rot[4] = {0.f, 0.f, 0.f, 1.f};
     struct Cohort {
         uint32_t n;
         float age;
@@ -292,6 +295,7 @@ struct fw_ctx {
     bool colors_dirty = false; // some SegHost::colors_dirty is set
     bool use_fifo = true;      // FW_FIFO=0: constant-lifetime types take the general (compacting) path too (A/B, tests)
     bool fifo_nested = true;   // FW_FIFO_NESTED=0: ... those of spawners with Nested entries do (A/B)
+    bool use_nospin = true;    // FW_NOSPIN=0: every type keeps its rotation plane (A/B)
     // Smallest (derived or given) capacity that makes a type a FIFO ring (FW_FIFO_MIN; the tests set 0).  Below a few
     // tens of thousands of particles a frame is launch latency whatever the path.  Next to compacting segments the ring
     // launch runs on its own stream (fifo_stream) and wins at any size (tools/fifo_threshold.py, tools/mixed_context.py);
@@ -677,6 +681,23 @@ fw_status fifo_to_general(fw_ctx *ctx, uint32_t si) {
     return FW_OK;
 }
 
+// A type stops being FW_TYPE_NOSPIN (the caller rewrites its particles, a non-finite dt is stepped): the rotation plane,
+// which nobody maintained, gets the constant rotation in every slot, then the flag goes.
+fw_status leave_nospin(fw_ctx *ctx, uint32_t si) {
+    SegHost &s = ctx->segs[si];
+    if (!s.nospin) return FW_OK;
+    fw_status st = sync(ctx);
+    if (st) return st;
+    FW_HIP(ctx, fw_launch_fill_rotation(ctx->stream, s.buf[0], s.fifo ? nullptr : s.buf[1], s.capacity, s.const_rot));
+    FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t zero = 0;
+    FW_HIP(ctx, hipMemcpy((char *)(ctx->d_types.d + s.type_idx) + offsetof(FwType, flags), &zero, sizeof zero, hipMemcpyHostToDevice));
+    s.nospin = false;
+    ctx->tab_force = true;  // (the tile descriptors carry the flag)
+    ctx->fc_ok = false, ctx->boxes_epoch = 0;
+    return FW_OK;
+}
+
 // A parent type grew: the types its particles emit onto (Nested entries targeting it) were sized from the parent's
 // capacity (derive_capacity) and cannot grow on demand themselves -- their counts are only known on the device -- so
 // they follow the parent now, by the same rule.  Types with a caller-given capacity are left alone.
@@ -862,6 +883,25 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         dt.bc_kind = T.base.kind, dt.bc_n = T.base.n;
         dt.em_kind = T.emis.kind, dt.em_n = T.emis.n;
         dt.pbr = p.pbr, dt.report_destroyed = p.report_destroyed;
+        bool nospin = ctx->use_nospin && p.angular_acceleration[0] == 0.f && p.angular_acceleration[1] == 0.f &&
+                      p.angular_acceleration[2] == 0.f;
+        {  // FW_TYPE_NOSPIN: every entry that feeds the type spawns with zero angular velocity and the same rotation
+            const fw_emission_settings *first = nullptr;
+            for (uint32_t i = 0; i < ne && nospin; i++) {
+                const fw_emission_settings &e = d->emission_settings[i];
+                if ((uint32_t)e.particle_index != t) continue;
+                nospin = e.initial_angular_velocity.magnitude.min == 0.f && e.initial_angular_velocity.magnitude.max == 0.f &&
+                         (!first || memcmp(first->initial_rotation, e.initial_rotation, sizeof e.initial_rotation) == 0);
+                if (!first) first = &e;
+            }
+            nospin = nospin && first != nullptr;
+            if (nospin) {
+                dt.flags |= FW_TYPE_NOSPIN;
+                // (+ 0.0f: a negative zero component becomes +0, which is what from_scaled_axis(0) * rotation makes of it in
+                // all but contrived cases; every reader then sees the same bits)
+                for (int c = 0; c < 4; c++) dt.const_rot[c] = first->initial_rotation[c] + 0.0f;
+            }
+        }
         FwTypeColl dc{};
         dc.coll_flags = (p.collision.enabled ? FW_COLL_ENABLED : 0u) |
                         (p.collision.enabled && p.collision.destroy_on_collision ? FW_COLL_DESTROY : 0u);
@@ -903,6 +943,8 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         S = SegHost{};
         S.in_use = true, S.spawner = h, S.type = (int)t, S.type_idx = type_idx;
         S.keys_off = dt.keys_off, S.keys_len = dt.keys_len;
+        S.nospin = nospin;
+        memcpy(S.const_rot, dt.const_rot, sizeof S.const_rot);
         sp.seg[t] = si;
         FW_HIP(ctx, hipMemcpy(ctx->d_keys.d + dt.keys_off, keys.data(), keys.size() * sizeof(float),
                               hipMemcpyHostToDevice));
@@ -1142,7 +1184,8 @@ fw_status update_tile_table(fw_ctx *ctx) {
     uint4 *hd = ctx->h_desc[slot];
     for (uint32_t i = 0; i < n_seg; i++)
         for (uint32_t t = 0; t < ctx->tiles_dev[i]; t++)
-            hd[h[i] + t] = make_uint4(i, h[i], ctx->tiles_dev[i], ctx->segs[i].type_idx);
+            hd[h[i] + t] = make_uint4(i, h[i], ctx->tiles_dev[i],
+                                      ctx->segs[i].type_idx | (ctx->segs[i].nospin ? FW_TYPE_IDX_NOSPIN : 0u));
     FW_HIP(ctx, hipMemcpyAsync(ctx->d_tile_first, h, (size_t)(n_seg + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
                                ctx->stream));
     if (total)
@@ -1308,6 +1351,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_FIFO")) ctx->use_fifo = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_NESTED")) ctx->fifo_nested = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_STREAM")) ctx->use_fifo_stream = atoi(m) != 0;
+    if (const char *m = getenv("FW_NOSPIN")) ctx->use_nospin = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
     if (const char *m = getenv("FW_OPS_ZEROCOPY")) ctx->ops_zerocopy = atoi(m) != 0;
@@ -1545,6 +1589,12 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     auto &levels = ctx->levels;
     for (auto &L : levels) L.g.clear(), L.n.clear();
     ctx->fifo_ops.clear(), ctx->fifo_mat_ops.clear();
+    if (!std::isfinite(dt))  // 0 * inf = NaN: an angular velocity of zero does not stay zero (core.rs:648-650)
+        for (uint32_t si = 0; si < ctx->segs.size(); si++)
+            if (ctx->segs[si].in_use && ctx->segs[si].nospin) {
+                fw_status nst = leave_nospin(ctx, si);
+                if (nst) return nst;
+            }
     if (ctx->n_fifo) {
         // the FIFO order rests on ages that never decrease: a negative or non-finite dt ends the mode (as does a dt so
         // small that the cohort list grows without bound)
@@ -1795,7 +1845,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     a.dbg = ctx->dbg;
     a.vt_rounds = ctx->vt_rounds;
     a.resident_slots = (uint32_t)kResidentSlots;
-    a.seg0_type = n_seg ? ctx->segs[0].type_idx : 0;
+    a.seg0_type = n_seg ? ctx->segs[0].type_idx | (ctx->segs[0].nospin ? FW_TYPE_IDX_NOSPIN : 0u) : 0;
     a.seg0_keys_off = n_seg ? ctx->segs[0].keys_off : 0;
     a.seg0_keys_len = n_seg ? ctx->segs[0].keys_len : 0;
     a.tile_keys = ctx->d_tile_keys;
@@ -1907,6 +1957,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     op.parent_cap = ctx->segs[op.parent_seg].capacity;
                     op.parent_head = ctx->segs[op.parent_seg].fifo ? ctx->segs[op.parent_seg].head : 0u;
                     op.child_head = ctx->segs[op.child_seg].fifo ? ctx->segs[op.child_seg].head : 0u;
+                    op.parent_nospin = ctx->segs[op.parent_seg].nospin ? 1u : 0u;
+                    memcpy(op.parent_rot, ctx->segs[op.parent_seg].const_rot, sizeof op.parent_rot);
                     h_nops[ni++] = op;
                 }
                 launches.push_back(Launch{true, first, ni - first, tiles});
@@ -2085,7 +2137,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             }
             FwFifoSeg &F = fa.s[fa.n_segs++];
             F.buf = S.buf[0], F.destroyed = S.destroyed, F.inst = S.inst;
-            F.inst_cap = S.inst_cap, F.capacity = S.capacity, F.seg = si, F.type_idx = S.type_idx;
+            F.inst_cap = S.inst_cap, F.capacity = S.capacity, F.seg = si;
+            F.type_idx = S.type_idx | (S.nospin ? FW_TYPE_IDX_NOSPIN : 0u), F.life = S.fifo_life;
             F.keys_off = S.keys_off, F.keys_len = S.keys_len;
             F.head = S.head, F.n_in = n_in, F.n_spawn = n_spawn, F.dead = dead;
             F.mat = mat ? 1u : 0u;
@@ -2201,7 +2254,7 @@ fw_status fw_spawner_poll_finished(fw_ctx *ctx, fw_spawner h, int32_t *out) {
 }
 
 static fw_status read_records(fw_ctx *ctx, const char *buf, uint32_t cap_seg, uint32_t n, int32_t pbr, bool aos,
-                              fw_particle *out, uint64_t cap, uint32_t head = 0) {
+                              fw_particle *out, uint64_t cap, uint32_t head = 0, const float *const_rot = nullptr) {
     const uint64_t m = std::min<uint64_t>(n, cap);
     if (!m || !out) return FW_OK;
     if (aos) {
@@ -2210,7 +2263,7 @@ static fw_status read_records(fw_ctx *ctx, const char *buf, uint32_t cap_seg, ui
     }
     void *tmp = nullptr;
     FW_HIP(ctx, hipMalloc(&tmp, m * sizeof(fw_particle)));
-    hipError_t e = fw_launch_gather(ctx->stream, buf, cap_seg, head, (uint32_t)m, pbr, tmp);
+    hipError_t e = fw_launch_gather(ctx->stream, buf, cap_seg, head, (uint32_t)m, pbr, tmp, const_rot);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(out, tmp, m * sizeof(fw_particle), hipMemcpyDeviceToHost);
     hipFree(tmp);
@@ -2230,7 +2283,7 @@ fw_status fw_spawner_read_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
     const uint32_t n = c[sp->seg[type]];
     if (n_out) *n_out = n;
     fw_status st2 = read_records(ctx, S.buf[ctx->parity], S.capacity, n, sp->types[type].ps.pbr, false, out, cap,
-                                 S.fifo ? S.head : 0u);
+                                 S.fifo ? S.head : 0u, S.nospin ? S.const_rot : nullptr);
     return st2 ? st2 : st;
 }
 
@@ -2271,6 +2324,7 @@ fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, c
     const uint32_t si = sp->seg[type];
     ctx->fc_ok = false, ctx->boxes_epoch = 0;
     if ((st = fifo_to_general(ctx, si))) return st;  // ages and lifetimes will be whatever the caller writes
+    if ((st = leave_nospin(ctx, si))) return st;      // ... and so will rotations and angular velocities
     if (n > ctx->segs[si].capacity) {
         ctx->segs[si].ub = 0;
         const uint32_t zero = 0;
@@ -2344,7 +2398,8 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
         if (jst) return jst;
     }
     FW_HIP(ctx, fw_launch_pack_instances(ctx->stream, S.buf[ctx->parity], S.capacity, S.fifo ? S.head : 0u,
-                                         ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, ub, d_out));
+                                         ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, ub, d_out,
+                                         S.nospin ? S.const_rot : nullptr));
     return FW_OK;
 }
 
@@ -2575,11 +2630,13 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t
         const float *aa = T.ps.angular_acceleration;
         const bool acc = aa[0] != 0.f || aa[1] != 0.f || aa[2] != 0.f;
         const uint32_t q2 = (spins || acc) ? 16u : 0u, q3 = ((spins && T.ps.angular_drag != 0.f) || acc) ? 16u : 0u;
-        moved = 64u + 32u + q2 + q3 + (T.scale.kind != 0 ? 4u : 0u) + colours;
+        // (a type that cannot turn: neither the rotation nor the angular-velocity / lifetime plane is read)
+        moved = (S.nospin ? 32u : 64u) + 32u + q2 + q3 + (T.scale.kind != 0 ? 4u : 0u) + colours;
         algo = moved - 4u - (q3 ? 4u : 0u);
     } else {
-        // compacting: every state plane lands at a new slot (+ the last_emitted planes of a Nested parent, read and written)
-        moved = 64u + 64u + 4u + colours + 8u * S.n_lplanes;
+        // compacting: every state plane lands at a new slot (+ the last_emitted planes of a Nested parent, read and written);
+        // a type that cannot turn keeps no rotation plane: -16 B read, -16 B written
+        moved = 64u + 64u + 4u + colours + 8u * S.n_lplanes - (S.nospin ? 32u : 0u);
         algo = moved - 8u;
     }
     if (moved_bytes) *moved_bytes = moved;

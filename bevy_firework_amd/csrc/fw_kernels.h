@@ -108,8 +108,9 @@ struct FwInlineOps {
 struct FwFifoSeg {
     char *buf;               // the ring (FwSeg::buf[0] == buf[1])
     char *destroyed, *inst;  // FwSeg::destroyed / inst (or null)
-    uint32_t inst_cap, capacity, seg, type_idx;
+    uint32_t inst_cap, capacity, seg, type_idx;  // type_idx: | FW_TYPE_IDX_NOSPIN for a type that cannot turn
     uint32_t keys_off, keys_len;
+    float life;  // the type's one lifetime value (a no-spin type's Q3 plane -- angular velocity 0, this lifetime -- is not read)
     uint32_t head;     // slot of logical particle 0 BEFORE this update
     uint32_t n_in;     // live particles before this frame's spawns
     uint32_t n_spawn;  // Global particles spawned this frame (logical indices [n_in, n_in + n_spawn))
@@ -162,13 +163,17 @@ hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d
                             uint32_t total_tiles, uint32_t parity, uint32_t tag, uint32_t spin_limit, uint32_t dbg = 0);
 // SoA -> AoS gather of `n` particles of one segment buffer into fw_particle records (device)
 // (head: slot of particle 0 -- 0 for every segment but a FIFO ring)
-hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, uint32_t n, int32_t pbr, void *d_out);
+// (const_rot: the rotation of a type that cannot turn -- FW_TYPE_NOSPIN, its plane is not maintained -- or null)
+hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, uint32_t n, int32_t pbr, void *d_out,
+                            const float *const_rot = nullptr);
 hipError_t fw_launch_scatter(hipStream_t s, char *buf, uint32_t capacity, uint32_t n, uint32_t n_lplanes,
                              const void *d_in);
 // fills the base / emissive colour planes of one (buf1 == nullptr) or both buffers of a segment (capacity slots each)
 hipError_t fw_launch_fill_colors(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, const float bc[4], const float em[4]);
 hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, const uint32_t *d_count,
-                                    uint32_t n_upper, void *d_out);
+                                    uint32_t n_upper, void *d_out, const float *const_rot = nullptr);
+// fills the rotation plane of both buffers of a segment (a type leaves FW_TYPE_NOSPIN)
+hipError_t fw_launch_fill_rotation(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, const float rot[4]);
 // seg_ids: host array; d_part: device scratch of 256 * 8 floats; h_out8: PINNED host {min.xyz, any, max.xyz, -}
 // seg_heads: ring heads of the segments (host array, or null = all 0)
 hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, const uint32_t *seg_heads, uint32_t n_segs,

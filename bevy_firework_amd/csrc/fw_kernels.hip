@@ -121,12 +121,13 @@ struct FwOutWin {  // output planes advanced to slot `first` (workgroup-uniform)
     // update does not write that plane again -- 16 of its 164 bytes per particle per constant gradient.  wr5 / wr6:
     // this launch writes base_color / emissive_color (always true for a few frames after the caller rewrote particles).
     bool wr5, wr6;
+    bool wr2;  // rotation plane (false for a type that cannot turn: FW_TYPE_NOSPIN)
 };
 __device__ __forceinline__ FwOutWin fw_out_window(char *ob, uint32_t C, uint32_t first, const FwType &T, uint32_t force_colors) {
     const size_t f16 = (size_t)first * 16u;
     return FwOutWin{ob + FW_OFF_Q0(C) + f16, ob + FW_OFF_Q1(C) + f16, ob + FW_OFF_Q2(C) + f16, ob + FW_OFF_Q3(C) + f16,
                     ob + FW_OFF_Q5(C) + f16, ob + FW_OFF_Q6(C) + f16, ob + FW_OFF_S4(C) + (size_t)first * 4u, first,
-                    T.bc_kind != 0 || force_colors != 0u, T.em_kind != 0 || force_colors != 0u};
+                    T.bc_kind != 0 || force_colors != 0u, T.em_kind != 0 || force_colors != 0u, !(T.flags & FW_TYPE_NOSPIN)};
 }
 
 // slot of logical particle i of a segment whose particle 0 sits in slot `head` (0 unless the segment is a FIFO ring)
@@ -324,6 +325,7 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
                                                    float4 *rec = nullptr, const fw_v3 *cpos = nullptr,
                                                    const fw_v3 *cvel = nullptr, float *box = nullptr,
                                                    bool box_on = false, bool full = false) {
+    if (T.flags & FW_TYPE_NOSPIN) q2 = make_float4(T.const_rot[0], T.const_rot[1], T.const_rot[2], T.const_rot[3]);
     const float lifetime = q3.w;
     const float age_percent = age_new / lifetime;
     const float scale_factor = fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_percent);
@@ -353,13 +355,13 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
                             (__float_as_uint(nr.z) ^ __float_as_uint(q2.z)) | (__float_as_uint(nr.w) ^ __float_as_uint(q2.w));
         const uint32_t d3 = (__float_as_uint(wx) ^ __float_as_uint(q3.x)) | (__float_as_uint(wy) ^ __float_as_uint(q3.y)) |
                             (__float_as_uint(wz) ^ __float_as_uint(q3.z));
-        if (__any(full || d2 != 0u)) fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));  // wave-uniform branches
+        if (W.wr2 && __any(full || d2 != 0u)) fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));  // wave-uniform branches
         if (__any(full || d3 != 0u)) fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
         if ((WM >= 0 ? (WM & 1) != 0 : W.wr5) || full) fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
         if ((WM >= 0 ? (WM & 2) != 0 : W.wr6) || full) fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
         if ((WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) || full) fw_st1w(W.s4, (o - W.first) * 4u, scale);
     } else {
-        fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
+        if (W.wr2) fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
         fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
         if (W.wr5) fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));  // workgroup-uniform branches
         if (W.wr6) fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
@@ -404,6 +406,7 @@ __device__ __forceinline__ void fw_store_destroyed(char *dbuf, const char *ib, u
                                                    const FwType &T, const float *s_keys, float4 q0, float4 q1,
                                                    float4 q2, float4 q3, float age_new, uint32_t d) {
     float *rec = reinterpret_cast<float *>(dbuf) + (size_t)d * 26;
+    if (T.flags & FW_TYPE_NOSPIN) q2 = make_float4(T.const_rot[0], T.const_rot[1], T.const_rot[2], T.const_rot[3]);
     const int32_t pbr = T.pbr;
     float4 bc, em;
     float sc;
@@ -666,6 +669,10 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         seg_tiles = a.seg_tile_first[seg + 1] - first;
         type_idx = g.segs[seg].type_idx;
     }
+    // (a type that cannot turn: the rotation plane is not read -- every lane asks for the same slot instead, one line per
+    // wave, and fw_integrate_store takes FwType::const_rot; an unconditional load keeps the prefetch structure)
+    const uint32_t m2 = (type_idx & FW_TYPE_IDX_NOSPIN) ? 0u : 0xFFFFFFFFu;
+    type_idx &= ~FW_TYPE_IDX_NOSPIN;
     uint32_t tis = blockIdx.x - first;
     const bool use_fc = FUSED && a.fc_in != nullptr;
     constexpr bool fc_small = !SUMS;  // one plain entry per tile (every segment small) instead of atomic sums
@@ -785,7 +792,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     {
         const uint32_t i0 = has_new ? 0u : min(base + tid, lim - 1u);
         q1c = fw_ld4(ib + FW_OFF_Q1(C), i0);
-        q2c = fw_ld4(ib + FW_OFF_Q2(C), i0);
+        q2c = fw_ld4(ib + FW_OFF_Q2(C), i0 & m2);
     }
 
     // per-type constants (scalar loads) and curve / gradient keys (staged in LDS) arrive under the loads
@@ -947,7 +954,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         // prefetch the next round's Q1 / Q2 (new particles were materialised above, so idx < n_tot is enough)
         const uint32_t in_ = has_new ? 0u : min(idx + BLK, lim - 1u);  // clamped, unconditional
         const float4 q1n = fw_ld4(ib + FW_OFF_Q1(C), in_);
-        const float4 q2n = fw_ld4(ib + FW_OFF_Q2(C), in_);
+        const float4 q2n = fw_ld4(ib + FW_OFF_Q2(C), in_ & m2);
         const bool valid = idx < lim, loaded = !has_new;
         const float4 q0 = s_q0[r * BLK + tid], q3 = s_q3[r * BLK + tid];
         if (SPAWN != FW_SPAWN_NONE && has_new && valid)
@@ -1152,6 +1159,8 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         const uint2 kd = a.tile_keys[seg];
         keys_off = kd.x, keys_len = kd.y;
     }
+    const uint32_t m2 = (type_idx & FW_TYPE_IDX_NOSPIN) ? 0u : 0xFFFFFFFFu;  // FW_TYPE_NOSPIN: no rotation-plane traffic
+    type_idx &= ~FW_TYPE_IDX_NOSPIN;
     // curve / gradient keys: requested first (into a register; they are moved to LDS after the other requests
     // are out, so nothing waits for them here)
     const float key0 = tid < keys_len ? g.keys[keys_off + tid] : 0.0f;
@@ -1191,7 +1200,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         q0c = fw_ld4w(ib + FW_OFF_Q0(C) + sfirst, i0);
         q3c = fw_ld4w(ib + FW_OFF_Q3(C) + sfirst, i0);
         q1c = fw_ld4w(ib + FW_OFF_Q1(C) + sfirst, i0);
-        q2c = fw_ld4w(ib + FW_OFF_Q2(C) + sfirst, i0);
+        q2c = fw_ld4w(ib + FW_OFF_Q2(C) + sfirst, i0 & m2);
     }
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
     // SPAWN_NONE frames may have had this frame's new particles MATERIALISED behind the live ones (Global ops of a frame
@@ -1284,7 +1293,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         q0c = fw_ld4w(iw0, i0);
         q3c = fw_ld4w(iw3, i0);
         q1c = fw_ld4w(iw1, i0);
-        q2c = fw_ld4w(iw2, i0);
+        q2c = fw_ld4w(iw2, i0 & m2);
     }
     const FwType T = g.types[type_idx];  // scalar loads; first needed in the round loop
     if (tid < keys_len) s_keys[tid] = key0;
@@ -1407,7 +1416,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             const float4 q0n = fw_ld4w(iw0, in_);
             const float4 q3n = fw_ld4w(iw3, in_);
             const float4 q1n = fw_ld4w(iw1, in_);
-            const float4 q2n = fw_ld4w(iw2, in_);
+            const float4 q2n = fw_ld4w(iw2, in_ & m2);
             const bool valid = idx < lim;
             float age_new;
             const bool alive = valid && fw_survives(q0c.w, a.dt, q3c.w, &age_new);
@@ -1591,28 +1600,34 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
     q0c = q1c = q2c = q3c = q0n = q1n = q2n = q3n = make_float4(0.f, 0.f, 0.f, 0.f);
     // (a ring whose live count only the device knows is launched over its whole capacity: its tiles look at the counters
     // first and the empty ones leave without having asked for a byte of particle data)
+    // a type that cannot turn (FW_TYPE_NOSPIN): rotation is FwType::const_rot, angular velocity 0, the lifetime the type's one
+    // value -- neither the Q2 nor the Q3 plane is read (every lane asks for the tile's first slot instead: one line per
+    // wave, loads stay unconditional)
+    const bool nospin = (F.type_idx & FW_TYPE_IDX_NOSPIN) != 0u;
+    const uint32_t m2 = nospin ? 0u : 0xFFFFFFFFu;
+    const float4 q3s = make_float4(0.0f, 0.0f, 0.0f, F.life);
     const bool defer = F.mat != 0u && F.n_in == 0xFFFFFFFFu;
     const uint32_t i1 = (uint32_t)(min(1, R - 1) * BLK + (int)tid) * 16u;
     if (!spawner && !defer) {
-        q0c = fw_ld4w(iw0, tid * 16u), q3c = fw_ld4w(iw3, tid * 16u);
-        q1c = fw_ld4w(iw1, tid * 16u), q2c = fw_ld4w(iw2, tid * 16u);
-        q0n = fw_ld4w(iw0, i1), q3n = fw_ld4w(iw3, i1);
-        q1n = fw_ld4w(iw1, i1), q2n = fw_ld4w(iw2, i1);
+        q0c = fw_ld4w(iw0, tid * 16u), q3c = fw_ld4w(iw3, (tid * 16u) & m2);
+        q1c = fw_ld4w(iw1, tid * 16u), q2c = fw_ld4w(iw2, (tid * 16u) & m2);
+        q0n = fw_ld4w(iw0, i1), q3n = fw_ld4w(iw3, i1 & m2);
+        q1n = fw_ld4w(iw1, i1), q2n = fw_ld4w(iw2, i1 & m2);
     }
     if (defer) {
         uint32_t i0 = sbase - head;
         if (sbase < head) i0 += C;
         if (tis != 0u && !(i0 < n_tot || (i0 + TILE > C && n_tot != 0u))) return;
-        q0c = fw_ld4w(iw0, tid * 16u), q3c = fw_ld4w(iw3, tid * 16u);
-        q1c = fw_ld4w(iw1, tid * 16u), q2c = fw_ld4w(iw2, tid * 16u);
-        q0n = fw_ld4w(iw0, i1), q3n = fw_ld4w(iw3, i1);
-        q1n = fw_ld4w(iw1, i1), q2n = fw_ld4w(iw2, i1);
+        q0c = fw_ld4w(iw0, tid * 16u), q3c = fw_ld4w(iw3, (tid * 16u) & m2);
+        q1c = fw_ld4w(iw1, tid * 16u), q2c = fw_ld4w(iw2, (tid * 16u) & m2);
+        q0n = fw_ld4w(iw0, i1), q3n = fw_ld4w(iw3, i1 & m2);
+        q1n = fw_ld4w(iw1, i1), q2n = fw_ld4w(iw2, i1 & m2);
     }
     if (blockIdx.x == 0 && tid == 0) {
         if (a.live_next) *a.live_next = 0ull;
         if (a.done_tag) *a.done_tag = a.done_value;
     }
-    const FwType T = g.types[F.type_idx];
+    const FwType T = g.types[F.type_idx & ~FW_TYPE_IDX_NOSPIN];
     if (tid < F.keys_len) s_keys[tid] = key0;
     for (uint32_t i = tid + BLK; i < F.keys_len; i += BLK) s_keys[i] = g.keys[F.keys_off + i];
     __syncthreads();
@@ -1671,7 +1686,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
                 if (s < head) i += C;
                 if (i < n_dead && i < n_in) {
                     const uint32_t b16 = (uint32_t)(r * BLK + (int)tid) * 16u;
-                    const float4 q0 = fw_ld4w(iw0, b16), q1 = fw_ld4w(iw1, b16), q2 = fw_ld4w(iw2, b16), q3 = fw_ld4w(iw3, b16);
+                    const float4 q0 = fw_ld4w(iw0, b16), q1 = fw_ld4w(iw1, b16), q2 = fw_ld4w(iw2, b16 & m2);
+                    const float4 q3 = nospin ? q3s : fw_ld4w(iw3, b16);
                     // (a materialised particle that dies in its first update: its planes hold the spawn-time colours and
                     // scale, which is what the record of a particle born and destroyed in one frame carries)
                     fw_store_destroyed(F.destroyed, buf, C, s, true, T, s_keys, q0, q1, q2, q3, q0.w + a.dt, i);
@@ -1684,8 +1700,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         for (int r = 0; r < R; r++) {
             const uint32_t s = sbase + r * BLK + tid;
             const uint32_t in_ = (uint32_t)(min(r + 2, R - 1) * BLK + (int)tid) * 16u;  // two rounds ahead (the last re-read)
-            const float4 q0f = fw_ld4w(iw0, in_), q3f = fw_ld4w(iw3, in_);
-            const float4 q1f = fw_ld4w(iw1, in_), q2f = fw_ld4w(iw2, in_);
+            const float4 q0f = fw_ld4w(iw0, in_), q3f = fw_ld4w(iw3, in_ & m2);
+            const float4 q1f = fw_ld4w(iw1, in_), q2f = fw_ld4w(iw2, in_ & m2);
+            if (nospin) q3c = q3s;
             uint32_t i = s - head;  // logical index of the slot
             if (s < head) i += C;
             float age_new;
@@ -2046,7 +2063,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
                 const uint32_t ps = fw_ring_slot(op.parent_head, idx, PC);
                 s_par[wave][0][lane] = fw_ld4(pb + FW_OFF_Q0(PC), ps);
                 s_par[wave][1][lane] = fw_ld4(pb + FW_OFF_Q1(PC), ps);
-                s_par[wave][2][lane] = fw_ld4(pb + FW_OFF_Q2(PC), ps);
+                s_par[wave][2][lane] = op.parent_nospin ? make_float4(op.parent_rot[0], op.parent_rot[1], op.parent_rot[2], op.parent_rot[3])
+                                                        : fw_ld4(pb + FW_OFF_Q2(PC), ps);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -2114,12 +2132,13 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
 // ---------------------------------------------------------------------------------
 
 // SoA planes -> fw_particle records (26 x 4 B)
-__global__ void fw_k_gather(const char *buf, uint32_t C, uint32_t head, uint32_t n, int32_t pbr, float *out) {
+// (rot: the rotation of every particle of a type that cannot turn -- FW_TYPE_NOSPIN, its plane is not maintained -- or null)
+__global__ void fw_k_gather(const char *buf, uint32_t C, uint32_t head, uint32_t n, int32_t pbr, float *out, bool nospin, float4 rot) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
     const uint32_t i = fw_ring_slot(head, li, C);
     const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i), q1 = fw_ld4(buf + FW_OFF_Q1(C), i),
-                 q2 = fw_ld4(buf + FW_OFF_Q2(C), i), q3 = fw_ld4(buf + FW_OFF_Q3(C), i),
+                 q2 = nospin ? rot : fw_ld4(buf + FW_OFF_Q2(C), i), q3 = fw_ld4(buf + FW_OFF_Q3(C), i),
                  bc = fw_ld4(buf + FW_OFF_Q5(C), i), em = fw_ld4(buf + FW_OFF_Q6(C), i);
     const float sc = reinterpret_cast<const float *>(buf + FW_OFF_S4(C))[i];
     float *r = out + (size_t)li * 26;
@@ -2156,12 +2175,20 @@ __global__ void fw_k_fill_colors(char *buf0, char *buf1, uint32_t C, float4 bc, 
     if (buf1) fw_st4(buf1 + FW_OFF_Q5(C), i, bc), fw_st4(buf1 + FW_OFF_Q6(C), i, em);
 }
 
+// a type leaves FW_TYPE_NOSPIN: its rotation plane, which nobody maintained, gets the constant rotation in every slot
+__global__ void fw_k_fill_rotation(char *buf0, char *buf1, uint32_t C, float4 rot) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    fw_st4(buf0 + FW_OFF_Q2(C), i, rot);
+    if (buf1) fw_st4(buf1 + FW_OFF_Q2(C), i, rot);
+}
+
 // ParticleInstance packing (reference src/render.rs:95-115): {pos, scale, rot, base, emissive}
 // SoA planes -> ParticleInstance records (render.rs:95-115).  Loads are plane-wise coalesced; the 64-byte records are
 // transposed through LDS so that every store instruction of a wave writes 1 KiB of consecutive bytes (a lane writing
 // its own record with four float4 stores would touch 64 lines a quarter at a time).
 __global__ __launch_bounds__(256) void fw_k_pack(const char *buf, uint32_t C, uint32_t head, const uint32_t *d_count,
-                                                 uint32_t n_upper, float4 *out) {
+                                                 uint32_t n_upper, float4 *out, bool nospin, float4 rot) {
     __shared__ float4 s_rec[256 * 4];
     const uint32_t n = min(*d_count, n_upper);
     const uint32_t tid = threadIdx.x;
@@ -2169,7 +2196,7 @@ __global__ __launch_bounds__(256) void fw_k_pack(const char *buf, uint32_t C, ui
         const uint32_t i = fw_ring_slot(head, min(b + tid, n - 1u), C);
         const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i);
         const float sc = fw_ld1(buf + FW_OFF_S4(C), i);
-        const float4 q2 = fw_ld4(buf + FW_OFF_Q2(C), i);
+        const float4 q2 = nospin ? rot : fw_ld4(buf + FW_OFF_Q2(C), i);
         const float4 q5 = fw_ld4(buf + FW_OFF_Q5(C), i);
         const float4 q6 = fw_ld4(buf + FW_OFF_Q6(C), i);
         s_rec[tid * 4 + 0] = make_float4(q0.x, q0.y, q0.z, sc);
@@ -2478,9 +2505,12 @@ hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d
     return hipGetLastError();
 }
 
-hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, uint32_t n, int32_t pbr, void *d_out) {
+hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, uint32_t n, int32_t pbr, void *d_out,
+                            const float *const_rot) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(fw_k_gather, dim3((n + 255) / 256), dim3(256), 0, s, buf, capacity, head, n, pbr, (float *)d_out);
+    const float4 rot = const_rot ? make_float4(const_rot[0], const_rot[1], const_rot[2], const_rot[3]) : make_float4(0.f, 0.f, 0.f, 1.f);
+    hipLaunchKernelGGL(fw_k_gather, dim3((n + 255) / 256), dim3(256), 0, s, buf, capacity, head, n, pbr, (float *)d_out,
+                       const_rot != nullptr, rot);
     return hipGetLastError();
 }
 
@@ -2499,12 +2529,21 @@ hipError_t fw_launch_fill_colors(hipStream_t s, char *buf0, char *buf1, uint32_t
     return hipGetLastError();
 }
 
+hipError_t fw_launch_fill_rotation(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, const float rot[4]) {
+    if (!capacity) return hipSuccess;
+    hipLaunchKernelGGL(fw_k_fill_rotation, dim3((capacity + 255) / 256), dim3(256), 0, s, buf0, buf1, capacity,
+                       make_float4(rot[0], rot[1], rot[2], rot[3]));
+    return hipGetLastError();
+}
+
 hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, const uint32_t *d_count,
-                                    uint32_t n_upper, void *d_out) {
+                                    uint32_t n_upper, void *d_out, const float *const_rot) {
     if (!n_upper) return hipSuccess;
     uint32_t blocks = (n_upper + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(fw_k_pack, dim3(blocks), dim3(256), 0, s, buf, capacity, head, d_count, n_upper, (float4 *)d_out);
+    const float4 rot = const_rot ? make_float4(const_rot[0], const_rot[1], const_rot[2], const_rot[3]) : make_float4(0.f, 0.f, 0.f, 1.f);
+    hipLaunchKernelGGL(fw_k_pack, dim3(blocks), dim3(256), 0, s, buf, capacity, head, d_count, n_upper, (float4 *)d_out,
+                       const_rot != nullptr, rot);
     return hipGetLastError();
 }
 

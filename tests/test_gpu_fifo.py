@@ -207,9 +207,10 @@ def test_unchanged_planes_are_not_written_but_changed_ones_are(system):
     pair = Pair(system, S.ParticleSpawner([still, spin], [e0, e1]), seed=SEED, uid=5)
     _expect_path(system, pair, 0), _expect_path(system, pair, 1)
     if system.path == "fifo":
-        # (default colours are one-key gradients: never rewritten; so is a constant scale curve; the second type spins
-        # and its angular velocity decays: rotation and angular velocity planes are written too)
-        assert pair.gpu.update_path(0)[1] == 64 + 32 and pair.gpu.update_path(1)[1] == 64 + 32 + 32 + 4
+        # (default colours are one-key gradients: never rewritten; so is a constant scale curve; a type that cannot turn
+        # reads neither its rotation nor its angular-velocity / lifetime plane: position+age and velocity in, the same out;
+        # the second type spins and its angular velocity decays: all four state planes in, all of them + the scale out)
+        assert pair.gpu.update_path(0)[1] == 32 + 32 and pair.gpu.update_path(1)[1] == 64 + 32 + 32 + 4
     for fr in range(90):
         system.update(DT)
         pair.step_cpu(DT)
