@@ -484,3 +484,70 @@ def test_settings_churn_does_not_leak_slots(system):
         system.update(DT)
         pair.step_cpu(DT)
     pair.check(what="after churn")
+
+
+def test_types_that_cannot_turn_keep_no_rotation_plane(system):
+    """FW_TYPE_NOSPIN: every entry feeding the type spawns with zero angular velocity and the same rotation, the type has no
+    angular acceleration -> rotation is that rotation for every particle for ever and the update moves no rotation
+    bytes; what the ABI shows (particles, instance records, destroyed records, children of such parents) must still be
+    the reference's.  A negative-zero component in the rotation, two feeding entries with the same rotation, and the
+    ways out of the mode: particles written by the caller (they may spin) and a non-finite step."""
+    rot = (0.0, math.sin(0.4), -0.0, math.cos(0.4))
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.3, 0.9), linear_drag=0.3, particles_destroyed=lambda dead: None,
+                            base_color=S.FireworkGradient.uneven_samples(workloads.STRESS_GRADIENT))
+    e0 = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(30000.0), initial_rotation=rot,
+                            initial_velocity=S.RandVec3(S.RandF32(1.0, 6.0), (0.0, 1.0, 0.0), 0.0))
+    e1 = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(7000.0), initial_rotation=rot,
+                            emission_shape=S.EmissionShape.Sphere(0.5))
+    pair = Pair(system, S.ParticleSpawner([ps], [e0, e1]), S.Transform((1.0, 2.0, 3.0)), seed=SEED, uid=61)
+    mode, moved, _ = pair.gpu.update_path(0)
+    assert moved == (164 - 16 - 32 if mode == "general" else None) or mode == "fifo"   # constant emissive, no rotation plane
+    for fr in range(60):
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr % 10 == 9:
+            pair.check(what=f"frame {fr}")
+            assert_particles_match(pair.gpu.destroyed(0), pair.cpu.destroyed(0), False, f"destroyed frame {fr}")
+            inst, parts = pair.gpu.instances(0), pair.gpu.particles(0)
+            assert np.array_equal(inst["rotation"], parts["rotation"]) and np.array_equal(parts["rotation"], pair.cpu.particles(0)["rotation"])
+    # the caller writes particles that DO spin: the plane is back, rotations evolve as the reference's
+    rng = np.random.default_rng(4)
+    parts = pair.cpu.particles(0).copy()
+    parts["angular_velocity"] = rng.uniform(-6.0, 6.0, size=(len(parts), 3)).astype(np.float32)
+    q = rng.normal(size=(len(parts), 4))
+    parts["rotation"] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    pair.gpu.write_particles(0, parts)
+    pair.cpu.write_particles(0, parts)
+    assert pair.gpu.update_path(0)[1] == 164 - 16
+    for fr in range(40):
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr % 8 == 7:
+            pair.check(what=f"after write {fr}")
+    assert pair.gpu.count(0) > 10000
+
+
+def test_two_entries_with_different_rotations_keep_the_plane(system):
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.3, 0.9))
+    e0 = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(9000.0), initial_rotation=(0.0, math.sin(0.4), 0.0, math.cos(0.4)))
+    e1 = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(9000.0), initial_rotation=(math.sin(0.2), 0.0, 0.0, math.cos(0.2)))
+    pair = Pair(system, S.ParticleSpawner([ps], [e0, e1]), seed=SEED, uid=62)
+    assert pair.gpu.update_path(0)[1] in (164 - 32, 64 + 32)   # both colours constant; rotation plane kept (ring: read only)
+    run(system, pair, 60, check_every=12, exact_all=True)
+    assert len(np.unique(pair.gpu.particles(0)["rotation"], axis=0)) == 2
+
+
+def test_a_non_finite_step_brings_the_rotation_plane_back(system):
+    """0 * inf = NaN: an angular velocity of zero does not stay zero through a non-finite dt (core.rs:648-650), so the type
+    stops being FW_TYPE_NOSPIN first; nothing may crash or hang, and the state is the reference's NaNs"""
+    ps = S.ParticleSettings(lifetime=S.RandF32(5.0, 9.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [S.EmissionSettings(emission_pacing=S.EmissionPacing.OneShot(5000))]), seed=SEED, uid=63)
+    run(system, pair, 5, exact_all=True)
+    before = pair.gpu.update_path(0)[1]
+    system.update(np.float32("nan"))
+    pair.step_cpu(np.float32("nan"))
+    assert pair.gpu.update_path(0)[1] == before + 32 and pair.gpu.update_path(0)[0] == "general"
+    g, c = pair.gpu.particles(0), pair.cpu.particles(0)
+    assert len(g) == len(c) == 5000
+    for f in ("age", "position", "angular_velocity", "rotation"):
+        assert np.array_equal(np.isnan(g[f]), np.isnan(c[f])), f
