@@ -154,8 +154,9 @@ struct alignas(16) FwNestOp {
     float n_count, n_start, n_end;  // CountOverDuration of the entry (core.rs:474-481)
     uint32_t parent_head;    // ring heads of the two segments (FIFO rings; 0 otherwise): particle i sits in slot
     uint32_t child_head;     // (head + i) mod capacity
-    uint32_t parent_nospin;  // the parent type cannot turn (FW_TYPE_NOSPIN): its rotation is parent_rot, not in the plane
-    uint32_t pad0[2];
+    uint32_t parent_nospin;  // the parent type cannot turn (FW_TYPE_NOSPIN): its rotation is parent_rot, not in the plane,
+    uint32_t parent_life_plane;  // ... and its lifetimes sit in this 4-byte plane (FW_OFF_L index), not in Q3;
+    float parent_life_const;     // 0xFFFFFFFF: the parent is a ring, all its particles have this lifetime
     float parent_rot[4];
 };
 

@@ -137,6 +137,9 @@ struct alignas(64) SegHost {
     // FW_TYPE_NOSPIN (fw_device.h): no particle of the type can turn; the rotation plane is neither read nor written
     bool nospin = false;
     float const_rot[4] = {0.f, 0.f, 0.f, 1.f};
+    // ... and keeps its lifetimes in one more 4-byte plane behind the n_lplanes last_emitted_age planes instead of in Q3
+    // (allocated with the type, kept when the type leaves the mode)
+    uint32_t n_xplanes = 0;
     struct Cohort {
         uint32_t n;
         float age;
@@ -556,7 +559,7 @@ fw_status upload_seg(fw_ctx *ctx, uint32_t si) {
 }
 
 fw_status alloc_seg_buffers(fw_ctx *ctx, SegHost &s, uint32_t capacity, bool want_destroyed) {
-    const size_t bytes = FW_BUF_BYTES((size_t)capacity, s.n_lplanes);
+    const size_t bytes = FW_BUF_BYTES((size_t)capacity, s.n_lplanes + s.n_xplanes);
     char *b = nullptr;
     hipError_t e = hipMalloc((void **)&b, bytes * (s.fifo ? 1 : 2));  // a FIFO ring is updated in place: one buffer
     if (e != hipSuccess) return fail(ctx, FW_ENOMEM, std::string("hipMalloc particle buffers: ") + hipGetErrorString(e));
@@ -652,7 +655,7 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
     FW_HIP(ctx, cp(FW_OFF_Q5(NC), FW_OFF_Q5(OC), 16));
     FW_HIP(ctx, cp(FW_OFF_Q6(NC), FW_OFF_Q6(OC), 16));
     FW_HIP(ctx, cp(FW_OFF_S4(NC), FW_OFF_S4(OC), 4));
-    for (uint32_t k = 0; k < s.n_lplanes; k++) FW_HIP(ctx, cp(FW_OFF_L(NC, k), FW_OFF_L(OC, k), 4));
+    for (uint32_t k = 0; k < s.n_lplanes + s.n_xplanes; k++) FW_HIP(ctx, cp(FW_OFF_L(NC, k), FW_OFF_L(OC, k), 4));
     if (old.destroyed)  // the records of the last update stay readable (fw_spawner_read_destroyed)
         FW_HIP(ctx, hipMemcpy(s.destroyed, old.destroyed, (size_t)std::min(old.capacity, ncap) * sizeof(fw_particle),
                               hipMemcpyDeviceToDevice));
@@ -678,6 +681,11 @@ fw_status fifo_to_general(fw_ctx *ctx, uint32_t si) {
     if (st) return st;
     SegHost &s = ctx->segs[si];
     s.win_ok = false;  // no lifetime window was kept: the bound follows the snapshots from here on
+    if (s.nospin) {  // a ring keeps no lifetime plane (one value); the compacting kernels read it
+        FW_HIP(ctx, fw_launch_fill_plane1(ctx->stream, s.buf[0], s.buf[1], FW_OFF_L((size_t)s.capacity, s.n_lplanes), s.capacity,
+                                          s.fifo_life));
+        FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return FW_OK;
 }
 
@@ -689,6 +697,8 @@ fw_status leave_nospin(fw_ctx *ctx, uint32_t si) {
     fw_status st = sync(ctx);
     if (st) return st;
     FW_HIP(ctx, fw_launch_fill_rotation(ctx->stream, s.buf[0], s.fifo ? nullptr : s.buf[1], s.capacity, s.const_rot));
+    FW_HIP(ctx, fw_launch_restore_q3(ctx->stream, s.buf[0], s.fifo ? nullptr : s.buf[1], s.capacity,
+                                     s.fifo ? 0xFFFFFFFFu : s.n_lplanes, s.fifo_life));
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t zero = 0;
     FW_HIP(ctx, hipMemcpy((char *)(ctx->d_types.d + s.type_idx) + offsetof(FwType, flags), &zero, sizeof zero, hipMemcpyHostToDevice));
@@ -943,7 +953,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         S = SegHost{};
         S.in_use = true, S.spawner = h, S.type = (int)t, S.type_idx = type_idx;
         S.keys_off = dt.keys_off, S.keys_len = dt.keys_len;
-        S.nospin = nospin;
+        S.nospin = nospin, S.n_xplanes = nospin ? 1u : 0u;
         memcpy(S.const_rot, dt.const_rot, sizeof S.const_rot);
         sp.seg[t] = si;
         FW_HIP(ctx, hipMemcpy(ctx->d_keys.d + dt.keys_off, keys.data(), keys.size() * sizeof(float),
@@ -1959,6 +1969,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     op.child_head = ctx->segs[op.child_seg].fifo ? ctx->segs[op.child_seg].head : 0u;
                     op.parent_nospin = ctx->segs[op.parent_seg].nospin ? 1u : 0u;
                     memcpy(op.parent_rot, ctx->segs[op.parent_seg].const_rot, sizeof op.parent_rot);
+                    // (its lifetimes: the lifetime plane of a compacting segment, one value for a ring)
+                    op.parent_life_plane = ctx->segs[op.parent_seg].fifo ? 0xFFFFFFFFu : ctx->segs[op.parent_seg].n_lplanes;
+                    op.parent_life_const = ctx->segs[op.parent_seg].fifo_life;
                     h_nops[ni++] = op;
                 }
                 launches.push_back(Launch{true, first, ni - first, tiles});
@@ -2254,7 +2267,8 @@ fw_status fw_spawner_poll_finished(fw_ctx *ctx, fw_spawner h, int32_t *out) {
 }
 
 static fw_status read_records(fw_ctx *ctx, const char *buf, uint32_t cap_seg, uint32_t n, int32_t pbr, bool aos,
-                              fw_particle *out, uint64_t cap, uint32_t head = 0, const float *const_rot = nullptr) {
+                              fw_particle *out, uint64_t cap, uint32_t head = 0, const float *const_rot = nullptr,
+                              uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.f) {
     const uint64_t m = std::min<uint64_t>(n, cap);
     if (!m || !out) return FW_OK;
     if (aos) {
@@ -2263,7 +2277,7 @@ static fw_status read_records(fw_ctx *ctx, const char *buf, uint32_t cap_seg, ui
     }
     void *tmp = nullptr;
     FW_HIP(ctx, hipMalloc(&tmp, m * sizeof(fw_particle)));
-    hipError_t e = fw_launch_gather(ctx->stream, buf, cap_seg, head, (uint32_t)m, pbr, tmp, const_rot);
+    hipError_t e = fw_launch_gather(ctx->stream, buf, cap_seg, head, (uint32_t)m, pbr, tmp, const_rot, life_plane, life_const);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(out, tmp, m * sizeof(fw_particle), hipMemcpyDeviceToHost);
     hipFree(tmp);
@@ -2283,7 +2297,8 @@ fw_status fw_spawner_read_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
     const uint32_t n = c[sp->seg[type]];
     if (n_out) *n_out = n;
     fw_status st2 = read_records(ctx, S.buf[ctx->parity], S.capacity, n, sp->types[type].ps.pbr, false, out, cap,
-                                 S.fifo ? S.head : 0u, S.nospin ? S.const_rot : nullptr);
+                                 S.fifo ? S.head : 0u, S.nospin ? S.const_rot : nullptr,
+                                 (S.nospin && !S.fifo) ? S.n_lplanes : 0xFFFFFFFFu, S.fifo_life);
     return st2 ? st2 : st;
 }
 
@@ -2635,8 +2650,9 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t
         algo = moved - 4u - (q3 ? 4u : 0u);
     } else {
         // compacting: every state plane lands at a new slot (+ the last_emitted planes of a Nested parent, read and written);
-        // a type that cannot turn keeps no rotation plane: -16 B read, -16 B written
-        moved = 64u + 64u + 4u + colours + 8u * S.n_lplanes - (S.nospin ? 32u : 0u);
+        // a type that cannot turn keeps no rotation plane: -16 B read, -16 B written,
+        // ... and its lifetimes in a 4-byte plane instead of Q3: -32 B again, +4 B read, +4 B written
+        moved = 64u + 64u + 4u + colours + 8u * S.n_lplanes - (S.nospin ? 32u + 32u - 8u : 0u);
         algo = moved - 8u;
     }
     if (moved_bytes) *moved_bytes = moved;

@@ -164,8 +164,12 @@ hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d
 // SoA -> AoS gather of `n` particles of one segment buffer into fw_particle records (device)
 // (head: slot of particle 0 -- 0 for every segment but a FIFO ring)
 // (const_rot: the rotation of a type that cannot turn -- FW_TYPE_NOSPIN, its plane is not maintained -- or null)
+// (... and then its lifetimes sit in plane `life_plane` behind the last_emitted_age planes, or -- a ring: 0xFFFFFFFF -- all
+// equal life_const)
 hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, uint32_t n, int32_t pbr, void *d_out,
-                            const float *const_rot = nullptr);
+                            const float *const_rot = nullptr, uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.0f);
+hipError_t fw_launch_fill_plane1(hipStream_t s, char *buf0, char *buf1, size_t plane_off, uint32_t capacity, float v);
+hipError_t fw_launch_restore_q3(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, uint32_t life_plane, float life_const);
 hipError_t fw_launch_scatter(hipStream_t s, char *buf, uint32_t capacity, uint32_t n, uint32_t n_lplanes,
                              const void *d_in);
 // fills the base / emissive colour planes of one (buf1 == nullptr) or both buffers of a segment (capacity slots each)

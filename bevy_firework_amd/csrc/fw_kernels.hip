@@ -101,6 +101,9 @@ __device__ __forceinline__ void fw_st4w(char *win, uint32_t byte_off, float4 v) 
     *p = x;
 #endif
 }
+__device__ __forceinline__ float fw_ld1w(const char *win, uint32_t byte_off) {
+    return *reinterpret_cast<const FW_GLOBAL float *>(reinterpret_cast<const FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off);
+}
 __device__ __forceinline__ void fw_st1w(char *win, uint32_t byte_off, float v) {
     *reinterpret_cast<FW_GLOBAL float *>(reinterpret_cast<FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off) = v;
 }
@@ -122,18 +125,31 @@ struct FwOutWin {  // output planes advanced to slot `first` (workgroup-uniform)
     // this launch writes base_color / emissive_color (always true for a few frames after the caller rewrote particles).
     bool wr5, wr6;
     bool wr2;  // rotation plane (false for a type that cannot turn: FW_TYPE_NOSPIN)
+    // ... and such a type keeps its lifetimes in a 4-byte plane of their own behind the last_emitted_age planes instead of
+    // Q3 (angular velocity 0 + lifetime): wr3 false -> the lifetime goes to `lf`, Q3 is not written
+    bool wr3;
+    char *lf;
 };
-__device__ __forceinline__ FwOutWin fw_out_window(char *ob, uint32_t C, uint32_t first, const FwType &T, uint32_t force_colors) {
+__device__ __forceinline__ FwOutWin fw_out_window(char *ob, uint32_t C, uint32_t first, const FwType &T, uint32_t force_colors,
+                                                  uint32_t n_lplanes = 0u) {
     const size_t f16 = (size_t)first * 16u;
     return FwOutWin{ob + FW_OFF_Q0(C) + f16, ob + FW_OFF_Q1(C) + f16, ob + FW_OFF_Q2(C) + f16, ob + FW_OFF_Q3(C) + f16,
                     ob + FW_OFF_Q5(C) + f16, ob + FW_OFF_Q6(C) + f16, ob + FW_OFF_S4(C) + (size_t)first * 4u, first,
-                    T.bc_kind != 0 || force_colors != 0u, T.em_kind != 0 || force_colors != 0u, !(T.flags & FW_TYPE_NOSPIN)};
+                    T.bc_kind != 0 || force_colors != 0u, T.em_kind != 0 || force_colors != 0u, !(T.flags & FW_TYPE_NOSPIN),
+                    !(T.flags & FW_TYPE_NOSPIN), ob + FW_OFF_L(C, n_lplanes) + (size_t)first * 4u};
 }
 
 // slot of logical particle i of a segment whose particle 0 sits in slot `head` (0 unless the segment is a FIFO ring)
 __device__ __forceinline__ uint32_t fw_ring_slot(uint32_t head, uint32_t i, uint32_t C) {
     const uint32_t s = head + i;  // head < C, i < C <= 0xFFFF0000 / 2 ... no overflow: capacities stay below 2^31
     return s >= C ? s - C : s;
+}
+
+// Q3 (angular velocity, lifetime) of particle `idx`: from the plane, or -- a type that cannot turn -- zero and the lifetime
+// plane (FwOutWin::lf)
+__device__ __forceinline__ float4 fw_load_q3(const char *buf, uint32_t C, uint32_t n_lplanes, uint32_t idx, bool nospin) {
+    if (nospin) return make_float4(0.0f, 0.0f, 0.0f, fw_ld1(buf + FW_OFF_L(C, n_lplanes), idx));
+    return fw_ld4(buf + FW_OFF_Q3(C), idx);
 }
 
 // alive test of update_particles: `if particle.age >= particle.lifetime { destroyed }` (core.rs:594-599)
@@ -235,6 +251,7 @@ __device__ __forceinline__ void fw_store_new(const FwGlobals &g, const FwSeg &S,
     fw_st4(buf + FW_OFF_Q1(C), slot, o.q1);
     fw_st4(buf + FW_OFF_Q2(C), slot, o.q2);
     fw_st4(buf + FW_OFF_Q3(C), slot, o.q3);
+    if (T.flags & FW_TYPE_NOSPIN) fw_st1(buf + FW_OFF_L(C, S.n_lplanes), slot, o.q3.w);  // the lifetime plane (FwOutWin::lf)
     fw_st4(buf + FW_OFF_Q5(C), slot, make_float4(bc[0], bc[1], bc[2], bc[3]));
     fw_st4(buf + FW_OFF_Q6(C), slot, make_float4(em[0], em[1], em[2], em[3]));
     fw_st1(buf + FW_OFF_S4(C), slot, o.q1.w);  // scale = initial_scale
@@ -356,13 +373,14 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
         const uint32_t d3 = (__float_as_uint(wx) ^ __float_as_uint(q3.x)) | (__float_as_uint(wy) ^ __float_as_uint(q3.y)) |
                             (__float_as_uint(wz) ^ __float_as_uint(q3.z));
         if (W.wr2 && __any(full || d2 != 0u)) fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));  // wave-uniform branches
-        if (__any(full || d3 != 0u)) fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
+        if (W.wr3 && __any(full || d3 != 0u)) fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
         if ((WM >= 0 ? (WM & 1) != 0 : W.wr5) || full) fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
         if ((WM >= 0 ? (WM & 2) != 0 : W.wr6) || full) fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
         if ((WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) || full) fw_st1w(W.s4, (o - W.first) * 4u, scale);
     } else {
         if (W.wr2) fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
-        fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
+        if (W.wr3) fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
+        else fw_st1w(W.lf, (o - W.first) * 4u, lifetime);
         if (W.wr5) fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));  // workgroup-uniform branches
         if (W.wr6) fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
         fw_st1w(W.s4, (o - W.first) * 4u, scale);
@@ -778,7 +796,11 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             // unconditional, clamped into the tile (a predicated load would be waited for in its own basic block)
             const uint32_t idx = has_new ? 0u : min(base + r * BLK + tid, lim - 1u);
             t0[r] = fw_ld4(ib + FW_OFF_Q0(C), idx);
-            t3[r] = fw_ld4(ib + FW_OFF_Q3(C), idx);
+            t3[r] = fw_ld4(ib + FW_OFF_Q3(C), idx & m2);
+            // a type that cannot turn: Q3 is not kept, the lifetime comes from its own plane (both loads unconditional: the
+            // one that is not needed asks for one and the same slot of a plane that exists)
+            const float lf = fw_ld1((m2 ? ib + FW_OFF_Q0(C) : ib + FW_OFF_L(C, n_lplanes)), m2 ? 0u : idx);
+            if (!m2) t3[r] = make_float4(0.0f, 0.0f, 0.0f, lf);
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -906,7 +928,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
                 for (uint32_t i = (use_fc ? n_in : 0u) + tid; i < base; i += BLK) {  // base is a particle index
                     float an, ag = 0.0f, lf;
                     if (i < n_in) {
-                        ag = fw_ld4(ib + FW_OFF_Q0(C), i).w, lf = fw_ld4(ib + FW_OFF_Q3(C), i).w;
+                        ag = fw_ld4(ib + FW_OFF_Q0(C), i).w, lf = fw_load_q3(ib, C, n_lplanes, i, m2 == 0u).w;
                     } else {  // a spawned particle: only its lifetime draw matters (RNG block 2, word 0)
                         const uint32_t k = i - n_in;
                         uint32_t oi = o0;
@@ -941,7 +963,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     // ---- phase 3: round loop -- integrate survivors, store them at their compacted slot
     const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
     excl = __builtin_amdgcn_readfirstlane(excl);  // workgroup-uniform: keep it on the scalar unit
-    const FwOutWin W = fw_out_window(ob, C, excl, T, a.force_colors);
+    const FwOutWin W = fw_out_window(ob, C, excl, T, a.force_colors, n_lplanes);
     const uint32_t fcA = excl / FW_TILE, fc_bnd = (fcA + 1u) * FW_TILE;  // output tiles this workgroup feeds
     uint32_t fa = 0, fb = 0;
     float box[6] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f, FW_F32_MIN, FW_F32_MIN, FW_F32_MIN};
@@ -1184,6 +1206,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     const uint32_t vt_rounds = a.vt_rounds;  // new-particle tile size: the host's choice (from its bounds)
     // ---- LONE: round 0 requested now, for the particle range this workgroup has if it is a live tile
     float4 q0c, q1c, q2c, q3c;
+    float lfc = 0.0f;  // lifetime of a particle that cannot turn (its Q3 plane is not kept: FwOutWin::lf)
     uint32_t spec_base = 0xFFFFFFFFu;  // first particle of the speculative request (none: 0xFFFFFFFF)
     if (LONE) {
         uint32_t ks = 0;  // spawns of this frame, known from the arguments (every inline op belongs to the lone segment)
@@ -1198,7 +1221,8 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         const size_t sfirst = spec_base != 0xFFFFFFFFu ? (size_t)spec_base * 16u : (size_t)0;
         const uint32_t i0 = tid * 16u;
         q0c = fw_ld4w(ib + FW_OFF_Q0(C) + sfirst, i0);
-        q3c = fw_ld4w(ib + FW_OFF_Q3(C) + sfirst, i0);
+        q3c = fw_ld4w(ib + FW_OFF_Q3(C) + sfirst, i0 & m2);
+        lfc = fw_ld1w((m2 ? ib + FW_OFF_Q0(C) : ib + FW_OFF_L(C, n_lplanes)) + (m2 ? (size_t)0 : sfirst / 4u), m2 ? 0u : i0 / 4u);
         q1c = fw_ld4w(ib + FW_OFF_Q1(C) + sfirst, i0);
         q2c = fw_ld4w(ib + FW_OFF_Q2(C) + sfirst, i0 & m2);
     }
@@ -1288,10 +1312,12 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     const size_t ifirst = loaded_tile ? (size_t)base * 16u : (size_t)0;
     const char *iw0 = ib + FW_OFF_Q0(C) + ifirst, *iw1 = ib + FW_OFF_Q1(C) + ifirst;
     const char *iw2 = ib + FW_OFF_Q2(C) + ifirst, *iw3 = ib + FW_OFF_Q3(C) + ifirst;
+    const char *iwl = m2 ? iw0 : ib + FW_OFF_L(C, n_lplanes) + ifirst / 4u;  // lifetime plane (or any valid address)
     if (!LONE || (loaded_tile && base != spec_base)) {  // LONE: only a tile whose role differs from the guess reloads
         const uint32_t i0 = loaded_tile ? min(tid, last - base) * 16u : 0u;
         q0c = fw_ld4w(iw0, i0);
-        q3c = fw_ld4w(iw3, i0);
+        q3c = fw_ld4w(iw3, i0 & m2);
+        lfc = fw_ld1w(iwl, m2 ? 0u : i0 / 4u);
         q1c = fw_ld4w(iw1, i0);
         q2c = fw_ld4w(iw2, i0 & m2);
     }
@@ -1401,7 +1427,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     float box[6] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f, FW_F32_MIN, FW_F32_MIN, FW_F32_MIN};
     const bool box_on = a.boxes != 0u;  // workgroup-uniform
     excl = __builtin_amdgcn_readfirstlane(excl);  // workgroup-uniform (summed from LDS): keep it on the scalar unit
-    const FwOutWin W = fw_out_window(ob, C, excl, T, a.force_colors);
+    const FwOutWin W = fw_out_window(ob, C, excl, T, a.force_colors, n_lplanes);
     uint32_t run = excl;
     int rr = 0;  // rounds done so far (the wave-count exchange area is double-buffered by round parity)
     if (loaded_tile) {
@@ -1414,9 +1440,11 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             const uint32_t idx = base + r * BLK + tid;
             const uint32_t in_ = min((r + 1) * BLK + tid, last - base) * 16u;  // next round's slot (clamped: see above)
             const float4 q0n = fw_ld4w(iw0, in_);
-            const float4 q3n = fw_ld4w(iw3, in_);
+            const float4 q3n = fw_ld4w(iw3, in_ & m2);
+            const float lfn = fw_ld1w(iwl, m2 ? 0u : in_ / 4u);
             const float4 q1n = fw_ld4w(iw1, in_);
             const float4 q2n = fw_ld4w(iw2, in_ & m2);
+            if (!m2) q3c = make_float4(0.0f, 0.0f, 0.0f, lfc);
             const bool valid = idx < lim;
             float age_new;
             const bool alive = valid && fw_survives(q0c.w, a.dt, q3c.w, &age_new);
@@ -1436,7 +1464,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             fw_round_finish(T, s_keys, a.dt, a.dbg, q0c, q1c, q2c, q3c, valid, alive, true, age_new, idx, o, ib, ob, W,
                             destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec, box, box_on);
             if (INST && inst != nullptr && !(a.dbg & 2u)) fw_inst_flush(inst, inst_cap, s_inst + wave * 256u, lane, m, wbase);
-            q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n;
+            q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n, lfc = lfn;
             if ((a.dbg & 8u) && r == 0) tsR1 = __builtin_amdgcn_s_memrealtime() + (o & 0u);
         }
     }
@@ -1759,13 +1787,14 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_count(FwGlobals g, FwUpdateArgs
         const FwSeg &S = g.segs[seg];
         const char *ib = S.buf[a.parity];
         const FwTypeColl &T = g.type_coll[S.type_idx];
+        const bool nospin = (g.types[S.type_idx].flags & FW_TYPE_NOSPIN) != 0u;
         const bool coll_kill = (T.coll_flags & (FW_COLL_ENABLED | FW_COLL_DESTROY)) == (FW_COLL_ENABLED | FW_COLL_DESTROY);
         for (int r = 0; r < FW_ROUNDS; r++) {
             const uint32_t idx = base + r * FW_BLOCK + tid;
             if (idx < n_tot) {
                 float an;
                 const float4 q0 = fw_ld4(ib + FW_OFF_Q0(S.capacity), idx);
-                bool al = fw_survives(q0.w, a.dt, fw_ld4(ib + FW_OFF_Q3(S.capacity), idx).w, &an);
+                bool al = fw_survives(q0.w, a.dt, fw_load_q3(ib, S.capacity, S.n_lplanes, idx, nospin).w, &an);
                 if (al && coll_kill) {  // destroy_on_collision removes particles too (core.rs:636-639)
                     const float4 q1 = fw_ld4(ib + FW_OFF_Q1(S.capacity), idx);
                     fw_v3 pos{q0.x, q0.y, q0.z}, vel{q1.x, q1.y, q1.z};
@@ -1821,7 +1850,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpda
     const bool coll = (TC.coll_flags & FW_COLL_ENABLED) != 0u, coll_kill = (TC.coll_flags & FW_COLL_DESTROY) != 0u;
     const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
     const uint32_t excl = g.tile_off[tile];
-    const FwOutWin W = fw_out_window(ob, C, excl, T, a.force_colors);
+    const FwOutWin W = fw_out_window(ob, C, excl, T, a.force_colors, n_lplanes);
     uint32_t run = excl;
     const uint32_t lim = min(base + FW_TILE, n_tot);
     const int n_rounds = (int)((lim - base + FW_BLOCK - 1u) / FW_BLOCK);
@@ -1831,7 +1860,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpda
         const bool valid = idx < lim;
         const uint32_t li = min(idx, lim - 1u);
         const float4 q0 = fw_ld4(ib + FW_OFF_Q0(C), li), q1 = fw_ld4(ib + FW_OFF_Q1(C), li),
-                     q2 = fw_ld4(ib + FW_OFF_Q2(C), li), q3 = fw_ld4(ib + FW_OFF_Q3(C), li);
+                     q2 = fw_ld4(ib + FW_OFF_Q2(C), li), q3 = fw_load_q3(ib, C, n_lplanes, li, (T.flags & FW_TYPE_NOSPIN) != 0u);
         float age_new;
         const bool young = valid && fw_survives(q0.w, a.dt, q3.w, &age_new);
         fw_v3 cpos{q0.x, q0.y, q0.z}, cvel{q1.x, q1.y, q1.z};
@@ -1986,7 +2015,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
     for (int r = 0; r < FW_NEST_TILE / FW_BLOCK; r++) {
         const uint32_t ci = fw_ring_slot(op.parent_head, min(pbase + r * FW_BLOCK + tid, op.parent_cap - 1u), op.parent_cap);
         p_age[r] = fw_ld4(op.parent_buf + FW_OFF_Q0(op.parent_cap), ci).w;
-        p_life[r] = fw_ld4(op.parent_buf + FW_OFF_Q3(op.parent_cap), ci).w;
+        p_life[r] = (op.parent_nospin != 0u && op.parent_life_plane == 0xFFFFFFFFu)
+                        ? op.parent_life_const
+                        : fw_load_q3(op.parent_buf, op.parent_cap, op.parent_life_plane, ci, op.parent_nospin != 0u).w;
         p_lea[r] = fw_ld1(op.parent_buf + FW_OFF_L(op.parent_cap, op.parent_lplane), ci);
     }
     const uint32_t sidx = parity * g.max_seg + op.parent_seg, cidx = parity * g.max_seg + op.child_seg;
@@ -2133,12 +2164,16 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
 
 // SoA planes -> fw_particle records (26 x 4 B)
 // (rot: the rotation of every particle of a type that cannot turn -- FW_TYPE_NOSPIN, its plane is not maintained -- or null)
-__global__ void fw_k_gather(const char *buf, uint32_t C, uint32_t head, uint32_t n, int32_t pbr, float *out, bool nospin, float4 rot) {
+__global__ void fw_k_gather(const char *buf, uint32_t C, uint32_t head, uint32_t n, int32_t pbr, float *out, bool nospin, float4 rot,
+                            uint32_t life_plane, float life_const) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
     const uint32_t i = fw_ring_slot(head, li, C);
     const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i), q1 = fw_ld4(buf + FW_OFF_Q1(C), i),
-                 q2 = nospin ? rot : fw_ld4(buf + FW_OFF_Q2(C), i), q3 = fw_ld4(buf + FW_OFF_Q3(C), i),
+                 q2 = nospin ? rot : fw_ld4(buf + FW_OFF_Q2(C), i),
+                 // (cannot turn: angular velocity 0; the lifetime from its plane, or -- a ring -- the type's one value)
+                 q3 = !nospin ? fw_ld4(buf + FW_OFF_Q3(C), i)
+                              : make_float4(0.0f, 0.0f, 0.0f, life_plane != 0xFFFFFFFFu ? fw_ld1(buf + FW_OFF_L(C, life_plane), i) : life_const),
                  bc = fw_ld4(buf + FW_OFF_Q5(C), i), em = fw_ld4(buf + FW_OFF_Q6(C), i);
     const float sc = reinterpret_cast<const float *>(buf + FW_OFF_S4(C))[i];
     float *r = out + (size_t)li * 26;
@@ -2181,6 +2216,22 @@ __global__ void fw_k_fill_rotation(char *buf0, char *buf1, uint32_t C, float4 ro
     if (i >= C) return;
     fw_st4(buf0 + FW_OFF_Q2(C), i, rot);
     if (buf1) fw_st4(buf1 + FW_OFF_Q2(C), i, rot);
+}
+
+// a 4-byte plane filled with one value (the lifetime plane of a ring that becomes a compacting segment)
+__global__ void fw_k_fill_plane1(char *buf0, char *buf1, size_t plane_off, uint32_t C, float v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    fw_st1(buf0 + plane_off, i, v);
+    if (buf1) fw_st1(buf1 + plane_off, i, v);
+}
+// a type leaves FW_TYPE_NOSPIN: Q3 = {0, 0, 0, lifetime} again, the lifetime from its plane (or one value: a ring)
+__global__ void fw_k_restore_q3(char *buf0, char *buf1, uint32_t C, uint32_t life_plane, float life_const) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    const bool pl = life_plane != 0xFFFFFFFFu;
+    fw_st4(buf0 + FW_OFF_Q3(C), i, make_float4(0.f, 0.f, 0.f, pl ? fw_ld1(buf0 + FW_OFF_L(C, life_plane), i) : life_const));
+    if (buf1) fw_st4(buf1 + FW_OFF_Q3(C), i, make_float4(0.f, 0.f, 0.f, pl ? fw_ld1(buf1 + FW_OFF_L(C, life_plane), i) : life_const));
 }
 
 // ParticleInstance packing (reference src/render.rs:95-115): {pos, scale, rot, base, emissive}
@@ -2506,11 +2557,11 @@ hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d
 }
 
 hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, uint32_t n, int32_t pbr, void *d_out,
-                            const float *const_rot) {
+                            const float *const_rot, uint32_t life_plane, float life_const) {
     if (!n) return hipSuccess;
     const float4 rot = const_rot ? make_float4(const_rot[0], const_rot[1], const_rot[2], const_rot[3]) : make_float4(0.f, 0.f, 0.f, 1.f);
     hipLaunchKernelGGL(fw_k_gather, dim3((n + 255) / 256), dim3(256), 0, s, buf, capacity, head, n, pbr, (float *)d_out,
-                       const_rot != nullptr, rot);
+                       const_rot != nullptr, rot, life_plane, life_const);
     return hipGetLastError();
 }
 
@@ -2526,6 +2577,17 @@ hipError_t fw_launch_fill_colors(hipStream_t s, char *buf0, char *buf1, uint32_t
     if (!capacity) return hipSuccess;
     hipLaunchKernelGGL(fw_k_fill_colors, dim3((capacity + 255) / 256), dim3(256), 0, s, buf0, buf1, capacity,
                        make_float4(bc[0], bc[1], bc[2], bc[3]), make_float4(em[0], em[1], em[2], em[3]));
+    return hipGetLastError();
+}
+
+hipError_t fw_launch_fill_plane1(hipStream_t s, char *buf0, char *buf1, size_t plane_off, uint32_t capacity, float v) {
+    if (!capacity) return hipSuccess;
+    hipLaunchKernelGGL(fw_k_fill_plane1, dim3((capacity + 255) / 256), dim3(256), 0, s, buf0, buf1, plane_off, capacity, v);
+    return hipGetLastError();
+}
+hipError_t fw_launch_restore_q3(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, uint32_t life_plane, float life_const) {
+    if (!capacity) return hipSuccess;
+    hipLaunchKernelGGL(fw_k_restore_q3, dim3((capacity + 255) / 256), dim3(256), 0, s, buf0, buf1, capacity, life_plane, life_const);
     return hipGetLastError();
 }
 
