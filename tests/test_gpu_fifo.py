@@ -299,3 +299,56 @@ def test_nested_rings_with_attached_instances_and_idle_frames(system):
             _expect_path(system, pair, 0), _expect_path(system, pair, 1)
     assert pair.gpu.update_path(1)[0] == "general"  # the 0.5 s step was longer than the smoke lives
     assert pair.gpu.count(1) > 5000
+
+
+def test_ring_launches_switch_between_the_side_stream_and_the_main_stream(system):
+    """a ring next to a compacting segment runs on a stream of its own; an attached instance buffer, a registered live-count
+    ring or a reader enqueued on the caller's stream move it back (or join the streams) -- every transition, with work of
+    both kinds in flight, must leave the reference's state, the records a reader sees and the per-frame live totals"""
+    import torch
+
+    ring = _ring_settings(lifetime=S.RandF32.constant(0.3), capacity=16384)
+    other = S.ParticleSettings(lifetime=S.RandF32(0.1, 0.5), linear_drag=0.4)
+    pa = Pair(system, S.ParticleSpawner([ring], [S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(30000.0))]), seed=SEED, uid=1)
+    pb = Pair(system, S.ParticleSpawner([other], [S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(20000.0),
+                                                                      emission_shape=S.EmissionShape.Sphere(1.0))]), seed=SEED, uid=2)
+    _expect_path(system, pa)
+    assert pb.gpu.update_path(0)[0] == "general"
+    cap = 12000
+    buf = torch.full((cap * 16,), float("nan"), dtype=torch.float32, device="cuda")
+    live = torch.zeros(8, dtype=torch.int64, device="cuda")
+    totals = []
+    steps_with_ring = 0  # updates since the live-count ring was registered (slot = that - 1, mod 8)
+
+    def step():
+        nonlocal steps_with_ring
+        system.update(DT)
+        pa.step_cpu(DT), pb.step_cpu(DT)
+        if 70 <= fr < 95:
+            steps_with_ring += 1
+
+    for fr in range(120):
+        if fr == 20:
+            pa.gpu.attach_instances(buf.data_ptr(), cap)        # -> ring launches on the main stream
+        if fr == 45:
+            pa.gpu.attach_instances(0, 0)                        # -> back to the side stream
+        if fr == 70:
+            system.live_count_ring(live.data_ptr(), 8)           # -> main stream again (the ring is fed by both launches)
+        if fr == 95:
+            system.live_count_ring(0, 0)
+        step()
+        if fr % 5 == 4:
+            # a reader enqueued on the main stream (the packing pass) ...
+            inst = pa.gpu.instances(0)
+            step()
+            # ... and the frame after it
+            pa.check(exact_all=True, what=f"ring frame {fr}"), pb.check(what=f"compacting frame {fr}")
+            assert len(inst) > 2000
+        if 20 <= fr < 45 and fr % 6 == 0:
+            n = pa.gpu.count(0)
+            got = buf[: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
+            assert np.array_equal(got, pa.gpu.instances(0).view(np.uint32).reshape(n, 16)), f"frame {fr}"
+        if 70 <= fr < 95:
+            torch.cuda.synchronize()
+            totals.append((int(live[(steps_with_ring - 1) % 8].item()), pa.cpu.counts()[0] + pb.cpu.counts()[0]))
+    assert len(totals) > 20 and all(a == b for a, b in totals), totals[:8]
