@@ -268,3 +268,57 @@ def _api_scenario(case, seed_base, const_p):
                     ref = pair.gpu.instances(0)[:n]
                     got = buf[: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
                     assert np.array_equal(got, ref.view(np.uint32).reshape(n, 16)), f"case {case} frame {i}: instance records"
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_every_shortcut_gives_the_state_of_the_plain_path(case, monkeypatch):
+    """rings (types with one lifetime value), no rotation / angular-velocity planes (types that cannot turn), the side
+    stream: each is a shortcut around work whose result is known in advance.  A random spawner at a size the oracle would
+    take minutes for (hundreds of thousands of particles), stepped irregularly, must end in EXACTLY the state the plain
+    path -- everything compacted, every plane kept, one stream -- produces: every field of every particle, numerically
+    equal (a shortcut may turn a negative zero into a positive one, nothing else), destroyed streams and bounds too."""
+    from bevy_firework_amd.system import ParticleSystem
+
+    rng0 = np.random.default_rng(31000 + case)
+    spawner = _spawner(rng0, scale=12.0, const_p=0.6)
+    for e in spawner.emission_settings:  # half of the cases: nothing spins
+        if case % 2 == 0:
+            e.initial_angular_velocity = S.RandVec3.constant((0.0, 0.0, 0.0))
+    if case % 2 == 0:
+        for p in spawner.particle_settings:
+            p.angular_acceleration = (0.0, 0.0, 0.0)
+    for p in spawner.particle_settings:
+        p.particles_destroyed = lambda dead: None
+    dts = [np.float32(x) for x in _steps(np.random.default_rng(32000 + case), 40)]
+    on_demand = any(e.emission_pacing.kind == S.PACING_ONDEMAND for e in spawner.emission_settings)
+    results = {}
+    for name, env in (("shortcuts", {"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_NOSPIN": "1"}),
+                      ("rings only", {"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_NOSPIN": "0"}),
+                      ("no planes only", {"FW_FIFO": "0", "FW_NOSPIN": "1"}),
+                      ("plain", {"FW_FIFO": "0", "FW_NOSPIN": "0", "FW_FIFO_STREAM": "0"})):
+        for k in ("FW_FIFO", "FW_FIFO_MIN", "FW_NOSPIN", "FW_FIFO_STREAM"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with ParticleSystem(device=0, seed=SEED) as system:
+            h = system.spawn(spawner, S.Transform((0.5, 1.0, -0.5)), uid=900 + case)
+            dead_total = 0
+            for i, dt in enumerate(dts):
+                if on_demand and i % 5 == 0:
+                    h.queue_particles(20000)
+                system.update(dt)
+                dead_total += sum(len(h.destroyed(t)) for t in range(len(spawner.particle_settings)))
+            results[name] = ([h.particles(t) for t in range(len(spawner.particle_settings))], h.aabb(), dead_total)
+    ref_parts, ref_box, ref_dead = results["plain"]
+    for name in ("shortcuts", "rings only", "no planes only"):
+        parts, box, dead = results[name]
+        assert dead == ref_dead, (name, dead, ref_dead)
+        for t, (a, b) in enumerate(zip(parts, ref_parts)):
+            assert len(a) == len(b), (name, t, len(a), len(b))
+            for f in a.dtype.names:
+                assert np.array_equal(a[f], b[f], equal_nan=True) if a[f].dtype.kind == "f" else np.array_equal(a[f], b[f]), (name, t, f)
+        assert box[0] == ref_box[0] and np.array_equal(box[1], ref_box[1]) and np.array_equal(box[2], ref_box[2]), name
+    test_every_shortcut_gives_the_state_of_the_plain_path.sizes[case] = sum(len(p) for p in ref_parts)
+
+
+test_every_shortcut_gives_the_state_of_the_plain_path.sizes = {}
