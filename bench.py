@@ -256,6 +256,25 @@ def main():
                                                      "configs[2]: 256 emitters x 65 536 live (16.8M particles)")
             extras["hbm_resident"]["whole_step_particles_per_s"] = whole
             extras["hbm_resident"]["whole_step_ms"] = el / 100 * 1e3
+            # ... and with every plane kept (FW_NOSPIN=0: what the kernel moved before planes that cannot change were elided;
+            # the knob is read when a context is created)
+        saved_nospin = os.environ.get("FW_NOSPIN")
+        os.environ["FW_NOSPIN"] = "0"
+        try:
+            with ParticleSystem(device=local_rank, seed=workloads.SEED, stream=stream.cuda_stream) as p2b:
+                for e, (s_, tf_) in enumerate(workloads.many_emitters(256, 65536)):
+                    p2b.spawn(s_, tf_, uid=e)
+                p2b.update(dt)
+                for _ in range(76 + 20):
+                    p2b.step(dt)
+                torch.cuda.synchronize()
+                extras["hbm_resident"]["with_every_plane_kept"] = kernel_roofline(
+                    p2b, lambda k: p2b.step(dt), 60, "configs[2] with FW_NOSPIN=0: rotation and angular-velocity planes kept")
+        finally:
+            if saved_nospin is None:
+                del os.environ["FW_NOSPIN"]
+            else:
+                os.environ["FW_NOSPIN"] = saved_nospin
         # (b') the ring path far beyond the Infinity Cache: configs[1]'s emitter at 16x the rate (16.4M particles in one ring)
         with ParticleSystem(device=local_rank, seed=workloads.SEED, stream=stream.cuda_stream) as p3:
             s_, tf_ = workloads.one_million(rate=16.0 * args.rate)
