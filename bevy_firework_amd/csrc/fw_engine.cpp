@@ -623,6 +623,7 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
     fw_status st = refresh_counts_exact(ctx);
     if (st) return st;
     SegHost old = s;
+    if (s.fifo && ncap >= 0x40000000u) make_general = true;  // ring slots are computed in 32 bits: head + index < 2^32
     if (make_general && s.fifo) {
         s.fifo = false, s.fifo_mat = s.fifo_dev = false, s.coh.clear();
         ctx->n_fifo--;
@@ -661,6 +662,14 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
                               hipMemcpyDeviceToDevice));
     FW_HIP(ctx, hipFree(old.buf[0]));
     if (old.destroyed) FW_HIP(ctx, hipFree(old.destroyed));
+    if (old.fifo && !s.fifo) {
+        s.win_ok = false;  // no lifetime window was kept: the bound follows the snapshots from here on
+        if (s.nospin) {  // a ring keeps no lifetime plane (one value); the compacting kernels read it
+            FW_HIP(ctx, fw_launch_fill_plane1(ctx->stream, s.buf[0], s.buf[1], FW_OFF_L((size_t)s.capacity, s.n_lplanes), s.capacity,
+                                              s.fifo_life));
+            FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
     if ((st = upload_seg(ctx, si))) return st;
     return ensure_tile_arrays(ctx);
 }
@@ -677,16 +686,7 @@ fw_status grow_segment(fw_ctx *ctx, uint32_t si, uint32_t need) {
 // continues as an ordinary segment
 fw_status fifo_to_general(fw_ctx *ctx, uint32_t si) {
     if (!ctx->segs[si].fifo) return FW_OK;
-    fw_status st = realloc_segment(ctx, si, ctx->segs[si].capacity, true);
-    if (st) return st;
-    SegHost &s = ctx->segs[si];
-    s.win_ok = false;  // no lifetime window was kept: the bound follows the snapshots from here on
-    if (s.nospin) {  // a ring keeps no lifetime plane (one value); the compacting kernels read it
-        FW_HIP(ctx, fw_launch_fill_plane1(ctx->stream, s.buf[0], s.buf[1], FW_OFF_L((size_t)s.capacity, s.n_lplanes), s.capacity,
-                                          s.fifo_life));
-        FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    return FW_OK;
+    return realloc_segment(ctx, si, ctx->segs[si].capacity, true);
 }
 
 // A type stops being FW_TYPE_NOSPIN (the caller rewrites its particles, a non-finite dt is stepped): the rotation plane,
@@ -984,7 +984,8 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             }
             S.fifo = ctx->use_fifo && !self_nested && !mixed_feed && !S.collides && p.lifetime.min == p.lifetime.max &&
                      std::isfinite(p.lifetime.min) && ctx->n_fifo < kMaxFifoSegs &&
-                     caps[t] >= ctx->fifo_min && (!any_nested || ctx->fifo_nested);
+                     caps[t] >= ctx->fifo_min && caps[t] < 0x40000000u &&  // (head + index stays far from 2^32)
+                     (!any_nested || ctx->fifo_nested);
             if (S.fifo) {
                 ctx->n_fifo++;
                 S.win_ok = false;
