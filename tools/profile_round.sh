@@ -12,6 +12,7 @@ python profiles/analyze_trace.py $OUT/${TAG}_stats_kernel_trace.csv 600 > $OUT/t
 # 3. PMC passes (own runs, kernel-trace only)
 ./tools/pmc.sh $OUT/pmc > /dev/null 2>&1
 python profiles/analyze_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
+./tools/pmc_configs.sh $OUT/pmc_cfg "c3 c4" > $OUT/pmc_configs.txt 2>&1; rm -rf $OUT/pmc_cfg   # traffic of configs[2] / configs[3]'s update kernels
 # 4. memory microbenchmarks (measured roofline of the kernel's load/store shape; copy sweep at 1 GiB)
 ./tools/membw 64 > $OUT/membw.txt 2>&1
 ./tools/membw 1024 copy > $OUT/copy_sweep.txt 2>&1
