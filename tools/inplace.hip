@@ -47,6 +47,41 @@ __global__ __launch_bounds__(256) void k_upd(const char* __restrict__ in, char* 
     }
 }
 
+// the same update with a TILED layout: the seven planes of a tile's 1024 slots are contiguous (100 KB per tile), so a
+// workgroup reads and writes ONE region instead of seven streams 16 C bytes apart
+template <int RD, int WR>
+__global__ __launch_bounds__(256) void k_upd_tiled(const char* __restrict__ in, char* __restrict__ out, uint32_t n, int K) {
+    constexpr int R = 4;
+    const size_t tb = (size_t)blockIdx.x * 102400u;  // 1024 * 100 B
+    float4 q[4][R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t l = r * 256 + threadIdx.x;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            q[p][r] = make_float4(1.f, 2.f, 3.f, 4.f);
+            if ((RD >> p & 1) && blockIdx.x * 1024u + l < n) q[p][r] = ((const float4*)(in + tb + (size_t)p * 16384u))[l];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t l = r * 256 + threadIdx.x;
+        if (blockIdx.x * 1024u + l < n) {
+            float4 a = q[0][r], b = q[1][r], c = q[2][r], d = q[3][r];
+            a.x = work(a.x + b.x, K);
+            float4 e = make_float4(a.x + b.x, a.y * c.y, d.z, a.w);
+            float4 f = make_float4(b.w, c.x, d.y, e.x);
+            if (WR & 1) ((float4*)(out + tb))[l] = a;
+            if (WR & 2) ((float4*)(out + tb + 16384u))[l] = b;
+            if (WR & 4) ((float4*)(out + tb + 32768u))[l] = c;
+            if (WR & 8) ((float4*)(out + tb + 49152u))[l] = d;
+            if (WR & 16) ((float4*)(out + tb + 65536u))[l] = e;
+            if (WR & 32) ((float4*)(out + tb + 81920u))[l] = f;
+            if (WR & 64) ((float*)(out + tb + 98304u))[l] = e.y;
+        }
+    }
+}
+
 template <typename F>
 double timeit(F f, int iters) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -71,6 +106,15 @@ int main() {
             t = timeit([&](int i) { char* a = (i & 1) ? p1 : p0; char* o = (inplace) ? a : ((i & 1) ? p0 : p1); \
                 hipLaunchKernelGGL((k_upd<4, RD, WR>), g, b, 0, 0, a, o, n, C, shift, K); }, 50); \
             printf("n=%8u K=%3d %-44s: %8.2f us  %7.1f GB/s moved\n", n, K, tag, t * 1e6, (double)(bytes) * n / t / 1e9);
+            t = timeit([&](int i) { char* a = (i & 1) ? p1 : p0; char* o = (i & 1) ? p0 : p1;
+                hipLaunchKernelGGL((k_upd_tiled<15, 127>), g, b, 0, 0, a, o, n, K); }, 50);
+            printf("n=%8u K=%3d %-44s: %8.2f us  %7.1f GB/s moved\n", n, K, "TILED layout, ping-pong r4 w7 (164 B)", t * 1e6, 164.0 * n / t / 1e9);
+            t = timeit([&](int i) { char* a = (i & 1) ? p1 : p0;
+                hipLaunchKernelGGL((k_upd_tiled<15, 127>), g, b, 0, 0, a, a, n, K); }, 50);
+            printf("n=%8u K=%3d %-44s: %8.2f us  %7.1f GB/s moved\n", n, K, "TILED layout, in place r4 w7 (164 B)", t * 1e6, 164.0 * n / t / 1e9);
+            t = timeit([&](int i) { char* a = (i & 1) ? p1 : p0;
+                hipLaunchKernelGGL((k_upd_tiled<3, 83>), g, b, 0, 0, a, a, n, K); }, 50);
+            printf("n=%8u K=%3d %-44s: %8.2f us  %7.1f GB/s moved\n", n, K, "TILED layout, in place r Q0 Q1 w Q0 Q1 Q5 S4 (84 B)", t * 1e6, 84.0 * n / t / 1e9);
             RUN(15, 127, false, 0u, 164, "ping-pong r4 w7 (164 B)")
             RUN(15, 127, false, 16667u, 164, "ping-pong shifted loads, aligned stores")
             for (uint32_t sh : {1u, 3u, 4u, 8u, 16667u}) {
