@@ -12,8 +12,13 @@ from bevy_firework_amd import workloads  # noqa: E402
 from bevy_firework_amd.system import ParticleSystem  # noqa: E402
 
 ps = ParticleSystem(seed=workloads.SEED)
-sp, tf = workloads.one_million()
-ps.spawn(sp, tf, uid=0)
+if os.environ.get("FW_TL_EMITTERS"):  # e.g. 2048x200: many small emitters instead of the one big one
+    n_em, per = (int(v) for v in os.environ["FW_TL_EMITTERS"].split("x"))
+    for e, (sp, tf) in enumerate(workloads.many_emitters(n_em, per)):
+        ps.spawn(sp, tf, uid=e)
+else:
+    sp, tf = workloads.one_million()
+    ps.spawn(sp, tf, uid=0)
 dt = np.float32(1 / 60)
 ps.update(dt)
 jitter = os.environ.get("FW_TL_JITTER") == "1"  # a dt that changes every frame (the look-back / death-threshold schedule)
