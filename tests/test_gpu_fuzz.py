@@ -3,6 +3,7 @@ emission entries per type, Nested entries, drag / acceleration, modifiers, trans
 HIP path against the CPU oracle through the C ABI.  Sizes are kept where the oracle finishes in about a second per case.
 Needs an MI355X."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ from parity import Pair
 
 pytestmark = pytest.mark.gpu
 SEED = 0x5EED
+EXTRA = int(os.environ.get("FW_FUZZ_EXTRA", "0"))  # more random cases than the committed suite runs (spare GPU time)
 
 
 def _curve(rng):
@@ -133,7 +135,7 @@ def _random_spawner_case(case, seed_base, const_p, sizes):
         sizes[case] = pair.gpu.counts()
 
 
-@pytest.mark.parametrize("case", list(range(40)) + [339])  # 339: OnDemand parents outgrow the derived capacity of their Nested children
+@pytest.mark.parametrize("case", list(range(40 + EXTRA)) + [339])  # 339: OnDemand parents outgrow the derived capacity of their Nested children
 def test_random_spawner_matches_the_oracle(case):
     _random_spawner_case(case, 1000, 0.2, test_random_spawner_matches_the_oracle.sizes)
 
@@ -141,7 +143,7 @@ def test_random_spawner_matches_the_oracle(case):
 test_random_spawner_matches_the_oracle.sizes = {}
 
 
-@pytest.mark.parametrize("case", range(30))
+@pytest.mark.parametrize("case", range(30 + EXTRA))
 def test_random_spawner_with_single_lifetimes_matches_the_oracle(case):
     """the same generator with nine types in ten on ONE lifetime value: rings that wrap and grow, rings of spawners with
     Nested entries (materialised spawns, children counted on the device), types that receive both kinds of particles
@@ -194,7 +196,7 @@ def test_random_multi_spawner_system(case):
         assert sum(sum(p.gpu.counts()) for p in pairs) > 5000
 
 
-@pytest.mark.parametrize("case", range(12))
+@pytest.mark.parametrize("case", range(12 + EXTRA // 4))
 def test_random_scenario_with_api_calls_between_frames(case):
     """the calls a host makes between frames -- moving the origin, parent velocity, modifier, queueing, rewriting the
     particles, the destroyed-particle stream, AABB and instance reads, attaching an instance buffer -- in random order
@@ -202,7 +204,7 @@ def test_random_scenario_with_api_calls_between_frames(case):
     _api_scenario(case, 9000, 0.2)
 
 
-@pytest.mark.parametrize("case", range(12))
+@pytest.mark.parametrize("case", range(12 + EXTRA // 4))
 def test_random_scenario_with_api_calls_on_single_lifetime_types(case):
     """... with nine types in ten on one lifetime value (rings; a rewritten type continues on the general path)"""
     _api_scenario(case, 23000, 0.9)
