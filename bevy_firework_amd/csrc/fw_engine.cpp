@@ -83,6 +83,8 @@ struct alignas(64) SegHost {
     uint32_t ub = 0;            // upper bound of the device count (after this frame's spawns)
     uint32_t frame_spawn = 0;   // Global particles appended this frame
     uint32_t dev_count = 0;     // nested_fed: live count of the latest snapshot row (growth trigger)
+    uint32_t snap_count = 0;    // nested_fed: ... the same count, kept together with
+    uint64_t snap_cum = 0;      //   cum_spawn of the frame that row describes: Global particles since then are host-known
     uint64_t cum_spawn = 0;     // Global particles ever appended (host-known)
     uint64_t win_sum = 0;
     double life_bound = 0.0;
@@ -113,6 +115,7 @@ struct alignas(64) SegHost {
         Spawned &front() { return v[head]; }
         Spawned &back() { return v[(head + n - 1) & (uint32_t)(v.size() - 1)]; }
         void pop_front() { head = (head + 1) & (uint32_t)(v.size() - 1), n--; }
+        void pop_back() { n--; }
         void push_back(const Spawned &x) {
             if (n == v.size()) {  // grow to the next power of two, oldest entry first
                 std::vector<Spawned> w(v.empty() ? 64 : v.size() * 2);
@@ -185,6 +188,13 @@ struct FwLevel {  // ops of one emission index (spawn order inside a frame: core
 struct fw_ctx {
     FwLevel levels[FW_MAX_EMISSIONS];  // per-frame scratch of fw_step
     std::vector<FwOp> ops_scratch;
+    std::vector<uint32_t> grow_scratch;  // fw_step: Nested-fed segments past half their capacity
+    // device staging of the record-format copies (read_particles / write_particles / pack_instances): ONE allocation that
+    // only ever grows, instead of a hipMalloc + hipFree pair per call (each a device-wide synchronisation and an address-
+    // space change; profiles/r02/shared_gpu.txt)
+    void *d_stage = nullptr;
+    size_t stage_bytes = 0;
+    bool seg_kind_changed = false;       // a ring left its mode inside the current fw_step (realloc_segment)
     // undo log of fw_step's host half: spawn_particles is all-or-nothing per frame in the reference, so a frame that
     // cannot be enqueued (limit exceeded, allocation failure) must leave clocks, queues and RNG serials untouched
     struct EmUndo {
@@ -313,6 +323,7 @@ struct fw_ctx {
 
     uint32_t nest_seq = 0;  // launches of fw_k_nest so far (tag of their look-back words)
     // FW_HOST_PROF=1: time spent in the sections of fw_step's host half (printed when the context is destroyed)
+    bool trace = false;  // FW_TRACE
     bool host_prof = false;
     uint64_t host_prof_skip = 0;  // FW_HOST_PROF=n (n > 1): frames to skip first (fill, table uploads)
     double prof_ns[10] = {};
@@ -463,10 +474,9 @@ uint32_t seg_tiles(const SegHost &s, uint32_t vt_rounds = 1) {
     return std::max<uint32_t>(1, seg_live_tiles(s) + (s.frame_spawn + vtile - 1) / vtile + 1);
 }
 
-// Size of the new-particle tiles for this frame: the smallest (most parallel) of 1 or 2 rounds for which all
-// ACTIVE tiles of the frame are resident at once (kResidentSlots workgroups: 4 per CU); a second, nearly
-// empty round of workgroups would cost a full tile lifetime.
-uint32_t choose_vt_rounds(const fw_ctx *ctx);
+// (size of the new-particle tiles of a frame, update_tile_table: the smallest -- most parallel -- of 1 or 2 rounds for
+// which all ACTIVE tiles of the frame are resident at once (kResidentSlots workgroups: 4 per CU); a second, nearly
+// empty round of workgroups would cost a full tile lifetime)
 
 // tile scratch sized for every segment at full capacity
 fw_status ensure_tile_arrays(fw_ctx *ctx) {
@@ -628,6 +638,7 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
         s.fifo = false, s.fifo_mat = s.fifo_dev = false, s.coh.clear();
         ctx->n_fifo--;
         ctx->tab_force = true;
+        ctx->seg_kind_changed = true;
     }
     st = alloc_seg_buffers(ctx, s, ncap, old.destroyed != nullptr);
     if (st) {
@@ -1096,30 +1107,25 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
     return FW_OK;
 }
 
-uint32_t choose_vt_rounds(const fw_ctx *ctx) {
-    // at most FW_TILE / 2: Q1/Q2 of new particles live in the upper half of the LDS planes
-    uint64_t act1 = 0, act2 = 0;
-    for (const SegHost &S : ctx->segs) {
-        if (!S.in_use || S.fifo) continue;
-        const uint32_t live = seg_live_tiles(S);
-        act1 += live + (S.frame_spawn + FW_VTILE - 1) / FW_VTILE;
-        act2 += live + (S.frame_spawn + 2 * FW_VTILE - 1) / (2 * FW_VTILE);
-        if (act2 > kResidentSlots) return 1;  // neither size keeps the frame resident: the smaller (more parallel) one
-    }
-    return act1 <= kResidentSlots ? 1 : 2;
-}
 
 // The update grid covers ceil(bound / FW_TILE) tiles per segment, where `bound` is the host's upper
 // bound of the live count.  The table lives on the device and is re-sent only when a segment's
 // need leaves the band [need, need * 5/4 + 8], so steady-state frames upload nothing.
 fw_status update_tile_table(fw_ctx *ctx) {
     const uint32_t n_seg = (uint32_t)ctx->segs.size();
-    ctx->vt_rounds = choose_vt_rounds(ctx);
     bool dirty = ctx->tiles_dev.size() != n_seg || ctx->tab_force;  // descriptors carry per-segment type indices
     ctx->tab_force = false;
     ctx->tiles_dev.resize(n_seg, 0);
+    // (the same pass picks the size of the new-particle tiles: one round of FW_VTILE, or two -- at most FW_TILE / 2, Q1/Q2
+    // of new particles live in the upper half of the LDS planes -- when only that keeps the whole frame resident)
+    uint64_t act1 = 0, act2 = 0;
     for (uint32_t i = 0; i < n_seg; i++) {
         const SegHost &S = ctx->segs[i];
+        if (S.in_use && !S.fifo) {
+            const uint32_t live = seg_live_tiles(S);
+            act1 += live + (S.frame_spawn + FW_VTILE - 1) / FW_VTILE;
+            act2 += live + (S.frame_spawn + 2 * FW_VTILE - 1) / (2 * FW_VTILE);
+        }
         // provision for one-round new-particle tiles whatever vt_rounds says: a lone segment picks its tile size on
         // the device from exact counts and may use the smaller tiles when the host, with looser bounds, would not
         const uint32_t need = seg_tiles(S, 1);
@@ -1137,7 +1143,9 @@ fw_status update_tile_table(fw_ctx *ctx) {
             dirty = true;
         }
     }
-    if (getenv("FW_TRACE"))
+    // neither size keeps the frame resident: the smaller (more parallel) one
+    ctx->vt_rounds = (act2 > kResidentSlots || act1 <= kResidentSlots) ? 1u : 2u;
+    if (ctx->trace)
         fprintf(stderr, "[fw] frame %llu tile table dirty=%d n_seg=%u have0=%u ub0=%u\n",
                 (unsigned long long)ctx->frame, (int)dirty, n_seg, n_seg ? ctx->tiles_dev[0] : 0u,
                 n_seg ? ctx->segs[0].ub : 0u);
@@ -1244,6 +1252,7 @@ void poll_snapshots(fw_ctx *ctx) {
             if (S.fifo && !S.fifo_dev) continue;  // the host's count is exact
             if (S.nested_fed) {
                 S.dev_count = (uint32_t)v;  // no host-side bound exists; the count only drives capacity growth
+                S.snap_count = (uint32_t)v, S.snap_cum = cum[i];
                 continue;
             }
             const uint64_t b = (uint64_t)(uint32_t)v + (S.cum_spawn - cum[i]);
@@ -1369,6 +1378,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_STATIC_NEW")) ctx->use_static_new = atoi(m) != 0;  // 0: always count + look back
     if (const char *m = getenv("FW_SNAP_EVERY")) ctx->snap_every = std::max(1, atoi(m));
     if (const char *m = getenv("FW_SPIN_LIMIT")) ctx->spin_limit = (uint32_t)strtoul(m, nullptr, 10);
+    ctx->trace = getenv("FW_TRACE") != nullptr;
     if (const char *m = getenv("FW_HOST_PROF")) ctx->host_prof = atoi(m) != 0, ctx->host_prof_skip = atoi(m) > 1 ? (uint64_t)atoi(m) : 0;
     if (ensure_max_seg(ctx, 1024) != FW_OK) {
         g_create_error = ctx->err;
@@ -1401,7 +1411,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
                      ctx->g.ndestroyed,   ctx->g.tile_cnt,      ctx->g.tile_off,      ctx->g.tile_status,
                      ctx->g.err,          ctx->g.stats,         ctx->g.nest_status,   ctx->g.nest_ticket,
                      ctx->d_aabb,         ctx->d_total,         ctx->d_segids,        ctx->g.dbg_ts,
-                     ctx->d_colliders,   ctx->g.tile_box};
+                     ctx->d_colliders,   ctx->g.tile_box,      ctx->d_stage};
     for (void *p : frees)
         if (p) hipFree(p);
     for (int i = 0; i < kParamRing; i++) {
@@ -1600,6 +1610,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     auto &levels = ctx->levels;
     for (auto &L : levels) L.g.clear(), L.n.clear();
     ctx->fifo_ops.clear(), ctx->fifo_mat_ops.clear();
+    ctx->seg_kind_changed = false;
     if (!std::isfinite(dt))  // 0 * inf = NaN: an angular velocity of zero does not stay zero (core.rs:648-650)
         for (uint32_t si = 0; si < ctx->segs.size(); si++)
             if (ctx->segs[si].in_use && ctx->segs[si].nospin) {
@@ -1626,6 +1637,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // (ages are fp32 sums of the same dt values on the device; the margin covers the rounding difference)
     if (!(dt >= 0.0f) || !std::isfinite(dt))
         for (auto &S : ctx->segs) S.win_ok = false;  // ages would not grow monotonically
+    // (the same pass notes what the rest of the frame asks of every segment: which Nested-fed ones must grow, whether a
+    // particle type collides, whether a compacting segment has an instance buffer attached)
+    bool any_coll = false, any_inst_general = false;
+    ctx->grow_scratch.clear();
     for (size_t si = 0, ns = ctx->segs.size(); si < ns; si++) {
         SegHost &S = ctx->segs[si];
         if (si + 8 < ns) {  // the oldest window entry of a later segment: a heap line of its own, fetched ahead of time
@@ -1633,7 +1648,12 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             if (N.win.n) __builtin_prefetch(&N.win.v[N.win.head]);
         }
         S.frame_spawn = 0;
-        if (!S.in_use || !S.win_ok) continue;
+        if (!S.in_use) continue;
+        any_coll |= S.collides;
+        any_inst_general |= !S.fifo && S.inst != nullptr;
+        if (S.nested_fed && S.auto_capacity && S.dev_count > S.capacity / 2 && S.capacity < 0x70000000u)
+            ctx->grow_scratch.push_back((uint32_t)si);
+        if (!S.win_ok) continue;
         // an age is an fp32 running sum of the dt values: up to half an ulp of the age per step taken, i.e. a relative
         // error below steps * 6e-8; the horizon carries that (with a factor 4) on top of a fixed 1e-3
         while (!S.win.empty() &&
@@ -1649,8 +1669,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // they cannot grow exactly when needed the way Global-fed ones do (the reference's Vec::push, core.rs:523).  Their
     // derived capacity follows the live count seen in the snapshot rows instead: past half full, it doubles -- well
     // before the device-side clamp (FW_ECAPACITY) could drop a particle.  Caller-given capacities are left alone.
-    for (uint32_t si = 0; si < ctx->segs.size(); si++) {
+    for (uint32_t si : ctx->grow_scratch) {
         SegHost &S = ctx->segs[si];
+        // (growing one type's children may already have grown a later entry of the list)
         if (!S.in_use || !S.nested_fed || !S.auto_capacity || S.dev_count <= S.capacity / 2) continue;
         if (S.capacity >= 0x70000000u) continue;
         S.dev_count = 0;
@@ -1669,8 +1690,37 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             E.enabled = u.enabled, E.serial = u.serial;
         }
         for (const auto &u : ctx->undo_sp) ctx->spawners[u.spawner].manual_queued_count = u.manual_queued_count;
+        // the spawn totals and lifetime windows the ops of this frame were entered into (note_spawned below)
+        auto forget = [&](const FwOp &op) {
+            SegHost &S = ctx->segs[op.seg];
+            S.cum_spawn -= op.n;
+            if (S.fifo || !S.win_ok || S.win.empty() || S.win.back().t != ctx->sim_time) return;
+            S.win_sum -= op.n;
+            if ((S.win.back().n -= op.n) == 0) S.win.pop_back();
+        };
+        for (auto &L : ctx->levels)
+            for (const FwOp &op : L.g) forget(op);
+        for (const FwOp &op : ctx->fifo_ops) forget(op);
+        for (const auto &io : ctx->fifo_mat_ops) forget(io.second);
         for (auto &S : ctx->segs) S.ub -= std::min(S.ub, S.frame_spawn), S.frame_spawn = 0;
         return why;
+    };
+    // a Global op enters its segment's spawn total and lifetime window as it is made (the segment record is in the cache
+    // then; `rollback` takes it out again)
+    auto note_spawned = [&](SegHost &S, uint64_t n) {
+        S.cum_spawn += n;
+        if (S.fifo || !S.win_ok) return;
+        if (!S.win.empty() && S.win.back().t == ctx->sim_time) {
+            S.win.back().n += n;
+        } else {
+            if (S.win.size() >= 8192) {  // very long lifetimes: fold the two oldest entries into the newer
+                const uint64_t m = S.win.front().n;
+                S.win.pop_front();
+                S.win.front().n += m;
+            }
+            S.win.push_back(SegHost::Spawned{ctx->sim_time, n, ctx->frame});
+        }
+        S.win_sum += n;
     };
 
     prof(0);
@@ -1718,6 +1768,24 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 if (n > kMaxSpawnPerOp)
                     return rollback(fail(ctx, FW_ECAPACITY, "emission count exceeds 2^30 particles in one frame"));
                 SegHost &S = ctx->segs[dst];
+                if (S.nested_fed && S.auto_capacity && S.capacity < 0x70000000u) {
+                    // A type that receives Nested children too: its children are counted on the device, but its Global
+                    // particles are counted right here.  Count of the latest snapshot row + every Global particle since
+                    // (at most those the lifetime window still holds) + this op: past half the capacity, the segment grows
+                    // NOW, however fast the burst -- the snapshot rule above only follows what the device has seen.
+                    uint64_t since = S.cum_spawn - S.snap_cum;  // (includes this frame's earlier ops: note_spawned)
+                    if (S.win_ok) since = std::min<uint64_t>(since, S.win_sum);
+                    const uint64_t est = (uint64_t)S.snap_count + since + n;
+                    if (est > S.capacity / 2) {
+                        fw_status st = grow_segment(ctx, dst, (uint32_t)std::min<uint64_t>(est * 2, 0x70000000ull));
+                        if (!st) st = grow_nested_children(ctx, sp, (uint32_t)es.particle_index);
+                        // (the growth refreshed every bound from the device's exact counts, without this frame's appends)
+                        for (auto &X : ctx->segs) X.ub += X.frame_spawn;
+                        if (st) return rollback(st);
+                        S.snap_count = S.ub - std::min(S.ub, S.frame_spawn), S.snap_cum = S.cum_spawn - S.frame_spawn;
+                        S.dev_count = 0;
+                    }
+                }
                 if (!S.nested_fed && (uint64_t)S.ub + n > S.capacity) {
                     fw_status st = refresh_counts_exact(ctx);
                     if (st) return rollback(st);
@@ -1756,7 +1824,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 E.serial += n;
                 S.frame_spawn += (uint32_t)n;
                 S.ub = (uint32_t)std::min<uint64_t>((uint64_t)S.ub + n, 0xFFFFFFFFull);
-                // (cum_spawn and the lifetime window are committed below, once nothing can fail any more)
+                note_spawned(S, n);
             } else {
                 if (es.pacing_kind != FW_PACING_COUNT_OVER_DURATION) continue;  // warn_once + continue core.rs:474-485
                 const SegHost &P = ctx->segs[sp.seg[es.target_particle_type]];
@@ -1809,37 +1877,11 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     if ((st = ensure_param_ring(ctx, round_up((n_seg + 1) * sizeof(uint32_t), 16) + n_g * sizeof(FwOp) +
                                          n_n * sizeof(FwNestOp) + 16)))
         return rollback(st);
-    // ---- commit: the frame will run
-    for (auto &L : levels)
-        for (size_t oi = 0, no = L.g.size(); oi < no; oi++) {
-            const FwOp &op = L.g[oi];
-            if (oi + 8 < no) {
-                const SegHost &N = ctx->segs[L.g[oi + 8].seg];
-                if (!N.win.v.empty()) __builtin_prefetch(&N.win.v[(N.win.head + N.win.n) & (uint32_t)(N.win.v.size() - 1)]);
-            }
-            SegHost &S = ctx->segs[op.seg];
-            const uint64_t n = op.n;
-            S.cum_spawn += n;
-            if (!S.win_ok) continue;
-            if (!S.win.empty() && S.win.back().t == ctx->sim_time) {
-                S.win.back().n += n;
-            } else {
-                if (S.win.size() >= 8192) {  // very long lifetimes: fold the two oldest entries into the newer
-                    const uint64_t m = S.win.front().n;
-                    S.win.pop_front();
-                    S.win.front().n += m;
-                }
-                S.win.push_back(SegHost::Spawned{ctx->sim_time, n, ctx->frame});
-            }
-            S.win_sum += n;
-        }
-    for (const FwOp &op : ctx->fifo_ops) ctx->segs[op.seg].cum_spawn += op.n;
+    // ---- the frame will run
     prof(3);
     const uint32_t p = ctx->parity;
     // Particle types with collision settings (core.rs:607-624) run the count / scan / update-with-collisions launches
     // (everything materialised first, like FW_UPDATE_MODE=split); the streaming kernels never see a collider.
-    bool any_coll = false;
-    for (const SegHost &S : ctx->segs) any_coll |= S.in_use && S.collides;
     const int frame_mode = any_coll ? FW_MODE_SPLIT_COLL : ctx->update_mode;
     const bool legacy = n_n != 0 || frame_mode != FW_MODE_FUSED;
 
@@ -1874,7 +1916,11 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     a.new_static = (new_static && ctx->use_static_new) ? 1u : 0u;
     a.boxes = (ctx->track_aabb && frame_mode == FW_MODE_FUSED) ? 1u : 0u;
     a.force_colors = ctx->colors_dirty ? 1u : 0u;
-    for (const SegHost &S : ctx->segs) a.any_inst |= (S.in_use && !S.fifo && S.inst != nullptr) ? 1u : 0u;
+    // (a ring that had to grow past the ring limit during this frame's spawner loop continues as a compacting segment:
+    // look again -- never in a steady-state frame)
+    if (ctx->seg_kind_changed)
+        for (const SegHost &S : ctx->segs) any_inst_general |= S.in_use && !S.fifo && S.inst != nullptr;
+    a.any_inst = any_inst_general ? 1u : 0u;
     a.use_stream = ctx->use_stream ? 1u : 0u;
     uint32_t dt_bits;
     memcpy(&dt_bits, &dt, 4);
@@ -2006,10 +2052,18 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     } else {
         // Global-only frame: spawn is fused into the update kernel (virtual particles).  Ops sorted by segment;
         // the order inside a segment stays the emission order (rel_base was assigned in that order).
-        std::vector<FwOp> &ops = ctx->ops_scratch;
-        ops.clear();
-        ops.reserve(n_g);
-        for (auto &L : levels) ops.insert(ops.end(), L.g.begin(), L.g.end());
+        // (one emission level holds all of them most of the time: its list is used as it is)
+        std::vector<FwOp> *one = nullptr;
+        size_t n_lists = 0;
+        for (auto &L : levels)
+            if (!L.g.empty()) one = &L.g, n_lists++;
+        if (n_lists != 1) {
+            one = &ctx->ops_scratch;
+            one->clear();
+            one->reserve(n_g);
+            for (auto &L : levels) one->insert(one->end(), L.g.begin(), L.g.end());
+        }
+        std::vector<FwOp> &ops = *one;
         // sorted by segment, emission order kept inside a segment; a single emission level is already in spawner
         // (= segment creation) order most of the time: skip the sort then
         if (!std::is_sorted(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; }))
@@ -2267,6 +2321,20 @@ fw_status fw_spawner_poll_finished(fw_ctx *ctx, fw_spawner h, int32_t *out) {
     return st;
 }
 
+static fw_status stage_buffer(fw_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->stage_bytes) {
+        fw_status st = sync(ctx);
+        if (st) return st;
+        if (ctx->d_stage) FW_HIP(ctx, hipFree(ctx->d_stage));
+        ctx->d_stage = nullptr, ctx->stage_bytes = 0;
+        const size_t nb = (std::max<size_t>(bytes + bytes / 4, (size_t)1 << 20) + 65535u) & ~(size_t)65535u;
+        FW_HIP(ctx, hipMalloc(&ctx->d_stage, nb));
+        ctx->stage_bytes = nb;
+    }
+    *out = ctx->d_stage;
+    return FW_OK;
+}
+
 static fw_status read_records(fw_ctx *ctx, const char *buf, uint32_t cap_seg, uint32_t n, int32_t pbr, bool aos,
                               fw_particle *out, uint64_t cap, uint32_t head = 0, const float *const_rot = nullptr,
                               uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.f) {
@@ -2277,11 +2345,12 @@ static fw_status read_records(fw_ctx *ctx, const char *buf, uint32_t cap_seg, ui
         return FW_OK;
     }
     void *tmp = nullptr;
-    FW_HIP(ctx, hipMalloc(&tmp, m * sizeof(fw_particle)));
+    fw_status st = stage_buffer(ctx, m * sizeof(fw_particle), &tmp);
+    if (st) return st;
     hipError_t e = fw_launch_gather(ctx->stream, buf, cap_seg, head, (uint32_t)m, pbr, tmp, const_rot, life_plane, life_const);
+    // (the copy goes through the stream the kernel ran on, then one wait for both)
+    if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, m * sizeof(fw_particle), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipMemcpy(out, tmp, m * sizeof(fw_particle), hipMemcpyDeviceToHost);
-    hipFree(tmp);
     FW_HIP(ctx, e);
     return FW_OK;
 }
@@ -2350,11 +2419,10 @@ fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, c
     SegHost &S = ctx->segs[si];
     if (n) {
         void *tmp = nullptr;
-        FW_HIP(ctx, hipMalloc(&tmp, n * sizeof(fw_particle)));
-        hipError_t e = hipMemcpy(tmp, in, n * sizeof(fw_particle), hipMemcpyHostToDevice);
+        if ((st = stage_buffer(ctx, n * sizeof(fw_particle), &tmp))) return st;
+        hipError_t e = hipMemcpyAsync(tmp, in, n * sizeof(fw_particle), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = fw_launch_scatter(ctx->stream, S.buf[ctx->parity], S.capacity, (uint32_t)n, S.n_lplanes, tmp);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        hipFree(tmp);
         FW_HIP(ctx, e);
     }
     const uint32_t n32 = (uint32_t)n;
@@ -2444,12 +2512,12 @@ fw_status fw_spawner_pack_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
     const uint64_t m = std::min<uint64_t>(n, cap);
     if (!m || !out) return st;
     void *tmp = nullptr;
-    FW_HIP(ctx, hipMalloc(&tmp, m * sizeof(fw_particle_instance)));
+    fw_status sst = stage_buffer(ctx, m * sizeof(fw_particle_instance), &tmp);
+    if (sst) return sst;
     uint64_t ub = 0;
     fw_status st2 = fw_spawner_pack_instances_device(ctx, h, type, tmp, m, &ub);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipMemcpy(out, tmp, m * sizeof(fw_particle_instance), hipMemcpyDeviceToHost);
-    hipFree(tmp);
+    hipError_t e = hipMemcpyAsync(out, tmp, m * sizeof(fw_particle_instance), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     FW_HIP(ctx, e);
     return st2 ? st2 : st;
 }

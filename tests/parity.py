@@ -34,14 +34,27 @@ def trig_field_errors(got: np.ndarray, want: np.ndarray):
     return ok, worst
 
 
+def _where(got: np.ndarray, want: np.ndarray) -> str:
+    """which particles of a field differ (for the assertion message)"""
+    bad = got != want
+    if bad.ndim > 1:
+        bad = bad.reshape(len(bad), -1).any(axis=1)
+    idx = np.flatnonzero(bad)
+    if not len(idx):
+        return "no element differs (NaN?)"
+    i = int(idx[0])
+    return (f"{len(idx)} of {len(bad)} particles differ, indices {i}..{int(idx[-1])}; first: got {got[i]!r} want {want[i]!r}"
+            + (f"; got[{i + 1}] {got[i + 1]!r} want[{i + 1}] {want[i + 1]!r}" if i + 1 < len(bad) else ""))
+
+
 def assert_particles_match(gpu: np.ndarray, cpu: np.ndarray, exact_all: bool = False, what: str = ""):
     assert len(gpu) == len(cpu), f"{what}: count {len(gpu)} != expected {len(cpu)}"
     for f in EXACT_FIELDS:
         if f in cpu.dtype.names:
-            assert np.array_equal(gpu[f], cpu[f]), f"{what}: field {f} not bit-exact"
+            assert np.array_equal(gpu[f], cpu[f]), f"{what}: field {f} not bit-exact: {_where(gpu[f], cpu[f])}"
     for f in TRIG_FIELDS:
         if exact_all:
-            assert np.array_equal(gpu[f], cpu[f]), f"{what}: field {f} not bit-exact"
+            assert np.array_equal(gpu[f], cpu[f]), f"{what}: field {f} not bit-exact: {_where(gpu[f], cpu[f])}"
         elif len(cpu):
             ok, worst = trig_field_errors(gpu[f], cpu[f])
             assert ok.all(), (f"{what}: field {f}: {np.count_nonzero(~ok)} elements outside rtol {RTOL} + atol {ATOL} "
@@ -72,7 +85,25 @@ class Pair:
     def check(self, exact_all=False, what=""):
         assert self.gpu.counts() == self.cpu.counts(), f"{what}: counts {self.gpu.counts()} != {self.cpu.counts()}"
         for t in range(self.n_types):
-            assert_particles_match(self.gpu.particles(t), self.cpu.particles(t), exact_all, f"{what} type {t}")
+            try:
+                assert_particles_match(self.gpu.particles(t), self.cpu.particles(t), exact_all, f"{what} type {t}")
+            except AssertionError as e:
+                # read the same state again: a second read that matches says the first READ was wrong, not the state
+                try:
+                    assert_particles_match(self.gpu.particles(t), self.cpu.particles(t), exact_all, "")
+                    again = "a SECOND read of the same state matches"
+                except AssertionError as e2:
+                    again = f"a second read differs too: {str(e2)[:160]}"
+                g, c = self.gpu.particles(t), self.cpu.particles(t)
+                per_field = {}
+                if len(g) == len(c):
+                    for f in c.dtype.names:
+                        bad = g[f] != c[f]
+                        if bad.ndim > 1:
+                            bad = bad.reshape(len(bad), -1).any(axis=1)
+                        per_field[f] = int(np.count_nonzero(bad))
+                raise AssertionError(f"{e} [{again}; path {self.gpu.update_path(t)}; a third read, differing particles per field "
+                                     f"(not bit-equal; trig fields differ legitimately): {per_field}]") from None
 
 
 # ---- golden trajectories ---------------------------------------------------------------------------------------

@@ -143,7 +143,7 @@ def test_random_spawner_matches_the_oracle(case):
 test_random_spawner_matches_the_oracle.sizes = {}
 
 
-@pytest.mark.parametrize("case", range(30 + EXTRA))
+@pytest.mark.parametrize("case", list(range(30 + EXTRA)) + ([1100] if EXTRA <= 1070 else []))  # 1100: a 17k-per-frame Global burst into a type that also receives Nested children
 def test_random_spawner_with_single_lifetimes_matches_the_oracle(case):
     """the same generator with nine types in ten on ONE lifetime value: rings that wrap and grow, rings of spawners with
     Nested entries (materialised spawns, children counted on the device), types that receive both kinds of particles
@@ -269,7 +269,12 @@ def _api_scenario(case, seed_base, const_p):
                     n = min(pair.gpu.count(0), 60000)
                     ref = pair.gpu.instances(0)[:n]
                     got = buf[: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
-                    assert np.array_equal(got, ref.view(np.uint32).reshape(n, 16)), f"case {case} frame {i}: instance records"
+                    want = ref.view(np.uint32).reshape(n, 16)
+                    if not np.array_equal(got, want):
+                        rows = np.flatnonzero((got != want).any(axis=1))
+                        raise AssertionError(f"case {case} frame {i}: instance records: {len(rows)} of {n} differ, rows "
+                                             f"{rows[0]}..{rows[-1]}, first got {got[rows[0]].view(np.float32)} want "
+                                             f"{want[rows[0]].view(np.float32)}")
 
 
 @pytest.mark.parametrize("case", range(16))
