@@ -73,6 +73,7 @@ class Pair:
         if modifier is not None:
             self.cpu.set_modifier(modifier)
         self.spawner = spawner
+        self.cpu_transform = transform
         self.n_types = len(spawner.particle_settings)
 
     def queue(self, n):
