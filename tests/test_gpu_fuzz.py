@@ -430,3 +430,71 @@ def test_colliding_cases_were_not_trivial():
         pytest.skip("the colliding cases did not run in this session")
     assert sum(bool(v[2]) for v in checked) >= len(checked) // 2, sizes
     assert sum(v[0] for v in sizes.values()) > 20000 and sum(v[1] for v in sizes.values()) > 0, sizes
+
+
+@pytest.mark.parametrize("case", range(24 + EXTRA // 2))
+def test_random_nested_topologies(case):
+    """Nested entries in every arrangement the settings allow: chains (smoke on sparks on seeds), several Nested entries on one
+    parent type (one last_emitted_age plane each), particles that emit onto their own type, a type that receives children from
+    two parent types and Global particles too -- and the entries in RANDOM order, so that a Nested entry may come before the
+    Global entry that feeds its parents (it then sees only the parents of earlier frames, core.rs:377-546 walks the entries in
+    index order).  Counts, order, ages and last_emitted_age bit for bit; small per-parent counts keep the population bounded."""
+    from bevy_firework_amd.system import ParticleSystem
+
+    rng = np.random.default_rng(51000 + case)
+    n_types = int(rng.integers(2, 4))
+    proto = _spawner(np.random.default_rng(52000 + case), scale=0.3, const_p=0.5 if case % 2 else 0.1)
+    types = []
+    for t in range(n_types):
+        p = proto.particle_settings[t % len(proto.particle_settings)]
+        lo = float(rng.uniform(0.15, 0.5))
+        types.append(S.ParticleSettings(
+            lifetime=S.RandF32.constant(lo) if rng.random() < (0.5 if case % 2 else 0.1) else S.RandF32(lo, float(lo + rng.uniform(0.0, 0.4))),
+            scale_curve=p.scale_curve, initial_scale=p.initial_scale, acceleration=p.acceleration,
+            angular_acceleration=p.angular_acceleration if rng.random() < 0.5 else (0.0, 0.0, 0.0), linear_drag=p.linear_drag,
+            angular_drag=p.angular_drag, base_color=p.base_color, emissive_color=p.emissive_color))
+    entries = [S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(float(rng.uniform(800.0, 4000.0))),
+                                  emission_shape=S.EmissionShape.Sphere(0.5), initial_velocity=_randvec(rng, 4.0),
+                                  initial_angular_velocity=_randvec(rng, 4.0) if rng.random() < 0.5 else S.RandVec3.constant((0.0, 0.0, 0.0)))]
+    if rng.random() < 0.4:  # a second Global entry somewhere (a type that gets both kinds of particles)
+        entries.append(S.EmissionSettings(particle_index=int(rng.integers(0, n_types)),
+                                          emission_pacing=_pacing(rng, 0.1), initial_velocity=_randvec(rng, 3.0)))
+    for _ in range(int(rng.integers(1, 5))):
+        child, parent = int(rng.integers(0, n_types)), int(rng.integers(0, n_types))
+        loop = child <= parent  # own type or back up the chain: keep the offspring below one per parent life
+        a, b = sorted(rng.uniform(0.0, 1.0, size=2))
+        if b - a < 0.1:
+            a, b = 0.0, float(rng.uniform(0.3, 1.0))
+        entries.append(S.EmissionSettings(
+            particle_index=child, emission_mode=S.EmissionMode.Nested(parent),
+            emission_pacing=S.EmissionPacing.CountOverDuration(float(rng.uniform(0.3, 0.9) if loop else rng.uniform(1.0, 5.0)), 1.0, float(a), float(b)),
+            inherit_parent_velocity=bool(rng.random() < 0.5), initial_velocity=_randvec(rng, 2.0),
+            emission_shape=S.EmissionShape.Point() if rng.random() < 0.5 else S.EmissionShape.Sphere(0.2)))
+    order = rng.permutation(len(entries))
+    entries = [entries[k] for k in order]
+    with ParticleSystem(device=0, seed=SEED) as system:
+        pair = Pair(system, S.ParticleSpawner(types, entries), S.Transform(tuple(float(c) for c in rng.uniform(-1.0, 1.0, size=3))),
+                    seed=SEED, uid=800 + case)
+        for i, dt in enumerate(_steps(rng, 48)):
+            dt = np.float32(dt)
+            system.update(dt)
+            pair.step_cpu(dt)
+            if i % 8 == 7:
+                pair.check(what=f"case {case} frame {i}")
+                for k, e in enumerate(entries):
+                    if e.emission_mode.kind == S.MODE_NESTED:
+                        t = e.emission_mode.target_particle_type
+                        assert np.array_equal(pair.gpu.last_emitted(t, k), pair.cpu.last_emitted(t, k)), f"case {case} frame {i}: last_emitted_age[{k}] of type {t}"
+        test_random_nested_topologies.sizes[case] = pair.gpu.counts()
+
+
+test_random_nested_topologies.sizes = {}
+
+
+def test_nested_topology_cases_were_not_trivial():
+    sizes = test_random_nested_topologies.sizes
+    if len(sizes) < 24:
+        pytest.skip("the topology cases did not run in this session")
+    totals = [sum(c) for c in sizes.values()]
+    children = [sum(c[1:]) for c in sizes.values()]
+    assert sum(t > 1000 for t in totals) >= len(totals) // 2 and sum(c > 300 for c in children) >= len(children) // 3, sizes
