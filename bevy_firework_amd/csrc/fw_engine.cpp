@@ -30,6 +30,16 @@
 
 namespace {
 
+// hipMemset runs on the null stream and may return before the fill has happened; the streams of a context are
+// non-blocking ones, which the null stream does not order itself against: a kernel enqueued right after would race the fill
+// (seen with two processes on the GPU: a fresh context's first frames read the forecast entries a previous context had left
+// in the recycled allocation).  Every fill of this file is part of an allocation (rare): wait for it.
+hipError_t fw_memset_done(void *p, int v, size_t bytes) {
+    hipError_t e = hipMemset(p, v, bytes);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    return e;
+}
+
 constexpr int kParamRing = 8;    // per-frame parameter buffers in flight
 constexpr int kSnapRing = 8;     // live-count snapshots in flight
 constexpr int kSnapEvery = 4;    // frames between snapshots
@@ -377,7 +387,7 @@ fw_status dev_reserve(fw_ctx *ctx, DevArray<T> &a, size_t need, size_t used) {
     size_t ncap = std::max<size_t>(need, a.cap * 2 + 64);
     T *nd = nullptr;
     FW_HIP(ctx, hipMalloc((void **)&nd, ncap * sizeof(T)));
-    FW_HIP(ctx, hipMemset(nd, 0, ncap * sizeof(T)));
+    FW_HIP(ctx, fw_memset_done(nd, 0, ncap * sizeof(T)));
     if (a.d && used) FW_HIP(ctx, hipMemcpy(nd, a.d, used * sizeof(T), hipMemcpyDeviceToDevice));
     if (a.d) FW_HIP(ctx, hipFree(a.d));
     a.d = nd;
@@ -416,7 +426,7 @@ fw_status ensure_max_seg(fw_ctx *ctx, uint32_t need) {
     auto regrow2 = [&](uint32_t *&p) -> fw_status {
         uint32_t *np = nullptr;
         FW_HIP(ctx, hipMalloc((void **)&np, 2ull * nmax * sizeof(uint32_t)));
-        FW_HIP(ctx, hipMemset(np, 0, 2ull * nmax * sizeof(uint32_t)));
+        FW_HIP(ctx, fw_memset_done(np, 0, 2ull * nmax * sizeof(uint32_t)));
         if (p) {
             for (int r = 0; r < 2; r++)
                 FW_HIP(ctx, hipMemcpy(np + (size_t)r * nmax, p + (size_t)r * ctx->max_seg,
@@ -432,7 +442,7 @@ fw_status ensure_max_seg(fw_ctx *ctx, uint32_t need) {
     {
         uint32_t *np = nullptr;
         FW_HIP(ctx, hipMalloc((void **)&np, (size_t)nmax * sizeof(uint32_t)));
-        FW_HIP(ctx, hipMemset(np, 0, (size_t)nmax * sizeof(uint32_t)));
+        FW_HIP(ctx, fw_memset_done(np, 0, (size_t)nmax * sizeof(uint32_t)));
         if (ctx->g.ndestroyed) {
             FW_HIP(ctx, hipMemcpy(np, ctx->g.ndestroyed, ctx->max_seg * sizeof(uint32_t), hipMemcpyDeviceToDevice));
             FW_HIP(ctx, hipFree(ctx->g.ndestroyed));
@@ -499,21 +509,21 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_cnt, ncap * sizeof(uint32_t)));
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_off, ncap * sizeof(uint32_t)));
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_status, ncap * sizeof(unsigned long long)));
-        FW_HIP(ctx, hipMemset(ctx->g.tile_status, 0, ncap * sizeof(unsigned long long)));
+        FW_HIP(ctx, fw_memset_done(ctx->g.tile_status, 0, ncap * sizeof(unsigned long long)));
         if (ctx->g.tile_box) hipFree(ctx->g.tile_box);
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.tile_box, ncap * 8 * sizeof(float)));
-        FW_HIP(ctx, hipMemset(ctx->g.tile_box, 0, ncap * 8 * sizeof(float)));
+        FW_HIP(ctx, fw_memset_done(ctx->g.tile_box, 0, ncap * 8 * sizeof(float)));
         ctx->boxes_epoch = 0;
         if (ctx->g.dbg_ts) hipFree(ctx->g.dbg_ts);
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.dbg_ts, (32768 + 8 * ncap) * sizeof(unsigned long long)));
-        FW_HIP(ctx, hipMemset(ctx->g.dbg_ts, 0, (32768 + 8 * ncap) * sizeof(unsigned long long)));
+        FW_HIP(ctx, fw_memset_done(ctx->g.dbg_ts, 0, (32768 + 8 * ncap) * sizeof(unsigned long long)));
         if (ctx->d_fce) hipFree(ctx->d_fce);
         FW_HIP(ctx, hipMalloc((void **)&ctx->d_fce, 2 * ncap * sizeof(uint4)));
-        FW_HIP(ctx, hipMemset(ctx->d_fce, 0, 2 * ncap * sizeof(uint4)));
+        FW_HIP(ctx, fw_memset_done(ctx->d_fce, 0, 2 * ncap * sizeof(uint4)));
         if (ctx->d_fc) hipFree(ctx->d_fc);
         ctx->fc_len = ncap + (ncap / 64 + 2) * FW_FC_S2_STRIDE + 8;  // P | P2 | tag (64-bit words)
         FW_HIP(ctx, hipMalloc((void **)&ctx->d_fc, 3 * ctx->fc_len * sizeof(unsigned long long)));
-        FW_HIP(ctx, hipMemset(ctx->d_fc, 0, 3 * ctx->fc_len * sizeof(unsigned long long)));
+        FW_HIP(ctx, fw_memset_done(ctx->d_fc, 0, 3 * ctx->fc_len * sizeof(unsigned long long)));
         ctx->fc_ok = false, ctx->boxes_epoch = 0;
         ctx->fc_dirty = false;
         ctx->tiles_cap = ncap;
@@ -524,7 +534,7 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         size_t ncap = nest_tiles * 2;
         if (ctx->g.nest_status) hipFree(ctx->g.nest_status);
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_status, ncap * sizeof(unsigned long long)));
-        FW_HIP(ctx, hipMemset(ctx->g.nest_status, 0, ncap * sizeof(unsigned long long)));
+        FW_HIP(ctx, fw_memset_done(ctx->g.nest_status, 0, ncap * sizeof(unsigned long long)));
         ctx->nest_tiles_cap = ncap;
     }
     if (nest_ops > ctx->nest_ops_cap) {
@@ -533,7 +543,7 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
         size_t ncap = nest_ops * 2 + 16;
         if (ctx->g.nest_ticket) hipFree(ctx->g.nest_ticket);
         FW_HIP(ctx, hipMalloc((void **)&ctx->g.nest_ticket, ncap * sizeof(unsigned long long)));
-        FW_HIP(ctx, hipMemset(ctx->g.nest_ticket, 0, ncap * sizeof(unsigned long long)));
+        FW_HIP(ctx, fw_memset_done(ctx->g.nest_ticket, 0, ncap * sizeof(unsigned long long)));
         ctx->nest_ops_cap = ncap;
     }
     return FW_OK;
@@ -615,7 +625,8 @@ fw_status check_device_errors(fw_ctx *ctx) {
     uint32_t zero = 0;
     FW_HIP(ctx, hipMemcpy(ctx->g.err, &zero, sizeof zero, hipMemcpyHostToDevice));
     if (e & FW_ERR_FORECAST)
-        return fail(ctx, FW_EHIP, "internal error: stale survivor-forecast entry (device flags " + std::to_string(e) + ")");
+        return fail(ctx, FW_EHIP, "internal error: stale survivor-forecast entry (device flags " + std::to_string(e) + ", check " +
+                                      std::to_string(ev[5]) + ": " + std::to_string(ev[6]) + " " + std::to_string(ev[7]) + ")");
     if (e & FW_ERR_CAPACITY)
         return fail(ctx, FW_ECAPACITY,
                     "a particle type overflowed its device capacity; particles were dropped "
@@ -1358,9 +1369,9 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if ((e = hipHostMalloc((void **)&ctx->h_done, 64, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
     *ctx->h_done = 0ull;
     if ((e = hipMalloc((void **)&ctx->g.err, 64)) != hipSuccess) return bail("hipMalloc", e);
-    hipMemset(ctx->g.err, 0, 64);
+    fw_memset_done(ctx->g.err, 0, 64);
     if ((e = hipMalloc((void **)&ctx->g.stats, 64)) != hipSuccess) return bail("hipMalloc", e);
-    hipMemset(ctx->g.stats, 0, 64);
+    fw_memset_done(ctx->g.stats, 0, 64);
     if ((e = hipMalloc((void **)&ctx->d_aabb, 256 * 8 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&ctx->d_total, 64)) != hipSuccess) return bail("hipMalloc", e);
     ctx->g.seed = seed;
@@ -2594,7 +2605,7 @@ fw_status fw_ctx_live_count_ring(fw_ctx *ctx, void *d_ring_u64, uint32_t n_slots
     ctx->live_ring = (unsigned long long *)d_ring_u64;
     ctx->live_ring_n = d_ring_u64 ? n_slots : 0;
     ctx->live_ring_frames = 0;
-    if (d_ring_u64) FW_HIP(ctx, hipMemset(d_ring_u64, 0, (size_t)n_slots * sizeof(unsigned long long)));
+    if (d_ring_u64) FW_HIP(ctx, fw_memset_done(d_ring_u64, 0, (size_t)n_slots * sizeof(unsigned long long)));
     return FW_OK;
 }
 
@@ -2748,8 +2759,8 @@ fw_status fw_ctx_measure_copy_bandwidth(fw_ctx *ctx, uint64_t bytes, int32_t ite
         hipFree(a);
         return fail(ctx, FW_ENOMEM, "copy probe allocation");
     }
-    hipMemset(a, 1, bytes);
-    hipMemset(b, 0, bytes);
+    fw_memset_done(a, 1, bytes);
+    fw_memset_done(b, 0, bytes);
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     for (int i = 0; i < 3; i++) fw_launch_copy_probe(ctx->stream, a, b, bytes);

@@ -890,7 +890,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     if (use_fc) {
         fc_part = fw_wave_sum(fc_part);
         if (lane == 0) s_part[0][wave] = fc_part, s_part[1][wave] = new_alive;
-        if (__any(fc_bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST);
+        if (__any(fc_bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 1u, g.err[6] = tile;
     }
     __syncthreads();
     const unsigned long long ts1 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     }
     fc_part = fw_wave_sum(fc_part);
     if (lane == 0) s_part[0][wave] = fc_part, s_part[1][wave] = new_alive;
-    if (__any(fc_bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST);
+    if (__any(fc_bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 2u, g.err[6] = tile;
     const unsigned long long tsB = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (fc_part & 0u)) : 0ull;
     __syncthreads();
     const unsigned long long ts1 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         excl += base - n_in;  // every earlier new particle survives
         // (materialised new particles come here only when the host has shown that: it does not schedule this kernel
         // for such a frame otherwise)
-        if (SPAWN == FW_SPAWN_NONE && !a.new_static && tid == 0) atomicOr(g.err, FW_ERR_FORECAST);
+        if (SPAWN == FW_SPAWN_NONE && !a.new_static && tid == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 3u, g.err[6] = tile;
     } else if (SPAWN != FW_SPAWN_NONE && has_new) {  // look back among the new-particle tiles only
         const bool lb_needed = tis > t_spawn;
         if (lb_needed && tid == 0)
@@ -1757,10 +1757,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
             q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f;
         }
     }
-    if (__any(bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST);
+    if (__any(bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 4u, g.err[6] = F.seg, g.err[7] = blockIdx.x;
     if (tis == 0 && tid == 0) {
         const uint32_t oidx = (a.parity ^ 1u) * g.max_seg + F.seg;
-        if (F.mat ? (F.n_in != 0xFFFFFFFFu && F.n_in != n_in) : g.count[sidx] != n_in) atomicOr(g.err, FW_ERR_FORECAST);
+        if (F.mat ? (F.n_in != 0xFFFFFFFFu && F.n_in != n_in) : g.count[sidx] != n_in)
+            atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 5u, g.err[6] = F.seg, g.err[7] = n_in;
         if (F.report) *F.report = ((unsigned long long)a.epoch << 32) | c_new;
         const uint32_t nc = n_tot - min(n_dead, n_tot);
         g.count[oidx] = nc;
@@ -2070,7 +2071,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
                                                    &timed_out);
             // (no recount is possible here: the earlier tiles have already advanced their parents' last_emitted_age.
             // Workgroups are dispatched in index order, so every predecessor is resident or done: the wait is bounded.)
-            if (timed_out && tid == 0) atomicOr(g.err, FW_ERR_FORECAST);
+            if (timed_out && tid == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 6u, g.err[6] = tile;
         }
         const unsigned long long incl64 = (unsigned long long)excl + tile_total;
         const uint32_t incl = incl64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)incl64;

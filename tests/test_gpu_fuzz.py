@@ -441,6 +441,24 @@ def test_random_nested_topologies(case):
     index order).  Counts, order, ages and last_emitted_age bit for bit; small per-parent counts keep the population bounded."""
     from bevy_firework_amd.system import ParticleSystem
 
+    rng, types, entries = _nested_topology(case)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        pair = Pair(system, S.ParticleSpawner(types, entries), S.Transform(tuple(float(c) for c in rng.uniform(-1.0, 1.0, size=3))),
+                    seed=SEED, uid=800 + case)
+        for i, dt in enumerate(_steps(rng, 48)):
+            dt = np.float32(dt)
+            system.update(dt)
+            pair.step_cpu(dt)
+            if i % 8 == 7:
+                pair.check(what=f"case {case} frame {i}")
+                for k, e in enumerate(entries):
+                    if e.emission_mode.kind == S.MODE_NESTED:
+                        t = e.emission_mode.target_particle_type
+                        assert np.array_equal(pair.gpu.last_emitted(t, k), pair.cpu.last_emitted(t, k)), f"case {case} frame {i}: last_emitted_age[{k}] of type {t}"
+        test_random_nested_topologies.sizes[case] = pair.gpu.counts()
+
+
+def _nested_topology(case):
     rng = np.random.default_rng(51000 + case)
     n_types = int(rng.integers(2, 4))
     proto = _spawner(np.random.default_rng(52000 + case), scale=0.3, const_p=0.5 if case % 2 else 0.1)
@@ -471,21 +489,7 @@ def test_random_nested_topologies(case):
             inherit_parent_velocity=bool(rng.random() < 0.5), initial_velocity=_randvec(rng, 2.0),
             emission_shape=S.EmissionShape.Point() if rng.random() < 0.5 else S.EmissionShape.Sphere(0.2)))
     order = rng.permutation(len(entries))
-    entries = [entries[k] for k in order]
-    with ParticleSystem(device=0, seed=SEED) as system:
-        pair = Pair(system, S.ParticleSpawner(types, entries), S.Transform(tuple(float(c) for c in rng.uniform(-1.0, 1.0, size=3))),
-                    seed=SEED, uid=800 + case)
-        for i, dt in enumerate(_steps(rng, 48)):
-            dt = np.float32(dt)
-            system.update(dt)
-            pair.step_cpu(dt)
-            if i % 8 == 7:
-                pair.check(what=f"case {case} frame {i}")
-                for k, e in enumerate(entries):
-                    if e.emission_mode.kind == S.MODE_NESTED:
-                        t = e.emission_mode.target_particle_type
-                        assert np.array_equal(pair.gpu.last_emitted(t, k), pair.cpu.last_emitted(t, k)), f"case {case} frame {i}: last_emitted_age[{k}] of type {t}"
-        test_random_nested_topologies.sizes[case] = pair.gpu.counts()
+    return rng, types, [entries[k] for k in order]
 
 
 test_random_nested_topologies.sizes = {}
