@@ -164,7 +164,7 @@ def test_random_cases_were_not_trivial():
     assert max(totals) > 50000, totals
 
 
-@pytest.mark.parametrize("case", range(4))
+@pytest.mark.parametrize("case", range(4 + EXTRA // 16))
 def test_random_multi_spawner_system(case):
     """a dozen random spawners in one context: many segments in one launch, more spawn ops than fit the kernel
     arguments (op table read from the pinned ring), per-segment forecast entries; every spawner against its own oracle"""
@@ -277,7 +277,7 @@ def _api_scenario(case, seed_base, const_p):
                                              f"{want[rows[0]].view(np.float32)}")
 
 
-@pytest.mark.parametrize("case", range(16))
+@pytest.mark.parametrize("case", range(16 + EXTRA // 32))
 def test_every_shortcut_gives_the_state_of_the_plain_path(case, monkeypatch):
     """rings (types with one lifetime value), no rotation / angular-velocity planes (types that cannot turn), the side
     stream: each is a shortcut around work whose result is known in advance.  A random spawner at a size the oracle would
