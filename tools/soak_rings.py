@@ -27,7 +27,7 @@ with ParticleSystem(seed=workloads.SEED) as ps:
     print("nested paths", h.update_path(0), h.update_path(1))
     ps.update(dt)
     t0 = time.perf_counter()
-    for i in range(20000):
+    for i in range(int(os.environ.get("FW_SOAK_NESTED_FRAMES", "20000"))):  # (the children-count report ring wraps at 32768 frames)
         ps.step(dt if (i // 2500) % 2 == 0 else np.float32(1 / 60 + rng.uniform(-0.004, 0.004)))
         if i % 5000 == 4999:
             c = h.counts()
