@@ -2503,6 +2503,9 @@ fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, 
     if (!sp || type >= sp->seg.size() || (d_out && !cap)) return FW_EINVAL;
     hipSetDevice(ctx->device);
     fw_status st = sync(ctx);  // kernels in flight hold the old record
+    // ... and whatever the caller enqueued on ITS streams to initialise the buffer has happened before a frame writes to it
+    // (the context's streams are non-blocking ones: nothing else orders them against, say, a fill on the null stream)
+    if (!st && d_out) FW_HIP(ctx, hipDeviceSynchronize());
     if (st) return st;
     SegHost &S = ctx->segs[sp->seg[type]];
     S.inst = (char *)d_out;
@@ -2601,6 +2604,7 @@ fw_status fw_ctx_live_count_ring(fw_ctx *ctx, void *d_ring_u64, uint32_t n_slots
     if (!ctx || (d_ring_u64 && n_slots < 2)) return FW_EINVAL;
     hipSetDevice(ctx->device);
     fw_status st = sync(ctx);
+    if (!st && d_ring_u64) FW_HIP(ctx, hipDeviceSynchronize());  // (the caller's zero-fill of the ring, on whatever stream)
     if (st) return st;
     ctx->live_ring = (unsigned long long *)d_ring_u64;
     ctx->live_ring_n = d_ring_u64 ? n_slots : 0;

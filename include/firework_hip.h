@@ -227,7 +227,8 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
  * no packing pass.  Records beyond `cap` are dropped.  Types that receive Nested children work too: children are spawned
  * before the update of the same frame (plugin.rs:46-60), so they are among the records.
  * d_out = NULL detaches; fw_spawner_update_settings (which rebuilds the particle types) detaches too.
- * Synchronises the context's stream once (the segment record changes). */
+ * Synchronises the DEVICE once (the segment record changes; and whatever the caller enqueued on its own streams to
+ * initialise the buffer has completed before a frame writes into it -- the same holds for fw_ctx_live_count_ring). */
 fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap);
 /* update_aabbs reduction (render.rs:677-703), world space; *any = 0 when no particles */
 fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out_max[3], int32_t *any);
