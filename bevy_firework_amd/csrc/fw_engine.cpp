@@ -615,7 +615,7 @@ fw_status check_device_errors(fw_ctx *ctx) {
     uint32_t ev[8] = {};
     FW_HIP(ctx, hipMemcpy(ev, ctx->g.err, sizeof ev, hipMemcpyDeviceToHost));
     const uint32_t e = ev[0];
-    if (getenv("FW_TRACE") && ctx->d_tile_first) {
+    if (ctx->trace && ctx->d_tile_first) {
         uint32_t t[2] = {77, 77};
         hipMemcpy(t, ctx->d_tile_first, sizeof t, hipMemcpyDeviceToHost);
         fprintf(stderr, "[fw] check: flags=%u table=[%u,%u] ptr=%p fc=%p tiles_cap=%zu\n", e, t[0], t[1],
