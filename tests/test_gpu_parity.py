@@ -552,3 +552,38 @@ def test_a_non_finite_step_brings_the_rotation_plane_back(system):
     assert len(g) == len(c) == 5000
     for f in ("age", "position", "angular_velocity", "rotation"):
         assert np.array_equal(np.isnan(g[f]), np.isnan(c[f])), f
+
+
+def test_a_frame_that_cannot_be_enqueued_changes_nothing(system):
+    """spawn_particles is all-or-nothing per frame: when one entry asks for more particles than a frame can hold
+    (2^30), fw_step fails BEFORE anything is enqueued and every clock, queue, RNG serial, spawn total and lifetime
+    window the earlier entries of the frame had already advanced is put back -- also those of the other spawners.
+    The neighbour keeps matching the oracle afterwards, the failing spawner's state is what it was."""
+    from bevy_firework_amd.system import FwError
+
+    nb = Pair(system, S.ParticleSpawner([S.ParticleSettings(lifetime=S.RandF32(0.2, 0.5))],
+                                        [S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(9000.0))]), seed=SEED, uid=71)
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.3, 0.6))
+    bad = Pair(system, S.ParticleSpawner([ps], [S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(5000.0)),
+                                                S.EmissionSettings(emission_pacing=S.EmissionPacing.OnDemand())]), seed=SEED, uid=72)
+    for fr in range(12):
+        system.update(DT)
+        nb.step_cpu(DT)
+        bad.step_cpu(DT)
+    nb.check(exact_all=True, what="before")
+    bad.check(exact_all=True, what="before")
+    before = bad.gpu.particles(0).copy()
+    bad.gpu.queue_particles((1 << 30) + 5)
+    for _ in range(3):  # the queue is part of what is put back: the frame keeps failing, and keeps changing nothing
+        with pytest.raises(FwError) as e:
+            system.update(DT)
+        assert e.value.status == -4  # FW_ECAPACITY
+    after = bad.gpu.particles(0)
+    assert len(after) == len(before) and all(np.array_equal(after[f], before[f]) for f in before.dtype.names)
+    nb.check(exact_all=True, what="after the failed frames")
+    system.despawn(bad.gpu)  # the entity goes away; the rest of the world runs on as if those frames had never been asked for
+    for fr in range(40):
+        system.update(DT)
+        nb.step_cpu(DT)
+        if fr % 10 == 9:
+            nb.check(exact_all=True, what=f"neighbour, frame {fr} after")
