@@ -11,6 +11,8 @@ print("paths", h.update_path(0), h.update_path(1))
 ps.update(dt)
 for _ in range(250): ps.step(dt)
 ps.synchronize()
+for _ in range(8): ps.step(dt)  # (what the host does on SEEING the device's counts -- one reallocation of the smoke ring -- happens here)
+ps.synchronize()
 u0 = ps.updated_total(); t0 = time.perf_counter()
 for _ in range(100): ps.step(dt)
 ps.synchronize(); el = time.perf_counter() - t0
