@@ -19,6 +19,10 @@ Workloads (BASELINE.json `configs`, built by bevy_firework_amd/workloads.py):
                    writes (bevy_firework_amd/sharding.py -- the same class the tests drive).
   --workload configs1|configs4 forces either at any N (configs4 at N=1 is the base point of the curve).
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment LAUNCHES the N ranks itself (it re-executes
+itself through `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one device per
+rank) and exits non-zero when fewer than N devices are visible: it never falls back to one GPU or to configs[1].
+
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline      HBM roofline of the dominant kernel (fw_k_update*), from HIP events attached to each
                 dispatch on the kernel's own stream; for N=1 also `hbm_resident` (configs[2], 16.8M particles:
@@ -126,6 +130,47 @@ def kernel_roofline(ps, step, frames, label):
                                             "frac": per_launch * SURVEY_BYTES / kt / 1e9 / HBM_PEAK_GBS}}
 
 
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks here (one per device) and hand their exit code back.  Never a
+    silent fallback: fewer than N visible devices is an error (the curve is N ranks or nothing)."""
+    import socket
+    import subprocess
+
+    check = os.environ.get("FW_BENCH_LAUNCH_CHECK") == "1"  # CPU test of the launch plumbing: gloo ranks, no device
+    if not check:
+        import torch
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible MI355X devices, found {have}; "
+                             "refusing to fall back to fewer ranks\n")
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL across processes)
+    env["FW_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(world, rank):
+    """FW_BENCH_LAUNCH_CHECK=1: the ranks only prove that they exist -- a gloo group of `world` processes, one all-reduce
+    -- and rank 0 prints what it saw (tests/test_bench_launch.py)."""
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo")
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "rccl_ranks": dist.get_world_size(), "ranks_seen": int(t.item()),
+                          "n_gpus": world, "self_launched": os.environ.get("FW_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +186,14 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events")
     ap.add_argument("--no-extras", action="store_true", help="N=1: skip the hbm_resident / variable_dt / configs4 figures")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: one rank per GPU, no fallback")
+    if os.environ.get("FW_BENCH_LAUNCH_CHECK") == "1":
+        return launch_check(int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0")))
 
     import numpy as np
     import torch
@@ -151,10 +204,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the particle path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} devices are visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("FW_BENCH_FORCE_DIST"):  # the env knob exercises the RCCL path on one GPU
@@ -228,6 +281,30 @@ def main():
         hist = []
 
     extras = {}
+    rccl_ranks = dist.get_world_size() if dist is not None else 1
+    # N > 1: the base point of the strong-scaling curve -- ALL emitters of configs[4] on rank 0's GPU alone, measured in
+    # the same process right after the timed region (the other ranks wait at the barrier), so the line carries
+    # speedup_vs_configs4_one_gpu next to the sharded figure
+    if world > 1 and workload == "configs4" and not args.no_extras:
+        if rank == 0:
+            with ParticleSystem(device=local_rank, seed=workloads.SEED, stream=stream.cuda_stream) as p4:
+                for e, (s_, tf_) in enumerate(workloads.many_emitters(args.emitters, args.live_per_emitter)):
+                    p4.spawn(s_, tf_, uid=e)
+                p4.update(dt)
+                for _ in range(76 + 10):
+                    p4.step(dt)
+                p4.synchronize()
+                b0 = p4.updated_total()
+                t1 = time.perf_counter()
+                for _ in range(40):
+                    p4.step(dt)
+                p4.synchronize()
+                el = time.perf_counter() - t1
+                extras["configs4_one_gpu"] = {"particles_per_s": (p4.updated_total() - b0) / el, "ms_per_step": el / 40 * 1e3,
+                                              "live_particles": p4.live_count(),
+                                              "workload": f"{args.emitters} emitters x {args.live_per_emitter} live on one GPU "
+                                                          "(rank 0's device, same process, after the timed region)"}
+        barrier()
     if rank == 0 and world == 1 and workload == "configs1" and not args.no_events and not args.no_extras:
         # (a) variable dt on the SAME system: a host that steps with the wall-clock delta never repeats dt bit for bit
         jit = [np.float32((1.0 / 60.0) * (1.0 + 0.1 * np.sin(0.7 * k))) for k in range(64)]
@@ -324,19 +401,29 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": wl, "emitters_total": em_total, "live_particles": live, "sharding": "emitter e -> rank e mod N",
+                "rccl_ranks": rccl_ranks,  # dist.get_world_size() of the nccl (= RCCL) group; 1 = no group
+                "self_launched": os.environ.get("FW_BENCH_SELF_LAUNCHED") == "1",
                 "live_count_allreduce_every": args.reduce_every if dist is not None else None,
                 "per_rank_ms_per_step": per_rank_ms,
                 "allreduced_live_count_last_frame": hist[-1] if hist else None,
+                "speedup_vs_configs4_one_gpu": (extras["configs4_one_gpu"]["ms_per_step"] / (elapsed / args.steps * 1e3)
+                                                if world > 1 and extras.get("configs4_one_gpu") else None),
                 "update_mode": os.environ.get("FW_UPDATE_MODE", "fused"),
             },
             "hbm_gbs_algorithmic_whole_step": value * (roof["algorithmic_bytes_per_particle"] if roof else SURVEY_BYTES) / 1e9,
         }
         if roof:
-            traffic = None
+            # HBM-side bytes per launch of this kernel: PMC counters cannot be read from inside the process, so this is the
+            # figure of the separate `rocprofv3 --pmc` passes over this same command (tools/pmc.sh ->
+            # profiles/pmc_traffic.json), labelled as such -- not a measurement of the run that prints it
+            traffic, traffic_src = None, None
             tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tp) and workload == "configs1":
                 try:
-                    traffic = json.load(open(tp)).get("fw_k_update_bytes_per_launch")
+                    tj = json.load(open(tp))
+                    traffic = tj.get("fw_k_update_bytes_per_launch")
+                    traffic_src = ("traffic_from_profile: profiles/pmc_traffic.json (" + str(tj.get("source", "rocprofv3 --pmc passes")) +
+                                   "), not measured by this run")
                 except Exception:
                     traffic = None
             fifo = roof.get("update_path") == "fifo"
@@ -344,7 +431,7 @@ def main():
                 "bound": "hbm",
                 "kernel": ("fw_k_update_fifo (in-place ring update of a one-lifetime particle type, any dt)" if fifo else
                            "fw_k_update_stream (forecast frames; fw_k_update<fused> when dt changes)"),
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "measured_hbm_copy_GBps": measured_copy / 1e9,
                 "note": ("at 1M particles the 100 MB ring sits in the 256 MiB Infinity Cache; `hbm_resident` is the general "
                          "(compacting) kernel on a 16.8M-particle working set -- configs[2]'s lifetimes are a range, so its "
