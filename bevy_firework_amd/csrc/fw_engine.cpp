@@ -915,8 +915,9 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         dt.bc_kind = T.base.kind, dt.bc_n = T.base.n;
         dt.em_kind = T.emis.kind, dt.em_n = T.emis.n;
         dt.pbr = p.pbr, dt.report_destroyed = p.report_destroyed;
+        // (angular_drag must be finite: 0 * inf = NaN, core.rs:648-650 would turn a zero angular velocity into NaN)
         bool nospin = ctx->use_nospin && p.angular_acceleration[0] == 0.f && p.angular_acceleration[1] == 0.f &&
-                      p.angular_acceleration[2] == 0.f;
+                      p.angular_acceleration[2] == 0.f && std::isfinite(p.angular_drag);
         {  // FW_TYPE_NOSPIN: every entry that feeds the type spawns with zero angular velocity and the same rotation
             const fw_emission_settings *first = nullptr;
             for (uint32_t i = 0; i < ne && nospin; i++) {
@@ -1873,6 +1874,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 ctx->fifo_ops.push_back(io.second);
             }
         }
+        // every routed op now sits in exactly one list `rollback` walks (levels[].g or fifo_ops): forgetting this one too
+        // would take its particles out of cum_spawn twice
+        ctx->fifo_mat_ops.clear();
     }
     // ---- segment -> tile table (device resident, re-uploaded only when a bound moves out of its band)
     prof(1);
@@ -2141,7 +2145,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     bool fifo_launched = false;
     if (ctx->n_fifo) {
         // the ring launch(es) of this frame: on the side stream when a general launch runs next to them (fw_ctx: fifo_stream)
-        bool side = ctx->use_fifo_stream && total_tiles != 0 && ctx->live_ring == nullptr;
+        // (never on a caller-supplied stream: work the caller orders behind fw_step on ITS stream must cover the whole
+        // frame, as it did before the side stream existed)
+        bool side = ctx->use_fifo_stream && ctx->own_stream && total_tiles != 0 && ctx->live_ring == nullptr;
         for (const SegHost &S : ctx->segs) side &= !(S.in_use && S.fifo && (S.fifo_mat || S.inst != nullptr));
         if (side && (!ctx->fifo_last_side || ctx->main_reads_ring)) {
             // the previous ring launch, or a reader of ring data, sits on the main stream: this launch comes after it

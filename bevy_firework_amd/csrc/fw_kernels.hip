@@ -419,12 +419,19 @@ __device__ __forceinline__ void fw_inst_flush(char *inst, uint32_t inst_cap, con
 }
 
 
+// the rotation a record of a particle carries: the plane's value, or -- FW_TYPE_NOSPIN: the plane is neither read nor
+// maintained -- the type's one rotation.  Shared by every writer of destroyed records.
+__device__ __forceinline__ float4 fw_record_rotation(const FwType &T, float4 q2) {
+    if (T.flags & FW_TYPE_NOSPIN) return make_float4(T.const_rot[0], T.const_rot[1], T.const_rot[2], T.const_rot[3]);
+    return q2;
+}
+
 // destroyed record = the clone with age already advanced, pose of the previous frame (core.rs:596-599)
 __device__ __forceinline__ void fw_store_destroyed(char *dbuf, const char *ib, uint32_t C, uint32_t idx, bool loaded,
                                                    const FwType &T, const float *s_keys, float4 q0, float4 q1,
                                                    float4 q2, float4 q3, float age_new, uint32_t d) {
     float *rec = reinterpret_cast<float *>(dbuf) + (size_t)d * 26;
-    if (T.flags & FW_TYPE_NOSPIN) q2 = make_float4(T.const_rot[0], T.const_rot[1], T.const_rot[2], T.const_rot[3]);
+    q2 = fw_record_rotation(T, q2);
     const int32_t pbr = T.pbr;
     float4 bc, em;
     float sc;
@@ -1897,8 +1904,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpda
                 const float sc = q1.w * fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_new / q3.w);
                 float *rec = reinterpret_cast<float *>(destroyed) + (size_t)(idx - o) * 26;
                 const float4 bc = fw_ld4(ib + FW_OFF_Q5(C), idx), em = fw_ld4(ib + FW_OFF_Q6(C), idx);
+                // (a type that cannot turn keeps no rotation plane: the loaded q2 is whatever the slot last held)
+                const float4 r2 = fw_record_rotation(T, q2);
                 rec[0] = cpos.x, rec[1] = cpos.y, rec[2] = cpos.z, rec[3] = cvel.x, rec[4] = cvel.y, rec[5] = cvel.z;
-                rec[6] = q2.x, rec[7] = q2.y, rec[8] = q2.z, rec[9] = q2.w, rec[10] = q3.x, rec[11] = q3.y, rec[12] = q3.z;
+                rec[6] = r2.x, rec[7] = r2.y, rec[8] = r2.z, rec[9] = r2.w, rec[10] = q3.x, rec[11] = q3.y, rec[12] = q3.z;
                 rec[13] = q1.w, rec[14] = sc, rec[15] = age_new, rec[16] = q3.w;
                 rec[17] = bc.x, rec[18] = bc.y, rec[19] = bc.z, rec[20] = bc.w;
                 rec[21] = em.x, rec[22] = em.y, rec[23] = em.z, rec[24] = em.w;
@@ -2059,7 +2068,17 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
         for (int r = 0; r < NR; r++)
 #pragma unroll
             for (int w = 0; w < NW; w++) tot64 += s_w[r][w];
-        const uint32_t tile_total = tot64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot64;
+        uint32_t tile_total = tot64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot64;
+        // The op's last active tile commits (child `appended`, RNG serial) as soon as its look-back has seen the status
+        // word of every earlier tile -- so a tile must have READ those counters (n_par, cbase, serial0) before it
+        // publishes.  Make that a data dependency, not an accident of instruction scheduling: the published value
+        // passes through an opaque instruction that also consumes the three loaded values (they are in registers, i.e.
+        // the loads have returned, when it executes; the status stores below consume its result).
+        {
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(cbase), d1 = __builtin_amdgcn_readfirstlane((uint32_t)serial0),
+                           d2 = __builtin_amdgcn_readfirstlane((uint32_t)(serial0 >> 32)), d3 = __builtin_amdgcn_readfirstlane(n_par);
+            asm volatile("; fw_k_nest: counters read before the tile publishes" : "+v"(tile_total) : "s"(d0), "s"(d1), "s"(d2), "s"(d3));
+        }
         // ---- exclusive prefix over the earlier parent tiles of this op
         const bool lb_needed = tile > op.first_tile;
         if (lb_needed && tid == 0)

@@ -70,6 +70,11 @@ class ShardedParticleSystem:
             self._ring = torch.zeros(self._ring_n, dtype=torch.int64, device="cuda" if self._device_ring else "cpu")
             if self._device_ring:
                 self.system.live_count_ring(self._ring.data_ptr(), self._ring_n)
+                if self._stream is None:
+                    # The update kernels write the ring on the SYSTEM's stream (a non-blocking stream of its own unless
+                    # the caller gave it one): the bucket copy and the collective must be ordered behind them there, not
+                    # on torch's current stream, which nothing orders against it.
+                    self._stream = torch.cuda.ExternalStream(int(self.system.stream))
 
     # ---- frames ---------------------------------------------------------------------------------------------
     def update(self, dt: float) -> None:

@@ -20,11 +20,13 @@
  *    at create time.
  *  - one context per GPU; calls on one context must be serialised by the caller
  *    (the reference chain is sequential too).  fw_step only ENQUEUES work on the
- *    context's HIP stream; readers synchronise that stream.  Part of a frame may run on a second, internal
- *    stream (the in-place update of ring segments next to the compacting launch): everything the library enqueues
- *    on the context's stream that looks at particle data -- attached instance buffers, the *_device entry points --
- *    is ordered after it by the library itself, and fw_ctx_synchronize waits for both.  To wait for a frame call
- *    fw_ctx_synchronize, not hipStreamSynchronize(fw_ctx_stream(ctx)).
+ *    context's HIP stream; readers synchronise that stream.  A context created on a CALLER-SUPPLIED stream keeps the
+ *    whole frame on that stream: work the caller orders behind fw_step on it (or hipStreamSynchronize of it) covers
+ *    the frame.  A context that owns its stream (stream = NULL at fw_ctx_create) may run part of a frame on a second,
+ *    internal stream (the in-place update of ring segments next to the compacting launch): everything the library
+ *    enqueues on the context's stream that looks at particle data -- attached instance buffers, the *_device entry
+ *    points -- is ordered after it by the library itself, and fw_ctx_synchronize waits for both; wait for a frame of
+ *    such a context with fw_ctx_synchronize, not hipStreamSynchronize(fw_ctx_stream(ctx)).
  *  - there is NO CPU fallback: without a usable HIP device fw_ctx_create fails
  *    with FW_ENODEV.
  */

@@ -407,7 +407,8 @@ def test_random_colliding_spawner_matches_the_oracle_bit_for_bit(case):
                 for t in range(n_types):
                     gd, cd = pair.gpu.destroyed(t), pair.cpu.destroyed(t)
                     assert len(gd) == len(cd), f"case {case} frame {i} type {t}: destroyed {len(gd)} != {len(cd)}"
-                    for f in ("age", "position", "velocity", "scale"):
+                    for f in ("age", "position", "velocity", "scale", "rotation", "angular_velocity", "lifetime",
+                              "initial_scale", "base_color", "emissive_color"):
                         assert np.array_equal(gd[f], cd[f]), f"case {case} frame {i} type {t}: destroyed.{f}"
                     hits += int(np.count_nonzero(cd["age"] < cd["lifetime"]))  # destroyed by a collision, not by age
         moved = None

@@ -31,8 +31,28 @@ def run(name, spawners, fill, steps, uids=None):
     el = time.perf_counter() - t0
     upd = ps.updated_total() - u0
     live = ps.live_count()
+    # bytes per particle-update from the library, per particle TYPE (fw_debug_update_path), weighted by the live counts:
+    # a type that cannot turn, or whose gradients are constant, moves far fewer than SURVEY's 156 B
+    algo_b = moved_b = 0.0
+    for h in ps.spawners.values():
+        for t, c in enumerate(h.counts()):
+            _, moved, algo = h.update_path(t)
+            algo_b += algo * c
+            moved_b += moved * c
+    algo_pp, moved_pp = algo_b / max(live, 1), moved_b / max(live, 1)
+    # the update launches alone (hipEvent pairs attached to the dispatches, the duration rocprofv3 reports)
+    ps.kernel_timing(True)
+    for _ in range(min(steps, 200)):
+        ps.step(dt)
+    ev_ms, launches, kparts = ps.kernel_timing_read()
+    ps.kernel_timing(False)
+    k_us = ev_ms * 1e3 / max(launches, 1)
     print(json.dumps({"config": name, "live": live, "us_per_step": el / steps * 1e6, "particles_per_s": upd / el,
-                      "algorithmic_GBps": upd / el * 156 / 1e9}))
+                      "algorithmic_bytes_per_particle": round(algo_pp, 1), "moved_bytes_per_particle": round(moved_pp, 1),
+                      "algorithmic_GBps": upd / el * algo_pp / 1e9, "frac_of_8TBps": upd / el * algo_pp / 8e12,
+                      "update_kernels_us_per_frame": k_us,
+                      "update_kernels_algorithmic_GBps": kparts / max(launches, 1) * algo_pp / (k_us * 1e-6) / 1e9 if k_us else None,
+                      "at_survey_156B_GBps": upd / el * 156 / 1e9}))
     ps.close()
 
 
