@@ -167,6 +167,21 @@ struct alignas(64) SegHost {
     // kReportRing] = {epoch, added}) long before the host needs it: when the cohort's age reaches the lifetime.
     bool fifo_mat = false, fifo_dev = false;
     unsigned long long *h_report = nullptr;
+    // Range ring (fw_kernels.h: FwRangeRec): a type whose lifetime is a RANGE, Global emission only, no collisions, in a
+    // spawner without Nested entries.  ONE buffer (buf[0] == buf[1]) used as a ring: [old survivors | young]; the young
+    // part -- slot of its first particle, its size, its spawn cohorts -- is host-known exactly (the host made every spawn
+    // count and replays the fp32 age of every cohort: fw_ctx::birth_age); the size of the old part is the device's
+    // count minus young_n.  `ub` bounds the total as for any segment (lifetime window, snapshots).
+    bool range = false;
+    uint32_t young_lo = 0, young_n = 0;
+    float range_life_lo = 0.f;  // every particle outlives an update that leaves its age below this (TypeHost::life_lo_safe)
+    struct YCohort {
+        uint64_t frame;  // frame of the spawn
+        uint32_t n;
+    };
+    std::deque<YCohort> ycoh;  // the young cohorts, oldest first
+    uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
+    bool ring() const { return fifo || range; }  // one buffer, particle 0 not in slot 0
 };
 
 struct SpawnerHost {
@@ -330,6 +345,32 @@ struct fw_ctx {
     std::vector<std::pair<uint32_t, FwOp>> fifo_mat_ops;  // {emission index, op}: rings of spawners with Nested entries -- the
                                                          // Nested pass of the frame, if there is one, must find them in memory
     uint64_t tev_frames = 0;   // frames timed so far (a frame may take several update launches)
+    // ---- range rings (SegHost::range)
+    bool use_range = true;       // FW_RANGE=0: lifetime-range types take the compacting path (A/B, tests)
+    uint32_t range_min = 12288;  // smallest capacity that makes one (FW_RANGE_MIN; the tests use 0): a range ring costs a
+                                 // small segment three workgroups where the compacting path needs one
+    uint32_t n_range = 0;
+    std::vector<FwOp> range_ops;  // this frame's Global ops that feed range rings
+    // age, BEFORE the current frame's update, of a particle born in frame f -- the same for every segment of the context:
+    // born with age 0, then one fp32 addition per frame (core.rs:594), exactly the device's additions
+    struct BirthAge {
+        uint64_t frame;
+        float age;
+    };
+    std::deque<BirthAge> birth_age;  // oldest first; only frames some range ring may still hold young particles of
+    float range_life_max = 0.f;      // largest SegHost::range_life_lo in the context
+    FwRangeDesc *d_rdesc = nullptr;  // device table: one descriptor per workgroup of the range launch
+    FwRangeDesc *h_rdesc = nullptr;  // pinned staging of it
+    size_t rdesc_cap = 0;
+    uint32_t r_total = 0;            // workgroups of the range launch
+    bool r_force = true;             // a range segment was (re)built: re-send the table
+    hipEvent_t ev_rtab = nullptr;
+    bool rtab_pending = false;
+    unsigned long long *d_rstatus = nullptr;  // look-back words of the OLD workgroups
+    char *h_rparam[kParamRing] = {};          // pinned per-frame records + ops, read by the kernel in place
+    size_t rparam_bytes = 0;
+    uint64_t rslot_frame[kParamRing] = {};    // frame that last used the slot (+1; 0 = free)
+    uint64_t rring_seq = 0;
 
     uint32_t nest_seq = 0;  // launches of fw_k_nest so far (tag of their look-back words)
     // FW_HOST_PROF=1: time spent in the sections of fw_step's host half (printed when the context is destroyed)
@@ -471,7 +512,7 @@ uint32_t seg_live_tiles(const SegHost &s) {
     return (live_ub + FW_TILE - 1) / FW_TILE;
 }
 uint32_t seg_tiles(const SegHost &s, uint32_t vt_rounds = 1) {
-    if (!s.in_use || s.fifo) return 0;  // (FIFO segments have their own launch: fw_k_update_fifo)
+    if (!s.in_use || s.ring()) return 0;  // (rings have their own launches: fw_k_update_fifo, fw_k_update_range)
     const uint32_t vtile = vt_rounds * FW_VTILE;
     if (!s.nested_fed && s.frame_spawn <= FW_VTILE) {
         // At most one round of new particles: they ride in the last live tile whenever it has room for them (both
@@ -492,7 +533,7 @@ uint32_t seg_tiles(const SegHost &s, uint32_t vt_rounds = 1) {
 fw_status ensure_tile_arrays(fw_ctx *ctx) {
     size_t tiles = 0, nest_tiles = 0, nest_ops = 0;
     for (auto &s : ctx->segs)
-        if (s.in_use && !s.fifo) tiles += (s.capacity + FW_VTILE - 1) / FW_VTILE + 2;  // worst case: every slot a new particle
+        if (s.in_use && !s.ring()) tiles += (s.capacity + FW_VTILE - 1) / FW_VTILE + 2;  // worst case: every slot a new particle
     for (auto &sp : ctx->spawners) {
         if (!sp.alive) continue;
         for (auto &e : sp.em)
@@ -549,6 +590,54 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
     return FW_OK;
 }
 
+// device table, look-back words and per-frame pinned records of the range launch, sized for the worst case of every range
+// segment (old + young workgroups cover at most the ring, new ones at most a ring of new particles) when a segment is built
+// or reallocated: fw_step itself never allocates for them
+fw_status ensure_range_arrays(fw_ctx *ctx) {
+    size_t tiles = 0;
+    for (auto &s : ctx->segs)
+        if (s.in_use && s.range) tiles += (size_t)s.capacity / FW_TILE + 4 + (size_t)s.capacity / FW_BLOCK + 2;
+    if (tiles > ctx->rdesc_cap) {
+        fw_status st = sync(ctx);
+        if (st) return st;
+        const size_t ncap = tiles + tiles / 2 + 64;
+        if (ctx->d_rdesc) hipFree(ctx->d_rdesc);
+        if (ctx->h_rdesc) hipHostFree(ctx->h_rdesc);
+        if (ctx->d_rstatus) hipFree(ctx->d_rstatus);
+        ctx->d_rdesc = nullptr, ctx->h_rdesc = nullptr, ctx->d_rstatus = nullptr, ctx->rdesc_cap = 0;
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_rdesc, ncap * sizeof(FwRangeDesc)));
+        FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_rdesc, ncap * sizeof(FwRangeDesc), hipHostMallocDefault));
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_rstatus, ncap * sizeof(unsigned long long)));
+        FW_HIP(ctx, fw_memset_done(ctx->d_rstatus, 0, ncap * sizeof(unsigned long long)));
+        ctx->rdesc_cap = ncap;
+        ctx->r_force = true, ctx->rtab_pending = false;
+    }
+    // one record per segment slot + one op per emission entry of the context
+    const size_t need = round_up((uint32_t)(ctx->max_seg * sizeof(FwRangeRec)), 64) + (size_t)(ctx->n_emits + 8) * sizeof(FwOp) + 64;
+    if (ctx->n_range && need > ctx->rparam_bytes) {
+        fw_status st = sync(ctx);
+        if (st) return st;
+        const size_t nb = need * 2;
+        for (int i = 0; i < kParamRing; i++) {
+            if (ctx->h_rparam[i]) hipHostFree(ctx->h_rparam[i]);
+            ctx->h_rparam[i] = nullptr;
+            FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_rparam[i], nb, hipHostMallocDefault));
+            memset(ctx->h_rparam[i], 0, nb);
+            ctx->rslot_frame[i] = 0;
+        }
+        ctx->rparam_bytes = nb;
+    }
+    return FW_OK;
+}
+
+// slot of particle 0 of a segment whose live count is `count` (exact): 0 unless the segment is a ring
+uint32_t ring_head_exact(const SegHost &S, uint32_t count) {
+    if (S.fifo) return S.head;
+    if (!S.range) return 0u;
+    const uint32_t n_old = count > S.young_n ? count - S.young_n : 0u;  // the old part sits right before the young part
+    return (uint32_t)(((uint64_t)S.young_lo + S.capacity - (n_old % S.capacity)) % S.capacity);
+}
+
 fw_status ensure_param_ring(fw_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->param_bytes) return FW_OK;
     fw_status st = sync(ctx);
@@ -581,17 +670,17 @@ fw_status upload_seg(fw_ctx *ctx, uint32_t si) {
 fw_status alloc_seg_buffers(fw_ctx *ctx, SegHost &s, uint32_t capacity, bool want_destroyed) {
     const size_t bytes = FW_BUF_BYTES((size_t)capacity, s.n_lplanes + s.n_xplanes);
     char *b = nullptr;
-    hipError_t e = hipMalloc((void **)&b, bytes * (s.fifo ? 1 : 2));  // a FIFO ring is updated in place: one buffer
+    hipError_t e = hipMalloc((void **)&b, bytes * (s.ring() ? 1 : 2));  // a ring is updated in place: one buffer
     if (e != hipSuccess) return fail(ctx, FW_ENOMEM, std::string("hipMalloc particle buffers: ") + hipGetErrorString(e));
     s.buf[0] = b;
-    s.buf[1] = s.fifo ? b : b + bytes;
+    s.buf[1] = s.ring() ? b : b + bytes;
     s.capacity = capacity;
     s.destroyed = nullptr;
     if (want_destroyed) {
         e = hipMalloc((void **)&s.destroyed, (size_t)capacity * sizeof(fw_particle));
         if (e != hipSuccess) return fail(ctx, FW_ENOMEM, "hipMalloc destroyed buffer");
     }
-    FW_HIP(ctx, fw_launch_fill_colors(ctx->stream, s.buf[0], s.fifo ? nullptr : s.buf[1], capacity, s.fill_bc, s.fill_em));
+    FW_HIP(ctx, fw_launch_fill_colors(ctx->stream, s.buf[0], s.ring() ? nullptr : s.buf[1], capacity, s.fill_bc, s.fill_em));
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));  // callers go on with blocking copies on the null stream
     return FW_OK;
 }
@@ -645,15 +734,23 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
     if (st) return st;
     SegHost old = s;
     if (s.fifo && ncap >= 0x40000000u) make_general = true;  // ring slots are computed in 32 bits: head + index < 2^32
+    if (s.range && ncap > FW_RANGE_MAX_CAPACITY) make_general = true;  // (32-bit byte offsets into a plane)
     if (make_general && s.fifo) {
         s.fifo = false, s.fifo_mat = s.fifo_dev = false, s.coh.clear();
         ctx->n_fifo--;
         ctx->tab_force = true;
         ctx->seg_kind_changed = true;
     }
+    if (make_general && s.range) {
+        s.range = false, s.ycoh.clear(), s.young_lo = s.young_n = 0;
+        ctx->n_range--;
+        ctx->tab_force = true, ctx->r_force = true;
+        ctx->seg_kind_changed = true;
+    }
     st = alloc_seg_buffers(ctx, s, ncap, old.destroyed != nullptr);
     if (st) {
         if (old.fifo && !s.fifo) ctx->n_fifo++;
+        if (old.range && !s.range) ctx->n_range++;
         s = old;
         return st;
     }
@@ -661,7 +758,11 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
     s.head = 0;
     const uint32_t p = ctx->parity;
     const uint32_t n = old.ub;  // exact after the refresh
-    const uint32_t h = old.fifo ? old.head : 0u;
+    const uint32_t h = ring_head_exact(old, n);
+    if (s.range) {  // the list now starts in slot 0: old part first, the young part right behind it
+        s.young_lo = n > old.young_n ? n - old.young_n : 0u;
+        ctx->r_force = true;
+    }
     const uint32_t n1 = std::min<uint32_t>(n, old.capacity - h);  // up to the end of the old buffer, then from its slot 0
     auto cp = [&](size_t noff, size_t ooff, size_t elem) -> hipError_t {
         hipError_t e = hipSuccess;
@@ -693,6 +794,7 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
         }
     }
     if ((st = upload_seg(ctx, si))) return st;
+    if ((st = ensure_range_arrays(ctx))) return st;
     return ensure_tile_arrays(ctx);
 }
 
@@ -707,7 +809,7 @@ fw_status grow_segment(fw_ctx *ctx, uint32_t si, uint32_t need) {
 // a FIFO segment whose premise no longer holds (the caller wrote particles, dt went negative or non-finite, ...)
 // continues as an ordinary segment
 fw_status fifo_to_general(fw_ctx *ctx, uint32_t si) {
-    if (!ctx->segs[si].fifo) return FW_OK;
+    if (!ctx->segs[si].ring()) return FW_OK;
     return realloc_segment(ctx, si, ctx->segs[si].capacity, true);
 }
 
@@ -718,14 +820,14 @@ fw_status leave_nospin(fw_ctx *ctx, uint32_t si) {
     if (!s.nospin) return FW_OK;
     fw_status st = sync(ctx);
     if (st) return st;
-    FW_HIP(ctx, fw_launch_fill_rotation(ctx->stream, s.buf[0], s.fifo ? nullptr : s.buf[1], s.capacity, s.const_rot));
-    FW_HIP(ctx, fw_launch_restore_q3(ctx->stream, s.buf[0], s.fifo ? nullptr : s.buf[1], s.capacity,
+    FW_HIP(ctx, fw_launch_fill_rotation(ctx->stream, s.buf[0], s.ring() ? nullptr : s.buf[1], s.capacity, s.const_rot));
+    FW_HIP(ctx, fw_launch_restore_q3(ctx->stream, s.buf[0], s.ring() ? nullptr : s.buf[1], s.capacity,
                                      s.fifo ? 0xFFFFFFFFu : s.n_lplanes, s.fifo_life));
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t zero = 0;
     FW_HIP(ctx, hipMemcpy((char *)(ctx->d_types.d + s.type_idx) + offsetof(FwType, flags), &zero, sizeof zero, hipMemcpyHostToDevice));
     s.nospin = false;
-    ctx->tab_force = true;  // (the tile descriptors carry the flag)
+    ctx->tab_force = true, ctx->r_force = true;  // (the tile descriptors carry the flag)
     ctx->fc_ok = false, ctx->boxes_epoch = 0;
     return FW_OK;
 }
@@ -1021,6 +1123,18 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
                 S.fifo_life = 0.0f * (p.lifetime.max - p.lifetime.min) + p.lifetime.min;  // u * (max - min) + min, any u
                 S.fifo_wm = (T.base.kind != 0 ? 1 : 0) | (T.emis.kind != 0 ? 2 : 0) | (T.scale.kind != 0 ? 4 : 0);
             }
+            // Range ring (SegHost::range): any finite lifetime range -- a single value included, for the types the eight
+            // FIFO records of a launch have no room for -- in a spawner without Nested entries; the young part of the
+            // list is updated in place, only the part that can lose particles this frame is compacted
+            S.range = ctx->use_range && !S.fifo && !any_nested && !S.collides && std::isfinite(p.lifetime.min) &&
+                      std::isfinite(p.lifetime.max) && T.life_lo_safe > 0.0f && caps[t] >= ctx->range_min &&
+                      caps[t] <= FW_RANGE_MAX_CAPACITY;
+            if (S.range) {
+                ctx->n_range++;
+                S.range_life_lo = T.life_lo_safe;
+                ctx->range_life_max = std::max(ctx->range_life_max, S.range_life_lo);
+                ctx->r_force = true;
+            }
         }
         for (int c = 0; c < 4; c++) {  // the first key is the colour at age 0 (and, for one key, at every age)
             S.fill_bc[c] = T.base.values.empty() ? 0.f : T.base.values[c];
@@ -1088,6 +1202,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         FW_HIP(ctx, hipMemcpy(ctx->d_emit_serial.d + E.emit_slot, &s0, sizeof s0, hipMemcpyHostToDevice));
     }
     sp.initialized = true;
+    if ((st = ensure_range_arrays(ctx))) return st;
     return ensure_tile_arrays(ctx);
 }
 
@@ -1107,6 +1222,7 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
         if (!S.in_use) continue;
         ctx->free_types.push_back(S.type_idx);
         if (S.fifo) ctx->n_fifo--;
+        if (S.range) ctx->n_range--, ctx->r_force = true;
         if (S.h_report) hipHostFree(S.h_report);
         if (S.buf[0]) FW_HIP(ctx, hipFree(S.buf[0]));
         if (S.destroyed) FW_HIP(ctx, hipFree(S.destroyed));
@@ -1133,7 +1249,7 @@ fw_status update_tile_table(fw_ctx *ctx) {
     uint64_t act1 = 0, act2 = 0;
     for (uint32_t i = 0; i < n_seg; i++) {
         const SegHost &S = ctx->segs[i];
-        if (S.in_use && !S.fifo) {
+        if (S.in_use && !S.ring()) {
             const uint32_t live = seg_live_tiles(S);
             act1 += live + (S.frame_spawn + FW_VTILE - 1) / FW_VTILE;
             act2 += live + (S.frame_spawn + 2 * FW_VTILE - 1) / (2 * FW_VTILE);
@@ -1142,7 +1258,7 @@ fw_status update_tile_table(fw_ctx *ctx) {
         // the device from exact counts and may use the smaller tiles when the host, with looser bounds, would not
         const uint32_t need = seg_tiles(S, 1);
         uint32_t &have = ctx->tiles_dev[i];
-        if (!S.in_use || S.fifo) {
+        if (!S.in_use || S.ring()) {
             if (have) have = 0, dirty = true;
             continue;
         }
@@ -1356,6 +1472,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if ((e = hipStreamCreateWithFlags(&ctx->fifo_stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate(rings)", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_rtab, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming)) != hipSuccess)
         return bail("hipEventCreate", e);
     for (int i = 0; i < kParamRing; i++) {
@@ -1384,6 +1501,8 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_FIFO_NESTED")) ctx->fifo_nested = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_STREAM")) ctx->use_fifo_stream = atoi(m) != 0;
     if (const char *m = getenv("FW_NOSPIN")) ctx->use_nospin = atoi(m) != 0;
+    if (const char *m = getenv("FW_RANGE")) ctx->use_range = atoi(m) != 0;
+    if (const char *m = getenv("FW_RANGE_MIN")) ctx->range_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
     if (const char *m = getenv("FW_OPS_ZEROCOPY")) ctx->ops_zerocopy = atoi(m) != 0;
@@ -1451,6 +1570,12 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     hipStreamDestroy(ctx->copy_stream);
     if (ctx->fifo_stream) hipStreamDestroy(ctx->fifo_stream);
     if (ctx->ev_side) hipEventDestroy(ctx->ev_side);
+    if (ctx->ev_rtab) hipEventDestroy(ctx->ev_rtab);
+    if (ctx->d_rdesc) hipFree(ctx->d_rdesc);
+    if (ctx->h_rdesc) hipHostFree(ctx->h_rdesc);
+    if (ctx->d_rstatus) hipFree(ctx->d_rstatus);
+    for (int i = 0; i < kParamRing; i++)
+        if (ctx->h_rparam[i]) hipHostFree(ctx->h_rparam[i]);
     if (ctx->ev_main) hipEventDestroy(ctx->ev_main);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1642,6 +1767,22 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             if (cst) return cst;
         }
     }
+    ctx->range_ops.clear();
+    if (ctx->n_range) {
+        // The in-place young part of a range ring rests on ages that never decrease and on nobody -- a particle spawned this
+        // frame included -- dying before its age reaches lifetime.min: a negative or non-finite dt, a step as long as the
+        // shortest lifetime, or a cohort list that grows without bound (a dt thousands of times smaller than the
+        // lifetimes) end the mode; the type continues on the compacting path.
+        const bool flood = ctx->birth_age.size() > (1u << 22);
+        for (uint32_t si = 0; si < ctx->segs.size(); si++) {
+            SegHost &S = ctx->segs[si];
+            if (!S.in_use || !S.range) continue;
+            if (!flood && dt >= 0.0f && dt < S.range_life_lo && S.ycoh.size() < kMaxCohorts) continue;
+            fw_status cst = fifo_to_general(ctx, si);
+            if (cst) return cst;
+        }
+    }
+    if (!ctx->n_range) ctx->birth_age.clear();
     // (frame_spawn is reset in the lifetime-window pass below: one pass over the segments instead of two)
     bool new_static = std::isfinite(dt);  // cleared by any Global op whose particles might not survive this step
 
@@ -1662,7 +1803,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         S.frame_spawn = 0;
         if (!S.in_use) continue;
         any_coll |= S.collides;
-        any_inst_general |= !S.fifo && S.inst != nullptr;
+        any_inst_general |= !S.ring() && S.inst != nullptr;
         if (S.nested_fed && S.auto_capacity && S.dev_count > S.capacity / 2 && S.capacity < 0x70000000u)
             ctx->grow_scratch.push_back((uint32_t)si);
         if (!S.win_ok) continue;
@@ -1713,6 +1854,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         for (auto &L : ctx->levels)
             for (const FwOp &op : L.g) forget(op);
         for (const FwOp &op : ctx->fifo_ops) forget(op);
+        for (const FwOp &op : ctx->range_ops) forget(op);
         for (const auto &io : ctx->fifo_mat_ops) forget(io.second);
         for (auto &S : ctx->segs) S.ub -= std::min(S.ub, S.frame_spawn), S.frame_spawn = 0;
         return why;
@@ -1818,7 +1960,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     }
                 }
                 // does every particle of this op outlive the step?  (TypeHost::life_lo_safe; false for NaN)
-                if (!S.fifo && !(dt < E.life_lo_safe)) new_static = false;
+                if (!S.ring() && !(dt < E.life_lo_safe)) new_static = false;
                 FwOp op{};
                 op.seg = dst, op.emit = E.emit_idx, op.n = (uint32_t)n;
                 op.rel_base = S.frame_spawn;
@@ -1831,6 +1973,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     ctx->fifo_mat_ops.push_back({(uint32_t)i, op});  // routed below, once the frame's Nested ops are known
                 else if (S.fifo)
                     ctx->fifo_ops.push_back(op);  // spawned inside fw_k_update_fifo, whatever else the frame holds
+                else if (S.range)
+                    ctx->range_ops.push_back(op);  // spawned inside fw_k_update_range
                 else
                     levels[i].g.push_back(op);
                 E.serial += n;
@@ -1917,7 +2061,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     a.seg0_keys_off = n_seg ? ctx->segs[0].keys_off : 0;
     a.seg0_keys_len = n_seg ? ctx->segs[0].keys_len : 0;
     a.tile_keys = ctx->d_tile_keys;
-    if (n_seg == 1 && ctx->segs[0].in_use && !ctx->segs[0].fifo) {
+    if (n_seg == 1 && ctx->segs[0].in_use && !ctx->segs[0].ring()) {
         const SegHost &S0 = ctx->segs[0];
         a.seg0_ib = S0.buf[p], a.seg0_ob = S0.buf[p ^ 1u];
         a.seg0_destroyed = S0.destroyed, a.seg0_inst = S0.inst;
@@ -1934,7 +2078,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // (a ring that had to grow past the ring limit during this frame's spawner loop continues as a compacting segment:
     // look again -- never in a steady-state frame)
     if (ctx->seg_kind_changed)
-        for (const SegHost &S : ctx->segs) any_inst_general |= S.in_use && !S.fifo && S.inst != nullptr;
+        for (const SegHost &S : ctx->segs) any_inst_general |= S.in_use && !S.ring() && S.inst != nullptr;
     a.any_inst = any_inst_general ? 1u : 0u;
     a.use_stream = ctx->use_stream ? 1u : 0u;
     uint32_t dt_bits;
@@ -2255,7 +2399,107 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         }
         FW_HIP(ctx, flush());
     }
-    if (total_tiles || !fifo_launched) {
+    // ---- range rings: in place, one launch for all of them (fw_kernels.h: FwRangeRec)
+    bool range_launched = false;
+    if (ctx->n_range) {
+        const int rslot = (int)(ctx->rring_seq++ % kParamRing);
+        if (ctx->rslot_frame[rslot]) {  // the kernel reads the slot in place: free once a launch AFTER that frame has started
+            const volatile unsigned long long *tag = ctx->h_done;
+            for (int spin = 0; *tag < ctx->rslot_frame[rslot] && spin < 200000; spin++) __builtin_ia32_pause();
+            if (*tag < ctx->rslot_frame[rslot]) FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->rslot_frame[rslot] = 0;
+        }
+        FwRangeRec *recs = (FwRangeRec *)ctx->h_rparam[rslot];
+        FwOp *rops = (FwOp *)(ctx->h_rparam[rslot] + round_up((uint32_t)(ctx->max_seg * sizeof(FwRangeRec)), 64));
+        std::vector<FwOp> &ops = ctx->range_ops;
+        if (!std::is_sorted(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; }))
+            std::stable_sort(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; });
+        if (!ops.empty()) memcpy(rops, ops.data(), ops.size() * sizeof(FwOp));
+        // age of a particle born in frame f before this frame's update (fw_ctx::birth_age: one entry per frame, contiguous)
+        auto age_before = [&](uint64_t f) -> float {
+            if (ctx->birth_age.empty() || f < ctx->birth_age.front().frame) return INFINITY;  // (long graduated)
+            const size_t i = (size_t)(f - ctx->birth_age.front().frame);
+            return i < ctx->birth_age.size() ? ctx->birth_age[i].age : 0.0f;  // this frame's own cohort: born with age 0
+        };
+        bool dirty = ctx->r_force, all_nospin = true;
+        size_t oi = 0;
+        for (uint32_t si = 0; si < n_seg; si++) {
+            SegHost &S = ctx->segs[si];
+            if (!S.in_use || !S.range) continue;
+            all_nospin &= S.nospin;
+            // cohorts that are no longer provably too young to die join the old part: the boundary moves, nothing is copied
+            uint32_t grad = 0;
+            while (!S.ycoh.empty()) {
+                const float an = age_before(S.ycoh.front().frame) + dt;  // the device's own addition (core.rs:594)
+                if (an < S.range_life_lo) break;
+                grad += S.ycoh.front().n;
+                S.ycoh.pop_front();
+            }
+            if (S.frame_spawn) S.ycoh.push_back(SegHost::YCohort{ctx->frame, S.frame_spawn});
+            S.young_lo = (uint32_t)(((uint64_t)S.young_lo + grad) % S.capacity);
+            const uint32_t y_exist = S.young_n - std::min(S.young_n, grad);
+            FwRangeRec &Rc = recs[si];
+            Rc.b = S.young_lo, Rc.y_exist = y_exist, Rc.n_spawn = S.frame_spawn;
+            while (oi < ops.size() && ops[oi].seg < si) oi++;
+            Rc.op0 = (uint32_t)oi, Rc.op_n = 0;
+            while (oi < ops.size() && ops[oi].seg == si) oi++, Rc.op_n++;
+            S.young_n = y_exist + S.frame_spawn;
+            // workgroups of each role (bands: the table is re-sent only when a need leaves its band)
+            const uint32_t live_before_ub = std::min(S.ub - std::min(S.ub, S.frame_spawn), S.capacity);
+            const uint32_t old_ub = live_before_ub - std::min(live_before_ub, y_exist);
+            const uint32_t need_old = std::max(1u, (old_ub + FW_TILE - 1) / FW_TILE);
+            const uint32_t need_new = (S.frame_spawn + FW_BLOCK - 1) / FW_BLOCK;
+            const uint32_t need_young = std::min(S.capacity / FW_TILE, (S.young_lo % FW_TILE + y_exist + FW_TILE - 1) / FW_TILE);
+            if (need_old > S.r_old || S.r_old > need_old + need_old / 2 + 4) S.r_old = need_old + need_old / 4 + 1, dirty = true;
+            if (need_new > S.r_new || S.r_new > need_new + need_new / 4 + 2) S.r_new = need_new + (need_new >= 8 ? need_new / 8 : 1u), dirty = true;
+            if (need_young > S.r_young || S.r_young > need_young + need_young / 4 + 2)
+                S.r_young = std::min(S.capacity / FW_TILE, need_young + (need_young >= 16 ? need_young / 8 : 1u)), dirty = true;
+        }
+        if (dirty) {
+            if (ctx->rtab_pending) {  // (one staging buffer: the previous upload must have left it)
+                FW_HIP(ctx, hipEventSynchronize(ctx->ev_rtab));
+                ctx->rtab_pending = false;
+            }
+            size_t t = 0;
+            for (uint32_t si = 0; si < n_seg; si++) {
+                const SegHost &S = ctx->segs[si];
+                if (!S.in_use || !S.range) continue;
+                const uint32_t old_first = (uint32_t)t;
+                const uint32_t roles[3] = {S.r_old, S.r_new, S.r_young};
+                for (uint32_t role = 0; role < 3; role++)
+                    for (uint32_t k = 0; k < roles[role]; k++) {
+                        if (t >= ctx->rdesc_cap) return fail(ctx, FW_EHIP, "internal error: range table overflow");
+                        FwRangeDesc &D = ctx->h_rdesc[t++];
+                        D.seg = si, D.role_k = (role << 30) | k, D.old_first = old_first;
+                        D.type_idx = S.type_idx | (S.nospin ? FW_TYPE_IDX_NOSPIN : 0u);
+                        D.keys_off = S.keys_off, D.keys_len = S.keys_len;
+                    }
+            }
+            ctx->r_total = (uint32_t)t;
+            if (t) FW_HIP(ctx, hipMemcpyAsync(ctx->d_rdesc, ctx->h_rdesc, t * sizeof(FwRangeDesc), hipMemcpyHostToDevice, ctx->stream));
+            FW_HIP(ctx, hipEventRecord(ctx->ev_rtab, ctx->stream));
+            ctx->rtab_pending = true;
+            ctx->r_force = false;
+        }
+        // the ages every later frame starts from
+        for (auto &e : ctx->birth_age) e.age = e.age + dt;
+        ctx->birth_age.push_back(fw_ctx::BirthAge{ctx->frame, 0.0f + dt});
+        while (!ctx->birth_age.empty() && !(ctx->birth_age.front().age < ctx->range_life_max)) ctx->birth_age.pop_front();
+        if (ctx->r_total) {
+            FwRangeArgs ra{};
+            ra.desc = ctx->d_rdesc, ra.recs = recs, ra.ops = rops, ra.status = ctx->d_rstatus;
+            ra.total_tiles = ctx->r_total, ra.parity = p, ra.epoch = a.epoch, ra.spin_limit = ctx->spin_limit, ra.dbg = ctx->dbg;
+            ra.dt = dt;
+            ra.done_tag = a.done_tag, ra.done_value = a.done_value;
+            ra.host_counts = a.host_counts, ra.live_out = a.live_out, ra.live_next = a.live_next;
+            hipEvent_t e0, e1;
+            next_timing_pair(&e0, &e1);
+            FW_HIP(ctx, fw_launch_update_range(ctx->stream, ctx->g, ra, all_nospin, e0, e1));
+            ctx->rslot_frame[rslot] = ctx->frame + 1;
+            range_launched = true;
+        }
+    }
+    if (total_tiles || !(fifo_launched || range_launched)) {
         hipEvent_t e0, e1;
         next_timing_pair(&e0, &e1);
         FW_HIP(ctx, fw_launch_update(ctx->stream, ctx->g, a, spawn_form == FW_SPAWN_INLINE ? &inl : nullptr, spawn_form,
@@ -2384,7 +2628,7 @@ fw_status fw_spawner_read_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
     const uint32_t n = c[sp->seg[type]];
     if (n_out) *n_out = n;
     fw_status st2 = read_records(ctx, S.buf[ctx->parity], S.capacity, n, sp->types[type].ps.pbr, false, out, cap,
-                                 S.fifo ? S.head : 0u, S.nospin ? S.const_rot : nullptr,
+                                 ring_head_exact(S, n), S.nospin ? S.const_rot : nullptr,
                                  (S.nospin && !S.fifo) ? S.n_lplanes : 0xFFFFFFFFu, S.fifo_life);
     return st2 ? st2 : st;
 }
@@ -2410,7 +2654,7 @@ fw_status fw_spawner_read_last_emitted(fw_ctx *ctx, fw_spawner h, uint32_t type,
         return st;
     }
     const char *pl = S.buf[ctx->parity] + FW_OFF_L((size_t)S.capacity, plane);
-    const uint32_t h0 = S.fifo ? S.head : 0u;  // a ring: from the head to the end of the buffer, then from slot 0
+    const uint32_t h0 = ring_head_exact(S, n);  // a ring: from the head to the end of the buffer, then from slot 0
     const uint64_t m1 = std::min<uint64_t>(m, S.capacity - h0);
     FW_HIP(ctx, hipMemcpy(out, pl + (size_t)h0 * sizeof(float), m1 * sizeof(float), hipMemcpyDeviceToHost));
     if (m > m1) FW_HIP(ctx, hipMemcpy(out + m1, pl, (m - m1) * sizeof(float), hipMemcpyDeviceToHost));
@@ -2482,7 +2726,9 @@ fw_status fw_spawner_read_destroyed(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
     uint32_t n = 0;
     if (S.destroyed) FW_HIP(ctx, hipMemcpy(&n, ctx->g.ndestroyed + sp->seg[type], 4, hipMemcpyDeviceToHost));
     if (n_out) *n_out = n;
-    return read_records(ctx, S.destroyed, S.capacity, n, 0, true, out, cap);
+    // (a range ring fills its records from the END of the buffer, the youngest dead first: the last n are in list order)
+    const char *first = S.destroyed + (S.range && n <= S.capacity ? (size_t)(S.capacity - n) * sizeof(fw_particle) : (size_t)0);
+    return read_records(ctx, first, S.capacity, n, 0, true, out, cap);
 }
 
 fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap,
@@ -2498,9 +2744,10 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
         fw_status jst = join_side(ctx);
         if (jst) return jst;
     }
-    FW_HIP(ctx, fw_launch_pack_instances(ctx->stream, S.buf[ctx->parity], S.capacity, S.fifo ? S.head : 0u,
+    // (a range ring: particle 0 sits `count - young_n` slots before the first young particle -- the kernel reads the count)
+    FW_HIP(ctx, fw_launch_pack_instances(ctx->stream, S.buf[ctx->parity], S.capacity, S.range ? S.young_lo : (S.fifo ? S.head : 0u),
                                          ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, ub, d_out,
-                                         S.nospin ? S.const_rot : nullptr));
+                                         S.nospin ? S.const_rot : nullptr, S.range ? S.young_n : 0xFFFFFFFFu));
     return FW_OK;
 }
 
@@ -2513,6 +2760,11 @@ fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, 
     // (the context's streams are non-blocking ones: nothing else orders them against, say, a fill on the null stream)
     if (!st && d_out) FW_HIP(ctx, hipDeviceSynchronize());
     if (st) return st;
+    if (d_out && ctx->segs[sp->seg[type]].range) {
+        // the records go to index `list position`, which a tile of a range ring only knows once the whole old part has
+        // been counted: such a type continues on the compacting path
+        if ((st = fifo_to_general(ctx, sp->seg[type]))) return st;
+    }
     SegHost &S = ctx->segs[sp->seg[type]];
     S.inst = (char *)d_out;
     S.inst_cap = d_out ? (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull) : 0u;
@@ -2551,12 +2803,13 @@ fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out
         fw_status jst = join_side(ctx);  // (the query kernels run on the main stream and may read rings)
         if (jst) return jst;
     }
-    bool any_fifo = false;  // FIFO segments leave no per-tile boxes: the two-pass query reads their rings
-    uint32_t heads[FW_MAX_TYPES] = {};
+    bool any_fifo = false;  // rings leave no per-tile boxes: the two-pass query reads them
+    uint32_t heads[FW_MAX_TYPES] = {}, range_y[FW_MAX_TYPES];
     for (size_t t = 0; t < sp->seg.size() && t < FW_MAX_TYPES; t++) {
         const SegHost &S = ctx->segs[sp->seg[t]];
-        any_fifo |= S.fifo;
-        heads[t] = S.fifo ? S.head : 0u;
+        any_fifo |= S.ring();
+        heads[t] = S.range ? S.young_lo : (S.fifo ? S.head : 0u);
+        range_y[t] = S.range ? S.young_n : 0xFFFFFFFFu;
     }
     if (ctx->boxes_epoch && ctx->d_tile_first && !any_fifo) {
         // the last update left the box of every tile's survivors (fw_ctx_track_aabbs): fold those -- one small launch
@@ -2565,7 +2818,7 @@ fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out
     } else {
         // two launches over the particles, the result lands in pinned memory: one synchronisation, no copies
         FW_HIP(ctx, fw_launch_aabb(ctx->stream, ctx->g, sp->seg.data(), heads, (uint32_t)sp->seg.size(), ctx->parity,
-                                   ctx->d_aabb, ctx->h_aabb));
+                                   ctx->d_aabb, ctx->h_aabb, range_y));
     }
     fw_status st = sync(ctx);
     if (!st) st = check_device_errors(ctx);
@@ -2722,10 +2975,10 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t
     if (!sp || type >= sp->seg.size()) return FW_EINVAL;
     const SegHost &S = ctx->segs[sp->seg[type]];
     const TypeHost &T = sp->types[type];
-    if (mode) *mode = S.fifo ? 1 : 0;
+    if (mode) *mode = S.fifo ? 1 : (S.range ? 2 : 0);
     const uint32_t colours = (T.base.kind != 0 ? 16u : 0u) + (T.emis.kind != 0 ? 16u : 0u);  // one-key gradients: never rewritten
     uint32_t moved, algo;
-    if (S.fifo) {
+    if (S.ring()) {
         // in place: position+age and velocity always; rotation only where some emitter makes the particles spin (or the
         // type accelerates them), angular velocity only if it then changes; scale unless its curve is constant
         bool spins = false;
@@ -2738,6 +2991,10 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t
         // (a type that cannot turn: neither the rotation nor the angular-velocity / lifetime plane is read)
         moved = (S.nospin ? 32u : 64u) + 32u + q2 + q3 + (T.scale.kind != 0 ? 4u : 0u) + colours;
         algo = moved - 4u - (q3 ? 4u : 0u);
+        // (a range ring: lifetimes differ from particle to particle -- 4 B read for a type that cannot turn, Q3 otherwise --
+        // and the scale depends on initial_scale; the part of the list that may lose particles, a fifth of configs[2], is
+        // compacted in place and rewrites every plane it keeps: the figure is the young part's)
+        if (S.range && S.nospin) moved += 4u, algo += 4u;
     } else {
         // compacting: every state plane lands at a new slot (+ the last_emitted planes of a Nested parent, read and written);
         // a type that cannot turn keeps no rotation plane: -16 B read, -16 B written,

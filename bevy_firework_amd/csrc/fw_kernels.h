@@ -147,6 +147,53 @@ struct FwFifoArgs {
     unsigned long long *live_out, *live_next;
 };
 
+// ---- range rings: particle types whose lifetime is a RANGE, updated in place ---------------------------------------
+// Ages never increase along the particle list (everybody is born with age 0 behind all older particles and every update
+// adds the same dt, core.rs:523, 594) and nobody dies before `age + dt >= lifetime.min`: only a PREFIX of the list -- the
+// OLD part -- can lose particles in an update; everybody younger is in the situation of a FIFO ring particle.  Such a type
+// lives in ONE buffer used as a ring:   [ ... free ... | old survivors | young | free ... ]
+//   * the YOUNG part is updated in place (a lane owns its slot from load to store; no counting, no look-back, any dt);
+//     the host knows it exactly -- it made every spawn count and replays the fp32 age of every spawn cohort -- as
+//     {b = slot of the first young particle, y = their number};
+//   * the OLD part [b - n_old, b) is compacted IN PLACE towards the young part (order kept): a tile of 1024 holds its
+//     whole input in registers before it publishes its survivor count, so the tiles further from b -- which need that
+//     count for their offset, and whose survivors land in slots of the tiles nearer to b -- cannot overwrite anything
+//     that is still to be read.  Tiles nearer to b have lower workgroup indices: whoever is waited for is resident or done;
+//   * cohorts whose age reaches lifetime.min simply join the old part: b moves, nothing is copied;
+//   * new particles are spawned at the tail, in the slot they will live in.
+// The first particle of the list sits in slot b - n_old: `n_old` = count - y is known to the device only.
+struct alignas(16) FwRangeRec {  // per segment, per frame: pinned host memory, read by the tiles in place
+    uint32_t b;         // slot of the first young particle, after this frame's cohorts have joined the old part
+    uint32_t y_exist;   // young particles before this frame's spawns
+    uint32_t n_spawn;   // particles spawned this frame (all of them outlive the step: dt < lifetime.min)
+    uint32_t op0, op_n; // their spawn ops in FwRangeArgs::ops
+    uint32_t pad[3];
+};
+#define FW_RANGE_OLD 0u
+#define FW_RANGE_NEW 1u
+#define FW_RANGE_YOUNG 2u
+struct alignas(16) FwRangeDesc {  // per workgroup (device table, re-sent only when a bound leaves its band)
+    uint32_t seg;
+    uint32_t role_k;     // role << 30 | index of the workgroup within its role and segment
+    uint32_t old_first;  // global index of the segment's first OLD workgroup (look-back window)
+    uint32_t type_idx;   // | FW_TYPE_IDX_NOSPIN
+    uint32_t keys_off, keys_len;
+    uint32_t pad[2];
+};
+struct FwRangeArgs {
+    const FwRangeDesc *desc;
+    const FwRangeRec *recs;         // [max_seg] indexed by segment (pinned host)
+    const FwOp *ops;                // this frame's spawn ops of range segments (pinned host)
+    unsigned long long *status;     // look-back words of the OLD workgroups, by global workgroup index
+    uint32_t total_tiles, parity, epoch, spin_limit, dbg;
+    float dt;
+    unsigned long long *done_tag;   // as in FwUpdateArgs
+    unsigned long long done_value;
+    unsigned long long *host_counts;
+    unsigned long long *live_out, *live_next;
+};
+#define FW_RANGE_MAX_CAPACITY 0x10000000u  // slots are addressed as 32-bit byte offsets into a float4 plane
+
 enum { FW_SPAWN_NONE = 0, FW_SPAWN_INLINE = 1, FW_SPAWN_TABLE = 2 };
 
 enum { FW_MODE_FUSED = 0, FW_MODE_SPLIT = 1, FW_MODE_SPLIT_COLL = 2 };  // SPLIT_COLL: frames with colliding particle types
@@ -159,6 +206,9 @@ hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArg
 // in-place update of up to FW_FIFO_PER_LAUNCH FIFO segments (their spawn ops in `inl`)
 hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifoArgs &a, const FwInlineOps &inl,
                                  uint32_t total_tiles, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// in-place update of every range ring of the context (all_nospin: no segment of the launch keeps a rotation plane)
+hipError_t fw_launch_update_range(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin,
+                                  hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d_ops, const FwNestOp *h_ops, uint32_t n_ops,
                             uint32_t total_tiles, uint32_t parity, uint32_t tag, uint32_t spin_limit, uint32_t dbg = 0);
 // SoA -> AoS gather of `n` particles of one segment buffer into fw_particle records (device)
@@ -174,14 +224,18 @@ hipError_t fw_launch_scatter(hipStream_t s, char *buf, uint32_t capacity, uint32
                              const void *d_in);
 // fills the base / emissive colour planes of one (buf1 == nullptr) or both buffers of a segment (capacity slots each)
 hipError_t fw_launch_fill_colors(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, const float bc[4], const float em[4]);
+// (range_y != 0xFFFFFFFF: a range ring -- `head` is the slot of its first YOUNG particle and particle 0 sits
+// (count - range_y) slots before it)
 hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, const uint32_t *d_count,
-                                    uint32_t n_upper, void *d_out, const float *const_rot = nullptr);
+                                    uint32_t n_upper, void *d_out, const float *const_rot = nullptr,
+                                    uint32_t range_y = 0xFFFFFFFFu);
 // fills the rotation plane of both buffers of a segment (a type leaves FW_TYPE_NOSPIN)
 hipError_t fw_launch_fill_rotation(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, const float rot[4]);
 // seg_ids: host array; d_part: device scratch of 256 * 8 floats; h_out8: PINNED host {min.xyz, any, max.xyz, -}
-// seg_heads: ring heads of the segments (host array, or null = all 0)
+// seg_heads: ring heads of the segments (host array, or null = all 0); seg_range_y (or null): per segment 0xFFFFFFFF, or --
+// a range ring -- its young count: seg_heads[i] is then the slot of its first young particle (see fw_launch_pack_instances)
 hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, const uint32_t *seg_heads, uint32_t n_segs,
-                          uint32_t parity, float *d_part, float *h_out8);
+                          uint32_t parity, float *d_part, float *h_out8, const uint32_t *seg_range_y = nullptr);
 // the same query answered from the per-tile boxes of the last update (epoch = that update's)
 hipError_t fw_launch_aabb_from_tiles(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, uint32_t n_segs,
                                      uint32_t parity, uint32_t epoch, const uint32_t *d_seg_tile_first, float *h_out8);

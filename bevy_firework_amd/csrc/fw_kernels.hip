@@ -1781,6 +1781,256 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Range rings (fw_kernels.h: FwRangeRec): update_particles IN PLACE for particle types whose lifetime is a range.
+// Three kinds of workgroups in one launch, dispatched in this order:
+//   OLD    1024 particles of the part of the list that may lose particles this frame (age + dt >= lifetime.min),
+//          counted from the young part downwards.  The whole input of the tile is held in registers before its survivor
+//          count is published; the exclusive count of the tiles nearer to the young part (decoupled look-back, those
+//          tiles have lower workgroup indices) is the tile's output offset; survivors are integrated and stored
+//          packed against the young part, order kept (core.rs:589-659).  The last active OLD tile of a segment knows
+//          the total and does the segment's bookkeeping.
+//   NEW    256 of this frame's new particles: spawn_particles (core.rs:437-469) + their first update, each in the slot
+//          it will live in (behind the young part).
+//   YOUNG  a ring tile of 1024 slots: in place, like fw_k_update_fifo without the death test.
+// Slots are addressed as 32-bit byte offsets from the plane base (capacity <= FW_RANGE_MAX_CAPACITY).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void fw_store_destroyed_vals(char *dbuf, size_t d, const FwType &T, float4 q0, float4 q1, float4 q2,
+                                                        float4 q3, float age_new, const float bc[4], const float em[4], float sc) {
+    float *rec = reinterpret_cast<float *>(dbuf) + d * 26;
+    q2 = fw_record_rotation(T, q2);
+    rec[0] = q0.x, rec[1] = q0.y, rec[2] = q0.z;
+    rec[3] = q1.x, rec[4] = q1.y, rec[5] = q1.z;
+    rec[6] = q2.x, rec[7] = q2.y, rec[8] = q2.z, rec[9] = q2.w;
+    rec[10] = q3.x, rec[11] = q3.y, rec[12] = q3.z;
+    rec[13] = q1.w, rec[14] = sc, rec[15] = age_new, rec[16] = q3.w;
+    rec[17] = bc[0], rec[18] = bc[1], rec[19] = bc[2], rec[20] = bc[3];
+    rec[21] = em[0], rec[22] = em[1], rec[23] = em[2], rec[24] = em[3];
+    reinterpret_cast<int32_t *>(rec)[25] = T.pbr;
+}
+
+template <bool ALLNOSPIN>
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
+    constexpr int BLK = FW_BLOCK;
+    constexpr int NW = BLK / 64;
+    constexpr int R = FW_TILE / BLK;
+    constexpr int LBW = 4;
+    constexpr uint32_t TILE = FW_TILE;
+    __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
+    __shared__ uint32_t s_cnt[R][NW];
+    __shared__ uint32_t s_lb[2 * LBW * NW];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const FwRangeDesc &D = a.desc[blockIdx.x];  // block-uniform: scalar loads
+    const uint32_t seg = D.seg, role = D.role_k >> 30, k = D.role_k & 0x3FFFFFFFu;
+    const bool nospin = ALLNOSPIN || (D.type_idx & FW_TYPE_IDX_NOSPIN) != 0u;
+    const uint32_t m2 = nospin ? 0u : 0xFFFFFFFFu;
+    const uint32_t keys_off = D.keys_off, keys_len = D.keys_len;
+    const float key0 = tid < keys_len ? g.keys[keys_off + tid] : 0.0f;
+    const FwRangeRec &Rc = a.recs[seg];  // pinned host memory
+    const uint32_t b = Rc.b, y_exist = Rc.y_exist, n_spawn_h = Rc.n_spawn;
+    const FwSeg *Sp = &g.segs[seg];
+    const uint32_t C = Sp->capacity;
+    char *buf = Sp->buf[0];
+    const uint32_t sidx = a.parity * g.max_seg + seg, oidx = (a.parity ^ 1u) * g.max_seg + seg;
+    if (blockIdx.x == 0 && tid == 0) {
+        if (a.live_next) *a.live_next = 0ull;
+        if (a.done_tag) *a.done_tag = a.done_value;
+    }
+    const char *p0 = buf + FW_OFF_Q0(C), *p1 = buf + FW_OFF_Q1(C), *p2 = buf + FW_OFF_Q2(C), *p3 = buf + FW_OFF_Q3(C);
+    const char *pl = buf + FW_OFF_L(C, Sp->n_lplanes);  // lifetimes of a type that cannot turn (FwOutWin::lf)
+
+    if (role == FW_RANGE_YOUNG) {
+        // ---- in place: a lane owns its slot from load to store
+        const uint32_t ring_tiles = C / TILE;
+        const uint32_t need = min(ring_tiles, (b % TILE + y_exist + TILE - 1u) / TILE);
+        if (k >= need) return;
+        uint32_t pt = b / TILE + k;
+        if (pt >= ring_tiles) pt -= ring_tiles;
+        const uint32_t sbase = pt * TILE;
+        float4 q0c, q1c, q2c, q3c, q0n, q1n, q2n, q3n;
+        float lfc, lfn;
+        const uint32_t i0 = (sbase + tid) * 16u, i1 = (sbase + (uint32_t)min(1, R - 1) * BLK + tid) * 16u;
+        q0c = fw_ld4w(p0, i0), q3c = fw_ld4w(p3, i0 & m2), lfc = fw_ld1w(m2 ? p0 : pl, m2 ? 0u : i0 / 4u);
+        q1c = fw_ld4w(p1, i0), q2c = fw_ld4w(p2, i0 & m2);
+        q0n = fw_ld4w(p0, i1), q3n = fw_ld4w(p3, i1 & m2), lfn = fw_ld1w(m2 ? p0 : pl, m2 ? 0u : i1 / 4u);
+        q1n = fw_ld4w(p1, i1), q2n = fw_ld4w(p2, i1 & m2);
+        const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
+        if (tid < keys_len) s_keys[tid] = key0;
+        for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
+        __syncthreads();
+        const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t s = sbase + r * BLK + tid;
+            const uint32_t in_ = (sbase + (uint32_t)min(r + 2, R - 1) * BLK + tid) * 16u;  // two rounds ahead (the last re-read)
+            const float4 q0f = fw_ld4w(p0, in_), q3f = fw_ld4w(p3, in_ & m2);
+            const float lff = fw_ld1w(m2 ? p0 : pl, m2 ? 0u : in_ / 4u);
+            const float4 q1f = fw_ld4w(p1, in_), q2f = fw_ld4w(p2, in_ & m2);
+            if (nospin) q3c = make_float4(0.0f, 0.0f, 0.0f, lfc);
+            uint32_t yi = s - b;  // index within the young part
+            if (s < b) yi += C;
+            const bool mine = yi < y_exist;
+            float age_new;
+            const bool surv = fw_survives(q0c.w, a.dt, q3c.w, &age_new);
+            bad |= mine && !surv;  // the host's cohort ages say nobody young can die
+            if (mine) fw_integrate_store<true, -1>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s);
+            q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n, lfc = lfn;
+            q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f, lfn = lff;
+        }
+        if (__any(bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 7u, g.err[6] = seg, g.err[7] = blockIdx.x;
+        return;
+    }
+
+    const uint32_t cnt_in = g.count[sidx];
+    const uint32_t n_old_in = cnt_in > y_exist ? cnt_in - y_exist : 0u;
+    // (what does not fit is dropped and reported, as everywhere: the host grows a segment before its bound reaches the capacity)
+    const uint32_t room = C - min(C, n_old_in + y_exist);
+    const uint32_t n_spawn = min(n_spawn_h, room);
+
+    if (role == FW_RANGE_NEW) {
+        if (k * BLK >= n_spawn_h) return;
+        const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
+        if (tid < keys_len) s_keys[tid] = key0;
+        for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
+        __syncthreads();
+        const uint32_t kk = k * BLK + tid;
+        if (kk >= n_spawn) {
+            if (kk < n_spawn_h && kk == n_spawn) atomicOr(g.err, FW_ERR_CAPACITY);
+            return;
+        }
+        uint32_t s = b + y_exist;  // < 2 C
+        if (s >= C) s -= C;
+        s += kk;                   // < 2 C
+        if (s >= C) s -= C;
+        uint32_t oi = Rc.op0;
+        for (uint32_t x = Rc.op0; x < Rc.op0 + Rc.op_n; x++)
+            if (kk >= a.ops[x].rel_base && kk - a.ops[x].rel_base < a.ops[x].n) oi = x;
+        const FwOp &op = a.ops[oi];
+        const FwSpawnOut so = fw_spawn_one(g.emits[op.emit], g.seed, op.serial_base + (kk - op.rel_base),
+                                           fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
+                                           fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
+                                           fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
+        float age_new;
+        const bool surv = fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);
+        if (!surv) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 8u, g.err[6] = seg, g.err[7] = kk;
+        // (the colour plane of a constant gradient holds that colour in every slot since the buffer was allocated)
+        const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
+        fw_integrate_store<false, -1>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s);
+        return;
+    }
+
+    // ---- OLD: in-place compaction towards the young part.  Distance d from the young part: slot = b - 1 - d.
+    const uint32_t base = k * TILE;
+    const bool want_destroyed_any = Sp->destroyed != nullptr;
+    if (base >= n_old_in) {
+        if (k == 0u && tid == 0u) {  // nobody old: the segment's bookkeeping is still this workgroup's
+            const uint32_t nc = y_exist + n_spawn;
+            g.count[oidx] = nc, g.spawned[oidx] = 0, g.appended[oidx] = 0, g.ndestroyed[seg] = 0;
+            if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;
+            if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
+            if (!(a.dbg & 128u)) atomicAdd(g.stats, (unsigned long long)nc);
+        }
+        return;
+    }
+    const uint32_t lim = min(base + TILE, n_old_in);
+    const uint32_t bm1 = b + C - 1u;
+    float4 q0[R], q1[R], q2[R], q3[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t d = min(base + r * BLK + tid, lim - 1u);
+        uint32_t s = bm1 - d;  // in [0, 2 C)
+        if (s >= C) s -= C;
+        q0[r] = fw_ld4w(p0, s * 16u);
+        q3[r] = fw_ld4w(p3, (s * 16u) & m2);
+        const float lf = fw_ld1w(m2 ? p0 : pl, m2 ? 0u : s * 4u);
+        q1[r] = fw_ld4w(p1, s * 16u);
+        q2[r] = fw_ld4w(p2, (s * 16u) & m2);
+        if (nospin) q3[r] = make_float4(0.0f, 0.0f, 0.0f, lf);
+    }
+    const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
+    if (tid < keys_len) s_keys[tid] = key0;
+    for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
+    float age_new[R];
+    unsigned long long m[R];
+    // Everything this tile will ever read from its slots is in registers before it publishes: the tiles that wait for
+    // its count go on to overwrite those slots.  So every wave's count passes, on its way to LDS (and from there, behind
+    // the barrier, into the published word), through an opaque instruction that also consumes one component of every
+    // loaded vector (a load returns whole): the compiler must have waited for all of them before the count exists.
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const bool valid = base + r * BLK + tid < lim;
+        const bool alive = valid && fw_survives(q0[r].w, a.dt, q3[r].w, &age_new[r]);
+        m[r] = __ballot(alive);
+        uint32_t c = (uint32_t)__popcll(m[r]);
+        asm volatile("; fw_k_update_range: input held before the count is published"
+                     : "+v"(c) : "v"(q0[r].x), "v"(q1[r].x), "v"(q2[r].x), "v"(q3[r].w));
+        if (lane == 0) s_cnt[r][wave] = c;
+    }
+    __syncthreads();
+    uint32_t tile_surv = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int w = 0; w < NW; w++) tile_surv += s_cnt[r][w];
+    const uint32_t tile = blockIdx.x;
+    uint32_t excl = 0;
+    if (k != 0u) {
+        if (tid == 0) __hip_atomic_store(&a.status[tile], fw_pack_status(a.epoch, FW_ST_AGG, tile_surv), RLX, AGENT);
+        bool timed_out = false;
+        excl = fw_lookback<BLK, NW, LBW>(a.status, D.old_first, tile, a.epoch, a.spin_limit * 64u + 1024u, s_lb, &timed_out);
+        // (no recount is possible: a predecessor that has not published may not have read its slots yet.  Predecessors have
+        // lower workgroup indices, so they are resident or done: the wait is bounded.)
+        if (timed_out && tid == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 9u, g.err[6] = seg, g.err[7] = tile;
+    }
+    if (tid == 0) __hip_atomic_store(&a.status[tile], fw_pack_status(a.epoch, FW_ST_INCL, excl + tile_surv), RLX, AGENT);
+    const bool want_destroyed = T.report_destroyed && want_destroyed_any;
+    const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
+    uint32_t run = excl;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        uint32_t wbase = run;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t c = s_cnt[r][w];
+            if ((uint32_t)w < wave) wbase += c;
+            run += c;
+        }
+        const uint32_t d = base + r * BLK + tid;
+        const bool valid = d < lim;
+        const bool alive = (m[r] >> lane) & 1ull;
+        const uint32_t od = wbase + fw_lane_prefix(m[r]);  // survivors nearer to the young part = the new distance
+        if (alive) {
+            uint32_t s = bm1 - od;
+            if (s >= C) s -= C;
+            fw_integrate_store<false, -1>(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], W, s);
+        } else if (valid && want_destroyed) {
+            // destroyed record (core.rs:596-599): the clone with the age advanced, pose, colours and scale of the previous
+            // frame.  The colour and scale planes of the slot hold what the previous update computed from the age that was
+            // just loaded: evaluated again here (same functions, same inputs) instead of being read -- the slot may
+            // already belong to somebody else.  Records are filled from the END of the buffer (the youngest dead first):
+            // fw_spawner_read_destroyed reads the last `ndestroyed` records, which are then in list order.
+            const float ap = q0[r].w / q3[r].w;
+            float bc[4], em[4];
+            fw_gradient_sample(T.bc_kind, T.bc_n, s_keys + T.o_bc_t, s_keys + T.o_bc_v, ap, bc);
+            fw_gradient_sample(T.em_kind, T.em_n, s_keys + T.o_em_t, s_keys + T.o_em_v, ap, em);
+            const float sc = q1[r].w * fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, ap);
+            const uint32_t dead_rank = d - od;  // the dead nearer to the young part
+            fw_store_destroyed_vals(Sp->destroyed, (size_t)(C - 1u - dead_rank), T, q0[r], q1[r], q2[r], q3[r], q0[r].w + a.dt, bc, em, sc);
+        }
+    }
+    if (lim == n_old_in && tid == 0) {  // the tile furthest from the young part knows the totals
+        const uint32_t n_old_out = excl + tile_surv;
+        const uint32_t nc = n_old_out + y_exist + n_spawn;
+        g.count[oidx] = nc, g.spawned[oidx] = 0, g.appended[oidx] = 0;
+        g.ndestroyed[seg] = n_old_in - n_old_out;
+        if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;
+        if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
+        if (!(a.dbg & 128u)) atomicAdd(g.stats, (unsigned long long)(n_old_in + y_exist + n_spawn));
+    }
+}
+
 // split mode, pass 1: survivors per tile
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_count(FwGlobals g, FwUpdateArgs a) {
     __shared__ uint32_t s_c[4];
@@ -2259,8 +2509,12 @@ __global__ void fw_k_restore_q3(char *buf0, char *buf1, uint32_t C, uint32_t lif
 // transposed through LDS so that every store instruction of a wave writes 1 KiB of consecutive bytes (a lane writing
 // its own record with four float4 stores would touch 64 lines a quarter at a time).
 __global__ __launch_bounds__(256) void fw_k_pack(const char *buf, uint32_t C, uint32_t head, const uint32_t *d_count,
-                                                 uint32_t n_upper, float4 *out, bool nospin, float4 rot) {
+                                                 uint32_t n_upper, float4 *out, bool nospin, float4 rot, uint32_t range_y) {
     __shared__ float4 s_rec[256 * 4];
+    if (range_y != 0xFFFFFFFFu) {  // a range ring: `head` is the slot of the first young particle (fw_kernels.h)
+        const uint32_t c = *d_count, n_old = c > range_y ? c - range_y : 0u;
+        head = head >= n_old ? head - n_old : head + C - n_old;
+    }
     const uint32_t n = min(*d_count, n_upper);
     const uint32_t tid = threadIdx.x;
     for (uint32_t b = blockIdx.x * 256u; b < n; b += gridDim.x * 256u) {
@@ -2313,6 +2567,7 @@ struct FwSegList {
     uint32_t n;
     uint32_t id[8];    // FW_MAX_TYPES
     uint32_t head[8];  // slot of each segment's particle 0 (FIFO rings; 0 otherwise)
+    uint32_t range_y[8];  // 0xFFFFFFFF, or -- a range ring -- its young count: head[] is the slot of its first young particle
 };
 #define FW_AABB_BLOCKS 256u
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, FwSegList L, uint32_t parity, float *part8) {
@@ -2324,8 +2579,13 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, FwSegList L, 
         const FwSeg &S = g.segs[seg];
         const uint32_t n = g.count[parity * g.max_seg + seg];
         const char *buf = S.buf[parity];
+        uint32_t head = L.head[k];
+        if (L.range_y[k] != 0xFFFFFFFFu) {
+            const uint32_t n_old = n > L.range_y[k] ? n - L.range_y[k] : 0u;
+            head = head >= n_old ? head - n_old : head + S.capacity - n_old;
+        }
         for (uint32_t li = blockIdx.x * FW_BLOCK + threadIdx.x; li < n; li += gridDim.x * FW_BLOCK) {
-            const uint32_t i = fw_ring_slot(L.head[k], li, S.capacity);
+            const uint32_t i = fw_ring_slot(head, li, S.capacity);
             const float4 q0 = fw_ld4(buf + FW_OFF_Q0(S.capacity), i);
             const float sc = fw_ld1(buf + FW_OFF_S4(S.capacity), i);
             mn[0] = fminf(mn[0], q0.x - sc), mn[1] = fminf(mn[1], q0.y - sc), mn[2] = fminf(mn[2], q0.z - sc);
@@ -2566,6 +2826,17 @@ hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifo
     return hipGetLastError();
 }
 
+hipError_t fw_launch_update_range(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin, hipEvent_t e0,
+                                  hipEvent_t e1) {
+    if (!a.total_tiles) return hipErrorInvalidValue;
+    const dim3 grid(a.total_tiles), block(FW_BLOCK);
+    if (all_nospin)
+        FW_LAUNCH_T((fw_k_update_range<true>), grid, block, s, e0, e1, g, a);
+    else
+        FW_LAUNCH_T((fw_k_update_range<false>), grid, block, s, e0, e1, g, a);
+    return hipGetLastError();
+}
+
 hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d_ops, const FwNestOp *h_ops, uint32_t n_ops,
                             uint32_t total_tiles, uint32_t parity, uint32_t tag, uint32_t spin_limit, uint32_t dbg) {
     if (!n_ops || !total_tiles) return hipSuccess;
@@ -2619,22 +2890,23 @@ hipError_t fw_launch_fill_rotation(hipStream_t s, char *buf0, char *buf1, uint32
 }
 
 hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, const uint32_t *d_count,
-                                    uint32_t n_upper, void *d_out, const float *const_rot) {
+                                    uint32_t n_upper, void *d_out, const float *const_rot, uint32_t range_y) {
     if (!n_upper) return hipSuccess;
     uint32_t blocks = (n_upper + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     const float4 rot = const_rot ? make_float4(const_rot[0], const_rot[1], const_rot[2], const_rot[3]) : make_float4(0.f, 0.f, 0.f, 1.f);
     hipLaunchKernelGGL(fw_k_pack, dim3(blocks), dim3(256), 0, s, buf, capacity, head, d_count, n_upper, (float4 *)d_out,
-                       const_rot != nullptr, rot);
+                       const_rot != nullptr, rot, range_y);
     return hipGetLastError();
 }
 
 hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, const uint32_t *seg_heads, uint32_t n_segs,
-                          uint32_t parity, float *d_part, float *h_out8) {
+                          uint32_t parity, float *d_part, float *h_out8, const uint32_t *seg_range_y) {
     if (!n_segs || n_segs > 8u) return hipErrorInvalidValue;  // FW_MAX_TYPES
     FwSegList L{};
     L.n = n_segs;
-    for (uint32_t i = 0; i < n_segs; i++) L.id[i] = seg_ids[i], L.head[i] = seg_heads ? seg_heads[i] : 0u;
+    for (uint32_t i = 0; i < n_segs; i++)
+        L.id[i] = seg_ids[i], L.head[i] = seg_heads ? seg_heads[i] : 0u, L.range_y[i] = seg_range_y ? seg_range_y[i] : 0xFFFFFFFFu;
     hipLaunchKernelGGL(fw_k_aabb, dim3(FW_AABB_BLOCKS), dim3(FW_BLOCK), 0, s, g, L, parity, d_part);
     hipLaunchKernelGGL(fw_k_aabb_fold, dim3(1), dim3(FW_AABB_BLOCKS), 0, s, g, L, parity, (const float *)d_part, h_out8);
     return hipGetLastError();

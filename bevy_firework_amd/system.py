@@ -136,12 +136,12 @@ class SpawnerData:
             self._sys._ctx, self.handle, particle_type, C.c_void_p(device_ptr) if device_ptr else None, int(capacity)))
 
     def update_path(self, particle_type: int = 0):
-        """("fifo" | "general", bytes one update of a live particle moves, of which algorithmic) -- which kernel family
+        """("fifo" | "range" | "general", bytes one update of a live particle moves, of which algorithmic) -- which kernel family
         updates this type and what it costs per particle (bench.py's roofline accounting)"""
         mode, moved, algo = C.c_int32(), C.c_uint32(), C.c_uint32()
         self._sys._check(self._sys._lib.fw_debug_update_path(self._sys._ctx, self.handle, particle_type, C.byref(mode),
                                                              C.byref(moved), C.byref(algo)))
-        return ("fifo" if mode.value else "general"), int(moved.value), int(algo.value)
+        return {0: "general", 1: "fifo", 2: "range"}[mode.value], int(moved.value), int(algo.value)
 
     def aabb(self):
         """(any, min, max) of position -/+ scale over all particle types (render.rs:677-703)."""

@@ -273,7 +273,8 @@ fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_
 fw_status fw_debug_read_timestamps2(fw_ctx *ctx, unsigned long long *out, unsigned long long *prev, uint64_t max_tiles,
                                     uint64_t *n_tiles);
 fw_status fw_debug_read_launches(fw_ctx *ctx, unsigned long long *out32768, uint32_t *epoch);
-/* which update path a particle type is on (1 = FIFO ring updated in place, 0 = general compacting path), the bytes one
+/* which update path a particle type is on (1 = FIFO ring updated in place, 2 = range ring: young part in place, old part
+ * compacted in place, 0 = general compacting path), the bytes one
  * update of a live particle moves on it, and how many of those are algorithmic (bench.py's roofline accounting) */
 fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner spawner, uint32_t type, int32_t *mode, uint32_t *moved_bytes,
                                uint32_t *algorithmic_bytes);

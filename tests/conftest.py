@@ -30,12 +30,16 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-# Every GPU test runs twice: with constant-lifetime particle types on the in-place FIFO ring path (whatever their size:
-# FW_FIFO_MIN=0) and with that path switched off (FW_FIFO=0: everything on the general, compacting path).  The knobs are
-# read when a context is created, so setting the environment before the test body is enough.
+# Every GPU test runs three times: with constant-lifetime particle types on the in-place FIFO ring path (whatever their
+# size: FW_FIFO_MIN=0), with every eligible particle type -- any lifetime range, no Nested entries in its spawner, no
+# collisions -- on an in-place RANGE ring (FW_RANGE_MIN=0; FIFO rings off, so constant lifetimes take it too), and with
+# both switched off (everything on the general, compacting path).  The knobs are read when a context is created, so setting
+# the environment before the test body is enough.
 def pytest_generate_tests(metafunc):
+    if metafunc.module.__name__.split(".")[-1] == "test_gpu_range":
+        return  # (sets its own knobs: every test of the file is about one path)
     if metafunc.definition.get_closest_marker("gpu") and "fw_path" in metafunc.fixturenames:
-        metafunc.parametrize("fw_path", ["fifo", "general"], indirect=True)
+        metafunc.parametrize("fw_path", ["fifo", "range", "general"], indirect=True)
 
 
 @pytest.fixture(autouse=True)
@@ -44,6 +48,12 @@ def fw_path(request, monkeypatch):
     if mode == "fifo":
         monkeypatch.setenv("FW_FIFO", "1")
         monkeypatch.setenv("FW_FIFO_MIN", "0")
+        monkeypatch.setenv("FW_RANGE", "0")
+    elif mode == "range":
+        monkeypatch.setenv("FW_FIFO", "0")
+        monkeypatch.setenv("FW_RANGE", "1")
+        monkeypatch.setenv("FW_RANGE_MIN", "0")
     elif mode == "general":
         monkeypatch.setenv("FW_FIFO", "0")
+        monkeypatch.setenv("FW_RANGE", "0")
     return mode

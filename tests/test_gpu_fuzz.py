@@ -299,11 +299,13 @@ def test_every_shortcut_gives_the_state_of_the_plain_path(case, monkeypatch):
     dts = [np.float32(x) for x in _steps(np.random.default_rng(32000 + case), 40)]
     on_demand = any(e.emission_pacing.kind == S.PACING_ONDEMAND for e in spawner.emission_settings)
     results = {}
-    for name, env in (("shortcuts", {"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_NOSPIN": "1"}),
-                      ("rings only", {"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_NOSPIN": "0"}),
-                      ("no planes only", {"FW_FIFO": "0", "FW_NOSPIN": "1"}),
-                      ("plain", {"FW_FIFO": "0", "FW_NOSPIN": "0", "FW_FIFO_STREAM": "0"})):
-        for k in ("FW_FIFO", "FW_FIFO_MIN", "FW_NOSPIN", "FW_FIFO_STREAM"):
+    for name, env in (("shortcuts", {"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_NOSPIN": "1", "FW_RANGE": "1", "FW_RANGE_MIN": "0"}),
+                      ("rings only", {"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_NOSPIN": "0", "FW_RANGE": "0"}),
+                      ("range rings only", {"FW_FIFO": "0", "FW_NOSPIN": "0", "FW_RANGE": "1", "FW_RANGE_MIN": "0"}),
+                      ("range rings, no planes", {"FW_FIFO": "0", "FW_NOSPIN": "1", "FW_RANGE": "1", "FW_RANGE_MIN": "0"}),
+                      ("no planes only", {"FW_FIFO": "0", "FW_NOSPIN": "1", "FW_RANGE": "0"}),
+                      ("plain", {"FW_FIFO": "0", "FW_NOSPIN": "0", "FW_FIFO_STREAM": "0", "FW_RANGE": "0"})):
+        for k in ("FW_FIFO", "FW_FIFO_MIN", "FW_NOSPIN", "FW_FIFO_STREAM", "FW_RANGE", "FW_RANGE_MIN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -317,7 +319,7 @@ def test_every_shortcut_gives_the_state_of_the_plain_path(case, monkeypatch):
                 dead_total += sum(len(h.destroyed(t)) for t in range(len(spawner.particle_settings)))
             results[name] = ([h.particles(t) for t in range(len(spawner.particle_settings))], h.aabb(), dead_total)
     ref_parts, ref_box, ref_dead = results["plain"]
-    for name in ("shortcuts", "rings only", "no planes only"):
+    for name in ("shortcuts", "rings only", "range rings only", "range rings, no planes", "no planes only"):
         parts, box, dead = results[name]
         assert dead == ref_dead, (name, dead, ref_dead)
         for t, (a, b) in enumerate(zip(parts, ref_parts)):

@@ -1,0 +1,206 @@
+"""The in-place RANGE ring path (fw_k_update_range: particle types whose lifetime is a range, in spawners without Nested
+entries) against the CPU oracle: the young part of the list is updated in place, the part that may lose particles this
+frame is compacted in place towards it, cohorts join the old part as they age, new particles appear at the tail.  The
+ring wraps, grows while wrapped, leaves the mode when its premise breaks, and everything the ABI can observe (order,
+state, destroyed records in list order, instance records, AABB, live totals) stays the reference's.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+import oracle  # noqa: F401
+from bevy_firework_amd import settings as S
+from bevy_firework_amd import workloads
+from parity import Pair, assert_particles_match
+
+pytestmark = pytest.mark.gpu
+DT = np.float32(1.0 / 60.0)
+SEED = workloads.SEED
+
+
+@pytest.fixture()
+def system(monkeypatch):
+    from bevy_firework_amd.system import ParticleSystem
+
+    monkeypatch.setenv("FW_FIFO", "0")
+    monkeypatch.setenv("FW_RANGE", "1")
+    monkeypatch.setenv("FW_RANGE_MIN", "0")
+    with ParticleSystem(device=0, seed=SEED) as ps:
+        yield ps
+
+
+def _settings(**kw):
+    base = dict(lifetime=S.RandF32(0.15, 0.45), initial_scale=S.RandF32(0.5, 2.0), linear_drag=0.2,
+                scale_curve=S.FireworkCurve.even_samples([1.0, 2.0, 0.5]),
+                base_color=S.FireworkGradient.uneven_samples(workloads.STRESS_GRADIENT))
+    base.update(kw)
+    return S.ParticleSettings(**base)
+
+
+def _emission(rate=11000.0, **kw):
+    base = dict(emission_pacing=S.EmissionPacing.rate(rate),
+                initial_velocity=S.RandVec3(S.RandF32(1.0, 6.0), (0.0, 1.0, 0.0), 0.0), initial_velocity_radial=S.RandF32(0.0, 1.0))
+    base.update(kw)
+    return S.EmissionSettings(**base)
+
+
+def test_small_ring_wraps_many_times_bit_exact(system):
+    """capacity 4096, ~3300 live: the young boundary, the old part and the tail cross the end of the buffer again and again;
+    deaths in every frame (lifetimes 0.15-0.45 s), no trig anywhere -> the whole state and the destroyed records bit-exact
+    every frame"""
+    ps = _settings(capacity=4096, particles_destroyed=lambda dead: None)
+    pair = Pair(system, S.ParticleSpawner([ps], [_emission()]), S.Transform((1.0, 2.0, 3.0)), seed=SEED, uid=3)
+    assert pair.gpu.update_path(0)[0] == "range"
+    for fr in range(260):
+        system.update(DT)
+        pair.step_cpu(DT)
+        pair.check(exact_all=True, what=f"frame {fr}")
+        assert_particles_match(pair.gpu.destroyed(0), pair.cpu.destroyed(0), True, f"destroyed, frame {fr}")
+    assert 2800 < pair.gpu.count(0) < 3800
+    assert pair.gpu.update_path(0)[0] == "range"
+
+
+def test_irregular_dt_zero_steps_and_spinning_particles(system):
+    """any dt >= 0 below the shortest lifetime: no forecast exists on this path, nothing to lose; zero steps; a type whose
+    particles spin (rotation + angular-velocity planes held across the old tiles' look-back) next to one that cannot"""
+    still = _settings(lifetime=S.RandF32(0.2, 0.6))
+    spin = _settings(lifetime=S.RandF32(0.3, 0.5), angular_acceleration=(0.1, 0.0, -0.2), angular_drag=0.3,
+                     particles_destroyed=lambda dead: None)
+    e0 = _emission(9000.0, particle_index=0)
+    e1 = _emission(14000.0, particle_index=1, initial_angular_velocity=S.RandVec3(S.RandF32(1.0, 9.0), (0.0, 0.6, 0.8), 0.5),
+                   emission_shape=S.EmissionShape.Sphere(0.7))
+    pair = Pair(system, S.ParticleSpawner([still, spin], [e0, e1]), seed=SEED, uid=5)
+    assert [pair.gpu.update_path(t)[0] for t in (0, 1)] == ["range", "range"]
+    rng = np.random.default_rng(5)
+    for fr in range(180):
+        dt = np.float32(0.0 if fr % 17 == 3 else rng.uniform(0.002, 0.03))
+        system.update(dt)
+        pair.step_cpu(dt)
+        if fr % 4 == 3:
+            pair.check(what=f"frame {fr}")
+            assert_particles_match(pair.gpu.destroyed(1), pair.cpu.destroyed(1), False, f"destroyed, frame {fr}")
+    assert pair.gpu.count(0) > 2000 and pair.gpu.count(1) > 3000
+    assert [pair.gpu.update_path(t)[0] for t in (0, 1)] == ["range", "range"]
+
+
+def test_growth_while_wrapped_and_bursts(system):
+    """a derived capacity that a OneShot burst and a rising OnDemand load outgrow: the ring is unwrapped into a larger one
+    (old part first) with the young boundary re-based, several times"""
+    ps = _settings(lifetime=S.RandF32(0.4, 1.1))
+    es = [_emission(6000.0), S.EmissionSettings(emission_pacing=S.EmissionPacing.OnDemand(), emission_shape=S.EmissionShape.Sphere(1.0))]
+    pair = Pair(system, S.ParticleSpawner([ps], es), seed=SEED, uid=9)
+    for fr in range(150):
+        if fr in (30, 31, 60, 90):
+            pair.queue(9000 * (1 + fr // 30))
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr % 5 == 4 or fr in (30, 31, 32, 60, 61, 90, 91):
+            pair.check(what=f"frame {fr}")
+    assert pair.gpu.update_path(0)[0] == "range" and pair.gpu.count(0) > 4000
+
+
+def test_readers_see_list_order(system):
+    """instance records (packing pass: the kernel derives particle 0's slot from the device count), AABB, last_emitted_age
+    (never touched: f32::MIN) and the per-frame live totals in a registered device ring"""
+    import torch
+
+    ps = _settings(capacity=8192)
+    pair = Pair(system, S.ParticleSpawner([ps], [_emission(13000.0)]), S.Transform((0.5, 0.0, -1.0)), seed=SEED, uid=21)
+    live = torch.zeros(8, dtype=torch.int64, device="cuda")
+    for fr in range(100):
+        if fr == 40:
+            system.live_count_ring(live.data_ptr(), 8)
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr % 9 == 8:
+            parts, inst = pair.gpu.particles(0), pair.gpu.instances(0)
+            ref = pair.cpu.particles(0)
+            assert_particles_match(parts, ref, True, f"frame {fr}")
+            for a, b in (("position", "position"), ("scale", "scale"), ("rotation", "rotation"), ("base_color", "base_color")):
+                assert np.array_equal(inst[a], ref[b]), (fr, a)
+            any_, mn, mx = pair.gpu.aabb()
+            lo = (ref["position"] - ref["scale"][:, None]).min(axis=0)
+            hi = (ref["position"] + ref["scale"][:, None]).max(axis=0)
+            assert any_ and np.array_equal(mn, lo) and np.array_equal(mx, hi), fr
+            assert (pair.gpu.last_emitted(0, 0) == np.float32(-3.40282347e+38)).all()
+        if fr >= 40:
+            torch.cuda.synchronize()
+            assert int(live[(fr - 40) % 8].item()) == pair.cpu.count(0), fr
+    system.live_count_ring(0, 0)
+
+
+def test_leaving_the_mode(system):
+    """what ends it: particles written by the caller, an attached instance buffer, a step as long as the shortest lifetime,
+    a negative step -- each continues on the compacting path with the reference's state"""
+    import torch
+
+    def make(uid):
+        return Pair(system, S.ParticleSpawner([_settings(lifetime=S.RandF32(0.3, 0.8), capacity=8192)], [_emission(9000.0)]), seed=SEED, uid=uid)
+
+    pairs = [make(30 + k) for k in range(4)]
+    buf = torch.full((8192 * 16,), float("nan"), dtype=torch.float32, device="cuda")
+    for fr in range(90):
+        if fr == 40:
+            parts = pairs[0].cpu.particles(0).copy()
+            parts["age"] = np.linspace(0.0, 0.29, len(parts), dtype=np.float32)  # no longer in spawn order
+            pairs[0].gpu.write_particles(0, parts), pairs[0].cpu.write_particles(0, parts)
+            pairs[1].gpu.attach_instances(buf.data_ptr(), 8192)
+        dt = np.float32(0.31 if fr == 55 else DT)  # 0.31 s >= lifetime.min: new particles could die in their first step
+        system.update(dt)
+        for p in pairs:
+            p.step_cpu(dt)
+        if fr % 6 == 5 or fr in (40, 41, 55, 56):
+            for k, p in enumerate(pairs):
+                p.check(exact_all=True, what=f"frame {fr} spawner {k}")
+        if fr == 39:
+            assert all(p.gpu.update_path(0)[0] == "range" for p in pairs)
+        if fr == 50:
+            assert [p.gpu.update_path(0)[0] for p in pairs] == ["general", "general", "range", "range"]
+            n = pairs[1].gpu.count(0)
+            got = buf[: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
+            assert np.array_equal(got, pairs[1].gpu.instances(0).view(np.uint32).reshape(n, 16))
+    assert all(p.gpu.update_path(0)[0] == "general" for p in pairs)
+    system.update(np.float32(-0.01))
+    for p in pairs:
+        p.step_cpu(np.float32(-0.01))
+        p.check(exact_all=True, what="negative step")
+
+
+def test_many_segments_in_one_launch_with_churn(system):
+    """forty spawners (two types each, one of them with a constant lifetime: more rings than the eight FIFO records of a
+    launch could hold) in one context: one launch updates all of them; spawners are rebuilt and despawned along the way"""
+    rng = np.random.default_rng(11)
+    pairs = []
+    for k in range(40):
+        a = _settings(lifetime=S.RandF32(0.2 + 0.01 * k, 0.5 + 0.02 * k), linear_drag=0.1 + 0.01 * k)
+        b = _settings(lifetime=S.RandF32.constant(0.3 + 0.01 * k), scale_curve=S.FireworkCurve.constant(1.0))
+        es = [_emission(float(rng.uniform(500.0, 6000.0)), particle_index=0), _emission(float(rng.uniform(500.0, 3000.0)), particle_index=1)]
+        pairs.append(Pair(system, S.ParticleSpawner([a, b], es), S.Transform((float(k), 0.0, 0.0)), seed=SEED, uid=100 + k))
+    assert all(p.gpu.update_path(t)[0] == "range" for p in pairs for t in (0, 1))
+    for fr in range(120):
+        if fr == 50:
+            pairs[3].gpu.update_settings(pairs[3].spawner)  # sync_spawner_data: emission state reset, particles dropped
+            pairs[3].cpu.reset()
+            system.despawn(pairs[7].gpu)
+            pairs.pop(7)
+        system.update(DT)
+        for p in pairs:
+            p.step_cpu(DT)
+        if fr % 15 == 14 or fr in (50, 51):
+            for k, p in enumerate(pairs):
+                p.check(exact_all=True, what=f"frame {fr} spawner {k}")
+    assert sum(sum(p.gpu.counts()) for p in pairs) > 50000
+
+
+def test_steady_state_at_a_million(system):
+    """1.1M particles with lifetimes 0.6-1.4 s in one ring (hundreds of old tiles look back in one chain) for 150 frames:
+    counts, order and every field against the oracle at three frames"""
+    ps = S.ParticleSettings(lifetime=S.RandF32(0.6, 1.4), linear_drag=0.1, scale_curve=S.FireworkCurve.even_samples([1.0, 2.0]),
+                            base_color=S.FireworkGradient.even_samples([(1.0, 1.0, 1.0, 1.0), (0.0, 0.0, 0.0, 0.0)]))
+    es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(1.1e6), initial_velocity=S.RandVec3(S.RandF32(0.0, 10.0), (0.0, 1.0, 0.0), 0.0))
+    pair = Pair(system, S.ParticleSpawner([ps], [es]), seed=SEED, uid=44)
+    assert pair.gpu.update_path(0)[0] == "range"
+    for fr in range(150):
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr in (40, 100, 149):
+            pair.check(exact_all=True, what=f"frame {fr}")
+    assert pair.gpu.count(0) > 1_000_000
