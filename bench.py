@@ -335,8 +335,9 @@ def main():
             extras["hbm_resident"]["whole_step_ms"] = el / 100 * 1e3
             # ... and with every plane kept (FW_NOSPIN=0: what the kernel moved before planes that cannot change were elided;
             # the knob is read when a context is created)
-        saved_nospin = os.environ.get("FW_NOSPIN")
+        saved_nospin, saved_knobs = os.environ.get("FW_NOSPIN"), os.environ.get("FW_ENABLE_KNOBS")
         os.environ["FW_NOSPIN"] = "0"
+        os.environ["FW_ENABLE_KNOBS"] = "1"  # (the library honours its A/B switches only with this set)
         try:
             with ParticleSystem(device=local_rank, seed=workloads.SEED, stream=stream.cuda_stream) as p2b:
                 for e, (s_, tf_) in enumerate(workloads.many_emitters(256, 65536)):
@@ -352,6 +353,10 @@ def main():
                 del os.environ["FW_NOSPIN"]
             else:
                 os.environ["FW_NOSPIN"] = saved_nospin
+            if saved_knobs is None:
+                del os.environ["FW_ENABLE_KNOBS"]
+            else:
+                os.environ["FW_ENABLE_KNOBS"] = saved_knobs
         # (b') the ring path far beyond the Infinity Cache: configs[1]'s emitter at 16x the rate (16.4M particles in one ring)
         with ParticleSystem(device=local_rank, seed=workloads.SEED, stream=stream.cuda_stream) as p3:
             s_, tf_ = workloads.one_million(rate=16.0 * args.rate)

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/firework_hip.h"
+#include "../../include/firework_hip_debug.h"
 #include "fw_kernels.h"
 #include "fw_math.h"
 
@@ -87,6 +88,8 @@ struct alignas(64) SegHost {
     bool in_use = false;
     bool nested_fed = false;    // receives Nested children: count not host-predictable
     bool collides = false;      // the type has collision settings (core.rs:137-138): frames run the collision path
+                                // (also set for a type whose curve keys exceed the LDS staging area: the same feature
+                                // kernels read them from device memory -- SegHost::bigkeys)
     bool auto_capacity = false; // capacity was derived (fw_particle_settings.capacity == 0): the library may grow it
     bool win_ok = false;
     uint32_t capacity = 0;
@@ -103,7 +106,9 @@ struct alignas(64) SegHost {
     int spawner = -1, type = -1;
     uint32_t type_idx = 0, n_lplanes = 0;
     uint32_t keys_off = 0, keys_len = 0;  // key pool window of the segment's type
-    int32_t lplane_emission[FW_MAX_EMISSIONS];
+    uint32_t keys_cap = 0;                // ... and the floats reserved for it (returned to fw_ctx::free_keys with the type)
+    bool bigkeys = false;                 // more keys than the streaming kernels stage in LDS (FW_KEYS_MAX floats)
+    std::vector<int32_t> lplane_emission;  // [n_lplanes] the emission entry each last_emitted_age plane belongs to
     char *buf[2] = {nullptr, nullptr};
     char *destroyed = nullptr;
     uint32_t inst_cap = 0;
@@ -181,6 +186,7 @@ struct alignas(64) SegHost {
     };
     std::deque<YCohort> ycoh;  // the young cohorts, oldest first
     uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
+    uint32_t r_low[3] = {0, 0, 0};               // frames in a row a role's need has been far below what is provided
     bool ring() const { return fifo || range; }  // one buffer, particle 0 not in slot 0
 };
 
@@ -211,7 +217,7 @@ struct FwLevel {  // ops of one emission index (spawn order inside a frame: core
 };
 
 struct fw_ctx {
-    FwLevel levels[FW_MAX_EMISSIONS];  // per-frame scratch of fw_step
+    std::vector<FwLevel> levels;  // per-frame scratch of fw_step: one entry per emission index in use
     std::vector<FwOp> ops_scratch;
     std::vector<uint32_t> grow_scratch;  // fw_step: Nested-fed segments past half their capacity
     // device staging of the record-format copies (read_particles / write_particles / pack_instances): ONE allocation that
@@ -262,6 +268,9 @@ struct fw_ctx {
     // table slots of destroyed / rebuilt spawners, reused by the next build (a type owns the key window
     // [type_idx * FW_KEYS_MAX, +FW_KEYS_MAX) of the key pool, so windows are recycled with their type)
     std::vector<uint32_t> free_types, free_emits, free_emit_slots;
+    // the key pool: every type owns a window sized for its own curves (any number of samples, curve.rs:40-75)
+    size_t keys_end = 0;                                      // floats handed out so far
+    std::vector<std::pair<uint32_t, uint32_t>> free_keys;     // {offset, length} of windows of released types
 
     FwGlobals g{};
     DevArray<FwSeg> d_segs;
@@ -368,9 +377,13 @@ struct fw_ctx {
     bool rtab_pending = false;
     unsigned long long *d_rstatus = nullptr;  // look-back words of the OLD workgroups
     char *h_rparam[kParamRing] = {};          // pinned per-frame records + ops, read by the kernel in place
+    char *d_rparam[kParamRing] = {};          // FW_RANGE_DEVREC=1: device copies of them (one H2D copy per frame in the stream)
+    bool range_devrec = false;
+    bool range_fold = false;   // FW_RANGE_FOLD: a handful of new particles ride in the YOUNG workgroups (A/B)
     size_t rparam_bytes = 0;
     uint64_t rslot_frame[kParamRing] = {};    // frame that last used the slot (+1; 0 = free)
     uint64_t rring_seq = 0;
+    uint64_t r_uploads = 0;  // times the range table was re-sent (FW_HOST_PROF prints it)
 
     uint32_t nest_seq = 0;  // launches of fw_k_nest so far (tag of their look-back words)
     // FW_HOST_PROF=1: time spent in the sections of fw_step's host half (printed when the context is destroyed)
@@ -398,6 +411,14 @@ struct fw_ctx {
 
     FwCollider *d_colliders = nullptr;  // device-resident analytic colliders (fw_ctx_set_colliders)
     uint32_t n_colliders = 0;
+    size_t coll_cap = 0;                // records the device table holds
+    // a new set travels as ONE copy in the context's stream (ordered behind the frames that read the old set, in front of the
+    // frames that will read the new one: no synchronisation); the pinned staging is double-buffered
+    FwCollider *h_coll[2] = {nullptr, nullptr};
+    size_t h_coll_cap[2] = {0, 0};
+    hipEvent_t ev_coll[2] = {nullptr, nullptr};
+    bool coll_pending[2] = {false, false};
+    uint64_t coll_seq = 0;
     float *d_aabb = nullptr;   // 256 partial boxes of the AABB query
     float *h_aabb = nullptr;   // pinned result {min.xyz, any, max.xyz, -}
     unsigned long long *d_total = nullptr;
@@ -623,6 +644,9 @@ fw_status ensure_range_arrays(fw_ctx *ctx) {
             ctx->h_rparam[i] = nullptr;
             FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_rparam[i], nb, hipHostMallocDefault));
             memset(ctx->h_rparam[i], 0, nb);
+            if (ctx->d_rparam[i]) hipFree(ctx->d_rparam[i]);
+            ctx->d_rparam[i] = nullptr;
+            FW_HIP(ctx, hipMalloc((void **)&ctx->d_rparam[i], nb));
             ctx->rslot_frame[i] = 0;
         }
         ctx->rparam_bytes = nb;
@@ -802,7 +826,7 @@ fw_status grow_segment(fw_ctx *ctx, uint32_t si, uint32_t need) {
     const SegHost &s = ctx->segs[si];
     const uint32_t ncap = round_up(std::max<uint32_t>((uint32_t)std::min<uint64_t>((uint64_t)need * 5 / 4, 0xFFFF0000ull),
                                                       s.capacity * 2),
-                                   FW_TILE);
+                                   std::max<uint32_t>(FW_TILE, fw_range_young_tile()));
     return realloc_segment(ctx, si, ncap, false);
 }
 
@@ -836,7 +860,7 @@ fw_status leave_nospin(fw_ctx *ctx, uint32_t si) {
 // capacity (derive_capacity) and cannot grow on demand themselves -- their counts are only known on the device -- so
 // they follow the parent now, by the same rule.  Types with a caller-given capacity are left alone.
 fw_status grow_nested_children(fw_ctx *ctx, SpawnerHost &sp, uint32_t parent_type, int depth = 0) {
-    if (depth > FW_MAX_TYPES) return FW_OK;
+    if (depth > (int)sp.types.size()) return FW_OK;
     const double pcap = ctx->segs[sp.seg[parent_type]].capacity;
     for (const EmissionHost &E : sp.em) {
         const fw_emission_settings &es = E.es;
@@ -887,8 +911,7 @@ void copy_curve(CurveCopy &dst, int32_t kind, int32_t n, const float *times, con
 
 fw_status validate_desc(fw_ctx *ctx, const fw_spawner_desc *d) {
     if (!d) return fail(ctx, FW_EINVAL, "null descriptor");
-    if (d->n_particle_settings > FW_MAX_TYPES || d->n_emission_settings > FW_MAX_EMISSIONS)
-        return fail(ctx, FW_EINVAL, "too many particle_settings / emission_settings entries");
+    // (Vec<ParticleSettings> / Vec<EmissionSettings> of any length, core.rs:178-185; the counts are 32-bit here)
     if ((d->n_particle_settings && !d->particle_settings) || (d->n_emission_settings && !d->emission_settings))
         return fail(ctx, FW_EINVAL, "null settings array");
     for (uint32_t i = 0; i < d->n_particle_settings; i++) {
@@ -899,7 +922,6 @@ fw_status validate_desc(fw_ctx *ctx, const fw_spawner_desc *d) {
         const void *ts[3] = {p.scale_curve.times, p.base_color.times, p.emissive_color.times};
         for (int k = 0; k < 3; k++) {
             if (ns[k] < 1) return fail(ctx, FW_EINVAL, "Cannot create curve from 0 samples");  // curve.rs:45,61,211,227
-            if (ns[k] > FW_MAX_KEYS) return fail(ctx, FW_EINVAL, "curve has more than FW_MAX_KEYS keys");
             if (ks[k] < 0 || ks[k] > 2 || !vs[k]) return fail(ctx, FW_EINVAL, "bad curve kind / null values");
             if (ks[k] == FW_CURVE_UNEVEN && !ts[k]) return fail(ctx, FW_EINVAL, "uneven curve without times");
             if (ks[k] == FW_CURVE_UNEVEN && ns[k] >= 2) {
@@ -934,7 +956,8 @@ fw_status validate_desc(fw_ctx *ctx, const fw_spawner_desc *d) {
 // capacity heuristic: expected live count from the emitters feeding a type, x1.25 + slack
 uint32_t derive_capacity(const fw_spawner_desc *d, uint32_t t, const std::vector<uint32_t> &caps) {
     const fw_particle_settings &p = d->particle_settings[t];
-    if (p.capacity) return round_up(std::max<uint32_t>(p.capacity, FW_TILE), FW_TILE);
+    const uint32_t FW_CAP_ROUND = std::max<uint32_t>(FW_TILE, fw_range_young_tile());  // every kernel's tile divides a capacity
+    if (p.capacity) return round_up(std::max<uint32_t>(p.capacity, FW_TILE), FW_CAP_ROUND);
     const double life = std::max(0.0, (double)std::max(p.lifetime.min, p.lifetime.max));
     double need = 0;
     for (uint32_t i = 0; i < d->n_emission_settings; i++) {
@@ -954,7 +977,7 @@ uint32_t derive_capacity(const fw_spawner_desc *d, uint32_t t, const std::vector
     }
     need = need * 1.25 + kMinCapacity;
     if (need > 3.0e9) need = 3.0e9;
-    return round_up((uint32_t)need, FW_TILE);
+    return round_up((uint32_t)need, FW_CAP_ROUND);
 }
 
 void fill_randvec3(const fw_rand_vec3 &r, float &mn, float &mx, float &spread, float dir[4], float arc[4]) {
@@ -974,6 +997,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
     const uint32_t nt = d->n_particle_settings, ne = d->n_emission_settings;
     sp.uid = d->uid;
     sp.starts_enabled = d->starts_enabled;
+    if (ctx->levels.size() < d->n_emission_settings) ctx->levels.resize(d->n_emission_settings);
     sp.types.assign(nt, TypeHost{});
     sp.em.assign(ne, EmissionHost{});
     sp.seg.assign(nt, kNoSeg);
@@ -983,8 +1007,6 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
     if ((st = dev_reserve(ctx, ctx->d_type_coll, ctx->n_types + nt, ctx->n_types))) return st;
     if ((st = dev_reserve(ctx, ctx->d_emits, ctx->n_emits + ne, ctx->n_emits))) return st;
     if ((st = dev_reserve(ctx, ctx->d_emit_serial, ctx->n_emit_slots + ne, ctx->n_emit_slots))) return st;
-    if ((st = dev_reserve(ctx, ctx->d_keys, (size_t)(ctx->n_types + nt) * FW_KEYS_MAX, (size_t)ctx->n_types * FW_KEYS_MAX)))
-        return st;
     if ((st = dev_reserve(ctx, ctx->d_segs, ctx->segs.size() + nt, ctx->segs.size()))) return st;
     if ((st = ensure_max_seg(ctx, (uint32_t)ctx->segs.size() + nt))) return st;
     ctx->g.type_coll = ctx->d_type_coll.d;
@@ -1055,7 +1077,8 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         dt.o_bc_v = put(T.base.values, 4 * T.base.n);
         dt.o_em_t = put(T.emis.times, pad4(T.emis.n));
         dt.o_em_v = put(T.emis.values, 4 * T.emis.n);
-        if (keys.size() > FW_KEYS_MAX) return fail(ctx, FW_EINVAL, "curve keys exceed the LDS staging area");
+        if (keys.size() > 0x3FFFFFFFu) return fail(ctx, FW_EINVAL, "curve keys exceed 2^30 floats");
+        const bool bigkeys = keys.size() > FW_KEYS_MAX;  // beyond the LDS staging area of the streaming kernels
         uint32_t type_idx;
         if (!ctx->free_types.empty()) {
             type_idx = ctx->free_types.back();
@@ -1063,7 +1086,22 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         } else {
             type_idx = ctx->n_types++;
         }
-        dt.keys_off = type_idx * FW_KEYS_MAX;
+        // a window of the key pool: the first released one that is large enough, or fresh floats at the end
+        uint32_t kwin_off = 0, kwin_cap = 0;
+        for (size_t fi = 0; fi < ctx->free_keys.size(); fi++)
+            if (ctx->free_keys[fi].second >= keys.size()) {
+                kwin_off = ctx->free_keys[fi].first, kwin_cap = ctx->free_keys[fi].second;
+                ctx->free_keys.erase(ctx->free_keys.begin() + (long)fi);
+                break;
+            }
+        if (!kwin_cap) {
+            kwin_cap = std::max<uint32_t>(64u, pad4((uint32_t)keys.size()));
+            if ((st = dev_reserve(ctx, ctx->d_keys, ctx->keys_end + kwin_cap, ctx->keys_end))) return st;
+            ctx->g.keys = ctx->d_keys.d;
+            kwin_off = (uint32_t)ctx->keys_end;
+            ctx->keys_end += kwin_cap;
+        }
+        dt.keys_off = kwin_off;
         dt.keys_len = (uint32_t)keys.size();
         // segment: the slot, its type index and the spawner's reference to it are recorded BEFORE anything that can
         // fail, so that release_spawner_segments undoes a build that stops half-way (nothing leaks, nothing dangles)
@@ -1077,7 +1115,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         SegHost &S = ctx->segs[si];
         S = SegHost{};
         S.in_use = true, S.spawner = h, S.type = (int)t, S.type_idx = type_idx;
-        S.keys_off = dt.keys_off, S.keys_len = dt.keys_len;
+        S.keys_off = dt.keys_off, S.keys_len = dt.keys_len, S.keys_cap = kwin_cap, S.bigkeys = bigkeys;
         S.nospin = nospin, S.n_xplanes = nospin ? 1u : 0u;
         memcpy(S.const_rot, dt.const_rot, sizeof S.const_rot);
         sp.seg[t] = si;
@@ -1085,15 +1123,15 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
                               hipMemcpyHostToDevice));
         FW_HIP(ctx, hipMemcpy(ctx->d_types.d + type_idx, &dt, sizeof dt, hipMemcpyHostToDevice));
         FW_HIP(ctx, hipMemcpy(ctx->d_type_coll.d + type_idx, &dc, sizeof dc, hipMemcpyHostToDevice));
-        for (int k = 0; k < FW_MAX_EMISSIONS; k++) S.lplane_emission[k] = -1;
+        S.lplane_emission.clear();
         for (uint32_t i = 0; i < ne; i++) {
             const fw_emission_settings &e = d->emission_settings[i];
             if (e.mode == FW_MODE_NESTED && (uint32_t)e.target_particle_type == t)
-                S.lplane_emission[S.n_lplanes++] = (int32_t)i;
+                S.lplane_emission.push_back((int32_t)i), S.n_lplanes++;
             if (e.mode == FW_MODE_NESTED && (uint32_t)e.particle_index == t) S.nested_fed = true;
         }
         S.auto_capacity = p.capacity == 0;
-        S.collides = p.collision.enabled != 0;
+        S.collides = p.collision.enabled != 0 || bigkeys;
         S.life_bound = (double)std::max(p.lifetime.min, p.lifetime.max);  // lifetime = lerp(min, max, u), u in [0, 1)
         S.win_ok = !S.nested_fed && std::isfinite(S.life_bound);
         {  // FIFO ring (SegHost::fifo): one lifetime value, no collisions; spawners whose particles emit onto their own
@@ -1221,6 +1259,7 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
         SegHost &S = ctx->segs[si];
         if (!S.in_use) continue;
         ctx->free_types.push_back(S.type_idx);
+        if (S.keys_cap) ctx->free_keys.push_back({S.keys_off, S.keys_cap});
         if (S.fifo) ctx->n_fifo--;
         if (S.range) ctx->n_range--, ctx->r_force = true;
         if (S.h_report) hipHostFree(S.h_report);
@@ -1493,6 +1532,10 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if ((e = hipMalloc((void **)&ctx->d_aabb, 256 * 8 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&ctx->d_total, 64)) != hipSuccess) return bail("hipMalloc", e);
     ctx->g.seed = seed;
+    // A/B and debugging switches (firework_hip_debug.h): read only when FW_ENABLE_KNOBS=1 -- a product process does not change
+    // behaviour because of a stray environment variable
+    const char *knobs_on = getenv("FW_ENABLE_KNOBS");
+    auto getenv = [&](const char *name) -> const char * { return (knobs_on && atoi(knobs_on) != 0) ? ::getenv(name) : nullptr; };
     if (const char *m = getenv("FW_UPDATE_MODE")) ctx->update_mode = !strcmp(m, "split") ? FW_MODE_SPLIT : FW_MODE_FUSED;
     if (const char *m = getenv("FW_DEBUG")) ctx->dbg = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_FORECAST")) ctx->use_forecast = atoi(m) != 0;
@@ -1503,6 +1546,8 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_NOSPIN")) ctx->use_nospin = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE")) ctx->use_range = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_MIN")) ctx->range_min = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_RANGE_DEVREC")) ctx->range_devrec = atoi(m) != 0;
+    if (const char *m = getenv("FW_RANGE_FOLD")) ctx->range_fold = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
     if (const char *m = getenv("FW_OPS_ZEROCOPY")) ctx->ops_zerocopy = atoi(m) != 0;
@@ -1526,7 +1571,8 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
         static const char *names[10] = {"windows+reset", "spawner loop", "tile table", "commit", "args", "op tables", "launch", "post", "", ""};
         fprintf(stderr, "[fw] host half of fw_step over %llu frames (ns per frame):", (unsigned long long)ctx->prof_frames);
         for (int i = 0; i < 8; i++) fprintf(stderr, "  %s %.0f", names[i], ctx->prof_ns[i] / (double)ctx->prof_frames);
-        fprintf(stderr, "\n");
+        fprintf(stderr, "\n[fw] table uploads: general %llu, range %llu over %llu frames\n", (unsigned long long)ctx->tab_seq,
+                (unsigned long long)ctx->r_uploads, (unsigned long long)ctx->frame);
     }
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
@@ -1571,11 +1617,17 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     if (ctx->fifo_stream) hipStreamDestroy(ctx->fifo_stream);
     if (ctx->ev_side) hipEventDestroy(ctx->ev_side);
     if (ctx->ev_rtab) hipEventDestroy(ctx->ev_rtab);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->ev_coll[i]) hipEventDestroy(ctx->ev_coll[i]);
+        if (ctx->h_coll[i]) hipHostFree(ctx->h_coll[i]);
+    }
     if (ctx->d_rdesc) hipFree(ctx->d_rdesc);
     if (ctx->h_rdesc) hipHostFree(ctx->h_rdesc);
     if (ctx->d_rstatus) hipFree(ctx->d_rstatus);
-    for (int i = 0; i < kParamRing; i++)
+    for (int i = 0; i < kParamRing; i++) {
         if (ctx->h_rparam[i]) hipHostFree(ctx->h_rparam[i]);
+        if (ctx->d_rparam[i]) hipFree(ctx->d_rparam[i]);
+    }
     if (ctx->ev_main) hipEventDestroy(ctx->ev_main);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1592,18 +1644,38 @@ fw_status fw_ctx_synchronize(fw_ctx *ctx) {
 }
 
 fw_status fw_ctx_set_colliders(fw_ctx *ctx, const fw_collider *colliders, uint32_t n) {
-    if (!ctx || (n && !colliders) || n > FW_MAX_COLLIDERS) return fail(ctx, FW_EINVAL, "bad collider set (at most FW_MAX_COLLIDERS)");
+    if (!ctx || (n && !colliders)) return fail(ctx, FW_EINVAL, "bad collider set");
     hipSetDevice(ctx->device);
     for (uint32_t i = 0; i < n; i++)
         if (colliders[i].kind < FW_COLLIDER_PLANE || colliders[i].kind > FW_COLLIDER_BOX)
             return fail(ctx, FW_EINVAL, "unknown collider kind");
-    fw_status st = sync(ctx);  // kernels in flight read the old set
-    if (st) return st;
-    if (!ctx->d_colliders) FW_HIP(ctx, hipMalloc((void **)&ctx->d_colliders, FW_MAX_COLLIDERS * sizeof(FwCollider)));
-    std::vector<FwCollider> h(n);
+    // The reference asks the live physics world every frame (core.rs:756-765): a set that changes every frame must not
+    // stall the frames in flight.  The new set is staged in pinned memory and copied by the stream itself.
+    const int slot = (int)(ctx->coll_seq++ & 1u);
+    if (ctx->coll_pending[slot]) {  // the copy of two calls ago: long done unless the caller replaces the set in a tight loop
+        FW_HIP(ctx, hipEventSynchronize(ctx->ev_coll[slot]));
+        ctx->coll_pending[slot] = false;
+    }
+    if (!ctx->ev_coll[slot]) FW_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_coll[slot], hipEventDisableTiming));
+    if (n > ctx->h_coll_cap[slot]) {
+        const size_t ncap = std::max<size_t>(64, (size_t)n * 2);
+        if (ctx->h_coll[slot]) FW_HIP(ctx, hipHostFree(ctx->h_coll[slot]));
+        ctx->h_coll[slot] = nullptr, ctx->h_coll_cap[slot] = 0;
+        FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_coll[slot], ncap * sizeof(FwCollider), hipHostMallocDefault));
+        ctx->h_coll_cap[slot] = ncap;
+    }
+    if (n > ctx->coll_cap) {  // a larger world than ever before: the one case that waits (kernels in flight read the old table)
+        fw_status st = sync(ctx);
+        if (st) return st;
+        const size_t ncap = std::max<size_t>(64, (size_t)n * 2);
+        if (ctx->d_colliders) FW_HIP(ctx, hipFree(ctx->d_colliders));
+        ctx->d_colliders = nullptr, ctx->coll_cap = 0;
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_colliders, ncap * sizeof(FwCollider)));
+        ctx->coll_cap = ncap;
+    }
     for (uint32_t i = 0; i < n; i++) {
         const fw_collider &c = colliders[i];
-        FwCollider &d = h[i];
+        FwCollider &d = ctx->h_coll[slot][i];
         d = FwCollider{};
         d.kind = c.kind, d.layers = c.layers, d.radius = c.radius;
         memcpy(d.position, c.position, sizeof c.position);
@@ -1611,7 +1683,11 @@ fw_status fw_ctx_set_colliders(fw_ctx *ctx, const fw_collider *colliders, uint32
         memcpy(d.normal, c.normal, sizeof c.normal);
         memcpy(d.half_extents, c.half_extents, sizeof c.half_extents);
     }
-    if (n) FW_HIP(ctx, hipMemcpy(ctx->d_colliders, h.data(), n * sizeof(FwCollider), hipMemcpyHostToDevice));
+    if (n) {
+        FW_HIP(ctx, hipMemcpyAsync(ctx->d_colliders, ctx->h_coll[slot], n * sizeof(FwCollider), hipMemcpyHostToDevice, ctx->stream));
+        FW_HIP(ctx, hipEventRecord(ctx->ev_coll[slot], ctx->stream));
+        ctx->coll_pending[slot] = true;
+    }
     ctx->n_colliders = n;
     ctx->g.colliders = ctx->d_colliders, ctx->g.n_colliders = n;
     ctx->fc_ok = false, ctx->boxes_epoch = 0;
@@ -2448,12 +2524,29 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             const uint32_t live_before_ub = std::min(S.ub - std::min(S.ub, S.frame_spawn), S.capacity);
             const uint32_t old_ub = live_before_ub - std::min(live_before_ub, y_exist);
             const uint32_t need_old = std::max(1u, (old_ub + FW_TILE - 1) / FW_TILE);
-            const uint32_t need_new = (S.frame_spawn + FW_BLOCK - 1) / FW_BLOCK;
-            const uint32_t need_young = std::min(S.capacity / FW_TILE, (S.young_lo % FW_TILE + y_exist + FW_TILE - 1) / FW_TILE);
-            if (need_old > S.r_old || S.r_old > need_old + need_old / 2 + 4) S.r_old = need_old + need_old / 4 + 1, dirty = true;
-            if (need_new > S.r_new || S.r_new > need_new + need_new / 4 + 2) S.r_new = need_new + (need_new >= 8 ? need_new / 8 : 1u), dirty = true;
-            if (need_young > S.r_young || S.r_young > need_young + need_young / 4 + 2)
-                S.r_young = std::min(S.capacity / FW_TILE, need_young + (need_young >= 16 ? need_young / 8 : 1u)), dirty = true;
+            // (at most one round of new particles is spawned by the YOUNG workgroups that own their slots: fw_k_update_range)
+            const bool fold = ctx->range_fold && S.frame_spawn <= FW_BLOCK;
+            const uint32_t need_new = fold ? 0u : (S.frame_spawn + FW_BLOCK - 1) / FW_BLOCK;
+            const uint32_t YT = fw_range_young_tile();
+            const uint32_t need_young = std::min(S.capacity / YT, (S.young_lo % YT + y_exist + (fold ? S.frame_spawn : 0u) + YT - 1) / YT);
+            // every provisioned workgroup is dispatched every frame, active or not (~3 us of a slot each): small needs get
+            // one spare, large ones an eighth -- a re-sent table is a copy in the stream, an idle workgroup a cost in every frame
+            // (the bound of the old part follows the snapshots in a sawtooth: a role grows at once, and shrinks only after its
+            // need has stayed far below what is provided for 64 frames in a row -- otherwise the table would be re-sent on
+            // every tooth)
+            auto fit = [&](uint32_t &have, uint32_t need, uint32_t spare, uint32_t &low) {
+                if (need > have) {
+                    have = need + spare, low = 0, dirty = true;
+                } else if (have > need + need / 4 + spare + 2) {
+                    if (++low > 64) have = need + spare, low = 0, dirty = true;
+                } else {
+                    low = 0;
+                }
+            };
+            fit(S.r_old, need_old, need_old >= 8 ? need_old / 4 : 1u, S.r_low[0]);
+            fit(S.r_new, need_new, need_new ? (need_new >= 8 ? need_new / 8 : 1u) : 0u, S.r_low[1]);
+            fit(S.r_young, need_young, need_young >= 16 ? need_young / 8 : 1u, S.r_low[2]);
+            S.r_young = std::min(S.r_young, S.capacity / YT);
         }
         if (dirty) {
             if (ctx->rtab_pending) {  // (one staging buffer: the previous upload must have left it)
@@ -2480,6 +2573,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             FW_HIP(ctx, hipEventRecord(ctx->ev_rtab, ctx->stream));
             ctx->rtab_pending = true;
             ctx->r_force = false;
+            ctx->r_uploads++;
         }
         // the ages every later frame starts from
         for (auto &e : ctx->birth_age) e.age = e.age + dt;
@@ -2488,8 +2582,15 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         if (ctx->r_total) {
             FwRangeArgs ra{};
             ra.desc = ctx->d_rdesc, ra.recs = recs, ra.ops = rops, ra.status = ctx->d_rstatus;
+            if (ctx->range_devrec) {
+                const size_t off_ops = round_up((uint32_t)(ctx->max_seg * sizeof(FwRangeRec)), 64);
+                const size_t bytes = off_ops + ops.size() * sizeof(FwOp);
+                FW_HIP(ctx, hipMemcpyAsync(ctx->d_rparam[rslot], ctx->h_rparam[rslot], bytes, hipMemcpyHostToDevice, ctx->stream));
+                ra.recs = (const FwRangeRec *)ctx->d_rparam[rslot], ra.ops = (const FwOp *)(ctx->d_rparam[rslot] + off_ops);
+            }
             ra.total_tiles = ctx->r_total, ra.parity = p, ra.epoch = a.epoch, ra.spin_limit = ctx->spin_limit, ra.dbg = ctx->dbg;
             ra.dt = dt;
+            ra.fold_new = ctx->range_fold ? 1u : 0u;
             ra.done_tag = a.done_tag, ra.done_value = a.done_value;
             ra.host_counts = a.host_counts, ra.live_out = a.live_out, ra.live_next = a.live_next;
             hipEvent_t e0, e1;
@@ -2803,30 +2904,50 @@ fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out
         fw_status jst = join_side(ctx);  // (the query kernels run on the main stream and may read rings)
         if (jst) return jst;
     }
-    bool any_fifo = false;  // rings leave no per-tile boxes: the two-pass query reads them
-    uint32_t heads[FW_MAX_TYPES] = {}, range_y[FW_MAX_TYPES];
-    for (size_t t = 0; t < sp->seg.size() && t < FW_MAX_TYPES; t++) {
-        const SegHost &S = ctx->segs[sp->seg[t]];
-        any_fifo |= S.ring();
-        heads[t] = S.range ? S.young_lo : (S.fifo ? S.head : 0u);
-        range_y[t] = S.range ? S.young_n : 0xFFFFFFFFu;
+    // the query kernels take up to eight particle types at a time (their segment list rides in the kernel arguments): a
+    // spawner with more is answered in chunks, folded here -- min / max are exact and order-independent
+    const size_t nt = sp->seg.size();
+    float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    bool got = false;
+    fw_status keep = FW_OK;
+    for (size_t t0 = 0; t0 < nt || t0 == 0; t0 += 8) {
+        const uint32_t n = (uint32_t)std::min<size_t>(8, nt - std::min(nt, t0));
+        if (!n) break;
+        bool any_ring = false;  // rings leave no per-tile boxes: the two-pass query reads them
+        uint32_t heads[8] = {}, range_y[8];
+        for (uint32_t t = 0; t < n; t++) {
+            const SegHost &S = ctx->segs[sp->seg[t0 + t]];
+            any_ring |= S.ring();
+            heads[t] = S.range ? S.young_lo : (S.fifo ? S.head : 0u);
+            range_y[t] = S.range ? S.young_n : 0xFFFFFFFFu;
+        }
+        if (ctx->boxes_epoch && ctx->d_tile_first && !any_ring) {
+            // the last update left the box of every tile's survivors (fw_ctx_track_aabbs): fold those -- one small launch
+            FW_HIP(ctx, fw_launch_aabb_from_tiles(ctx->stream, ctx->g, sp->seg.data() + t0, n, ctx->parity, ctx->boxes_epoch,
+                                                  ctx->d_tile_first, ctx->h_aabb));
+        } else {
+            // two launches over the particles, the result lands in pinned memory: one synchronisation, no copies
+            FW_HIP(ctx, fw_launch_aabb(ctx->stream, ctx->g, sp->seg.data() + t0, heads, n, ctx->parity, ctx->d_aabb, ctx->h_aabb,
+                                       range_y));
+        }
+        fw_status st = sync(ctx);
+        if (!st) st = check_device_errors(ctx);
+        if (st && st != FW_ECAPACITY) return st;
+        if (st) keep = st;
+        const volatile float *r = ctx->h_aabb;
+        if (r[3] != 0.0f) {
+            for (int c = 0; c < 3; c++) {
+                mn[c] = got ? std::min(mn[c], (float)r[c]) : (float)r[c];
+                mx[c] = got ? std::max(mx[c], (float)r[4 + c]) : (float)r[4 + c];
+            }
+            got = true;
+        } else if (!got && t0 + 8 >= nt) {  // nothing anywhere: report the last chunk's (empty) box as before
+            for (int c = 0; c < 3; c++) mn[c] = r[c], mx[c] = r[4 + c];
+        }
     }
-    if (ctx->boxes_epoch && ctx->d_tile_first && !any_fifo) {
-        // the last update left the box of every tile's survivors (fw_ctx_track_aabbs): fold those -- one small launch
-        FW_HIP(ctx, fw_launch_aabb_from_tiles(ctx->stream, ctx->g, sp->seg.data(), (uint32_t)sp->seg.size(), ctx->parity,
-                                              ctx->boxes_epoch, ctx->d_tile_first, ctx->h_aabb));
-    } else {
-        // two launches over the particles, the result lands in pinned memory: one synchronisation, no copies
-        FW_HIP(ctx, fw_launch_aabb(ctx->stream, ctx->g, sp->seg.data(), heads, (uint32_t)sp->seg.size(), ctx->parity,
-                                   ctx->d_aabb, ctx->h_aabb, range_y));
-    }
-    fw_status st = sync(ctx);
-    if (!st) st = check_device_errors(ctx);
-    if (st && st != FW_ECAPACITY) return st;
-    const volatile float *r = ctx->h_aabb;
-    if (any) *any = r[3] != 0.0f ? 1 : 0;
-    for (int c = 0; c < 3; c++) out_min[c] = r[c], out_max[c] = r[4 + c];
-    return st;
+    if (any) *any = got ? 1 : 0;
+    for (int c = 0; c < 3; c++) out_min[c] = mn[c], out_max[c] = mx[c];
+    return keep;
 }
 
 fw_status fw_ctx_track_aabbs(fw_ctx *ctx, int32_t enable) {

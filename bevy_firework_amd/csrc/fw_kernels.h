@@ -187,6 +187,7 @@ struct FwRangeArgs {
     unsigned long long *status;     // look-back words of the OLD workgroups, by global workgroup index
     uint32_t total_tiles, parity, epoch, spin_limit, dbg;
     float dt;
+    uint32_t fold_new;              // 1: at most one round of new particles is spawned by the YOUNG workgroups owning their slots
     unsigned long long *done_tag;   // as in FwUpdateArgs
     unsigned long long done_value;
     unsigned long long *host_counts;
@@ -206,6 +207,7 @@ hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArg
 // in-place update of up to FW_FIFO_PER_LAUNCH FIFO segments (their spawn ops in `inl`)
 hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifoArgs &a, const FwInlineOps &inl,
                                  uint32_t total_tiles, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+uint32_t fw_range_young_tile(void);  // ring slots a YOUNG workgroup of fw_k_update_range covers (a build-time choice)
 // in-place update of every range ring of the context (all_nospin: no segment of the launch keeps a rotation plane)
 hipError_t fw_launch_update_range(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin,
                                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);

@@ -1810,6 +1810,11 @@ __device__ __forceinline__ void fw_store_destroyed_vals(char *dbuf, size_t d, co
     reinterpret_cast<int32_t *>(rec)[25] = T.pbr;
 }
 
+#ifndef FW_RANGE_YR
+#define FW_RANGE_YR 4  // rounds of a YOUNG workgroup: it covers FW_RANGE_YR * 256 ring slots
+#endif
+uint32_t fw_range_young_tile(void) { return FW_RANGE_YR * FW_BLOCK; }
+
 template <bool ALLNOSPIN>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
     constexpr int BLK = FW_BLOCK;
@@ -1842,15 +1847,21 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
 
     if (role == FW_RANGE_YOUNG) {
         // ---- in place: a lane owns its slot from load to store
-        const uint32_t ring_tiles = C / TILE;
-        const uint32_t need = min(ring_tiles, (b % TILE + y_exist + TILE - 1u) / TILE);
+        constexpr int YR = FW_RANGE_YR;
+        constexpr uint32_t YT = YR * BLK;  // (capacities are multiples of it: the host rounds them, fw_range_young_tile)
+        const uint32_t ring_tiles = C / YT;
+        // (a handful of new particles -- at most one round -- have no workgroup of their own: they sit right behind the young
+        // part and are spawned by the YOUNG workgroups that own their slots, after their streaming loop)
+        const uint32_t n_fold = (a.fold_new && n_spawn_h <= (uint32_t)BLK) ? n_spawn_h : 0u;
+        const uint32_t need = min(ring_tiles, (b % YT + y_exist + n_fold + YT - 1u) / YT);
         if (k >= need) return;
-        uint32_t pt = b / TILE + k;
+        const uint32_t cnt_y = n_fold ? g.count[sidx] : 0u;  // (requested now, used after the loop: the capacity clamp)
+        uint32_t pt = b / YT + k;
         if (pt >= ring_tiles) pt -= ring_tiles;
-        const uint32_t sbase = pt * TILE;
+        const uint32_t sbase = pt * YT;
         float4 q0c, q1c, q2c, q3c, q0n, q1n, q2n, q3n;
         float lfc, lfn;
-        const uint32_t i0 = (sbase + tid) * 16u, i1 = (sbase + (uint32_t)min(1, R - 1) * BLK + tid) * 16u;
+        const uint32_t i0 = (sbase + tid) * 16u, i1 = (sbase + (uint32_t)min(1, YR - 1) * BLK + tid) * 16u;
         q0c = fw_ld4w(p0, i0), q3c = fw_ld4w(p3, i0 & m2), lfc = fw_ld1w(m2 ? p0 : pl, m2 ? 0u : i0 / 4u);
         q1c = fw_ld4w(p1, i0), q2c = fw_ld4w(p2, i0 & m2);
         q0n = fw_ld4w(p0, i1), q3n = fw_ld4w(p3, i1 & m2), lfn = fw_ld1w(m2 ? p0 : pl, m2 ? 0u : i1 / 4u);
@@ -1862,9 +1873,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
         bool bad = false;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
+        for (int r = 0; r < YR; r++) {
             const uint32_t s = sbase + r * BLK + tid;
-            const uint32_t in_ = (sbase + (uint32_t)min(r + 2, R - 1) * BLK + tid) * 16u;  // two rounds ahead (the last re-read)
+            const uint32_t in_ = (sbase + (uint32_t)min(r + 2, YR - 1) * BLK + tid) * 16u;  // two rounds ahead (the last re-read)
             const float4 q0f = fw_ld4w(p0, in_), q3f = fw_ld4w(p3, in_ & m2);
             const float lff = fw_ld1w(m2 ? p0 : pl, m2 ? 0u : in_ / 4u);
             const float4 q1f = fw_ld4w(p1, in_), q2f = fw_ld4w(p2, in_ & m2);
@@ -1880,6 +1891,34 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f, lfn = lff;
         }
         if (__any(bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 7u, g.err[6] = seg, g.err[7] = blockIdx.x;
+        if (n_fold) {
+            const uint32_t n_old_y = cnt_y > y_exist ? cnt_y - y_exist : 0u;
+            const uint32_t n_sp = min(n_fold, C - min(C, n_old_y + y_exist));
+            const FwOutWin Wn = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
+#pragma unroll 1
+            for (int r = 0; r < YR; r++) {
+                const uint32_t s = sbase + r * BLK + tid;
+                uint32_t yi = s - b;
+                if (s < b) yi += C;
+                const bool is_new = yi >= y_exist && yi - y_exist < n_sp;
+                if (!__any(is_new)) continue;  // wave-uniform
+                if (is_new) {
+                    const uint32_t kk = yi - y_exist;
+                    uint32_t oi = Rc.op0;
+                    for (uint32_t x = Rc.op0; x < Rc.op0 + Rc.op_n; x++)
+                        if (kk >= a.ops[x].rel_base && kk - a.ops[x].rel_base < a.ops[x].n) oi = x;
+                    const FwOp &op = a.ops[oi];
+                    const FwSpawnOut so = fw_spawn_one(g.emits[op.emit], g.seed, op.serial_base + (kk - op.rel_base),
+                                                       fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
+                                                       fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
+                                                       fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
+                    float age_new;
+                    if (!fw_survives(so.q0.w, a.dt, so.q3.w, &age_new)) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 8u, g.err[6] = seg, g.err[7] = kk;
+                    fw_integrate_store<false, -1>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, Wn, s);
+                }
+            }
+            if (n_sp < n_fold && tid == 0 && k + 1u == need) atomicOr(g.err, FW_ERR_CAPACITY);
+        }
         return;
     }
 
@@ -1890,7 +1929,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     const uint32_t n_spawn = min(n_spawn_h, room);
 
     if (role == FW_RANGE_NEW) {
-        if (k * BLK >= n_spawn_h) return;
+        if ((a.fold_new && n_spawn_h <= (uint32_t)BLK) || k * BLK >= n_spawn_h) return;  // (at most one round: the YOUNG workgroups spawn them)
         const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
         if (tid < keys_len) s_keys[tid] = key0;
         for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
@@ -2076,7 +2115,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_count(FwGlobals g, FwUpdateArgs
 // the tuned one: no forecast, no fused spawn (the streaming kernels never run collisions and keep their registers).
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpdateArgs a) {
     constexpr int NW = FW_BLOCK / 64;
-    __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
+    __shared__ __attribute__((aligned(16))) float s_keys_lds[FW_KEYS_MAX];
     __shared__ uint32_t s_c[2][NW];
     const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t seg = fw_upper_slot(a.seg_tile_first, a.n_seg, tile);
@@ -2102,8 +2141,13 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpda
     char *inst = Sp->inst;
     const uint32_t inst_cap = Sp->inst_cap;
     const FwType T = g.types[Sp->type_idx];
-    for (uint32_t i = tid; i < T.keys_len; i += FW_BLOCK) s_keys[i] = g.keys[T.keys_off + i];
+    // curves of any length (curve.rs:40-75): what fits the staging area is sampled from LDS, longer key sets straight from
+    // device memory (this is the feature path; the streaming kernels only ever see types whose keys fit)
+    const bool bigkeys = T.keys_len > FW_KEYS_MAX;
+    if (!bigkeys)
+        for (uint32_t i = tid; i < T.keys_len; i += FW_BLOCK) s_keys_lds[i] = g.keys[T.keys_off + i];
     __syncthreads();
+    const float *s_keys = bigkeys ? g.keys + T.keys_off : s_keys_lds;
     const FwTypeColl TC = g.type_coll[Sp->type_idx];
     const bool coll = (TC.coll_flags & FW_COLL_ENABLED) != 0u, coll_kill = (TC.coll_flags & FW_COLL_DESTROY) != 0u;
     const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
@@ -2735,7 +2779,7 @@ hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *d_ops,
 // packet's own begin / end timestamps, which is what rocprofv3 --kernel-trace reports for the kernel.
 // (fw_dyn_lds: experiment knob FW_DYN_LDS -- unused dynamic LDS per workgroup lowers the number of resident workgroups
 // per CU; measured on the HBM-resident configurations)
-static unsigned fw_dyn_lds = getenv("FW_DYN_LDS") ? (unsigned)atoi(getenv("FW_DYN_LDS")) : 0u;
+static unsigned fw_dyn_lds = (getenv("FW_ENABLE_KNOBS") && atoi(getenv("FW_ENABLE_KNOBS")) && getenv("FW_DYN_LDS")) ? (unsigned)atoi(getenv("FW_DYN_LDS")) : 0u;
 #define FW_LAUNCH_T(kern, grid, block, s, e0, e1, ...)                                          \
     do {                                                                                          \
         if ((e0) || (e1))                                                                         \

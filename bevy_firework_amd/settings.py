@@ -25,7 +25,6 @@ Vec3 = Tuple[float, float, float]
 Quat = Tuple[float, float, float, float]  # xyzw
 Rgba = Tuple[float, float, float, float]
 
-MAX_KEYS = 32  # FW_MAX_KEYS
 
 WHITE: Rgba = (1.0, 1.0, 1.0, 1.0)  # LinearRgba::WHITE
 BLACK: Rgba = (0.0, 0.0, 0.0, 1.0)  # LinearRgba::BLACK

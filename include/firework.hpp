@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "firework_hip.h"
+#include "firework_hip_debug.h"  // update_path(): which kernels a particle type runs on (diagnostics)
 
 namespace firework {
 

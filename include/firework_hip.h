@@ -41,9 +41,11 @@ extern "C" {
 #endif
 
 #define FW_ABI_VERSION 2
-#define FW_MAX_KEYS 32          /* keys per curve / gradient */
-#define FW_MAX_TYPES 8          /* particle_settings entries per spawner */
-#define FW_MAX_EMISSIONS 8      /* emission_settings entries per spawner */
+/* (no FW_MAX_TYPES / FW_MAX_EMISSIONS / FW_MAX_KEYS / FW_MAX_COLLIDERS: the reference's Vec<ParticleSettings>,
+ * Vec<EmissionSettings> (core.rs:178-185), curve sample vectors (curve.rs:40-75) and collider world are unbounded, and so
+ * are the descriptors below -- FW_EINVAL is for input the reference itself rejects.  Curves and gradients of up to
+ * FW_FAST_KEYS samples are staged in LDS; longer ones are read from device memory by the feature kernels.) */
+#define FW_FAST_KEYS 32
 
 typedef enum fw_status {
     FW_OK = 0,
@@ -111,7 +113,6 @@ typedef struct fw_collider {
     float radius;           /* SPHERE only */
     float half_extents[3];  /* BOX only */
 } fw_collider;
-#define FW_MAX_COLLIDERS 64
 
 enum { FW_PACING_ONESHOT = 0, FW_PACING_ONDEMAND = 1, FW_PACING_COUNT_OVER_DURATION = 2 }; /* core.rs:12-29 */
 enum { FW_MODE_GLOBAL = 0, FW_MODE_NESTED = 1 };                                           /* core.rs:47-54 */
@@ -178,8 +179,10 @@ const char *fw_last_error(const fw_ctx *ctx); /* ctx may be NULL: last create er
 void *fw_ctx_stream(const fw_ctx *ctx);       /* the hipStream_t in use */
 fw_status fw_ctx_synchronize(fw_ctx *ctx);
 
-/* replaces the context's collider set (copied; n <= FW_MAX_COLLIDERS; n = 0 clears it).  Takes effect at the next
- * fw_step; synchronises the stream. */
+/* replaces the context's collider set (copied; any n; n = 0 clears it).  Takes effect at the next fw_step.  Does NOT
+ * synchronise: the set travels as one copy in the context's stream, behind the frames that read the old one (the
+ * reference queries the live physics world every frame, core.rs:756-765 -- moving colliders cost one small copy per
+ * frame).  Only a set larger than any before reallocates the device table, which waits for the frames in flight. */
 fw_status fw_ctx_set_colliders(fw_ctx *ctx, const fw_collider *colliders, uint32_t n);
 
 /* ---- spawners ----------------------------------------------------------------- */
@@ -254,30 +257,9 @@ fw_status fw_ctx_live_count_ring(fw_ctx *ctx, void *d_ring_u64, uint32_t n_slots
 /* running total of particles that entered update_particles (after spawn) since the context was created */
 fw_status fw_ctx_last_step_updated(fw_ctx *ctx, uint64_t *out);
 
-/* ---- measurement hooks (bench.py / profiles) -------------------------------------- */
-/* HIP-event timing of the dominant kernel on the context's stream: enable, run
- * steps, then read (sum of kernel durations in ms, number of launches).  The start / stop
- * events are attached to the update dispatch itself (hipExtLaunchKernel), so each pair
- * spans exactly the kernel's begin / end timestamps -- the duration rocprofv3 reports. */
-fw_status fw_ctx_kernel_timing(fw_ctx *ctx, int32_t enable);
-fw_status fw_ctx_kernel_timing_read(fw_ctx *ctx, double *ms_total, uint64_t *launches, uint64_t *particles);
-/* cost of an empty hipEventRecord pair on the stream (informational; nothing is subtracted from the figure above) */
-fw_status fw_ctx_kernel_timing_overhead(fw_ctx *ctx, double *ms_per_pair);
-/* device-to-device copy bandwidth probe (bytes moved R+W per second) for the measured-roofline line */
-fw_status fw_ctx_measure_copy_bandwidth(fw_ctx *ctx, uint64_t bytes, int32_t iters, double *bytes_per_s);
-
-/* in-kernel timestamps of the update kernel when the context was created under FW_DEBUG=8 (tools/tile_timeline.py,
- * tools/launch_gaps.py): per tile {entry, after the count barrier, after the prefix, end, 4 more phase marks} of the
- * last launch (and of the one before it: `prev`); {~earliest start [64], latest end [64]} of the last 256 launches */
-fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_t max_tiles, uint64_t *n_tiles);
-fw_status fw_debug_read_timestamps2(fw_ctx *ctx, unsigned long long *out, unsigned long long *prev, uint64_t max_tiles,
-                                    uint64_t *n_tiles);
-fw_status fw_debug_read_launches(fw_ctx *ctx, unsigned long long *out32768, uint32_t *epoch);
-/* which update path a particle type is on (1 = FIFO ring updated in place, 2 = range ring: young part in place, old part
- * compacted in place, 0 = general compacting path), the bytes one
- * update of a live particle moves on it, and how many of those are algorithmic (bench.py's roofline accounting) */
-fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner spawner, uint32_t type, int32_t *mode, uint32_t *moved_bytes,
-                               uint32_t *algorithmic_bytes);
+/* (measurement and debugging hooks -- kernel timing, the copy-bandwidth probe, in-kernel timestamps, which update path a
+ * particle type is on -- are declared in firework_hip_debug.h: exported by the same library, not part of the surface a
+ * host binds) */
 
 /* ---- pure host helpers (no GPU needed; the bit-exact count arithmetic) ------------ */
 /* compute_emission_count (core.rs:553-575) exactly as fw_step's host side evaluates it */

@@ -45,6 +45,7 @@ def pytest_generate_tests(metafunc):
 @pytest.fixture(autouse=True)
 def fw_path(request, monkeypatch):
     mode = getattr(request, "param", None)
+    monkeypatch.setenv("FW_ENABLE_KNOBS", "1")  # the library reads its A/B switches only with this set (firework_hip_debug.h)
     if mode == "fifo":
         monkeypatch.setenv("FW_FIFO", "1")
         monkeypatch.setenv("FW_FIFO_MIN", "0")

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FW_ENABLE_KNOBS=1   # the library honours its A/B switches only with this set
 # A/B bench of library builds: tools/ab.sh variants/a.so variants/b.so ...   (run on the GPU box)
 for rep in 1 2 3; do
   for so in "$@"; do

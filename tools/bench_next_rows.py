@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the rows SURVEY.md §8(f) ranks next: instance packing (render.rs:403) and the AABB reduction
 (render.rs:677-703), on the 1M-particle configuration.  Run on the GPU box."""
+import os as _os; _os.environ.setdefault("FW_ENABLE_KNOBS", "1")  # the A/B switches are honoured only with this set
 import ctypes as C
 import json
 import os

@@ -1,6 +1,7 @@
 """Where does a ring of its own pay in a MIXED context?  One general-path segment (lifetime range) of 500k particles plus
 one single-lifetime type of X particles: frame time with the second type on a ring (its own launch) and on the general
 path (one launch for both).  Sets the default of FW_FIFO_MIN."""
+import os as _os; _os.environ.setdefault("FW_ENABLE_KNOBS", "1")  # the A/B switches are honoured only with this set
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r'''

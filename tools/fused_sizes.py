@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("FW_ENABLE_KNOBS", "1")  # the A/B switches are honoured only with this set
 import ctypes as C, json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

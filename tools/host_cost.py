@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Host-side cost of enqueueing one fw_step (small batches so the HW queue never fills)."""
+import os as _os; _os.environ.setdefault("FW_ENABLE_KNOBS", "1")  # the A/B switches are honoured only with this set
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

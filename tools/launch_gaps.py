@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU-side gaps between consecutive update launches (FW_DEBUG=8): last workgroup end of launch i -> first workgroup
 start of launch i+1, from the per-launch {min start, max end} ring the kernels keep.  Run on the GPU box."""
+import os as _os; _os.environ.setdefault("FW_ENABLE_KNOBS", "1")  # the A/B switches are honoured only with this set
 import ctypes as C
 import os
 import sys

@@ -1,5 +1,6 @@
 """A big ring next to a few small compacting segments: what does the second launch cost?  configs[1]'s emitter plus K
 small emitters with a lifetime range (1000 particles each); frame time with the big type on a ring / on the general path."""
+import os as _os; _os.environ.setdefault("FW_ENABLE_KNOBS", "1")  # the A/B switches are honoured only with this set
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r'''

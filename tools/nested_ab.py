@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("FW_ENABLE_KNOBS", "1")  # the A/B switches are honoured only with this set
 import os, sys, json, time
 sys.path.insert(0, os.getcwd())
 import numpy as np

@@ -1,5 +1,6 @@
 """configs[3] (Nested, both types on rings) in chunks: us per frame with and without a host synchronisation between the chunks
 (a free-running host shows where fw_step itself has to wait for the device)."""
+import os as _os; _os.environ.setdefault("FW_ENABLE_KNOBS", "1")  # the A/B switches are honoured only with this set
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np

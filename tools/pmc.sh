@@ -1,4 +1,5 @@
 #!/bin/bash
+export FW_ENABLE_KNOBS=1   # the library honours its A/B switches only with this set
 # PMC passes for the bench (run on the GPU box): tools/pmc.sh <outdir> [lib.so]
 # Counters are collected in their own runs (kernel-trace only), one rocprofv3 pass per counter group.
 OUT=$1; LIB=${2:-}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FW_ENABLE_KNOBS=1   # the library honours its A/B switches only with this set
 # Counter comparison of the real update kernel against its structural twin (run on the GPU box):
 #   tools/pmc_compare.sh <outdir>
 # One rocprofv3 pass per counter group (kernel-trace only), for `./tools/launchgap twin` and for the C++ stress test.

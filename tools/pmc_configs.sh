@@ -1,4 +1,5 @@
 #!/bin/bash
+export FW_ENABLE_KNOBS=1   # the library honours its A/B switches only with this set
 # HBM-side traffic (PMC) of the update kernels of the other configs: tools/pmc_configs.sh <outdir> "c3 c4"   (GPU box)
 # FETCH_SIZE / WRITE_SIZE in their own rocprofv3 passes (kernel-trace only), summarised per kernel by analyze_pmc.py.
 OUT=$1; W=${2:-c3}

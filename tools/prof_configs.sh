@@ -1,4 +1,5 @@
 #!/bin/bash
+export FW_ENABLE_KNOBS=1   # the library honours its A/B switches only with this set
 # rocprofv3 --kernel-trace --stats of the HBM-resident configurations (run on the GPU box):
 #   tools/prof_configs.sh r03       -> gpurun_out/prof_configs_r03/{configs2,configs4_share}_{kernel_stats.csv,trace_summary.txt,bench.json}
 # Every hbm_resident figure of the bench line is then reproducible from a CSV under profiles/.

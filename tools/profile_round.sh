@@ -1,4 +1,5 @@
 #!/bin/bash
+export FW_ENABLE_KNOBS=1   # the library honours its A/B switches only with this set
 # Produce the committed profile artefacts of a round (run on the GPU box):  tools/profile_round.sh r02
 TAG=${1:-r02}
 R=$PWD; OUT=gpurun_out/profile_$TAG; mkdir -p $OUT; export TMPDIR=/tmp

@@ -1,6 +1,7 @@
 """Long run of the ring paths against closed-form expectations (no oracle: too slow for 10^5 frames): configs[1] and the
 Nested configs[3] shape, fixed and jittering dt.  Any disagreement between the host's cohort bookkeeping and the particles
 raises FW_ERR_FORECAST inside the update kernel and surfaces as an exception at the next count read."""
+import os as _os; _os.environ.setdefault("FW_ENABLE_KNOBS", "1")  # the A/B switches are honoured only with this set
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

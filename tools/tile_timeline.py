@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Per-tile timeline of fw_k_update (FW_DEBUG=8): when workgroups start, how long each phase takes."""
+import os as _os; _os.environ.setdefault("FW_ENABLE_KNOBS", "1")  # the A/B switches are honoured only with this set
 import ctypes as C
 import os
 import sys

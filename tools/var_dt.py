@@ -1,5 +1,6 @@
 """configs[1] stepped with a jittering dt (what Bevy's `Update` schedule delivers): per-step time and update-kernel time.
    python tools/var_dt.py [frames]"""
+import os as _os; _os.environ.setdefault("FW_ENABLE_KNOBS", "1")  # the A/B switches are honoured only with this set
 import os
 import sys
 import time
