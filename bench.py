@@ -333,12 +333,37 @@ def main():
                                                      "configs[2]: 256 emitters x 65 536 live (16.8M particles)")
             extras["hbm_resident"]["whole_step_particles_per_s"] = whole
             extras["hbm_resident"]["whole_step_ms"] = el / 100 * 1e3
+            # ... stepped with a dt that never repeats (range rings need no forecast: the same speed is the claim)
+            for k in range(32):
+                p2.step(jit[k % 64])
+            extras["hbm_resident"]["variable_dt"] = kernel_roofline(
+                p2, lambda k: p2.step(jit[k % 64]), 100, "configs[2] stepped with dt = 1/60 * (1 + 0.1 sin(0.7 k))")
             # ... and with every plane kept (FW_NOSPIN=0: what the kernel moved before planes that cannot change were elided;
             # the knob is read when a context is created)
-        saved_nospin, saved_knobs = os.environ.get("FW_NOSPIN"), os.environ.get("FW_ENABLE_KNOBS")
-        os.environ["FW_NOSPIN"] = "0"
+        saved_nospin, saved_knobs, saved_range = os.environ.get("FW_NOSPIN"), os.environ.get("FW_ENABLE_KNOBS"), os.environ.get("FW_RANGE")
         os.environ["FW_ENABLE_KNOBS"] = "1"  # (the library honours its A/B switches only with this set)
         try:
+            # the same workload on the compacting path (FW_RANGE=0: every lifetime-range type ping-pongs and is compacted as a
+            # whole, with the survivor forecast -- what round 2 measured), fixed dt and a dt that never repeats
+            os.environ["FW_RANGE"] = "0"
+            with ParticleSystem(device=local_rank, seed=workloads.SEED, stream=stream.cuda_stream) as p2c:
+                for e, (s_, tf_) in enumerate(workloads.many_emitters(256, 65536)):
+                    p2c.spawn(s_, tf_, uid=e)
+                p2c.update(dt)
+                for _ in range(76 + 20):
+                    p2c.step(dt)
+                torch.cuda.synchronize()
+                extras["hbm_resident"]["compacting_path"] = kernel_roofline(
+                    p2c, lambda k: p2c.step(dt), 60, "configs[2] with FW_RANGE=0: the compacting kernels (survivor forecast)")
+                for k in range(32):
+                    p2c.step(jit[k % 64])
+                extras["hbm_resident"]["compacting_path"]["variable_dt"] = kernel_roofline(
+                    p2c, lambda k: p2c.step(jit[k % 64]), 60, "... stepped with a dt that never repeats (decoupled look-back)")
+            if saved_range is None:
+                del os.environ["FW_RANGE"]
+            else:
+                os.environ["FW_RANGE"] = saved_range
+            os.environ["FW_NOSPIN"] = "0"
             with ParticleSystem(device=local_rank, seed=workloads.SEED, stream=stream.cuda_stream) as p2b:
                 for e, (s_, tf_) in enumerate(workloads.many_emitters(256, 65536)):
                     p2b.spawn(s_, tf_, uid=e)
@@ -350,9 +375,13 @@ def main():
                     p2b, lambda k: p2b.step(dt), 60, "configs[2] with FW_NOSPIN=0: rotation and angular-velocity planes kept")
         finally:
             if saved_nospin is None:
-                del os.environ["FW_NOSPIN"]
+                os.environ.pop("FW_NOSPIN", None)
             else:
                 os.environ["FW_NOSPIN"] = saved_nospin
+            if saved_range is None:
+                os.environ.pop("FW_RANGE", None)
+            else:
+                os.environ["FW_RANGE"] = saved_range
             if saved_knobs is None:
                 del os.environ["FW_ENABLE_KNOBS"]
             else:
@@ -435,12 +464,14 @@ def main():
             roof.update({
                 "bound": "hbm",
                 "kernel": ("fw_k_update_fifo (in-place ring update of a one-lifetime particle type, any dt)" if fifo else
+                           "fw_k_update_range (in-place range rings: young part in place, old part compacted in place, any dt)"
+                           if roof.get("update_path") == "range" else
                            "fw_k_update_stream (forecast frames; fw_k_update<fused> when dt changes)"),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "measured_hbm_copy_GBps": measured_copy / 1e9,
-                "note": ("at 1M particles the 100 MB ring sits in the 256 MiB Infinity Cache; `hbm_resident` is the general "
-                         "(compacting) kernel on a 16.8M-particle working set -- configs[2]'s lifetimes are a range, so its "
-                         "particles do not die in order" if fifo else
+                "note": ("at 1M particles the 100 MB ring sits in the 256 MiB Infinity Cache; `hbm_resident` is configs[2], a "
+                         "16.8M-particle working set whose lifetimes are a range: in-place range rings (fw_k_update_range), with "
+                         "the compacting kernels on the same workload under `compacting_path`" if fifo else
                          "at 1M particles the 200 MB ping-pong working set sits in the 256 MiB Infinity Cache; "
                          "`hbm_resident` is the same kernel on a 16.8M-particle working set"),
                 "timing": "hipEvent start/stop attached to each update dispatch on the context's stream "

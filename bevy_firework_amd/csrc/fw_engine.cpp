@@ -96,6 +96,8 @@ struct alignas(64) SegHost {
     uint32_t ub = 0;            // upper bound of the device count (after this frame's spawns)
     uint32_t frame_spawn = 0;   // Global particles appended this frame
     uint32_t dev_count = 0;     // nested_fed: live count of the latest snapshot row (growth trigger)
+    uint32_t dev_epoch = 0;     //   ... the frame that row describes, and
+    float dev_rate = 0.f;       //   ... how fast the count was growing between the last two rows (particles per frame, >= 0)
     uint32_t snap_count = 0;    // nested_fed: ... the same count, kept together with
     uint64_t snap_cum = 0;      //   cum_spawn of the frame that row describes: Global particles since then are host-known
     uint64_t cum_spawn = 0;     // Global particles ever appended (host-known)
@@ -822,12 +824,27 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
     return ensure_tile_arrays(ctx);
 }
 
-fw_status grow_segment(fw_ctx *ctx, uint32_t si, uint32_t need) {
+// (at_least_double: the amortised growth of a Vec -- `need` with a quarter of slack, never less than twice the capacity;
+// false: exactly what the caller asks for)
+fw_status grow_segment(fw_ctx *ctx, uint32_t si, uint32_t need, bool at_least_double = true) {
     const SegHost &s = ctx->segs[si];
-    const uint32_t ncap = round_up(std::max<uint32_t>((uint32_t)std::min<uint64_t>((uint64_t)need * 5 / 4, 0xFFFF0000ull),
-                                                      s.capacity * 2),
+    const uint32_t ncap = round_up(at_least_double ? std::max<uint32_t>((uint32_t)std::min<uint64_t>((uint64_t)need * 5 / 4, 0xFFFF0000ull),
+                                                                        s.capacity * 2)
+                                                   : std::max<uint32_t>(need, s.capacity),
                                    std::max<uint32_t>(FW_TILE, fw_range_young_tile()));
     return realloc_segment(ctx, si, ncap, false);
+}
+
+// Types fed by Nested entries cannot be bounded by the host (children are counted per parent on the device), so they cannot
+// grow exactly when needed the way Global-fed ones do (the reference's Vec::push, core.rs:523).  Their DERIVED capacity
+// (parent capacity x children per parent x lifetime ratio x 1.25) is an upper estimate of the steady state already: such a
+// segment grows when the count seen in the snapshot rows passes 85 % of it, or when at the rate it was last seen growing
+// it would fill up within 64 frames (the rows a free-running host looks at are up to a dozen frames old) -- long before the
+// device-side clamp (FW_ECAPACITY) could drop a particle, and without the 2x over-allocation and the ~30 ms reallocation
+// the old "half full" rule cost a steady configs[3].
+bool nested_fed_wants_growth(const SegHost &S) {
+    if (!S.nested_fed || !S.auto_capacity || S.capacity >= 0x70000000u) return false;
+    return (double)S.dev_count > 0.85 * (double)S.capacity || (double)S.dev_count + 64.0 * (double)S.dev_rate > (double)S.capacity;
 }
 
 // a FIFO segment whose premise no longer holds (the caller wrote particles, dt went negative or non-finite, ...)
@@ -1418,7 +1435,11 @@ void poll_snapshots(fw_ctx *ctx) {
             if ((uint32_t)(v >> 32) != ctx->snap_epoch[k]) continue;  // that segment's store has not landed yet
             if (S.fifo && !S.fifo_dev) continue;  // the host's count is exact
             if (S.nested_fed) {
-                S.dev_count = (uint32_t)v;  // no host-side bound exists; the count only drives capacity growth
+                {   // no host-side bound exists; the count and its growth rate only drive capacity growth
+                    const uint32_t ep = ctx->snap_epoch[k], c = (uint32_t)v;
+                    if (S.dev_epoch && ep > S.dev_epoch) S.dev_rate = c > S.dev_count ? (float)(c - S.dev_count) / (float)(ep - S.dev_epoch) : 0.f;
+                    S.dev_count = c, S.dev_epoch = ep;
+                }
                 S.snap_count = (uint32_t)v, S.snap_cum = cum[i];
                 continue;
             }
@@ -1880,8 +1901,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         if (!S.in_use) continue;
         any_coll |= S.collides;
         any_inst_general |= !S.ring() && S.inst != nullptr;
-        if (S.nested_fed && S.auto_capacity && S.dev_count > S.capacity / 2 && S.capacity < 0x70000000u)
-            ctx->grow_scratch.push_back((uint32_t)si);
+        if (S.nested_fed && nested_fed_wants_growth(S)) ctx->grow_scratch.push_back((uint32_t)si);
         if (!S.win_ok) continue;
         // an age is an fp32 running sum of the dt values: up to half an ulp of the age per step taken, i.e. a relative
         // error below steps * 6e-8; the horizon carries that (with a factor 4) on top of a fixed 1e-3
@@ -1894,17 +1914,15 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         if (S.win_sum < S.ub) S.ub = (uint32_t)S.win_sum;
     }
 
-    // Types fed by Nested entries cannot be bounded by the host (children are counted per parent on the device), so
-    // they cannot grow exactly when needed the way Global-fed ones do (the reference's Vec::push, core.rs:523).  Their
-    // derived capacity follows the live count seen in the snapshot rows instead: past half full, it doubles -- well
-    // before the device-side clamp (FW_ECAPACITY) could drop a particle.  Caller-given capacities are left alone.
+    // Nested-fed segments whose count (or its growth) nears their derived capacity: nested_fed_wants_growth.  By half again,
+    // not by doubling.  Caller-given capacities are left alone.
     for (uint32_t si : ctx->grow_scratch) {
         SegHost &S = ctx->segs[si];
         // (growing one type's children may already have grown a later entry of the list)
-        if (!S.in_use || !S.nested_fed || !S.auto_capacity || S.dev_count <= S.capacity / 2) continue;
-        if (S.capacity >= 0x70000000u) continue;
-        S.dev_count = 0;
-        fw_status gst = grow_segment(ctx, si, S.capacity * 2u);
+        if (!S.in_use || !nested_fed_wants_growth(S)) continue;
+        const uint32_t want = (uint32_t)std::min<uint64_t>((uint64_t)S.capacity * 3 / 2 + (uint64_t)(64.0f * S.dev_rate), 0x70000000ull);
+        S.dev_count = 0, S.dev_rate = 0.f, S.dev_epoch = 0;
+        fw_status gst = grow_segment(ctx, si, want, false);
         if (!gst) gst = grow_nested_children(ctx, ctx->spawners[S.spawner], (uint32_t)S.type);
         if (gst) return gst;
     }

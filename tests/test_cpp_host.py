@@ -22,6 +22,8 @@ def test_cpp_example_builds_and_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 1 and "no CPU fallback" in r.stderr
+    r = subprocess.run([os.path.join(ROOT, "examples", "sharded"), "--gpus", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr  # the native multi-GPU host: same rule
 
 
 @pytest.mark.gpu
@@ -105,3 +107,46 @@ def test_cpp_mirror_and_python_mirror_drive_the_library_identically():
     lines.append(f"destroyed reported {seen[0]}")
     assert cpp_lines == lines, "\n".join(["C++:"] + cpp_lines + ["Python:"] + lines)
     assert int(cpp_lines[-2].split()[3]) > 1000 and seen[0] > 2000
+
+
+@pytest.mark.gpu
+def test_native_sharded_host_matches_the_python_sharding(tmp_path):
+    """examples/sharded.cpp -- N contexts, the live-count device ring, ncclAllReduce of bucketed per-frame totals, all from
+    C++ over include/firework.hpp -- against bevy_firework_amd.sharding.ShardedParticleSystem on the same workload (one GPU
+    here: one rank; the RCCL calls are made all the same): the per-frame global live totals and the per-emitter counts must be
+    identical, in the single-process form and in the one-process-per-GPU form"""
+    import numpy as np
+    import torch
+
+    from bevy_firework_amd import sharding, workloads
+    from bevy_firework_amd.system import ParticleSystem
+
+    build()
+    exe = os.path.join(ROOT, "examples", "sharded")
+    common = ["--emitters", "48", "--live", "2048", "--frames", "44", "--reduce-every", "8"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = []
+    for how in (["--gpus", "1"], ["--rank", "0", "--world", "1", "--id-file", str(tmp_path / "nccl_id")]):
+        r = subprocess.run([exe] + how + common, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines())
+    assert outs[0][:45] == outs[1][:45]
+    cpp_hist = [int(ln.split()[3]) for ln in outs[0] if ln.startswith("frame ")]
+    cpp_digest = re.search(r"counts_digest ([0-9a-f]{16})", "\n".join(outs[0])).group(1)
+    assert len(cpp_hist) == 44 and cpp_hist[-1] > 60000
+
+    stream = torch.cuda.Stream()
+    dt = np.float32(1.0 / 60.0)
+    sh = sharding.ShardedParticleSystem(lambda: ParticleSystem(device=0, seed=workloads.SEED, stream=stream.cuda_stream),
+                                        workloads.many_emitters(48, 2048), 0, 1, reduce_every=8, torch_stream=stream, exchange=True)
+    sh.update(dt)
+    for _ in range(43):
+        sh.step(dt)
+    sh.flush()
+    assert sh.global_live_history == cpp_hist
+    h = 1469598103934665603
+    for e, d in zip(sh.global_indices, sh.handles):
+        for x in np.array([e, d.count(0)], dtype=np.uint32).tobytes():
+            h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert f"{h:016x}" == cpp_digest
+    sh.system.close()
