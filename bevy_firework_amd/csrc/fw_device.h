@@ -84,6 +84,13 @@ struct alignas(16) FwType {
     float const_rot[4];
 };
 #define FW_TYPE_NOSPIN 1u
+// FW_TYPE_DERIVED: the type has an attached ParticleInstance buffer (fw_spawner_attach_instances), which receives scale,
+// base colour and emissive colour of every survivor in its 64-byte record -- the planes S4 / Q5 / Q6 would only hold a
+// second copy (36 of the 228 bytes an update + records moved per particle).  They are pure functions of (age, lifetime,
+// initial_scale): the update does not store them, and whoever reads them (fw_k_gather, fw_k_pack, the AABB query, the
+// destroyed records) evaluates them again from the stored age -- the same functions on the same inputs the update used,
+// bit for bit (render.rs:95-115, 403).  Cleared, after fw_k_rederive has filled the planes, when the buffer is detached.
+#define FW_TYPE_DERIVED 2u
 // (the update kernels of the general path learn the flag before the type record arrives -- their loads depend on it --
 // from bit 31 of the type index in the tile descriptor / FwUpdateArgs::seg0_type / FwFifoSeg::type_idx)
 #define FW_TYPE_IDX_NOSPIN 0x80000000u

@@ -190,6 +190,12 @@ struct alignas(64) SegHost {
     uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
     uint32_t r_low[3] = {0, 0, 0};               // frames in a row a role's need has been far below what is provided
     bool ring() const { return fifo || range; }  // one buffer, particle 0 not in slot 0
+    // FW_TYPE_DERIVED (fw_device.h): an instance buffer is attached -- its records carry scale and colours, the planes S4 / Q5 /
+    // Q6 are not stored by the update; every reader evaluates them from age / lifetime / initial_scale
+    bool derived = false;
+    // where the lifetime of particle i is when the type cannot turn: a plane index (compacting / range segments), or
+    // 0xFFFFFFFF = the one value fifo_life (a FIFO ring)
+    uint32_t life_plane() const { return (nospin && !fifo) ? n_lplanes : 0xFFFFFFFFu; }
 };
 
 struct SpawnerHost {
@@ -345,6 +351,7 @@ struct fw_ctx {
     bool use_fifo = true;      // FW_FIFO=0: constant-lifetime types take the general (compacting) path too (A/B, tests)
     bool fifo_nested = true;   // FW_FIFO_NESTED=0: ... those of spawners with Nested entries do (A/B)
     bool use_nospin = true;    // FW_NOSPIN=0: every type keeps its rotation plane (A/B)
+    bool use_derived = true;   // FW_DERIVED=0: types with an attached instance buffer keep storing scale / colour planes (A/B)
     // Smallest (derived or given) capacity that makes a type a FIFO ring (FW_FIFO_MIN; the tests set 0).  Below a few
     // tens of thousands of particles a frame is launch latency whatever the path.  Next to compacting segments the ring
     // launch runs on its own stream (fifo_stream) and wins at any size (tools/fifo_threshold.py, tools/mixed_context.py);
@@ -865,10 +872,29 @@ fw_status leave_nospin(fw_ctx *ctx, uint32_t si) {
     FW_HIP(ctx, fw_launch_restore_q3(ctx->stream, s.buf[0], s.ring() ? nullptr : s.buf[1], s.capacity,
                                      s.fifo ? 0xFFFFFFFFu : s.n_lplanes, s.fifo_life));
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t zero = 0;
-    FW_HIP(ctx, hipMemcpy((char *)(ctx->d_types.d + s.type_idx) + offsetof(FwType, flags), &zero, sizeof zero, hipMemcpyHostToDevice));
+    const uint32_t flags = s.derived ? FW_TYPE_DERIVED : 0u;
+    FW_HIP(ctx, hipMemcpy((char *)(ctx->d_types.d + s.type_idx) + offsetof(FwType, flags), &flags, sizeof flags, hipMemcpyHostToDevice));
     s.nospin = false;
     ctx->tab_force = true, ctx->r_force = true;  // (the tile descriptors carry the flag)
+    ctx->fc_ok = false, ctx->boxes_epoch = 0;
+    return FW_OK;
+}
+
+// FW_TYPE_DERIVED on / off (SegHost::derived).  Off: the planes nobody maintained are filled from age / lifetime / initial_scale
+// first (`refill` false when the caller is about to overwrite the particles anyway).
+fw_status set_derived(fw_ctx *ctx, uint32_t si, bool on, bool refill = true) {
+    SegHost &s = ctx->segs[si];
+    if (s.derived == on) return FW_OK;
+    fw_status st = sync(ctx);
+    if (st) return st;
+    if (!on && refill) {
+        FW_HIP(ctx, fw_launch_rederive(ctx->stream, s.buf[ctx->parity], s.capacity, ctx->d_types.d + s.type_idx, ctx->d_keys.d, s.nospin,
+                                       s.life_plane(), s.fifo_life));
+        FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    uint32_t flags = (s.nospin ? FW_TYPE_NOSPIN : 0u) | (on ? FW_TYPE_DERIVED : 0u);
+    FW_HIP(ctx, hipMemcpy((char *)(ctx->d_types.d + s.type_idx) + offsetof(FwType, flags), &flags, sizeof flags, hipMemcpyHostToDevice));
+    s.derived = on;
     ctx->fc_ok = false, ctx->boxes_epoch = 0;
     return FW_OK;
 }
@@ -1566,6 +1592,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_FIFO_STREAM")) ctx->use_fifo_stream = atoi(m) != 0;
     if (const char *m = getenv("FW_NOSPIN")) ctx->use_nospin = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE")) ctx->use_range = atoi(m) != 0;
+    if (const char *m = getenv("FW_DERIVED")) ctx->use_derived = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_MIN")) ctx->range_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_RANGE_DEVREC")) ctx->range_devrec = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_FOLD")) ctx->range_fold = atoi(m) != 0;
@@ -2425,8 +2452,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             uint32_t k_ops = 0;
             for (const FwOp &op : ctx->fifo_ops) k_ops += op.seg == si ? 1u : 0u;  // (at most FW_MAX_EMISSIONS)
             if (fa.n_segs == FW_FIFO_PER_LAUNCH || f_ops + k_ops > FW_INLINE_OPS) FW_HIP(ctx, flush());
-            if (!fa.n_segs) fa.write_mask = S.fifo_wm;
-            else if (fa.write_mask != S.fifo_wm) fa.write_mask = -1;
+            const int32_t wm = S.derived ? 0 : S.fifo_wm;  // (FW_TYPE_DERIVED: none of the optional planes is stored)
+            if (!fa.n_segs) fa.write_mask = wm;
+            else if (fa.write_mask != wm) fa.write_mask = -1;
             // frames that materialise (Nested pass): the segment's Global particles of this frame already sit in the ring
             const bool mat_frame = S.fifo_mat && nested_frame;
             const bool mat = S.fifo_dev || mat_frame;
@@ -2583,7 +2611,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                         FwRangeDesc &D = ctx->h_rdesc[t++];
                         D.seg = si, D.role_k = (role << 30) | k, D.old_first = old_first;
                         D.type_idx = S.type_idx | (S.nospin ? FW_TYPE_IDX_NOSPIN : 0u);
-                        D.keys_off = S.keys_off, D.keys_len = S.keys_len;
+                        D.keys_off = S.keys_off, D.keys_len = S.keys_len, D.n_old = S.r_old, D.pad = 0;
                     }
             }
             ctx->r_total = (uint32_t)t;
@@ -2717,7 +2745,7 @@ static fw_status stage_buffer(fw_ctx *ctx, size_t bytes, void **out) {
 
 static fw_status read_records(fw_ctx *ctx, const char *buf, uint32_t cap_seg, uint32_t n, int32_t pbr, bool aos,
                               fw_particle *out, uint64_t cap, uint32_t head = 0, const float *const_rot = nullptr,
-                              uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.f) {
+                              uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.f, const FwType *derived = nullptr) {
     const uint64_t m = std::min<uint64_t>(n, cap);
     if (!m || !out) return FW_OK;
     if (aos) {
@@ -2727,7 +2755,8 @@ static fw_status read_records(fw_ctx *ctx, const char *buf, uint32_t cap_seg, ui
     void *tmp = nullptr;
     fw_status st = stage_buffer(ctx, m * sizeof(fw_particle), &tmp);
     if (st) return st;
-    hipError_t e = fw_launch_gather(ctx->stream, buf, cap_seg, head, (uint32_t)m, pbr, tmp, const_rot, life_plane, life_const);
+    hipError_t e = fw_launch_gather(ctx->stream, buf, cap_seg, head, (uint32_t)m, pbr, tmp, const_rot, life_plane, life_const,
+                                    derived, ctx->d_keys.d);
     // (the copy goes through the stream the kernel ran on, then one wait for both)
     if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, m * sizeof(fw_particle), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -2748,7 +2777,8 @@ fw_status fw_spawner_read_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
     if (n_out) *n_out = n;
     fw_status st2 = read_records(ctx, S.buf[ctx->parity], S.capacity, n, sp->types[type].ps.pbr, false, out, cap,
                                  ring_head_exact(S, n), S.nospin ? S.const_rot : nullptr,
-                                 (S.nospin && !S.fifo) ? S.n_lplanes : 0xFFFFFFFFu, S.fifo_life);
+                                 (S.nospin && !S.fifo) ? S.n_lplanes : 0xFFFFFFFFu, S.fifo_life,
+                                 S.derived ? ctx->d_types.d + S.type_idx : nullptr);
     return st2 ? st2 : st;
 }
 
@@ -2790,6 +2820,7 @@ fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, c
     ctx->fc_ok = false, ctx->boxes_epoch = 0;
     if ((st = fifo_to_general(ctx, si))) return st;  // ages and lifetimes will be whatever the caller writes
     if ((st = leave_nospin(ctx, si))) return st;      // ... and so will rotations and angular velocities
+    if ((st = set_derived(ctx, si, false))) return st;  // ... and scales and colours (an attached buffer keeps receiving records)
     if (n > ctx->segs[si].capacity) {
         ctx->segs[si].ub = 0;
         const uint32_t zero = 0;
@@ -2866,7 +2897,8 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
     // (a range ring: particle 0 sits `count - young_n` slots before the first young particle -- the kernel reads the count)
     FW_HIP(ctx, fw_launch_pack_instances(ctx->stream, S.buf[ctx->parity], S.capacity, S.range ? S.young_lo : (S.fifo ? S.head : 0u),
                                          ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, ub, d_out,
-                                         S.nospin ? S.const_rot : nullptr, S.range ? S.young_n : 0xFFFFFFFFu));
+                                         S.nospin ? S.const_rot : nullptr, S.range ? S.young_n : 0xFFFFFFFFu,
+                                         S.derived ? ctx->d_types.d + S.type_idx : nullptr, ctx->d_keys.d, S.life_plane(), S.fifo_life));
     return FW_OK;
 }
 
@@ -2887,6 +2919,11 @@ fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, 
     SegHost &S = ctx->segs[sp->seg[type]];
     S.inst = (char *)d_out;
     S.inst_cap = d_out ? (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull) : 0u;
+    // the records carry scale and colours from now on: the update stops storing the three planes that would duplicate them
+    // (every reader of those planes evaluates them instead, so a buffer smaller than the live count loses nothing either);
+    // colliding types stay as they are (the feature path)
+    const bool derive = d_out != nullptr && ctx->use_derived && !S.collides;
+    if ((st = set_derived(ctx, sp->seg[type], derive))) return st;
     return upload_seg(ctx, sp->seg[type]);
 }
 
@@ -2932,12 +2969,14 @@ fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out
         const uint32_t n = (uint32_t)std::min<size_t>(8, nt - std::min(nt, t0));
         if (!n) break;
         bool any_ring = false;  // rings leave no per-tile boxes: the two-pass query reads them
-        uint32_t heads[8] = {}, range_y[8];
+        uint32_t heads[8] = {}, range_y[8], life_plane[8];
+        float life_const[8];
         for (uint32_t t = 0; t < n; t++) {
             const SegHost &S = ctx->segs[sp->seg[t0 + t]];
             any_ring |= S.ring();
             heads[t] = S.range ? S.young_lo : (S.fifo ? S.head : 0u);
             range_y[t] = S.range ? S.young_n : 0xFFFFFFFFu;
+            life_plane[t] = S.life_plane(), life_const[t] = S.fifo_life;
         }
         if (ctx->boxes_epoch && ctx->d_tile_first && !any_ring) {
             // the last update left the box of every tile's survivors (fw_ctx_track_aabbs): fold those -- one small launch
@@ -2946,7 +2985,7 @@ fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out
         } else {
             // two launches over the particles, the result lands in pinned memory: one synchronisation, no copies
             FW_HIP(ctx, fw_launch_aabb(ctx->stream, ctx->g, sp->seg.data() + t0, heads, n, ctx->parity, ctx->d_aabb, ctx->h_aabb,
-                                       range_y));
+                                       range_y, life_plane, life_const));
         }
         fw_status st = sync(ctx);
         if (!st) st = check_device_errors(ctx);
@@ -3140,6 +3179,10 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t
         // ... and its lifetimes in a 4-byte plane instead of Q3: -32 B again, +4 B read, +4 B written
         moved = 64u + 64u + 4u + colours + 8u * S.n_lplanes - (S.nospin ? 32u + 32u - 8u : 0u);
         algo = moved - 8u;
+    }
+    if (S.derived) {  // scale and colour planes are not stored (the instance record carries them: +64 B written per particle)
+        const uint32_t skipped = colours + ((S.ring() && T.scale.kind == 0) ? 0u : 4u);
+        moved -= std::min(moved, skipped), algo -= std::min(algo, skipped);
     }
     if (moved_bytes) *moved_bytes = moved;
     if (algorithmic_bytes) *algorithmic_bytes = algo;

@@ -178,7 +178,8 @@ struct alignas(16) FwRangeDesc {  // per workgroup (device table, re-sent only w
     uint32_t old_first;  // global index of the segment's first OLD workgroup (look-back window)
     uint32_t type_idx;   // | FW_TYPE_IDX_NOSPIN
     uint32_t keys_off, keys_len;
-    uint32_t pad[2];
+    uint32_t n_old;      // OLD workgroups the table provides for the segment (the kernel checks the old part against it)
+    uint32_t pad;
 };
 struct FwRangeArgs {
     const FwRangeDesc *desc;
@@ -218,8 +219,13 @@ hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d
 // (const_rot: the rotation of a type that cannot turn -- FW_TYPE_NOSPIN, its plane is not maintained -- or null)
 // (... and then its lifetimes sit in plane `life_plane` behind the last_emitted_age planes, or -- a ring: 0xFFFFFFFF -- all
 // equal life_const)
+// (derived: the type's device record when it is FW_TYPE_DERIVED -- scale and colours are then evaluated, not read -- + the key pool)
 hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, uint32_t n, int32_t pbr, void *d_out,
-                            const float *const_rot = nullptr, uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.0f);
+                            const float *const_rot = nullptr, uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.0f,
+                            const FwType *derived = nullptr, const float *keys = nullptr);
+// fills the scale / colour planes of one buffer from age, lifetime and initial_scale (a type leaves FW_TYPE_DERIVED)
+hipError_t fw_launch_rederive(hipStream_t s, char *buf, uint32_t capacity, const FwType *d_type, const float *d_keys, bool nospin,
+                              uint32_t life_plane, float life_const);
 hipError_t fw_launch_fill_plane1(hipStream_t s, char *buf0, char *buf1, size_t plane_off, uint32_t capacity, float v);
 hipError_t fw_launch_restore_q3(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, uint32_t life_plane, float life_const);
 hipError_t fw_launch_scatter(hipStream_t s, char *buf, uint32_t capacity, uint32_t n, uint32_t n_lplanes,
@@ -230,14 +236,16 @@ hipError_t fw_launch_fill_colors(hipStream_t s, char *buf0, char *buf1, uint32_t
 // (count - range_y) slots before it)
 hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, const uint32_t *d_count,
                                     uint32_t n_upper, void *d_out, const float *const_rot = nullptr,
-                                    uint32_t range_y = 0xFFFFFFFFu);
+                                    uint32_t range_y = 0xFFFFFFFFu, const FwType *derived = nullptr, const float *keys = nullptr,
+                                    uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.0f);
 // fills the rotation plane of both buffers of a segment (a type leaves FW_TYPE_NOSPIN)
 hipError_t fw_launch_fill_rotation(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, const float rot[4]);
 // seg_ids: host array; d_part: device scratch of 256 * 8 floats; h_out8: PINNED host {min.xyz, any, max.xyz, -}
 // seg_heads: ring heads of the segments (host array, or null = all 0); seg_range_y (or null): per segment 0xFFFFFFFF, or --
 // a range ring -- its young count: seg_heads[i] is then the slot of its first young particle (see fw_launch_pack_instances)
 hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, const uint32_t *seg_heads, uint32_t n_segs,
-                          uint32_t parity, float *d_part, float *h_out8, const uint32_t *seg_range_y = nullptr);
+                          uint32_t parity, float *d_part, float *h_out8, const uint32_t *seg_range_y = nullptr,
+                          const uint32_t *seg_life_plane = nullptr, const float *seg_life_const = nullptr);
 // the same query answered from the per-tile boxes of the last update (epoch = that update's)
 hipError_t fw_launch_aabb_from_tiles(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, uint32_t n_segs,
                                      uint32_t parity, uint32_t epoch, const uint32_t *d_seg_tile_first, float *h_out8);

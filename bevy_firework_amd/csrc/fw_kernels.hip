@@ -129,14 +129,16 @@ struct FwOutWin {  // output planes advanced to slot `first` (workgroup-uniform)
     // Q3 (angular velocity 0 + lifetime): wr3 false -> the lifetime goes to `lf`, Q3 is not written
     bool wr3;
     char *lf;
+    bool wr4;  // scale plane (false, like wr5 / wr6, for a type whose instance records carry it: FW_TYPE_DERIVED)
 };
 __device__ __forceinline__ FwOutWin fw_out_window(char *ob, uint32_t C, uint32_t first, const FwType &T, uint32_t force_colors,
                                                   uint32_t n_lplanes = 0u) {
     const size_t f16 = (size_t)first * 16u;
     return FwOutWin{ob + FW_OFF_Q0(C) + f16, ob + FW_OFF_Q1(C) + f16, ob + FW_OFF_Q2(C) + f16, ob + FW_OFF_Q3(C) + f16,
                     ob + FW_OFF_Q5(C) + f16, ob + FW_OFF_Q6(C) + f16, ob + FW_OFF_S4(C) + (size_t)first * 4u, first,
-                    T.bc_kind != 0 || force_colors != 0u, T.em_kind != 0 || force_colors != 0u, !(T.flags & FW_TYPE_NOSPIN),
-                    !(T.flags & FW_TYPE_NOSPIN), ob + FW_OFF_L(C, n_lplanes) + (size_t)first * 4u};
+                    (T.bc_kind != 0 || force_colors != 0u) && !(T.flags & FW_TYPE_DERIVED),
+                    (T.em_kind != 0 || force_colors != 0u) && !(T.flags & FW_TYPE_DERIVED), !(T.flags & FW_TYPE_NOSPIN),
+                    !(T.flags & FW_TYPE_NOSPIN), ob + FW_OFF_L(C, n_lplanes) + (size_t)first * 4u, !(T.flags & FW_TYPE_DERIVED)};
 }
 
 // slot of logical particle i of a segment whose particle 0 sits in slot `head` (0 unless the segment is a FIFO ring)
@@ -376,14 +378,14 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
         if (W.wr3 && __any(full || d3 != 0u)) fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
         if ((WM >= 0 ? (WM & 1) != 0 : W.wr5) || full) fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
         if ((WM >= 0 ? (WM & 2) != 0 : W.wr6) || full) fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
-        if ((WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) || full) fw_st1w(W.s4, (o - W.first) * 4u, scale);
+        if ((WM >= 0 ? (WM & 4) != 0 : (T.sc_kind != 0 && W.wr4)) || full) fw_st1w(W.s4, (o - W.first) * 4u, scale);
     } else {
         if (W.wr2) fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
         if (W.wr3) fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
         else fw_st1w(W.lf, (o - W.first) * 4u, lifetime);
         if (W.wr5) fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));  // workgroup-uniform branches
         if (W.wr6) fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
-        fw_st1w(W.s4, (o - W.first) * 4u, scale);
+        if (W.wr4) fw_st1w(W.s4, (o - W.first) * 4u, scale);
     }
     if (box_on) {  // update_aabbs (render.rs:677-703): running min / max of position -/+ scale, per lane
         // (`box` always points at the caller's local array when box_on can be true: never selected against null, so it
@@ -426,6 +428,18 @@ __device__ __forceinline__ float4 fw_record_rotation(const FwType &T, float4 q2)
     return q2;
 }
 
+// scale, base colour and emissive colour of a particle as the update that produced its stored `age` computed them
+// (core.rs:601-605, 652-655): what the S4 / Q5 / Q6 planes hold -- or would hold, for a FW_TYPE_DERIVED type
+__device__ __forceinline__ void fw_derived_values(const FwType &T, const float *keys, float age, float lifetime, float initial_scale,
+                                                  float4 *bc, float4 *em, float *sc) {
+    const float ap = age / lifetime;
+    float b4[4], e4[4];
+    fw_gradient_sample(T.bc_kind, T.bc_n, keys + T.o_bc_t, keys + T.o_bc_v, ap, b4);
+    fw_gradient_sample(T.em_kind, T.em_n, keys + T.o_em_t, keys + T.o_em_v, ap, e4);
+    *bc = make_float4(b4[0], b4[1], b4[2], b4[3]), *em = make_float4(e4[0], e4[1], e4[2], e4[3]);
+    *sc = initial_scale * fw_curve_sample(T.sc_kind, T.sc_n, keys, keys + T.o_sc_v, ap);
+}
+
 // destroyed record = the clone with age already advanced, pose of the previous frame (core.rs:596-599)
 __device__ __forceinline__ void fw_store_destroyed(char *dbuf, const char *ib, uint32_t C, uint32_t idx, bool loaded,
                                                    const FwType &T, const float *s_keys, float4 q0, float4 q1,
@@ -435,7 +449,9 @@ __device__ __forceinline__ void fw_store_destroyed(char *dbuf, const char *ib, u
     const int32_t pbr = T.pbr;
     float4 bc, em;
     float sc;
-    if (loaded) {
+    if (loaded && (T.flags & FW_TYPE_DERIVED)) {  // the planes are not maintained: what the previous update computed, again
+        fw_derived_values(T, s_keys, q0.w, q3.w, q1.w, &bc, &em, &sc);
+    } else if (loaded) {
         bc = fw_ld4(ib + FW_OFF_Q5(C), idx), em = fw_ld4(ib + FW_OFF_Q6(C), idx);
         sc = reinterpret_cast<const float *>(ib + FW_OFF_S4(C))[idx];
     } else {  // born and destroyed in the same frame: spawn-time colours and scale (core.rs:457-461)
@@ -1723,9 +1739,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
                     const uint32_t b16 = (uint32_t)(r * BLK + (int)tid) * 16u;
                     const float4 q0 = fw_ld4w(iw0, b16), q1 = fw_ld4w(iw1, b16), q2 = fw_ld4w(iw2, b16 & m2);
                     const float4 q3 = nospin ? q3s : fw_ld4w(iw3, b16);
-                    // (a materialised particle that dies in its first update: its planes hold the spawn-time colours and
-                    // scale, which is what the record of a particle born and destroyed in one frame carries)
-                    fw_store_destroyed(F.destroyed, buf, C, s, true, T, s_keys, q0, q1, q2, q3, q0.w + a.dt, i);
+                    // (a materialised particle that dies in its first update carries the spawn-time colours and scale, like any
+                    // particle born and destroyed in one frame: evaluated, not read -- the planes of a FW_TYPE_DERIVED type
+                    // are not maintained, and for everybody else they hold exactly these values)
+                    fw_store_destroyed(F.destroyed, buf, C, s, i < full_from, T, s_keys, q0, q1, q2, q3, q0.w + a.dt, i);
                 }
             }
         }
@@ -1962,6 +1979,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
 
     // ---- OLD: in-place compaction towards the young part.  Distance d from the young part: slot = b - 1 - d.
     const uint32_t base = k * TILE;
+    if (k == 0u && tid == 0u && n_old_in > D.n_old * TILE) {  // the host's bound of the old part was not one (internal error)
+        atomicOr(g.err, FW_ERR_CAPACITY);
+        g.err[1] = seg, g.err[2] = n_old_in, g.err[3] = D.n_old, g.err[4] = cnt_in;
+    }
     const bool want_destroyed_any = Sp->destroyed != nullptr;
     if (base >= n_old_in) {
         if (k == 0u && tid == 0u) {  // nobody old: the segment's bookkeeping is still this workgroup's
@@ -2122,7 +2143,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpda
     const uint32_t tis = tile - a.seg_tile_first[seg];
     const uint32_t p = a.parity;
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
-    const uint32_t n_tot = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
+    const uint32_t n_before = g.count[sidx];  // particles that existed before this frame's spawns
+    const uint32_t n_tot = n_before + g.spawned[sidx] + g.appended[sidx];
     const uint32_t base = tis * FW_TILE;
     if (blockIdx.x == 0 && tid == 0 && a.live_next) *a.live_next = 0ull;
     if (blockIdx.x == 0 && tid == 0 && a.done_tag) *a.done_tag = a.done_value;
@@ -2193,11 +2215,18 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpda
             for (uint32_t k = 0; k < n_lplanes; k++) fw_st1(ob + FW_OFF_L(C, k), o, fw_ld1(ib + FW_OFF_L(C, k), idx));
         } else if (valid && want_destroyed) {
             if (!killed) {  // died of age: the clone with the advanced age, pose of the previous frame (core.rs:596-599)
-                fw_store_destroyed(destroyed, ib, C, idx, true, T, s_keys, q0, q1, q2, q3, age_new, idx - o);
+                // (idx >= count: materialised this frame, never updated -- spawn-time colours and scale, evaluated)
+                fw_store_destroyed(destroyed, ib, C, idx, idx < n_before, T, s_keys, q0, q1, q2, q3, age_new, idx - o);
             } else {  // destroyed by a collision (core.rs:633-639): new position, velocity and scale; the rest as loaded
                 const float sc = q1.w * fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_new / q3.w);
                 float *rec = reinterpret_cast<float *>(destroyed) + (size_t)(idx - o) * 26;
-                const float4 bc = fw_ld4(ib + FW_OFF_Q5(C), idx), em = fw_ld4(ib + FW_OFF_Q6(C), idx);
+                float4 bc, em;
+                if ((T.flags & FW_TYPE_DERIVED) && idx < n_before) {
+                    float unused;
+                    fw_derived_values(T, s_keys, q0.w, q3.w, q1.w, &bc, &em, &unused);
+                } else {  // (a particle materialised this frame: its slot was written in full when it was spawned)
+                    bc = fw_ld4(ib + FW_OFF_Q5(C), idx), em = fw_ld4(ib + FW_OFF_Q6(C), idx);
+                }
                 // (a type that cannot turn keeps no rotation plane: the loaded q2 is whatever the slot last held)
                 const float4 r2 = fw_record_rotation(T, q2);
                 rec[0] = cpos.x, rec[1] = cpos.y, rec[2] = cpos.z, rec[3] = cvel.x, rec[4] = cvel.y, rec[5] = cvel.z;
@@ -2479,7 +2508,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
 // SoA planes -> fw_particle records (26 x 4 B)
 // (rot: the rotation of every particle of a type that cannot turn -- FW_TYPE_NOSPIN, its plane is not maintained -- or null)
 __global__ void fw_k_gather(const char *buf, uint32_t C, uint32_t head, uint32_t n, int32_t pbr, float *out, bool nospin, float4 rot,
-                            uint32_t life_plane, float life_const) {
+                            uint32_t life_plane, float life_const, const FwType *derived, const float *keys) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
     const uint32_t i = fw_ring_slot(head, li, C);
@@ -2488,8 +2517,10 @@ __global__ void fw_k_gather(const char *buf, uint32_t C, uint32_t head, uint32_t
                  // (cannot turn: angular velocity 0; the lifetime from its plane, or -- a ring -- the type's one value)
                  q3 = !nospin ? fw_ld4(buf + FW_OFF_Q3(C), i)
                               : make_float4(0.0f, 0.0f, 0.0f, life_plane != 0xFFFFFFFFu ? fw_ld1(buf + FW_OFF_L(C, life_plane), i) : life_const),
-                 bc = fw_ld4(buf + FW_OFF_Q5(C), i), em = fw_ld4(buf + FW_OFF_Q6(C), i);
-    const float sc = reinterpret_cast<const float *>(buf + FW_OFF_S4(C))[i];
+                 bc0 = fw_ld4(buf + FW_OFF_Q5(C), i), em0 = fw_ld4(buf + FW_OFF_Q6(C), i);
+    float4 bc = bc0, em = em0;
+    float sc = reinterpret_cast<const float *>(buf + FW_OFF_S4(C))[i];
+    if (derived) fw_derived_values(*derived, keys + derived->keys_off, q0.w, q3.w, q1.w, &bc, &em, &sc);  // FW_TYPE_DERIVED
     float *r = out + (size_t)li * 26;
     r[0] = q0.x, r[1] = q0.y, r[2] = q0.z;
     r[3] = q1.x, r[4] = q1.y, r[5] = q1.z;
@@ -2524,6 +2555,26 @@ __global__ void fw_k_fill_colors(char *buf0, char *buf1, uint32_t C, float4 bc, 
     if (buf1) fw_st4(buf1 + FW_OFF_Q5(C), i, bc), fw_st4(buf1 + FW_OFF_Q6(C), i, em);
 }
 
+// a type leaves FW_TYPE_DERIVED (its instance buffer is detached): scale and colour planes of every slot, evaluated from
+// the slot's age / lifetime / initial_scale -- what the updates would have stored
+__global__ void fw_k_rederive(char *buf, uint32_t C, const FwType *T, const float *keys, bool nospin, uint32_t life_plane, float life_const) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i);
+    const float life = !nospin ? fw_ld4(buf + FW_OFF_Q3(C), i).w
+                               : (life_plane != 0xFFFFFFFFu ? fw_ld1(buf + FW_OFF_L(C, life_plane), i) : life_const);
+    float4 bc, em;
+    float sc;
+    fw_derived_values(*T, keys + T->keys_off, q0.w, life, fw_ld4(buf + FW_OFF_Q1(C), i).w, &bc, &em, &sc);
+    fw_st4(buf + FW_OFF_Q5(C), i, bc), fw_st4(buf + FW_OFF_Q6(C), i, em), fw_st1(buf + FW_OFF_S4(C), i, sc);
+}
+hipError_t fw_launch_rederive(hipStream_t s, char *buf, uint32_t capacity, const FwType *d_type, const float *d_keys, bool nospin,
+                              uint32_t life_plane, float life_const) {
+    if (!capacity) return hipSuccess;
+    hipLaunchKernelGGL(fw_k_rederive, dim3((capacity + 255) / 256), dim3(256), 0, s, buf, capacity, d_type, d_keys, nospin, life_plane, life_const);
+    return hipGetLastError();
+}
+
 // a type leaves FW_TYPE_NOSPIN: its rotation plane, which nobody maintained, gets the constant rotation in every slot
 __global__ void fw_k_fill_rotation(char *buf0, char *buf1, uint32_t C, float4 rot) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2553,7 +2604,8 @@ __global__ void fw_k_restore_q3(char *buf0, char *buf1, uint32_t C, uint32_t lif
 // transposed through LDS so that every store instruction of a wave writes 1 KiB of consecutive bytes (a lane writing
 // its own record with four float4 stores would touch 64 lines a quarter at a time).
 __global__ __launch_bounds__(256) void fw_k_pack(const char *buf, uint32_t C, uint32_t head, const uint32_t *d_count,
-                                                 uint32_t n_upper, float4 *out, bool nospin, float4 rot, uint32_t range_y) {
+                                                 uint32_t n_upper, float4 *out, bool nospin, float4 rot, uint32_t range_y,
+                                                 const FwType *derived, const float *keys, uint32_t life_plane, float life_const) {
     __shared__ float4 s_rec[256 * 4];
     if (range_y != 0xFFFFFFFFu) {  // a range ring: `head` is the slot of the first young particle (fw_kernels.h)
         const uint32_t c = *d_count, n_old = c > range_y ? c - range_y : 0u;
@@ -2564,10 +2616,15 @@ __global__ __launch_bounds__(256) void fw_k_pack(const char *buf, uint32_t C, ui
     for (uint32_t b = blockIdx.x * 256u; b < n; b += gridDim.x * 256u) {
         const uint32_t i = fw_ring_slot(head, min(b + tid, n - 1u), C);
         const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i);
-        const float sc = fw_ld1(buf + FW_OFF_S4(C), i);
+        float sc = fw_ld1(buf + FW_OFF_S4(C), i);
         const float4 q2 = nospin ? rot : fw_ld4(buf + FW_OFF_Q2(C), i);
-        const float4 q5 = fw_ld4(buf + FW_OFF_Q5(C), i);
-        const float4 q6 = fw_ld4(buf + FW_OFF_Q6(C), i);
+        float4 q5 = fw_ld4(buf + FW_OFF_Q5(C), i);
+        float4 q6 = fw_ld4(buf + FW_OFF_Q6(C), i);
+        if (derived) {  // FW_TYPE_DERIVED: the three planes are not maintained -- what the last update computed, again
+            const float life = !nospin ? fw_ld4(buf + FW_OFF_Q3(C), i).w
+                                       : (life_plane != 0xFFFFFFFFu ? fw_ld1(buf + FW_OFF_L(C, life_plane), i) : life_const);
+            fw_derived_values(*derived, keys + derived->keys_off, q0.w, life, fw_ld4(buf + FW_OFF_Q1(C), i).w, &q5, &q6, &sc);
+        }
         s_rec[tid * 4 + 0] = make_float4(q0.x, q0.y, q0.z, sc);
         s_rec[tid * 4 + 1] = q2;
         s_rec[tid * 4 + 2] = q5;
@@ -2612,6 +2669,8 @@ struct FwSegList {
     uint32_t id[8];    // FW_MAX_TYPES
     uint32_t head[8];  // slot of each segment's particle 0 (FIFO rings; 0 otherwise)
     uint32_t range_y[8];  // 0xFFFFFFFF, or -- a range ring -- its young count: head[] is the slot of its first young particle
+    uint32_t life_plane[8];  // FW_TYPE_DERIVED types (scale evaluated from age / lifetime): where a type that cannot turn keeps
+    float life_const[8];     // its lifetimes -- a plane behind the last_emitted_age planes, or (0xFFFFFFFF) one value
 };
 #define FW_AABB_BLOCKS 256u
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, FwSegList L, uint32_t parity, float *part8) {
@@ -2623,6 +2682,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, FwSegList L, 
         const FwSeg &S = g.segs[seg];
         const uint32_t n = g.count[parity * g.max_seg + seg];
         const char *buf = S.buf[parity];
+        const FwType &TT = g.types[S.type_idx];
         uint32_t head = L.head[k];
         if (L.range_y[k] != 0xFFFFFFFFu) {
             const uint32_t n_old = n > L.range_y[k] ? n - L.range_y[k] : 0u;
@@ -2631,7 +2691,13 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, FwSegList L, 
         for (uint32_t li = blockIdx.x * FW_BLOCK + threadIdx.x; li < n; li += gridDim.x * FW_BLOCK) {
             const uint32_t i = fw_ring_slot(head, li, S.capacity);
             const float4 q0 = fw_ld4(buf + FW_OFF_Q0(S.capacity), i);
-            const float sc = fw_ld1(buf + FW_OFF_S4(S.capacity), i);
+            float sc = fw_ld1(buf + FW_OFF_S4(S.capacity), i);
+            if (TT.flags & FW_TYPE_DERIVED) {  // the scale plane is not maintained: what the last update computed, again
+                const float life = !(TT.flags & FW_TYPE_NOSPIN) ? fw_ld4(buf + FW_OFF_Q3(S.capacity), i).w
+                                   : (L.life_plane[k] != 0xFFFFFFFFu ? fw_ld1(buf + FW_OFF_L(S.capacity, L.life_plane[k]), i) : L.life_const[k]);
+                const float *keys = g.keys + TT.keys_off;
+                sc = fw_ld4(buf + FW_OFF_Q1(S.capacity), i).w * fw_curve_sample(TT.sc_kind, TT.sc_n, keys, keys + TT.o_sc_v, q0.w / life);
+            }
             mn[0] = fminf(mn[0], q0.x - sc), mn[1] = fminf(mn[1], q0.y - sc), mn[2] = fminf(mn[2], q0.z - sc);
             mx[0] = fmaxf(mx[0], q0.x + sc), mx[1] = fmaxf(mx[1], q0.y + sc), mx[2] = fmaxf(mx[2], q0.z + sc);
         }
@@ -2892,11 +2958,11 @@ hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d
 }
 
 hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, uint32_t n, int32_t pbr, void *d_out,
-                            const float *const_rot, uint32_t life_plane, float life_const) {
+                            const float *const_rot, uint32_t life_plane, float life_const, const FwType *derived, const float *keys) {
     if (!n) return hipSuccess;
     const float4 rot = const_rot ? make_float4(const_rot[0], const_rot[1], const_rot[2], const_rot[3]) : make_float4(0.f, 0.f, 0.f, 1.f);
     hipLaunchKernelGGL(fw_k_gather, dim3((n + 255) / 256), dim3(256), 0, s, buf, capacity, head, n, pbr, (float *)d_out,
-                       const_rot != nullptr, rot, life_plane, life_const);
+                       const_rot != nullptr, rot, life_plane, life_const, derived, keys);
     return hipGetLastError();
 }
 
@@ -2934,23 +3000,26 @@ hipError_t fw_launch_fill_rotation(hipStream_t s, char *buf0, char *buf1, uint32
 }
 
 hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, const uint32_t *d_count,
-                                    uint32_t n_upper, void *d_out, const float *const_rot, uint32_t range_y) {
+                                    uint32_t n_upper, void *d_out, const float *const_rot, uint32_t range_y, const FwType *derived,
+                                    const float *keys, uint32_t life_plane, float life_const) {
     if (!n_upper) return hipSuccess;
     uint32_t blocks = (n_upper + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     const float4 rot = const_rot ? make_float4(const_rot[0], const_rot[1], const_rot[2], const_rot[3]) : make_float4(0.f, 0.f, 0.f, 1.f);
     hipLaunchKernelGGL(fw_k_pack, dim3(blocks), dim3(256), 0, s, buf, capacity, head, d_count, n_upper, (float4 *)d_out,
-                       const_rot != nullptr, rot, range_y);
+                       const_rot != nullptr, rot, range_y, derived, keys, life_plane, life_const);
     return hipGetLastError();
 }
 
 hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, const uint32_t *seg_heads, uint32_t n_segs,
-                          uint32_t parity, float *d_part, float *h_out8, const uint32_t *seg_range_y) {
+                          uint32_t parity, float *d_part, float *h_out8, const uint32_t *seg_range_y, const uint32_t *seg_life_plane,
+                          const float *seg_life_const) {
     if (!n_segs || n_segs > 8u) return hipErrorInvalidValue;  // FW_MAX_TYPES
     FwSegList L{};
     L.n = n_segs;
     for (uint32_t i = 0; i < n_segs; i++)
-        L.id[i] = seg_ids[i], L.head[i] = seg_heads ? seg_heads[i] : 0u, L.range_y[i] = seg_range_y ? seg_range_y[i] : 0xFFFFFFFFu;
+        L.id[i] = seg_ids[i], L.head[i] = seg_heads ? seg_heads[i] : 0u, L.range_y[i] = seg_range_y ? seg_range_y[i] : 0xFFFFFFFFu,
+        L.life_plane[i] = seg_life_plane ? seg_life_plane[i] : 0xFFFFFFFFu, L.life_const[i] = seg_life_const ? seg_life_const[i] : 0.0f;
     hipLaunchKernelGGL(fw_k_aabb, dim3(FW_AABB_BLOCKS), dim3(FW_BLOCK), 0, s, g, L, parity, d_part);
     hipLaunchKernelGGL(fw_k_aabb_fold, dim3(1), dim3(FW_AABB_BLOCKS), 0, s, g, L, parity, (const float *)d_part, h_out8);
     return hipGetLastError();

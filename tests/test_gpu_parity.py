@@ -417,6 +417,68 @@ def test_attached_instances_are_the_packed_records(system):
     pair.check(what="after detach")
 
 
+def test_attached_instances_replace_the_scale_and_colour_planes(system):
+    """with an instance buffer attached, the records carry scale and both colours:
+    the update stops storing the three planes that would duplicate them (FW_TYPE_DERIVED) and every reader evaluates them
+    from age / lifetime / initial_scale instead -- particles, the packing pass, destroyed records, the AABB must be what
+    they were; detaching fills the planes again.  A one-lifetime type (a FIFO ring where rings are on) and a lifetime range."""
+    import torch
+
+    grads = dict(scale_curve=S.FireworkCurve.even_samples([1.5, 2.0, 0.5]),  # (1.5 at age 0: scale != initial_scale there)
+                 base_color=S.FireworkGradient.uneven_samples(workloads.STRESS_GRADIENT),
+                 emissive_color=S.FireworkGradient.even_samples([(4.0, 2.0, 0.0, 1.0), (0.0, 0.0, 0.0, 1.0)]))
+    cap = 65536
+    t0 = S.ParticleSettings(lifetime=S.RandF32.constant(0.5), initial_scale=S.RandF32(0.02, 0.08), capacity=cap,
+                            particles_destroyed=lambda dead: None, **grads)
+    t1 = S.ParticleSettings(lifetime=S.RandF32(0.3, 0.9), initial_scale=S.RandF32(0.02, 0.08), capacity=cap, linear_drag=0.4,
+                            particles_destroyed=lambda dead: None, **grads)
+    es = [S.EmissionSettings(particle_index=t, emission_pacing=S.EmissionPacing.rate(50000.0),
+                             initial_velocity=S.RandVec3(S.RandF32(0.0, 4.0), (0.0, 1.0, 0.0), 0.0)) for t in (0, 1)]
+    pair = Pair(system, S.ParticleSpawner([t0, t1], es), S.Transform((0.0, 1.0, 0.0)), seed=SEED, uid=73)
+    bufs = [torch.full((cap * 16,), float("nan"), dtype=torch.float32, device="cuda") for _ in (0, 1)]
+    before = [pair.gpu.update_path(t)[1] for t in (0, 1)]
+    pair_path0 = pair.gpu.update_path(0)[0]
+
+    def check(what):
+        pair.check(exact_all=True, what=what)
+        for t in (0, 1):
+            assert_particles_match(pair.gpu.destroyed(t), pair.cpu.destroyed(t), True, f"{what}: destroyed records, type {t}")
+        any_, mn, mx = pair.gpu.aabb()
+        parts = [p for p in (pair.cpu.particles(t) for t in (0, 1)) if len(p)]
+        lo = np.min([(p["position"] - p["scale"][:, None]).min(axis=0) for p in parts], axis=0)
+        hi = np.max([(p["position"] + p["scale"][:, None]).max(axis=0) for p in parts], axis=0)
+        assert any_ and np.array_equal(mn, lo) and np.array_equal(mx, hi), what
+
+    for fr in range(130):
+        if fr == 40:
+            for t in (0, 1):
+                pair.gpu.attach_instances(bufs[t].data_ptr(), cap, particle_type=t)
+            attached = [pair.gpu.update_path(t) for t in (0, 1)]
+            # 4 B of scale + 16 B per non-constant gradient no longer stored (the path of type 1 may have changed: a range ring
+            # continues on the compacting path once records are wanted)
+            # (a range ring continues on the compacting path once records are wanted: 4 B more for the lifetime plane it rewrites)
+            assert attached[0][1] == before[0] - 36 + (4 if attached[0][0] != pair_path0 else 0), (before, attached)
+        if fr == 100:
+            for t in (0, 1):
+                pair.gpu.attach_instances(0, 0, particle_type=t)
+            assert pair.gpu.update_path(0)[1] == attached[0][1] + 36
+            check("right after detaching")
+        dt = np.float32(0.55 if fr == 70 else DT)  # frame 70: longer than type 0 lives -- born and destroyed in one frame
+        system.update(dt)
+        pair.step_cpu(dt)
+        if fr % 10 == 9 or fr in (40, 41, 70, 71, 100, 101):
+            check(f"frame {fr}")
+            if 40 <= fr < 100:
+                for t in (0, 1):
+                    n = pair.gpu.count(t)
+                    got = bufs[t][: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
+                    assert np.array_equal(got, pair.gpu.instances(t).view(np.uint32).reshape(n, 16)), f"frame {fr} type {t}"
+                    rec = bufs[t][: n * 16].cpu().numpy().view(S.INSTANCE_DTYPE).reshape(n)
+                    for k in ("scale", "base_color", "emissive_color"):
+                        assert np.array_equal(rec[k], pair.cpu.particles(t)[k]), (fr, t, k)
+    assert all(n > 15000 for n in pair.gpu.counts())
+
+
 def test_attached_instances_of_a_nested_child_type(system):
     """frames with Nested entries spawn the children before the update of the same frame (plugin.rs:46-60), so the
     records the update writes for the child type cover the new children too; sparks -> smoke, both types attached"""

@@ -204,3 +204,32 @@ def test_steady_state_at_a_million(system):
         if fr in (40, 100, 149):
             pair.check(exact_all=True, what=f"frame {fr}")
     assert pair.gpu.count(0) > 1_000_000
+
+
+def test_product_defaults_put_each_type_on_its_path(monkeypatch):
+    """no knob set at all (what a product process sees): a large one-lifetime type is a FIFO ring, a large lifetime-range type
+    a range ring, small types and the types of a spawner with Nested entries that do not qualify stay on the compacting
+    path -- all in one context, three launches per frame, against the oracle"""
+    from bevy_firework_amd.system import ParticleSystem
+
+    for k in ("FW_ENABLE_KNOBS", "FW_FIFO", "FW_FIFO_MIN", "FW_RANGE", "FW_RANGE_MIN", "FW_NOSPIN"):
+        monkeypatch.delenv(k, raising=False)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        big_const = S.ParticleSpawner([_settings(lifetime=S.RandF32.constant(0.6))], [_emission(90000.0)])
+        big_range = S.ParticleSpawner([_settings(lifetime=S.RandF32(0.4, 0.9))], [_emission(40000.0, emission_shape=S.EmissionShape.Sphere(0.5))])
+        small = S.ParticleSpawner([_settings(lifetime=S.RandF32(0.2, 0.5))], [_emission(2000.0)])
+        sparks, tf = workloads.nested(spark_rate=3000.0, smoke_per_spark=8.0)
+        pairs = [Pair(system, sp, S.Transform((float(i), 0.5, 0.0)), seed=SEED, uid=500 + i) for i, sp in enumerate((big_const, big_range, small))]
+        pairs.append(Pair(system, sparks, tf, seed=SEED, uid=510))
+        assert [p.gpu.update_path(0)[0] for p in pairs[:3]] == ["fifo", "range", "general"]
+        rng = np.random.default_rng(12)
+        for fr in range(150):
+            dt = np.float32(DT if fr < 80 else rng.uniform(0.005, 0.025))
+            system.update(dt)
+            for p in pairs:
+                p.step_cpu(dt)
+            if fr % 15 == 14:
+                for k, p in enumerate(pairs):
+                    p.check(what=f"frame {fr} spawner {k}")
+        assert [p.gpu.update_path(0)[0] for p in pairs[:3]] == ["fifo", "range", "general"]
+        assert pairs[0].gpu.count(0) > 40000 and pairs[1].gpu.count(0) > 20000
