@@ -175,7 +175,7 @@ struct alignas(16) FwRangeRec {  // per segment, per frame: pinned host memory, 
 struct alignas(16) FwRangeDesc {  // per workgroup (device table, re-sent only when a bound leaves its band)
     uint32_t seg;
     uint32_t role_k;     // role << 30 | index of the workgroup within its role and segment
-    uint32_t old_first;  // global index of the segment's first OLD workgroup (look-back window)
+    uint32_t old_first;  // index of the segment's first look-back word in FwRangeArgs::status (its OLD workgroup k uses word old_first + k)
     uint32_t type_idx;   // | FW_TYPE_IDX_NOSPIN
     uint32_t keys_off, keys_len;
     uint32_t n_old;      // OLD workgroups the table provides for the segment (the kernel checks the old part against it)
@@ -185,7 +185,7 @@ struct FwRangeArgs {
     const FwRangeDesc *desc;
     const FwRangeRec *recs;         // [max_seg] indexed by segment (pinned host)
     const FwOp *ops;                // this frame's spawn ops of range segments (pinned host)
-    unsigned long long *status;     // look-back words of the OLD workgroups, by global workgroup index
+    unsigned long long *status;     // look-back words of the OLD workgroups (FwRangeDesc::old_first + k)
     uint32_t total_tiles, parity, epoch, spin_limit, dbg;
     float dt;
     uint32_t fold_new;              // 1: at most one round of new particles is spawned by the YOUNG workgroups owning their slots

@@ -2034,7 +2034,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     for (int r = 0; r < R; r++)
 #pragma unroll
         for (int w = 0; w < NW; w++) tile_surv += s_cnt[r][w];
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = D.old_first + k;  // the segment's look-back words: [old_first, old_first + its OLD workgroups)
     uint32_t excl = 0;
     if (k != 0u) {
         if (tid == 0) __hip_atomic_store(&a.status[tile], fw_pack_status(a.epoch, FW_ST_AGG, tile_surv), RLX, AGENT);

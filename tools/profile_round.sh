@@ -5,7 +5,7 @@ TAG=${1:-r02}
 R=$PWD; OUT=gpurun_out/profile_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 # 1. the bench line itself (default flags)
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-FW_FIFO=0 timeout 900 python bench.py --no-cpu > $OUT/bench_general_path.json 2>> $OUT/bench.err   # the same line with every type on the compacting path
+FW_FIFO=0 FW_RANGE=0 timeout 900 python bench.py --no-cpu > $OUT/bench_general_path.json 2>> $OUT/bench.err   # the same line with every type on the compacting path
 # 2. rocprofv3 kernel trace + stats of the same command (without the CPU baseline and the extra workloads: the
 #    kernel of the headline configuration only)
 cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT -o ${TAG}_stats --output-format csv -- python $R/bench.py --no-cpu --no-extras > $R/$OUT/stats_bench.json 2>/dev/null; cd $R
@@ -13,7 +13,7 @@ python profiles/analyze_trace.py $OUT/${TAG}_stats_kernel_trace.csv 600 > $OUT/t
 # 3. PMC passes (own runs, kernel-trace only)
 ./tools/pmc.sh $OUT/pmc > /dev/null 2>&1
 python profiles/analyze_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
-./tools/pmc_configs.sh $OUT/pmc_cfg "c3 c4" > $OUT/pmc_configs.txt 2>&1; rm -rf $OUT/pmc_cfg   # traffic of configs[2] / configs[3]'s update kernels
+./tools/pmc_configs.sh $OUT/pmc_cfg "c3 c4 c5" > $OUT/pmc_configs.txt 2>&1; rm -rf $OUT/pmc_cfg   # traffic of the update kernels of configs[2] / [3] / [4]'s share
 # 4. memory microbenchmarks (measured roofline of the kernel's load/store shape; copy sweep at 1 GiB)
 ./tools/membw 64 > $OUT/membw.txt 2>&1
 ./tools/membw 1024 copy > $OUT/copy_sweep.txt 2>&1
@@ -22,7 +22,6 @@ python profiles/analyze_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
 FW_FIFO=0 timeout 200 python tools/launch_gaps.py > $OUT/launch_gaps.txt 2>&1   # (in-kernel timestamps exist in the general path's kernels)
 FW_FIFO=0 timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline.txt 2>&1   # (instrumentation of the general path's kernels)
 FW_FIFO=0 FW_TL_JITTER=1 timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline_variable_dt.txt 2>&1
-timeout 300 python tools/bench_next_rows.py > $OUT/next_rows.txt 2>&1
 timeout 300 python tools/fused_sizes.py > $OUT/fused_sizes.txt 2>&1
 FW_FIFO=0 timeout 300 python tools/fused_sizes.py > $OUT/fused_sizes_general_path.txt 2>&1
 timeout 300 python tools/dbg_modes.py > $OUT/dbg_modes.txt 2>&1
@@ -32,6 +31,12 @@ FW_FIFO=0 timeout 300 python tools/var_dt.py 400 > $OUT/var_dt_general_path.txt 
 timeout 600 python tools/bench_configs.py > $OUT/configs.txt 2>&1
 timeout 300 python tools/small_emitters_gpu.py > $OUT/small_emitters.txt 2>&1
 FW_HOST_PROF=1 timeout 300 python tools/small_emitters.py >> $OUT/small_emitters.txt 2>&1
+# 6b. range rings (round 3): same-box A/B against the compacting path and the two knobs that lost, the size sweep, and
+#     rocprofv3 kernel-trace summaries of configs[2] / configs[4]'s share / configs[3] (tools/prof_configs.sh)
+timeout 900 tools/range_ab.sh "" "FW_RANGE=0" "FW_RANGE_DEVREC=1" "FW_RANGE_FOLD=1" > $OUT/range_ab.txt 2>&1
+(timeout 600 python tools/range_sweep.py; echo "FW_RANGE=0:"; FW_RANGE=0 timeout 600 python tools/range_sweep.py) > $OUT/range_sweep.txt 2>&1
+timeout 1200 tools/prof_configs.sh $TAG > /dev/null 2>&1; cp gpurun_out/prof_configs_$TAG/*_kernel_stats.csv gpurun_out/prof_configs_$TAG/*_trace_summary.txt gpurun_out/prof_configs_$TAG/*_bench.json $OUT/ 2>/dev/null
+(timeout 300 python tools/bench_next_rows.py; echo "FW_DERIVED=0 (scale / colour planes kept next to the records):"; FW_DERIVED=0 timeout 300 python tools/bench_next_rows.py) > $OUT/next_rows.txt 2>&1
 # 7. configs[3] (Nested): rocprofv3 kernel stats of the steady state
 cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/nested -o nested --output-format csv -- python $R/tools/nested_prof.py > $R/$OUT/nested_step.txt 2>/dev/null; cd $R
 python profiles/analyze_trace.py $OUT/nested/nested_kernel_trace.csv 400 > $OUT/nested_trace_summary.txt 2>&1
