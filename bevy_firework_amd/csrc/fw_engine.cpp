@@ -92,6 +92,8 @@ struct alignas(64) SegHost {
                                 // kernels read them from device memory -- SegHost::bigkeys)
     bool auto_capacity = false; // capacity was derived (fw_particle_settings.capacity == 0): the library may grow it
     bool win_ok = false;
+    bool dead_at_end = false;   // the last step left this type's destroyed records at the END of its buffer (a range ring's
+                                // update fills them from there, the youngest dead first: fw_k_update_range)
     uint32_t capacity = 0;
     uint32_t ub = 0;            // upper bound of the device count (after this frame's spawns)
     uint32_t frame_spawn = 0;   // Global particles appended this frame
@@ -813,9 +815,12 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
     FW_HIP(ctx, cp(FW_OFF_Q6(NC), FW_OFF_Q6(OC), 16));
     FW_HIP(ctx, cp(FW_OFF_S4(NC), FW_OFF_S4(OC), 4));
     for (uint32_t k = 0; k < s.n_lplanes + s.n_xplanes; k++) FW_HIP(ctx, cp(FW_OFF_L(NC, k), FW_OFF_L(OC, k), 4));
-    if (old.destroyed)  // the records of the last update stay readable (fw_spawner_read_destroyed)
-        FW_HIP(ctx, hipMemcpy(s.destroyed, old.destroyed, (size_t)std::min(old.capacity, ncap) * sizeof(fw_particle),
+    if (old.destroyed) {  // the records of the last update stay readable (fw_spawner_read_destroyed)
+        const size_t m = std::min(old.capacity, ncap);  // (from the start of the buffer, or -- a range ring's -- up to its end)
+        const size_t so = old.dead_at_end ? (size_t)old.capacity - m : 0, dof = old.dead_at_end ? (size_t)ncap - m : 0;
+        FW_HIP(ctx, hipMemcpy(s.destroyed + dof * sizeof(fw_particle), old.destroyed + so * sizeof(fw_particle), m * sizeof(fw_particle),
                               hipMemcpyDeviceToDevice));
+    }
     FW_HIP(ctx, hipFree(old.buf[0]));
     if (old.destroyed) FW_HIP(ctx, hipFree(old.destroyed));
     if (old.fifo && !s.fifo) {
@@ -1926,6 +1931,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         }
         S.frame_spawn = 0;
         if (!S.in_use) continue;
+        S.dead_at_end = false;  // (set again below for the segments this frame updates as range rings)
         any_coll |= S.collides;
         any_inst_general |= !S.ring() && S.inst != nullptr;
         if (S.nested_fed && nested_fed_wants_growth(S)) ctx->grow_scratch.push_back((uint32_t)si);
@@ -2549,6 +2555,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             SegHost &S = ctx->segs[si];
             if (!S.in_use || !S.range) continue;
             all_nospin &= S.nospin;
+            S.dead_at_end = true;
             // cohorts that are no longer provably too young to die join the old part: the boundary moves, nothing is copied
             uint32_t grad = 0;
             while (!S.ycoh.empty()) {
@@ -2887,7 +2894,7 @@ fw_status fw_spawner_read_destroyed(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
     if (S.destroyed) FW_HIP(ctx, hipMemcpy(&n, ctx->g.ndestroyed + sp->seg[type], 4, hipMemcpyDeviceToHost));
     if (n_out) *n_out = n;
     // (a range ring fills its records from the END of the buffer, the youngest dead first: the last n are in list order)
-    const char *first = S.destroyed + (S.range && n <= S.capacity ? (size_t)(S.capacity - n) * sizeof(fw_particle) : (size_t)0);
+    const char *first = S.destroyed + (S.dead_at_end && n <= S.capacity ? (size_t)(S.capacity - n) * sizeof(fw_particle) : (size_t)0);
     return read_records(ctx, first, S.capacity, n, 0, true, out, cap);
 }
 

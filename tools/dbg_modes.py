@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SETS = (
     ("FIFO ring path (fw_k_update_fifo; configs[1]'s particle type has one lifetime value)", {},
      ((0, "full kernel"), (2, "no arithmetic (planes streamed through, same loads and stores)"))),
-    ("general path (FW_FIFO=0: fw_k_update_stream, survivor forecast)", {"FW_FIFO": "0"},
+    ("general path (FW_FIFO=0 FW_RANGE=0: fw_k_update_stream, survivor forecast)", {"FW_FIFO": "0", "FW_RANGE": "0"},
      ((0, "full kernel"), (16, "forecast table read TWICE per tile (the difference = what the read costs)"),
       (2, "no arithmetic (planes streamed through)"), (18, "both"))),
 )

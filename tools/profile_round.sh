@@ -19,14 +19,14 @@ python profiles/analyze_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
 ./tools/membw 1024 copy > $OUT/copy_sweep.txt 2>&1
 [ -x tools/inplace ] && ./tools/inplace > $OUT/inplace.txt 2>&1   # what in-place ring updates of various plane sets can reach
 # 5. in-kernel timelines, launch period, the rows ranked next, size sweep, ablations
-FW_FIFO=0 timeout 200 python tools/launch_gaps.py > $OUT/launch_gaps.txt 2>&1   # (in-kernel timestamps exist in the general path's kernels)
-FW_FIFO=0 timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline.txt 2>&1   # (instrumentation of the general path's kernels)
-FW_FIFO=0 FW_TL_JITTER=1 timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline_variable_dt.txt 2>&1
+FW_FIFO=0 FW_RANGE=0 timeout 200 python tools/launch_gaps.py > $OUT/launch_gaps.txt 2>&1   # (in-kernel timestamps exist in the general path's kernels)
+FW_FIFO=0 FW_RANGE=0 timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline.txt 2>&1   # (instrumentation of the general path's kernels)
+FW_FIFO=0 FW_RANGE=0 FW_TL_JITTER=1 timeout 200 python tools/tile_timeline.py > $OUT/tile_timeline_variable_dt.txt 2>&1
 timeout 300 python tools/fused_sizes.py > $OUT/fused_sizes.txt 2>&1
-FW_FIFO=0 timeout 300 python tools/fused_sizes.py > $OUT/fused_sizes_general_path.txt 2>&1
+FW_FIFO=0 FW_RANGE=0 timeout 300 python tools/fused_sizes.py > $OUT/fused_sizes_general_path.txt 2>&1
 timeout 300 python tools/dbg_modes.py > $OUT/dbg_modes.txt 2>&1
 timeout 300 python tools/var_dt.py 400 > $OUT/var_dt.txt 2>&1
-FW_FIFO=0 timeout 300 python tools/var_dt.py 400 > $OUT/var_dt_general_path.txt 2>&1
+FW_FIFO=0 FW_RANGE=0 timeout 300 python tools/var_dt.py 400 > $OUT/var_dt_general_path.txt 2>&1
 # 6. the other BASELINE configs on one GPU, the small-emitter regime and the host half of fw_step
 timeout 600 python tools/bench_configs.py > $OUT/configs.txt 2>&1
 timeout 300 python tools/small_emitters_gpu.py > $OUT/small_emitters.txt 2>&1
