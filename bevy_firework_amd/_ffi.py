@@ -240,6 +240,8 @@ SYMBOLS = [
     ("fw_spawner_pack_instances", C.c_int, [_P, C.c_int32, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("fw_spawner_pack_instances_device", C.c_int, [_P, C.c_int32, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("fw_spawner_attach_instances", C.c_int, [_P, C.c_int32, C.c_uint32, _P, C.c_uint64]),
+    ("fw_spawner_attach_instances_window", C.c_int, [_P, C.c_int32, C.c_uint32, _P, C.c_uint64]),
+    ("fw_spawner_instance_window", C.c_int, [_P, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("fw_spawner_aabb", C.c_int, [_P, C.c_int32, _F3, _F3, C.POINTER(C.c_int32)]),
     ("fw_ctx_track_aabbs", C.c_int, [_P, C.c_int32]),
     ("fw_ctx_live_count", C.c_int, [_P, C.POINTER(C.c_uint64)]),
@@ -276,7 +278,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.fw_abi_version() != 2:
+    if lib.fw_abi_version() != 3:
         raise ImportError("libfirework_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -195,6 +195,10 @@ struct alignas(64) SegHost {
     // FW_TYPE_DERIVED (fw_device.h): an instance buffer is attached -- its records carry scale and colours, the planes S4 / Q5 /
     // Q6 are not stored by the update; every reader evaluates them from age / lifetime / initial_scale
     bool derived = false;
+    // the attached buffer is a WINDOWED one (fw_spawner_attach_instances_window): the caller draws d_out[first, first + count)
+    // and asks for `first` -- which lets a range ring keep its path (its tiles know a record's index counted from the
+    // particles the update destroys, not from 0)
+    bool inst_window = false;
     // where the lifetime of particle i is when the type cannot turn: a plane index (compacting / range segments), or
     // 0xFFFFFFFF = the one value fifo_life (a FIFO ring)
     uint32_t life_plane() const { return (nospin && !fifo) ? n_lplanes : 0xFFFFFFFFu; }
@@ -628,7 +632,8 @@ fw_status ensure_tile_arrays(fw_ctx *ctx) {
 fw_status ensure_range_arrays(fw_ctx *ctx) {
     size_t tiles = 0;
     for (auto &s : ctx->segs)
-        if (s.in_use && s.range) tiles += (size_t)s.capacity / FW_TILE + 4 + (size_t)s.capacity / FW_BLOCK + 2;
+        if (s.in_use && s.range)  // OLD tiles of FW_TILE, YOUNG tiles of the build's size, NEW workgroups of FW_BLOCK
+            tiles += (size_t)s.capacity / FW_TILE + 4 + (size_t)s.capacity / fw_range_young_tile() + 4 + (size_t)s.capacity / FW_BLOCK + 2;
     if (tiles > ctx->rdesc_cap) {
         fw_status st = sync(ctx);
         if (st) return st;
@@ -2549,12 +2554,13 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             const size_t i = (size_t)(f - ctx->birth_age.front().frame);
             return i < ctx->birth_age.size() ? ctx->birth_age[i].age : 0.0f;  // this frame's own cohort: born with age 0
         };
-        bool dirty = ctx->r_force, all_nospin = true;
+        bool dirty = ctx->r_force, all_nospin = true, range_inst = false;
         size_t oi = 0;
         for (uint32_t si = 0; si < n_seg; si++) {
             SegHost &S = ctx->segs[si];
             if (!S.in_use || !S.range) continue;
             all_nospin &= S.nospin;
+            range_inst |= S.inst != nullptr;
             S.dead_at_end = true;
             // cohorts that are no longer provably too young to die join the old part: the boundary moves, nothing is copied
             uint32_t grad = 0;
@@ -2654,6 +2660,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             ra.total_tiles = ctx->r_total, ra.parity = p, ra.epoch = a.epoch, ra.spin_limit = ctx->spin_limit, ra.dbg = ctx->dbg;
             ra.dt = dt;
             ra.fold_new = ctx->range_fold ? 1u : 0u;
+            ra.any_inst = range_inst ? 1u : 0u;
             ra.done_tag = a.done_tag, ra.done_value = a.done_value;
             ra.host_counts = a.host_counts, ra.live_out = a.live_out, ra.live_next = a.live_next;
             hipEvent_t e0, e1;
@@ -2919,7 +2926,7 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
     return FW_OK;
 }
 
-fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap) {
+static fw_status attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap, bool window) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || type >= sp->seg.size() || (d_out && !cap)) return FW_EINVAL;
     hipSetDevice(ctx->device);
@@ -2928,20 +2935,45 @@ fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, 
     // (the context's streams are non-blocking ones: nothing else orders them against, say, a fill on the null stream)
     if (!st && d_out) FW_HIP(ctx, hipDeviceSynchronize());
     if (st) return st;
-    if (d_out && ctx->segs[sp->seg[type]].range) {
-        // the records go to index `list position`, which a tile of a range ring only knows once the whole old part has
-        // been counted: such a type continues on the compacting path
+    if (d_out && !window && ctx->segs[sp->seg[type]].range) {
+        // records at index `list position` counted from 0: a tile of a range ring only knows that once the whole old part
+        // has been counted -- such a type continues on the compacting path (the windowed attach keeps it a ring)
         if ((st = fifo_to_general(ctx, sp->seg[type]))) return st;
     }
     SegHost &S = ctx->segs[sp->seg[type]];
     S.inst = (char *)d_out;
     S.inst_cap = d_out ? (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull) : 0u;
+    S.inst_window = d_out != nullptr && window;
     // the records carry scale and colours from now on: the update stops storing the three planes that would duplicate them
     // (every reader of those planes evaluates them instead, so a buffer smaller than the live count loses nothing either);
     // colliding types stay as they are (the feature path)
     const bool derive = d_out != nullptr && ctx->use_derived && !S.collides;
     if ((st = set_derived(ctx, sp->seg[type], derive))) return st;
     return upload_seg(ctx, sp->seg[type]);
+}
+
+fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap) {
+    return attach_instances(ctx, h, type, d_out, cap, false);
+}
+
+fw_status fw_spawner_attach_instances_window(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap) {
+    return attach_instances(ctx, h, type, d_out, cap, true);
+}
+
+fw_status fw_spawner_instance_window(fw_ctx *ctx, fw_spawner h, uint32_t type, uint64_t *first, uint64_t *count) {
+    SpawnerHost *sp = get_spawner(ctx, h);
+    if (!sp || type >= sp->seg.size() || !first || !count) return FW_EINVAL;
+    hipSetDevice(ctx->device);
+    std::vector<uint32_t> c;
+    fw_status st = read_counts(ctx, c);
+    if (st && st != FW_ECAPACITY) return st;
+    const uint32_t si = sp->seg[type];
+    const SegHost &S = ctx->segs[si];
+    uint32_t dead = 0;
+    // a range ring's update numbers its records from the particles it destroys (fw_k_update_range): they sit behind them
+    if (S.dead_at_end && S.inst_window) FW_HIP(ctx, hipMemcpy(&dead, ctx->g.ndestroyed + si, 4, hipMemcpyDeviceToHost));
+    *first = dead, *count = c[si];
+    return st;
 }
 
 fw_status fw_spawner_pack_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, fw_particle_instance *out, uint64_t cap,

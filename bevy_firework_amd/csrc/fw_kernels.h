@@ -189,6 +189,7 @@ struct FwRangeArgs {
     uint32_t total_tiles, parity, epoch, spin_limit, dbg;
     float dt;
     uint32_t fold_new;              // 1: at most one round of new particles is spawned by the YOUNG workgroups owning their slots
+    uint32_t any_inst;              // some segment has a windowed instance buffer attached: the kernels that also write records
     unsigned long long *done_tag;   // as in FwUpdateArgs
     unsigned long long done_value;
     unsigned long long *host_counts;

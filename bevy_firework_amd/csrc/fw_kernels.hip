@@ -1827,12 +1827,41 @@ __device__ __forceinline__ void fw_store_destroyed_vals(char *dbuf, size_t d, co
     reinterpret_cast<int32_t *>(rec)[25] = T.pbr;
 }
 
+// ParticleInstance records of a wave's particles of one round (range rings, windowed hand-off: fw_kernels.h): the lanes in
+// `m` hold records for consecutive indices -- ascending with the lane, or (OLD tiles: reversed) descending -- staged in the
+// wave's LDS area in ascending index order; a wave whose run is broken (the young part wraps around the whole ring) stores
+// lane by lane.
+__device__ __forceinline__ void fw_range_inst_out(char *inst, uint32_t inst_cap, const float4 *s_inst_wave, const float4 *rec,
+                                                  uint32_t lane, unsigned long long m, uint32_t idx, bool reversed) {
+    if (inst == nullptr || m == 0ull) return;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    const uint32_t i_lo_lane = __builtin_amdgcn_readlane(idx, __ffsll((long long)m) - 1);
+    const uint32_t i_hi_lane = __builtin_amdgcn_readlane(idx, 63 - __clzll((long long)m));
+    const uint32_t lowest = reversed ? i_hi_lane : i_lo_lane, highest = reversed ? i_lo_lane : i_hi_lane;
+    if (highest - lowest + 1u == cnt) {
+        fw_inst_flush(inst, inst_cap, s_inst_wave, lane, m, lowest);
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (((m >> lane) & 1ull) && idx < inst_cap)
+            for (uint32_t k = 0; k < 4; k++) fw_st4(inst + (size_t)idx * 64u, k, rec[k]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 #ifndef FW_RANGE_YR
 #define FW_RANGE_YR 4  // rounds of a YOUNG workgroup: it covers FW_RANGE_YR * 256 ring slots
 #endif
 uint32_t fw_range_young_tile(void) { return FW_RANGE_YR * FW_BLOCK; }
 
-template <bool ALLNOSPIN>
+// INST: some segment of the launch has a WINDOWED instance buffer attached (fw_spawner_attach_instances_window): every
+// survivor's ParticleInstance record goes to index  n_old_in + (its position in the young part)  /  n_old_in - 1 - (its
+// new distance from the young part)  -- both known to a tile without waiting for anybody: the records of the frame are
+// d_out[first, first + count) with first = the particles this update destroyed (n_old_in - n_old_out = ndestroyed), in list
+// order.  (An index counted from 0 would need the old part's survivor total, which only its last tile knows.)
+template <bool ALLNOSPIN, bool INST>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
@@ -1840,6 +1869,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     constexpr int LBW = 4;
     constexpr uint32_t TILE = FW_TILE;
     __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
+    __shared__ __attribute__((aligned(16))) float4 s_inst[INST ? NW * 256 : 1];  // per wave: 64 records of 4 float4
     __shared__ uint32_t s_cnt[R][NW];
     __shared__ uint32_t s_lb[2 * LBW * NW];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1861,6 +1891,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     }
     const char *p0 = buf + FW_OFF_Q0(C), *p1 = buf + FW_OFF_Q1(C), *p2 = buf + FW_OFF_Q2(C), *p3 = buf + FW_OFF_Q3(C);
     const char *pl = buf + FW_OFF_L(C, Sp->n_lplanes);  // lifetimes of a type that cannot turn (FwOutWin::lf)
+    char *inst = INST ? Sp->inst : nullptr;
+    const uint32_t inst_cap = INST ? Sp->inst_cap : 0u;
+    float4 *s_inst_wave = s_inst + (INST ? wave * 256u : 0u);
 
     if (role == FW_RANGE_YOUNG) {
         // ---- in place: a lane owns its slot from load to store
@@ -1872,7 +1905,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         const uint32_t n_fold = (a.fold_new && n_spawn_h <= (uint32_t)BLK) ? n_spawn_h : 0u;
         const uint32_t need = min(ring_tiles, (b % YT + y_exist + n_fold + YT - 1u) / YT);
         if (k >= need) return;
-        const uint32_t cnt_y = n_fold ? g.count[sidx] : 0u;  // (requested now, used after the loop: the capacity clamp)
+        const uint32_t cnt_y = (n_fold || (INST && inst != nullptr)) ? g.count[sidx] : 0u;  // (requested now, used later)
+        const uint32_t rec0 = cnt_y > y_exist ? cnt_y - y_exist : 0u;  // record index of the first young particle (= n_old_in)
         uint32_t pt = b / YT + k;
         if (pt >= ring_tiles) pt -= ring_tiles;
         const uint32_t sbase = pt * YT;
@@ -1903,7 +1937,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             float age_new;
             const bool surv = fw_survives(q0c.w, a.dt, q3c.w, &age_new);
             bad |= mine && !surv;  // the host's cohort ages say nobody young can die
-            if (mine) fw_integrate_store<true, -1>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s);
+            const unsigned long long mi = (INST && inst != nullptr) ? __ballot(mine) : 0ull;
+            float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(mi) * 4u : nullptr;
+            if (mine) fw_integrate_store<true, -1>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec);
+            if (INST) fw_range_inst_out(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n, lfc = lfn;
             q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f, lfn = lff;
         }
@@ -1931,7 +1968,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
                                                        fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
                     float age_new;
                     if (!fw_survives(so.q0.w, a.dt, so.q3.w, &age_new)) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 8u, g.err[6] = seg, g.err[7] = kk;
-                    fw_integrate_store<false, -1>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, Wn, s);
+                    float4 rec4[4];
+                    fw_integrate_store<false, -1>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, Wn, s, (INST && inst != nullptr) ? rec4 : nullptr);
+                    if (INST && inst != nullptr && rec0 + yi < inst_cap)
+                        for (uint32_t x = 0; x < 4; x++) fw_st4(inst + (size_t)(rec0 + yi) * 64u, x, rec4[x]);
                 }
             }
             if (n_sp < n_fold && tid == 0 && k + 1u == need) atomicOr(g.err, FW_ERR_CAPACITY);
@@ -1952,28 +1992,32 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
         __syncthreads();
         const uint32_t kk = k * BLK + tid;
-        if (kk >= n_spawn) {
-            if (kk < n_spawn_h && kk == n_spawn) atomicOr(g.err, FW_ERR_CAPACITY);
-            return;
-        }
+        const bool is_new = kk < n_spawn;
+        if (kk < n_spawn_h && kk == n_spawn) atomicOr(g.err, FW_ERR_CAPACITY);
+        const unsigned long long mi = (INST && inst != nullptr) ? __ballot(is_new) : 0ull;
+        float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(mi) * 4u : nullptr;
+        if (!INST && !is_new) return;
         uint32_t s = b + y_exist;  // < 2 C
         if (s >= C) s -= C;
         s += kk;                   // < 2 C
         if (s >= C) s -= C;
-        uint32_t oi = Rc.op0;
-        for (uint32_t x = Rc.op0; x < Rc.op0 + Rc.op_n; x++)
-            if (kk >= a.ops[x].rel_base && kk - a.ops[x].rel_base < a.ops[x].n) oi = x;
-        const FwOp &op = a.ops[oi];
-        const FwSpawnOut so = fw_spawn_one(g.emits[op.emit], g.seed, op.serial_base + (kk - op.rel_base),
-                                           fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
-                                           fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
-                                           fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
-        float age_new;
-        const bool surv = fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);
-        if (!surv) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 8u, g.err[6] = seg, g.err[7] = kk;
-        // (the colour plane of a constant gradient holds that colour in every slot since the buffer was allocated)
-        const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
-        fw_integrate_store<false, -1>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s);
+        if (is_new) {
+            uint32_t oi = Rc.op0;
+            for (uint32_t x = Rc.op0; x < Rc.op0 + Rc.op_n; x++)
+                if (kk >= a.ops[x].rel_base && kk - a.ops[x].rel_base < a.ops[x].n) oi = x;
+            const FwOp &op = a.ops[oi];
+            const FwSpawnOut so = fw_spawn_one(g.emits[op.emit], g.seed, op.serial_base + (kk - op.rel_base),
+                                               fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
+                                               fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
+                                               fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
+            float age_new;
+            const bool surv = fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);
+            if (!surv) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 8u, g.err[6] = seg, g.err[7] = kk;
+            // (the colour plane of a constant gradient holds that colour in every slot since the buffer was allocated)
+            const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
+            fw_integrate_store<false, -1>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec);
+        }
+        if (INST) fw_range_inst_out(inst, inst_cap, s_inst_wave, rec, lane, mi, n_old_in + y_exist + kk, false);
         return;
     }
 
@@ -2061,11 +2105,15 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         const bool valid = d < lim;
         const bool alive = (m[r] >> lane) & 1ull;
         const uint32_t od = wbase + fw_lane_prefix(m[r]);  // survivors nearer to the young part = the new distance
+        // (records: index n_old_in - 1 - od, descending with the lane -- staged in reverse so that LDS holds them ascending)
+        float4 *rec = (INST && inst != nullptr) ? s_inst_wave + ((uint32_t)__popcll(m[r]) - 1u - fw_lane_prefix(m[r])) * 4u : nullptr;
         if (alive) {
             uint32_t s = bm1 - od;
             if (s >= C) s -= C;
-            fw_integrate_store<false, -1>(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], W, s);
-        } else if (valid && want_destroyed) {
+            fw_integrate_store<false, -1>(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], W, s, rec);
+        }
+        if (INST) fw_range_inst_out(inst, inst_cap, s_inst_wave, rec, lane, m[r], n_old_in - 1u - od, true);
+        if (!alive && valid && want_destroyed) {
             // destroyed record (core.rs:596-599): the clone with the age advanced, pose, colours and scale of the previous
             // frame.  The colour and scale planes of the slot hold what the previous update computed from the age that was
             // just loaded: evaluated again here (same functions, same inputs) instead of being read -- the slot may
@@ -2940,10 +2988,16 @@ hipError_t fw_launch_update_range(hipStream_t s, const FwGlobals &g, const FwRan
                                   hipEvent_t e1) {
     if (!a.total_tiles) return hipErrorInvalidValue;
     const dim3 grid(a.total_tiles), block(FW_BLOCK);
-    if (all_nospin)
-        FW_LAUNCH_T((fw_k_update_range<true>), grid, block, s, e0, e1, g, a);
-    else
-        FW_LAUNCH_T((fw_k_update_range<false>), grid, block, s, e0, e1, g, a);
+    if (a.any_inst) {
+        if (all_nospin)
+            FW_LAUNCH_T((fw_k_update_range<true, true>), grid, block, s, e0, e1, g, a);
+        else
+            FW_LAUNCH_T((fw_k_update_range<false, true>), grid, block, s, e0, e1, g, a);
+    } else if (all_nospin) {
+        FW_LAUNCH_T((fw_k_update_range<true, false>), grid, block, s, e0, e1, g, a);
+    } else {
+        FW_LAUNCH_T((fw_k_update_range<false, false>), grid, block, s, e0, e1, g, a);
+    }
     return hipGetLastError();
 }
 

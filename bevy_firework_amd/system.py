@@ -135,6 +135,18 @@ class SpawnerData:
         self._sys._check(self._sys._lib.fw_spawner_attach_instances(
             self._sys._ctx, self.handle, particle_type, C.c_void_p(device_ptr) if device_ptr else None, int(capacity)))
 
+    def attach_instances_window(self, device_ptr: int, capacity: int, particle_type: int = 0) -> None:
+        """The same for a host that can draw an instance sub-range: the records of a step's survivors are
+        buffer[first : first + count] with (first, count) = ``instance_window()``; lets a lifetime-range type keep its ring."""
+        self._sys._check(self._sys._lib.fw_spawner_attach_instances_window(
+            self._sys._ctx, self.handle, particle_type, C.c_void_p(device_ptr) if device_ptr else None, int(capacity)))
+
+    def instance_window(self, particle_type: int = 0):
+        """(first, count) of the attached windowed buffer's live records after the last step (synchronises)"""
+        first, count = C.c_uint64(), C.c_uint64()
+        self._sys._check(self._sys._lib.fw_spawner_instance_window(self._sys._ctx, self.handle, particle_type, C.byref(first), C.byref(count)))
+        return int(first.value), int(count.value)
+
     def update_path(self, particle_type: int = 0):
         """("fifo" | "range" | "general", bytes one update of a live particle moves, of which algorithmic) -- which kernel family
         updates this type and what it costs per particle (bench.py's roofline accounting)"""

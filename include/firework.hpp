@@ -223,6 +223,16 @@ class ParticleSpawnerData {
     std::vector<fw_particle_instance> instances(uint32_t particle_type);  // render.rs:95-115
     // render hand-off fused into the update (fw_spawner_attach_instances): device buffer of `cap` 64-byte records
     void attach_instances(void *device_buffer, uint64_t cap, uint32_t particle_type = 0);
+    // ... for a renderer that draws an instance sub-range: the live records are buffer[first, first + count) (instance_window);
+    // lets a lifetime-range type keep its in-place ring (fw_spawner_attach_instances_window)
+    void attach_instances_window(void *device_buffer, uint64_t cap, uint32_t particle_type = 0) {
+        check_(fw_spawner_attach_instances_window(raw_(), handle, particle_type, device_buffer, cap));
+    }
+    std::pair<uint64_t, uint64_t> instance_window(uint32_t particle_type = 0) {
+        uint64_t first = 0, count = 0;
+        check_(fw_spawner_instance_window(raw_(), handle, particle_type, &first, &count));
+        return {first, count};
+    }
     bool aabb(Vec3 &mn, Vec3 &mx);                                        // render.rs:677-703
     // which kernel family updates a particle type: true = in-place FIFO ring (types with one lifetime value)
     bool on_fifo_path(uint32_t particle_type = 0) {

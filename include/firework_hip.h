@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 2
+#define FW_ABI_VERSION 3
 /* (no FW_MAX_TYPES / FW_MAX_EMISSIONS / FW_MAX_KEYS / FW_MAX_COLLIDERS: the reference's Vec<ParticleSettings>,
  * Vec<EmissionSettings> (core.rs:178-185), curve sample vectors (curve.rs:40-75) and collider world are unbounded, and so
  * are the descriptors below -- FW_EINVAL is for input the reference itself rejects.  Curves and gradients of up to
@@ -235,6 +235,14 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
  * Synchronises the DEVICE once (the segment record changes; and whatever the caller enqueued on its own streams to
  * initialise the buffer has completed before a frame writes into it -- the same holds for fw_ctx_live_count_ring). */
 fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap);
+/* The same hand-off for a host that can draw an instance SUB-RANGE (every graphics API can: firstInstance): the records of
+ * the particles that survive a step are d_out[first, first + count), particle order, with `first` and `count` reported by
+ * fw_spawner_instance_window after the step (one readback: the count has to be read anyway).  `first` is 0 on most update
+ * paths; a particle type with a lifetime RANGE that the library keeps in a ring numbers its records from the particles the
+ * step destroys (first = their number): with the plain attach above such a type is moved to the compacting path, with this
+ * one it keeps its in-place update.  Records beyond `cap` are dropped; d_out = NULL detaches. */
+fw_status fw_spawner_attach_instances_window(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap);
+fw_status fw_spawner_instance_window(fw_ctx *ctx, fw_spawner h, uint32_t type, uint64_t *first, uint64_t *count);
 /* update_aabbs reduction (render.rs:677-703), world space; *any = 0 when no particles */
 fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out_max[3], int32_t *any);
 /* AABB fused into the update: from the next fw_step on, every tile of the update kernel also leaves the box of

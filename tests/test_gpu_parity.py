@@ -479,6 +479,39 @@ def test_attached_instances_replace_the_scale_and_colour_planes(system):
     assert all(n > 15000 for n in pair.gpu.counts())
 
 
+def test_windowed_attach_is_the_plain_attach_where_the_list_starts_at_record_zero(system):
+    """fw_spawner_attach_instances_window on whatever path a type is on: the live records are buffer[first : first + count];
+    first is 0 except on a range ring, where it is the number of particles the step destroyed"""
+    import torch
+
+    t0 = S.ParticleSettings(lifetime=S.RandF32.constant(0.5), initial_scale=S.RandF32(0.02, 0.08), capacity=32768,
+                            particles_destroyed=lambda dead: None,
+                            base_color=S.FireworkGradient.uneven_samples(workloads.STRESS_GRADIENT))
+    t1 = S.ParticleSettings(lifetime=S.RandF32(0.3, 0.9), initial_scale=S.RandF32(0.02, 0.08), capacity=32768, linear_drag=0.4,
+                            particles_destroyed=lambda dead: None,
+                            scale_curve=S.FireworkCurve.even_samples([1.0, 2.0, 0.5]))
+    es = [S.EmissionSettings(particle_index=t, emission_pacing=S.EmissionPacing.rate(30000.0),
+                             initial_velocity=S.RandVec3(S.RandF32(0.0, 4.0), (0.0, 1.0, 0.0), 0.0)) for t in (0, 1)]
+    pair = Pair(system, S.ParticleSpawner([t0, t1], es), seed=SEED, uid=74)
+    bufs = [torch.full((32768 * 16,), float("nan"), dtype=torch.float32, device="cuda") for _ in (0, 1)]
+    paths = [pair.gpu.update_path(t)[0] for t in (0, 1)]
+    for t in (0, 1):
+        pair.gpu.attach_instances_window(bufs[t].data_ptr(), 32768, particle_type=t)
+    assert [pair.gpu.update_path(t)[0] for t in (0, 1)] == paths  # nobody changes path for a windowed buffer
+    for fr in range(90):
+        system.update(DT)
+        pair.step_cpu(DT)
+        if fr % 10 == 9:
+            pair.check(exact_all=True, what=f"frame {fr}")
+            for t in (0, 1):
+                first, n = pair.gpu.instance_window(t)
+                assert n == pair.cpu.count(t)
+                assert first == (len(pair.cpu.destroyed(t)) if paths[t] == "range" else 0), (fr, t, first, paths)
+                got = bufs[t][first * 16: (first + n) * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
+                assert np.array_equal(got, pair.gpu.instances(t).view(np.uint32).reshape(n, 16)), (fr, t)
+    assert all(c > 10000 for c in pair.gpu.counts())
+
+
 def test_attached_instances_of_a_nested_child_type(system):
     """frames with Nested entries spawn the children before the update of the same frame (plugin.rs:46-60), so the
     records the update writes for the child type cover the new children too; sparks -> smoke, both types attached"""

@@ -233,3 +233,54 @@ def test_product_defaults_put_each_type_on_its_path(monkeypatch):
                     p.check(what=f"frame {fr} spawner {k}")
         assert [p.gpu.update_path(0)[0] for p in pairs[:3]] == ["fifo", "range", "general"]
         assert pairs[0].gpu.count(0) > 40000 and pairs[1].gpu.count(0) > 20000
+
+
+def test_windowed_instance_buffer_keeps_the_ring(system):
+    """fw_spawner_attach_instances_window: the update of a range ring writes the ParticleInstance records itself, at indices
+    counted from the particles the step destroys -- the live records are buffer[first : first + count] -- and the type stays a
+    ring (the plain attach moves it to the compacting path).  Records against the packing pass and against the oracle; the
+    scale / colour planes are not stored meanwhile (FW_TYPE_DERIVED) and come back when the buffer is detached.  A type that
+    cannot turn and one that spins; rings that wrap; a buffer too small for one of them."""
+    import torch
+
+    still = _settings(lifetime=S.RandF32(0.2, 0.6), capacity=8192, particles_destroyed=lambda dead: None,
+                      emissive_color=S.FireworkGradient.even_samples([(4.0, 2.0, 0.0, 1.0), (0.0, 0.0, 0.0, 1.0)]))
+    spin = _settings(lifetime=S.RandF32(0.3, 0.5), capacity=8192, angular_acceleration=(0.1, 0.0, -0.2), angular_drag=0.3)
+    e0 = _emission(12000.0, particle_index=0)
+    e1 = _emission(14000.0, particle_index=1, initial_angular_velocity=S.RandVec3(S.RandF32(1.0, 9.0), (0.0, 0.6, 0.8), 0.0))
+    pair = Pair(system, S.ParticleSpawner([still, spin], [e0, e1]), S.Transform((0.0, 1.0, 0.0)), seed=SEED, uid=61)
+    caps = [8192, 3000]  # (the second buffer is smaller than the type's live count: records beyond it are dropped)
+    guard = 64
+    bufs = [torch.full(((c + guard) * 16,), float("nan"), dtype=torch.float32, device="cuda") for c in caps]
+    rng = np.random.default_rng(9)
+    for fr in range(200):
+        if fr == 30:
+            for t in (0, 1):
+                pair.gpu.attach_instances_window(bufs[t].data_ptr(), caps[t], particle_type=t)
+        if fr == 150:
+            for t in (0, 1):
+                pair.gpu.attach_instances_window(0, 0, particle_type=t)
+            pair.check(what="right after detaching")
+        dt = np.float32(DT if fr < 90 else rng.uniform(0.004, 0.03))
+        system.update(dt)
+        pair.step_cpu(dt)
+        if fr % 6 == 5 or fr in (30, 31, 150, 151):
+            pair.check(what=f"frame {fr}")
+            assert_particles_match(pair.gpu.destroyed(0), pair.cpu.destroyed(0), True, f"destroyed, frame {fr}")
+            assert [pair.gpu.update_path(t)[0] for t in (0, 1)] == ["range", "range"], fr
+            if 30 <= fr < 150:
+                for t in (0, 1):
+                    first, n = pair.gpu.instance_window(t)
+                    assert n == pair.cpu.count(t), (fr, t, first, n)
+                    if t == 0:  # (the type with a particles_destroyed handler: the oracle says how many this step destroyed)
+                        assert first == len(pair.cpu.destroyed(0)), (fr, first, len(pair.cpu.destroyed(0)))
+                    m = min(n, max(0, caps[t] - first))
+                    got = bufs[t][first * 16: (first + m) * 16].cpu().numpy().view(np.uint32).reshape(m, 16)
+                    ref = pair.gpu.instances(t)[:m]
+                    assert np.array_equal(got, ref.view(np.uint32).reshape(m, 16)), f"frame {fr} type {t}: window != packing pass"
+                    rec = got.view(np.float32).view(S.INSTANCE_DTYPE).reshape(m)
+                    cp = pair.cpu.particles(t)[:m]
+                    for k in ("scale", "base_color", "emissive_color"):
+                        assert np.array_equal(rec[k], cp[k]), (fr, t, k)
+                    assert bool(torch.isnan(bufs[t][caps[t] * 16:]).all()), "wrote past the attached buffer"
+    assert pair.gpu.count(0) > 3000 and pair.gpu.count(1) > 4000
