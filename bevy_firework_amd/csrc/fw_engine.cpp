@@ -195,6 +195,9 @@ struct alignas(64) SegHost {
     // FW_TYPE_DERIVED (fw_device.h): an instance buffer is attached -- its records carry scale and colours, the planes S4 / Q5 /
     // Q6 are not stored by the update; every reader evaluates them from age / lifetime / initial_scale
     bool derived = false;
+    // ... but not yet: the caller wrote particles (any scale, any colours), and those that die in the very next step carry
+    // what was written in their destroyed records -- the planes are read for one more frame, then the mode starts
+    bool derive_pending = false;
     // the attached buffer is a WINDOWED one (fw_spawner_attach_instances_window): the caller draws d_out[first, first + count)
     // and asks for `first` -- which lets a range ring keep its path (its tiles know a record's index counted from the
     // particles the update destroys, not from 0)
@@ -2687,6 +2690,16 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             S.colors_dirty = false;
         }
         ctx->colors_dirty = false;
+        // every particle has been through an update since the caller's write: scale and colours are functions of the age
+        // again, a type with an attached instance buffer can stop storing them (FW_TYPE_DERIVED; waits for this frame: rare)
+        for (uint32_t i = 0; i < n_seg; i++)
+            if (ctx->segs[i].in_use && ctx->segs[i].derive_pending) {
+                ctx->segs[i].derive_pending = false;
+                if (ctx->segs[i].inst != nullptr) {
+                    const fw_status dst = set_derived(ctx, i, true);  // (waits for the frame just enqueued, which still stores the planes)
+                    if (dst) return dst;
+                }
+            }
     }
     prof(6);
     if (slot >= 0) {
@@ -2844,7 +2857,10 @@ fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, c
     ctx->fc_ok = false, ctx->boxes_epoch = 0;
     if ((st = fifo_to_general(ctx, si))) return st;  // ages and lifetimes will be whatever the caller writes
     if ((st = leave_nospin(ctx, si))) return st;      // ... and so will rotations and angular velocities
-    if ((st = set_derived(ctx, si, false))) return st;  // ... and scales and colours (an attached buffer keeps receiving records)
+    // ... and scales and colours: the planes are stored and read again until every particle has been through an update
+    // (an attached buffer keeps receiving records; the mode comes back after the next step)
+    if ((st = set_derived(ctx, si, false, false))) return st;
+    ctx->segs[si].derive_pending = ctx->segs[si].inst != nullptr && ctx->use_derived && !ctx->segs[si].collides;
     if (n > ctx->segs[si].capacity) {
         ctx->segs[si].ub = 0;
         const uint32_t zero = 0;
@@ -2948,7 +2964,8 @@ static fw_status attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void
     // (every reader of those planes evaluates them instead, so a buffer smaller than the live count loses nothing either);
     // colliding types stay as they are (the feature path)
     const bool derive = d_out != nullptr && ctx->use_derived && !S.collides;
-    if ((st = set_derived(ctx, sp->seg[type], derive))) return st;
+    S.derive_pending = derive && S.colors_dirty;  // (particles written by the caller, not updated yet: one frame later)
+    if ((st = set_derived(ctx, sp->seg[type], derive && !S.colors_dirty))) return st;
     return upload_seg(ctx, sp->seg[type]);
 }
 

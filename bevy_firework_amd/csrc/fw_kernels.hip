@@ -722,7 +722,10 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     if (use_fc && fc_small) fw_fce_request<BLK>(a.fce_in, first, seg_tiles, fce);
     const uint32_t p = a.parity;
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
-    const uint32_t n_in = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];
+    // particles that existed before this frame; [n_before, n_in) were materialised this frame (fw_k_spawn / fw_k_nest) and have
+    // never been updated: their slots hold the spawn-time scale and colours, whatever FW_TYPE_DERIVED says about the planes
+    const uint32_t n_before = g.count[sidx];
+    const uint32_t n_in = n_before + g.spawned[sidx] + g.appended[sidx];
     uint32_t o0 = 0, o1 = 0, n_spawn = 0;  // this segment's ops (contiguous: ops are sorted by segment)
     if (SPAWN == FW_SPAWN_INLINE) {
         for (uint32_t i = 0; i < a.n_ops; i++) {
@@ -1001,6 +1004,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         const float4 q1n = fw_ld4(ib + FW_OFF_Q1(C), in_);
         const float4 q2n = fw_ld4(ib + FW_OFF_Q2(C), in_ & m2);
         const bool valid = idx < lim, loaded = !has_new;
+        const bool updated_before = loaded && idx < n_before;  // (destroyed records: evaluate / read the planes vs spawn-time values)
         const float4 q0 = s_q0[r * BLK + tid], q3 = s_q3[r * BLK + tid];
         if (SPAWN != FW_SPAWN_NONE && has_new && valid)
             q1c = s_q0[FW_TILE / 2 + r * BLK + tid], q2c = s_q3[FW_TILE / 2 + r * BLK + tid];
@@ -1037,7 +1041,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             for (uint32_t k = 0; k < n_lplanes; k++)  // new particles: vec![f32::MIN; n] (core.rs:467)
                 fw_st1(ob + FW_OFF_L(C, k), o, loaded ? fw_ld1(ib + FW_OFF_L(C, k), idx) : FW_F32_MIN);
         } else if (valid && want_destroyed) {
-            fw_store_destroyed(destroyed, ib, C, idx, loaded, T, s_keys, q0, q1c, q2c, q3, age_new, idx - o);
+            fw_store_destroyed(destroyed, ib, C, idx, updated_before, T, s_keys, q0, q1c, q2c, q3, age_new, idx - o);
         }
         q1c = q1n, q2c = q2n;
     }
@@ -1150,7 +1154,8 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
                                                 float age_new, uint32_t idx, uint32_t o, const char *ib, char *ob,
                                                 const FwOutWin &W, char *destroyed, bool want_destroyed, uint32_t C,
                                                 uint32_t n_lplanes, bool forecast, uint32_t fc_bnd, FwRoundOut &acc,
-                                                float4 *rec = nullptr, float *box = nullptr, bool box_on = false) {
+                                                float4 *rec = nullptr, float *box = nullptr, bool box_on = false,
+                                                bool fresh = false) {  // fresh: materialised this frame, never updated
     if (forecast) {  // will it survive one more step of the same dt?  (same expression as fw_survives)
         float an2;
         const bool nx = alive && fw_survives(age_new, dt, q3.w, &an2);
@@ -1168,7 +1173,8 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
         for (uint32_t k = 0; k < n_lplanes; k++)  // new particles: vec![f32::MIN; n] (core.rs:467)
             fw_st1(ob + FW_OFF_L(C, k), o, loaded ? fw_ld1(ib + FW_OFF_L(C, k), idx) : FW_F32_MIN);
     } else if (valid && want_destroyed) {
-        fw_store_destroyed(destroyed, ib, C, idx, loaded, T, s_keys, q0, q1, q2, q3, age_new, idx - o);
+        // (a never-updated particle carries its spawn-time scale and colours: evaluated, which is also what its slot holds)
+        fw_store_destroyed(destroyed, ib, C, idx, loaded && !fresh, T, s_keys, q0, q1, q2, q3, age_new, idx - o);
     }
 }
 
@@ -1485,7 +1491,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             // the lane's instance record goes to its rank in the wave's LDS area as soon as each part is computed
             float4 *rec = (INST && inst != nullptr) ? s_inst + wave * 256u + (o - wbase) * 4u : nullptr;
             fw_round_finish(T, s_keys, a.dt, a.dbg, q0c, q1c, q2c, q3c, valid, alive, true, age_new, idx, o, ib, ob, W,
-                            destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec, box, box_on);
+                            destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec, box, box_on, idx >= n_in);
             if (INST && inst != nullptr && !(a.dbg & 2u)) fw_inst_flush(inst, inst_cap, s_inst + wave * 256u, lane, m, wbase);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n, lfc = lfn;
             if ((a.dbg & 8u) && r == 0) tsR1 = __builtin_amdgcn_s_memrealtime() + (o & 0u);

@@ -10,10 +10,23 @@ from bevy_firework_amd.system import ParticleSystem
 dt = np.float32(1 / 60)
 
 
-def run(name, spawners, fill, steps, uids=None):
+ATTACH = os.environ.get("FW_BENCH_ATTACH", "")  # "window" / "plain": every type gets a device buffer for its ParticleInstance records
+
+
+def run(name, spawners, fill, steps, uids=None, inst_cap=None):
     ps = ParticleSystem(seed=workloads.SEED)
+    keep = []
     for i, (sp, tf) in enumerate(spawners):
-        ps.spawn(sp, tf, uid=(uids[i] if uids else i))
+        h = ps.spawn(sp, tf, uid=(uids[i] if uids else i))
+        if ATTACH and inst_cap:
+            import torch
+
+            for t, cap in enumerate(inst_cap):
+                buf = torch.empty(cap * 64, dtype=torch.uint8, device="cuda")
+                keep.append(buf)
+                (h.attach_instances_window if ATTACH == "window" else h.attach_instances)(buf.data_ptr(), cap, particle_type=t)
+    if ATTACH and inst_cap:
+        name += f" + {ATTACH} instance buffers"
     ps.update(dt)
     for _ in range(fill):
         ps.step(dt)
@@ -61,10 +74,10 @@ which = sys.argv[1:] or ["c3", "c4", "c5", "c1"]
 if "c1" in which:
     run("configs[0] stress_test rate 160000", [workloads.stress_test(160000.0)], 70, 600)
 if "c3" in which:
-    run("configs[2] 256 emitters x 64Ki", workloads.many_emitters(256, 65536), 80, 100)
+    run("configs[2] 256 emitters x 64Ki", workloads.many_emitters(256, 65536), 80, 100, inst_cap=[110000])
 if "c5" in which:
     ems = workloads.many_emitters(4096, 8192)
     mine = sharding.local_indices(4096, 0, 8)
-    run("configs[4] one GPU's share: 512 of 4096 emitters x 8192", [ems[e] for e in mine], 80, 200, uids=mine)
+    run("configs[4] one GPU's share: 512 of 4096 emitters x 8192", [ems[e] for e in mine], 80, 200, uids=mine, inst_cap=[20000])
 if "c4" in which:
     run("configs[3] nested sparks->smoke ~4M", [workloads.nested(100000.0, 20.0)], 250, 100)
