@@ -221,6 +221,8 @@ def _api_scenario(case, seed_base, const_p):
     with ParticleSystem(device=0, seed=SEED) as system:
         pair = Pair(system, spawner, S.Transform(), seed=SEED, uid=(seed_base // 30) + case)
         buf = None
+        # every other case attaches the WINDOWED buffer (records at [first, first + count): a range ring keeps its path)
+        attach = pair.gpu.attach_instances_window if case % 2 else pair.gpu.attach_instances
         for i, dt in enumerate(_steps(rng, 30)):
             dt = np.float32(dt)
             a = int(rng.integers(0, 8))
@@ -246,12 +248,12 @@ def _api_scenario(case, seed_base, const_p):
                 pair.cpu.write_particles(t, parts)
             elif a == 5 and buf is None:
                 buf = torch.full((60000 * 16,), float("nan"), dtype=torch.float32, device="cuda")
-                pair.gpu.attach_instances(buf.data_ptr(), 60000, particle_type=0)
+                attach(buf.data_ptr(), 60000, particle_type=0)
             elif a == 6 and i > 8 and rng.random() < 0.4:  # Changed<ParticleSpawner>: state reset (core.rs:343-365)
                 pair.gpu.update_settings(spawner)
                 pair.cpu.reset()
                 if buf is not None:  # the rebuilt types start detached
-                    pair.gpu.attach_instances(buf.data_ptr(), 60000, particle_type=0)
+                    attach(buf.data_ptr(), 60000, particle_type=0)
             system.update(dt)
             pair.step_cpu(dt)
             if i % 3 == 2:
@@ -266,9 +268,10 @@ def _api_scenario(case, seed_base, const_p):
                 if any_g:
                     assert np.allclose(mn_g, mn_c, rtol=1e-5, atol=1e-4) and np.allclose(mx_g, mx_c, rtol=1e-5, atol=1e-4)
                 if buf is not None:
-                    n = min(pair.gpu.count(0), 60000)
+                    first = pair.gpu.instance_window(0)[0] if case % 2 else 0
+                    n = max(0, min(pair.gpu.count(0), 60000 - first))
                     ref = pair.gpu.instances(0)[:n]
-                    got = buf[: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
+                    got = buf[first * 16: (first + n) * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
                     want = ref.view(np.uint32).reshape(n, 16)
                     if not np.array_equal(got, want):
                         rows = np.flatnonzero((got != want).any(axis=1))

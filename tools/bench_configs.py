@@ -3,6 +3,7 @@
 import os as _os; _os.environ.setdefault("FW_ENABLE_KNOBS", "1")  # the A/B switches are honoured only with this set
 import json, os, sys, time
 import numpy as np
+import torch  # (before the library: two HIP runtimes in one process must be loaded in this order)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bevy_firework_amd import workloads, sharding
 from bevy_firework_amd.system import ParticleSystem
@@ -19,8 +20,6 @@ def run(name, spawners, fill, steps, uids=None, inst_cap=None):
     for i, (sp, tf) in enumerate(spawners):
         h = ps.spawn(sp, tf, uid=(uids[i] if uids else i))
         if ATTACH and inst_cap:
-            import torch
-
             for t, cap in enumerate(inst_cap):
                 buf = torch.empty(cap * 64, dtype=torch.uint8, device="cuda")
                 keep.append(buf)
