@@ -424,8 +424,8 @@ def main():
             scaling, em_total = "weak", world
         else:
             wl = (f"configs[4]: {args.emitters} Sphere emitters x {args.live_per_emitter} live (radial velocity, lifetimes "
-                  "0.8-1.2 s, per-emitter constants), emitter e on rank e mod N, dt=1/60, spawn+update+stable compaction "
-                  "every step, RCCL all-reduce of per-frame live counts")
+                  "0.8-1.2 s, per-emitter constants), emitter e on rank e mod N, dt=1/60, spawn + update + order-preserving "
+                  "removal of the dead every step, RCCL all-reduce of per-frame live counts")
             scaling, em_total = "strong", args.emitters
         out = {
             "metric": "particles updated/sec (stress_test, 1M live)" if workload == "configs1" else

@@ -398,6 +398,7 @@ struct fw_ctx {
     char *d_rparam[kParamRing] = {};          // FW_RANGE_DEVREC=1: device copies of them (one H2D copy per frame in the stream)
     bool range_devrec = false;
     bool range_fold = false;   // FW_RANGE_FOLD: a handful of new particles ride in the YOUNG workgroups (A/B)
+    uint32_t range_old_extra = 0;  // FW_RANGE_OLD_EXTRA=n: n more (idle) OLD workgroups per segment -- what an idle one costs
     size_t rparam_bytes = 0;
     uint64_t rslot_frame[kParamRing] = {};    // frame that last used the slot (+1; 0 = free)
     uint64_t rring_seq = 0;
@@ -1220,7 +1221,10 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             // Range ring (SegHost::range): any finite lifetime range -- a single value included, for the types the eight
             // FIFO records of a launch have no room for -- in a spawner without Nested entries; the young part of the
             // list is updated in place, only the part that can lose particles this frame is compacted
-            S.range = ctx->use_range && !S.fifo && !any_nested && !S.collides && std::isfinite(p.lifetime.min) &&
+            // (in a spawner WITH Nested entries: only the types no entry emits from or onto -- their Global particles need
+            // no place in the frame's emission order; parents are addressed by index through a head only the device knows)
+            const bool in_nested_pass = S.n_lplanes != 0 || S.nested_fed;
+            S.range = ctx->use_range && !S.fifo && !in_nested_pass && !S.collides && std::isfinite(p.lifetime.min) &&
                       std::isfinite(p.lifetime.max) && T.life_lo_safe > 0.0f && caps[t] >= ctx->range_min &&
                       caps[t] <= FW_RANGE_MAX_CAPACITY;
             if (S.range) {
@@ -1609,6 +1613,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_RANGE_MIN")) ctx->range_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_RANGE_DEVREC")) ctx->range_devrec = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_FOLD")) ctx->range_fold = atoi(m) != 0;
+    if (const char *m = getenv("FW_RANGE_OLD_EXTRA")) ctx->range_old_extra = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
     if (const char *m = getenv("FW_OPS_ZEROCOPY")) ctx->ops_zerocopy = atoi(m) != 0;
@@ -2585,7 +2590,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             // workgroups of each role (bands: the table is re-sent only when a need leaves its band)
             const uint32_t live_before_ub = std::min(S.ub - std::min(S.ub, S.frame_spawn), S.capacity);
             const uint32_t old_ub = live_before_ub - std::min(live_before_ub, y_exist);
-            const uint32_t need_old = std::max(1u, (old_ub + FW_TILE - 1) / FW_TILE);
+            const uint32_t need_old = std::max(1u, (old_ub + FW_TILE - 1) / FW_TILE) + ctx->range_old_extra;
             // (at most one round of new particles is spawned by the YOUNG workgroups that own their slots: fw_k_update_range)
             const bool fold = ctx->range_fold && S.frame_spawn <= FW_BLOCK;
             const uint32_t need_new = fold ? 0u : (S.frame_spawn + FW_BLOCK - 1) / FW_BLOCK;
