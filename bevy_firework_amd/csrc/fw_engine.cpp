@@ -398,6 +398,7 @@ struct fw_ctx {
     char *d_rparam[kParamRing] = {};          // FW_RANGE_DEVREC=1: device copies of them (one H2D copy per frame in the stream)
     bool range_devrec = false;
     bool range_fold = false;   // FW_RANGE_FOLD: a handful of new particles ride in the YOUNG workgroups (A/B)
+    bool range_spread_new = true;   // FW_RANGE_SPREAD_NEW=0: a segment's NEW workgroups all in front of its YOUNG ones (A/B)
     uint32_t range_old_extra = 0;  // FW_RANGE_OLD_EXTRA=n: n more (idle) OLD workgroups per segment -- what an idle one costs
     size_t rparam_bytes = 0;
     uint64_t rslot_frame[kParamRing] = {};    // frame that last used the slot (+1; 0 = free)
@@ -1614,6 +1615,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_RANGE_DEVREC")) ctx->range_devrec = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_FOLD")) ctx->range_fold = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_OLD_EXTRA")) ctx->range_old_extra = (uint32_t)atoi(m);
+    if (const char *m = getenv("FW_RANGE_SPREAD_NEW")) ctx->range_spread_new = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
     if (const char *m = getenv("FW_OPS_ZEROCOPY")) ctx->ops_zerocopy = atoi(m) != 0;
@@ -2622,7 +2624,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             }
             // Workgroup order of a segment: its OLD workgroups (k ascending: whoever an old tile waits for has a lower workgroup
             // index), then its NEW ones, then the YOUNG ones; segment after segment, so the latency-bound old tiles of one
-            // segment overlap the streaming of its neighbours.  (Old and young workgroups interleaved within a segment --
+            // segment overlap the streaming of its neighbours.  A segment with many NEW workgroups (one large emitter: a
+            // thousand of them, each ~5x the arithmetic of a YOUNG one and no memory traffic to speak of) gets them spread
+            // over the first three quarters of its YOUNG ones instead of as a block: 374-384 -> 364-375 us at 1 x 16M,
+            // nothing elsewhere (profiles/r03/range_spread_new.txt).  (Old and young workgroups interleaved within a segment --
             // so that a context with ONE large segment would not start with a front of old tiles -- was measured: 381 -> 384 us
             // at 1 x 16M, 96 -> 100 us at 512 x 8192: no.)  Look-back words are indexed per segment (old_first + k).
             size_t t = 0;
@@ -2640,8 +2645,19 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 };
                 bool ok = true;
                 for (uint32_t k = 0; k < S.r_old && ok; k++) ok = put(FW_RANGE_OLD, k);
-                for (uint32_t k = 0; k < S.r_new && ok; k++) ok = put(FW_RANGE_NEW, k);
-                for (uint32_t k = 0; k < S.r_young && ok; k++) ok = put(FW_RANGE_YOUNG, k);
+                if (!ctx->range_spread_new || S.r_new <= 8) {
+                    for (uint32_t k = 0; k < S.r_new && ok; k++) ok = put(FW_RANGE_NEW, k);
+                    for (uint32_t k = 0; k < S.r_young && ok; k++) ok = put(FW_RANGE_YOUNG, k);
+                } else {  // many NEW workgroups (one large segment): spread over the first three quarters of the YOUNG ones
+                    const uint64_t span = (uint64_t)S.r_new + (uint64_t)S.r_young * 3 / 4;
+                    uint32_t kn = 0, ky = 0;
+                    for (uint64_t i = 0; i < span && ok; i++) {
+                        if (kn < S.r_new && (uint64_t)kn * span / S.r_new <= i) ok = put(FW_RANGE_NEW, kn++);
+                        else if (ky < S.r_young) ok = put(FW_RANGE_YOUNG, ky++);
+                    }
+                    while (kn < S.r_new && ok) ok = put(FW_RANGE_NEW, kn++);
+                    while (ky < S.r_young && ok) ok = put(FW_RANGE_YOUNG, ky++);
+                }
                 if (!ok) return fail(ctx, FW_EHIP, "internal error: range table overflow");
                 status_base += S.r_old;
             }

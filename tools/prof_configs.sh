@@ -6,8 +6,10 @@ export FW_ENABLE_KNOBS=1   # the library honours its A/B switches only with this
 TAG=${1:-r03}
 R=$PWD; OUT=$R/gpurun_out/prof_configs_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 cd /tmp
-for cfg in "c3 configs2" "c5 configs4_share" "c4 configs3_nested"; do
+export FW_ENABLE_KNOBS=1
+for cfg in "c3 configs2" "c5 configs4_share" "c4 configs3_nested" "c3 configs2_compacting FW_RANGE=0" "c5 configs4_share_compacting FW_RANGE=0"; do
   set -- $cfg
+  [ -n "$3" ] && export $3 || unset FW_RANGE
   rm -rf $OUT/tmp_$2
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/tmp_$2 -o $2 --output-format csv -- python $R/tools/bench_configs.py $1 > $OUT/$2_bench.json 2> $OUT/$2.err
   f=$(find $OUT/tmp_$2 -name "$2_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/$2_kernel_stats.csv
