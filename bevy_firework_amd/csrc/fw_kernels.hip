@@ -1974,8 +1974,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
                                                        fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
                     float age_new;
                     if (!fw_survives(so.q0.w, a.dt, so.q3.w, &age_new)) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 8u, g.err[6] = seg, g.err[7] = kk;
-                    float4 rec4[4];
-                    fw_integrate_store<false, -1>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, Wn, s, (INST && inst != nullptr) ? rec4 : nullptr);
+                    // (the record goes through the lane's own slot of the wave's LDS area: no private array, no scratch)
+                    float4 *rec4 = (INST && inst != nullptr) ? s_inst_wave + lane * 4u : nullptr;
+                    fw_integrate_store<false, -1>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, Wn, s, rec4);
                     if (INST && inst != nullptr && rec0 + yi < inst_cap)
                         for (uint32_t x = 0; x < 4; x++) fw_st4(inst + (size_t)(rec0 + yi) * 64u, x, rec4[x]);
                 }
