@@ -399,6 +399,10 @@ struct fw_ctx {
     bool range_devrec = false;
     bool range_fold = false;   // FW_RANGE_FOLD: a handful of new particles ride in the YOUNG workgroups (A/B)
     bool range_spread_new = true;   // FW_RANGE_SPREAD_NEW=0: a segment's NEW workgroups all in front of its YOUNG ones (A/B)
+    // An in-place ring launch (FIFO / range) that streams more than this uses the non-temporal form of its kernel: several
+    // times the 256 MiB Infinity Cache, where allocating lines that cannot survive until the next frame only costs
+    // (fw_kernels.hip: fw_ld4w; FW_NT_MB=n knob, 0 = always)
+    uint64_t nt_bytes = 768ull << 20;  // (crossover measured at 0.65-0.85 GB for both kernels: profiles/r03/nt_sweep.txt)
     uint32_t range_old_extra = 0;  // FW_RANGE_OLD_EXTRA=n: n more (idle) OLD workgroups per segment -- what an idle one costs
     size_t rparam_bytes = 0;
     uint64_t rslot_frame[kParamRing] = {};    // frame that last used the slot (+1; 0 = free)
@@ -1615,6 +1619,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_RANGE_DEVREC")) ctx->range_devrec = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_FOLD")) ctx->range_fold = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_OLD_EXTRA")) ctx->range_old_extra = (uint32_t)atoi(m);
+    if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_RANGE_SPREAD_NEW")) ctx->range_spread_new = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
@@ -2450,6 +2455,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         FwFifoArgs fa{};
         FwInlineOps fio;
         uint32_t f_ops = 0, f_tiles = 0;
+        uint64_t f_bytes = 0;  // what the launch streams, roughly: its tiles x the bytes a particle of the type moves
         auto flush = [&]() -> hipError_t {
             if (!fa.n_segs) return hipSuccess;
             fa.parity = p, fa.epoch = a.epoch, fa.dbg = ctx->dbg, fa.dt = dt;
@@ -2460,10 +2466,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             fa.live_out = a.live_out, fa.live_next = a.live_next;
             hipEvent_t e0, e1;
             next_timing_pair(&e0, &e1);
-            const hipError_t e = fw_launch_update_fifo(fstream, ctx->g, fa, fio, f_tiles, e0, e1);
+            const hipError_t e = fw_launch_update_fifo(fstream, ctx->g, fa, fio, f_tiles, f_bytes > ctx->nt_bytes, e0, e1);
             if (side) ctx->side_dirty = true;
             fa = FwFifoArgs{};
-            f_ops = f_tiles = 0;
+            f_ops = f_tiles = 0, f_bytes = 0;
             fifo_launched = true;
             return e;
         };
@@ -2536,6 +2542,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             F.n_tiles = std::max(1u, F.n_vt_a + F.n_vt_b + live_tiles);
             F.tile_first = f_tiles;
             f_tiles += F.n_tiles;
+            f_bytes += (uint64_t)live_tiles * ftile * (S.nospin ? 104u : 164u);
             fa.any_inst |= S.inst != nullptr ? 1u : 0u;
             S.head = (uint32_t)(((uint64_t)S.head + dead) % S.capacity);
             if (!S.fifo_dev) S.ub = n_in + n_spawn - std::min(dead, n_in + n_spawn);  // exact
@@ -2565,12 +2572,14 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             return i < ctx->birth_age.size() ? ctx->birth_age[i].age : 0.0f;  // this frame's own cohort: born with age 0
         };
         bool dirty = ctx->r_force, all_nospin = true, range_inst = false;
+        uint64_t r_bytes = 0;  // what the launch streams, roughly (the non-temporal form of the kernel: fw_ctx::nt_bytes)
         size_t oi = 0;
         for (uint32_t si = 0; si < n_seg; si++) {
             SegHost &S = ctx->segs[si];
             if (!S.in_use || !S.range) continue;
             all_nospin &= S.nospin;
             range_inst |= S.inst != nullptr;
+            r_bytes += (uint64_t)S.ub * (S.nospin ? 104u : 164u);
             S.dead_at_end = true;
             // cohorts that are no longer provably too young to die join the old part: the boundary moves, nothing is copied
             uint32_t grad = 0;
@@ -2689,7 +2698,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             ra.host_counts = a.host_counts, ra.live_out = a.live_out, ra.live_next = a.live_next;
             hipEvent_t e0, e1;
             next_timing_pair(&e0, &e1);
-            FW_HIP(ctx, fw_launch_update_range(ctx->stream, ctx->g, ra, all_nospin, e0, e1));
+            FW_HIP(ctx, fw_launch_update_range(ctx->stream, ctx->g, ra, all_nospin, r_bytes > ctx->nt_bytes, e0, e1));
             ctx->rslot_frame[rslot] = ctx->frame + 1;
             range_launched = true;
         }

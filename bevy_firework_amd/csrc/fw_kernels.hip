@@ -81,31 +81,37 @@ __device__ __forceinline__ void fw_st1(char *plane, uint32_t i, float v) {
 // each output plane.  With the plane pointer advanced to the window start on the scalar unit and a 32-bit byte offset
 // per lane, the access is "SGPR pair + VGPR offset" (the saddr form of global_load / global_store): no 64-bit vector
 // address arithmetic and no address register pairs kept alive per plane.
-// (FW_NT_LOADS / FW_NT_STORES: experiment builds with non-temporal plane accesses, tools/ab.sh)
+// NT: non-temporal accesses (the `nt` bit of global_load / global_store).  A launch whose planes exceed the 256 MiB Infinity
+// Cache several times over gains 4-8 % from them (configs[2] on range rings 332 -> 317 us, one 16M ring 497 -> 464 us); a
+// launch that fits loses up to 25 % (configs[1] 24.0 -> 30.8 us, configs[3] 74 -> 85 us): the host decides per launch
+// (fw_ctx::nt_bytes), the kernels that stream large rings in place exist in both forms (profiles/r03/nt_ab.txt).
+template <bool NT = false>
 __device__ __forceinline__ float4 fw_ld4w(const char *win, uint32_t byte_off) {
     const FW_GLOBAL fw_f4 *p = reinterpret_cast<const FW_GLOBAL fw_f4 *>(
         reinterpret_cast<const FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off);
-#ifdef FW_NT_LOADS
-    const fw_f4 v = __builtin_nontemporal_load(p);
-#else
-    const fw_f4 v = *p;
-#endif
+    fw_f4 v;
+    if constexpr (NT) v = __builtin_nontemporal_load(p);
+    else v = *p;
     return make_float4(v.x, v.y, v.z, v.w);
 }
+template <bool NT = false>
 __device__ __forceinline__ void fw_st4w(char *win, uint32_t byte_off, float4 v) {
     const fw_f4 x = {v.x, v.y, v.z, v.w};
     FW_GLOBAL fw_f4 *p = reinterpret_cast<FW_GLOBAL fw_f4 *>(reinterpret_cast<FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off);
-#ifdef FW_NT_STORES
-    __builtin_nontemporal_store(x, p);
-#else
-    *p = x;
-#endif
+    if constexpr (NT) __builtin_nontemporal_store(x, p);
+    else *p = x;
 }
+template <bool NT = false>
 __device__ __forceinline__ float fw_ld1w(const char *win, uint32_t byte_off) {
-    return *reinterpret_cast<const FW_GLOBAL float *>(reinterpret_cast<const FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off);
+    const FW_GLOBAL float *p = reinterpret_cast<const FW_GLOBAL float *>(reinterpret_cast<const FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off);
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
 }
+template <bool NT = false>
 __device__ __forceinline__ void fw_st1w(char *win, uint32_t byte_off, float v) {
-    *reinterpret_cast<FW_GLOBAL float *>(reinterpret_cast<FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off) = v;
+    FW_GLOBAL float *p = reinterpret_cast<FW_GLOBAL float *>(reinterpret_cast<FW_GLOBAL char *>(reinterpret_cast<uintptr_t>(win)) + byte_off);
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
 }
 __device__ __forceinline__ uint4 fw_ld4u(const char *win, uint32_t byte_off) {
     typedef uint32_t fw_u4v __attribute__((ext_vector_type(4)));
@@ -338,7 +344,7 @@ __device__ __forceinline__ fw_q4 fw_quat_step(fw_v3 v) {
 // that do not spin, the scale under a constant curve); `full` marks a lane whose slot holds nothing yet (a particle
 // spawned this frame): it writes everything.
 // WM >= 0: which of the optional planes the launch writes is a compile-time fact (bit 0 base colour, 1 emissive, 2 scale)
-template <bool INPLACE = false, int WM = -1>
+template <bool INPLACE = false, int WM = -1, bool NT = false>
 __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float *s_keys, float dt, float4 q0, float4 q1,
                                                    float4 q2, float4 q3, float age_new, const FwOutWin &W, uint32_t o,
                                                    float4 *rec = nullptr, const fw_v3 *cpos = nullptr,
@@ -367,25 +373,25 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     fw_gradient_sample(T.bc_kind, T.bc_n, s_keys + T.o_bc_t, s_keys + T.o_bc_v, age_percent, bc);
     fw_gradient_sample(T.em_kind, T.em_n, s_keys + T.o_em_t, s_keys + T.o_em_v, age_percent, em);
     const uint32_t b16 = (o - W.first) * 16u;  // < 16 KiB + a tile: the window starts at the tile's first output slot
-    fw_st4w(W.q0, b16, make_float4(px, py, pz, age_new));
-    fw_st4w(W.q1, b16, make_float4(vx, vy, vz, q1.w));
+    fw_st4w<NT>(W.q0, b16, make_float4(px, py, pz, age_new));
+    fw_st4w<NT>(W.q1, b16, make_float4(vx, vy, vz, q1.w));
     if (INPLACE) {
         const uint32_t d2 = (__float_as_uint(nr.x) ^ __float_as_uint(q2.x)) | (__float_as_uint(nr.y) ^ __float_as_uint(q2.y)) |
                             (__float_as_uint(nr.z) ^ __float_as_uint(q2.z)) | (__float_as_uint(nr.w) ^ __float_as_uint(q2.w));
         const uint32_t d3 = (__float_as_uint(wx) ^ __float_as_uint(q3.x)) | (__float_as_uint(wy) ^ __float_as_uint(q3.y)) |
                             (__float_as_uint(wz) ^ __float_as_uint(q3.z));
-        if (W.wr2 && __any(full || d2 != 0u)) fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));  // wave-uniform branches
-        if (W.wr3 && __any(full || d3 != 0u)) fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
-        if ((WM >= 0 ? (WM & 1) != 0 : W.wr5) || full) fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
-        if ((WM >= 0 ? (WM & 2) != 0 : W.wr6) || full) fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
-        if ((WM >= 0 ? (WM & 4) != 0 : (T.sc_kind != 0 && W.wr4)) || full) fw_st1w(W.s4, (o - W.first) * 4u, scale);
+        if (W.wr2 && __any(full || d2 != 0u)) fw_st4w<NT>(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));  // wave-uniform branches
+        if (W.wr3 && __any(full || d3 != 0u)) fw_st4w<NT>(W.q3, b16, make_float4(wx, wy, wz, lifetime));
+        if ((WM >= 0 ? (WM & 1) != 0 : W.wr5) || full) fw_st4w<NT>(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
+        if ((WM >= 0 ? (WM & 2) != 0 : W.wr6) || full) fw_st4w<NT>(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
+        if ((WM >= 0 ? (WM & 4) != 0 : (T.sc_kind != 0 && W.wr4)) || full) fw_st1w<NT>(W.s4, (o - W.first) * 4u, scale);
     } else {
-        if (W.wr2) fw_st4w(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
-        if (W.wr3) fw_st4w(W.q3, b16, make_float4(wx, wy, wz, lifetime));
-        else fw_st1w(W.lf, (o - W.first) * 4u, lifetime);
-        if (W.wr5) fw_st4w(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));  // workgroup-uniform branches
-        if (W.wr6) fw_st4w(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
-        if (W.wr4) fw_st1w(W.s4, (o - W.first) * 4u, scale);
+        if (W.wr2) fw_st4w<NT>(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
+        if (W.wr3) fw_st4w<NT>(W.q3, b16, make_float4(wx, wy, wz, lifetime));
+        else fw_st1w<NT>(W.lf, (o - W.first) * 4u, lifetime);
+        if (W.wr5) fw_st4w<NT>(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));  // workgroup-uniform branches
+        if (W.wr6) fw_st4w<NT>(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
+        if (W.wr4) fw_st1w<NT>(W.s4, (o - W.first) * 4u, scale);
     }
     if (box_on) {  // update_aabbs (render.rs:677-703): running min / max of position -/+ scale, per lane
         // (`box` always points at the caller's local array when box_on can be true: never selected against null, so it
@@ -1612,7 +1618,7 @@ __device__ __forceinline__ void fw_fifo_inst_out(const FwFifoSeg &F, char *inst,
 #ifndef FW_FIFO_UNROLL
 #define FW_FIFO_UNROLL 4
 #endif
-template <bool INST, int WM>
+template <bool INST, int WM, bool NT = false>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifoArgs a, FwInlineOps inl) {
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
@@ -1666,19 +1672,19 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
     const bool defer = F.mat != 0u && F.n_in == 0xFFFFFFFFu;
     const uint32_t i1 = (uint32_t)(min(1, R - 1) * BLK + (int)tid) * 16u;
     if (!spawner && !defer) {
-        q0c = fw_ld4w(iw0, tid * 16u), q3c = fw_ld4w(iw3, (tid * 16u) & m2);
-        q1c = fw_ld4w(iw1, tid * 16u), q2c = fw_ld4w(iw2, (tid * 16u) & m2);
-        q0n = fw_ld4w(iw0, i1), q3n = fw_ld4w(iw3, i1 & m2);
-        q1n = fw_ld4w(iw1, i1), q2n = fw_ld4w(iw2, i1 & m2);
+        q0c = fw_ld4w<NT>(iw0, tid * 16u), q3c = fw_ld4w<NT>(iw3, (tid * 16u) & m2);
+        q1c = fw_ld4w<NT>(iw1, tid * 16u), q2c = fw_ld4w<NT>(iw2, (tid * 16u) & m2);
+        q0n = fw_ld4w<NT>(iw0, i1), q3n = fw_ld4w<NT>(iw3, i1 & m2);
+        q1n = fw_ld4w<NT>(iw1, i1), q2n = fw_ld4w<NT>(iw2, i1 & m2);
     }
     if (defer) {
         uint32_t i0 = sbase - head;
         if (sbase < head) i0 += C;
         if (tis != 0u && !(i0 < n_tot || (i0 + TILE > C && n_tot != 0u))) return;
-        q0c = fw_ld4w(iw0, tid * 16u), q3c = fw_ld4w(iw3, (tid * 16u) & m2);
-        q1c = fw_ld4w(iw1, tid * 16u), q2c = fw_ld4w(iw2, (tid * 16u) & m2);
-        q0n = fw_ld4w(iw0, i1), q3n = fw_ld4w(iw3, i1 & m2);
-        q1n = fw_ld4w(iw1, i1), q2n = fw_ld4w(iw2, i1 & m2);
+        q0c = fw_ld4w<NT>(iw0, tid * 16u), q3c = fw_ld4w<NT>(iw3, (tid * 16u) & m2);
+        q1c = fw_ld4w<NT>(iw1, tid * 16u), q2c = fw_ld4w<NT>(iw2, (tid * 16u) & m2);
+        q0n = fw_ld4w<NT>(iw0, i1), q3n = fw_ld4w<NT>(iw3, i1 & m2);
+        q1n = fw_ld4w<NT>(iw1, i1), q2n = fw_ld4w<NT>(iw2, i1 & m2);
     }
     if (blockIdx.x == 0 && tid == 0) {
         if (a.live_next) *a.live_next = 0ull;
@@ -1726,7 +1732,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         const unsigned long long m = __ballot(alive);
         float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(m) * 4u : nullptr;
         if (alive)
-            fw_integrate_store<true, -1>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, nullptr, nullptr,
+            fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, nullptr, nullptr,
                                          nullptr, false, true);
         else if (is_new && want_destroyed)  // born and destroyed in the same frame (dt >= lifetime)
             fw_store_destroyed(F.destroyed, buf, C, s, false, T, s_keys, so.q0, so.q1, so.q2, so.q3, age_new, i);
@@ -1743,8 +1749,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
                 if (s < head) i += C;
                 if (i < n_dead && i < n_in) {
                     const uint32_t b16 = (uint32_t)(r * BLK + (int)tid) * 16u;
-                    const float4 q0 = fw_ld4w(iw0, b16), q1 = fw_ld4w(iw1, b16), q2 = fw_ld4w(iw2, b16 & m2);
-                    const float4 q3 = nospin ? q3s : fw_ld4w(iw3, b16);
+                    const float4 q0 = fw_ld4w<NT>(iw0, b16), q1 = fw_ld4w<NT>(iw1, b16), q2 = fw_ld4w<NT>(iw2, b16 & m2);
+                    const float4 q3 = nospin ? q3s : fw_ld4w<NT>(iw3, b16);
                     // (a materialised particle that dies in its first update carries the spawn-time colours and scale, like any
                     // particle born and destroyed in one frame: evaluated, not read -- the planes of a FW_TYPE_DERIVED type
                     // are not maintained, and for everybody else they hold exactly these values)
@@ -1758,8 +1764,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         for (int r = 0; r < R; r++) {
             const uint32_t s = sbase + r * BLK + tid;
             const uint32_t in_ = (uint32_t)(min(r + 2, R - 1) * BLK + (int)tid) * 16u;  // two rounds ahead (the last re-read)
-            const float4 q0f = fw_ld4w(iw0, in_), q3f = fw_ld4w(iw3, in_ & m2);
-            const float4 q1f = fw_ld4w(iw1, in_), q2f = fw_ld4w(iw2, in_ & m2);
+            const float4 q0f = fw_ld4w<NT>(iw0, in_), q3f = fw_ld4w<NT>(iw3, in_ & m2);
+            const float4 q1f = fw_ld4w<NT>(iw1, in_), q2f = fw_ld4w<NT>(iw2, in_ & m2);
             if (nospin) q3c = q3s;
             uint32_t i = s - head;  // logical index of the slot
             if (s < head) i += C;
@@ -1773,12 +1779,12 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
             if (alive) {
                 if (a.dbg & 2u) {  // profiling only: stream without arithmetic
                     const uint32_t b16 = (s - W.first) * 16u;
-                    fw_st4w(W.q0, b16, make_float4(q0c.x, q0c.y, q0c.z, age_new)), fw_st4w(W.q1, b16, q1c);
-                    if (WM >= 0 ? (WM & 1) != 0 : W.wr5) fw_st4w(W.q5, b16, q0c);
-                    if (WM >= 0 ? (WM & 2) != 0 : W.wr6) fw_st4w(W.q6, b16, q1c);
-                    if (WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) fw_st1w(W.s4, (s - W.first) * 4u, q1c.w);
+                    fw_st4w<NT>(W.q0, b16, make_float4(q0c.x, q0c.y, q0c.z, age_new)), fw_st4w<NT>(W.q1, b16, q1c);
+                    if (WM >= 0 ? (WM & 1) != 0 : W.wr5) fw_st4w<NT>(W.q5, b16, q0c);
+                    if (WM >= 0 ? (WM & 2) != 0 : W.wr6) fw_st4w<NT>(W.q6, b16, q1c);
+                    if (WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) fw_st1w<NT>(W.s4, (s - W.first) * 4u, q1c.w);
                 } else {
-                    fw_integrate_store<true, WM>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, nullptr, nullptr, nullptr,
+                    fw_integrate_store<true, WM, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, nullptr, nullptr, nullptr,
                                                  false, i >= full_from);
                 }
             }
@@ -1867,7 +1873,7 @@ uint32_t fw_range_young_tile(void) { return FW_RANGE_YR * FW_BLOCK; }
 // new distance from the young part)  -- both known to a tile without waiting for anybody: the records of the frame are
 // d_out[first, first + count) with first = the particles this update destroyed (n_old_in - n_old_out = ndestroyed), in list
 // order.  (An index counted from 0 would need the old part's survivor total, which only its last tile knows.)
-template <bool ALLNOSPIN, bool INST>
+template <bool ALLNOSPIN, bool INST, bool NT>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
@@ -1919,10 +1925,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         float4 q0c, q1c, q2c, q3c, q0n, q1n, q2n, q3n;
         float lfc, lfn;
         const uint32_t i0 = (sbase + tid) * 16u, i1 = (sbase + (uint32_t)min(1, YR - 1) * BLK + tid) * 16u;
-        q0c = fw_ld4w(p0, i0), q3c = fw_ld4w(p3, i0 & m2), lfc = fw_ld1w(m2 ? p0 : pl, m2 ? 0u : i0 / 4u);
-        q1c = fw_ld4w(p1, i0), q2c = fw_ld4w(p2, i0 & m2);
-        q0n = fw_ld4w(p0, i1), q3n = fw_ld4w(p3, i1 & m2), lfn = fw_ld1w(m2 ? p0 : pl, m2 ? 0u : i1 / 4u);
-        q1n = fw_ld4w(p1, i1), q2n = fw_ld4w(p2, i1 & m2);
+        q0c = fw_ld4w<NT>(p0, i0), q3c = fw_ld4w<NT>(p3, i0 & m2), lfc = fw_ld1w<NT>(m2 ? p0 : pl, m2 ? 0u : i0 / 4u);
+        q1c = fw_ld4w<NT>(p1, i0), q2c = fw_ld4w<NT>(p2, i0 & m2);
+        q0n = fw_ld4w<NT>(p0, i1), q3n = fw_ld4w<NT>(p3, i1 & m2), lfn = fw_ld1w<NT>(m2 ? p0 : pl, m2 ? 0u : i1 / 4u);
+        q1n = fw_ld4w<NT>(p1, i1), q2n = fw_ld4w<NT>(p2, i1 & m2);
         const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
         if (tid < keys_len) s_keys[tid] = key0;
         for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
@@ -1933,9 +1939,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         for (int r = 0; r < YR; r++) {
             const uint32_t s = sbase + r * BLK + tid;
             const uint32_t in_ = (sbase + (uint32_t)min(r + 2, YR - 1) * BLK + tid) * 16u;  // two rounds ahead (the last re-read)
-            const float4 q0f = fw_ld4w(p0, in_), q3f = fw_ld4w(p3, in_ & m2);
-            const float lff = fw_ld1w(m2 ? p0 : pl, m2 ? 0u : in_ / 4u);
-            const float4 q1f = fw_ld4w(p1, in_), q2f = fw_ld4w(p2, in_ & m2);
+            const float4 q0f = fw_ld4w<NT>(p0, in_), q3f = fw_ld4w<NT>(p3, in_ & m2);
+            const float lff = fw_ld1w<NT>(m2 ? p0 : pl, m2 ? 0u : in_ / 4u);
+            const float4 q1f = fw_ld4w<NT>(p1, in_), q2f = fw_ld4w<NT>(p2, in_ & m2);
             if (nospin) q3c = make_float4(0.0f, 0.0f, 0.0f, lfc);
             uint32_t yi = s - b;  // index within the young part
             if (s < b) yi += C;
@@ -1945,7 +1951,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             bad |= mine && !surv;  // the host's cohort ages say nobody young can die
             const unsigned long long mi = (INST && inst != nullptr) ? __ballot(mine) : 0ull;
             float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(mi) * 4u : nullptr;
-            if (mine) fw_integrate_store<true, -1>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec);
+            if (mine) fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec);
             if (INST) fw_range_inst_out(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n, lfc = lfn;
             q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f, lfn = lff;
@@ -1976,7 +1982,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
                     if (!fw_survives(so.q0.w, a.dt, so.q3.w, &age_new)) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 8u, g.err[6] = seg, g.err[7] = kk;
                     // (the record goes through the lane's own slot of the wave's LDS area: no private array, no scratch)
                     float4 *rec4 = (INST && inst != nullptr) ? s_inst_wave + lane * 4u : nullptr;
-                    fw_integrate_store<false, -1>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, Wn, s, rec4);
+                    fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, Wn, s, rec4);
                     if (INST && inst != nullptr && rec0 + yi < inst_cap)
                         for (uint32_t x = 0; x < 4; x++) fw_st4(inst + (size_t)(rec0 + yi) * 64u, x, rec4[x]);
                 }
@@ -2022,7 +2028,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             if (!surv) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 8u, g.err[6] = seg, g.err[7] = kk;
             // (the colour plane of a constant gradient holds that colour in every slot since the buffer was allocated)
             const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
-            fw_integrate_store<false, -1>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec);
+            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec);
         }
         if (INST) fw_range_inst_out(inst, inst_cap, s_inst_wave, rec, lane, mi, n_old_in + y_exist + kk, false);
         return;
@@ -2053,11 +2059,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         const uint32_t d = min(base + r * BLK + tid, lim - 1u);
         uint32_t s = bm1 - d;  // in [0, 2 C)
         if (s >= C) s -= C;
-        q0[r] = fw_ld4w(p0, s * 16u);
-        q3[r] = fw_ld4w(p3, (s * 16u) & m2);
-        const float lf = fw_ld1w(m2 ? p0 : pl, m2 ? 0u : s * 4u);
-        q1[r] = fw_ld4w(p1, s * 16u);
-        q2[r] = fw_ld4w(p2, (s * 16u) & m2);
+        q0[r] = fw_ld4w<NT>(p0, s * 16u);
+        q3[r] = fw_ld4w<NT>(p3, (s * 16u) & m2);
+        const float lf = fw_ld1w<NT>(m2 ? p0 : pl, m2 ? 0u : s * 4u);
+        q1[r] = fw_ld4w<NT>(p1, s * 16u);
+        q2[r] = fw_ld4w<NT>(p2, (s * 16u) & m2);
         if (nospin) q3[r] = make_float4(0.0f, 0.0f, 0.0f, lf);
     }
     const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
@@ -2117,7 +2123,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         if (alive) {
             uint32_t s = bm1 - od;
             if (s >= C) s -= C;
-            fw_integrate_store<false, -1>(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], W, s, rec);
+            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], W, s, rec);
         }
         if (INST) fw_range_inst_out(inst, inst_cap, s_inst_wave, rec, lane, m[r], n_old_in - 1u - od, true);
         if (!alive && valid && want_destroyed) {
@@ -2968,9 +2974,16 @@ hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArg
 }
 
 hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifoArgs &a, const FwInlineOps &inl,
-                                 uint32_t total_tiles, hipEvent_t e0, hipEvent_t e1) {
+                                 uint32_t total_tiles, bool nt, hipEvent_t e0, hipEvent_t e1) {
     if (!total_tiles || !a.n_segs) return hipErrorInvalidValue;
     const dim3 grid(total_tiles), block(FW_BLOCK);
+    if (nt) {  // non-temporal form (fw_ld4w): the generic write mask only -- at HBM speed the compile-time one buys nothing
+        if (a.any_inst)
+            FW_LAUNCH_T((fw_k_update_fifo<true, -1, true>), grid, block, s, e0, e1, g, a, inl);
+        else
+            FW_LAUNCH_T((fw_k_update_fifo<false, -1, true>), grid, block, s, e0, e1, g, a, inl);
+        return hipGetLastError();
+    }
 #define FW_FIFO_CASE(wm)                                                                   \
     case wm:                                                                               \
         if (a.any_inst)                                                                    \
@@ -2991,20 +3004,27 @@ hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifo
     return hipGetLastError();
 }
 
-hipError_t fw_launch_update_range(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin, hipEvent_t e0,
-                                  hipEvent_t e1) {
-    if (!a.total_tiles) return hipErrorInvalidValue;
+template <bool NT>
+static void fw_launch_update_range_t(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin, hipEvent_t e0,
+                                     hipEvent_t e1) {
     const dim3 grid(a.total_tiles), block(FW_BLOCK);
     if (a.any_inst) {
         if (all_nospin)
-            FW_LAUNCH_T((fw_k_update_range<true, true>), grid, block, s, e0, e1, g, a);
+            FW_LAUNCH_T((fw_k_update_range<true, true, NT>), grid, block, s, e0, e1, g, a);
         else
-            FW_LAUNCH_T((fw_k_update_range<false, true>), grid, block, s, e0, e1, g, a);
+            FW_LAUNCH_T((fw_k_update_range<false, true, NT>), grid, block, s, e0, e1, g, a);
     } else if (all_nospin) {
-        FW_LAUNCH_T((fw_k_update_range<true, false>), grid, block, s, e0, e1, g, a);
+        FW_LAUNCH_T((fw_k_update_range<true, false, NT>), grid, block, s, e0, e1, g, a);
     } else {
-        FW_LAUNCH_T((fw_k_update_range<false, false>), grid, block, s, e0, e1, g, a);
+        FW_LAUNCH_T((fw_k_update_range<false, false, NT>), grid, block, s, e0, e1, g, a);
     }
+}
+
+hipError_t fw_launch_update_range(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin, bool nt,
+                                  hipEvent_t e0, hipEvent_t e1) {
+    if (!a.total_tiles) return hipErrorInvalidValue;
+    if (nt) fw_launch_update_range_t<true>(s, g, a, all_nospin, e0, e1);
+    else fw_launch_update_range_t<false>(s, g, a, all_nospin, e0, e1);
     return hipGetLastError();
 }
 

@@ -352,3 +352,19 @@ def test_ring_launches_switch_between_the_side_stream_and_the_main_stream(system
             torch.cuda.synchronize()
             totals.append((int(live[(steps_with_ring - 1) % 8].item()), pa.cpu.counts()[0] + pb.cpu.counts()[0]))
     assert len(totals) > 20 and all(a == b for a, b in totals), totals[:8]
+
+
+@pytest.mark.parametrize("case", [test_ring_wraps_many_times_bit_exact, test_irregular_dt_needs_no_forecast, test_growth_while_wrapped,
+                                  test_instances_destroyed_and_aabb_on_a_wrapped_ring, test_nested_spawner_on_rings_bit_exact,
+                                  test_nested_rings_with_attached_instances_and_idle_frames], ids=lambda f: f.__name__[5:])
+def test_non_temporal_form_of_the_kernel(fw_path, monkeypatch, case):
+    """a ring launch that streams more than fw_ctx::nt_bytes (several times the Infinity Cache) runs the kernel's
+    non-temporal instantiation (fw_ld4w<NT>): the same results, bit for bit -- forced here at every size"""
+    from bevy_firework_amd.system import ParticleSystem
+
+    if fw_path == "general":
+        pytest.skip("the compacting path has no non-temporal form")
+    monkeypatch.setenv("FW_NT_MB", "0")
+    with ParticleSystem(device=0, seed=SEED) as nt_system:  # (the knob is read when the context is created)
+        nt_system.path = fw_path
+        case(nt_system)

@@ -303,12 +303,15 @@ def test_every_shortcut_gives_the_state_of_the_plain_path(case, monkeypatch):
     on_demand = any(e.emission_pacing.kind == S.PACING_ONDEMAND for e in spawner.emission_settings)
     results = {}
     for name, env in (("shortcuts", {"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_NOSPIN": "1", "FW_RANGE": "1", "FW_RANGE_MIN": "0"}),
+                      # (the non-temporal form of the ring kernels: what a launch of more than fw_ctx::nt_bytes runs)
+                      ("shortcuts, nt", {"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_NOSPIN": "1", "FW_RANGE": "1", "FW_RANGE_MIN": "0", "FW_NT_MB": "0"}),
+                      ("rings, nt", {"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_NOSPIN": "0", "FW_RANGE": "1", "FW_RANGE_MIN": "0", "FW_NT_MB": "0"}),
                       ("rings only", {"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_NOSPIN": "0", "FW_RANGE": "0"}),
                       ("range rings only", {"FW_FIFO": "0", "FW_NOSPIN": "0", "FW_RANGE": "1", "FW_RANGE_MIN": "0"}),
                       ("range rings, no planes", {"FW_FIFO": "0", "FW_NOSPIN": "1", "FW_RANGE": "1", "FW_RANGE_MIN": "0"}),
                       ("no planes only", {"FW_FIFO": "0", "FW_NOSPIN": "1", "FW_RANGE": "0"}),
                       ("plain", {"FW_FIFO": "0", "FW_NOSPIN": "0", "FW_FIFO_STREAM": "0", "FW_RANGE": "0"})):
-        for k in ("FW_FIFO", "FW_FIFO_MIN", "FW_NOSPIN", "FW_FIFO_STREAM", "FW_RANGE", "FW_RANGE_MIN"):
+        for k in ("FW_FIFO", "FW_FIFO_MIN", "FW_NOSPIN", "FW_FIFO_STREAM", "FW_RANGE", "FW_RANGE_MIN", "FW_NT_MB"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -322,7 +325,7 @@ def test_every_shortcut_gives_the_state_of_the_plain_path(case, monkeypatch):
                 dead_total += sum(len(h.destroyed(t)) for t in range(len(spawner.particle_settings)))
             results[name] = ([h.particles(t) for t in range(len(spawner.particle_settings))], h.aabb(), dead_total)
     ref_parts, ref_box, ref_dead = results["plain"]
-    for name in ("shortcuts", "rings only", "range rings only", "range rings, no planes", "no planes only"):
+    for name in ("shortcuts", "shortcuts, nt", "rings, nt", "rings only", "range rings only", "range rings, no planes", "no planes only"):
         parts, box, dead = results[name]
         assert dead == ref_dead, (name, dead, ref_dead)
         for t, (a, b) in enumerate(zip(parts, ref_parts)):
