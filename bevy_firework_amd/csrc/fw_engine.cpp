@@ -399,10 +399,13 @@ struct fw_ctx {
     bool range_devrec = false;
     bool range_fold = false;   // FW_RANGE_FOLD: a handful of new particles ride in the YOUNG workgroups (A/B)
     bool range_spread_new = true;   // FW_RANGE_SPREAD_NEW=0: a segment's NEW workgroups all in front of its YOUNG ones (A/B)
-    // An in-place ring launch (FIFO / range) that streams more than this uses the non-temporal form of its kernel: several
-    // times the 256 MiB Infinity Cache, where allocating lines that cannot survive until the next frame only costs
-    // (fw_kernels.hip: fw_ld4w; FW_NT_MB=n knob, 0 = always)
+    // An in-place ring launch (FIFO / range) that streams more than nt_bytes uses the fully non-temporal form of its kernel:
+    // several times the 256 MiB Infinity Cache, where allocating lines that cannot survive until the next frame only costs.
+    // One that streams more than nt_wo_bytes -- no longer all of it fits -- stores the planes no update reads back (scale,
+    // colours) non-temporally, so that the cache keeps what the next frame reads (fw_kernels.hip: fw_ld4w; knobs FW_NT_MB=n,
+    // FW_NT_WO_MB=n: 0 = always)
     uint64_t nt_bytes = 768ull << 20;  // (crossover measured at 0.65-0.85 GB for both kernels: profiles/r03/nt_sweep.txt)
+    uint64_t nt_wo_bytes = 200ull << 20;
     uint32_t range_old_extra = 0;  // FW_RANGE_OLD_EXTRA=n: n more (idle) OLD workgroups per segment -- what an idle one costs
     size_t rparam_bytes = 0;
     uint64_t rslot_frame[kParamRing] = {};    // frame that last used the slot (+1; 0 = free)
@@ -1620,6 +1623,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_RANGE_FOLD")) ctx->range_fold = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_OLD_EXTRA")) ctx->range_old_extra = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;
+    if (const char *m = getenv("FW_NT_WO_MB")) ctx->nt_wo_bytes = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_RANGE_SPREAD_NEW")) ctx->range_spread_new = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
@@ -2466,7 +2470,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             fa.live_out = a.live_out, fa.live_next = a.live_next;
             hipEvent_t e0, e1;
             next_timing_pair(&e0, &e1);
-            const hipError_t e = fw_launch_update_fifo(fstream, ctx->g, fa, fio, f_tiles, f_bytes > ctx->nt_bytes, e0, e1);
+            const hipError_t e = fw_launch_update_fifo(fstream, ctx->g, fa, fio, f_tiles, f_bytes > ctx->nt_bytes ? 2 : f_bytes > ctx->nt_wo_bytes ? 1 : 0, e0, e1);
             if (side) ctx->side_dirty = true;
             fa = FwFifoArgs{};
             f_ops = f_tiles = 0, f_bytes = 0;
@@ -2698,7 +2702,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             ra.host_counts = a.host_counts, ra.live_out = a.live_out, ra.live_next = a.live_next;
             hipEvent_t e0, e1;
             next_timing_pair(&e0, &e1);
-            FW_HIP(ctx, fw_launch_update_range(ctx->stream, ctx->g, ra, all_nospin, r_bytes > ctx->nt_bytes, e0, e1));
+            FW_HIP(ctx, fw_launch_update_range(ctx->stream, ctx->g, ra, all_nospin, r_bytes > ctx->nt_bytes ? 2 : r_bytes > ctx->nt_wo_bytes ? 1 : 0, e0, e1));
             ctx->rslot_frame[rslot] = ctx->frame + 1;
             range_launched = true;
         }

@@ -208,11 +208,11 @@ hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArg
                             int spawn_form, int mode, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // in-place update of up to FW_FIFO_PER_LAUNCH FIFO segments (their spawn ops in `inl`)
 hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifoArgs &a, const FwInlineOps &inl,
-                                 uint32_t total_tiles, bool nt, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                                 uint32_t total_tiles, int nt, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 uint32_t fw_range_young_tile(void);  // ring slots a YOUNG workgroup of fw_k_update_range covers (a build-time choice)
 // in-place update of every range ring of the context (all_nospin: no segment of the launch keeps a rotation plane)
-// nt: the non-temporal form of the kernel (a launch whose planes exceed the Infinity Cache several times over: fw_ctx::nt_bytes)
-hipError_t fw_launch_update_range(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin, bool nt,
+// nt: which form of the kernel (fw_kernels.hip, fw_ld4w): 0 plain, 1 the write-only planes non-temporal, 2 every plane access
+hipError_t fw_launch_update_range(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin, int nt,
                                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d_ops, const FwNestOp *h_ops, uint32_t n_ops,
                             uint32_t total_tiles, uint32_t parity, uint32_t tag, uint32_t spin_limit, uint32_t dbg = 0);

@@ -81,10 +81,15 @@ __device__ __forceinline__ void fw_st1(char *plane, uint32_t i, float v) {
 // each output plane.  With the plane pointer advanced to the window start on the scalar unit and a 32-bit byte offset
 // per lane, the access is "SGPR pair + VGPR offset" (the saddr form of global_load / global_store): no 64-bit vector
 // address arithmetic and no address register pairs kept alive per plane.
-// NT: non-temporal accesses (the `nt` bit of global_load / global_store).  A launch whose planes exceed the 256 MiB Infinity
-// Cache several times over gains 4-8 % from them (configs[2] on range rings 332 -> 317 us, one 16M ring 497 -> 464 us); a
-// launch that fits loses up to 25 % (configs[1] 24.0 -> 30.8 us, configs[3] 74 -> 85 us): the host decides per launch
-// (fw_ctx::nt_bytes), the kernels that stream large rings in place exist in both forms (profiles/r03/nt_ab.txt).
+// NT: non-temporal accesses (the `nt` bit of global_load / global_store).  The kernels that update rings in place exist in
+// three forms, the host picks one per launch from what the launch streams (fw_ctx::nt_bytes / nt_wo_bytes):
+//   0  plain: everything may stay in the 256 MiB Infinity Cache (configs[1]: 164 MB, and it does);
+//   1  the planes no update ever reads back -- scale, base colour, emissive colour: 36 of a particle's 100-164 bytes --
+//      are stored non-temporally, so what the cache keeps is what the next frame reads (configs[4]'s share, 425 MB: 92.8 ->
+//      87.8 us; a 4M-particle ring, 645 MB: 115 -> 100 us; at 164 MB: nothing either way; profiles/r03/nt_wo.txt);
+//   2  every plane access non-temporal: a launch several times the cache gains another 4-8 % (configs[2] 332 -> 317 us, one
+//      16M ring 497 -> 464 us); one that fits would lose up to 25 % (configs[1] 24.0 -> 30.8 us; profiles/r03/nt_ab.txt,
+//      nt_sweep.txt).
 template <bool NT = false>
 __device__ __forceinline__ float4 fw_ld4w(const char *win, uint32_t byte_off) {
     const FW_GLOBAL fw_f4 *p = reinterpret_cast<const FW_GLOBAL fw_f4 *>(
@@ -344,7 +349,7 @@ __device__ __forceinline__ fw_q4 fw_quat_step(fw_v3 v) {
 // that do not spin, the scale under a constant curve); `full` marks a lane whose slot holds nothing yet (a particle
 // spawned this frame): it writes everything.
 // WM >= 0: which of the optional planes the launch writes is a compile-time fact (bit 0 base colour, 1 emissive, 2 scale)
-template <bool INPLACE = false, int WM = -1, bool NT = false>
+template <bool INPLACE = false, int WM = -1, int NT = 0>
 __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float *s_keys, float dt, float4 q0, float4 q1,
                                                    float4 q2, float4 q3, float age_new, const FwOutWin &W, uint32_t o,
                                                    float4 *rec = nullptr, const fw_v3 *cpos = nullptr,
@@ -373,25 +378,25 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     fw_gradient_sample(T.bc_kind, T.bc_n, s_keys + T.o_bc_t, s_keys + T.o_bc_v, age_percent, bc);
     fw_gradient_sample(T.em_kind, T.em_n, s_keys + T.o_em_t, s_keys + T.o_em_v, age_percent, em);
     const uint32_t b16 = (o - W.first) * 16u;  // < 16 KiB + a tile: the window starts at the tile's first output slot
-    fw_st4w<NT>(W.q0, b16, make_float4(px, py, pz, age_new));
-    fw_st4w<NT>(W.q1, b16, make_float4(vx, vy, vz, q1.w));
+    fw_st4w<NT == 2>(W.q0, b16, make_float4(px, py, pz, age_new));
+    fw_st4w<NT == 2>(W.q1, b16, make_float4(vx, vy, vz, q1.w));
     if (INPLACE) {
         const uint32_t d2 = (__float_as_uint(nr.x) ^ __float_as_uint(q2.x)) | (__float_as_uint(nr.y) ^ __float_as_uint(q2.y)) |
                             (__float_as_uint(nr.z) ^ __float_as_uint(q2.z)) | (__float_as_uint(nr.w) ^ __float_as_uint(q2.w));
         const uint32_t d3 = (__float_as_uint(wx) ^ __float_as_uint(q3.x)) | (__float_as_uint(wy) ^ __float_as_uint(q3.y)) |
                             (__float_as_uint(wz) ^ __float_as_uint(q3.z));
-        if (W.wr2 && __any(full || d2 != 0u)) fw_st4w<NT>(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));  // wave-uniform branches
-        if (W.wr3 && __any(full || d3 != 0u)) fw_st4w<NT>(W.q3, b16, make_float4(wx, wy, wz, lifetime));
-        if ((WM >= 0 ? (WM & 1) != 0 : W.wr5) || full) fw_st4w<NT>(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
-        if ((WM >= 0 ? (WM & 2) != 0 : W.wr6) || full) fw_st4w<NT>(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
-        if ((WM >= 0 ? (WM & 4) != 0 : (T.sc_kind != 0 && W.wr4)) || full) fw_st1w<NT>(W.s4, (o - W.first) * 4u, scale);
+        if (W.wr2 && __any(full || d2 != 0u)) fw_st4w<NT == 2>(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));  // wave-uniform branches
+        if (W.wr3 && __any(full || d3 != 0u)) fw_st4w<NT == 2>(W.q3, b16, make_float4(wx, wy, wz, lifetime));
+        if ((WM >= 0 ? (WM & 1) != 0 : W.wr5) || full) fw_st4w<NT != 0>(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
+        if ((WM >= 0 ? (WM & 2) != 0 : W.wr6) || full) fw_st4w<NT != 0>(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
+        if ((WM >= 0 ? (WM & 4) != 0 : (T.sc_kind != 0 && W.wr4)) || full) fw_st1w<NT != 0>(W.s4, (o - W.first) * 4u, scale);
     } else {
-        if (W.wr2) fw_st4w<NT>(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
-        if (W.wr3) fw_st4w<NT>(W.q3, b16, make_float4(wx, wy, wz, lifetime));
-        else fw_st1w<NT>(W.lf, (o - W.first) * 4u, lifetime);
-        if (W.wr5) fw_st4w<NT>(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));  // workgroup-uniform branches
-        if (W.wr6) fw_st4w<NT>(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
-        if (W.wr4) fw_st1w<NT>(W.s4, (o - W.first) * 4u, scale);
+        if (W.wr2) fw_st4w<NT == 2>(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
+        if (W.wr3) fw_st4w<NT == 2>(W.q3, b16, make_float4(wx, wy, wz, lifetime));
+        else fw_st1w<NT == 2>(W.lf, (o - W.first) * 4u, lifetime);
+        if (W.wr5) fw_st4w<NT != 0>(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));  // workgroup-uniform branches
+        if (W.wr6) fw_st4w<NT != 0>(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
+        if (W.wr4) fw_st1w<NT != 0>(W.s4, (o - W.first) * 4u, scale);
     }
     if (box_on) {  // update_aabbs (render.rs:677-703): running min / max of position -/+ scale, per lane
         // (`box` always points at the caller's local array when box_on can be true: never selected against null, so it
@@ -408,6 +413,7 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
 // Render hand-off fused into the update: the ParticleInstance records of a wave's survivors of one round occupy
 // consecutive slots [wbase, wbase + cnt), i.e. one contiguous run of cnt * 64 bytes.  The lanes park their records in
 // a wave-private LDS area at their rank and the wave then stores the run with fully coalesced float4 stores.
+template <bool NT = false>
 __device__ __forceinline__ void fw_inst_flush(char *inst, uint32_t inst_cap, const float4 *s_wave, uint32_t lane,
                                               unsigned long long m, uint32_t wbase) {
     const uint32_t cnt = (uint32_t)__popcll(m);
@@ -420,7 +426,7 @@ __device__ __forceinline__ void fw_inst_flush(char *inst, uint32_t inst_cap, con
 #pragma unroll 1  // one float4 in registers at a time: the kernel sits at the 128-VGPR occupancy step
     for (uint32_t k = 0; k < 4; k++) {
         const uint32_t e = k * 64u + lane;
-        if (e < room4) fw_st4w(dst, e * 16u, s_wave[e]);
+        if (e < room4) fw_st4w<NT>(dst, e * 16u, s_wave[e]);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1594,7 +1600,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
 // velocity only in waves where they changed: 132 B for the linear 2-key curves of configs[1] instead of 164.
 // ---------------------------------------------------------------------------------
 // the ParticleInstance records of a wave's survivors: consecutive in the output unless the wave straddles the ring's head
-template <bool INST>
+template <bool INST, bool NT = false>
 __device__ __forceinline__ void fw_fifo_inst_out(const FwFifoSeg &F, char *inst, const float4 *s_inst_wave, const float4 *rec,
                                                  uint32_t lane, unsigned long long m, bool alive, uint32_t o) {
     if (!INST || inst == nullptr || m == 0ull) return;
@@ -1602,7 +1608,7 @@ __device__ __forceinline__ void fw_fifo_inst_out(const FwFifoSeg &F, char *inst,
     const uint32_t o_first = __builtin_amdgcn_readlane(o, __ffsll((long long)m) - 1);
     const uint32_t o_last = __builtin_amdgcn_readlane(o, 63 - __clzll((long long)m));
     if (o_last - o_first + 1u == cnt) {
-        fw_inst_flush(inst, F.inst_cap, s_inst_wave, lane, m, o_first);
+        fw_inst_flush<NT>(inst, F.inst_cap, s_inst_wave, lane, m, o_first);
     } else {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1618,7 +1624,7 @@ __device__ __forceinline__ void fw_fifo_inst_out(const FwFifoSeg &F, char *inst,
 #ifndef FW_FIFO_UNROLL
 #define FW_FIFO_UNROLL 4
 #endif
-template <bool INST, int WM, bool NT = false>
+template <bool INST, int WM, int NT = 0>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifoArgs a, FwInlineOps inl) {
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
@@ -1672,19 +1678,19 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
     const bool defer = F.mat != 0u && F.n_in == 0xFFFFFFFFu;
     const uint32_t i1 = (uint32_t)(min(1, R - 1) * BLK + (int)tid) * 16u;
     if (!spawner && !defer) {
-        q0c = fw_ld4w<NT>(iw0, tid * 16u), q3c = fw_ld4w<NT>(iw3, (tid * 16u) & m2);
-        q1c = fw_ld4w<NT>(iw1, tid * 16u), q2c = fw_ld4w<NT>(iw2, (tid * 16u) & m2);
-        q0n = fw_ld4w<NT>(iw0, i1), q3n = fw_ld4w<NT>(iw3, i1 & m2);
-        q1n = fw_ld4w<NT>(iw1, i1), q2n = fw_ld4w<NT>(iw2, i1 & m2);
+        q0c = fw_ld4w<NT == 2>(iw0, tid * 16u), q3c = fw_ld4w<NT == 2>(iw3, (tid * 16u) & m2);
+        q1c = fw_ld4w<NT == 2>(iw1, tid * 16u), q2c = fw_ld4w<NT == 2>(iw2, (tid * 16u) & m2);
+        q0n = fw_ld4w<NT == 2>(iw0, i1), q3n = fw_ld4w<NT == 2>(iw3, i1 & m2);
+        q1n = fw_ld4w<NT == 2>(iw1, i1), q2n = fw_ld4w<NT == 2>(iw2, i1 & m2);
     }
     if (defer) {
         uint32_t i0 = sbase - head;
         if (sbase < head) i0 += C;
         if (tis != 0u && !(i0 < n_tot || (i0 + TILE > C && n_tot != 0u))) return;
-        q0c = fw_ld4w<NT>(iw0, tid * 16u), q3c = fw_ld4w<NT>(iw3, (tid * 16u) & m2);
-        q1c = fw_ld4w<NT>(iw1, tid * 16u), q2c = fw_ld4w<NT>(iw2, (tid * 16u) & m2);
-        q0n = fw_ld4w<NT>(iw0, i1), q3n = fw_ld4w<NT>(iw3, i1 & m2);
-        q1n = fw_ld4w<NT>(iw1, i1), q2n = fw_ld4w<NT>(iw2, i1 & m2);
+        q0c = fw_ld4w<NT == 2>(iw0, tid * 16u), q3c = fw_ld4w<NT == 2>(iw3, (tid * 16u) & m2);
+        q1c = fw_ld4w<NT == 2>(iw1, tid * 16u), q2c = fw_ld4w<NT == 2>(iw2, (tid * 16u) & m2);
+        q0n = fw_ld4w<NT == 2>(iw0, i1), q3n = fw_ld4w<NT == 2>(iw3, i1 & m2);
+        q1n = fw_ld4w<NT == 2>(iw1, i1), q2n = fw_ld4w<NT == 2>(iw2, i1 & m2);
     }
     if (blockIdx.x == 0 && tid == 0) {
         if (a.live_next) *a.live_next = 0ull;
@@ -1736,7 +1742,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
                                          nullptr, false, true);
         else if (is_new && want_destroyed)  // born and destroyed in the same frame (dt >= lifetime)
             fw_store_destroyed(F.destroyed, buf, C, s, false, T, s_keys, so.q0, so.q1, so.q2, so.q3, age_new, i);
-        fw_fifo_inst_out<INST>(F, inst, s_inst_wave, rec, lane, m, alive, i - n_dead);
+        fw_fifo_inst_out<INST, NT == 2>(F, inst, s_inst_wave, rec, lane, m, alive, i - n_dead);
     } else {
         // ---- (1) records of the particles this update destroys (core.rs:596-599).  Kept out of the streaming loop:
         // memory reads inside a divergent branch make the compiler drain every outstanding load -- the prefetch
@@ -1749,8 +1755,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
                 if (s < head) i += C;
                 if (i < n_dead && i < n_in) {
                     const uint32_t b16 = (uint32_t)(r * BLK + (int)tid) * 16u;
-                    const float4 q0 = fw_ld4w<NT>(iw0, b16), q1 = fw_ld4w<NT>(iw1, b16), q2 = fw_ld4w<NT>(iw2, b16 & m2);
-                    const float4 q3 = nospin ? q3s : fw_ld4w<NT>(iw3, b16);
+                    const float4 q0 = fw_ld4w<NT == 2>(iw0, b16), q1 = fw_ld4w<NT == 2>(iw1, b16), q2 = fw_ld4w<NT == 2>(iw2, b16 & m2);
+                    const float4 q3 = nospin ? q3s : fw_ld4w<NT == 2>(iw3, b16);
                     // (a materialised particle that dies in its first update carries the spawn-time colours and scale, like any
                     // particle born and destroyed in one frame: evaluated, not read -- the planes of a FW_TYPE_DERIVED type
                     // are not maintained, and for everybody else they hold exactly these values)
@@ -1764,8 +1770,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         for (int r = 0; r < R; r++) {
             const uint32_t s = sbase + r * BLK + tid;
             const uint32_t in_ = (uint32_t)(min(r + 2, R - 1) * BLK + (int)tid) * 16u;  // two rounds ahead (the last re-read)
-            const float4 q0f = fw_ld4w<NT>(iw0, in_), q3f = fw_ld4w<NT>(iw3, in_ & m2);
-            const float4 q1f = fw_ld4w<NT>(iw1, in_), q2f = fw_ld4w<NT>(iw2, in_ & m2);
+            const float4 q0f = fw_ld4w<NT == 2>(iw0, in_), q3f = fw_ld4w<NT == 2>(iw3, in_ & m2);
+            const float4 q1f = fw_ld4w<NT == 2>(iw1, in_), q2f = fw_ld4w<NT == 2>(iw2, in_ & m2);
             if (nospin) q3c = q3s;
             uint32_t i = s - head;  // logical index of the slot
             if (s < head) i += C;
@@ -1779,16 +1785,16 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
             if (alive) {
                 if (a.dbg & 2u) {  // profiling only: stream without arithmetic
                     const uint32_t b16 = (s - W.first) * 16u;
-                    fw_st4w<NT>(W.q0, b16, make_float4(q0c.x, q0c.y, q0c.z, age_new)), fw_st4w<NT>(W.q1, b16, q1c);
-                    if (WM >= 0 ? (WM & 1) != 0 : W.wr5) fw_st4w<NT>(W.q5, b16, q0c);
-                    if (WM >= 0 ? (WM & 2) != 0 : W.wr6) fw_st4w<NT>(W.q6, b16, q1c);
-                    if (WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) fw_st1w<NT>(W.s4, (s - W.first) * 4u, q1c.w);
+                    fw_st4w<NT == 2>(W.q0, b16, make_float4(q0c.x, q0c.y, q0c.z, age_new)), fw_st4w<NT == 2>(W.q1, b16, q1c);
+                    if (WM >= 0 ? (WM & 1) != 0 : W.wr5) fw_st4w<NT != 0>(W.q5, b16, q0c);
+                    if (WM >= 0 ? (WM & 2) != 0 : W.wr6) fw_st4w<NT != 0>(W.q6, b16, q1c);
+                    if (WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) fw_st1w<NT != 0>(W.s4, (s - W.first) * 4u, q1c.w);
                 } else {
                     fw_integrate_store<true, WM, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, nullptr, nullptr, nullptr,
                                                  false, i >= full_from);
                 }
             }
-            fw_fifo_inst_out<INST>(F, inst, s_inst_wave, rec, lane, m, alive, i - n_dead);
+            fw_fifo_inst_out<INST, NT == 2>(F, inst, s_inst_wave, rec, lane, m, alive, i - n_dead);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n;
             q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f;
         }
@@ -1843,6 +1849,7 @@ __device__ __forceinline__ void fw_store_destroyed_vals(char *dbuf, size_t d, co
 // `m` hold records for consecutive indices -- ascending with the lane, or (OLD tiles: reversed) descending -- staged in the
 // wave's LDS area in ascending index order; a wave whose run is broken (the young part wraps around the whole ring) stores
 // lane by lane.
+template <bool NT = false>
 __device__ __forceinline__ void fw_range_inst_out(char *inst, uint32_t inst_cap, const float4 *s_inst_wave, const float4 *rec,
                                                   uint32_t lane, unsigned long long m, uint32_t idx, bool reversed) {
     if (inst == nullptr || m == 0ull) return;
@@ -1851,7 +1858,7 @@ __device__ __forceinline__ void fw_range_inst_out(char *inst, uint32_t inst_cap,
     const uint32_t i_hi_lane = __builtin_amdgcn_readlane(idx, 63 - __clzll((long long)m));
     const uint32_t lowest = reversed ? i_hi_lane : i_lo_lane, highest = reversed ? i_lo_lane : i_hi_lane;
     if (highest - lowest + 1u == cnt) {
-        fw_inst_flush(inst, inst_cap, s_inst_wave, lane, m, lowest);
+        fw_inst_flush<NT>(inst, inst_cap, s_inst_wave, lane, m, lowest);
     } else {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1873,7 +1880,7 @@ uint32_t fw_range_young_tile(void) { return FW_RANGE_YR * FW_BLOCK; }
 // new distance from the young part)  -- both known to a tile without waiting for anybody: the records of the frame are
 // d_out[first, first + count) with first = the particles this update destroyed (n_old_in - n_old_out = ndestroyed), in list
 // order.  (An index counted from 0 would need the old part's survivor total, which only its last tile knows.)
-template <bool ALLNOSPIN, bool INST, bool NT>
+template <bool ALLNOSPIN, bool INST, int NT>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
@@ -1925,10 +1932,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         float4 q0c, q1c, q2c, q3c, q0n, q1n, q2n, q3n;
         float lfc, lfn;
         const uint32_t i0 = (sbase + tid) * 16u, i1 = (sbase + (uint32_t)min(1, YR - 1) * BLK + tid) * 16u;
-        q0c = fw_ld4w<NT>(p0, i0), q3c = fw_ld4w<NT>(p3, i0 & m2), lfc = fw_ld1w<NT>(m2 ? p0 : pl, m2 ? 0u : i0 / 4u);
-        q1c = fw_ld4w<NT>(p1, i0), q2c = fw_ld4w<NT>(p2, i0 & m2);
-        q0n = fw_ld4w<NT>(p0, i1), q3n = fw_ld4w<NT>(p3, i1 & m2), lfn = fw_ld1w<NT>(m2 ? p0 : pl, m2 ? 0u : i1 / 4u);
-        q1n = fw_ld4w<NT>(p1, i1), q2n = fw_ld4w<NT>(p2, i1 & m2);
+        q0c = fw_ld4w<NT == 2>(p0, i0), q3c = fw_ld4w<NT == 2>(p3, i0 & m2), lfc = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : i0 / 4u);
+        q1c = fw_ld4w<NT == 2>(p1, i0), q2c = fw_ld4w<NT == 2>(p2, i0 & m2);
+        q0n = fw_ld4w<NT == 2>(p0, i1), q3n = fw_ld4w<NT == 2>(p3, i1 & m2), lfn = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : i1 / 4u);
+        q1n = fw_ld4w<NT == 2>(p1, i1), q2n = fw_ld4w<NT == 2>(p2, i1 & m2);
         const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
         if (tid < keys_len) s_keys[tid] = key0;
         for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
@@ -1939,9 +1946,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         for (int r = 0; r < YR; r++) {
             const uint32_t s = sbase + r * BLK + tid;
             const uint32_t in_ = (sbase + (uint32_t)min(r + 2, YR - 1) * BLK + tid) * 16u;  // two rounds ahead (the last re-read)
-            const float4 q0f = fw_ld4w<NT>(p0, in_), q3f = fw_ld4w<NT>(p3, in_ & m2);
-            const float lff = fw_ld1w<NT>(m2 ? p0 : pl, m2 ? 0u : in_ / 4u);
-            const float4 q1f = fw_ld4w<NT>(p1, in_), q2f = fw_ld4w<NT>(p2, in_ & m2);
+            const float4 q0f = fw_ld4w<NT == 2>(p0, in_), q3f = fw_ld4w<NT == 2>(p3, in_ & m2);
+            const float lff = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : in_ / 4u);
+            const float4 q1f = fw_ld4w<NT == 2>(p1, in_), q2f = fw_ld4w<NT == 2>(p2, in_ & m2);
             if (nospin) q3c = make_float4(0.0f, 0.0f, 0.0f, lfc);
             uint32_t yi = s - b;  // index within the young part
             if (s < b) yi += C;
@@ -1952,7 +1959,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             const unsigned long long mi = (INST && inst != nullptr) ? __ballot(mine) : 0ull;
             float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(mi) * 4u : nullptr;
             if (mine) fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec);
-            if (INST) fw_range_inst_out(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
+            if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n, lfc = lfn;
             q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f, lfn = lff;
         }
@@ -2030,7 +2037,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
             fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec);
         }
-        if (INST) fw_range_inst_out(inst, inst_cap, s_inst_wave, rec, lane, mi, n_old_in + y_exist + kk, false);
+        if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, n_old_in + y_exist + kk, false);
         return;
     }
 
@@ -2059,11 +2066,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         const uint32_t d = min(base + r * BLK + tid, lim - 1u);
         uint32_t s = bm1 - d;  // in [0, 2 C)
         if (s >= C) s -= C;
-        q0[r] = fw_ld4w<NT>(p0, s * 16u);
-        q3[r] = fw_ld4w<NT>(p3, (s * 16u) & m2);
-        const float lf = fw_ld1w<NT>(m2 ? p0 : pl, m2 ? 0u : s * 4u);
-        q1[r] = fw_ld4w<NT>(p1, s * 16u);
-        q2[r] = fw_ld4w<NT>(p2, (s * 16u) & m2);
+        q0[r] = fw_ld4w<NT == 2>(p0, s * 16u);
+        q3[r] = fw_ld4w<NT == 2>(p3, (s * 16u) & m2);
+        const float lf = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : s * 4u);
+        q1[r] = fw_ld4w<NT == 2>(p1, s * 16u);
+        q2[r] = fw_ld4w<NT == 2>(p2, (s * 16u) & m2);
         if (nospin) q3[r] = make_float4(0.0f, 0.0f, 0.0f, lf);
     }
     const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
@@ -2125,7 +2132,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             if (s >= C) s -= C;
             fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], W, s, rec);
         }
-        if (INST) fw_range_inst_out(inst, inst_cap, s_inst_wave, rec, lane, m[r], n_old_in - 1u - od, true);
+        if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, m[r], n_old_in - 1u - od, true);
         if (!alive && valid && want_destroyed) {
             // destroyed record (core.rs:596-599): the clone with the age advanced, pose, colours and scale of the previous
             // frame.  The colour and scale planes of the slot hold what the previous update computed from the age that was
@@ -2974,14 +2981,18 @@ hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArg
 }
 
 hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifoArgs &a, const FwInlineOps &inl,
-                                 uint32_t total_tiles, bool nt, hipEvent_t e0, hipEvent_t e1) {
+                                 uint32_t total_tiles, int nt, hipEvent_t e0, hipEvent_t e1) {
     if (!total_tiles || !a.n_segs) return hipErrorInvalidValue;
     const dim3 grid(total_tiles), block(FW_BLOCK);
-    if (nt) {  // non-temporal form (fw_ld4w): the generic write mask only -- at HBM speed the compile-time one buys nothing
-        if (a.any_inst)
-            FW_LAUNCH_T((fw_k_update_fifo<true, -1, true>), grid, block, s, e0, e1, g, a, inl);
+    if (nt) {  // non-temporal forms (fw_ld4w): the generic write mask only -- beyond the Infinity Cache the compile-time one buys nothing
+        if (a.any_inst && nt == 2)
+            FW_LAUNCH_T((fw_k_update_fifo<true, -1, 2>), grid, block, s, e0, e1, g, a, inl);
+        else if (a.any_inst)
+            FW_LAUNCH_T((fw_k_update_fifo<true, -1, 1>), grid, block, s, e0, e1, g, a, inl);
+        else if (nt == 2)
+            FW_LAUNCH_T((fw_k_update_fifo<false, -1, 2>), grid, block, s, e0, e1, g, a, inl);
         else
-            FW_LAUNCH_T((fw_k_update_fifo<false, -1, true>), grid, block, s, e0, e1, g, a, inl);
+            FW_LAUNCH_T((fw_k_update_fifo<false, -1, 1>), grid, block, s, e0, e1, g, a, inl);
         return hipGetLastError();
     }
 #define FW_FIFO_CASE(wm)                                                                   \
@@ -3004,7 +3015,7 @@ hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifo
     return hipGetLastError();
 }
 
-template <bool NT>
+template <int NT>
 static void fw_launch_update_range_t(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin, hipEvent_t e0,
                                      hipEvent_t e1) {
     const dim3 grid(a.total_tiles), block(FW_BLOCK);
@@ -3020,11 +3031,12 @@ static void fw_launch_update_range_t(hipStream_t s, const FwGlobals &g, const Fw
     }
 }
 
-hipError_t fw_launch_update_range(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin, bool nt,
+hipError_t fw_launch_update_range(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin, int nt,
                                   hipEvent_t e0, hipEvent_t e1) {
     if (!a.total_tiles) return hipErrorInvalidValue;
-    if (nt) fw_launch_update_range_t<true>(s, g, a, all_nospin, e0, e1);
-    else fw_launch_update_range_t<false>(s, g, a, all_nospin, e0, e1);
+    if (nt == 2) fw_launch_update_range_t<2>(s, g, a, all_nospin, e0, e1);
+    else if (nt == 1) fw_launch_update_range_t<1>(s, g, a, all_nospin, e0, e1);
+    else fw_launch_update_range_t<0>(s, g, a, all_nospin, e0, e1);
     return hipGetLastError();
 }
 

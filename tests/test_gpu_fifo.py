@@ -357,14 +357,16 @@ def test_ring_launches_switch_between_the_side_stream_and_the_main_stream(system
 @pytest.mark.parametrize("case", [test_ring_wraps_many_times_bit_exact, test_irregular_dt_needs_no_forecast, test_growth_while_wrapped,
                                   test_instances_destroyed_and_aabb_on_a_wrapped_ring, test_nested_spawner_on_rings_bit_exact,
                                   test_nested_rings_with_attached_instances_and_idle_frames], ids=lambda f: f.__name__[5:])
-def test_non_temporal_form_of_the_kernel(fw_path, monkeypatch, case):
-    """a ring launch that streams more than fw_ctx::nt_bytes (several times the Infinity Cache) runs the kernel's
-    non-temporal instantiation (fw_ld4w<NT>): the same results, bit for bit -- forced here at every size"""
+@pytest.mark.parametrize("knob", ["FW_NT_MB", "FW_NT_WO_MB"])
+def test_non_temporal_form_of_the_kernel(fw_path, monkeypatch, case, knob):
+    """a ring launch that streams more than fw_ctx::nt_wo_bytes / nt_bytes (no longer fits the Infinity Cache / several times
+    its size) runs a non-temporal instantiation of the kernel (fw_ld4w<NT>: the write-only planes / every plane access): the
+    same results, bit for bit -- forced here at every size"""
     from bevy_firework_amd.system import ParticleSystem
 
     if fw_path == "general":
         pytest.skip("the compacting path has no non-temporal form")
-    monkeypatch.setenv("FW_NT_MB", "0")
+    monkeypatch.setenv(knob, "0")
     with ParticleSystem(device=0, seed=SEED) as nt_system:  # (the knob is read when the context is created)
         nt_system.path = fw_path
         case(nt_system)

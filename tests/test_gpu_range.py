@@ -289,11 +289,13 @@ def test_windowed_instance_buffer_keeps_the_ring(system):
 @pytest.mark.parametrize("case", [test_small_ring_wraps_many_times_bit_exact, test_irregular_dt_zero_steps_and_spinning_particles,
                                   test_growth_while_wrapped_and_bursts, test_many_segments_in_one_launch_with_churn,
                                   test_windowed_instance_buffer_keeps_the_ring], ids=lambda f: f.__name__[5:])
-def test_non_temporal_form_of_the_kernel(system, monkeypatch, case):
-    """a launch that streams more than fw_ctx::nt_bytes (several times the Infinity Cache) runs the kernel's non-temporal
-    instantiation (fw_ld4w<NT>): the same results, bit for bit -- forced here at every size"""
+@pytest.mark.parametrize("knob", ["FW_NT_MB", "FW_NT_WO_MB"])
+def test_non_temporal_form_of_the_kernel(system, monkeypatch, case, knob):
+    """a launch that streams more than fw_ctx::nt_wo_bytes / nt_bytes (no longer fits the Infinity Cache / several times its
+    size) runs a non-temporal instantiation of the kernel (fw_ld4w<NT>: the write-only planes / every plane access): the same
+    results, bit for bit -- forced here at every size"""
     from bevy_firework_amd.system import ParticleSystem
 
-    monkeypatch.setenv("FW_NT_MB", "0")
+    monkeypatch.setenv(knob, "0")
     with ParticleSystem(device=0, seed=SEED) as nt_system:  # (the knob is read when the context is created)
         case(nt_system)
