@@ -14,6 +14,40 @@ __device__ __forceinline__ float work(float x, int K) {
 
 // RD: bit i = read plane i (0..3);  WR: bit i = write plane i (0..3), bit 4 = Q5, bit 5 = Q6, bit 6 = S4.
 // in == out for in-place; shift: out slot j reads in slot j + shift (aligned stores, misaligned loads)
+// the in-place shapes again with non-temporal accesses: NT 1 = the planes nobody reads back (Q5 Q6 S4), 2 = everything
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int RD, int WR, int NT>
+__global__ __launch_bounds__(256) void k_upd_nt(char* __restrict__ buf, uint32_t n, uint32_t C, int K) {
+    constexpr int R = 4;
+    const uint32_t base = blockIdx.x * 256 * R;
+    f4v q[4][R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = base + r * 256 + threadIdx.x;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            q[p][r] = f4v{1.f, 2.f, 3.f, 4.f};
+            if ((RD >> p & 1) && i < n) {
+                const f4v* a = (const f4v*)(buf + (size_t)16 * p * C) + i;
+                q[p][r] = NT == 2 ? __builtin_nontemporal_load(a) : *a;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = base + r * 256 + threadIdx.x;
+        if (i < n) {
+            f4v a = q[0][r], b = q[1][r], c = q[2][r], d = q[3][r];
+            a.x = work(a.x + b.x, K);
+            f4v e = {a.x + b.x, a.y * c.y, d.z, a.w}, f = {b.w, c.x, d.y, e.x};
+#define ST(cond, off, val, nt) if (cond) { f4v* o = (f4v*)(buf + (size_t)(off) * C) + i; if (nt) __builtin_nontemporal_store(val, o); else *o = val; }
+            ST(WR & 1, 0, a, NT == 2) ST(WR & 2, 16, b, NT == 2) ST(WR & 4, 32, c, NT == 2) ST(WR & 8, 48, d, NT == 2)
+            ST(WR & 16, 64, e, NT >= 1) ST(WR & 32, 80, f, NT >= 1)
+            if (WR & 64) { float* o = (float*)(buf + (size_t)96 * C) + i; if (NT >= 1) __builtin_nontemporal_store(e.y, o); else *o = e.y; }
+        }
+    }
+}
+
 template <int R, int RD, int WR, bool STSHIFT = false>
 __global__ __launch_bounds__(256) void k_upd(const char* __restrict__ in, char* __restrict__ out, uint32_t n, uint32_t C, uint32_t shift, int K) {
     const uint32_t base = blockIdx.x * 256 * R;
@@ -102,6 +136,15 @@ int main() {
         const dim3 g((n + 1023) / 1024), b(256);
         for (int K : {0, 150}) {
             double t;
+#define RUN_NT(RD, WR, NT, bytes, tag) \
+            t = timeit([&](int i) { hipLaunchKernelGGL((k_upd_nt<RD, WR, NT>), g, b, 0, 0, p0, n, C, K); }, 50); \
+            printf("n=%8u K=%3d %-44s: %8.2f us  %7.1f GB/s moved\n", n, K, tag, t * 1e6, (double)(bytes) * n / t / 1e9);
+            RUN_NT(15, 127, 0, 164, "ONE buffer in place r4 w7 (164 B)")
+            RUN_NT(15, 127, 1, 164, "  ... Q5 Q6 S4 non-temporal")
+            RUN_NT(15, 127, 2, 164, "  ... everything non-temporal")
+            RUN_NT(3, 115, 0, 100, "ONE buffer in place r Q0 Q1 w Q0 Q1 Q5 Q6 S4 (100 B)")
+            RUN_NT(3, 115, 1, 100, "  ... Q5 Q6 S4 non-temporal")
+            RUN_NT(3, 115, 2, 100, "  ... everything non-temporal")
 #define RUN(RD, WR, inplace, shift, bytes, tag) \
             t = timeit([&](int i) { char* a = (i & 1) ? p1 : p0; char* o = (inplace) ? a : ((i & 1) ? p0 : p1); \
                 hipLaunchKernelGGL((k_upd<4, RD, WR>), g, b, 0, 0, a, o, n, C, shift, K); }, 50); \
