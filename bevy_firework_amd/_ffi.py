@@ -255,6 +255,7 @@ SYMBOLS = [
     ("fw_debug_read_timestamps", C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("fw_debug_read_timestamps2", C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("fw_debug_read_launches", C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
+    ("fw_debug_read_range_timestamps", C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("fw_debug_update_path", C.c_int, [_P, C.c_int, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("fw_compute_emission_count", C.c_uint64,
      [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]),

@@ -191,6 +191,7 @@ struct alignas(64) SegHost {
     std::deque<YCohort> ycoh;  // the young cohorts, oldest first
     uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
     uint32_t r_low[3] = {0, 0, 0};               // frames in a row a role's need has been far below what is provided
+    uint32_t r_status_base = 0;                  // first look-back word of its OLD workgroups in the current table
     bool ring() const { return fifo || range; }  // one buffer, particle 0 not in slot 0
     // FW_TYPE_DERIVED (fw_device.h): an instance buffer is attached -- its records carry scale and colours, the planes S4 / Q5 /
     // Q6 are not stored by the update; every reader evaluates them from age / lifetime / initial_scale
@@ -406,6 +407,9 @@ struct fw_ctx {
     // FW_NT_WO_MB=n: 0 = always)
     uint64_t nt_bytes = 768ull << 20;  // (crossover measured at 0.65-0.85 GB for both kernels: profiles/r03/nt_sweep.txt)
     uint64_t nt_wo_bytes = 200ull << 20;
+    unsigned long long *d_rts = nullptr;  // FW_DEBUG & 8: per-workgroup timestamps of the last range launch
+    uint32_t range_old_ahead = 0;  // FW_RANGE_OLD_AHEAD=n: the OLD workgroups of a segment come n segments before its other ones
+    std::vector<uint32_t> range_scratch;
     uint32_t range_old_extra = 0;  // FW_RANGE_OLD_EXTRA=n: n more (idle) OLD workgroups per segment -- what an idle one costs
     size_t rparam_bytes = 0;
     uint64_t rslot_frame[kParamRing] = {};    // frame that last used the slot (+1; 0 = free)
@@ -658,6 +662,12 @@ fw_status ensure_range_arrays(fw_ctx *ctx) {
         FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_rdesc, ncap * sizeof(FwRangeDesc), hipHostMallocDefault));
         FW_HIP(ctx, hipMalloc((void **)&ctx->d_rstatus, ncap * sizeof(unsigned long long)));
         FW_HIP(ctx, fw_memset_done(ctx->d_rstatus, 0, ncap * sizeof(unsigned long long)));
+        if (ctx->dbg & 8u) {  // per-workgroup timestamps of the last range launch (tools/range_timeline.py)
+            if (ctx->d_rts) hipFree(ctx->d_rts);
+            ctx->d_rts = nullptr;
+            FW_HIP(ctx, hipMalloc((void **)&ctx->d_rts, ncap * 8 * sizeof(unsigned long long)));
+            FW_HIP(ctx, fw_memset_done(ctx->d_rts, 0, ncap * 8 * sizeof(unsigned long long)));
+        }
         ctx->rdesc_cap = ncap;
         ctx->r_force = true, ctx->rtab_pending = false;
     }
@@ -1622,6 +1632,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_RANGE_DEVREC")) ctx->range_devrec = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_FOLD")) ctx->range_fold = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_OLD_EXTRA")) ctx->range_old_extra = (uint32_t)atoi(m);
+    if (const char *m = getenv("FW_RANGE_OLD_AHEAD")) ctx->range_old_ahead = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_NT_WO_MB")) ctx->nt_wo_bytes = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_RANGE_SPREAD_NEW")) ctx->range_spread_new = atoi(m) != 0;
@@ -1701,6 +1712,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     if (ctx->d_rdesc) hipFree(ctx->d_rdesc);
     if (ctx->h_rdesc) hipHostFree(ctx->h_rdesc);
     if (ctx->d_rstatus) hipFree(ctx->d_rstatus);
+    if (ctx->d_rts) hipFree(ctx->d_rts);
     for (int i = 0; i < kParamRing; i++) {
         if (ctx->h_rparam[i]) hipHostFree(ctx->h_rparam[i]);
         if (ctx->d_rparam[i]) hipFree(ctx->d_rparam[i]);
@@ -2644,36 +2656,55 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             // so that a context with ONE large segment would not start with a front of old tiles -- was measured: 381 -> 384 us
             // at 1 x 16M, 96 -> 100 us at 512 x 8192: no.)  Look-back words are indexed per segment (old_first + k).
             size_t t = 0;
-            uint32_t status_base = 0;
-            for (uint32_t si = 0; si < n_seg; si++) {
+            bool ok = true;
+            auto put = [&](uint32_t si, uint32_t role, uint32_t k) {
+                if (t >= ctx->rdesc_cap) {
+                    ok = false;
+                    return;
+                }
                 const SegHost &S = ctx->segs[si];
-                if (!S.in_use || !S.range) continue;
-                auto put = [&](uint32_t role, uint32_t k) -> bool {
-                    if (t >= ctx->rdesc_cap) return false;
-                    FwRangeDesc &D = ctx->h_rdesc[t++];
-                    D.seg = si, D.role_k = (role << 30) | k, D.old_first = status_base;
-                    D.type_idx = S.type_idx | (S.nospin ? FW_TYPE_IDX_NOSPIN : 0u);
-                    D.keys_off = S.keys_off, D.keys_len = S.keys_len, D.n_old = S.r_old, D.pad = 0;
-                    return true;
-                };
-                bool ok = true;
-                for (uint32_t k = 0; k < S.r_old && ok; k++) ok = put(FW_RANGE_OLD, k);
+                FwRangeDesc &D = ctx->h_rdesc[t++];
+                D.seg = si, D.role_k = (role << 30) | k, D.old_first = S.r_status_base;
+                D.type_idx = S.type_idx | (S.nospin ? FW_TYPE_IDX_NOSPIN : 0u);
+                D.keys_off = S.keys_off, D.keys_len = S.keys_len, D.n_old = S.r_old, D.pad = 0;
+            };
+            auto put_old = [&](uint32_t si) {
+                for (uint32_t k = 0; k < ctx->segs[si].r_old && ok; k++) put(si, FW_RANGE_OLD, k);
+            };
+            auto put_rest = [&](uint32_t si) {
+                const SegHost &S = ctx->segs[si];
                 if (!ctx->range_spread_new || S.r_new <= 8) {
-                    for (uint32_t k = 0; k < S.r_new && ok; k++) ok = put(FW_RANGE_NEW, k);
-                    for (uint32_t k = 0; k < S.r_young && ok; k++) ok = put(FW_RANGE_YOUNG, k);
+                    for (uint32_t k = 0; k < S.r_new && ok; k++) put(si, FW_RANGE_NEW, k);
+                    for (uint32_t k = 0; k < S.r_young && ok; k++) put(si, FW_RANGE_YOUNG, k);
                 } else {  // many NEW workgroups (one large segment): spread over the first three quarters of the YOUNG ones
                     const uint64_t span = (uint64_t)S.r_new + (uint64_t)S.r_young * 3 / 4;
                     uint32_t kn = 0, ky = 0;
                     for (uint64_t i = 0; i < span && ok; i++) {
-                        if (kn < S.r_new && (uint64_t)kn * span / S.r_new <= i) ok = put(FW_RANGE_NEW, kn++);
-                        else if (ky < S.r_young) ok = put(FW_RANGE_YOUNG, ky++);
+                        if (kn < S.r_new && (uint64_t)kn * span / S.r_new <= i) put(si, FW_RANGE_NEW, kn++);
+                        else if (ky < S.r_young) put(si, FW_RANGE_YOUNG, ky++);
                     }
-                    while (kn < S.r_new && ok) ok = put(FW_RANGE_NEW, kn++);
-                    while (ky < S.r_young && ok) ok = put(FW_RANGE_YOUNG, ky++);
+                    while (kn < S.r_new && ok) put(si, FW_RANGE_NEW, kn++);
+                    while (ky < S.r_young && ok) put(si, FW_RANGE_YOUNG, ky++);
                 }
-                if (!ok) return fail(ctx, FW_EHIP, "internal error: range table overflow");
-                status_base += S.r_old;
+            };
+            auto &rs = ctx->range_scratch;  // the range segments, in segment order
+            rs.clear();
+            uint32_t status_base = 0;
+            for (uint32_t si = 0; si < n_seg; si++) {
+                SegHost &S = ctx->segs[si];
+                if (!S.in_use || !S.range) continue;
+                S.r_status_base = status_base, status_base += S.r_old;
+                rs.push_back(si);
             }
+            // The OLD workgroups of a segment are dispatched `ahead` segments before its other ones: an old tile lives 2-3x
+            // as long as a young one (it waits for its predecessor's count), and those of the last segments used to be the
+            // last workgroups of the launch to finish (profiles/r03/range_timeline.txt)
+            const size_t nr = rs.size(), ahead = std::min<size_t>(nr, ctx->range_old_ahead);
+            for (size_t i = 0; i < nr + ahead && ok; i++) {
+                if (i < nr) put_old(rs[i]);
+                if (i >= ahead) put_rest(rs[i - ahead]);
+            }
+            if (!ok) return fail(ctx, FW_EHIP, "internal error: range table overflow");
             ctx->r_total = (uint32_t)t;
             if (t) FW_HIP(ctx, hipMemcpyAsync(ctx->d_rdesc, ctx->h_rdesc, t * sizeof(FwRangeDesc), hipMemcpyHostToDevice, ctx->stream));
             FW_HIP(ctx, hipEventRecord(ctx->ev_rtab, ctx->stream));
@@ -2700,6 +2731,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             ra.any_inst = range_inst ? 1u : 0u;
             ra.done_tag = a.done_tag, ra.done_value = a.done_value;
             ra.host_counts = a.host_counts, ra.live_out = a.live_out, ra.live_next = a.live_next;
+            ra.ts = ctx->d_rts;
             hipEvent_t e0, e1;
             next_timing_pair(&e0, &e1);
             FW_HIP(ctx, fw_launch_update_range(ctx->stream, ctx->g, ra, all_nospin, r_bytes > ctx->nt_bytes ? 2 : r_bytes > ctx->nt_wo_bytes ? 1 : 0, e0, e1));
@@ -3231,6 +3263,16 @@ fw_status fw_debug_read_timestamps2(fw_ctx *ctx, unsigned long long *out, unsign
     if (n && prev)
         FW_HIP(ctx, hipMemcpy(prev, ctx->g.dbg_ts + 32768 + (last ^ 1u) * stride, n * 8 * sizeof(unsigned long long),
                               hipMemcpyDeviceToHost));
+    return FW_OK;
+}
+// ... and of the last range-ring launch: 8 words per workgroup {start, 0, 0, end of wave 0, role_k, segment, 0, 0}
+fw_status fw_debug_read_range_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_t max_tiles, uint64_t *n_tiles) {
+    if (!ctx || !ctx->d_rts) return FW_EINVAL;
+    fw_status st = sync(ctx);
+    if (st) return st;
+    const uint64_t n = std::min<uint64_t>(max_tiles, ctx->r_total);
+    if (n_tiles) *n_tiles = n;
+    if (n && out) FW_HIP(ctx, hipMemcpy(out, ctx->d_rts, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return FW_OK;
 }
 // {~earliest workgroup start [64], latest workgroup end [64]} of the last 256 update launches (slot = epoch & 255);

@@ -194,6 +194,7 @@ struct FwRangeArgs {
     unsigned long long done_value;
     unsigned long long *host_counts;
     unsigned long long *live_out, *live_next;
+    unsigned long long *ts;         // FW_DEBUG & 8: 8 words per workgroup {start, 0, 0, end of wave 0, role_k, seg, 0, 0} (profiling)
 };
 #define FW_RANGE_MAX_CAPACITY 0x10000000u  // slots are addressed as 32-bit byte offsets into a float4 plane
 

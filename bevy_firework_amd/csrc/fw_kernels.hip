@@ -99,6 +99,12 @@ __device__ __forceinline__ float4 fw_ld4w(const char *win, uint32_t byte_off) {
     else v = *p;
     return make_float4(v.x, v.y, v.z, v.w);
 }
+// (a plane no particle type of the launch has -- rotation / angular velocity in an all-FW_TYPE_NOSPIN launch: not even a dummy load)
+template <bool SKIP, bool NT>
+__device__ __forceinline__ float4 fw_ld4w_opt(const char *win, uint32_t byte_off) {
+    if constexpr (SKIP) return make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    else return fw_ld4w<NT>(win, byte_off);
+}
 template <bool NT = false>
 __device__ __forceinline__ void fw_st4w(char *win, uint32_t byte_off, float4 v) {
     const fw_f4 x = {v.x, v.y, v.z, v.w};
@@ -1894,6 +1900,21 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const FwRangeDesc &D = a.desc[blockIdx.x];  // block-uniform: scalar loads
     const uint32_t seg = D.seg, role = D.role_k >> 30, k = D.role_k & 0x3FFFFFFFu;
+#ifdef FW_RANGE_SLEEP  // (experiment: what a microsecond more of dead time per workgroup costs)
+    __builtin_amdgcn_s_sleep(FW_RANGE_SLEEP);
+#endif
+#ifdef FW_RANGE_STAMP  // (an instrumented build only -- make timeline: the four scalar stores and the branch cost 6 % of configs[4]'s share even unused)
+    struct Stamp {  // FW_DEBUG & 8 (tools/range_timeline.py): when the workgroup started and when its wave 0 left, by whichever return
+        unsigned long long *p;
+        __device__ ~Stamp() {
+            if (p && threadIdx.x == 0) p[3] = __builtin_amdgcn_s_memrealtime();
+        }
+    } stamp{(a.dbg & 8u) && a.ts ? a.ts + (size_t)blockIdx.x * 8u : nullptr};
+    if (stamp.p && tid == 0) stamp.p[0] = __builtin_amdgcn_s_memrealtime(), stamp.p[4] = D.role_k, stamp.p[5] = seg;
+#define FW_STAMP(i, dep) do { if (stamp.p && tid == 0) stamp.p[i] = __builtin_amdgcn_s_memrealtime() + ((unsigned long long)(dep) & 0ull); } while (0)
+#else
+#define FW_STAMP(i, dep) do { } while (0)
+#endif
     const bool nospin = ALLNOSPIN || (D.type_idx & FW_TYPE_IDX_NOSPIN) != 0u;
     const uint32_t m2 = nospin ? 0u : 0xFFFFFFFFu;
     const uint32_t keys_off = D.keys_off, keys_len = D.keys_len;
@@ -1929,26 +1950,29 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         uint32_t pt = b / YT + k;
         if (pt >= ring_tiles) pt -= ring_tiles;
         const uint32_t sbase = pt * YT;
+        FW_STAMP(1, sbase);  // the descriptor, the pinned record and the segment record have arrived
         float4 q0c, q1c, q2c, q3c, q0n, q1n, q2n, q3n;
         float lfc, lfn;
         const uint32_t i0 = (sbase + tid) * 16u, i1 = (sbase + (uint32_t)min(1, YR - 1) * BLK + tid) * 16u;
-        q0c = fw_ld4w<NT == 2>(p0, i0), q3c = fw_ld4w<NT == 2>(p3, i0 & m2), lfc = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : i0 / 4u);
-        q1c = fw_ld4w<NT == 2>(p1, i0), q2c = fw_ld4w<NT == 2>(p2, i0 & m2);
-        q0n = fw_ld4w<NT == 2>(p0, i1), q3n = fw_ld4w<NT == 2>(p3, i1 & m2), lfn = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : i1 / 4u);
-        q1n = fw_ld4w<NT == 2>(p1, i1), q2n = fw_ld4w<NT == 2>(p2, i1 & m2);
+        q0c = fw_ld4w<NT == 2>(p0, i0), q3c = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p3, i0 & m2), lfc = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : i0 / 4u);
+        q1c = fw_ld4w<NT == 2>(p1, i0), q2c = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p2, i0 & m2);
+        q0n = fw_ld4w<NT == 2>(p0, i1), q3n = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p3, i1 & m2), lfn = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : i1 / 4u);
+        q1n = fw_ld4w<NT == 2>(p1, i1), q2n = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p2, i1 & m2);
         const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
         if (tid < keys_len) s_keys[tid] = key0;
         for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
         __syncthreads();
+        FW_STAMP(2, T.flags);  // type record + keys in LDS
         const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
         bool bad = false;
+        FW_STAMP(6, __float_as_uint(q0c.w) | __float_as_uint(q1c.w));  // the first round's particles have arrived
 #pragma unroll
         for (int r = 0; r < YR; r++) {
             const uint32_t s = sbase + r * BLK + tid;
             const uint32_t in_ = (sbase + (uint32_t)min(r + 2, YR - 1) * BLK + tid) * 16u;  // two rounds ahead (the last re-read)
-            const float4 q0f = fw_ld4w<NT == 2>(p0, in_), q3f = fw_ld4w<NT == 2>(p3, in_ & m2);
+            const float4 q0f = fw_ld4w<NT == 2>(p0, in_), q3f = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p3, in_ & m2);
             const float lff = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : in_ / 4u);
-            const float4 q1f = fw_ld4w<NT == 2>(p1, in_), q2f = fw_ld4w<NT == 2>(p2, in_ & m2);
+            const float4 q1f = fw_ld4w<NT == 2>(p1, in_), q2f = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p2, in_ & m2);
             if (nospin) q3c = make_float4(0.0f, 0.0f, 0.0f, lfc);
             uint32_t yi = s - b;  // index within the young part
             if (s < b) yi += C;
@@ -2067,10 +2091,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         uint32_t s = bm1 - d;  // in [0, 2 C)
         if (s >= C) s -= C;
         q0[r] = fw_ld4w<NT == 2>(p0, s * 16u);
-        q3[r] = fw_ld4w<NT == 2>(p3, (s * 16u) & m2);
+        q3[r] = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p3, (s * 16u) & m2);
         const float lf = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : s * 4u);
         q1[r] = fw_ld4w<NT == 2>(p1, s * 16u);
-        q2[r] = fw_ld4w<NT == 2>(p2, (s * 16u) & m2);
+        q2[r] = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p2, (s * 16u) & m2);
         if (nospin) q3[r] = make_float4(0.0f, 0.0f, 0.0f, lf);
     }
     const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];

@@ -37,6 +37,9 @@ fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_
 fw_status fw_debug_read_timestamps2(fw_ctx *ctx, unsigned long long *out, unsigned long long *prev, uint64_t max_tiles,
                                     uint64_t *n_tiles);
 fw_status fw_debug_read_launches(fw_ctx *ctx, unsigned long long *out32768, uint32_t *epoch);
+/* ... and of the last range-ring launch (tools/range_timeline.py): 8 words per workgroup {start, 0, 0, end of its wave 0,
+ * role << 30 | k, segment, 0, 0} */
+fw_status fw_debug_read_range_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_t max_tiles, uint64_t *n_tiles);
 /* which update path a particle type is on (1 = FIFO ring updated in place, 2 = range ring: young part in place, old part
  * compacted in place, 0 = general compacting path), the bytes one
  * update of a live particle moves on it, and how many of those are algorithmic (bench.py's roofline accounting) */
