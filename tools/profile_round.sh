@@ -36,6 +36,8 @@ FW_HOST_PROF=1 timeout 300 python tools/small_emitters.py >> $OUT/small_emitters
 timeout 900 tools/range_ab.sh "" "FW_RANGE=0" "FW_RANGE_DEVREC=1" "FW_RANGE_FOLD=1" > $OUT/range_ab.txt 2>&1
 (timeout 600 python tools/range_sweep.py; echo "FW_RANGE=0:"; FW_RANGE=0 timeout 600 python tools/range_sweep.py) > $OUT/range_sweep.txt 2>&1
 timeout 1200 tools/prof_configs.sh $TAG > /dev/null 2>&1; cp gpurun_out/prof_configs_$TAG/*_kernel_stats.csv gpurun_out/prof_configs_$TAG/*_trace_summary.txt gpurun_out/prof_configs_$TAG/*_bench.json $OUT/ 2>/dev/null
+timeout 600 python tools/nt_sweep.py > $OUT/nt_sweep.txt 2>&1   # plain against fully non-temporal ring kernels over 0.2-2.6 GB
+[ -f bevy_firework_amd/csrc/libfirework_hip_timeline.so ] && (timeout 300 python tools/range_timeline.py; FW_TL_EMITTERS=256x65536 timeout 300 python tools/range_timeline.py) 2>&1 | cut -c1-2500 > $OUT/range_timeline_run.txt
 (timeout 300 python tools/bench_next_rows.py; echo "FW_DERIVED=0 (scale / colour planes kept next to the records):"; FW_DERIVED=0 timeout 300 python tools/bench_next_rows.py) > $OUT/next_rows.txt 2>&1
 # 7. configs[3] (Nested): rocprofv3 kernel stats of the steady state
 cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/nested -o nested --output-format csv -- python $R/tools/nested_prof.py > $R/$OUT/nested_step.txt 2>/dev/null; cd $R
