@@ -406,7 +406,10 @@ struct fw_ctx {
     // colours) non-temporally, so that the cache keeps what the next frame reads (fw_kernels.hip: fw_ld4w; knobs FW_NT_MB=n,
     // FW_NT_WO_MB=n: 0 = always)
     uint64_t nt_bytes = 768ull << 20;  // (crossover measured at 0.65-0.85 GB for both kernels: profiles/r03/nt_sweep.txt)
-    uint64_t nt_wo_bytes = 200ull << 20;
+    // (the write-only form measured over 50-970 MB, profiles/r03/nt_sweep_wo.txt: range rings gain from the smallest size on
+    // (-1..4 % below 250 MB, -10..16 % at 320-425 MB); the FIFO kernel's non-temporal forms carry the generic write mask, which
+    // costs 1-2 % where everything fits the cache, and gain from ~300 MB on (-10..16 % at 480-650 MB))
+    uint64_t nt_wo_bytes = 280ull << 20, nt_wo_bytes_range = 64ull << 20;
     unsigned long long *d_rts = nullptr;  // FW_DEBUG & 8: per-workgroup timestamps of the last range launch
     uint32_t range_old_ahead = 0;  // FW_RANGE_OLD_AHEAD=n: the OLD workgroups of a segment come n segments before its other ones
     std::vector<uint32_t> range_scratch;
@@ -1634,7 +1637,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_RANGE_OLD_EXTRA")) ctx->range_old_extra = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_RANGE_OLD_AHEAD")) ctx->range_old_ahead = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;
-    if (const char *m = getenv("FW_NT_WO_MB")) ctx->nt_wo_bytes = (uint64_t)atoll(m) << 20;
+    if (const char *m = getenv("FW_NT_WO_MB")) ctx->nt_wo_bytes = ctx->nt_wo_bytes_range = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_RANGE_SPREAD_NEW")) ctx->range_spread_new = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
@@ -2734,7 +2737,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             ra.ts = ctx->d_rts;
             hipEvent_t e0, e1;
             next_timing_pair(&e0, &e1);
-            FW_HIP(ctx, fw_launch_update_range(ctx->stream, ctx->g, ra, all_nospin, r_bytes > ctx->nt_bytes ? 2 : r_bytes > ctx->nt_wo_bytes ? 1 : 0, e0, e1));
+            FW_HIP(ctx, fw_launch_update_range(ctx->stream, ctx->g, ra, all_nospin, r_bytes > ctx->nt_bytes ? 2 : r_bytes > ctx->nt_wo_bytes_range ? 1 : 0, e0, e1));
             ctx->rslot_frame[rslot] = ctx->frame + 1;
             range_launched = true;
         }
