@@ -191,6 +191,7 @@ struct alignas(64) SegHost {
     std::deque<YCohort> ycoh;  // the young cohorts, oldest first
     uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
     uint32_t r_low[3] = {0, 0, 0};               // frames in a row a role's need has been far below what is provided
+    uint32_t r_need[3] = {0, 0, 0};              // what each role needed in the latest frame (the table keeps more: fit())
     uint32_t r_status_base = 0;                  // first look-back word of its OLD workgroups in the current table
     bool ring() const { return fifo || range; }  // one buffer, particle 0 not in slot 0
     // FW_TYPE_DERIVED (fw_device.h): an instance buffer is attached -- its records carry scale and colours, the planes S4 / Q5 /
@@ -411,6 +412,7 @@ struct fw_ctx {
     // costs 1-2 % where everything fits the cache, and gain from ~300 MB on (-10..16 % at 480-650 MB))
     uint64_t nt_wo_bytes = 280ull << 20, nt_wo_bytes_range = 64ull << 20;
     unsigned long long *d_rts = nullptr;  // FW_DEBUG & 8: per-workgroup timestamps of the last range launch
+    bool range_idle_last = true;   // FW_RANGE_IDLE_LAST=0: provisioned-but-idle workgroups stay next to their segment's active ones
     uint32_t range_old_ahead = 0;  // FW_RANGE_OLD_AHEAD=n: the OLD workgroups of a segment come n segments before its other ones
     std::vector<uint32_t> range_scratch;
     uint32_t range_old_extra = 0;  // FW_RANGE_OLD_EXTRA=n: n more (idle) OLD workgroups per segment -- what an idle one costs
@@ -1636,6 +1638,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_RANGE_FOLD")) ctx->range_fold = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_OLD_EXTRA")) ctx->range_old_extra = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_RANGE_OLD_AHEAD")) ctx->range_old_ahead = (uint32_t)atoi(m);
+    if (const char *m = getenv("FW_RANGE_IDLE_LAST")) ctx->range_idle_last = atoi(m) != 0;
     if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_NT_WO_MB")) ctx->nt_wo_bytes = ctx->nt_wo_bytes_range = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_RANGE_SPREAD_NEW")) ctx->range_spread_new = atoi(m) != 0;
@@ -2640,6 +2643,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     low = 0;
                 }
             };
+            S.r_need[0] = need_old, S.r_need[1] = need_new, S.r_need[2] = need_young;
             fit(S.r_old, need_old, need_old >= 8 ? need_old / 4 : 1u, S.r_low[0]);
             fit(S.r_new, need_new, need_new ? (need_new >= 8 ? need_new / 8 : 1u) : 0u, S.r_low[1]);
             fit(S.r_young, need_young, need_young >= 16 ? need_young / 8 : 1u, S.r_low[2]);
@@ -2671,24 +2675,41 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 D.type_idx = S.type_idx | (S.nospin ? FW_TYPE_IDX_NOSPIN : 0u);
                 D.keys_off = S.keys_off, D.keys_len = S.keys_len, D.n_old = S.r_old, D.pad = 0;
             };
+            // Workgroups that are provisioned but probably idle -- the spares of every role, and the upper part of the OLD range
+            // (its bound counts everybody older than lifetime.min as alive) -- go to the END of the table, behind every
+            // segment's probably-active ones: an idle workgroup still holds a slot for ~2.5 us (descriptor, record, count),
+            // and there it does so while the launch drains and slots are free anyway.  An OLD tile stays behind the lower
+            // tiles of its segment, so the look-back order holds; a "probably idle" workgroup that does have work simply
+            // does it there.
+            auto main_old = [&](const SegHost &S) { return ctx->range_idle_last ? std::min(S.r_old, std::max(1u, (S.r_need[0] * 5u + 7u) / 8u)) : S.r_old; };
+            auto main_new = [&](const SegHost &S) { return ctx->range_idle_last ? std::min(S.r_new, S.r_need[1]) : S.r_new; };
+            auto main_young = [&](const SegHost &S) { return ctx->range_idle_last ? std::min(S.r_young, S.r_need[2]) : S.r_young; };
             auto put_old = [&](uint32_t si) {
-                for (uint32_t k = 0; k < ctx->segs[si].r_old && ok; k++) put(si, FW_RANGE_OLD, k);
+                const uint32_t n = main_old(ctx->segs[si]);
+                for (uint32_t k = 0; k < n && ok; k++) put(si, FW_RANGE_OLD, k);
             };
             auto put_rest = [&](uint32_t si) {
                 const SegHost &S = ctx->segs[si];
-                if (!ctx->range_spread_new || S.r_new <= 8) {
-                    for (uint32_t k = 0; k < S.r_new && ok; k++) put(si, FW_RANGE_NEW, k);
-                    for (uint32_t k = 0; k < S.r_young && ok; k++) put(si, FW_RANGE_YOUNG, k);
+                const uint32_t n_new = main_new(S), n_young = main_young(S);
+                if (!ctx->range_spread_new || n_new <= 8) {
+                    for (uint32_t k = 0; k < n_new && ok; k++) put(si, FW_RANGE_NEW, k);
+                    for (uint32_t k = 0; k < n_young && ok; k++) put(si, FW_RANGE_YOUNG, k);
                 } else {  // many NEW workgroups (one large segment): spread over the first three quarters of the YOUNG ones
-                    const uint64_t span = (uint64_t)S.r_new + (uint64_t)S.r_young * 3 / 4;
+                    const uint64_t span = (uint64_t)n_new + (uint64_t)n_young * 3 / 4;
                     uint32_t kn = 0, ky = 0;
                     for (uint64_t i = 0; i < span && ok; i++) {
-                        if (kn < S.r_new && (uint64_t)kn * span / S.r_new <= i) put(si, FW_RANGE_NEW, kn++);
-                        else if (ky < S.r_young) put(si, FW_RANGE_YOUNG, ky++);
+                        if (kn < n_new && (uint64_t)kn * span / n_new <= i) put(si, FW_RANGE_NEW, kn++);
+                        else if (ky < n_young) put(si, FW_RANGE_YOUNG, ky++);
                     }
-                    while (kn < S.r_new && ok) put(si, FW_RANGE_NEW, kn++);
-                    while (ky < S.r_young && ok) put(si, FW_RANGE_YOUNG, ky++);
+                    while (kn < n_new && ok) put(si, FW_RANGE_NEW, kn++);
+                    while (ky < n_young && ok) put(si, FW_RANGE_YOUNG, ky++);
                 }
+            };
+            auto put_tail = [&](uint32_t si) {
+                const SegHost &S = ctx->segs[si];
+                for (uint32_t k = main_old(S); k < S.r_old && ok; k++) put(si, FW_RANGE_OLD, k);
+                for (uint32_t k = main_new(S); k < S.r_new && ok; k++) put(si, FW_RANGE_NEW, k);
+                for (uint32_t k = main_young(S); k < S.r_young && ok; k++) put(si, FW_RANGE_YOUNG, k);
             };
             auto &rs = ctx->range_scratch;  // the range segments, in segment order
             rs.clear();
@@ -2699,14 +2720,13 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 S.r_status_base = status_base, status_base += S.r_old;
                 rs.push_back(si);
             }
-            // The OLD workgroups of a segment are dispatched `ahead` segments before its other ones: an old tile lives 2-3x
-            // as long as a young one (it waits for its predecessor's count), and those of the last segments used to be the
-            // last workgroups of the launch to finish (profiles/r03/range_timeline.txt)
+            // (FW_RANGE_OLD_AHEAD=n: the OLD workgroups of a segment n segments before its other ones -- measured, no gain)
             const size_t nr = rs.size(), ahead = std::min<size_t>(nr, ctx->range_old_ahead);
             for (size_t i = 0; i < nr + ahead && ok; i++) {
                 if (i < nr) put_old(rs[i]);
                 if (i >= ahead) put_rest(rs[i - ahead]);
             }
+            for (size_t i = 0; i < nr && ok; i++) put_tail(rs[i]);
             if (!ok) return fail(ctx, FW_EHIP, "internal error: range table overflow");
             ctx->r_total = (uint32_t)t;
             if (t) FW_HIP(ctx, hipMemcpyAsync(ctx->d_rdesc, ctx->h_rdesc, t * sizeof(FwRangeDesc), hipMemcpyHostToDevice, ctx->stream));
