@@ -14,6 +14,7 @@ from parity import Pair
 pytestmark = pytest.mark.gpu
 SEED = 0x5EED
 EXTRA = int(os.environ.get("FW_FUZZ_EXTRA", "0"))  # more random cases than the committed suite runs (spare GPU time)
+OFF = int(os.environ.get("FW_FUZZ_OFFSET", "0"))  # ... and other ones: the case numbers (= the seeds) start here
 
 
 def _curve(rng):
@@ -135,7 +136,7 @@ def _random_spawner_case(case, seed_base, const_p, sizes):
         sizes[case] = pair.gpu.counts()
 
 
-@pytest.mark.parametrize("case", list(range(40 + EXTRA)) + [339])  # 339: OnDemand parents outgrow the derived capacity of their Nested children
+@pytest.mark.parametrize("case", list(range(OFF, OFF + 40 + EXTRA)) + [339])  # 339: OnDemand parents outgrow the derived capacity of their Nested children
 def test_random_spawner_matches_the_oracle(case):
     _random_spawner_case(case, 1000, 0.2, test_random_spawner_matches_the_oracle.sizes)
 
@@ -143,7 +144,7 @@ def test_random_spawner_matches_the_oracle(case):
 test_random_spawner_matches_the_oracle.sizes = {}
 
 
-@pytest.mark.parametrize("case", list(range(30 + EXTRA)) + ([1100] if EXTRA <= 1070 else []))  # 1100: a 17k-per-frame Global burst into a type that also receives Nested children
+@pytest.mark.parametrize("case", list(range(OFF, OFF + 30 + EXTRA)) + ([1100] if OFF or EXTRA <= 1070 else []))  # 1100: a 17k-per-frame Global burst into a type that also receives Nested children
 def test_random_spawner_with_single_lifetimes_matches_the_oracle(case):
     """the same generator with nine types in ten on ONE lifetime value: rings that wrap and grow, rings of spawners with
     Nested entries (materialised spawns, children counted on the device), types that receive both kinds of particles
@@ -164,7 +165,7 @@ def test_random_cases_were_not_trivial():
     assert max(totals) > 50000, totals
 
 
-@pytest.mark.parametrize("case", range(4 + EXTRA // 16))
+@pytest.mark.parametrize("case", range(OFF, OFF + 4 + EXTRA // 16))
 def test_random_multi_spawner_system(case):
     """a dozen random spawners in one context: many segments in one launch, more spawn ops than fit the kernel
     arguments (op table read from the pinned ring), per-segment forecast entries; every spawner against its own oracle"""
@@ -196,7 +197,7 @@ def test_random_multi_spawner_system(case):
         assert sum(sum(p.gpu.counts()) for p in pairs) > 5000
 
 
-@pytest.mark.parametrize("case", range(12 + EXTRA // 4))
+@pytest.mark.parametrize("case", range(OFF, OFF + 12 + EXTRA // 4))
 def test_random_scenario_with_api_calls_between_frames(case):
     """the calls a host makes between frames -- moving the origin, parent velocity, modifier, queueing, rewriting the
     particles, the destroyed-particle stream, AABB and instance reads, attaching an instance buffer -- in random order
@@ -204,7 +205,7 @@ def test_random_scenario_with_api_calls_between_frames(case):
     _api_scenario(case, 9000, 0.2)
 
 
-@pytest.mark.parametrize("case", range(12 + EXTRA // 4))
+@pytest.mark.parametrize("case", range(OFF, OFF + 12 + EXTRA // 4))
 def test_random_scenario_with_api_calls_on_single_lifetime_types(case):
     """... with nine types in ten on one lifetime value (rings; a rewritten type continues on the general path)"""
     _api_scenario(case, 23000, 0.9)
@@ -280,7 +281,7 @@ def _api_scenario(case, seed_base, const_p):
                                              f"{want[rows[0]].view(np.float32)}")
 
 
-@pytest.mark.parametrize("case", range(16 + EXTRA // 32))
+@pytest.mark.parametrize("case", range(OFF, OFF + 16 + EXTRA // 32))
 def test_every_shortcut_gives_the_state_of_the_plain_path(case, monkeypatch):
     """rings (types with one lifetime value), no rotation / angular-velocity planes (types that cannot turn), the side
     stream: each is a shortcut around work whose result is known in advance.  A random spawner at a size the oracle would
@@ -352,7 +353,7 @@ def _collider(rng):
                           tuple(float(c) for c in rng.uniform(0.2, 1.0, size=3)), tuple(float(c) for c in q / np.linalg.norm(q)), layers)
 
 
-@pytest.mark.parametrize("case", range(16 + EXTRA // 4))
+@pytest.mark.parametrize("case", range(OFF, OFF + 16 + EXTRA // 4))
 def test_random_colliding_spawner_matches_the_oracle_bit_for_bit(case):
     """particle_collision (core.rs:744-800) under random settings: one to four random colliders (planes, spheres, rotated
     boxes, on different layers), random restitution / friction / destroy_on_collision / filter mask, one or two colliding
@@ -441,7 +442,7 @@ def test_colliding_cases_were_not_trivial():
     assert sum(v[0] for v in sizes.values()) > 20000 and sum(v[1] for v in sizes.values()) > 0, sizes
 
 
-@pytest.mark.parametrize("case", range(24 + EXTRA // 2))
+@pytest.mark.parametrize("case", range(OFF, OFF + 24 + EXTRA // 2))
 def test_random_nested_topologies(case):
     """Nested entries in every arrangement the settings allow: chains (smoke on sparks on seeds), several Nested entries on one
     parent type (one last_emitted_age plane each), particles that emit onto their own type, a type that receives children from
