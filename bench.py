@@ -57,13 +57,50 @@ def path_bytes(ps):
     return mode, algo, moved
 
 
-def cpu_baseline(args, dt):
-    """Reference CPU path restated in C (oracle/), timed on this box: bounded samples of the same workloads."""
+def cpu_baseline(args, dt, world=1, check=False):
+    """Reference CPU path restated in C (oracle/), timed on this box: bounded samples of the same workloads.
+    world == 1: configs[1] on one thread (the headline) + configs[2]'s emitters on all cores under `many_emitters`.
+    world > 1: the workload of that line -- configs[4]'s emitters (8192 live each), one spawner per thread on all host cores,
+    on rank 0 while the other ranks wait at the barrier (outside the timed region).
+    check: the launch-plumbing test (tests/test_bench_launch.py) -- the same code on a sample of a few hundred particles."""
     from concurrent.futures import ThreadPoolExecutor
 
     import oracle
     from bevy_firework_amd import workloads
 
+    def many(emitters, live, fill2, frames2, label, per_thread=1):
+        # one spawner per thread (the reference's par_iter_mut over spawners, core.rs:583-585): as many emitters as there
+        # are host cores (ctypes releases the GIL inside the oracle calls)
+        threads = max(1, min(emitters, os.cpu_count() or 1, 2 if check else 1 << 30))
+        used = min(emitters, threads * per_thread)
+        ems = workloads.many_emitters(emitters, live)[:used]
+        sp = [oracle.OracleSpawner(s, seed=workloads.SEED, uid=e, transform=tf_) for e, (s, tf_) in enumerate(ems)]
+
+        def run(o_, k):
+            m = 0
+            for _ in range(k):
+                o_.spawn(dt)
+                m += o_.count(0)
+                o_.update(dt)
+            return m
+
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            list(ex.map(lambda o_: run(o_, fill2), sp))
+            t0 = time.perf_counter()
+            n2 = sum(ex.map(lambda o_: run(o_, frames2), sp))
+            el2 = time.perf_counter() - t0
+        return {
+            "value": n2 / el2, "unit": "particles/s", "cores": threads, "kind": "port",
+            "sample": f"{label}: {used} of the {emitters} emitters x {live} live, one spawner per task on {threads} threads, "
+                      f"{frames2} frames after a {fill2}-frame fill ({n2 // frames2} particles per frame); host has "
+                      f"{os.cpu_count()} cores",
+        }
+
+    if world > 1:
+        if check:
+            return many(8, 300, 5, 2, "launch check (not a measurement)")
+        # (76 frames to the steady state of lifetimes up to 1.2 s; 8192-particle emitters are ~1 ms of one core per frame)
+        return many(args.emitters, args.live_per_emitter, 76, 60, "configs[4]", per_thread=8)
     spawner, tf = workloads.one_million(rate=args.rate)
     o = oracle.OracleSpawner(spawner, seed=workloads.SEED, uid=0, transform=tf)
     fill = int(round(1.0 / float(dt))) + 2
@@ -82,32 +119,18 @@ def cpu_baseline(args, dt):
                   "GPU run; 1 thread because the reference runs one spawner on one core (core.rs:583-586); "
                   f"host has {os.cpu_count()} cores",
     }
-    # configs[2]'s emitters, one spawner per thread (the reference's par_iter_mut over spawners, core.rs:583-585):
-    # as many of the 256 emitters as there are host cores (ctypes releases the GIL inside the oracle calls)
-    threads = max(1, min(256, os.cpu_count() or 1))
-    ems = workloads.many_emitters(256, 65536)[:threads]
-    sp = [oracle.OracleSpawner(s, seed=workloads.SEED, uid=e, transform=tf_) for e, (s, tf_) in enumerate(ems)]
-    fill2, frames2 = 76, 6  # lifetimes reach 1.2 s: 76 frames to steady state
-
-    def run(o_, k):
-        m = 0
-        for _ in range(k):
-            o_.spawn(dt)
-            m += o_.count(0)
-            o_.update(dt)
-        return m
-
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        list(ex.map(lambda o_: run(o_, fill2), sp))
-        t0 = time.perf_counter()
-        n2 = sum(ex.map(lambda o_: run(o_, frames2), sp))
-        el2 = time.perf_counter() - t0
-    out["many_emitters"] = {
-        "value": n2 / el2, "unit": "particles/s", "cores": threads, "kind": "port",
-        "sample": f"configs[2]: {threads} of the 256 emitters x 65 536 live, one spawner per thread, {frames2} frames "
-                  f"after a {fill2}-frame fill ({n2 // frames2} particles per frame)",
-    }
+    out["many_emitters"] = many(256, 65536, 76, 6, "configs[2]")
     return out
+
+
+def roofline_dict(label, kt, per_launch, launches, mode, algo, moved):
+    """the roofline object of one kernel: algorithmic bytes per launch / average launch duration against the HBM peak"""
+    achieved = per_launch * algo / kt / 1e9
+    return {"workload": label, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "particles_per_launch": per_launch, "avg_kernel_us": kt * 1e6, "launches": launches, "update_path": mode,
+            "algorithmic_bytes_per_particle": algo, "moved_bytes_per_particle": moved,
+            "at_survey_156B_per_particle": {"achieved": per_launch * SURVEY_BYTES / kt / 1e9,
+                                            "frac": per_launch * SURVEY_BYTES / kt / 1e9 / HBM_PEAK_GBS}}
 
 
 def kernel_roofline(ps, step, frames, label):
@@ -119,15 +142,122 @@ def kernel_roofline(ps, step, frames, label):
     ps.kernel_timing(False)
     if not launches:
         return None
-    kt = ev_ms * 1e-3 / launches
-    per_launch = particles / launches
     mode, algo, moved = path_bytes(ps)
-    achieved = per_launch * algo / kt / 1e9
-    return {"workload": label, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "particles_per_launch": per_launch, "avg_kernel_us": kt * 1e6, "launches": launches, "update_path": mode,
-            "algorithmic_bytes_per_particle": algo, "moved_bytes_per_particle": moved,
-            "at_survey_156B_per_particle": {"achieved": per_launch * SURVEY_BYTES / kt / 1e9,
-                                            "frac": per_launch * SURVEY_BYTES / kt / 1e9 / HBM_PEAK_GBS}}
+    return roofline_dict(label, ev_ms * 1e-3 / launches, particles / launches, launches, mode, algo, moved)
+
+
+def gather_ranks(dist, world, device, elapsed, updated, live, roof):
+    """one row per rank {wall time of the timed region, particles updated, live particles, average update-kernel duration (us),
+    particles per launch, launches}: what rank 0 needs for the whole-job line (all_gather: RCCL on the GPU, gloo in the
+    launch check)"""
+    row = [float(elapsed), float(updated), float(live), float(roof["avg_kernel_us"]) if roof else 0.0,
+           float(roof["particles_per_launch"]) if roof else 0.0, float(roof["launches"]) if roof else 0.0]
+    if dist is None:
+        return [row]
+    import torch
+
+    t = torch.tensor(row, dtype=torch.float64, device=device)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allt, t)
+    return [[float(v) for v in x.tolist()] for x in allt]
+
+
+def assemble_line(args, world, workload, rows, roof, extras, cpu, hist, rccl_ranks, measured_copy, reduce_every):
+    """rank 0's ONE JSON line from the per-rank rows (gather_ranks), rank 0's roofline object, the extra measurements and the
+    CPU baseline.  Pure bookkeeping: the launch check (tests/test_bench_launch.py) runs it on stand-in numbers."""
+    elapsed = max(r[0] for r in rows)  # the slowest rank's clock around the barrier-bracketed region
+    updated, live = int(sum(r[1] for r in rows)), int(sum(r[2] for r in rows))
+    per_rank_ms = [r[0] / args.steps * 1e3 for r in rows]
+    value = updated / elapsed
+    if workload == "configs1":
+        wl = ("configs[1]: 1 emitter x rate 1e6/s x lifetime 1 s per GPU (983 333 live), Point emission, linear 2-key "
+              "scale/colour curves, dt=1/60, spawn + update + removal of the dead (order kept) every step")
+        scaling, em_total = "weak", world
+    else:
+        wl = (f"configs[4]: {args.emitters} Sphere emitters x {args.live_per_emitter} live (radial velocity, lifetimes "
+              "0.8-1.2 s, per-emitter constants), emitter e on rank e mod N, dt=1/60, spawn + update + order-preserving "
+              "removal of the dead every step, RCCL all-reduce of per-frame live counts")
+        scaling, em_total = "strong", args.emitters
+    out = {
+        "metric": "particles updated/sec (stress_test, 1M live)" if workload == "configs1" else
+                  "particles updated/sec (stress_test emitter array)",
+        "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": wl, "emitters_total": em_total, "live_particles": live, "sharding": "emitter e -> rank e mod N",
+            "rccl_ranks": rccl_ranks,  # dist.get_world_size() of the nccl (= RCCL) group; 1 = no group
+            "self_launched": os.environ.get("FW_BENCH_SELF_LAUNCHED") == "1",
+            "live_count_allreduce_every": reduce_every,
+            "per_rank_ms_per_step": per_rank_ms,
+            "per_rank_live": [int(r[2]) for r in rows],
+            "allreduced_live_count_last_frame": hist[-1] if hist else None,
+            "speedup_vs_configs4_one_gpu": (extras["configs4_one_gpu"]["ms_per_step"] / (elapsed / args.steps * 1e3)
+                                            if world > 1 and extras.get("configs4_one_gpu") else None),
+            "update_mode": os.environ.get("FW_UPDATE_MODE", "fused"),
+        },
+        "hbm_gbs_algorithmic_whole_step": value * (roof["algorithmic_bytes_per_particle"] if roof else SURVEY_BYTES) / 1e9,
+    }
+    if roof:
+        # HBM-side bytes per launch of this kernel: PMC counters cannot be read from inside the process, so this is the
+        # figure of the separate `rocprofv3 --pmc` passes over this same command (tools/pmc.sh ->
+        # profiles/pmc_traffic.json), labelled as such -- not a measurement of the run that prints it
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp) and workload == "configs1" and world == 1:
+            try:
+                tj = json.load(open(tp))
+                traffic = tj.get("fw_k_update_bytes_per_launch")
+                traffic_src = ("traffic_from_profile: profiles/pmc_traffic.json (" + str(tj.get("source", "rocprofv3 --pmc passes")) +
+                               "), not measured by this run")
+            except Exception:
+                traffic = None
+        fifo = roof.get("update_path") == "fifo"
+        roof.update({
+            "bound": "hbm",
+            "kernel": ("fw_k_update_fifo (in-place ring update of a one-lifetime particle type, any dt)" if fifo else
+                       "fw_k_update_range (in-place range rings: young part in place, old part compacted in place, any dt)"
+                       if roof.get("update_path") == "range" else
+                       "fw_k_update_stream (forecast frames; fw_k_update<fused> when dt changes)"),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "measured_hbm_copy_GBps": measured_copy / 1e9,
+            "note": ("at 1M particles the 164 MB ring is resident in the 256 MiB Infinity Cache: `frac` is a cache-resident "
+                     "figure, not an HBM one; `hbm_resident` is configs[2], a 16.8M-particle working set whose lifetimes are a "
+                     "range: in-place range rings (fw_k_update_range), with the compacting kernels on the same workload "
+                     "under `compacting_path`" if fifo and world == 1 else
+                     "one GPU's share of configs[4] (lifetime ranges: in-place range rings), 100 B algorithmic per particle; the "
+                     "share's ~420 MB exceed the 256 MiB Infinity Cache" if world > 1 else
+                     "at 1M particles the 200 MB ping-pong working set sits in the 256 MiB Infinity Cache; "
+                     "`hbm_resident` is the same kernel on a 16.8M-particle working set"),
+            "timing": "hipEvent start/stop attached to each update dispatch on the context's stream "
+                      "(hipExtLaunchKernel: the packet's begin/end timestamps, the same duration rocprofv3 "
+                      "--kernel-trace reports); second pass over the same steady state, kept out of `value`",
+        })
+        if world > 1:
+            # every rank timed its own dispatches; the headline figures of the object are the SLOWEST rank's
+            algo = roof["algorithmic_bytes_per_particle"]
+            per_rank = []
+            for r, row in enumerate(rows):
+                kt_us, ppl = row[3], row[4]
+                ach = ppl * algo / (kt_us * 1e-6) / 1e9 if kt_us > 0 else None
+                per_rank.append({"rank": r, "avg_kernel_us": kt_us, "particles_per_launch": ppl, "launches": int(row[5]),
+                                 "achieved": ach, "frac": ach / HBM_PEAK_GBS if ach is not None else None})
+            timed = [x for x in per_rank if x["achieved"] is not None]
+            if timed:
+                worst = min(timed, key=lambda x: x["frac"])
+                roof.update({"achieved": worst["achieved"], "frac": worst["frac"], "avg_kernel_us": worst["avg_kernel_us"],
+                             "particles_per_launch": worst["particles_per_launch"], "rank_reported": worst["rank"],
+                             "kernel_us_min": min(x["avg_kernel_us"] for x in timed),
+                             "kernel_us_max": max(x["avg_kernel_us"] for x in timed)})
+            roof["per_rank"] = per_rank
+            roof["workload"] = (f"{workload}: each rank's share ({args.emitters // world} emitters x {args.live_per_emitter} live); "
+                                "achieved / frac are the slowest rank's, per-rank figures under `per_rank`")
+        roof.update(extras)
+    out["roofline"] = roof
+    if extras.get("configs4_one_gpu"):
+        out["config"]["configs4_one_gpu"] = extras["configs4_one_gpu"]
+    out["cpu_baseline"] = cpu
+    return out
 
 
 def self_launch(args):
@@ -156,18 +286,27 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def launch_check(world, rank):
-    """FW_BENCH_LAUNCH_CHECK=1: the ranks only prove that they exist -- a gloo group of `world` processes, one all-reduce
-    -- and rank 0 prints what it saw (tests/test_bench_launch.py)."""
+def launch_check(args, world, rank):
+    """FW_BENCH_LAUNCH_CHECK=1 (tests/test_bench_launch.py, CPU only): the ranks prove that they exist -- a gloo group of
+    `world` processes, one all-reduce -- and rank 0 prints the line the real run would print, assembled by the SAME code
+    (gather_ranks, assemble_line, cpu_baseline) from stand-in numbers: marked `launch_check`, never a measurement."""
     import torch
     import torch.distributed as dist
 
     dist.init_process_group("gloo")
     t = torch.ones(1, dtype=torch.int64)
     dist.all_reduce(t)
+    workload = args.workload if args.workload != "auto" else ("configs1" if world == 1 else "configs4")
+    # stand-ins: rank r "ran" for 1 + r/10 s, updated 1000 (r + 1) particles, its kernel took 50 + r us per launch
+    roof = roofline_dict(workload, (50.0 + rank) * 1e-6, 100.0 * (rank + 1), 3, "range", 100, 104)
+    rows = gather_ranks(dist, world, "cpu", 1.0 + 0.1 * rank, 1000 * (rank + 1), 100 * (rank + 1), roof)
     if rank == 0:
-        print(json.dumps({"launch_check": True, "rccl_ranks": dist.get_world_size(), "ranks_seen": int(t.item()),
-                          "n_gpus": world, "self_launched": os.environ.get("FW_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+        cpu = None if args.no_cpu else cpu_baseline(args, 1.0 / 60.0, world, check=True)
+        out = assemble_line(args, world, workload, rows, roof, {}, cpu, [], dist.get_world_size(), 0.0, args.reduce_every)
+        out.update({"launch_check": True, "rccl_ranks": dist.get_world_size(), "ranks_seen": int(t.item()),
+                    "self_launched": os.environ.get("FW_BENCH_SELF_LAUNCHED") == "1"})
+        print(json.dumps(out), flush=True)
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -193,7 +332,7 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: one rank per GPU, no fallback")
     if os.environ.get("FW_BENCH_LAUNCH_CHECK") == "1":
-        return launch_check(int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0")))
+        return launch_check(args, int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0")))
 
     import numpy as np
     import torch
@@ -258,27 +397,16 @@ def main():
     # Second pass over the same steady state with a hipEvent pair attached to every update dispatch on the kernel's
     # own stream (hipExtLaunchKernel start/stop events: the packet's begin / end timestamps, i.e. the duration
     # rocprofv3 --kernel-trace reports).  A separate pass so that per-dispatch signals cannot touch `value`.
+    # (N > 1: every rank times its own share -- the line reports the slowest rank's kernel and all of them under `per_rank`)
     roof, measured_copy = None, 0.0
-    if not args.no_events and rank == 0:
+    if not args.no_events:
         roof = kernel_roofline(ps, lambda k: ps.step(dt), min(args.steps, 1000), workload)
-        measured_copy = ps.measure_copy_bandwidth(1 << 30, 20)  # float4 copy, 1 GiB -> 1 GiB (read + written bytes / s)
+        if rank == 0:
+            measured_copy = ps.measure_copy_bandwidth(1 << 30, 20)  # float4 copy, 1 GiB -> 1 GiB (read + written bytes / s)
     barrier()
 
-    my_ms = elapsed / args.steps * 1e3
-    per_rank_ms = [my_ms]
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
-        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        u = torch.tensor([updated, live], dtype=torch.int64, device="cuda")
-        dist.all_reduce(u)
-        updated, live = int(u[0].item()), int(u[1].item())
-        hist = sh.global_live_history  # the RCCL-reduced per-frame totals (brought to the host only here)
-    else:
-        hist = []
+    rows = gather_ranks(dist, world, "cuda", elapsed, updated, live, roof)
+    hist = sh.global_live_history if dist is not None else []  # the RCCL-reduced per-frame totals (brought to the host only here)
 
     extras = {}
     rccl_ranks = dist.get_world_size() if dist is not None else 1
@@ -416,77 +544,16 @@ def main():
     if ps is not None:
         ps.close()
 
+    # the CPU baseline: rank 0, outside the timed region, the other ranks at the barrier below
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        cpu = cpu_baseline(args, dt, world)
     if rank == 0:
-        value = updated / elapsed
-        if workload == "configs1":
-            wl = ("configs[1]: 1 emitter x rate 1e6/s x lifetime 1 s per GPU (983 333 live), Point emission, linear 2-key "
-                  "scale/colour curves, dt=1/60, spawn + update + removal of the dead (order kept) every step")
-            scaling, em_total = "weak", world
-        else:
-            wl = (f"configs[4]: {args.emitters} Sphere emitters x {args.live_per_emitter} live (radial velocity, lifetimes "
-                  "0.8-1.2 s, per-emitter constants), emitter e on rank e mod N, dt=1/60, spawn + update + order-preserving "
-                  "removal of the dead every step, RCCL all-reduce of per-frame live counts")
-            scaling, em_total = "strong", args.emitters
-        out = {
-            "metric": "particles updated/sec (stress_test, 1M live)" if workload == "configs1" else
-                      "particles updated/sec (stress_test emitter array)",
-            "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": wl, "emitters_total": em_total, "live_particles": live, "sharding": "emitter e -> rank e mod N",
-                "rccl_ranks": rccl_ranks,  # dist.get_world_size() of the nccl (= RCCL) group; 1 = no group
-                "self_launched": os.environ.get("FW_BENCH_SELF_LAUNCHED") == "1",
-                "live_count_allreduce_every": args.reduce_every if dist is not None else None,
-                "per_rank_ms_per_step": per_rank_ms,
-                "allreduced_live_count_last_frame": hist[-1] if hist else None,
-                "speedup_vs_configs4_one_gpu": (extras["configs4_one_gpu"]["ms_per_step"] / (elapsed / args.steps * 1e3)
-                                                if world > 1 and extras.get("configs4_one_gpu") else None),
-                "update_mode": os.environ.get("FW_UPDATE_MODE", "fused"),
-            },
-            "hbm_gbs_algorithmic_whole_step": value * (roof["algorithmic_bytes_per_particle"] if roof else SURVEY_BYTES) / 1e9,
-        }
-        if roof:
-            # HBM-side bytes per launch of this kernel: PMC counters cannot be read from inside the process, so this is the
-            # figure of the separate `rocprofv3 --pmc` passes over this same command (tools/pmc.sh ->
-            # profiles/pmc_traffic.json), labelled as such -- not a measurement of the run that prints it
-            traffic, traffic_src = None, None
-            tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tp) and workload == "configs1":
-                try:
-                    tj = json.load(open(tp))
-                    traffic = tj.get("fw_k_update_bytes_per_launch")
-                    traffic_src = ("traffic_from_profile: profiles/pmc_traffic.json (" + str(tj.get("source", "rocprofv3 --pmc passes")) +
-                                   "), not measured by this run")
-                except Exception:
-                    traffic = None
-            fifo = roof.get("update_path") == "fifo"
-            roof.update({
-                "bound": "hbm",
-                "kernel": ("fw_k_update_fifo (in-place ring update of a one-lifetime particle type, any dt)" if fifo else
-                           "fw_k_update_range (in-place range rings: young part in place, old part compacted in place, any dt)"
-                           if roof.get("update_path") == "range" else
-                           "fw_k_update_stream (forecast frames; fw_k_update<fused> when dt changes)"),
-                "traffic": traffic, "traffic_source": traffic_src,
-                "measured_hbm_copy_GBps": measured_copy / 1e9,
-                "note": ("at 1M particles the 100 MB ring sits in the 256 MiB Infinity Cache; `hbm_resident` is configs[2], a "
-                         "16.8M-particle working set whose lifetimes are a range: in-place range rings (fw_k_update_range), with "
-                         "the compacting kernels on the same workload under `compacting_path`" if fifo else
-                         "at 1M particles the 200 MB ping-pong working set sits in the 256 MiB Infinity Cache; "
-                         "`hbm_resident` is the same kernel on a 16.8M-particle working set"),
-                "timing": "hipEvent start/stop attached to each update dispatch on the context's stream "
-                          "(hipExtLaunchKernel: the packet's begin/end timestamps, the same duration rocprofv3 "
-                          "--kernel-trace reports); second pass over the same steady state, kept out of `value`",
-            })
-            roof.update(extras)
-        out["roofline"] = roof
-        if extras.get("configs4_one_gpu"):
-            out["config"]["configs4_one_gpu"] = extras["configs4_one_gpu"]
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args, dt)
-        else:
-            out["cpu_baseline"] = None
+        out = assemble_line(args, world, workload, rows, roof, extras, cpu, hist, rccl_ranks, measured_copy,
+                            args.reduce_every if dist is not None else None)
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        barrier()
     if dist is not None:
         dist.destroy_process_group()
 

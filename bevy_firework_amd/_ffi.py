@@ -225,6 +225,7 @@ SYMBOLS = [
     ("fw_spawner_update_settings", C.c_int, [_P, C.c_int32, C.POINTER(SpawnerDesc)]),
     ("fw_spawner_destroy", C.c_int, [_P, C.c_int32]),
     ("fw_spawner_set_origin", C.c_int, [_P, C.c_int32, _F3, _F3]),
+    ("fw_ctx_set_origins", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_int32), _F3, _F3]),
     ("fw_spawner_set_parent_velocity", C.c_int, [_P, C.c_int32, _F3]),
     ("fw_spawner_set_modifier", C.c_int, [_P, C.c_int32, C.c_float, C.c_float]),
     ("fw_spawner_queue", C.c_int, [_P, C.c_int32, C.c_uint64]),
@@ -279,7 +280,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.fw_abi_version() != 3:
+    if lib.fw_abi_version() != 4:
         raise ImportError("libfirework_hip.so ABI version mismatch")
     _lib = lib
     return lib

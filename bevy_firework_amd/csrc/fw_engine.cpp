@@ -200,6 +200,7 @@ struct alignas(64) SegHost {
     // ... but not yet: the caller wrote particles (any scale, any colours), and those that die in the very next step carry
     // what was written in their destroyed records -- the planes are read for one more frame, then the mode starts
     bool derive_pending = false;
+    bool derive_ready = false;  // ... that frame has been enqueued: the flag flips at the start of the next fw_step
     // the attached buffer is a WINDOWED one (fw_spawner_attach_instances_window): the caller draws d_out[first, first + count)
     // and asks for `first` -- which lets a range ring keep its path (its tiles know a record's index counted from the
     // particles the update destroys, not from 0)
@@ -245,6 +246,7 @@ struct fw_ctx {
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
     bool seg_kind_changed = false;       // a ring left its mode inside the current fw_step (realloc_segment)
+    bool derive_ready_any = false;       // some SegHost::derive_ready is set
     // undo log of fw_step's host half: spawn_particles is all-or-nothing per frame in the reference, so a frame that
     // cannot be enqueued (limit exceeded, allocation failure) must leave clocks, queues and RNG serials untouched
     struct EmUndo {
@@ -397,9 +399,6 @@ struct fw_ctx {
     bool rtab_pending = false;
     unsigned long long *d_rstatus = nullptr;  // look-back words of the OLD workgroups
     char *h_rparam[kParamRing] = {};          // pinned per-frame records + ops, read by the kernel in place
-    char *d_rparam[kParamRing] = {};          // FW_RANGE_DEVREC=1: device copies of them (one H2D copy per frame in the stream)
-    bool range_devrec = false;
-    bool range_fold = false;   // FW_RANGE_FOLD: a handful of new particles ride in the YOUNG workgroups (A/B)
     bool range_spread_new = true;   // FW_RANGE_SPREAD_NEW=0: a segment's NEW workgroups all in front of its YOUNG ones (A/B)
     // An in-place ring launch (FIFO / range) that streams more than nt_bytes uses the fully non-temporal form of its kernel:
     // several times the 256 MiB Infinity Cache, where allocating lines that cannot survive until the next frame only costs.
@@ -413,9 +412,7 @@ struct fw_ctx {
     uint64_t nt_wo_bytes = 280ull << 20, nt_wo_bytes_range = 64ull << 20;
     unsigned long long *d_rts = nullptr;  // FW_DEBUG & 8: per-workgroup timestamps of the last range launch
     bool range_idle_last = true;   // FW_RANGE_IDLE_LAST=0: provisioned-but-idle workgroups stay next to their segment's active ones
-    uint32_t range_old_ahead = 0;  // FW_RANGE_OLD_AHEAD=n: the OLD workgroups of a segment come n segments before its other ones
     std::vector<uint32_t> range_scratch;
-    uint32_t range_old_extra = 0;  // FW_RANGE_OLD_EXTRA=n: n more (idle) OLD workgroups per segment -- what an idle one costs
     size_t rparam_bytes = 0;
     uint64_t rslot_frame[kParamRing] = {};    // frame that last used the slot (+1; 0 = free)
     uint64_t rring_seq = 0;
@@ -687,9 +684,6 @@ fw_status ensure_range_arrays(fw_ctx *ctx) {
             ctx->h_rparam[i] = nullptr;
             FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_rparam[i], nb, hipHostMallocDefault));
             memset(ctx->h_rparam[i], 0, nb);
-            if (ctx->d_rparam[i]) hipFree(ctx->d_rparam[i]);
-            ctx->d_rparam[i] = nullptr;
-            FW_HIP(ctx, hipMalloc((void **)&ctx->d_rparam[i], nb));
             ctx->rslot_frame[i] = 0;
         }
         ctx->rparam_bytes = nb;
@@ -1219,13 +1213,19 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             // ... and so does a type that receives Nested children AND Global particles (its Global particles would have to be
             // placed behind a live count only the device knows)
             bool any_nested = false, self_nested = false, mixed_feed = false;
+            uint32_t n_global_feed = 0;  // Global entries that feed the type: each may add one op to a frame
             for (uint32_t i = 0; i < ne; i++) {
                 const fw_emission_settings &e = d->emission_settings[i];
+                n_global_feed += (e.mode == FW_MODE_GLOBAL && (uint32_t)e.particle_index == t) ? 1u : 0u;
                 any_nested |= e.mode == FW_MODE_NESTED;
                 self_nested |= e.mode == FW_MODE_NESTED && e.target_particle_type == e.particle_index;
                 mixed_feed |= S.nested_fed && e.mode == FW_MODE_GLOBAL && (uint32_t)e.particle_index == t;
             }
+            // (a ring's spawn ops of a frame travel in the kernel arguments of its launch -- FwInlineOps, FW_INLINE_OPS of
+            // them: a type fed by more Global entries than that takes the range or the compacting path, whose tiles read op
+            // tables from memory)
             S.fifo = ctx->use_fifo && !self_nested && !mixed_feed && !S.collides && p.lifetime.min == p.lifetime.max &&
+                     n_global_feed <= FW_INLINE_OPS &&
                      std::isfinite(p.lifetime.min) && ctx->n_fifo < kMaxFifoSegs &&
                      caps[t] >= ctx->fifo_min && caps[t] < 0x40000000u &&  // (head + index stays far from 2^32)
                      (!any_nested || ctx->fifo_nested);
@@ -1623,33 +1623,33 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     // behaviour because of a stray environment variable
     const char *knobs_on = getenv("FW_ENABLE_KNOBS");
     auto getenv = [&](const char *name) -> const char * { return (knobs_on && atoi(knobs_on) != 0) ? ::getenv(name) : nullptr; };
+    // -- path selectors: every one of them names a path the product takes by itself under some workload; the tests force each
     if (const char *m = getenv("FW_UPDATE_MODE")) ctx->update_mode = !strcmp(m, "split") ? FW_MODE_SPLIT : FW_MODE_FUSED;
-    if (const char *m = getenv("FW_DEBUG")) ctx->dbg = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_FORECAST")) ctx->use_forecast = atoi(m) != 0;
     if (const char *m = getenv("FW_STREAM")) ctx->use_stream = atoi(m) != 0;
+    if (const char *m = getenv("FW_STATIC_NEW")) ctx->use_static_new = atoi(m) != 0;  // 0: always count + look back
+    if (const char *m = getenv("FW_SPIN_LIMIT")) ctx->spin_limit = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_FIFO")) ctx->use_fifo = atoi(m) != 0;
-    if (const char *m = getenv("FW_FIFO_NESTED")) ctx->fifo_nested = atoi(m) != 0;
+    if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_FIFO_STREAM")) ctx->use_fifo_stream = atoi(m) != 0;
-    if (const char *m = getenv("FW_NOSPIN")) ctx->use_nospin = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE")) ctx->use_range = atoi(m) != 0;
-    if (const char *m = getenv("FW_DERIVED")) ctx->use_derived = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_MIN")) ctx->range_min = (uint32_t)strtoul(m, nullptr, 10);
-    if (const char *m = getenv("FW_RANGE_DEVREC")) ctx->range_devrec = atoi(m) != 0;
-    if (const char *m = getenv("FW_RANGE_FOLD")) ctx->range_fold = atoi(m) != 0;
-    if (const char *m = getenv("FW_RANGE_OLD_EXTRA")) ctx->range_old_extra = (uint32_t)atoi(m);
-    if (const char *m = getenv("FW_RANGE_OLD_AHEAD")) ctx->range_old_ahead = (uint32_t)atoi(m);
-    if (const char *m = getenv("FW_RANGE_IDLE_LAST")) ctx->range_idle_last = atoi(m) != 0;
+    if (const char *m = getenv("FW_NOSPIN")) ctx->use_nospin = atoi(m) != 0;
     if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_NT_WO_MB")) ctx->nt_wo_bytes = ctx->nt_wo_bytes_range = (uint64_t)atoll(m) << 20;
+#ifdef FW_AB
+    // -- the experiment surface: only in the `make ab` build (libfirework_hip_ab.so; the tools load it through FW_LIB_PATH)
+    if (const char *m = getenv("FW_DEBUG")) ctx->dbg = (uint32_t)atoi(m);
+    if (const char *m = getenv("FW_FIFO_NESTED")) ctx->fifo_nested = atoi(m) != 0;
+    if (const char *m = getenv("FW_DERIVED")) ctx->use_derived = atoi(m) != 0;
+    if (const char *m = getenv("FW_RANGE_IDLE_LAST")) ctx->range_idle_last = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_SPREAD_NEW")) ctx->range_spread_new = atoi(m) != 0;
-    if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
     if (const char *m = getenv("FW_OPS_ZEROCOPY")) ctx->ops_zerocopy = atoi(m) != 0;
-    if (const char *m = getenv("FW_STATIC_NEW")) ctx->use_static_new = atoi(m) != 0;  // 0: always count + look back
     if (const char *m = getenv("FW_SNAP_EVERY")) ctx->snap_every = std::max(1, atoi(m));
-    if (const char *m = getenv("FW_SPIN_LIMIT")) ctx->spin_limit = (uint32_t)strtoul(m, nullptr, 10);
     ctx->trace = getenv("FW_TRACE") != nullptr;
     if (const char *m = getenv("FW_HOST_PROF")) ctx->host_prof = atoi(m) != 0, ctx->host_prof_skip = atoi(m) > 1 ? (uint64_t)atoi(m) : 0;
+#endif
     if (ensure_max_seg(ctx, 1024) != FW_OK) {
         g_create_error = ctx->err;
         delete ctx;
@@ -1721,7 +1721,6 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     if (ctx->d_rts) hipFree(ctx->d_rts);
     for (int i = 0; i < kParamRing; i++) {
         if (ctx->h_rparam[i]) hipHostFree(ctx->h_rparam[i]);
-        if (ctx->d_rparam[i]) hipFree(ctx->d_rparam[i]);
     }
     if (ctx->ev_main) hipEventDestroy(ctx->ev_main);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -1875,6 +1874,19 @@ fw_status fw_spawner_set_origin(fw_ctx *ctx, fw_spawner h, const float t[3], con
     return FW_OK;
 }
 
+fw_status fw_ctx_set_origins(fw_ctx *ctx, uint32_t n, const fw_spawner *handles, const float *translations,
+                             const float *rotations_xyzw) {
+    if (!ctx || (n && (!handles || !translations || !rotations_xyzw))) return FW_EINVAL;
+    for (uint32_t i = 0; i < n; i++)
+        if (!get_spawner(ctx, handles[i])) return fail(ctx, FW_EINVAL, "fw_ctx_set_origins: invalid spawner handle");
+    for (uint32_t i = 0; i < n; i++) {
+        SpawnerHost &sp = ctx->spawners[(size_t)handles[i]];
+        memcpy(sp.origin_pos, translations + (size_t)i * 3, sizeof sp.origin_pos);
+        memcpy(sp.origin_rot, rotations_xyzw + (size_t)i * 4, sizeof sp.origin_rot);
+    }
+    return FW_OK;
+}
+
 fw_status fw_spawner_set_parent_velocity(fw_ctx *ctx, fw_spawner h, const float v[3]) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || !v) return FW_EINVAL;
@@ -1912,6 +1924,17 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         prof_t = now;
     };
     poll_snapshots(ctx);
+    if (ctx->derive_ready_any) {  // types whose caller-written particles have all been through an update (see the end of fw_step)
+        ctx->derive_ready_any = false;
+        for (uint32_t i = 0; i < ctx->segs.size(); i++) {
+            SegHost &S = ctx->segs[i];
+            if (!S.in_use || !S.derive_ready) continue;
+            S.derive_ready = false;
+            if (S.inst == nullptr || S.colors_dirty || S.collides || !ctx->use_derived) continue;  // (detached / rewritten since)
+            const fw_status dst = set_derived(ctx, i, true);
+            if (dst) return dst;
+        }
+    }
 
     // per-frame scratch lives in the context: with thousands of emitters the allocations were a visible part of the
     // host's ~60 ns per emitter
@@ -2190,6 +2213,31 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         // every routed op now sits in exactly one list `rollback` walks (levels[].g or fifo_ops): forgetting this one too
         // would take its particles out of cum_spawn twice
         ctx->fifo_mat_ops.clear();
+    }
+    // A ring that had to grow past its mode's slot limit inside the loop above (realloc_segment) continues as a compacting
+    // segment from this very frame: the ops already queued for it as a ring's go where a compacting segment's ops go -- its
+    // emission level -- or they would never be spawned while cum_spawn, ub and the lifetime window count them.
+    if (ctx->seg_kind_changed) {
+        auto reroute = [&](std::vector<FwOp> &list, bool was_fifo) {
+            size_t w = 0;
+            for (size_t r = 0; r < list.size(); r++) {
+                const FwOp &op = list[r];
+                const SegHost &S = ctx->segs[op.seg];
+                if (was_fifo ? S.fifo : S.range) {
+                    list[w++] = op;
+                    continue;
+                }
+                size_t lvl = 0;
+                const SpawnerHost &osp = ctx->spawners[S.spawner];
+                for (size_t i = 0; i < osp.em.size(); i++)
+                    if (osp.em[i].emit_idx == op.emit) lvl = i;
+                levels[lvl].g.push_back(op);
+                if (!(dt < osp.em[lvl].life_lo_safe)) new_static = false;  // (the test a compacting segment's op gets above)
+            }
+            list.resize(w);
+        };
+        reroute(ctx->fifo_ops, true);
+        reroute(ctx->range_ops, false);
     }
     // ---- segment -> tile table (device resident, re-uploaded only when a bound moves out of its band)
     prof(1);
@@ -2499,7 +2547,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             SegHost &S = ctx->segs[si];
             if (!S.in_use || !S.fifo) continue;
             uint32_t k_ops = 0;
-            for (const FwOp &op : ctx->fifo_ops) k_ops += op.seg == si ? 1u : 0u;  // (at most FW_MAX_EMISSIONS)
+            for (const FwOp &op : ctx->fifo_ops) k_ops += op.seg == si ? 1u : 0u;
+            if (k_ops > FW_INLINE_OPS)  // (build_spawner never makes such a type a ring)
+                return fail(ctx, FW_EHIP, "internal error: a FIFO ring with more spawn ops than its launch can carry");
             if (fa.n_segs == FW_FIFO_PER_LAUNCH || f_ops + k_ops > FW_INLINE_OPS) FW_HIP(ctx, flush());
             const int32_t wm = S.derived ? 0 : S.fifo_wm;  // (FW_TYPE_DERIVED: none of the optional planes is stored)
             if (!fa.n_segs) fa.write_mask = wm;
@@ -2623,12 +2673,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             // workgroups of each role (bands: the table is re-sent only when a need leaves its band)
             const uint32_t live_before_ub = std::min(S.ub - std::min(S.ub, S.frame_spawn), S.capacity);
             const uint32_t old_ub = live_before_ub - std::min(live_before_ub, y_exist);
-            const uint32_t need_old = std::max(1u, (old_ub + FW_TILE - 1) / FW_TILE) + ctx->range_old_extra;
-            // (at most one round of new particles is spawned by the YOUNG workgroups that own their slots: fw_k_update_range)
-            const bool fold = ctx->range_fold && S.frame_spawn <= FW_BLOCK;
-            const uint32_t need_new = fold ? 0u : (S.frame_spawn + FW_BLOCK - 1) / FW_BLOCK;
+            const uint32_t need_old = std::max(1u, (old_ub + FW_TILE - 1) / FW_TILE);
+            const uint32_t need_new = (S.frame_spawn + FW_BLOCK - 1) / FW_BLOCK;
             const uint32_t YT = fw_range_young_tile();
-            const uint32_t need_young = std::min(S.capacity / YT, (S.young_lo % YT + y_exist + (fold ? S.frame_spawn : 0u) + YT - 1) / YT);
+            const uint32_t need_young = std::min(S.capacity / YT, (S.young_lo % YT + y_exist + YT - 1) / YT);
             // every provisioned workgroup is dispatched every frame, active or not (~3 us of a slot each): small needs get
             // one spare, large ones an eighth -- a re-sent table is a copy in the stream, an idle workgroup a cost in every frame
             // (the bound of the old part follows the snapshots in a sawtooth: a role grows at once, and shrinks only after its
@@ -2720,12 +2768,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 S.r_status_base = status_base, status_base += S.r_old;
                 rs.push_back(si);
             }
-            // (FW_RANGE_OLD_AHEAD=n: the OLD workgroups of a segment n segments before its other ones -- measured, no gain)
-            const size_t nr = rs.size(), ahead = std::min<size_t>(nr, ctx->range_old_ahead);
-            for (size_t i = 0; i < nr + ahead && ok; i++) {
-                if (i < nr) put_old(rs[i]);
-                if (i >= ahead) put_rest(rs[i - ahead]);
-            }
+            // (the OLD workgroups of a segment dispatched n segments ahead of its other ones: measured, no gain --
+            // profiles/r03/range_old_ahead.txt)
+            const size_t nr = rs.size();
+            for (size_t i = 0; i < nr && ok; i++) put_old(rs[i]), put_rest(rs[i]);
             for (size_t i = 0; i < nr && ok; i++) put_tail(rs[i]);
             if (!ok) return fail(ctx, FW_EHIP, "internal error: range table overflow");
             ctx->r_total = (uint32_t)t;
@@ -2742,15 +2788,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         if (ctx->r_total) {
             FwRangeArgs ra{};
             ra.desc = ctx->d_rdesc, ra.recs = recs, ra.ops = rops, ra.status = ctx->d_rstatus;
-            if (ctx->range_devrec) {
-                const size_t off_ops = round_up((uint32_t)(ctx->max_seg * sizeof(FwRangeRec)), 64);
-                const size_t bytes = off_ops + ops.size() * sizeof(FwOp);
-                FW_HIP(ctx, hipMemcpyAsync(ctx->d_rparam[rslot], ctx->h_rparam[rslot], bytes, hipMemcpyHostToDevice, ctx->stream));
-                ra.recs = (const FwRangeRec *)ctx->d_rparam[rslot], ra.ops = (const FwOp *)(ctx->d_rparam[rslot] + off_ops);
-            }
             ra.total_tiles = ctx->r_total, ra.parity = p, ra.epoch = a.epoch, ra.spin_limit = ctx->spin_limit, ra.dbg = ctx->dbg;
             ra.dt = dt;
-            ra.fold_new = ctx->range_fold ? 1u : 0u;
             ra.any_inst = range_inst ? 1u : 0u;
             ra.done_tag = a.done_tag, ra.done_value = a.done_value;
             ra.host_counts = a.host_counts, ra.live_out = a.live_out, ra.live_next = a.live_next;
@@ -2781,13 +2820,13 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         ctx->colors_dirty = false;
         // every particle has been through an update since the caller's write: scale and colours are functions of the age
         // again, a type with an attached instance buffer can stop storing them (FW_TYPE_DERIVED; waits for this frame: rare)
+        // (the flag flips at the START of the next fw_step, before anything of that frame is enqueued: flipping it waits for
+        // the stream -- the frame just enqueued still stores the planes -- and may fail; fw_step itself only enqueues, and
+        // by now this frame must finish its bookkeeping whatever happens)
         for (uint32_t i = 0; i < n_seg; i++)
             if (ctx->segs[i].in_use && ctx->segs[i].derive_pending) {
                 ctx->segs[i].derive_pending = false;
-                if (ctx->segs[i].inst != nullptr) {
-                    const fw_status dst = set_derived(ctx, i, true);  // (waits for the frame just enqueued, which still stores the planes)
-                    if (dst) return dst;
-                }
+                if (ctx->segs[i].inst != nullptr) ctx->segs[i].derive_ready = true, ctx->derive_ready_any = true;
             }
     }
     prof(6);
@@ -3349,6 +3388,8 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t
         const uint32_t skipped = colours + ((S.ring() && T.scale.kind == 0) ? 0u : 4u);
         moved -= std::min(moved, skipped), algo -= std::min(algo, skipped);
     }
+    // an attached instance buffer: the update also writes the 64-byte ParticleInstance record of every survivor (render.rs:95-103)
+    if (S.inst != nullptr) moved += 64u, algo += 64u;
     if (moved_bytes) *moved_bytes = moved;
     if (algorithmic_bytes) *algorithmic_bytes = algo;
     return FW_OK;

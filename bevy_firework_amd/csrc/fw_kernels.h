@@ -6,6 +6,16 @@
 #include "fw_device.h"
 #include "fw_collide.h"
 
+// The product build (the default `make`) carries no experiment surface: the FW_DEBUG profiling modes (kernel ablations, in-kernel
+// timestamps) and the A/B switches of measured-and-rejected variants exist only in the `make ab` build (-DFW_AB,
+// libfirework_hip_ab.so, loaded by the tools through FW_LIB_PATH).  FW_DBG(x, bit) is a compile-time 0 in the product: the
+// branches fold away (an UNUSED timestamp branch was measured at 6 % of one GPU's share of configs[4], profiles/r03).
+#ifdef FW_AB
+#define FW_DBG(x, bit) (((x) & (bit)) != 0u)
+#else
+#define FW_DBG(x, bit) (false)
+#endif
+
 // pointers to the context's persistent device state (passed by value as a kernel argument)
 struct FwGlobals {
     FwSeg *segs;
@@ -188,7 +198,6 @@ struct FwRangeArgs {
     unsigned long long *status;     // look-back words of the OLD workgroups (FwRangeDesc::old_first + k)
     uint32_t total_tiles, parity, epoch, spin_limit, dbg;
     float dt;
-    uint32_t fold_new;              // 1: at most one round of new particles is spawned by the YOUNG workgroups owning their slots
     uint32_t any_inst;              // some segment has a windowed instance buffer attached: the kernels that also write records
     unsigned long long *done_tag;   // as in FwUpdateArgs
     unsigned long long done_value;

@@ -714,7 +714,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     __shared__ uint32_t s_part[4][NW];  // per-wave partials: forecast prefix, new survivors, next-frame sums A / B
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const unsigned long long ts0 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long ts0 = FW_DBG(a.dbg, 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // workgroup -> (segment, tile in segment): one table read instead of a dependent binary search
     uint32_t seg, first, seg_tiles, type_idx;
     if (a.n_seg == 1u) {  // a lone segment: everything is in the kernel arguments, no table read on the critical path
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     char *inst = INST ? Sp->inst : nullptr;
     const uint32_t inst_cap = INST ? Sp->inst_cap : 0u;
 
-    const unsigned long long tsA = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (C & 0u)) : 0ull;
+    const unsigned long long tsA = FW_DBG(a.dbg, 8u) ? (__builtin_amdgcn_s_memrealtime() + (C & 0u)) : 0ull;
     // ---- phase 1: the planes that decide survival: Q0 (age in .w) and Q3 (lifetime in .w); all R loads of
     // both planes are in flight together, then parked in LDS
     {
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             if (!has_new && idx < lim) s_q0[r * BLK + tid] = t0[r], s_q3[r * BLK + tid] = t3[r];
         }
     }
-    const unsigned long long tsB = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long tsB = FW_DBG(a.dbg, 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // first round's Q1 / Q2 go out now; later rounds are prefetched one round ahead
     float4 q1c, q2c;
     {
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         fc_bad = tid == 0 && fw_ld2u(a.fc_in, a.fc_tag).x != a.epoch - 1u;
     }
 
-    const unsigned long long tsC = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (fc_part & 0u)) : 0ull;
+    const unsigned long long tsC = FW_DBG(a.dbg, 8u) ? (__builtin_amdgcn_s_memrealtime() + (fc_part & 0u)) : 0ull;
     if (SPAWN != FW_SPAWN_NONE && has_new) {
         // New particles (src/core.rs:437-469), generated from the counter RNG straight into LDS: Q0/Q3 where a
         // loaded tile parks them, Q1/Q2 in the upper half of the same planes (a new-particle tile is at most
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         if (__any(fc_bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 1u, g.err[6] = tile;
     }
     __syncthreads();
-    const unsigned long long ts1 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long ts1 = FW_DBG(a.dbg, 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t cnt = 0;
 #pragma unroll
     for (int r = 0; r <= R; r++) {
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         if (lb_publish && lb_needed && tid == 0)
             __hip_atomic_store(&g.tile_status[tile], fw_pack_status(a.epoch, FW_ST_AGG, lb_val), RLX, AGENT);
         uint32_t lb_excl = 0;
-        if (lb_needed && !(a.dbg & 1u)) {
+        if (lb_needed && !FW_DBG(a.dbg, 1u)) {
             bool timed_out = false;
             lb_excl = fw_lookback<BLK, NW, LBW>(g.tile_status, lb_lo, tile, a.epoch, a.spin_limit, s_lb, &timed_out);
             if (timed_out) {
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         excl = g.tile_off[tile];
     }
 
-    const unsigned long long ts2 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long ts2 = FW_DBG(a.dbg, 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // ---- phase 3: round loop -- integrate survivors, store them at their compacted slot
     const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
     excl = __builtin_amdgcn_readfirstlane(excl);  // workgroup-uniform: keep it on the scalar unit
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             fa += (uint32_t)__popcll(__ballot(nx && o < fc_bnd));
             fb += (uint32_t)__popcll(__ballot(nx && o >= fc_bnd));
         }
-        if (alive && (a.dbg & 2u)) {  // profiling only: stream without arithmetic
+        if (alive && FW_DBG(a.dbg, 2u)) {  // profiling only: stream without arithmetic
             const uint32_t b16 = (o - W.first) * 16u;
             fw_st4w(W.q0, b16, make_float4(q0.x, q0.y, q0.z, age_new)), fw_st4w(W.q1, b16, q1c);
             fw_st4w(W.q2, b16, q2c), fw_st4w(W.q3, b16, q3);
@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         fw_tile_box_flush<NW>(g.tile_box, tile, a.epoch, box, reinterpret_cast<float (*)[6]>(s_lb));
     }
 
-    if ((a.dbg & 8u) && g.dbg_ts && tid == 0) {
+    if (FW_DBG(a.dbg, 8u) && g.dbg_ts && tid == 0) {
         unsigned long long *d = g.dbg_ts + 32768 + ((size_t)(a.epoch & 1u) * gridDim.x + tile) * 8;  // two launches kept
         {  // ring of the last 256 launches: earliest start / latest end, spread over 64 words each to keep the atomics apart
             unsigned long long *rg = g.dbg_ts + (size_t)(a.epoch & 255u) * 128u;
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         g.ndestroyed[seg] = n_tot - nc;
         if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;  // one 8-byte store: tag + count
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        if (!(a.dbg & 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
+        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
     }
 }
 
@@ -1180,7 +1180,7 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
         acc.fa += (uint32_t)__popcll(__ballot(nx && o < fc_bnd));
         acc.fb += (uint32_t)__popcll(__ballot(nx && o >= fc_bnd));
     }
-    if (alive && (dbg & 2u)) {  // profiling only: stream without arithmetic
+    if (alive && FW_DBG(dbg, 2u)) {  // profiling only: stream without arithmetic
         const uint32_t b16 = (o - W.first) * 16u;
         fw_st4w(W.q0, b16, make_float4(q0.x, q0.y, q0.z, age_new)), fw_st4w(W.q1, b16, q1);
         fw_st4w(W.q2, b16, q2), fw_st4w(W.q3, b16, q3);
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     __shared__ uint32_t s_part[4][NW];  // per-wave partials: forecast prefix, new survivors, next-frame sums A / B
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const unsigned long long ts0 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long ts0 = FW_DBG(a.dbg, 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t seg, first, seg_tiles, type_idx, keys_off, keys_len;
     if (LONE) {
         seg = 0, first = 0, seg_tiles = a.total_tiles, type_idx = a.seg0_type;
@@ -1347,7 +1347,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     if (blockIdx.x == 0 && tid == 0 && a.live_next) *a.live_next = 0ull;
     if (blockIdx.x == 0 && tid == 0 && a.done_tag) *a.done_tag = a.done_value;
 
-    const unsigned long long tsA = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (C & 0u)) : 0ull;
+    const unsigned long long tsA = FW_DBG(a.dbg, 8u) ? (__builtin_amdgcn_s_memrealtime() + (C & 0u)) : 0ull;
     // round 0 of a live tile goes out now (unless the speculative request above already covers it)
     // (Loads are issued UNCONDITIONALLY at an index clamped into the tile: a load under a lane predicate lives in
     // its own basic block, and the copy into the merged value at the end of that block makes the compiler wait for
@@ -1407,7 +1407,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             new_alive += (uint32_t)__popcll(__ballot(al));
         }
     }
-    if (fc_small && (a.dbg & 16u)) {  // FW_DEBUG 16 (profiling): read the table a second time -- what does the read cost?
+    if (fc_small && FW_DBG(a.dbg, 16u)) {  // FW_DEBUG 16 (profiling): read the table a second time -- what does the read cost?
         uint4 e2[FW_FCE_U];
         fw_fce_request<BLK>(a.fce_out, first, seg_tiles, e2);
 #pragma unroll
@@ -1416,9 +1416,9 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     fc_part = fw_wave_sum(fc_part);
     if (lane == 0) s_part[0][wave] = fc_part, s_part[1][wave] = new_alive;
     if (__any(fc_bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 2u, g.err[6] = tile;
-    const unsigned long long tsB = (a.dbg & 8u) ? (__builtin_amdgcn_s_memrealtime() + (fc_part & 0u)) : 0ull;
+    const unsigned long long tsB = FW_DBG(a.dbg, 8u) ? (__builtin_amdgcn_s_memrealtime() + (fc_part & 0u)) : 0ull;
     __syncthreads();
-    const unsigned long long ts1 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long ts1 = FW_DBG(a.dbg, 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t excl = 0, new_cnt = 0;
 #pragma unroll
     for (int w = 0; w < NW; w++) excl += s_part[0][w], new_cnt += s_part[1][w];
@@ -1466,7 +1466,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         excl += lb_excl;
     }
 
-    const unsigned long long ts2 = (a.dbg & 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long ts2 = FW_DBG(a.dbg, 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long tsR1 = 0;
     const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
     const uint32_t fcA = excl / FW_TILE, fc_bnd = (fcA + 1u) * FW_TILE;
@@ -1510,9 +1510,9 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             float4 *rec = (INST && inst != nullptr) ? s_inst + wave * 256u + (o - wbase) * 4u : nullptr;
             fw_round_finish(T, s_keys, a.dt, a.dbg, q0c, q1c, q2c, q3c, valid, alive, true, age_new, idx, o, ib, ob, W,
                             destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec, box, box_on, idx >= n_in);
-            if (INST && inst != nullptr && !(a.dbg & 2u)) fw_inst_flush(inst, inst_cap, s_inst + wave * 256u, lane, m, wbase);
+            if (INST && inst != nullptr && !FW_DBG(a.dbg, 2u)) fw_inst_flush(inst, inst_cap, s_inst + wave * 256u, lane, m, wbase);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n, lfc = lfn;
-            if ((a.dbg & 8u) && r == 0) tsR1 = __builtin_amdgcn_s_memrealtime() + (o & 0u);
+            if (FW_DBG(a.dbg, 8u) && r == 0) tsR1 = __builtin_amdgcn_s_memrealtime() + (o & 0u);
         }
     }
     if (SPAWN != FW_SPAWN_NONE && (!loaded_tile || tail_new)) {
@@ -1554,7 +1554,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             float4 *rec = (INST && inst != nullptr) ? s_inst + wave * 256u + (o - wbase) * 4u : nullptr;
             fw_round_finish(T, s_keys, a.dt, a.dbg, so.q0, so.q1, so.q2, so.q3, valid, alive, false, age_new, idx, o, ib,
                             ob, W, destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec, box, box_on);
-            if (INST && inst != nullptr && !(a.dbg & 2u)) fw_inst_flush(inst, inst_cap, s_inst + wave * 256u, lane, m, wbase);
+            if (INST && inst != nullptr && !FW_DBG(a.dbg, 2u)) fw_inst_flush(inst, inst_cap, s_inst + wave * 256u, lane, m, wbase);
         }
     }
     if (lane == 0) s_part[2][wave] = acc.fa, s_part[3][wave] = acc.fb;
@@ -1567,7 +1567,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         else fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, seg_tiles);
     }
     if (a.boxes) fw_tile_box_flush<NW>(g.tile_box, tile, a.epoch, box, reinterpret_cast<float (*)[6]>(s_lb));
-    if ((a.dbg & 8u) && g.dbg_ts && tid == 0) {
+    if (FW_DBG(a.dbg, 8u) && g.dbg_ts && tid == 0) {
         unsigned long long *d = g.dbg_ts + 32768 + ((size_t)(a.epoch & 1u) * gridDim.x + tile) * 8;  // two launches kept
         {  // ring of the last 256 launches: earliest start / latest end, spread over 64 words each to keep the atomics apart
             unsigned long long *rg = g.dbg_ts + (size_t)(a.epoch & 255u) * 128u;
@@ -1591,7 +1591,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         g.ndestroyed[seg] = n_tot - nc;
         if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;  // one 8-byte store: tag + count
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        if (!(a.dbg & 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
+        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
     }
 }
 
@@ -1789,7 +1789,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
             const unsigned long long m = INST ? __ballot(alive) : 0ull;
             float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(m) * 4u : nullptr;
             if (alive) {
-                if (a.dbg & 2u) {  // profiling only: stream without arithmetic
+                if FW_DBG(a.dbg, 2u) {  // profiling only: stream without arithmetic
                     const uint32_t b16 = (s - W.first) * 16u;
                     fw_st4w<NT == 2>(W.q0, b16, make_float4(q0c.x, q0c.y, q0c.z, age_new)), fw_st4w<NT == 2>(W.q1, b16, q1c);
                     if (WM >= 0 ? (WM & 1) != 0 : W.wr5) fw_st4w<NT != 0>(W.q5, b16, q0c);
@@ -1818,7 +1818,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         g.ndestroyed[F.seg] = n_tot - nc;
         if (a.host_counts) a.host_counts[F.seg] = ((unsigned long long)a.epoch << 32) | nc;
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        if (!(a.dbg & 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);
+        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);
     }
 }
 
@@ -1879,6 +1879,9 @@ __device__ __forceinline__ void fw_range_inst_out(char *inst, uint32_t inst_cap,
 #ifndef FW_RANGE_YR
 #define FW_RANGE_YR 4  // rounds of a YOUNG workgroup: it covers FW_RANGE_YR * 256 ring slots
 #endif
+#ifndef FW_RANGE_PF_ALL
+#define FW_RANGE_PF_ALL 0  // 1: a YOUNG workgroup of an all-NOSPIN launch requests all its rounds up front (A/B build)
+#endif
 uint32_t fw_range_young_tile(void) { return FW_RANGE_YR * FW_BLOCK; }
 
 // INST: some segment of the launch has a WINDOWED instance buffer attached (fw_spawner_attach_instances_window): every
@@ -1909,7 +1912,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         __device__ ~Stamp() {
             if (p && threadIdx.x == 0) p[3] = __builtin_amdgcn_s_memrealtime();
         }
-    } stamp{(a.dbg & 8u) && a.ts ? a.ts + (size_t)blockIdx.x * 8u : nullptr};
+    } stamp{FW_DBG(a.dbg, 8u) && a.ts ? a.ts + (size_t)blockIdx.x * 8u : nullptr};
     if (stamp.p && tid == 0) stamp.p[0] = __builtin_amdgcn_s_memrealtime(), stamp.p[4] = D.role_k, stamp.p[5] = seg;
 #define FW_STAMP(i, dep) do { if (stamp.p && tid == 0) stamp.p[i] = __builtin_amdgcn_s_memrealtime() + ((unsigned long long)(dep) & 0ull); } while (0)
 #else
@@ -1940,17 +1943,50 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         constexpr int YR = FW_RANGE_YR;
         constexpr uint32_t YT = YR * BLK;  // (capacities are multiples of it: the host rounds them, fw_range_young_tile)
         const uint32_t ring_tiles = C / YT;
-        // (a handful of new particles -- at most one round -- have no workgroup of their own: they sit right behind the young
-        // part and are spawned by the YOUNG workgroups that own their slots, after their streaming loop)
-        const uint32_t n_fold = (a.fold_new && n_spawn_h <= (uint32_t)BLK) ? n_spawn_h : 0u;
-        const uint32_t need = min(ring_tiles, (b % YT + y_exist + n_fold + YT - 1u) / YT);
+        const uint32_t need = min(ring_tiles, (b % YT + y_exist + YT - 1u) / YT);
         if (k >= need) return;
-        const uint32_t cnt_y = (n_fold || (INST && inst != nullptr)) ? g.count[sidx] : 0u;  // (requested now, used later)
+        const uint32_t cnt_y = (INST && inst != nullptr) ? g.count[sidx] : 0u;  // (requested now, used later)
         const uint32_t rec0 = cnt_y > y_exist ? cnt_y - y_exist : 0u;  // record index of the first young particle (= n_old_in)
         uint32_t pt = b / YT + k;
         if (pt >= ring_tiles) pt -= ring_tiles;
         const uint32_t sbase = pt * YT;
         FW_STAMP(1, sbase);  // the descriptor, the pinned record and the segment record have arrived
+#if FW_RANGE_PF_ALL
+        if constexpr (ALLNOSPIN) {
+            // every round's loads requested up front (9 VGPRs per round for a type that cannot turn: the kernel's budget is set
+            // by the OLD path, which holds a whole tile): twice the bytes in flight per streaming workgroup
+            float4 q0a[YR], q1a[YR];
+            float lfa[YR];
+#pragma unroll
+            for (int r = 0; r < YR; r++) {
+                const uint32_t ir = (sbase + (uint32_t)r * BLK + tid) * 16u;
+                q0a[r] = fw_ld4w<NT == 2>(p0, ir), lfa[r] = fw_ld1w<NT == 2>(pl, ir / 4u), q1a[r] = fw_ld4w<NT == 2>(p1, ir);
+            }
+            const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
+            if (tid < keys_len) s_keys[tid] = key0;
+            for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
+            __syncthreads();
+            const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < YR; r++) {
+                const uint32_t s = sbase + r * BLK + tid;
+                uint32_t yi = s - b;  // index within the young part
+                if (s < b) yi += C;
+                const bool mine = yi < y_exist;
+                const float4 q3v = make_float4(0.0f, 0.0f, 0.0f, lfa[r]);
+                float age_new;
+                const bool surv = fw_survives(q0a[r].w, a.dt, q3v.w, &age_new);
+                bad |= mine && !surv;
+                const unsigned long long mi = (INST && inst != nullptr) ? __ballot(mine) : 0ull;
+                float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(mi) * 4u : nullptr;
+                if (mine) fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0a[r], q1a[r], q3v, q3v, age_new, W, s, rec);
+                if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
+            }
+            if (__any(bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 7u, g.err[6] = seg, g.err[7] = blockIdx.x;
+            return;
+        }
+#endif
         float4 q0c, q1c, q2c, q3c, q0n, q1n, q2n, q3n;
         float lfc, lfn;
         const uint32_t i0 = (sbase + tid) * 16u, i1 = (sbase + (uint32_t)min(1, YR - 1) * BLK + tid) * 16u;
@@ -1988,38 +2024,6 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f, lfn = lff;
         }
         if (__any(bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 7u, g.err[6] = seg, g.err[7] = blockIdx.x;
-        if (n_fold) {
-            const uint32_t n_old_y = cnt_y > y_exist ? cnt_y - y_exist : 0u;
-            const uint32_t n_sp = min(n_fold, C - min(C, n_old_y + y_exist));
-            const FwOutWin Wn = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
-#pragma unroll 1
-            for (int r = 0; r < YR; r++) {
-                const uint32_t s = sbase + r * BLK + tid;
-                uint32_t yi = s - b;
-                if (s < b) yi += C;
-                const bool is_new = yi >= y_exist && yi - y_exist < n_sp;
-                if (!__any(is_new)) continue;  // wave-uniform
-                if (is_new) {
-                    const uint32_t kk = yi - y_exist;
-                    uint32_t oi = Rc.op0;
-                    for (uint32_t x = Rc.op0; x < Rc.op0 + Rc.op_n; x++)
-                        if (kk >= a.ops[x].rel_base && kk - a.ops[x].rel_base < a.ops[x].n) oi = x;
-                    const FwOp &op = a.ops[oi];
-                    const FwSpawnOut so = fw_spawn_one(g.emits[op.emit], g.seed, op.serial_base + (kk - op.rel_base),
-                                                       fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
-                                                       fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
-                                                       fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
-                    float age_new;
-                    if (!fw_survives(so.q0.w, a.dt, so.q3.w, &age_new)) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 8u, g.err[6] = seg, g.err[7] = kk;
-                    // (the record goes through the lane's own slot of the wave's LDS area: no private array, no scratch)
-                    float4 *rec4 = (INST && inst != nullptr) ? s_inst_wave + lane * 4u : nullptr;
-                    fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, Wn, s, rec4);
-                    if (INST && inst != nullptr && rec0 + yi < inst_cap)
-                        for (uint32_t x = 0; x < 4; x++) fw_st4(inst + (size_t)(rec0 + yi) * 64u, x, rec4[x]);
-                }
-            }
-            if (n_sp < n_fold && tid == 0 && k + 1u == need) atomicOr(g.err, FW_ERR_CAPACITY);
-        }
         return;
     }
 
@@ -2030,7 +2034,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     const uint32_t n_spawn = min(n_spawn_h, room);
 
     if (role == FW_RANGE_NEW) {
-        if ((a.fold_new && n_spawn_h <= (uint32_t)BLK) || k * BLK >= n_spawn_h) return;  // (at most one round: the YOUNG workgroups spawn them)
+        if (k * BLK >= n_spawn_h) return;
         const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
         if (tid < keys_len) s_keys[tid] = key0;
         for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
@@ -2078,7 +2082,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             g.count[oidx] = nc, g.spawned[oidx] = 0, g.appended[oidx] = 0, g.ndestroyed[seg] = 0;
             if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;
             if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-            if (!(a.dbg & 128u)) atomicAdd(g.stats, (unsigned long long)nc);
+            if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)nc);
         }
         return;
     }
@@ -2179,7 +2183,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         g.ndestroyed[seg] = n_old_in - n_old_out;
         if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        if (!(a.dbg & 128u)) atomicAdd(g.stats, (unsigned long long)(n_old_in + y_exist + n_spawn));
+        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)(n_old_in + y_exist + n_spawn));
     }
 }
 
@@ -2336,7 +2340,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpda
         g.ndestroyed[seg] = n_tot - nc;
         if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        if (!(a.dbg & 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
+        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
     }
 }
 
@@ -2499,7 +2503,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
         if (lb_needed && tid == 0)
             __hip_atomic_store(&g.nest_status[tile], fw_pack_status(tag, FW_ST_AGG, tile_total), RLX, AGENT);
         uint32_t excl = 0;
-        if (lb_needed && !(dbg & 64u)) {  // (FW_DEBUG 64: profiling only, no look-back)
+        if (lb_needed && !FW_DBG(dbg, 64u)) {  // (FW_DEBUG 64: profiling only, no look-back)
             bool timed_out = false;
             excl = fw_lookback<FW_BLOCK, NW, LBW>(g.nest_status, op.first_tile, tile, tag, spin_limit * 64u + 1024u, s_lb,
                                                    &timed_out);
@@ -2521,7 +2525,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
                 if ((uint32_t)w < wave) woff += s_w[r][w];
                 run += s_w[r][w];
             }
-            const uint32_t tw = (dbg & 32u) ? 0u : s_w[r][wave];  // wave-uniform (FW_DEBUG 32: profiling only, no children)
+            const uint32_t tw = FW_DBG(dbg, 32u) ? 0u : s_w[r][wave];  // wave-uniform (FW_DEBUG 32: profiling only, no children)
             if (tw == 0) continue;
             const uint32_t idx = base + r * FW_BLOCK + tid;
             s_inc[wave][lane] = inc[r];

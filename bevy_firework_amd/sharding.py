@@ -130,6 +130,10 @@ class ShardedParticleSystem:
     @property
     def global_live_history(self) -> List[int]:
         """all-reduced live count of every frame reduced so far (synchronises: copies the buckets to the host)"""
+        # The bucket copy and the collective were enqueued on the SYSTEM's stream (a non-blocking one); `tolist` copies on
+        # torch's current stream, which nothing orders behind it: wait for the producer stream first.
+        if self._buckets and self._device_ring and self._stream is not None:
+            self._stream.synchronize()
         for b in self._buckets:
             self._history += [int(x) for x in b.tolist()]
         self._buckets = []

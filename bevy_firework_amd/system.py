@@ -238,14 +238,23 @@ class ParticleSystem:
         self.spawners.pop(data.handle, None)
 
     def _push_origins(self) -> None:
-        for d in self.spawners.values():
+        """the transforms of ALL spawners in one call (fw_ctx_set_origins): spawn_particles reads them for every spawner
+        entity of the query in one system (core.rs:377, 432-435)"""
+        n = len(self.spawners)
+        if not n:
+            return
+        handles = (C.c_int32 * n)()
+        tr = (C.c_float * (3 * n))()
+        ro = (C.c_float * (4 * n))()
+        for i, d in enumerate(self.spawners.values()):
             # SpawnTransformMode (core.rs:432-435): Global -> GlobalTransform.compute_transform(), Local -> Transform
             t = d.transform
             if d.settings.spawn_transform_mode == S.SpawnTransformMode.Global and d.global_transform is not None:
                 t = d.global_transform
-            tr = (C.c_float * 3)(*[float(c) for c in t.translation])
-            ro = (C.c_float * 4)(*[float(c) for c in t.rotation])
-            self._check(self._lib.fw_spawner_set_origin(self._ctx, d.handle, tr, ro))
+            handles[i] = d.handle
+            tr[3 * i:3 * i + 3] = [float(c) for c in t.translation]
+            ro[4 * i:4 * i + 4] = [float(c) for c in t.rotation]
+        self._check(self._lib.fw_ctx_set_origins(self._ctx, n, handles, tr, ro))
 
     def step(self, dt: float) -> None:
         """Enqueue one frame (spawn_particles + update_particles) without touching transforms or callbacks."""

@@ -359,13 +359,16 @@ class ParticleSystemPlugin {
 
     // one run of the chained systems (plugin.rs:46-60)
     void update(float dt) {
+        // the transforms of all spawners in ONE call: spawn_particles walks every spawner of the query (core.rs:377)
+        origin_h_.clear(), origin_t_.clear(), origin_r_.clear();
         for (auto *d : spawners_) {
             const Transform &t = (d->settings.spawn_transform_mode == SpawnTransformMode::Global && d->has_global)
                                      ? d->global_transform : d->transform;  // core.rs:432-435
-            const float tr[3] = {t.translation.x, t.translation.y, t.translation.z};
-            const float ro[4] = {t.rotation.x, t.rotation.y, t.rotation.z, t.rotation.w};
-            check(fw_spawner_set_origin(ctx_, d->handle, tr, ro));
+            origin_h_.push_back(d->handle);
+            origin_t_.insert(origin_t_.end(), {t.translation.x, t.translation.y, t.translation.z});
+            origin_r_.insert(origin_r_.end(), {t.rotation.x, t.rotation.y, t.rotation.z, t.rotation.w});
         }
+        check(fw_ctx_set_origins(ctx_, (uint32_t)origin_h_.size(), origin_h_.data(), origin_t_.data(), origin_r_.data()));
         check(fw_step(ctx_, dt));
         for (auto *d : spawners_) {
             for (size_t i = 0; i < d->settings.particle_settings.size(); i++)
@@ -402,6 +405,8 @@ class ParticleSystemPlugin {
     fw_ctx *ctx_ = nullptr;
     std::vector<ParticleSpawnerData *> spawners_;
     uint32_t next_uid_ = 0;
+    std::vector<fw_spawner> origin_h_;  // scratch of update(): handles / translations / rotations of fw_ctx_set_origins
+    std::vector<float> origin_t_, origin_r_;
 };
 
 inline fw_ctx *ParticleSpawnerData::raw_() { return sys->raw(); }

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 3
+#define FW_ABI_VERSION 4
 /* (no FW_MAX_TYPES / FW_MAX_EMISSIONS / FW_MAX_KEYS / FW_MAX_COLLIDERS: the reference's Vec<ParticleSettings>,
  * Vec<EmissionSettings> (core.rs:178-185), curve sample vectors (curve.rs:40-75) and collider world are unbounded, and so
  * are the descriptors below -- FW_EINVAL is for input the reference itself rejects.  Curves and gradients of up to
@@ -194,6 +194,11 @@ fw_status fw_spawner_destroy(fw_ctx *ctx, fw_spawner h);
 
 /* per-frame inputs the ECS owns */
 fw_status fw_spawner_set_origin(fw_ctx *ctx, fw_spawner h, const float translation[3], const float rotation_xyzw[4]);
+/* ... for ALL spawners in one call: spawn_particles walks every spawner entity in one system (core.rs:377), and a host with
+ * thousands of them would otherwise cross the FFI once per spawner per frame.  handles[n], translations[n][3],
+ * rotations_xyzw[n][4]; all-or-nothing: one invalid handle -> FW_EINVAL and no origin changes. */
+fw_status fw_ctx_set_origins(fw_ctx *ctx, uint32_t n, const fw_spawner *handles, const float *translations,
+                             const float *rotations_xyzw);
 fw_status fw_spawner_set_parent_velocity(fw_ctx *ctx, fw_spawner h, const float v[3]); /* core.rs:276,444-448 */
 fw_status fw_spawner_set_modifier(fw_ctx *ctx, fw_spawner h, float scale, float speed); /* EffectModifier core.rs:323-327 */
 fw_status fw_spawner_queue(fw_ctx *ctx, fw_spawner h, uint64_t count);                  /* queue_particles core.rs:284-286 */
@@ -240,7 +245,10 @@ fw_status fw_spawner_attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, 
  * fw_spawner_instance_window after the step (one readback: the count has to be read anyway).  `first` is 0 on most update
  * paths; a particle type with a lifetime RANGE that the library keeps in a ring numbers its records from the particles the
  * step destroys (first = their number): with the plain attach above such a type is moved to the compacting path, with this
- * one it keeps its in-place update.  Records beyond `cap` are dropped; d_out = NULL detaches. */
+ * one it keeps its in-place update.  The buffer is indexed from 0, not from `first`: `cap` must cover first + count --
+ * a buffer of the particle type's capacity always does (first + count never exceeds the live count before the step);
+ * records at an index >= cap are dropped, so a buffer sized for the live count alone loses its last `first` records.
+ * d_out = NULL detaches. */
 fw_status fw_spawner_attach_instances_window(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap);
 fw_status fw_spawner_instance_window(fw_ctx *ctx, fw_spawner h, uint32_t type, uint64_t *first, uint64_t *count);
 /* update_aabbs reduction (render.rs:677-703), world space; *any = 0 when no particles */

@@ -26,6 +26,21 @@ def test_gpus_2_without_a_launcher_starts_two_ranks():
     out = lines[0]
     assert out["launch_check"] and out["self_launched"]
     assert out["rccl_ranks"] == 2 and out["ranks_seen"] == 2 and out["n_gpus"] == 2
+    # ... and the line is the one a real N > 1 run prints, assembled by the same code from stand-in numbers: it carries the
+    # whole-job figures, a roofline object with every rank's kernel in it and a CPU baseline (round 3's N > 1 line had
+    # `cpu_baseline: null` and described rank 0 only)
+    assert out["scaling"] == "strong" and out["config"]["workload"].startswith("configs[4]")
+    assert out["value"] == (1000 + 2000) / 1.1 and out["ms_per_step"] == 1.1 / 3 * 1e3  # sum over ranks / the slowest rank
+    assert out["config"]["per_rank_live"] == [100, 200] and out["config"]["live_particles"] == 300
+    assert len(out["config"]["per_rank_ms_per_step"]) == 2
+    roof = out["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "per_rank", "kernel_us_min", "kernel_us_max"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert [r["rank"] for r in roof["per_rank"]] == [0, 1] and all(r["frac"] > 0 for r in roof["per_rank"])
+    assert roof["frac"] == min(r["frac"] for r in roof["per_rank"]) and roof["kernel_us_max"] == 51.0
+    cpu = out["cpu_baseline"]
+    assert cpu is not None and cpu["value"] > 0 and cpu["unit"] == "particles/s" and cpu["kind"] == "port" and cpu["cores"] >= 1
 
 
 def test_gpus_n_with_too_few_devices_fails_loudly():

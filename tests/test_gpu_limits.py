@@ -86,6 +86,36 @@ def test_more_ring_types_than_one_fifo_launch_holds(monkeypatch):
                     p.check(exact_all=True, what=f"frame {fr} spawner {k}")
 
 
+@pytest.mark.parametrize("defaults", [False, True])
+def test_ten_global_emitters_feed_one_constant_lifetime_type(system, monkeypatch, defaults):
+    """more Global entries on ONE one-lifetime type than a FIFO launch carries spawn ops for (FW_INLINE_OPS = 8): the type
+    must not become a FIFO ring (its ops would overflow the launch's argument block) -- it takes the range ring or the
+    compacting path; with the product's default thresholds too (capacity >= 32768 is what made it a FIFO ring before)"""
+    if defaults:
+        if system.path != "fifo":
+            pytest.skip("one run with the product's defaults is enough")
+        for k in ("FW_FIFO", "FW_FIFO_MIN", "FW_RANGE", "FW_RANGE_MIN"):
+            monkeypatch.delenv(k, raising=False)
+    from bevy_firework_amd.system import ParticleSystem
+
+    ps = S.ParticleSettings(lifetime=S.RandF32.constant(0.5), linear_drag=0.1,
+                            base_color=S.FireworkGradient.uneven_samples(workloads.STRESS_GRADIENT))
+    es = [S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(9000.0 + 700.0 * k),
+                             initial_velocity=S.RandVec3(S.RandF32(1.0, 5.0), (0.0, 1.0, 0.0), 0.0)) for k in range(10)]
+    with ParticleSystem(device=0, seed=SEED) as fresh:  # (the knobs are read when a context is created)
+        pair = Pair(fresh, S.ParticleSpawner([ps], es), S.Transform((0.0, 0.5, 0.0)), seed=SEED, uid=77)
+        path = pair.gpu.update_path(0)[0]
+        assert path != "fifo", path
+        if defaults:
+            assert path == "range", path  # ~58k live particles: well above the range threshold
+        for fr in range(50):
+            fresh.update(DT)
+            pair.step_cpu(DT)
+            if fr % 10 == 9:
+                pair.check(exact_all=True, what=f"frame {fr}")
+        assert pair.gpu.counts()[0] > 40000
+
+
 def test_gradients_longer_than_the_staging_area(system):
     """a 33-key uneven gradient (still staged in LDS), and a type with a 200-key base colour, a 150-key emissive colour and a
     300-key scale curve (2350 floats: read from device memory by the feature kernels) next to an ordinary type"""
@@ -139,3 +169,39 @@ def test_a_hundred_colliders_that_move_every_frame(system):
         if fr % 12 == 11:
             pair.check(exact_all=True, what=f"frame {fr}")
     assert pair.gpu.count(0) > 4000
+
+
+def test_batched_origins_are_all_or_nothing(system):
+    """fw_ctx_set_origins (one FFI call for the transforms of every spawner, core.rs:377): the same effect as one
+    fw_spawner_set_origin per spawner; one invalid handle -> FW_EINVAL and no origin changes"""
+    import ctypes as C
+
+    from bevy_firework_amd import _ffi
+    from bevy_firework_amd.system import FwError
+
+    pairs = []
+    for k in range(5):
+        sp, _ = workloads.stress_test(rate=3000.0)
+        pairs.append(Pair(system, sp, S.Transform((float(k), 0.1, 0.0)), seed=SEED, uid=500 + k))
+    for fr in range(20):
+        for k, p in enumerate(pairs):  # every spawner moves every frame: update() pushes all of them in one call
+            tf = S.Transform((float(k) + 0.01 * fr, 0.1, 0.02 * fr))
+            p.gpu.set_transform(tf)
+            p.cpu.set_origin(tf.translation, tf.rotation)
+        system.update(DT)
+        for p in pairs:
+            p.step_cpu(DT)
+    lib, ctx = system._lib, system._ctx
+    n = len(pairs)
+    handles = (C.c_int32 * n)(*[p.gpu.handle for p in pairs])
+    handles[3] = 9999  # not a spawner
+    tr = (C.c_float * (3 * n))(*([100.0] * (3 * n)))
+    ro = (C.c_float * (4 * n))(*([0.0, 0.0, 0.0, 1.0] * n))
+    assert lib.fw_ctx_set_origins(ctx, n, handles, tr, ro) == _ffi.FW_EINVAL
+    for fr in range(20, 40):  # nobody moved to x = 100: step() keeps the origins of the last update()
+        system.step(DT)
+        for p in pairs:
+            p.step_cpu(DT)
+    for k, p in enumerate(pairs):
+        p.check(what=f"spawner {k}")
+        assert p.gpu.counts()[0] > 1000

@@ -457,11 +457,12 @@ def test_attached_instances_replace_the_scale_and_colour_planes(system):
             # 4 B of scale + 16 B per non-constant gradient no longer stored (the path of type 1 may have changed: a range ring
             # continues on the compacting path once records are wanted)
             # (a range ring continues on the compacting path once records are wanted: 4 B more for the lifetime plane it rewrites)
-            assert attached[0][1] == before[0] - 36 + (4 if attached[0][0] != pair_path0 else 0), (before, attached)
+            # (+ the 64-byte record itself, which the update now writes per survivor)
+            assert attached[0][1] == before[0] - 36 + 64 + (4 if attached[0][0] != pair_path0 else 0), (before, attached)
         if fr == 100:
             for t in (0, 1):
                 pair.gpu.attach_instances(0, 0, particle_type=t)
-            assert pair.gpu.update_path(0)[1] == attached[0][1] + 36
+            assert pair.gpu.update_path(0)[1] == attached[0][1] + 36 - 64
             check("right after detaching")
         dt = np.float32(0.55 if fr == 70 else DT)  # frame 70: longer than type 0 lives -- born and destroyed in one frame
         system.update(dt)
