@@ -76,33 +76,34 @@ FW_HD bool fw_ray_collider(const FwCollider &c, fw_v3 origin, fw_v3 dir, float m
     const fw_q4 qi{-q.x, -q.y, -q.z, q.w};  // conjugate = inverse of a unit quaternion
     const fw_v3 ol = fw_quat_mul_vec3(qi, fw_sub3(origin, cpos));
     const fw_v3 dl = fw_quat_mul_vec3(qi, dir);
-    const float o3[3] = {ol.x, ol.y, ol.z}, d3[3] = {dl.x, dl.y, dl.z};
-    bool inside = true;
-    for (int i = 0; i < 3; i++) inside = inside && fabsf(o3[i]) <= c.half_extents[i];
-    if (inside) {
+    // (the three slabs written out one by one, in axis order: indexed arrays of three would live in scratch memory on the device)
+    const float hx = c.half_extents[0], hy = c.half_extents[1], hz = c.half_extents[2];
+    if (fabsf(ol.x) <= hx && fabsf(ol.y) <= hy && fabsf(ol.z) <= hz) {  // inside (or on) the box
         *hit = FwRayHit{0.0f, fw_v3{0.0f, 0.0f, 0.0f}};
         return true;
     }
     float tnear = -INFINITY, tfar = INFINITY;
     int axis = 0;
     float sign = 0.0f;
-    for (int i = 0; i < 3; i++) {
-        const float h = c.half_extents[i];
-        if (d3[i] == 0.0f) {
-            if (fabsf(o3[i]) > h) return false;
-            continue;
-        }
-        const float inv = 1.0f / d3[i];
-        float t1 = (-h - o3[i]) * inv, t2 = (h - o3[i]) * inv;
-        float s = -1.0f;  // entering through the -h face: outward normal -e_i
-        if (t1 > t2) {
-            const float tmp = t1;
-            t1 = t2, t2 = tmp, s = 1.0f;
-        }
-        if (t1 > tnear) tnear = t1, axis = i, sign = s;
-        if (t2 < tfar) tfar = t2;
-        if (tnear > tfar) return false;
+#define FW_SLAB(o, d, h, i)                                                              \
+    if ((d) == 0.0f) {                                                                   \
+        if (fabsf(o) > (h)) return false;                                                \
+    } else {                                                                             \
+        const float inv = 1.0f / (d);                                                    \
+        float t1 = (-(h) - (o)) * inv, t2 = ((h) - (o)) * inv;                           \
+        float s = -1.0f; /* entering through the -h face: outward normal -e_i */         \
+        if (t1 > t2) {                                                                   \
+            const float tmp = t1;                                                        \
+            t1 = t2, t2 = tmp, s = 1.0f;                                                 \
+        }                                                                                \
+        if (t1 > tnear) tnear = t1, axis = (i), sign = s;                                \
+        if (t2 < tfar) tfar = t2;                                                        \
+        if (tnear > tfar) return false;                                                  \
     }
+    FW_SLAB(ol.x, dl.x, hx, 0)
+    FW_SLAB(ol.y, dl.y, hy, 1)
+    FW_SLAB(ol.z, dl.z, hz, 2)
+#undef FW_SLAB
     if (!(tnear >= 0.0f && tnear <= max_distance)) return false;
     fw_v3 nl{0.0f, 0.0f, 0.0f};
     if (axis == 0) nl.x = sign;

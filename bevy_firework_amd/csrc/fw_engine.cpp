@@ -88,6 +88,8 @@ struct alignas(64) SegHost {
     bool in_use = false;
     bool nested_fed = false;    // receives Nested children: count not host-predictable
     bool collides = false;      // the type has collision settings (core.rs:137-138): frames run the collision path
+    bool coll_inplace = false;  // ... without destroy_on_collision: a bounce changes neither age, lifetime nor order
+                                // (core.rs:607-643), so the type may live in a ring (the COLL instantiations of the ring kernels)
                                 // (also set for a type whose curve keys exceed the LDS staging area: the same feature
                                 // kernels read them from device memory -- SegHost::bigkeys)
     bool auto_capacity = false; // capacity was derived (fw_particle_settings.capacity == 0): the library may grow it
@@ -221,6 +223,13 @@ struct SpawnerHost {
     bool initialized = false, finished_notified = false;
     float origin_pos[3] = {0, 0, 0}, origin_rot[4] = {0, 0, 0, 1}, parent_vel[3] = {0, 0, 0};
     float mod_scale = 1.f, mod_speed = 1.f;
+    // An internal error of an update kernel (FwGlobals::err_host) named one of this spawner's particle types: its particle
+    // state can no longer be trusted -- an in-place ring update that went wrong has overwritten its own input and cannot be
+    // redone.  Sticky: fw_step refuses to run and every call that reads or writes the spawner's particles returns FW_EHIP
+    // until fw_spawner_update_settings rebuilds it (which drops all particles, core.rs:343-365) or it is destroyed.
+    bool poisoned = false;
+    // ... and the rebuilt spawner keeps its particle types off the in-place ring paths
+    bool no_rings = false;
 };
 
 template <typename T>
@@ -314,6 +323,8 @@ struct fw_ctx {
     // that launch reports through a pinned word (FwUpdateArgs::done_tag).  FW_OPS_ZEROCOPY=0: staged copy + events.
     bool ops_zerocopy = true;
     unsigned long long *h_done = nullptr;      // pinned; written by workgroup 0 of every update launch
+    unsigned long long *h_err = nullptr;       // pinned; FwGlobals::err_host (h_done + 4: the same allocation)
+    std::string poison_msg;                    // what poll_device_error saw
     uint64_t slot_frame[kParamRing] = {};      // frame that last used the slot through the zero-copy path (+1; 0 = free)
 
     // live-count snapshots written by the update kernel into pinned host memory
@@ -761,7 +772,11 @@ fw_status refresh_counts_exact(fw_ctx *ctx) {
     return FW_OK;
 }
 
+bool poll_device_error(fw_ctx *ctx);
+fw_status poisoned_status(fw_ctx *ctx);
 fw_status check_device_errors(fw_ctx *ctx) {
+    // (the stream has been waited for: whatever a kernel reported is in the pinned word by now)
+    const bool fresh = poll_device_error(ctx);
     uint32_t ev[8] = {};
     FW_HIP(ctx, hipMemcpy(ev, ctx->g.err, sizeof ev, hipMemcpyDeviceToHost));
     const uint32_t e = ev[0];
@@ -774,9 +789,15 @@ fw_status check_device_errors(fw_ctx *ctx) {
     if (!e) return FW_OK;
     uint32_t zero = 0;
     FW_HIP(ctx, hipMemcpy(ctx->g.err, &zero, sizeof zero, hipMemcpyHostToDevice));
-    if (e & FW_ERR_FORECAST)
-        return fail(ctx, FW_EHIP, "internal error: stale survivor-forecast entry (device flags " + std::to_string(e) + ", check " +
-                                      std::to_string(ev[5]) + ": " + std::to_string(ev[6]) + " " + std::to_string(ev[7]) + ")");
+    if (e & FW_ERR_FORECAST) {
+        // An internal check of an update kernel failed.  The spawner it names is marked (poll_device_error): its own calls
+        // refuse from now on.  Whoever synchronises first is told once; later synchronisations -- of healthy spawners -- are
+        // not failed again for an error that has been reported and contained.
+        if (!fresh) return FW_OK;
+        ctx->poison_msg += " [device flags " + std::to_string(e) + ", check " + std::to_string(ev[5]) + ": " + std::to_string(ev[6]) +
+                           " " + std::to_string(ev[7]) + "]";
+        return poisoned_status(ctx);
+    }
     if (e & FW_ERR_CAPACITY)
         return fail(ctx, FW_ECAPACITY,
                     "a particle type overflowed its device capacity; particles were dropped "
@@ -1206,6 +1227,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         }
         S.auto_capacity = p.capacity == 0;
         S.collides = p.collision.enabled != 0 || bigkeys;
+        S.coll_inplace = p.collision.enabled != 0 && p.collision.destroy_on_collision == 0 && !bigkeys;
         S.life_bound = (double)std::max(p.lifetime.min, p.lifetime.max);  // lifetime = lerp(min, max, u), u in [0, 1)
         S.win_ok = !S.nested_fed && std::isfinite(S.life_bound);
         {  // FIFO ring (SegHost::fifo): one lifetime value, no collisions; spawners whose particles emit onto their own
@@ -1224,7 +1246,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             // (a ring's spawn ops of a frame travel in the kernel arguments of its launch -- FwInlineOps, FW_INLINE_OPS of
             // them: a type fed by more Global entries than that takes the range or the compacting path, whose tiles read op
             // tables from memory)
-            S.fifo = ctx->use_fifo && !self_nested && !mixed_feed && !S.collides && p.lifetime.min == p.lifetime.max &&
+            S.fifo = ctx->use_fifo && !sp.no_rings && !self_nested && !mixed_feed && (!S.collides || S.coll_inplace) && p.lifetime.min == p.lifetime.max &&
                      n_global_feed <= FW_INLINE_OPS &&
                      std::isfinite(p.lifetime.min) && ctx->n_fifo < kMaxFifoSegs &&
                      caps[t] >= ctx->fifo_min && caps[t] < 0x40000000u &&  // (head + index stays far from 2^32)
@@ -1247,7 +1269,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             // (in a spawner WITH Nested entries: only the types no entry emits from or onto -- their Global particles need
             // no place in the frame's emission order; parents are addressed by index through a head only the device knows)
             const bool in_nested_pass = S.n_lplanes != 0 || S.nested_fed;
-            S.range = ctx->use_range && !S.fifo && !in_nested_pass && !S.collides && std::isfinite(p.lifetime.min) &&
+            S.range = ctx->use_range && !sp.no_rings && !S.fifo && !in_nested_pass && (!S.collides || S.coll_inplace) && std::isfinite(p.lifetime.min) &&
                       std::isfinite(p.lifetime.max) && T.life_lo_safe > 0.0f && caps[t] >= ctx->range_min &&
                       caps[t] <= FW_RANGE_MAX_CAPACITY;
             if (S.range) {
@@ -1465,6 +1487,34 @@ fw_status update_tile_table(fw_ctx *ctx) {
     return FW_OK;
 }
 
+// The pinned error word (FwGlobals::err_host): a kernel's internal check failed.  No synchronisation, no HIP call: fw_step and
+// every reader look here first.  The spawner the segment belongs to (every spawner, when the error names none) is marked.
+bool poll_device_error(fw_ctx *ctx) {
+    const volatile unsigned long long *w = ctx->h_err;
+    const unsigned long long v = w ? *w : 0ull;
+    if (!v) return false;
+    *ctx->h_err = 0ull;
+    const uint32_t check = (uint32_t)(v >> 32) & 0x7FFFFFFFu, seg = (uint32_t)v;
+    // (frames enqueued before the host looked here repeat the report: only a spawner that was healthy so far is news)
+    bool one = false, news = false;
+    if (seg < ctx->segs.size() && ctx->segs[seg].in_use && ctx->segs[seg].spawner >= 0 &&
+        (size_t)ctx->segs[seg].spawner < ctx->spawners.size()) {
+        SpawnerHost &sp = ctx->spawners[ctx->segs[seg].spawner];
+        news = !sp.poisoned;
+        sp.poisoned = true;
+        one = true;
+    }
+    if (!one)
+        for (auto &sp : ctx->spawners) news |= sp.alive && !sp.poisoned, sp.poisoned |= sp.alive;
+    if (!news) return false;
+    ctx->poison_msg = "internal error: check " + std::to_string(check) + " of an update kernel failed" +
+                      (one ? " for segment " + std::to_string(seg) : std::string()) +
+                      "; the particle state of the spawner is invalid -- rebuild it with fw_spawner_update_settings (drops its "
+                      "particles) or destroy it";
+    return true;
+}
+fw_status poisoned_status(fw_ctx *ctx) { return fail(ctx, FW_EHIP, ctx->poison_msg.empty() ? "spawner poisoned by an earlier internal error" : ctx->poison_msg); }
+
 SpawnerHost *get_spawner(fw_ctx *ctx, fw_spawner h) {
     if (!ctx || h < 0 || (size_t)h >= ctx->spawners.size() || !ctx->spawners[h].alive) {
         if (ctx) ctx->err = "invalid spawner handle";
@@ -1612,6 +1662,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
             return bail("hipEventCreate", e);
     if ((e = hipHostMalloc((void **)&ctx->h_done, 64, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
     *ctx->h_done = 0ull;
+    ctx->h_err = ctx->h_done + 4, *ctx->h_err = 0ull, ctx->g.err_host = ctx->h_err;
     if ((e = hipMalloc((void **)&ctx->g.err, 64)) != hipSuccess) return bail("hipMalloc", e);
     fw_memset_done(ctx->g.err, 0, 64);
     if ((e = hipMalloc((void **)&ctx->g.stats, 64)) != hipSuccess) return bail("hipMalloc", e);
@@ -1823,6 +1874,13 @@ fw_status fw_spawner_update_settings(fw_ctx *ctx, fw_spawner h, const fw_spawner
     fw_status st = validate_desc(ctx, desc);
     if (st) return st;
     if ((st = sync(ctx))) return st;
+    if (sp->poisoned) {
+        // everything enqueued on top of the invalid state has finished: what those frames reported again is not news, and the
+        // segment slots the report names are about to be reused by the rebuilt spawner
+        *ctx->h_err = 0ull;
+        const uint32_t zero = 0;
+        FW_HIP(ctx, hipMemcpy(ctx->g.err, &zero, sizeof zero, hipMemcpyHostToDevice));
+    }
     // RNG streams never replay: carry the serials of surviving emission indices
     std::vector<uint64_t> serials;
     for (const EmissionHost &e : sp->em) {
@@ -1841,6 +1899,7 @@ fw_status fw_spawner_update_settings(fw_ctx *ctx, fw_spawner h, const fw_spawner
     memcpy(sp->origin_rot, keep.origin_rot, sizeof keep.origin_rot);
     memcpy(sp->parent_vel, keep.parent_vel, sizeof keep.parent_vel);
     sp->mod_scale = keep.mod_scale, sp->mod_speed = keep.mod_speed;
+    sp->no_rings = keep.no_rings || keep.poisoned;  // (rebuilt after an internal error: compacting path only from now on)
     st = build_spawner(ctx, h, desc, &serials);
     if (st) {
         // the old particle types are gone and the new ones could not be built: the handle dies (every later call on
@@ -1861,6 +1920,11 @@ fw_status fw_spawner_destroy(fw_ctx *ctx, fw_spawner h) {
     hipSetDevice(ctx->device);
     fw_status st = sync(ctx);
     if (st) return st;
+    if (sp->poisoned) {  // (as in fw_spawner_update_settings)
+        *ctx->h_err = 0ull;
+        const uint32_t zero = 0;
+        FW_HIP(ctx, hipMemcpy(ctx->g.err, &zero, sizeof zero, hipMemcpyHostToDevice));
+    }
     if ((st = release_spawner_segments(ctx, *sp))) return st;
     *sp = SpawnerHost{};
     return FW_OK;
@@ -1923,6 +1987,11 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         ctx->prof_ns[i] += std::chrono::duration<double, std::nano>(now - prof_t).count();
         prof_t = now;
     };
+    // a spawner whose particle state an internal error invalidated (SpawnerHost::poisoned): no further frame is enqueued on
+    // top of it -- for anybody: the frame is all-or-nothing -- until it has been rebuilt or destroyed
+    poll_device_error(ctx);
+    for (const SpawnerHost &sp : ctx->spawners)
+        if (sp.alive && sp.poisoned) return poisoned_status(ctx);
     poll_snapshots(ctx);
     if (ctx->derive_ready_any) {  // types whose caller-written particles have all been through an update (see the end of fw_step)
         ctx->derive_ready_any = false;
@@ -1997,7 +2066,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         S.frame_spawn = 0;
         if (!S.in_use) continue;
         S.dead_at_end = false;  // (set again below for the segments this frame updates as range rings)
-        any_coll |= S.collides;
+        any_coll |= S.collides && !S.ring();  // (a colliding type in a ring is updated by its ring kernel)
         any_inst_general |= !S.ring() && S.inst != nullptr;
         if (S.nested_fed && nested_fed_wants_growth(S)) ctx->grow_scratch.push_back((uint32_t)si);
         if (!S.win_ok) continue;
@@ -2258,6 +2327,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     const uint32_t p = ctx->parity;
     // Particle types with collision settings (core.rs:607-624) run the count / scan / update-with-collisions launches
     // (everything materialised first, like FW_UPDATE_MODE=split); the streaming kernels never see a collider.
+    if (ctx->seg_kind_changed)  // (a colliding ring that left its mode inside the spawner loop is a compacting segment from this frame on)
+        for (const SegHost &S : ctx->segs) any_coll |= S.in_use && S.collides && !S.ring();
     const int frame_mode = any_coll ? FW_MODE_SPLIT_COLL : ctx->update_mode;
     const bool legacy = n_n != 0 || frame_mode != FW_MODE_FUSED;
 
@@ -2509,7 +2580,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         // (never on a caller-supplied stream: work the caller orders behind fw_step on ITS stream must cover the whole
         // frame, as it did before the side stream existed)
         bool side = ctx->use_fifo_stream && ctx->own_stream && total_tiles != 0 && ctx->live_ring == nullptr;
-        for (const SegHost &S : ctx->segs) side &= !(S.in_use && S.fifo && (S.fifo_mat || S.inst != nullptr));
+        // (... nor with a colliding ring: a new collider set travels in the MAIN stream, fw_ctx_set_colliders)
+        for (const SegHost &S : ctx->segs) side &= !(S.in_use && S.fifo && (S.fifo_mat || S.inst != nullptr || S.collides));
         if (side && (!ctx->fifo_last_side || ctx->main_reads_ring)) {
             // the previous ring launch, or a reader of ring data, sits on the main stream: this launch comes after it
             FW_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
@@ -2616,6 +2688,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             f_tiles += F.n_tiles;
             f_bytes += (uint64_t)live_tiles * ftile * (S.nospin ? 104u : 164u);
             fa.any_inst |= S.inst != nullptr ? 1u : 0u;
+            fa.any_coll |= S.collides ? 1u : 0u;
             S.head = (uint32_t)(((uint64_t)S.head + dead) % S.capacity);
             if (!S.fifo_dev) S.ub = n_in + n_spawn - std::min(dead, n_in + n_spawn);  // exact
         }
@@ -2643,7 +2716,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             const size_t i = (size_t)(f - ctx->birth_age.front().frame);
             return i < ctx->birth_age.size() ? ctx->birth_age[i].age : 0.0f;  // this frame's own cohort: born with age 0
         };
-        bool dirty = ctx->r_force, all_nospin = true, range_inst = false;
+        bool dirty = ctx->r_force, all_nospin = true, range_inst = false, range_coll = false;
         uint64_t r_bytes = 0;  // what the launch streams, roughly (the non-temporal form of the kernel: fw_ctx::nt_bytes)
         size_t oi = 0;
         for (uint32_t si = 0; si < n_seg; si++) {
@@ -2651,6 +2724,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             if (!S.in_use || !S.range) continue;
             all_nospin &= S.nospin;
             range_inst |= S.inst != nullptr;
+            range_coll |= S.collides;
             r_bytes += (uint64_t)S.ub * (S.nospin ? 104u : 164u);
             S.dead_at_end = true;
             // cohorts that are no longer provably too young to die join the old part: the boundary moves, nothing is copied
@@ -2771,6 +2845,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             // (the OLD workgroups of a segment dispatched n segments ahead of its other ones: measured, no gain --
             // profiles/r03/range_old_ahead.txt)
             const size_t nr = rs.size();
+            // (XCD-aware order -- the runs of eight consecutive segments interleaved entry by entry, so that the workgroups of one
+            // segment share an XCD and its L2 -- was built and measured in round 4: nothing at one GPU's share of configs[4]
+            // (86.4 against 86.5 us), 2.5 % slower at configs[2]: profiles/r04/range_xcd_order_ab.txt)
             for (size_t i = 0; i < nr && ok; i++) put_old(rs[i]), put_rest(rs[i]);
             for (size_t i = 0; i < nr && ok; i++) put_tail(rs[i]);
             if (!ok) return fail(ctx, FW_EHIP, "internal error: range table overflow");
@@ -2791,6 +2868,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             ra.total_tiles = ctx->r_total, ra.parity = p, ra.epoch = a.epoch, ra.spin_limit = ctx->spin_limit, ra.dbg = ctx->dbg;
             ra.dt = dt;
             ra.any_inst = range_inst ? 1u : 0u;
+            ra.any_coll = range_coll ? 1u : 0u;
             ra.done_tag = a.done_tag, ra.done_value = a.done_value;
             ra.host_counts = a.host_counts, ra.live_out = a.live_out, ra.live_next = a.live_next;
             ra.ts = ctx->d_rts;
@@ -2858,6 +2936,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
 fw_status fw_spawner_counts(fw_ctx *ctx, fw_spawner h, uint32_t *per_type, uint32_t n_types) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || !per_type) return FW_EINVAL;
+    if (poll_device_error(ctx), sp->poisoned) return poisoned_status(ctx);
     hipSetDevice(ctx->device);
     std::vector<uint32_t> c;
     fw_status st = read_counts(ctx, c);
@@ -2869,6 +2948,7 @@ fw_status fw_spawner_counts(fw_ctx *ctx, fw_spawner h, uint32_t *per_type, uint3
 fw_status fw_spawner_active(fw_ctx *ctx, fw_spawner h, int32_t *out) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || !out) return FW_EINVAL;
+    if (poll_device_error(ctx), sp->poisoned) return poisoned_status(ctx);
     hipSetDevice(ctx->device);
     std::vector<uint32_t> c;
     fw_status st = read_counts(ctx, c);
@@ -2880,6 +2960,7 @@ fw_status fw_spawner_active(fw_ctx *ctx, fw_spawner h, int32_t *out) {
 fw_status fw_spawner_poll_finished(fw_ctx *ctx, fw_spawner h, int32_t *out) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || !out) return FW_EINVAL;
+    if (poll_device_error(ctx), sp->poisoned) return poisoned_status(ctx);
     hipSetDevice(ctx->device);
     std::vector<uint32_t> c;
     fw_status st = read_counts(ctx, c);
@@ -2933,6 +3014,7 @@ fw_status fw_spawner_read_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
                                     uint64_t *n_out) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || type >= sp->seg.size()) return FW_EINVAL;
+    if (poll_device_error(ctx), sp->poisoned) return poisoned_status(ctx);
     hipSetDevice(ctx->device);
     std::vector<uint32_t> c;
     fw_status st = read_counts(ctx, c);
@@ -2951,6 +3033,7 @@ fw_status fw_spawner_read_last_emitted(fw_ctx *ctx, fw_spawner h, uint32_t type,
                                        uint64_t cap, uint64_t *n_out) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || type >= sp->seg.size() || emission_index >= sp->em.size()) return FW_EINVAL;
+    if (poll_device_error(ctx), sp->poisoned) return poisoned_status(ctx);
     hipSetDevice(ctx->device);
     std::vector<uint32_t> c;
     fw_status st = read_counts(ctx, c);
@@ -2978,6 +3061,7 @@ fw_status fw_spawner_read_last_emitted(fw_ctx *ctx, fw_spawner h, uint32_t type,
 fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, const fw_particle *in, uint64_t n) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || type >= sp->seg.size() || (n && !in) || n > 0xF0000000ull) return FW_EINVAL;
+    if (poll_device_error(ctx), sp->poisoned) return poisoned_status(ctx);
     hipSetDevice(ctx->device);
     fw_status st = sync(ctx);
     if (st) return st;
@@ -3017,6 +3101,7 @@ fw_status fw_spawner_write_last_emitted(fw_ctx *ctx, fw_spawner h, uint32_t type
                                         const float *in, uint64_t n) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || type >= sp->seg.size() || emission_index >= sp->em.size() || (n && !in)) return FW_EINVAL;
+    if (poll_device_error(ctx), sp->poisoned) return poisoned_status(ctx);
     hipSetDevice(ctx->device);
     fw_status st = sync(ctx);
     if (st) return st;
@@ -3037,6 +3122,7 @@ fw_status fw_spawner_read_destroyed(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
                                     uint64_t *n_out) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || type >= sp->seg.size()) return FW_EINVAL;
+    if (poll_device_error(ctx), sp->poisoned) return poisoned_status(ctx);
     hipSetDevice(ctx->device);
     fw_status st = sync(ctx);
     if (st) return st;
@@ -3053,6 +3139,7 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
                                            uint64_t *n_upper_bound) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || type >= sp->seg.size() || !d_out) return FW_EINVAL;
+    if (poll_device_error(ctx), sp->poisoned) return poisoned_status(ctx);
     hipSetDevice(ctx->device);
     const uint32_t si = sp->seg[type];
     const SegHost &S = ctx->segs[si];
@@ -3073,6 +3160,7 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
 static fw_status attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void *d_out, uint64_t cap, bool window) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || type >= sp->seg.size() || (d_out && !cap)) return FW_EINVAL;
+    if (poll_device_error(ctx), sp->poisoned) return poisoned_status(ctx);
     hipSetDevice(ctx->device);
     fw_status st = sync(ctx);  // kernels in flight hold the old record
     // ... and whatever the caller enqueued on ITS streams to initialise the buffer has happened before a frame writes to it
@@ -3108,6 +3196,7 @@ fw_status fw_spawner_attach_instances_window(fw_ctx *ctx, fw_spawner h, uint32_t
 fw_status fw_spawner_instance_window(fw_ctx *ctx, fw_spawner h, uint32_t type, uint64_t *first, uint64_t *count) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || type >= sp->seg.size() || !first || !count) return FW_EINVAL;
+    if (poll_device_error(ctx), sp->poisoned) return poisoned_status(ctx);
     hipSetDevice(ctx->device);
     std::vector<uint32_t> c;
     fw_status st = read_counts(ctx, c);
@@ -3125,6 +3214,7 @@ fw_status fw_spawner_pack_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
                                     uint64_t *n_out) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || type >= sp->seg.size()) return FW_EINVAL;
+    if (poll_device_error(ctx), sp->poisoned) return poisoned_status(ctx);
     hipSetDevice(ctx->device);
     std::vector<uint32_t> c;
     fw_status st = read_counts(ctx, c);
@@ -3147,6 +3237,7 @@ fw_status fw_spawner_pack_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
 fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out_max[3], int32_t *any) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp || !out_min || !out_max) return FW_EINVAL;
+    if (poll_device_error(ctx), sp->poisoned) return poisoned_status(ctx);
     hipSetDevice(ctx->device);
     if (!ctx->h_aabb) FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_aabb, 8 * sizeof(float), hipHostMallocDefault));
     {

@@ -34,6 +34,10 @@ struct FwGlobals {
     unsigned long long *tile_status; // fused mode: decoupled look-back words
     float *tile_box;                 // [tiles][8] {min.xyz, epoch, max.xyz, -} of the survivors each tile stored (FwUpdateArgs::boxes)
     uint32_t *err;                   // sticky FW_ERR_* flags
+    // pinned host word: the first internal error of a kernel also lands here ({1 : 1 | check : 31 | segment : 32}, segment
+    // 0xFFFFFFFF = not tied to one), so that the NEXT fw_step sees it without a synchronisation and stops stepping the
+    // spawner it belongs to (fw_engine.cpp: poll_device_error) -- an in-place ring update that went wrong cannot be redone
+    unsigned long long *err_host;
     unsigned long long *stats;       // [0] particles that entered update (running total)
     unsigned long long *dbg_ts;      // FW_DEBUG & 8: 4 timestamps per tile of the last update (profiling)
     unsigned long long *emit_serial; // RNG serials of Nested emission entries
@@ -147,6 +151,7 @@ struct FwFifoArgs {
     uint32_t n_segs, parity, epoch, dbg;
     float dt;
     uint32_t any_inst;
+    uint32_t any_coll;  // some segment's particle type has collision settings: the launch runs the COLL instantiation (fw_kernels.hip: FwCollArm)
     // which optional planes the particle types of this launch write: bit 0 base colour (gradient not constant), bit 1
     // emissive colour, bit 2 scale (curve not constant) when all its segments agree -- the kernel is then compiled for
     // exactly that set of stores; -1: they differ, read the flags from each type
@@ -199,6 +204,7 @@ struct FwRangeArgs {
     uint32_t total_tiles, parity, epoch, spin_limit, dbg;
     float dt;
     uint32_t any_inst;              // some segment has a windowed instance buffer attached: the kernels that also write records
+    uint32_t any_coll;              // some segment's particle type has collision settings: the COLL instantiation (FwCollArm)
     unsigned long long *done_tag;   // as in FwUpdateArgs
     unsigned long long done_value;
     unsigned long long *host_counts;

@@ -29,6 +29,14 @@
 // small device helpers
 // ---------------------------------------------------------------------------------
 
+// an internal error (a check of the host's bookkeeping against the particles failed, a look-back wait ran out): the device
+// flags for whoever synchronises next, and the pinned word the next fw_step looks at (FwGlobals::err_host)
+__device__ __forceinline__ void fw_raise(const FwGlobals &g, uint32_t check, uint32_t seg, uint32_t x) {
+    atomicOr(g.err, FW_ERR_FORECAST);
+    g.err[5] = check, g.err[6] = seg, g.err[7] = x;
+    if (g.err_host) *g.err_host = (1ull << 63) | ((unsigned long long)check << 32) | seg;
+}
+
 __device__ __forceinline__ uint32_t fw_lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -133,6 +141,31 @@ __device__ __forceinline__ uint4 fw_ld4u(const char *win, uint32_t byte_off) {
 __device__ __forceinline__ uint32_t fw_ld1u(const uint32_t *base, uint32_t idx) {
     return reinterpret_cast<const FW_GLOBAL uint32_t *>(reinterpret_cast<uintptr_t>(base))[idx];
 }
+// Bounds-checked window loads (buffer_load through a 128-bit resource descriptor): a lane whose offset falls outside
+// [0, bytes) gets zeros and costs NO memory traffic -- a negative offset wraps to a huge one, so one descriptor clips a tile at
+// both ends.  Used where a tile of a ring only partly holds the particles it is dispatched for (the ends of a range ring's
+// young part: 7-8 tiles for the 6.4 tiles of data of a configs[4] emitter -- unconditional loads fetched every slot of them).
+// The descriptor is built from workgroup-uniform values only.
+typedef __amdgpu_buffer_rsrc_t fw_rsrc;
+__device__ __forceinline__ fw_rsrc fw_make_rsrc(const char *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), (short)0, (int)bytes, 0x00020000);
+}
+template <bool NT>
+__device__ __forceinline__ float4 fw_ldb4(fw_rsrc r, uint32_t byte_off) {
+    typedef uint32_t fw_u4b __attribute__((ext_vector_type(4)));
+    const fw_u4b v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, NT ? 2 : 0);  // aux bit 1 = nt
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+template <bool SKIP, bool NT>
+__device__ __forceinline__ float4 fw_ldb4_opt(fw_rsrc r, uint32_t byte_off) {
+    if constexpr (SKIP) return make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    else return fw_ldb4<NT>(r, byte_off);
+}
+template <bool NT>
+__device__ __forceinline__ float fw_ldb1(fw_rsrc r, uint32_t byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, NT ? 2 : 0));
+}
+
 struct FwOutWin {  // output planes advanced to slot `first` (workgroup-uniform)
     char *q0, *q1, *q2, *q3, *q5, *q6, *s4;
     uint32_t first;
@@ -934,7 +967,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     if (use_fc) {
         fc_part = fw_wave_sum(fc_part);
         if (lane == 0) s_part[0][wave] = fc_part, s_part[1][wave] = new_alive;
-        if (__any(fc_bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 1u, g.err[6] = tile;
+        if (__any(fc_bad) && lane == 0) fw_raise(g, 1u, 0xFFFFFFFFu, tile);
     }
     __syncthreads();
     const unsigned long long ts1 = FW_DBG(a.dbg, 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1415,7 +1448,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     }
     fc_part = fw_wave_sum(fc_part);
     if (lane == 0) s_part[0][wave] = fc_part, s_part[1][wave] = new_alive;
-    if (__any(fc_bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 2u, g.err[6] = tile;
+    if (__any(fc_bad) && lane == 0) fw_raise(g, 2u, 0xFFFFFFFFu, tile);
     const unsigned long long tsB = FW_DBG(a.dbg, 8u) ? (__builtin_amdgcn_s_memrealtime() + (fc_part & 0u)) : 0ull;
     __syncthreads();
     const unsigned long long ts1 = FW_DBG(a.dbg, 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1427,7 +1460,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         excl += base - n_in;  // every earlier new particle survives
         // (materialised new particles come here only when the host has shown that: it does not schedule this kernel
         // for such a frame otherwise)
-        if (SPAWN == FW_SPAWN_NONE && !a.new_static && tid == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 3u, g.err[6] = tile;
+        if (SPAWN == FW_SPAWN_NONE && !a.new_static && tid == 0) fw_raise(g, 3u, 0xFFFFFFFFu, tile);
     } else if (SPAWN != FW_SPAWN_NONE && has_new) {  // look back among the new-particle tiles only
         const bool lb_needed = tis > t_spawn;
         if (lb_needed && tid == 0)
@@ -1626,11 +1659,42 @@ __device__ __forceinline__ void fw_fifo_inst_out(const FwFifoSeg &F, char *inst,
     }
 }
 
+// The physics_avian arm of update_particles (core.rs:607-624) for particle types that live in rings: a type with collision
+// settings and destroy_on_collision == false changes neither age, lifetime nor the order of its particles -- a bounce only
+// replaces `position + velocity * dt` and the velocity the drag step starts from (core.rs:626-643) -- so the "deaths are a
+// prefix" / "nobody young dies" arguments of the ring paths hold unchanged and the type keeps its in-place update
+// (examples/stress_test_collision.rs:92-115 is such a type).  COLL instantiations of the ring kernels only: the plain ones
+// never see a collider and keep their register budget.  destroy_on_collision types stay on the count -> scan ->
+// fw_k_update_coll path (a collision that removes a particle changes the survivor count).
+struct FwCollArm {
+    bool on;  // the workgroup's particle type has collision settings (workgroup-uniform)
+    float restitution, friction;
+    uint32_t mask;
+};
+template <bool COLL>
+__device__ __forceinline__ FwCollArm fw_coll_arm(const FwGlobals &g, uint32_t type_idx) {
+    if constexpr (COLL) {
+        const FwTypeColl TC = g.type_coll[type_idx];
+        return FwCollArm{(TC.coll_flags & FW_COLL_ENABLED) != 0u, TC.coll_restitution, TC.coll_friction, TC.coll_mask};
+    } else {
+        return FwCollArm{false, 0.0f, 0.0f, 0u};
+    }
+}
+// position / velocity after particle_collision (a particle that meets nothing comes out as position + velocity * dt, velocity)
+template <bool COLL>
+__device__ __forceinline__ void fw_coll_step(const FwGlobals &g, const FwCollArm &A, bool active, float dt, float4 q0, float4 q1,
+                                             fw_v3 *cpos, fw_v3 *cvel) {
+    *cpos = fw_v3{q0.x, q0.y, q0.z}, *cvel = fw_v3{q1.x, q1.y, q1.z};
+    if constexpr (COLL) {
+        if (A.on && active) fw_particle_collision(cpos, cvel, dt, A.restitution, A.friction, false, A.mask, g.colliders, g.n_colliders);
+    }
+}
+
 // WM: the optional planes this launch's particle types write (fw_integrate_store), or -1 = read from the type
 #ifndef FW_FIFO_UNROLL
 #define FW_FIFO_UNROLL 4
 #endif
-template <bool INST, int WM, int NT = 0>
+template <bool INST, int WM, int NT = 0, bool COLL = false>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifoArgs a, FwInlineOps inl) {
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
@@ -1703,6 +1767,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         if (a.done_tag) *a.done_tag = a.done_value;
     }
     const FwType T = g.types[F.type_idx & ~FW_TYPE_IDX_NOSPIN];
+    const FwCollArm CA = fw_coll_arm<COLL>(g, F.type_idx & ~FW_TYPE_IDX_NOSPIN);
     if (tid < F.keys_len) s_keys[tid] = key0;
     for (uint32_t i = tid + BLK; i < F.keys_len; i += BLK) s_keys[i] = g.keys[F.keys_off + i];
     __syncthreads();
@@ -1743,9 +1808,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         const bool alive = is_new && !dead;
         const unsigned long long m = __ballot(alive);
         float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(m) * 4u : nullptr;
+        fw_v3 cpos, cvel;
+        fw_coll_step<COLL>(g, CA, alive, a.dt, so.q0, so.q1, &cpos, &cvel);
         if (alive)
-            fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, nullptr, nullptr,
-                                         nullptr, false, true);
+            fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
+                                         (COLL && CA.on) ? &cvel : nullptr, nullptr, false, true);
         else if (is_new && want_destroyed)  // born and destroyed in the same frame (dt >= lifetime)
             fw_store_destroyed(F.destroyed, buf, C, s, false, T, s_keys, so.q0, so.q1, so.q2, so.q3, age_new, i);
         fw_fifo_inst_out<INST, NT == 2>(F, inst, s_inst_wave, rec, lane, m, alive, i - n_dead);
@@ -1788,6 +1855,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
             const bool alive = mine && !dead;
             const unsigned long long m = INST ? __ballot(alive) : 0ull;
             float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(m) * 4u : nullptr;
+            fw_v3 cpos, cvel;
+            fw_coll_step<COLL>(g, CA, alive, a.dt, q0c, q1c, &cpos, &cvel);
             if (alive) {
                 if FW_DBG(a.dbg, 2u) {  // profiling only: stream without arithmetic
                     const uint32_t b16 = (s - W.first) * 16u;
@@ -1796,8 +1865,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
                     if (WM >= 0 ? (WM & 2) != 0 : W.wr6) fw_st4w<NT != 0>(W.q6, b16, q1c);
                     if (WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) fw_st1w<NT != 0>(W.s4, (s - W.first) * 4u, q1c.w);
                 } else {
-                    fw_integrate_store<true, WM, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, nullptr, nullptr, nullptr,
-                                                 false, i >= full_from);
+                    fw_integrate_store<true, WM, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
+                                                 (COLL && CA.on) ? &cvel : nullptr, nullptr, false, i >= full_from);
                 }
             }
             fw_fifo_inst_out<INST, NT == 2>(F, inst, s_inst_wave, rec, lane, m, alive, i - n_dead);
@@ -1805,11 +1874,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
             q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f;
         }
     }
-    if (__any(bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 4u, g.err[6] = F.seg, g.err[7] = blockIdx.x;
+    if (__any(bad) && lane == 0) fw_raise(g, 4u, F.seg, blockIdx.x);
     if (tis == 0 && tid == 0) {
         const uint32_t oidx = (a.parity ^ 1u) * g.max_seg + F.seg;
         if (F.mat ? (F.n_in != 0xFFFFFFFFu && F.n_in != n_in) : g.count[sidx] != n_in)
-            atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 5u, g.err[6] = F.seg, g.err[7] = n_in;
+            fw_raise(g, 5u, F.seg, n_in);
         if (F.report) *F.report = ((unsigned long long)a.epoch << 32) | c_new;
         const uint32_t nc = n_tot - min(n_dead, n_tot);
         g.count[oidx] = nc;
@@ -1880,7 +1949,8 @@ __device__ __forceinline__ void fw_range_inst_out(char *inst, uint32_t inst_cap,
 #define FW_RANGE_YR 4  // rounds of a YOUNG workgroup: it covers FW_RANGE_YR * 256 ring slots
 #endif
 #ifndef FW_RANGE_PF_ALL
-#define FW_RANGE_PF_ALL 0  // 1: a YOUNG workgroup of an all-NOSPIN launch requests all its rounds up front (A/B build)
+#define FW_RANGE_PF_ALL 1  // a YOUNG workgroup of an all-NOSPIN launch requests all its rounds up front (0: two rounds in flight;
+                          // configs[2] 321 -> 316 us, one GPU's share of configs[4] 87.9 -> 86.6 us, profiles/r04/strip_pf_ab.txt)
 #endif
 uint32_t fw_range_young_tile(void) { return FW_RANGE_YR * FW_BLOCK; }
 
@@ -1889,7 +1959,7 @@ uint32_t fw_range_young_tile(void) { return FW_RANGE_YR * FW_BLOCK; }
 // new distance from the young part)  -- both known to a tile without waiting for anybody: the records of the frame are
 // d_out[first, first + count) with first = the particles this update destroyed (n_old_in - n_old_out = ndestroyed), in list
 // order.  (An index counted from 0 would need the old part's survivor total, which only its last tile knows.)
-template <bool ALLNOSPIN, bool INST, int NT>
+template <bool ALLNOSPIN, bool INST, int NT, bool COLL = false>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
@@ -1951,6 +2021,26 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         if (pt >= ring_tiles) pt -= ring_tiles;
         const uint32_t sbase = pt * YT;
         FW_STAMP(1, sbase);  // the descriptor, the pinned record and the segment record have arrived
+        // The slots of this tile that hold young particles: [w_lo, w_lo + w_n) -- from the tile's first slot when that lies
+        // inside the young part, from b otherwise.  Loads go through descriptors clipped to that window: the partly filled tiles
+        // at the two ends of the young part fetch only what they own.  (A young part that wraps around nearly the whole ring
+        // could re-enter the tile at its end: such a tile loads all its slots, as before.)
+        uint32_t yi0 = sbase - b;
+        if (sbase < b) yi0 += C;
+        uint32_t w_lo = sbase, w_n = YT;
+        if (y_exist + YT <= C) {
+            if (yi0 < y_exist) w_n = min(YT, y_exist - yi0);
+            else w_lo = b, w_n = (b >= sbase && b - sbase < YT) ? min(sbase + YT - b, y_exist) : 0u;
+        }
+        const fw_rsrc r0 = fw_make_rsrc(p0 + (size_t)w_lo * 16u, w_n * 16u), r1 = fw_make_rsrc(p1 + (size_t)w_lo * 16u, w_n * 16u);
+        const fw_rsrc rl = fw_make_rsrc(pl + (size_t)w_lo * 4u, w_n * 4u);
+        // this lane's byte offset in the window, round r; a slot below the window gets an offset far beyond it (clipped like one
+        // above it) -- not the wrapped negative one, whose last bytes would wrap back to offset 0 in the range check
+        const int wd0 = (int)(sbase - w_lo) + (int)tid;
+        auto woff = [&](int r) -> uint32_t {
+            const int d = wd0 + r * BLK;
+            return d < 0 ? 0x7FFFFFF0u : (uint32_t)d * 16u;
+        };
 #if FW_RANGE_PF_ALL
         if constexpr (ALLNOSPIN) {
             // every round's loads requested up front (9 VGPRs per round for a type that cannot turn: the kernel's budget is set
@@ -1959,10 +2049,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             float lfa[YR];
 #pragma unroll
             for (int r = 0; r < YR; r++) {
-                const uint32_t ir = (sbase + (uint32_t)r * BLK + tid) * 16u;
-                q0a[r] = fw_ld4w<NT == 2>(p0, ir), lfa[r] = fw_ld1w<NT == 2>(pl, ir / 4u), q1a[r] = fw_ld4w<NT == 2>(p1, ir);
+                const uint32_t ir = woff(r);
+                q0a[r] = fw_ldb4<NT == 2>(r0, ir), lfa[r] = fw_ldb1<NT == 2>(rl, ir / 4u), q1a[r] = fw_ldb4<NT == 2>(r1, ir);
             }
             const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
+            const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & ~FW_TYPE_IDX_NOSPIN);
             if (tid < keys_len) s_keys[tid] = key0;
             for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
             __syncthreads();
@@ -1980,21 +2071,30 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
                 bad |= mine && !surv;
                 const unsigned long long mi = (INST && inst != nullptr) ? __ballot(mine) : 0ull;
                 float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(mi) * 4u : nullptr;
-                if (mine) fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0a[r], q1a[r], q3v, q3v, age_new, W, s, rec);
+                fw_v3 cpos, cvel;
+                fw_coll_step<COLL>(g, CA, mine, a.dt, q0a[r], q1a[r], &cpos, &cvel);
+                if (mine)
+                    fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0a[r], q1a[r], q3v, q3v, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
+                                                     (COLL && CA.on) ? &cvel : nullptr);
                 if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             }
-            if (__any(bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 7u, g.err[6] = seg, g.err[7] = blockIdx.x;
+            if (__any(bad) && lane == 0) fw_raise(g, 7u, seg, blockIdx.x);
             return;
         }
 #endif
         float4 q0c, q1c, q2c, q3c, q0n, q1n, q2n, q3n;
         float lfc, lfn;
-        const uint32_t i0 = (sbase + tid) * 16u, i1 = (sbase + (uint32_t)min(1, YR - 1) * BLK + tid) * 16u;
-        q0c = fw_ld4w<NT == 2>(p0, i0), q3c = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p3, i0 & m2), lfc = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : i0 / 4u);
-        q1c = fw_ld4w<NT == 2>(p1, i0), q2c = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p2, i0 & m2);
-        q0n = fw_ld4w<NT == 2>(p0, i1), q3n = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p3, i1 & m2), lfn = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : i1 / 4u);
-        q1n = fw_ld4w<NT == 2>(p1, i1), q2n = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p2, i1 & m2);
+        // (a type that cannot turn reads neither rotation nor angular velocity: a zero-length window; one that can reads its
+        // lifetime in Q3, not in the lifetime plane)
+        const fw_rsrc r2 = fw_make_rsrc(p2 + (size_t)w_lo * 16u, m2 ? w_n * 16u : 0u), r3 = fw_make_rsrc(p3 + (size_t)w_lo * 16u, m2 ? w_n * 16u : 0u);
+        const fw_rsrc rlf = fw_make_rsrc(pl + (size_t)w_lo * 4u, m2 ? 0u : w_n * 4u);
+        const uint32_t i0 = woff(0), i1 = woff(min(1, YR - 1));
+        q0c = fw_ldb4<NT == 2>(r0, i0), q3c = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r3, i0), lfc = fw_ldb1<NT == 2>(rlf, i0 / 4u);
+        q1c = fw_ldb4<NT == 2>(r1, i0), q2c = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r2, i0);
+        q0n = fw_ldb4<NT == 2>(r0, i1), q3n = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r3, i1), lfn = fw_ldb1<NT == 2>(rlf, i1 / 4u);
+        q1n = fw_ldb4<NT == 2>(r1, i1), q2n = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r2, i1);
         const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
+        const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & ~FW_TYPE_IDX_NOSPIN);
         if (tid < keys_len) s_keys[tid] = key0;
         for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
         __syncthreads();
@@ -2005,10 +2105,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
 #pragma unroll
         for (int r = 0; r < YR; r++) {
             const uint32_t s = sbase + r * BLK + tid;
-            const uint32_t in_ = (sbase + (uint32_t)min(r + 2, YR - 1) * BLK + tid) * 16u;  // two rounds ahead (the last re-read)
-            const float4 q0f = fw_ld4w<NT == 2>(p0, in_), q3f = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p3, in_ & m2);
-            const float lff = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : in_ / 4u);
-            const float4 q1f = fw_ld4w<NT == 2>(p1, in_), q2f = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p2, in_ & m2);
+            const uint32_t in_ = woff(min(r + 2, YR - 1));  // two rounds ahead (the last re-read)
+            const float4 q0f = fw_ldb4<NT == 2>(r0, in_), q3f = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r3, in_);
+            const float lff = fw_ldb1<NT == 2>(rlf, in_ / 4u);
+            const float4 q1f = fw_ldb4<NT == 2>(r1, in_), q2f = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r2, in_);
             if (nospin) q3c = make_float4(0.0f, 0.0f, 0.0f, lfc);
             uint32_t yi = s - b;  // index within the young part
             if (s < b) yi += C;
@@ -2018,12 +2118,16 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             bad |= mine && !surv;  // the host's cohort ages say nobody young can die
             const unsigned long long mi = (INST && inst != nullptr) ? __ballot(mine) : 0ull;
             float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(mi) * 4u : nullptr;
-            if (mine) fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec);
+            fw_v3 cpos, cvel;
+            fw_coll_step<COLL>(g, CA, mine, a.dt, q0c, q1c, &cpos, &cvel);
+            if (mine)
+                fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
+                                                 (COLL && CA.on) ? &cvel : nullptr);
             if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n, lfc = lfn;
             q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f, lfn = lff;
         }
-        if (__any(bad) && lane == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 7u, g.err[6] = seg, g.err[7] = blockIdx.x;
+        if (__any(bad) && lane == 0) fw_raise(g, 7u, seg, blockIdx.x);
         return;
     }
 
@@ -2036,6 +2140,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     if (role == FW_RANGE_NEW) {
         if (k * BLK >= n_spawn_h) return;
         const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
+        const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & ~FW_TYPE_IDX_NOSPIN);
         if (tid < keys_len) s_keys[tid] = key0;
         for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
         __syncthreads();
@@ -2060,16 +2165,22 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
                                                fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
             float age_new;
             const bool surv = fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);
-            if (!surv) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 8u, g.err[6] = seg, g.err[7] = kk;
+            if (!surv) fw_raise(g, 8u, seg, kk);
             // (the colour plane of a constant gradient holds that colour in every slot since the buffer was allocated)
             const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
-            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec);
+            fw_v3 cpos, cvel;
+            fw_coll_step<COLL>(g, CA, true, a.dt, so.q0, so.q1, &cpos, &cvel);
+            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
+                                              (COLL && CA.on) ? &cvel : nullptr);
         }
         if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, n_old_in + y_exist + kk, false);
         return;
     }
 
     // ---- OLD: in-place compaction towards the young part.  Distance d from the young part: slot = b - 1 - d.
+    // (ONE workgroup walking the few tiles of a small old part itself -- no status words, no waiting, no provisioned-but-idle
+    // workgroups -- was built and measured in round 4: the tile loop costs the kernel 9-35 VGPRs, and even at equal occupancy
+    // one GPU's share of configs[4] ran 86.4 us against 85.6 with the tiles in parallel: profiles/r04/range_seq_old_ab.txt)
     const uint32_t base = k * TILE;
     if (k == 0u && tid == 0u && n_old_in > D.n_old * TILE) {  // the host's bound of the old part was not one (internal error)
         atomicOr(g.err, FW_ERR_CAPACITY);
@@ -2102,6 +2213,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         if (nospin) q3[r] = make_float4(0.0f, 0.0f, 0.0f, lf);
     }
     const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
+    const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & ~FW_TYPE_IDX_NOSPIN);
     if (tid < keys_len) s_keys[tid] = key0;
     for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
     float age_new[R];
@@ -2127,16 +2239,19 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
 #pragma unroll
         for (int w = 0; w < NW; w++) tile_surv += s_cnt[r][w];
     const uint32_t tile = D.old_first + k;  // the segment's look-back words: [old_first, old_first + its OLD workgroups)
+    // (FW_DEBUG 256, `make ab` only -- fault injection: the segment's second OLD tile never publishes, whoever waits for it
+    // times out: tests/test_gpu_range.py drives the error path with it)
+    const bool withhold = FW_DBG(a.dbg, 256u) && k == 1u;
     uint32_t excl = 0;
     if (k != 0u) {
-        if (tid == 0) __hip_atomic_store(&a.status[tile], fw_pack_status(a.epoch, FW_ST_AGG, tile_surv), RLX, AGENT);
+        if (tid == 0 && !withhold) __hip_atomic_store(&a.status[tile], fw_pack_status(a.epoch, FW_ST_AGG, tile_surv), RLX, AGENT);
         bool timed_out = false;
         excl = fw_lookback<BLK, NW, LBW>(a.status, D.old_first, tile, a.epoch, a.spin_limit * 64u + 1024u, s_lb, &timed_out);
         // (no recount is possible: a predecessor that has not published may not have read its slots yet.  Predecessors have
         // lower workgroup indices, so they are resident or done: the wait is bounded.)
-        if (timed_out && tid == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 9u, g.err[6] = seg, g.err[7] = tile;
+        if (timed_out && tid == 0) fw_raise(g, 9u, seg, tile);
     }
-    if (tid == 0) __hip_atomic_store(&a.status[tile], fw_pack_status(a.epoch, FW_ST_INCL, excl + tile_surv), RLX, AGENT);
+    if (tid == 0 && !withhold) __hip_atomic_store(&a.status[tile], fw_pack_status(a.epoch, FW_ST_INCL, excl + tile_surv), RLX, AGENT);
     const bool want_destroyed = T.report_destroyed && want_destroyed_any;
     const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
     uint32_t run = excl;
@@ -2155,10 +2270,13 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         const uint32_t od = wbase + fw_lane_prefix(m[r]);  // survivors nearer to the young part = the new distance
         // (records: index n_old_in - 1 - od, descending with the lane -- staged in reverse so that LDS holds them ascending)
         float4 *rec = (INST && inst != nullptr) ? s_inst_wave + ((uint32_t)__popcll(m[r]) - 1u - fw_lane_prefix(m[r])) * 4u : nullptr;
+        fw_v3 cpos, cvel;
+        fw_coll_step<COLL>(g, CA, alive, a.dt, q0[r], q1[r], &cpos, &cvel);
         if (alive) {
             uint32_t s = bm1 - od;
             if (s >= C) s -= C;
-            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], W, s, rec);
+            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
+                                              (COLL && CA.on) ? &cvel : nullptr);
         }
         if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, m[r], n_old_in - 1u - od, true);
         if (!alive && valid && want_destroyed) {
@@ -2509,7 +2627,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
                                                    &timed_out);
             // (no recount is possible here: the earlier tiles have already advanced their parents' last_emitted_age.
             // Workgroups are dispatched in index order, so every predecessor is resident or done: the wait is bounded.)
-            if (timed_out && tid == 0) atomicOr(g.err, FW_ERR_FORECAST), g.err[5] = 6u, g.err[6] = tile;
+            if (timed_out && tid == 0) fw_raise(g, 6u, 0xFFFFFFFFu, tile);
         }
         const unsigned long long incl64 = (unsigned long long)excl + tile_total;
         const uint32_t incl = incl64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)incl64;
@@ -3012,6 +3130,17 @@ hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifo
                                  uint32_t total_tiles, int nt, hipEvent_t e0, hipEvent_t e1) {
     if (!total_tiles || !a.n_segs) return hipErrorInvalidValue;
     const dim3 grid(total_tiles), block(FW_BLOCK);
+    if (a.any_coll) {  // some ring of the launch collides (FwCollArm): generic write mask, plain or fully non-temporal
+        if (a.any_inst && nt == 2)
+            FW_LAUNCH_T((fw_k_update_fifo<true, -1, 2, true>), grid, block, s, e0, e1, g, a, inl);
+        else if (a.any_inst)
+            FW_LAUNCH_T((fw_k_update_fifo<true, -1, 0, true>), grid, block, s, e0, e1, g, a, inl);
+        else if (nt == 2)
+            FW_LAUNCH_T((fw_k_update_fifo<false, -1, 2, true>), grid, block, s, e0, e1, g, a, inl);
+        else
+            FW_LAUNCH_T((fw_k_update_fifo<false, -1, 0, true>), grid, block, s, e0, e1, g, a, inl);
+        return hipGetLastError();
+    }
     if (nt) {  // non-temporal forms (fw_ld4w): the generic write mask only -- beyond the Infinity Cache the compile-time one buys nothing
         if (a.any_inst && nt == 2)
             FW_LAUNCH_T((fw_k_update_fifo<true, -1, 2>), grid, block, s, e0, e1, g, a, inl);
@@ -3047,6 +3176,19 @@ template <int NT>
 static void fw_launch_update_range_t(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin, hipEvent_t e0,
                                      hipEvent_t e1) {
     const dim3 grid(a.total_tiles), block(FW_BLOCK);
+    if constexpr (NT != 1) {
+        if (a.any_coll) {  // some range ring of the launch collides (FwCollArm)
+            if (a.any_inst) {
+                if (all_nospin) FW_LAUNCH_T((fw_k_update_range<true, true, NT, true>), grid, block, s, e0, e1, g, a);
+                else FW_LAUNCH_T((fw_k_update_range<false, true, NT, true>), grid, block, s, e0, e1, g, a);
+            } else if (all_nospin) {
+                FW_LAUNCH_T((fw_k_update_range<true, false, NT, true>), grid, block, s, e0, e1, g, a);
+            } else {
+                FW_LAUNCH_T((fw_k_update_range<false, false, NT, true>), grid, block, s, e0, e1, g, a);
+            }
+            return;
+        }
+    }
     if (a.any_inst) {
         if (all_nospin)
             FW_LAUNCH_T((fw_k_update_range<true, true, NT>), grid, block, s, e0, e1, g, a);
@@ -3062,6 +3204,7 @@ static void fw_launch_update_range_t(hipStream_t s, const FwGlobals &g, const Fw
 hipError_t fw_launch_update_range(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin, int nt,
                                   hipEvent_t e0, hipEvent_t e1) {
     if (!a.total_tiles) return hipErrorInvalidValue;
+    if (a.any_coll && nt == 1) nt = 0;  // (the collision instantiations exist plain and fully non-temporal)
     if (nt == 2) fw_launch_update_range_t<2>(s, g, a, all_nospin, e0, e1);
     else if (nt == 1) fw_launch_update_range_t<1>(s, g, a, all_nospin, e0, e1);
     else fw_launch_update_range_t<0>(s, g, a, all_nospin, e0, e1);

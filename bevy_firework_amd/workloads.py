@@ -5,8 +5,8 @@ import math
 from typing import List, Tuple
 
 from .settings import (
-    EmissionMode, EmissionPacing, EmissionSettings, EmissionShape, FireworkCurve, FireworkGradient, ParticleSettings,
-    ParticleSpawner, RandF32, RandVec3, Transform,
+    Collider, EmissionMode, EmissionPacing, EmissionSettings, EmissionShape, FireworkCurve, FireworkGradient,
+    ParticleCollisionSettings, ParticleSettings, ParticleSpawner, RandF32, RandVec3, Transform,
 )
 
 DT_60 = 1.0 / 60.0
@@ -100,3 +100,40 @@ def nested(spark_rate: float = 100000.0, smoke_per_spark: float = 20.0) -> Tuple
         inherit_parent_velocity=False,
     )
     return ParticleSpawner([sparks, smoke], [e_sparks, e_smoke]), Transform((-2.0, 2.0, 0.0))
+
+
+def _quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return (aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+            aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz)
+
+
+STRESS_COLLISION_GRADIENT = [  # examples/stress_test_collision.rs:101-107
+    (0.0, (100.0, 70.0, 10.0, 1.0)), (0.7, (3.0, 1.0, 1.0, 1.0)), (0.8, (1.0, 0.3, 0.3, 1.0)),
+    (0.9, (0.3, 0.3, 0.3, 1.0)), (1.0, (0.1, 0.1, 0.1, 0.0)),
+]
+
+
+def stress_test_collision(rate: float = 80000.0):
+    """examples/stress_test_collision.rs:68-151: one emitter (Circle, cone velocity 6-8, lifetime 2 s, linear_drag 0.15) whose
+    particles bounce (restitution 0.6, friction 0.2, destroy_on_collision false) off a ground slab and an angled cube.
+    Returns (spawner, transform, colliders): the two `Collider::cuboid`s of the example as this backend's analytic boxes
+    (cuboid(x, y, z) takes full extents: half extents here)."""
+    ps = ParticleSettings(
+        lifetime=RandF32.constant(2.0), initial_scale=RandF32(0.02, 0.08), scale_curve=FireworkCurve.constant(1.0),
+        linear_drag=0.15, base_color=FireworkGradient.uneven_samples(STRESS_COLLISION_GRADIENT), pbr=False,
+        collision_settings=ParticleCollisionSettings(restitution=0.6, friction=0.2, destroy_on_collision=False),
+    )
+    es = EmissionSettings(
+        emission_pacing=EmissionPacing.rate(rate), emission_shape=EmissionShape.Circle((0.0, 1.0, 0.0), 0.3),
+        initial_velocity=RandVec3(RandF32(6.0, 8.0), (0.0, 1.0, 0.0), 30.0 / 180.0 * math.pi), inherit_parent_velocity=True,
+    )
+    h = math.pi / 8.0  # half of PI / 4
+    tf = Transform((5.0, 0.5, 0.0), (0.0, 0.0, math.sin(h), math.cos(h)))  # Quat::from_rotation_z(PI / 4.)
+    cube_rot = _quat_mul((math.sin(h), 0.0, 0.0, math.cos(h)), (0.0, math.sin(h), 0.0, math.cos(h)))  # rotation_x * rotation_y
+    colliders = [
+        Collider.Box((0.0, -0.5, 0.0), (4.0, 0.5, 4.0)),               # Collider::cuboid(8., 1., 8.) at (0, -0.5, 0)
+        Collider.Box((0.0, 0.5, 0.0), (0.5, 0.5, 0.5), cube_rot),      # Collider::cuboid(1., 1., 1.), the angled cube
+    ]
+    return ParticleSpawner([ps], [es]), tf, colliders

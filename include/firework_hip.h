@@ -51,12 +51,20 @@ typedef enum fw_status {
     FW_OK = 0,
     FW_EINVAL = -1,    /* bad argument / descriptor (mirrors the reference's panics) */
     FW_ENOMEM = -2,    /* host or device allocation failed */
-    FW_EHIP = -3,      /* a HIP call failed (message in fw_last_error) */
+    FW_EHIP = -3,      /* a HIP call failed, or an internal consistency check of an update kernel did (fw_last_error) */
     FW_ECAPACITY = -4, /* a particle type overflowed its device capacity (nested emission) */
     FW_ENODEV = -5,    /* no usable HIP device / kernels not loadable */
     FW_ESMALL = -6     /* output buffer too small; required size reported */
 } fw_status;
 
+/* Internal errors are STICKY PER SPAWNER.  The update kernels check the host's bookkeeping against the particles they load
+ * (which particles a step destroys, live counts, look-back waits).  A failed check means the library's own state is wrong;
+ * where the type is updated in place (ring paths) the frame has overwritten its input and cannot be redone.  The library
+ * then does not guess: the spawner the particle type belongs to is marked invalid, fw_step returns FW_EHIP without
+ * enqueuing anything (for any spawner: the frame is all-or-nothing) and so does every call that reads or writes that
+ * spawner's particles, until fw_spawner_update_settings rebuilds it -- sync_spawner_data (core.rs:343-365): emission state
+ * reset, all particles dropped; the rebuilt spawner stays off the in-place paths -- or fw_spawner_destroy removes it.  Other
+ * spawners keep their state. */
 typedef struct fw_ctx fw_ctx;
 typedef int32_t fw_spawner; /* handle, >= 0 */
 

@@ -299,3 +299,72 @@ def test_non_temporal_form_of_the_kernel(system, monkeypatch, case, knob):
     monkeypatch.setenv(knob, "0")
     with ParticleSystem(device=0, seed=SEED) as nt_system:  # (the knob is read when the context is created)
         case(nt_system)
+
+
+def test_an_internal_error_is_sticky_for_its_spawner_until_it_is_rebuilt():
+    """Fault injection (the `make ab` build, FW_DEBUG 256: the second OLD tile of every range ring never publishes its count):
+    whoever waits for it times out -- an in-place update that went wrong cannot be redone.  The library must not carry on as
+    if nothing happened: the NEXT fw_step refuses (FW_EHIP), every call that touches the spawner's particles refuses, the
+    neighbour spawner keeps its state, and fw_spawner_update_settings brings the spawner back -- empty, on the compacting
+    path -- after which both run and match the oracle again.  In a subprocess: the knobs and the library are per process."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ab = os.path.join(root, "bevy_firework_amd", "csrc", "libfirework_hip_ab.so")
+    if not os.path.exists(ab):
+        pytest.skip("libfirework_hip_ab.so not built (make -C bevy_firework_amd/csrc ab)")
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np
+        import oracle
+        from bevy_firework_amd import settings as S, workloads, _ffi
+        from bevy_firework_amd.system import ParticleSystem, FwError
+        from parity import Pair
+        DT = np.float32(1 / 60)
+        def spawner(lo, hi, rate):
+            ps = S.ParticleSettings(lifetime=S.RandF32(lo, hi), linear_drag=0.2)
+            es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(rate),
+                                    initial_velocity=S.RandVec3(S.RandF32(1.0, 5.0), (0.0, 1.0, 0.0), 0.0))
+            return S.ParticleSpawner([ps], [es])
+        with ParticleSystem(device=0, seed=7) as ps:
+            victim = ps.spawn(spawner(0.3, 1.5, 40000.0), uid=1)     # old part: several tiles -> parallel OLD tiles, look-back
+            bystander = Pair(ps, spawner(5.0, 9.0, 3000.0), seed=7, uid=2)  # nobody old for 5 s: one OLD tile, never waits
+            assert victim.update_path(0)[0] == "range" and bystander.gpu.update_path(0)[0] == "range"
+            frames, failed = 0, None
+            for fr in range(200):
+                try:
+                    ps.update(DT)
+                    frames += 1
+                    if fr %% 10 == 9: ps.synchronize()
+                except FwError as e:
+                    failed = e
+                    break
+            assert failed is not None and "FW_EHIP" in str(failed), failed
+            assert frames > 20                          # the first frames have no third OLD tile: nothing to wait for
+            for call in (lambda: ps.step(DT), lambda: victim.counts(), lambda: victim.particles(0), lambda: victim.aabb()):
+                try:
+                    call(); raise SystemExit("a call on the invalid spawner went through")
+                except FwError as e:
+                    assert "FW_EHIP" in str(e) and "rebuild" in str(e), e
+            n_by = bystander.gpu.count(0)               # the neighbour is readable and was not touched by the refused frames
+            assert n_by > 0
+            victim.update_settings(spawner(0.3, 1.5, 40000.0))   # fw_spawner_update_settings
+            assert victim.update_path(0)[0] == "general" and victim.counts() == [0]
+            o = oracle.OracleSpawner(spawner(0.3, 1.5, 40000.0), seed=7, uid=1)
+            for fr in range(120):
+                ps.update(DT); o.step(DT)
+            g, c = victim.particles(0), o.particles(0)
+            assert len(g) == len(c) > 20000
+            for f in ("age", "lifetime", "position", "velocity", "scale"):
+                assert np.array_equal(g[f], c[f]), f
+            assert bystander.gpu.count(0) > n_by
+        print("STICKY-OK", frames)
+    """) % (root, root)
+    env = dict(os.environ, FW_ENABLE_KNOBS="1", FW_LIB_PATH=ab, FW_DEBUG="256", FW_FIFO="0", FW_RANGE="1", FW_RANGE_MIN="0",
+               FW_SPIN_LIMIT="4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "STICKY-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -14,8 +14,10 @@ dt = np.float32(1 / 60)
 ATTACH = os.environ.get("FW_BENCH_ATTACH", "")  # "window" / "plain": every type gets a device buffer for its ParticleInstance records
 
 
-def run(name, spawners, fill, steps, uids=None, inst_cap=None):
+def run(name, spawners, fill, steps, uids=None, inst_cap=None, colliders=None):
     ps = ParticleSystem(seed=workloads.SEED)
+    if colliders:
+        ps.set_colliders(colliders)
     keep = []
     for i, (sp, tf) in enumerate(spawners):
         h = ps.spawn(sp, tf, uid=(uids[i] if uids else i))
@@ -80,3 +82,8 @@ if "c5" in which:
     run("configs[4] one GPU's share: 512 of 4096 emitters x 8192", [ems[e] for e in mine], 80, 200, uids=mine, inst_cap=[20000])
 if "c4" in which:
     run("configs[3] nested sparks->smoke ~4M", [workloads.nested(100000.0, 20.0)], 250, 100)
+if "cc" in which:  # examples/stress_test_collision.rs: bouncing particles (at the example's rate, and at 8x it: 1.26M live)
+    sp, tf, world = workloads.stress_test_collision(80000.0)
+    run("stress_test_collision rate 80000 (~157k live)", [(sp, tf)], 130, 600, colliders=world)
+    sp, tf, world = workloads.stress_test_collision(640000.0)
+    run("stress_test_collision rate 640000 (~1.26M live)", [(sp, tf)], 130, 300, colliders=world)
