@@ -141,7 +141,9 @@ struct alignas(16) FwOp {
     float origin_rot[4];
     float parent_vel[4];
     float speed, scale;   // EffectModifier (src/core.rs:323-327)
-    uint32_t pad1[2];
+    uint32_t range_ring;  // 1: `seg` is a RANGE ring -- `head` is the slot of its first young particle, particle 0 sits
+                          // FwGlobals::rold slots before it (fw_ring_head)
+    uint32_t pad1;
 };
 
 // one Nested emission operation of the current frame (src/core.rs:471-546)
@@ -165,6 +167,9 @@ struct alignas(16) FwNestOp {
     uint32_t parent_life_plane;  // ... and its lifetimes sit in this 4-byte plane (FW_OFF_L index), not in Q3;
     float parent_life_const;     // 0xFFFFFFFF: the parent is a ring, all its particles have this lifetime
     float parent_rot[4];
+    uint32_t parent_range, child_range;  // 1: the segment is a RANGE ring -- its `head` above is the slot of its first young
+                                         // particle, particle 0 sits FwGlobals::rold slots before it (fw_ring_head)
+    uint32_t pad2[2];
 };
 
 // decoupled look-back status word: {epoch:30 | state:2 | value:32}

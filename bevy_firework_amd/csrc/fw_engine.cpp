@@ -191,6 +191,24 @@ struct alignas(64) SegHost {
         uint32_t n;
     };
     std::deque<YCohort> ycoh;  // the young cohorts, oldest first
+    // ... in a spawner WITH Nested entries (core.rs:471-546):
+    //   range_mat  other particles' entries emit FROM this type: in frames that run a Nested pass its Global particles are
+    //              materialised behind the young part by fw_k_spawn before the pass (core.rs:488) and fw_k_update_range
+    //              gives them their first update (FW_RREC_MAT);
+    //   range_dev  the type RECEIVES Nested children: its live count -- hence the size of its young part -- is known to the
+    //              device only (FW_RREC_DEV).  The host still knows where the young part STARTS: cohorts join the old part a
+    //              lifetime.min after they were added, and by then the update of their frame has long left their size in the
+    //              pinned ring h_report (as for a FIFO ring that receives children).
+    bool range_mat = false, range_dev = false;
+    struct DCohort {
+        uint64_t frame;
+        uint32_t n;
+        bool known;
+    };
+    std::deque<DCohort> dcoh;   // range_dev: the young cohorts, oldest first (sizes unknown until they are needed)
+    std::deque<YCohort> gcoh;   // range_dev: cohorts that have joined the old part and may still hold survivors (their bound)
+    uint64_t gcoh_sum = 0;
+    uint32_t rold_seen = 0;     // the old part's size as of the last exact read (refresh_counts_exact): FwGlobals::rold
     uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
     uint32_t r_low[3] = {0, 0, 0};               // frames in a row a role's need has been far below what is provided
     uint32_t r_need[3] = {0, 0, 0};              // what each role needed in the latest frame (the table keeps more: fit())
@@ -384,6 +402,7 @@ struct fw_ctx {
     uint32_t fifo_min = 32768;
     uint32_t n_fifo = 0;       // FIFO segments in use (at most kMaxFifoSegs: their records travel in kernel arguments)
     std::vector<FwOp> fifo_ops;  // this frame's Global ops that feed FIFO segments (spawned inside fw_k_update_fifo)
+    std::vector<std::pair<uint32_t, FwOp>> range_mat_ops;  // the same for range rings other particles' entries emit from
     std::vector<std::pair<uint32_t, FwOp>> fifo_mat_ops;  // {emission index, op}: rings of spawners with Nested entries -- the
                                                          // Nested pass of the frame, if there is one, must find them in memory
     uint64_t tev_frames = 0;   // frames timed so far (a frame may take several update launches)
@@ -401,6 +420,7 @@ struct fw_ctx {
     };
     std::deque<BirthAge> birth_age;  // oldest first; only frames some range ring may still hold young particles of
     float range_life_max = 0.f;      // largest SegHost::range_life_lo in the context
+    float range_age_keep = 0.f;      // largest lifetime.max of a range ring that receives Nested children (plus a margin)
     FwRangeDesc *d_rdesc = nullptr;  // device table: one descriptor per workgroup of the range launch
     FwRangeDesc *h_rdesc = nullptr;  // pinned staging of it
     size_t rdesc_cap = 0;
@@ -545,6 +565,7 @@ fw_status ensure_max_seg(fw_ctx *ctx, uint32_t need) {
     if ((st = regrow2(ctx->g.count))) return st;
     if ((st = regrow2(ctx->g.spawned))) return st;
     if ((st = regrow2(ctx->g.appended))) return st;
+    if ((st = regrow2(ctx->g.rold))) return st;
     {
         uint32_t *np = nullptr;
         FW_HIP(ctx, hipMalloc((void **)&np, (size_t)nmax * sizeof(uint32_t)));
@@ -703,10 +724,12 @@ fw_status ensure_range_arrays(fw_ctx *ctx) {
 }
 
 // slot of particle 0 of a segment whose live count is `count` (exact): 0 unless the segment is a ring
+// (a range ring: the old part sits right before the young part; its size is the device's -- rold_seen, refreshed together
+// with the exact counts -- for a type that receives Nested children, and count - young_n, the same number, otherwise)
 uint32_t ring_head_exact(const SegHost &S, uint32_t count) {
     if (S.fifo) return S.head;
     if (!S.range) return 0u;
-    const uint32_t n_old = count > S.young_n ? count - S.young_n : 0u;  // the old part sits right before the young part
+    const uint32_t n_old = S.range_dev ? std::min(S.rold_seen, count) : (count > S.young_n ? count - S.young_n : 0u);
     return (uint32_t)(((uint64_t)S.young_lo + S.capacity - (n_old % S.capacity)) % S.capacity);
 }
 
@@ -757,6 +780,20 @@ fw_status alloc_seg_buffers(fw_ctx *ctx, SegHost &s, uint32_t capacity, bool wan
     return FW_OK;
 }
 
+// the size of the old part of every range ring that receives Nested children, as the device has it (the stream has been
+// waited for): what ring_head_exact derives such a ring's first slot from
+fw_status refresh_rold(fw_ctx *ctx) {
+    bool any = false;
+    for (const SegHost &S : ctx->segs) any |= S.in_use && S.range && S.range_dev;
+    if (!any) return FW_OK;
+    const uint32_t n = (uint32_t)ctx->segs.size();
+    std::vector<uint32_t> r(n);
+    FW_HIP(ctx, hipMemcpy(r.data(), ctx->g.rold + (size_t)ctx->parity * ctx->max_seg, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++)
+        if (ctx->segs[i].in_use && ctx->segs[i].range) ctx->segs[i].rold_seen = r[i];
+    return FW_OK;
+}
+
 // exact device counts -> host upper bounds (synchronises)
 fw_status refresh_counts_exact(fw_ctx *ctx) {
     fw_status st = sync(ctx);
@@ -769,7 +806,7 @@ fw_status refresh_counts_exact(fw_ctx *ctx) {
     for (uint32_t i = 0; i < n; i++)
         if (ctx->segs[i].in_use) ctx->segs[i].ub = c[i];
     for (int i = 0; i < kSnapRing; i++) ctx->snap_pending[i] = false;
-    return FW_OK;
+    return refresh_rold(ctx);
 }
 
 bool poll_device_error(fw_ctx *ctx);
@@ -824,7 +861,8 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
         ctx->seg_kind_changed = true;
     }
     if (make_general && s.range) {
-        s.range = false, s.ycoh.clear(), s.young_lo = s.young_n = 0;
+        s.range = false, s.ycoh.clear(), s.dcoh.clear(), s.gcoh.clear(), s.gcoh_sum = 0, s.young_lo = s.young_n = 0;
+        s.range_mat = s.range_dev = false;
         ctx->n_range--;
         ctx->tab_force = true, ctx->r_force = true;
         ctx->seg_kind_changed = true;
@@ -836,13 +874,13 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
         s = old;
         return st;
     }
-    if (old.fifo && !s.fifo && s.h_report) hipHostFree(s.h_report), s.h_report = nullptr;
+    if (((old.fifo && !s.fifo) || (old.range && !s.range)) && s.h_report) hipHostFree(s.h_report), s.h_report = nullptr;
     s.head = 0;
     const uint32_t p = ctx->parity;
     const uint32_t n = old.ub;  // exact after the refresh
     const uint32_t h = ring_head_exact(old, n);
     if (s.range) {  // the list now starts in slot 0: old part first, the young part right behind it
-        s.young_lo = n > old.young_n ? n - old.young_n : 0u;
+        s.young_lo = old.range_dev ? std::min(old.rold_seen, n) : (n > old.young_n ? n - old.young_n : 0u);
         ctx->r_force = true;
     }
     const uint32_t n1 = std::min<uint32_t>(n, old.capacity - h);  // up to the end of the old buffer, then from its slot 0
@@ -1266,10 +1304,13 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             // Range ring (SegHost::range): any finite lifetime range -- a single value included, for the types the eight
             // FIFO records of a launch have no room for -- in a spawner without Nested entries; the young part of the
             // list is updated in place, only the part that can lose particles this frame is compacted
-            // (in a spawner WITH Nested entries: only the types no entry emits from or onto -- their Global particles need
-            // no place in the frame's emission order; parents are addressed by index through a head only the device knows)
-            const bool in_nested_pass = S.n_lplanes != 0 || S.nested_fed;
-            S.range = ctx->use_range && !sp.no_rings && !S.fifo && !in_nested_pass && (!S.collides || S.coll_inplace) && std::isfinite(p.lifetime.min) &&
+            // In a spawner WITH Nested entries (round 4): types other particles' entries emit FROM (range_mat: fw_k_spawn /
+            // fw_k_nest address their particles by list index through the size of the old part, which the device keeps --
+            // FwGlobals::rold) and types that RECEIVE children (range_dev: the device alone knows their count) qualify too;
+            // as for FIFO rings, not a type that emits onto itself, nor one that receives children AND Global particles; at
+            // most two last_emitted_age planes (the old tiles carry them in registers).
+            S.range = ctx->use_range && !sp.no_rings && !S.fifo && !self_nested && !mixed_feed && S.n_lplanes <= 2 &&
+                      (!S.collides || S.coll_inplace) && std::isfinite(p.lifetime.min) &&
                       std::isfinite(p.lifetime.max) && T.life_lo_safe > 0.0f && caps[t] >= ctx->range_min &&
                       caps[t] <= FW_RANGE_MAX_CAPACITY;
             if (S.range) {
@@ -1277,6 +1318,14 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
                 S.range_life_lo = T.life_lo_safe;
                 ctx->range_life_max = std::max(ctx->range_life_max, S.range_life_lo);
                 ctx->r_force = true;
+                S.range_mat = S.n_lplanes != 0;
+                S.range_dev = S.nested_fed;
+                if (S.range_dev) {
+                    S.win_ok = false;
+                    ctx->range_age_keep = std::max(ctx->range_age_keep, (float)(S.life_bound * 1.01 + 1e-3));
+                    FW_HIP(ctx, hipHostMalloc((void **)&S.h_report, (size_t)kReportRing * sizeof(unsigned long long), hipHostMallocDefault));
+                    memset(S.h_report, 0, (size_t)kReportRing * sizeof(unsigned long long));
+                }
             }
         }
         for (int c = 0; c < 4; c++) {  // the first key is the colour at age 0 (and, for one key, at every age)
@@ -1291,6 +1340,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             FW_HIP(ctx, hipMemcpy(ctx->g.count + (size_t)r * ctx->max_seg + si, zero2, 4, hipMemcpyHostToDevice));
             FW_HIP(ctx, hipMemcpy(ctx->g.spawned + (size_t)r * ctx->max_seg + si, zero2, 4, hipMemcpyHostToDevice));
             FW_HIP(ctx, hipMemcpy(ctx->g.appended + (size_t)r * ctx->max_seg + si, zero2, 4, hipMemcpyHostToDevice));
+            FW_HIP(ctx, hipMemcpy(ctx->g.rold + (size_t)r * ctx->max_seg + si, zero2, 4, hipMemcpyHostToDevice));
         }
         FW_HIP(ctx, hipMemcpy(ctx->g.ndestroyed + si, zero2, 4, hipMemcpyHostToDevice));
     }
@@ -1572,6 +1622,7 @@ fw_status read_counts(fw_ctx *ctx, std::vector<uint32_t> &out) {
     if (!out.empty())
         FW_HIP(ctx, hipMemcpy(out.data(), ctx->g.count + (size_t)ctx->parity * ctx->max_seg,
                               out.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if ((st = refresh_rold(ctx))) return st;
     return check_device_errors(ctx);
 }
 
@@ -1729,7 +1780,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
         if (S.h_report) hipHostFree(S.h_report);
     }
     void *frees[] = {ctx->d_type_coll.d, ctx->d_segs.d,       ctx->d_types.d,       ctx->d_keys.d,        ctx->d_emits.d,
-                     ctx->d_emit_serial.d, ctx->g.count,        ctx->g.spawned,       ctx->g.appended,
+                     ctx->d_emit_serial.d, ctx->g.count,        ctx->g.spawned,       ctx->g.appended,     ctx->g.rold,
                      ctx->g.ndestroyed,   ctx->g.tile_cnt,      ctx->g.tile_off,      ctx->g.tile_status,
                      ctx->g.err,          ctx->g.stats,         ctx->g.nest_status,   ctx->g.nest_ticket,
                      ctx->d_aabb,         ctx->d_total,         ctx->d_segids,        ctx->g.dbg_ts,
@@ -2009,7 +2060,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // host's ~60 ns per emitter
     auto &levels = ctx->levels;
     for (auto &L : levels) L.g.clear(), L.n.clear();
-    ctx->fifo_ops.clear(), ctx->fifo_mat_ops.clear();
+    ctx->fifo_ops.clear(), ctx->fifo_mat_ops.clear(), ctx->range_mat_ops.clear();
     ctx->seg_kind_changed = false;
     if (!std::isfinite(dt))  // 0 * inf = NaN: an angular velocity of zero does not stay zero (core.rs:648-650)
         for (uint32_t si = 0; si < ctx->segs.size(); si++)
@@ -2040,7 +2091,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         for (uint32_t si = 0; si < ctx->segs.size(); si++) {
             SegHost &S = ctx->segs[si];
             if (!S.in_use || !S.range) continue;
-            if (!flood && dt >= 0.0f && dt < S.range_life_lo && S.ycoh.size() < kMaxCohorts) continue;
+            if (!flood && dt >= 0.0f && dt < S.range_life_lo && S.ycoh.size() < kMaxCohorts && S.dcoh.size() < kMaxCohorts) continue;
             fw_status cst = fifo_to_general(ctx, si);
             if (cst) return cst;
         }
@@ -2117,6 +2168,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         for (const FwOp &op : ctx->fifo_ops) forget(op);
         for (const FwOp &op : ctx->range_ops) forget(op);
         for (const auto &io : ctx->fifo_mat_ops) forget(io.second);
+        for (const auto &io : ctx->range_mat_ops) forget(io.second);
         for (auto &S : ctx->segs) S.ub -= std::min(S.ub, S.frame_spawn), S.frame_spawn = 0;
         return why;
     };
@@ -2234,6 +2286,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     ctx->fifo_mat_ops.push_back({(uint32_t)i, op});  // routed below, once the frame's Nested ops are known
                 else if (S.fifo)
                     ctx->fifo_ops.push_back(op);  // spawned inside fw_k_update_fifo, whatever else the frame holds
+                else if (S.range && S.range_mat)
+                    ctx->range_mat_ops.push_back({(uint32_t)i, op});  // routed below, once the frame's Nested ops are known
                 else if (S.range)
                     ctx->range_ops.push_back(op);  // spawned inside fw_k_update_range
                 else
@@ -2279,9 +2333,19 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 ctx->fifo_ops.push_back(io.second);
             }
         }
-        // every routed op now sits in exactly one list `rollback` walks (levels[].g or fifo_ops): forgetting this one too
-        // would take its particles out of cum_spawn twice
-        ctx->fifo_mat_ops.clear();
+        // (range rings other particles' entries emit from: the same choice; materialised at the tail of the ring -- the slot of
+        // the list's first particle follows from the old part's size, which the device keeps: FwOp::range_ring)
+        for (auto &io : ctx->range_mat_ops) {
+            if (nested_frame) {
+                io.second.head = ctx->segs[io.second.seg].young_lo, io.second.range_ring = 1u;
+                levels[io.first].g.push_back(io.second);
+            } else {
+                ctx->range_ops.push_back(io.second);
+            }
+        }
+        // every routed op now sits in exactly one list `rollback` walks (levels[].g, fifo_ops or range_ops): forgetting this one
+        // too would take its particles out of cum_spawn twice
+        ctx->fifo_mat_ops.clear(), ctx->range_mat_ops.clear();
     }
     // A ring that had to grow past its mode's slot limit inside the loop above (realloc_segment) continues as a compacting
     // segment from this very frame: the ops already queued for it as a ring's go where a compacting segment's ops go -- its
@@ -2307,6 +2371,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         };
         reroute(ctx->fifo_ops, true);
         reroute(ctx->range_ops, false);
+        for (auto &L : levels)
+            for (FwOp &op : L.g)
+                if (op.range_ring && !ctx->segs[op.seg].range) op.range_ring = 0u, op.head = 0u;
     }
     // ---- segment -> tile table (device resident, re-uploaded only when a bound moves out of its band)
     prof(1);
@@ -2459,8 +2526,12 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     tiles += op.n_tiles;
                     op.parent_buf = ctx->segs[op.parent_seg].buf[p];
                     op.parent_cap = ctx->segs[op.parent_seg].capacity;
-                    op.parent_head = ctx->segs[op.parent_seg].fifo ? ctx->segs[op.parent_seg].head : 0u;
-                    op.child_head = ctx->segs[op.child_seg].fifo ? ctx->segs[op.child_seg].head : 0u;
+                    // (a range ring: the slot of its first YOUNG particle as of the last update -- this frame's cohorts join the
+                    // old part further down, after these launches have been enqueued -- and the device subtracts the old part)
+                    const SegHost &PS = ctx->segs[op.parent_seg], &CS = ctx->segs[op.child_seg];
+                    op.parent_head = PS.fifo ? PS.head : (PS.range ? PS.young_lo : 0u);
+                    op.child_head = CS.fifo ? CS.head : (CS.range ? CS.young_lo : 0u);
+                    op.parent_range = PS.range ? 1u : 0u, op.child_range = CS.range ? 1u : 0u;
                     op.parent_nospin = ctx->segs[op.parent_seg].nospin ? 1u : 0u;
                     memcpy(op.parent_rot, ctx->segs[op.parent_seg].const_rot, sizeof op.parent_rot);
                     // (its lifetimes: the lifetime plane of a compacting segment, one value for a ring)
@@ -2725,32 +2796,71 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             all_nospin &= S.nospin;
             range_inst |= S.inst != nullptr;
             range_coll |= S.collides;
-            r_bytes += (uint64_t)S.ub * (S.nospin ? 104u : 164u);
+            r_bytes += (uint64_t)(S.range_dev ? S.capacity / 2 : S.ub) * (S.nospin ? 104u : 164u);
             S.dead_at_end = true;
             // cohorts that are no longer provably too young to die join the old part: the boundary moves, nothing is copied
+            const bool mat_frame = S.range_mat && nested_frame;  // its Global particles of this frame already sit in the ring
             uint32_t grad = 0;
-            while (!S.ycoh.empty()) {
-                const float an = age_before(S.ycoh.front().frame) + dt;  // the device's own addition (core.rs:594)
-                if (an < S.range_life_lo) break;
-                grad += S.ycoh.front().n;
-                S.ycoh.pop_front();
+            if (!S.range_dev) {
+                while (!S.ycoh.empty()) {
+                    const float an = age_before(S.ycoh.front().frame) + dt;  // the device's own addition (core.rs:594)
+                    if (an < S.range_life_lo) break;
+                    grad += S.ycoh.front().n;
+                    S.ycoh.pop_front();
+                }
+                if (S.frame_spawn) S.ycoh.push_back(SegHost::YCohort{ctx->frame, S.frame_spawn});
+            } else {
+                // a type that receives Nested children: a cohort's size is whatever the device appended in its frame; the update
+                // of that frame left it in the pinned ring, and it is only needed now, a lifetime.min later
+                while (!S.dcoh.empty()) {
+                    SegHost::DCohort &c = S.dcoh.front();
+                    const float an = age_before(c.frame) + dt;
+                    if (an < S.range_life_lo) break;
+                    if (!c.known) {
+                        const uint32_t ep = (uint32_t)((c.frame + 1) & 0x3FFFFFFFu) ? (uint32_t)((c.frame + 1) & 0x3FFFFFFFu) : 1u;
+                        const volatile unsigned long long *row = S.h_report + (c.frame % kReportRing);
+                        for (int spin = 0; (uint32_t)(*row >> 32) != ep && spin < 100000; spin++) __builtin_ia32_pause();
+                        if ((uint32_t)(*row >> 32) != ep) FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                        if ((uint32_t)(*row >> 32) != ep) return fail(ctx, FW_EHIP, "internal error: cohort report missing (range ring)");
+                        c.n = (uint32_t)*row, c.known = true;
+                    }
+                    grad += c.n;
+                    if (c.n) S.gcoh.push_back(SegHost::YCohort{c.frame, c.n}), S.gcoh_sum += c.n;
+                    S.dcoh.pop_front();
+                }
+                S.dcoh.push_back(SegHost::DCohort{ctx->frame, 0u, false});
+                // graduated cohorts whose every particle an EARLIER update has destroyed (age >= lifetime.max before this frame)
+                while (!S.gcoh.empty() && !(age_before(S.gcoh.front().frame) < (float)S.life_bound)) {
+                    S.gcoh_sum -= S.gcoh.front().n;
+                    S.gcoh.pop_front();
+                }
             }
-            if (S.frame_spawn) S.ycoh.push_back(SegHost::YCohort{ctx->frame, S.frame_spawn});
             S.young_lo = (uint32_t)(((uint64_t)S.young_lo + grad) % S.capacity);
-            const uint32_t y_exist = S.young_n - std::min(S.young_n, grad);
+            const uint32_t y_exist = S.range_dev ? 0u : S.young_n - std::min(S.young_n, grad);
             FwRangeRec &Rc = recs[si];
-            Rc.b = S.young_lo, Rc.y_exist = y_exist, Rc.n_spawn = S.frame_spawn;
+            Rc.b = S.young_lo, Rc.y_exist = y_exist, Rc.n_spawn = (mat_frame || S.range_dev) ? 0u : S.frame_spawn;
+            Rc.grad = grad, Rc.flags = (mat_frame ? FW_RREC_MAT : 0u) | (S.range_dev ? (FW_RREC_MAT | FW_RREC_DEV) : 0u), Rc.pad = 0;
+            Rc.report = S.range_dev ? S.h_report + (ctx->frame % kReportRing) : nullptr, Rc.pad2 = 0;
             while (oi < ops.size() && ops[oi].seg < si) oi++;
             Rc.op0 = (uint32_t)oi, Rc.op_n = 0;
             while (oi < ops.size() && ops[oi].seg == si) oi++, Rc.op_n++;
-            S.young_n = y_exist + S.frame_spawn;
+            S.young_n = S.range_dev ? 0u : y_exist + S.frame_spawn;
             // workgroups of each role (bands: the table is re-sent only when a need leaves its band)
-            const uint32_t live_before_ub = std::min(S.ub - std::min(S.ub, S.frame_spawn), S.capacity);
-            const uint32_t old_ub = live_before_ub - std::min(live_before_ub, y_exist);
-            const uint32_t need_old = std::max(1u, (old_ub + FW_TILE - 1) / FW_TILE);
-            const uint32_t need_new = (S.frame_spawn + FW_BLOCK - 1) / FW_BLOCK;
             const uint32_t YT = fw_range_young_tile();
-            const uint32_t need_young = std::min(S.capacity / YT, (S.young_lo % YT + y_exist + YT - 1) / YT);
+            uint32_t need_old, need_new, need_young;
+            if (S.range_dev) {
+                // the old part: at most the cohorts that have joined it and may still hold survivors (all sizes known); the young
+                // part: somewhere behind b -- the grid covers the ring, a tile without young particles leaves at once
+                need_old = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((S.gcoh_sum + FW_TILE - 1) / FW_TILE, S.capacity / FW_TILE + 1));
+                need_new = 0u;
+                need_young = S.capacity / YT;
+            } else {
+                const uint32_t live_before_ub = std::min(S.ub - std::min(S.ub, S.frame_spawn), S.capacity);
+                const uint32_t old_ub = live_before_ub - std::min(live_before_ub, y_exist);
+                need_old = std::max(1u, (old_ub + FW_TILE - 1) / FW_TILE);
+                need_new = mat_frame ? 0u : (S.frame_spawn + FW_BLOCK - 1) / FW_BLOCK;
+                need_young = std::min(S.capacity / YT, (S.young_lo % YT + y_exist + (mat_frame ? S.frame_spawn : 0u) + YT - 1) / YT);
+            }
             // every provisioned workgroup is dispatched every frame, active or not (~3 us of a slot each): small needs get
             // one spare, large ones an eighth -- a re-sent table is a copy in the stream, an idle workgroup a cost in every frame
             // (the bound of the old part follows the snapshots in a sawtooth: a role grows at once, and shrinks only after its
@@ -2861,7 +2971,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         // the ages every later frame starts from
         for (auto &e : ctx->birth_age) e.age = e.age + dt;
         ctx->birth_age.push_back(fw_ctx::BirthAge{ctx->frame, 0.0f + dt});
-        while (!ctx->birth_age.empty() && !(ctx->birth_age.front().age < ctx->range_life_max)) ctx->birth_age.pop_front();
+        // (kept while some ring may still ask for the age: until lifetime.min for every ring, until lifetime.max for those that
+        // bound their old part by the cohorts in it -- range_age_keep)
+        while (!ctx->birth_age.empty() && !(ctx->birth_age.front().age < std::max(ctx->range_life_max, ctx->range_age_keep))) ctx->birth_age.pop_front();
         if (ctx->r_total) {
             FwRangeArgs ra{};
             ra.desc = ctx->d_rdesc, ra.recs = recs, ra.ops = rops, ra.status = ctx->d_rstatus;
@@ -3152,7 +3264,7 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
     // (a range ring: particle 0 sits `count - young_n` slots before the first young particle -- the kernel reads the count)
     FW_HIP(ctx, fw_launch_pack_instances(ctx->stream, S.buf[ctx->parity], S.capacity, S.range ? S.young_lo : (S.fifo ? S.head : 0u),
                                          ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, ub, d_out,
-                                         S.nospin ? S.const_rot : nullptr, S.range ? S.young_n : 0xFFFFFFFFu,
+                                         S.nospin ? S.const_rot : nullptr, S.range ? ctx->g.rold + (size_t)ctx->parity * ctx->max_seg + si : nullptr,
                                          S.derived ? ctx->d_types.d + S.type_idx : nullptr, ctx->d_keys.d, S.life_plane(), S.fifo_life));
     return FW_OK;
 }
@@ -3260,7 +3372,7 @@ fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out
             const SegHost &S = ctx->segs[sp->seg[t0 + t]];
             any_ring |= S.ring();
             heads[t] = S.range ? S.young_lo : (S.fifo ? S.head : 0u);
-            range_y[t] = S.range ? S.young_n : 0xFFFFFFFFu;
+            range_y[t] = S.range ? 1u : 0xFFFFFFFFu;  // (a range ring: the kernel takes the old part's size from FwGlobals::rold)
             life_plane[t] = S.life_plane(), life_const[t] = S.fifo_life;
         }
         if (ctx->boxes_epoch && ctx->d_tile_first && !any_ring) {

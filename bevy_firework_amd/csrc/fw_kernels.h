@@ -27,6 +27,11 @@ struct FwGlobals {
     uint32_t *spawned;   // [2][max_seg]  Global spawns appended this frame
     uint32_t *appended;  // [2][max_seg]  Nested children appended this frame
     uint32_t *ndestroyed;  // [max_seg]   particles destroyed by the last update
+    // [2][max_seg], by buffer parity like `count`: survivors in the OLD part of a range ring (FwRangeRec) after the last update.
+    // Particle 0 of such a ring sits `rold` slots before its first young particle -- the one fact about a range ring only the
+    // device knows; everything that addresses its particles by list index (fw_k_spawn, fw_k_nest, fw_k_pack, the AABB query,
+    // the host's readers) derives the slot of particle 0 from it
+    uint32_t *rold;
     uint32_t max_seg;
     uint32_t seed;
     uint32_t *tile_cnt;              // split mode: survivors per tile
@@ -179,11 +184,25 @@ struct FwFifoArgs {
 // The first particle of the list sits in slot b - n_old: `n_old` = count - y is known to the device only.
 struct alignas(16) FwRangeRec {  // per segment, per frame: pinned host memory, read by the tiles in place
     uint32_t b;         // slot of the first young particle, after this frame's cohorts have joined the old part
-    uint32_t y_exist;   // young particles before this frame's spawns
-    uint32_t n_spawn;   // particles spawned this frame (all of them outlive the step: dt < lifetime.min)
+    uint32_t y_exist;   // young particles before this frame's spawns (host-known; FW_RREC_DEV: unknown, the device derives it)
+    uint32_t n_spawn;   // particles spawned this frame by the NEW workgroups (all of them outlive the step: dt < lifetime.min)
     uint32_t op0, op_n; // their spawn ops in FwRangeArgs::ops
-    uint32_t pad[3];
+    uint32_t grad;      // particles that joined the old part this frame (b moved by so many slots): old part = rold + grad
+    uint32_t flags;     // FW_RREC_*
+    uint32_t pad;
+    unsigned long long *report;  // FW_RREC_DEV: pinned host word that receives {epoch << 32 | particles added this frame}
+    unsigned long long pad2;
 };
+// Range rings of spawners WITH Nested entries (core.rs:471-546):
+// FW_RREC_MAT  this frame's new particles of the segment were MATERIALISED behind the young part before the update (frames
+//              with a Nested pass: Global ops by fw_k_spawn -- the per-parent pass must find them in memory, core.rs:488 --
+//              children by fw_k_nest): n_spawn is 0, the device counters say how many (spawned + appended), and those
+//              particles get their first update with every plane written;
+// FW_RREC_DEV  the type receives Nested children: how many particles it holds is known to the device only -- the young
+//              count is  count + spawned + appended - (rold + grad)  -- and the size of each frame's cohort reaches the host
+//              through `report`, long before the host needs it (when the cohort joins the old part).
+#define FW_RREC_MAT 1u
+#define FW_RREC_DEV 2u
 #define FW_RANGE_OLD 0u
 #define FW_RANGE_NEW 1u
 #define FW_RANGE_YOUNG 2u
@@ -250,17 +269,17 @@ hipError_t fw_launch_scatter(hipStream_t s, char *buf, uint32_t capacity, uint32
                              const void *d_in);
 // fills the base / emissive colour planes of one (buf1 == nullptr) or both buffers of a segment (capacity slots each)
 hipError_t fw_launch_fill_colors(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, const float bc[4], const float em[4]);
-// (range_y != 0xFFFFFFFF: a range ring -- `head` is the slot of its first YOUNG particle and particle 0 sits
-// (count - range_y) slots before it)
+// (d_rold != null: a range ring -- `head` is the slot of its first YOUNG particle and particle 0 sits *d_rold slots before it:
+// the segment's word of FwGlobals::rold)
 hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, const uint32_t *d_count,
                                     uint32_t n_upper, void *d_out, const float *const_rot = nullptr,
-                                    uint32_t range_y = 0xFFFFFFFFu, const FwType *derived = nullptr, const float *keys = nullptr,
+                                    const uint32_t *d_rold = nullptr, const FwType *derived = nullptr, const float *keys = nullptr,
                                     uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.0f);
 // fills the rotation plane of both buffers of a segment (a type leaves FW_TYPE_NOSPIN)
 hipError_t fw_launch_fill_rotation(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, const float rot[4]);
 // seg_ids: host array; d_part: device scratch of 256 * 8 floats; h_out8: PINNED host {min.xyz, any, max.xyz, -}
 // seg_heads: ring heads of the segments (host array, or null = all 0); seg_range_y (or null): per segment 0xFFFFFFFF, or --
-// a range ring -- its young count: seg_heads[i] is then the slot of its first young particle (see fw_launch_pack_instances)
+// a range ring -- anything else: seg_heads[i] is then the slot of its first young particle (see fw_launch_pack_instances)
 hipError_t fw_launch_aabb(hipStream_t s, const FwGlobals &g, const uint32_t *seg_ids, const uint32_t *seg_heads, uint32_t n_segs,
                           uint32_t parity, float *d_part, float *h_out8, const uint32_t *seg_range_y = nullptr,
                           const uint32_t *seg_life_plane = nullptr, const float *seg_life_const = nullptr);

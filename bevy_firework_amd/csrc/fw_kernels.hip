@@ -197,6 +197,13 @@ __device__ __forceinline__ uint32_t fw_ring_slot(uint32_t head, uint32_t i, uint
     return s >= C ? s - C : s;
 }
 
+// slot of particle 0 of a RANGE ring whose first young particle sits in slot b: the old part (`rold` survivors, FwGlobals::rold)
+// lies right before it
+__device__ __forceinline__ uint32_t fw_range_head(uint32_t b, uint32_t rold, uint32_t C) {
+    const uint32_t back = rold >= C ? 0u : rold;  // (rold < C always: a guard against a wild value, not a case)
+    return b >= back ? b - back : b + C - back;
+}
+
 // Q3 (angular velocity, lifetime) of particle `idx`: from the plane, or -- a type that cannot turn -- zero and the lifetime
 // plane (FwOutWin::lf)
 __device__ __forceinline__ float4 fw_load_q3(const char *buf, uint32_t C, uint32_t n_lplanes, uint32_t idx, bool nospin) {
@@ -342,7 +349,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_spawn(FwGlobals g, FwInlineOps 
         if (op.n > room) atomicOr(g.err, FW_ERR_CAPACITY);
     }
     if (k >= op.n || k >= room) return;
-    const uint32_t slot = fw_ring_slot(op.head, base + k, S.capacity);  // (base + k < capacity)
+    const uint32_t head = op.range_ring ? fw_range_head(op.head, g.rold[sidx], S.capacity) : op.head;
+    const uint32_t slot = fw_ring_slot(head, base + k, S.capacity);  // (base + k < capacity)
     const FwEmit &e = g.emits[op.emit];
     FwSpawnOut o = fw_spawn_one(e, g.seed, op.serial_base + k, fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
                                 fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
@@ -1993,11 +2001,23 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     const uint32_t keys_off = D.keys_off, keys_len = D.keys_len;
     const float key0 = tid < keys_len ? g.keys[keys_off + tid] : 0.0f;
     const FwRangeRec &Rc = a.recs[seg];  // pinned host memory
-    const uint32_t b = Rc.b, y_exist = Rc.y_exist, n_spawn_h = Rc.n_spawn;
+    const uint32_t b = Rc.b, n_spawn_h = Rc.n_spawn, rflags = Rc.flags;
+    uint32_t y_exist = Rc.y_exist;
     const FwSeg *Sp = &g.segs[seg];
     const uint32_t C = Sp->capacity;
     char *buf = Sp->buf[0];
     const uint32_t sidx = a.parity * g.max_seg + seg, oidx = (a.parity ^ 1u) * g.max_seg + seg;
+    // Rings of spawners with Nested entries (FW_RREC_MAT / FW_RREC_DEV): this frame's new particles were materialised behind the
+    // young part before the update, and for a type that receives children only the device knows how many particles it holds.
+    // The young part is then  everything  -  the old part (rold + grad: survivors of the last update + the cohorts that joined
+    // this frame); the particles from index y_full on were born this frame and get their first update with every plane written.
+    uint32_t y_full = 0xFFFFFFFFu, n_old_dev = 0u;
+    if (rflags & (FW_RREC_MAT | FW_RREC_DEV)) {
+        const uint32_t c0 = g.count[sidx], c1 = g.spawned[sidx] + g.appended[sidx];
+        n_old_dev = g.rold[sidx] + Rc.grad;
+        y_full = c0 - min(c0, n_old_dev);
+        y_exist = y_full + c1;
+    }
     if (blockIdx.x == 0 && tid == 0) {
         if (a.live_next) *a.live_next = 0ull;
         if (a.done_tag) *a.done_tag = a.done_value;
@@ -2015,8 +2035,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         const uint32_t ring_tiles = C / YT;
         const uint32_t need = min(ring_tiles, (b % YT + y_exist + YT - 1u) / YT);
         if (k >= need) return;
-        const uint32_t cnt_y = (INST && inst != nullptr) ? g.count[sidx] : 0u;  // (requested now, used later)
-        const uint32_t rec0 = cnt_y > y_exist ? cnt_y - y_exist : 0u;  // record index of the first young particle (= n_old_in)
+        const uint32_t cnt_y = (INST && inst != nullptr && !(rflags & (FW_RREC_MAT | FW_RREC_DEV))) ? g.count[sidx] : 0u;  // (requested now, used later)
+        // record index of the first young particle (= n_old_in)
+        const uint32_t rec0 = (rflags & (FW_RREC_MAT | FW_RREC_DEV)) ? n_old_dev : (cnt_y > y_exist ? cnt_y - y_exist : 0u);
         uint32_t pt = b / YT + k;
         if (pt >= ring_tiles) pt -= ring_tiles;
         const uint32_t sbase = pt * YT;
@@ -2075,7 +2096,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
                 fw_coll_step<COLL>(g, CA, mine, a.dt, q0a[r], q1a[r], &cpos, &cvel);
                 if (mine)
                     fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0a[r], q1a[r], q3v, q3v, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
-                                                     (COLL && CA.on) ? &cvel : nullptr);
+                                                     (COLL && CA.on) ? &cvel : nullptr, nullptr, false, yi >= y_full);
                 if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             }
             if (__any(bad) && lane == 0) fw_raise(g, 7u, seg, blockIdx.x);
@@ -2122,7 +2143,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             fw_coll_step<COLL>(g, CA, mine, a.dt, q0c, q1c, &cpos, &cvel);
             if (mine)
                 fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
-                                                 (COLL && CA.on) ? &cvel : nullptr);
+                                                 (COLL && CA.on) ? &cvel : nullptr, nullptr, false, yi >= y_full);
             if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n, lfc = lfn;
             q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f, lfn = lff;
@@ -2132,7 +2153,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     }
 
     const uint32_t cnt_in = g.count[sidx];
-    const uint32_t n_old_in = cnt_in > y_exist ? cnt_in - y_exist : 0u;
+    const uint32_t n_old_in = (rflags & (FW_RREC_MAT | FW_RREC_DEV)) ? n_old_dev : (cnt_in > y_exist ? cnt_in - y_exist : 0u);
+    const uint32_t n_added = (rflags & (FW_RREC_MAT | FW_RREC_DEV)) ? y_exist - y_full : 0u;  // materialised this frame
     // (what does not fit is dropped and reported, as everywhere: the host grows a segment before its bound reaches the capacity)
     const uint32_t room = C - min(C, n_old_in + y_exist);
     const uint32_t n_spawn = min(n_spawn_h, room);
@@ -2172,6 +2194,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             fw_coll_step<COLL>(g, CA, true, a.dt, so.q0, so.q1, &cpos, &cvel);
             fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
                                               (COLL && CA.on) ? &cvel : nullptr);
+            // (a type other particles' entries emit from: last_emitted_age = [f32::MIN; n], core.rs:467)
+            for (uint32_t lk = 0; lk < Sp->n_lplanes; lk++) fw_st1(buf + FW_OFF_L(C, lk), s, FW_F32_MIN);
         }
         if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, n_old_in + y_exist + kk, false);
         return;
@@ -2186,11 +2210,14 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         atomicOr(g.err, FW_ERR_CAPACITY);
         g.err[1] = seg, g.err[2] = n_old_in, g.err[3] = D.n_old, g.err[4] = cnt_in;
     }
+    // (the host's young count against the device's own record of the old part: what both derive the list's first slot from)
+    if (k == 0u && tid == 0u && !(rflags & (FW_RREC_MAT | FW_RREC_DEV)) && g.rold[sidx] + Rc.grad != n_old_in) fw_raise(g, 10u, seg, n_old_in);
     const bool want_destroyed_any = Sp->destroyed != nullptr;
     if (base >= n_old_in) {
         if (k == 0u && tid == 0u) {  // nobody old: the segment's bookkeeping is still this workgroup's
             const uint32_t nc = y_exist + n_spawn;
-            g.count[oidx] = nc, g.spawned[oidx] = 0, g.appended[oidx] = 0, g.ndestroyed[seg] = 0;
+            g.count[oidx] = nc, g.spawned[oidx] = 0, g.appended[oidx] = 0, g.ndestroyed[seg] = 0, g.rold[oidx] = 0;
+            if (Rc.report) *Rc.report = ((unsigned long long)a.epoch << 32) | n_added;
             if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;
             if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
             if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)nc);
@@ -2212,6 +2239,26 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         q2[r] = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p2, (s * 16u) & m2);
         if (nospin) q3[r] = make_float4(0.0f, 0.0f, 0.0f, lf);
     }
+    // a type other particles' entries emit from (Nested, core.rs:471-546) carries last_emitted_age per entry: those planes
+    // move with the survivors (at most FW_RANGE_LK of them: the host keeps types with more off the range path)
+    constexpr int FW_RANGE_LK = 2;
+    const uint32_t nlp = Sp->n_lplanes;
+    float lkv[FW_RANGE_LK][R];
+#pragma unroll
+    for (int j = 0; j < FW_RANGE_LK; j++)
+#pragma unroll
+        for (int r = 0; r < R; r++) lkv[j][r] = 0.0f;
+    if (nlp) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t d = min(base + r * BLK + tid, lim - 1u);
+            uint32_t s = bm1 - d;
+            if (s >= C) s -= C;
+#pragma unroll
+            for (int j = 0; j < FW_RANGE_LK; j++)
+                if ((uint32_t)j < nlp) lkv[j][r] = fw_ld1w<NT == 2>(buf + FW_OFF_L(C, j), s * 4u);
+        }
+    }
     const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
     const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & ~FW_TYPE_IDX_NOSPIN);
     if (tid < keys_len) s_keys[tid] = key0;
@@ -2230,6 +2277,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         uint32_t c = (uint32_t)__popcll(m[r]);
         asm volatile("; fw_k_update_range: input held before the count is published"
                      : "+v"(c) : "v"(q0[r].x), "v"(q1[r].x), "v"(q2[r].x), "v"(q3[r].w));
+        if (nlp) asm volatile("; ... and the last_emitted_age planes" : "+v"(c) : "v"(lkv[0][r]), "v"(lkv[1][r]));
         if (lane == 0) s_cnt[r][wave] = c;
     }
     __syncthreads();
@@ -2277,6 +2325,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             if (s >= C) s -= C;
             fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
                                               (COLL && CA.on) ? &cvel : nullptr);
+            if (nlp) {
+#pragma unroll
+                for (int j = 0; j < FW_RANGE_LK; j++)
+                    if ((uint32_t)j < nlp) fw_st1w<NT == 2>(buf + FW_OFF_L(C, j), s * 4u, lkv[j][r]);
+            }
         }
         if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, m[r], n_old_in - 1u - od, true);
         if (!alive && valid && want_destroyed) {
@@ -2297,8 +2350,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     if (lim == n_old_in && tid == 0) {  // the tile furthest from the young part knows the totals
         const uint32_t n_old_out = excl + tile_surv;
         const uint32_t nc = n_old_out + y_exist + n_spawn;
-        g.count[oidx] = nc, g.spawned[oidx] = 0, g.appended[oidx] = 0;
+        g.count[oidx] = nc, g.spawned[oidx] = 0, g.appended[oidx] = 0, g.rold[oidx] = n_old_out;
         g.ndestroyed[seg] = n_old_in - n_old_out;
+        if (Rc.report) *Rc.report = ((unsigned long long)a.epoch << 32) | n_added;
         if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
         if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)(n_old_in + y_exist + n_spawn));
@@ -2555,25 +2609,29 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
         for (uint32_t i = 1; i < FW_INLINE_OPS; i++)
             if (i < n_ops && inl.ops[i].first_tile <= tile) oi = i, op = inl.ops[i];
     }
+    const uint32_t sidx = parity * g.max_seg + op.parent_seg, cidx = parity * g.max_seg + op.child_seg;
+    // (a RANGE ring is addressed through the size of its old part, which only the device knows: one dependent hop more before
+    // the parents can be requested)
+    const uint32_t parent_head = op.parent_range ? fw_range_head(op.parent_head, g.rold[sidx], op.parent_cap) : op.parent_head;
     // the parents' counting inputs: requested now, at an index clamped into the buffer, together with the counters below
     const uint32_t pbase = (tile - op.first_tile) * FW_NEST_TILE;
     float p_age[FW_NEST_TILE / FW_BLOCK], p_life[FW_NEST_TILE / FW_BLOCK], p_lea[FW_NEST_TILE / FW_BLOCK];
 #pragma unroll
     for (int r = 0; r < FW_NEST_TILE / FW_BLOCK; r++) {
-        const uint32_t ci = fw_ring_slot(op.parent_head, min(pbase + r * FW_BLOCK + tid, op.parent_cap - 1u), op.parent_cap);
+        const uint32_t ci = fw_ring_slot(parent_head, min(pbase + r * FW_BLOCK + tid, op.parent_cap - 1u), op.parent_cap);
         p_age[r] = fw_ld4(op.parent_buf + FW_OFF_Q0(op.parent_cap), ci).w;
         p_life[r] = (op.parent_nospin != 0u && op.parent_life_plane == 0xFFFFFFFFu)
                         ? op.parent_life_const
                         : fw_load_q3(op.parent_buf, op.parent_cap, op.parent_life_plane, ci, op.parent_nospin != 0u).w;
         p_lea[r] = fw_ld1(op.parent_buf + FW_OFF_L(op.parent_cap, op.parent_lplane), ci);
     }
-    const uint32_t sidx = parity * g.max_seg + op.parent_seg, cidx = parity * g.max_seg + op.child_seg;
     const uint32_t n_par = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];  // bound fixed once (core.rs:488)
     const uint32_t cbase = g.count[cidx] + g.spawned[cidx] + g.appended[cidx];  // first child slot of the op
     const unsigned long long serial0 = g.emit_serial[op.emit_slot];
     const uint32_t base = (tile - op.first_tile) * FW_NEST_TILE;
     const FwSeg &Cs = g.segs[op.child_seg];
     const uint32_t ccap = Cs.capacity;
+    const uint32_t child_head = op.child_range ? fw_range_head(op.child_head, g.rold[cidx], ccap) : op.child_head;
     uint32_t op_total = 0;  // non-zero only in the op's last active tile
     if (base < n_par) {
         const FwEmit &e = g.emits[op.emit];
@@ -2588,7 +2646,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
                 float next;
                 const uint64_t cnt = fw_emission_count(p_age[r], p_lea[r], p_life[r], op.n_start, op.n_end, op.n_count, &next);
                 n[r] = cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cnt;  // core.rs:490-498
-                fw_st1(pb + FW_OFF_L(PC, op.parent_lplane), fw_ring_slot(op.parent_head, idx, PC), next);  // other_particle.last_emitted_age[i] = next (core.rs:500)
+                fw_st1(pb + FW_OFF_L(PC, op.parent_lplane), fw_ring_slot(parent_head, idx, PC), next);  // other_particle.last_emitted_age[i] = next (core.rs:500)
             }
             uint32_t x = n[r];
 #pragma unroll
@@ -2648,7 +2706,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
             const uint32_t idx = base + r * FW_BLOCK + tid;
             s_inc[wave][lane] = inc[r];
             if (n[r] != 0) {
-                const uint32_t ps = fw_ring_slot(op.parent_head, idx, PC);
+                const uint32_t ps = fw_ring_slot(parent_head, idx, PC);
                 s_par[wave][0][lane] = fw_ld4(pb + FW_OFF_Q0(PC), ps);
                 s_par[wave][1][lane] = fw_ld4(pb + FW_OFF_Q1(PC), ps);
                 s_par[wave][2][lane] = op.parent_nospin ? make_float4(op.parent_rot[0], op.parent_rot[1], op.parent_rot[2], op.parent_rot[3])
@@ -2673,7 +2731,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
                         FwSpawnOut o = fw_spawn_one(e, g.seed, serial0 + j, fw_v3{pq0.x, pq0.y, pq0.z},
                                                     fw_q4{pq2.x, pq2.y, pq2.z, pq2.w}, fw_v3{pq1.x, pq1.y, pq1.z}, op.speed,
                                                     op.scale);
-                        fw_store_new(g, Cs, Cs.buf[parity], fw_ring_slot(op.child_head, (uint32_t)slot, ccap), o);
+                        fw_store_new(g, Cs, Cs.buf[parity], fw_ring_slot(child_head, (uint32_t)slot, ccap), o);
                     }
                 }
             }
@@ -2818,13 +2876,11 @@ __global__ void fw_k_restore_q3(char *buf0, char *buf1, uint32_t C, uint32_t lif
 // transposed through LDS so that every store instruction of a wave writes 1 KiB of consecutive bytes (a lane writing
 // its own record with four float4 stores would touch 64 lines a quarter at a time).
 __global__ __launch_bounds__(256) void fw_k_pack(const char *buf, uint32_t C, uint32_t head, const uint32_t *d_count,
-                                                 uint32_t n_upper, float4 *out, bool nospin, float4 rot, uint32_t range_y,
+                                                 uint32_t n_upper, float4 *out, bool nospin, float4 rot, const uint32_t *d_rold,
                                                  const FwType *derived, const float *keys, uint32_t life_plane, float life_const) {
     __shared__ float4 s_rec[256 * 4];
-    if (range_y != 0xFFFFFFFFu) {  // a range ring: `head` is the slot of the first young particle (fw_kernels.h)
-        const uint32_t c = *d_count, n_old = c > range_y ? c - range_y : 0u;
-        head = head >= n_old ? head - n_old : head + C - n_old;
-    }
+    // a range ring (d_rold: the size of its old part, FwGlobals::rold): `head` is the slot of the first young particle
+    if (d_rold) head = fw_range_head(head, *d_rold, C);
     const uint32_t n = min(*d_count, n_upper);
     const uint32_t tid = threadIdx.x;
     for (uint32_t b = blockIdx.x * 256u; b < n; b += gridDim.x * 256u) {
@@ -2898,10 +2954,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, FwSegList L, 
         const char *buf = S.buf[parity];
         const FwType &TT = g.types[S.type_idx];
         uint32_t head = L.head[k];
-        if (L.range_y[k] != 0xFFFFFFFFu) {
-            const uint32_t n_old = n > L.range_y[k] ? n - L.range_y[k] : 0u;
-            head = head >= n_old ? head - n_old : head + S.capacity - n_old;
-        }
+        if (L.range_y[k] != 0xFFFFFFFFu) head = fw_range_head(head, g.rold[parity * g.max_seg + seg], S.capacity);  // (a range ring)
         for (uint32_t li = blockIdx.x * FW_BLOCK + threadIdx.x; li < n; li += gridDim.x * FW_BLOCK) {
             const uint32_t i = fw_ring_slot(head, li, S.capacity);
             const float4 q0 = fw_ld4(buf + FW_OFF_Q0(S.capacity), i);
@@ -3264,14 +3317,14 @@ hipError_t fw_launch_fill_rotation(hipStream_t s, char *buf0, char *buf1, uint32
 }
 
 hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, const uint32_t *d_count,
-                                    uint32_t n_upper, void *d_out, const float *const_rot, uint32_t range_y, const FwType *derived,
+                                    uint32_t n_upper, void *d_out, const float *const_rot, const uint32_t *d_rold, const FwType *derived,
                                     const float *keys, uint32_t life_plane, float life_const) {
     if (!n_upper) return hipSuccess;
     uint32_t blocks = (n_upper + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     const float4 rot = const_rot ? make_float4(const_rot[0], const_rot[1], const_rot[2], const_rot[3]) : make_float4(0.f, 0.f, 0.f, 1.f);
     hipLaunchKernelGGL(fw_k_pack, dim3(blocks), dim3(256), 0, s, buf, capacity, head, d_count, n_upper, (float4 *)d_out,
-                       const_rot != nullptr, rot, range_y, derived, keys, life_plane, life_const);
+                       const_rot != nullptr, rot, d_rold, derived, keys, life_plane, life_const);
     return hipGetLastError();
 }
 
