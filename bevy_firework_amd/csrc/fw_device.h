@@ -56,7 +56,12 @@ struct alignas(16) FwSeg {
     uint32_t n_lplanes;   // number of Lk planes
     uint32_t inst_cap;    // records that fit in `inst`
     char *inst;           // attached ParticleInstance output (render hand-off fused into the update), or null
-    char *pad1;
+    // A type other particles' entries emit from, spawned INSIDE its ring's update kernel even in frames with a Nested pass
+    // (fw_engine.cpp: SegHost::virt_parent): the FwEmit of the Nested entry that owns last_emitted_age plane k (k < 2), or
+    // 0xFFFFFFFF.  The pass of the frame would have visited the new particle -- age 0, last_emitted_age f32::MIN -- emitted
+    // nothing (offsets >= 0) and left `next` in the plane (core.rs:488-500): the spawning lane computes that value itself
+    // (fw_init_last_emitted) and fw_k_spawn has nothing to materialise.
+    uint32_t lplane_emit[2];
 };
 
 // per particle type constants (ParticleSettings, reference src/core.rs:99-142)

@@ -200,6 +200,13 @@ struct alignas(64) SegHost {
     //              lifetime.min after they were added, and by then the update of their frame has long left their size in the
     //              pinned ring h_report (as for a FIFO ring that receives children).
     bool range_mat = false, range_dev = false;
+    // A ring type other particles' entries emit from whose Global particles need NOT be in memory for the frame's Nested pass:
+    // every Nested entry on it is a CountOverDuration with count > 0 and 0 <= offset_start <= offset_end, and the type's
+    // lifetimes are positive -- then compute_emission_count(age 0, last f32::MIN, ..) emits nothing for a particle born this
+    // frame (core.rs:553-575: since = min(0, end) - start <= 0) and only leaves `next` in its last_emitted_age, which the lane
+    // that spawns the particle inside the ring's update kernel computes itself (fw_init_last_emitted).  Such a type is spawned
+    // in its update kernel in EVERY frame: a steady Nested frame is fw_k_nest + the update, without fw_k_spawn.
+    bool virt_parent = false;
     struct DCohort {
         uint64_t frame;
         uint32_t n;
@@ -758,6 +765,13 @@ fw_status upload_seg(fw_ctx *ctx, uint32_t si) {
     d.type_idx = s.type_idx;
     d.n_lplanes = s.n_lplanes;
     d.inst = s.inst, d.inst_cap = s.inst_cap;
+    d.lplane_emit[0] = d.lplane_emit[1] = 0xFFFFFFFFu;
+    if (s.virt_parent && s.spawner >= 0)
+        for (uint32_t k = 0; k < s.n_lplanes && k < 2u; k++) {
+            const auto &em = ctx->spawners[s.spawner].em;
+            const int32_t ei = s.lplane_emission[k];
+            if (ei >= 0 && (size_t)ei < em.size() && em[ei].assigned) d.lplane_emit[k] = em[ei].emit_idx;
+        }
     FW_HIP(ctx, hipMemcpy(ctx->d_segs.d + si, &d, sizeof d, hipMemcpyHostToDevice));
     return FW_OK;
 }
@@ -1393,6 +1407,24 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         FW_HIP(ctx, hipMemcpy(ctx->d_emits.d + E.emit_idx, &de, sizeof de, hipMemcpyHostToDevice));
         const unsigned long long s0 = E.serial;
         FW_HIP(ctx, hipMemcpy(ctx->d_emit_serial.d + E.emit_slot, &s0, sizeof s0, hipMemcpyHostToDevice));
+    }
+    // ring types other particles' entries emit from that need no materialisation (SegHost::virt_parent)
+    for (uint32_t t = 0; t < nt; t++) {
+        SegHost &S = ctx->segs[sp.seg[t]];
+        if (!S.ring() || S.nested_fed || S.n_lplanes > 2) continue;
+        if (S.n_lplanes == 0) {  // (no entry emits from it or onto it: nothing in a Nested pass ever looks at its particles)
+            S.virt_parent = true;
+            continue;
+        }
+        const fw_particle_settings &p = d->particle_settings[t];
+        bool ok = std::min(p.lifetime.min, p.lifetime.max) > 0.0f;
+        for (uint32_t k = 0; k < S.n_lplanes && ok; k++) {
+            const fw_emission_settings &e = d->emission_settings[S.lplane_emission[k]];
+            ok = e.pacing_kind == FW_PACING_COUNT_OVER_DURATION && e.count > 0.0f && e.offset_start >= 0.0f && e.offset_end >= e.offset_start &&
+                 std::isfinite(e.count) && std::isfinite(e.offset_end);
+        }
+        S.virt_parent = ok;
+        if (ok && (st = upload_seg(ctx, sp.seg[t]))) return st;
     }
     sp.initialized = true;
     if ((st = ensure_range_arrays(ctx))) return st;
@@ -2282,11 +2314,11 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 memcpy(op.origin_rot, sp.origin_rot, sizeof sp.origin_rot);
                 memcpy(op.parent_vel, sp.parent_vel, sizeof sp.parent_vel);
                 op.speed = sp.mod_speed, op.scale = sp.mod_scale;
-                if (S.fifo && S.fifo_mat)
+                if (S.fifo && S.fifo_mat && !S.virt_parent)
                     ctx->fifo_mat_ops.push_back({(uint32_t)i, op});  // routed below, once the frame's Nested ops are known
                 else if (S.fifo)
                     ctx->fifo_ops.push_back(op);  // spawned inside fw_k_update_fifo, whatever else the frame holds
-                else if (S.range && S.range_mat)
+                else if (S.range && S.range_mat && !S.virt_parent)
                     ctx->range_mat_ops.push_back({(uint32_t)i, op});  // routed below, once the frame's Nested ops are known
                 else if (S.range)
                     ctx->range_ops.push_back(op);  // spawned inside fw_k_update_range
@@ -2698,7 +2730,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             if (!fa.n_segs) fa.write_mask = wm;
             else if (fa.write_mask != wm) fa.write_mask = -1;
             // frames that materialise (Nested pass): the segment's Global particles of this frame already sit in the ring
-            const bool mat_frame = S.fifo_mat && nested_frame;
+            const bool mat_frame = S.fifo_mat && nested_frame && !S.virt_parent;
             const bool mat = S.fifo_dev || mat_frame;
             const uint32_t n_spawn = mat_frame ? 0u : S.frame_spawn;  // spawned by fw_k_update_fifo itself
             // live particles before fw_k_update_fifo's own spawns (a type that receives children: only the device knows)
@@ -2735,6 +2767,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             F.keys_off = S.keys_off, F.keys_len = S.keys_len;
             F.head = S.head, F.n_in = n_in, F.n_spawn = n_spawn, F.dead = dead;
             F.mat = mat ? 1u : 0u;
+            F.n_lplanes = S.n_lplanes;
             F.report = S.fifo_dev ? S.h_report + (ctx->frame % kReportRing) : nullptr;
             F.op0 = f_ops;
             if (!mat_frame)
@@ -2799,7 +2832,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             r_bytes += (uint64_t)(S.range_dev ? S.capacity / 2 : S.ub) * (S.nospin ? 104u : 164u);
             S.dead_at_end = true;
             // cohorts that are no longer provably too young to die join the old part: the boundary moves, nothing is copied
-            const bool mat_frame = S.range_mat && nested_frame;  // its Global particles of this frame already sit in the ring
+            const bool mat_frame = S.range_mat && nested_frame && !S.virt_parent;  // its Global particles of this frame already sit in the ring
             uint32_t grad = 0;
             if (!S.range_dev) {
                 while (!S.ycoh.empty()) {

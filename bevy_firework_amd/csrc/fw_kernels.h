@@ -148,6 +148,7 @@ struct FwFifoSeg {
     // plane written).  report (or null): pinned host word that receives {epoch << 32 | particles added this frame} --
     // how the host learns the size of each cohort of children, long before it needs it (when the cohort dies)
     uint32_t mat;
+    uint32_t n_lplanes;  // FwSeg::n_lplanes (new particles spawned here initialise those planes: fw_init_last_emitted)
     unsigned long long *report;
 };
 #define FW_FIFO_PER_LAUNCH 8

@@ -317,6 +317,24 @@ __device__ __forceinline__ void fw_store_new(const FwGlobals &g, const FwSeg &S,
     for (uint32_t k = 0; k < S.n_lplanes; k++) fw_st1(buf + FW_OFF_L(C, k), slot, FW_F32_MIN);  // core.rs:467
 }
 
+// last_emitted_age planes of a particle spawned inside a ring's update kernel (FwSeg::lplane_emit): f32::MIN (core.rs:467), or --
+// the frame's Nested pass would have visited the new particle, entry order permitting (core.rs:377-428: entries run in index
+// order, the pass sees what earlier entries pushed) -- what that visit leaves behind: compute_emission_count(0, f32::MIN, ..)
+// emits nothing for offsets >= 0 and returns `next` (core.rs:490-500), evaluated here with the same function
+__device__ __forceinline__ void fw_init_last_emitted(const FwGlobals &g, const FwSeg &S, char *buf, uint32_t slot,
+                                                     uint32_t new_emission_index, float lifetime) {
+    const uint32_t C = S.capacity;
+    for (uint32_t k = 0; k < S.n_lplanes; k++) {
+        float v = FW_F32_MIN;
+        const uint32_t ei = k < 2u ? S.lplane_emit[k] : 0xFFFFFFFFu;
+        if (ei != 0xFFFFFFFFu) {
+            const FwEmit &e = g.emits[ei];
+            if (new_emission_index < e.emission_index) fw_emission_count(0.0f, FW_F32_MIN, lifetime, e.n_start, e.n_end, e.n_count, &v);
+        }
+        fw_st1(buf + FW_OFF_L(C, k), slot, v);
+    }
+}
+
 // Global emission: ops[] lists this frame's (segment, entry, count) triples; op i owns
 // workgroups [first_block_i, first_block_{i+1}).
 // (`ops` = device table, or null: the ops ride in the kernel arguments -- no staging copy, no event in the stream)
@@ -1799,11 +1817,13 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         const uint32_t i = n_in + k, s = sbase + tid;
         FwSpawnOut so;
         so.q0 = so.q1 = so.q2 = so.q3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t new_ei = 0u;  // emission index of the entry that spawns this lane's particle
         if (is_new) {
             uint32_t oi = F.op0;
             for (uint32_t x = F.op0; x < F.op1; x++)
                 if (k >= inl.ops[x].rel_base && k - inl.ops[x].rel_base < inl.ops[x].n) oi = x;
             const FwOp &op = inl.ops[oi];
+            new_ei = g.emits[op.emit].emission_index;
             so = fw_spawn_one(g.emits[op.emit], g.seed, op.serial_base + (k - op.rel_base),
                               fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
                               fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
@@ -1818,10 +1838,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(m) * 4u : nullptr;
         fw_v3 cpos, cvel;
         fw_coll_step<COLL>(g, CA, alive, a.dt, so.q0, so.q1, &cpos, &cvel);
-        if (alive)
+        if (alive) {
             fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
                                          (COLL && CA.on) ? &cvel : nullptr, nullptr, false, true);
-        else if (is_new && want_destroyed)  // born and destroyed in the same frame (dt >= lifetime)
+            if (F.n_lplanes) fw_init_last_emitted(g, g.segs[F.seg], buf, s, new_ei, so.q3.w);  // (a type other particles' entries emit from)
+        } else if (is_new && want_destroyed)  // born and destroyed in the same frame (dt >= lifetime)
             fw_store_destroyed(F.destroyed, buf, C, s, false, T, s_keys, so.q0, so.q1, so.q2, so.q3, age_new, i);
         fw_fifo_inst_out<INST, NT == 2>(F, inst, s_inst_wave, rec, lane, m, alive, i - n_dead);
     } else {
@@ -2066,10 +2087,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         if constexpr (ALLNOSPIN) {
             // every round's loads requested up front (9 VGPRs per round for a type that cannot turn: the kernel's budget is set
             // by the OLD path, which holds a whole tile): twice the bytes in flight per streaming workgroup
-            float4 q0a[YR], q1a[YR];
-            float lfa[YR];
+            constexpr int PF = YR < 4 ? YR : 4;  // rounds in flight (a workgroup of more rounds refills the slot it has just used)
+            float4 q0a[PF], q1a[PF];
+            float lfa[PF];
 #pragma unroll
-            for (int r = 0; r < YR; r++) {
+            for (int r = 0; r < PF; r++) {
                 const uint32_t ir = woff(r);
                 q0a[r] = fw_ldb4<NT == 2>(r0, ir), lfa[r] = fw_ldb1<NT == 2>(rl, ir / 4u), q1a[r] = fw_ldb4<NT == 2>(r1, ir);
             }
@@ -2086,16 +2108,21 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
                 uint32_t yi = s - b;  // index within the young part
                 if (s < b) yi += C;
                 const bool mine = yi < y_exist;
-                const float4 q3v = make_float4(0.0f, 0.0f, 0.0f, lfa[r]);
+                const float4 q0v = q0a[r % PF], q1v = q1a[r % PF];
+                const float4 q3v = make_float4(0.0f, 0.0f, 0.0f, lfa[r % PF]);
+                if (r + PF < YR) {
+                    const uint32_t ir = woff(r + PF);
+                    q0a[r % PF] = fw_ldb4<NT == 2>(r0, ir), lfa[r % PF] = fw_ldb1<NT == 2>(rl, ir / 4u), q1a[r % PF] = fw_ldb4<NT == 2>(r1, ir);
+                }
                 float age_new;
-                const bool surv = fw_survives(q0a[r].w, a.dt, q3v.w, &age_new);
+                const bool surv = fw_survives(q0v.w, a.dt, q3v.w, &age_new);
                 bad |= mine && !surv;
                 const unsigned long long mi = (INST && inst != nullptr) ? __ballot(mine) : 0ull;
                 float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(mi) * 4u : nullptr;
                 fw_v3 cpos, cvel;
-                fw_coll_step<COLL>(g, CA, mine, a.dt, q0a[r], q1a[r], &cpos, &cvel);
+                fw_coll_step<COLL>(g, CA, mine, a.dt, q0v, q1v, &cpos, &cvel);
                 if (mine)
-                    fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0a[r], q1a[r], q3v, q3v, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
+                    fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0v, q1v, q3v, q3v, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
                                                      (COLL && CA.on) ? &cvel : nullptr, nullptr, false, yi >= y_full);
                 if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             }
@@ -2194,8 +2221,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             fw_coll_step<COLL>(g, CA, true, a.dt, so.q0, so.q1, &cpos, &cvel);
             fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
                                               (COLL && CA.on) ? &cvel : nullptr);
-            // (a type other particles' entries emit from: last_emitted_age = [f32::MIN; n], core.rs:467)
-            for (uint32_t lk = 0; lk < Sp->n_lplanes; lk++) fw_st1(buf + FW_OFF_L(C, lk), s, FW_F32_MIN);
+            if (Sp->n_lplanes) fw_init_last_emitted(g, *Sp, buf, s, g.emits[op.emit].emission_index, so.q3.w);  // (other particles' entries emit from it)
         }
         if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, n_old_in + y_exist + kk, false);
         return;
