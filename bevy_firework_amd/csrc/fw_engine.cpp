@@ -350,6 +350,7 @@ struct fw_ctx {
     unsigned long long *h_done = nullptr;      // pinned; written by workgroup 0 of every update launch
     unsigned long long *h_err = nullptr;       // pinned; FwGlobals::err_host (h_done + 4: the same allocation)
     std::string poison_msg;                    // what poll_device_error saw
+    uint32_t n_poisoned = 0;                   // spawners ever marked (fw_step scans for live ones only while non-zero)
     uint64_t slot_frame[kParamRing] = {};      // frame that last used the slot through the zero-copy path (+1; 0 = free)
 
     // live-count snapshots written by the update kernel into pinned host memory
@@ -1585,9 +1586,10 @@ bool poll_device_error(fw_ctx *ctx) {
         news = !sp.poisoned;
         sp.poisoned = true;
         one = true;
+        ctx->n_poisoned++;
     }
     if (!one)
-        for (auto &sp : ctx->spawners) news |= sp.alive && !sp.poisoned, sp.poisoned |= sp.alive;
+        for (auto &sp : ctx->spawners) news |= sp.alive && !sp.poisoned, sp.poisoned |= sp.alive, ctx->n_poisoned++;
     if (!news) return false;
     ctx->poison_msg = "internal error: check " + std::to_string(check) + " of an update kernel failed" +
                       (one ? " for segment " + std::to_string(seg) : std::string()) +
@@ -2073,8 +2075,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // a spawner whose particle state an internal error invalidated (SpawnerHost::poisoned): no further frame is enqueued on
     // top of it -- for anybody: the frame is all-or-nothing -- until it has been rebuilt or destroyed
     poll_device_error(ctx);
-    for (const SpawnerHost &sp : ctx->spawners)
-        if (sp.alive && sp.poisoned) return poisoned_status(ctx);
+    if (ctx->n_poisoned)  // (counted, not looked for: with thousands of spawners a scan of their records would be a cost of every frame)
+        for (const SpawnerHost &sp : ctx->spawners)
+            if (sp.alive && sp.poisoned) return poisoned_status(ctx);
     poll_snapshots(ctx);
     if (ctx->derive_ready_any) {  // types whose caller-written particles have all been through an update (see the end of fw_step)
         ctx->derive_ready_any = false;

@@ -215,6 +215,54 @@ def test_config4_nested_full_rate_steady_state(system):
     assert want[259]["counts"] == want[230]["counts"]  # the steady state was reached: deaths balance the spawns
 
 
+def test_config4_nested_with_lifetime_ranges_on_range_rings(monkeypatch):
+    """configs[3]'s spawner with lifetimes that are RANGES (1.6-2.4 s, sparks and smoke alike) at its full rates, with the
+    PRODUCT'S DEFAULT thresholds: both types live in range rings (round 4) -- the sparks' ring is addressed by fw_k_nest
+    through the size of its old part (FwGlobals::rold), its new particles are spawned inside the update kernel and carry the
+    last_emitted_age the frame's Nested pass would have left (fw_init_last_emitted); the smoke ring's particle count is known
+    to the device alone (FW_RREC_DEV), its cohorts join the old part by sizes read from the pinned report ring a lifetime.min
+    later.  200 frames (56 past the longest lifetime: both types lose particles every frame, the old parts are compacted in
+    place, last_emitted_age planes move with the surviving sparks) against the oracle: the whole state at two frames, counts
+    and digests of the exact fields at three more, > 3M particles."""
+    from bevy_firework_amd.system import ParticleSystem
+
+    monkeypatch.setenv("FW_ENABLE_KNOBS", "1")
+    for k in ("FW_FIFO", "FW_FIFO_MIN", "FW_RANGE", "FW_RANGE_MIN"):
+        monkeypatch.delenv(k, raising=False)
+    spawner, tf = workloads.nested(spark_rate=100000.0, smoke_per_spark=20.0)
+    for ps in spawner.particle_settings:
+        ps.lifetime = S.RandF32(1.6, 2.4)
+    full, digest = (150, 199), (60, 100, 175)
+    o = oracle.OracleSpawner(spawner, seed=SEED, uid=2, transform=tf)
+    want = {}
+    for fr in range(200):
+        o.step(DT)
+        if fr in full or fr in digest:
+            parts = [o.particles(t) for t in (0, 1)]
+            want[fr] = {"counts": o.counts(), "digest": [_digest(p) for p in parts], "lea": o.last_emitted(0, 1).copy(),
+                        "parts": [p.copy() for p in parts] if fr in full else None}
+    o.close()
+    with ParticleSystem(device=0, seed=SEED) as system:
+        h = system.spawn(spawner, tf, uid=2)
+        assert [h.update_path(t)[0] for t in (0, 1)] == ["range", "range"]
+        for fr in range(200):
+            system.update(DT)
+            if fr not in want:
+                continue
+            w = want[fr]
+            assert h.counts() == w["counts"], (fr, h.counts(), w["counts"])
+            parts = [h.particles(t) for t in (0, 1)]
+            assert [_digest(p) for p in parts] == w["digest"], f"frame {fr}: exact-field digests differ"
+            assert np.array_equal(h.last_emitted(0, 1), w["lea"]), f"frame {fr}: last_emitted_age"
+            for t in (0, 1):
+                assert (parts[t]["age"] < parts[t]["lifetime"]).all() and (np.diff(parts[t]["age"]) <= 0).all(), (fr, t)
+                if w["parts"] is not None:
+                    assert_particles_match(parts[t], w["parts"][t], what=f"nested lifetime ranges, frame {fr}, type {t}")
+        assert [h.update_path(t)[0] for t in (0, 1)] == ["range", "range"]
+        c = h.counts()
+        assert c[1] > 3_000_000 and c[0] > 150_000, c
+
+
 def test_single_segment_beyond_the_entry_table(system):
     """one particle type with more than FW_FC_DIRECT (2048) tiles: the survivor forecast switches from one plain entry
     per tile to atomic per-tile sums + group sums, and back when enough particles have died; counts, order and
