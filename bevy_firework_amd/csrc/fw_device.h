@@ -186,7 +186,7 @@ struct alignas(16) FwNestOp {
 #define FW_ERR_LOOKBACK_TIMEOUT 2u
 #define FW_ERR_FORECAST 4u          // a forecast entry carried the wrong frame tag (internal error)
 
-// survivor forecast sums (fw_kernels.hip), in 64-bit words: stride between consecutive group counters P2 (one 64-byte
+// survivor forecast sums (fw_dev.h), in 64-bit words: stride between consecutive group counters P2 (one 64-byte
 // line each: they are hot) and the segment size up to which tiles sum P directly instead of using P2
 #define FW_FC_S2_STRIDE 8u
 #define FW_FC_DIRECT 2048u

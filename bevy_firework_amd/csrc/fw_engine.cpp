@@ -442,7 +442,7 @@ struct fw_ctx {
     // An in-place ring launch (FIFO / range) that streams more than nt_bytes uses the fully non-temporal form of its kernel:
     // several times the 256 MiB Infinity Cache, where allocating lines that cannot survive until the next frame only costs.
     // One that streams more than nt_wo_bytes -- no longer all of it fits -- stores the planes no update reads back (scale,
-    // colours) non-temporally, so that the cache keeps what the next frame reads (fw_kernels.hip: fw_ld4w; knobs FW_NT_MB=n,
+    // colours) non-temporally, so that the cache keeps what the next frame reads (fw_dev.h: fw_ld4w; knobs FW_NT_MB=n,
     // FW_NT_WO_MB=n: 0 = always)
     uint64_t nt_bytes = 768ull << 20;  // (crossover measured at 0.65-0.85 GB for both kernels: profiles/r03/nt_sweep.txt)
     // (the write-only form measured over 50-970 MB, profiles/r03/nt_sweep_wo.txt: range rings gain from the smallest size on

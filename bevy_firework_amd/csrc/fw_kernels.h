@@ -1,5 +1,5 @@
 // fw_kernels.h -- launch interface between the host engine (fw_engine.cpp) and the
-// gfx950 kernels (fw_kernels.hip).
+// gfx950 kernels (fw_k_general.hip, fw_k_rings.hip, fw_k_nested.hip, fw_k_aux.hip; shared device helpers: fw_dev.h).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -157,7 +157,7 @@ struct FwFifoArgs {
     uint32_t n_segs, parity, epoch, dbg;
     float dt;
     uint32_t any_inst;
-    uint32_t any_coll;  // some segment's particle type has collision settings: the launch runs the COLL instantiation (fw_kernels.hip: FwCollArm)
+    uint32_t any_coll;  // some segment's particle type has collision settings: the launch runs the COLL instantiation (fw_k_rings.hip: FwCollArm)
     // which optional planes the particle types of this launch write: bit 0 base colour (gradient not constant), bit 1
     // emissive colour, bit 2 scale (curve not constant) when all its segments agree -- the kernel is then compiled for
     // exactly that set of stores; -1: they differ, read the flags from each type
@@ -247,7 +247,7 @@ hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifo
                                  uint32_t total_tiles, int nt, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 uint32_t fw_range_young_tile(void);  // ring slots a YOUNG workgroup of fw_k_update_range covers (a build-time choice)
 // in-place update of every range ring of the context (all_nospin: no segment of the launch keeps a rotation plane)
-// nt: which form of the kernel (fw_kernels.hip, fw_ld4w): 0 plain, 1 the write-only planes non-temporal, 2 every plane access
+// nt: which form of the kernel (fw_dev.h: fw_ld4w): 0 plain, 1 the write-only planes non-temporal, 2 every plane access
 hipError_t fw_launch_update_range(hipStream_t s, const FwGlobals &g, const FwRangeArgs &a, bool all_nospin, int nt,
                                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d_ops, const FwNestOp *h_ops, uint32_t n_ops,
