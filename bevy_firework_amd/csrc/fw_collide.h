@@ -12,7 +12,8 @@ struct alignas(16) FwCollider {
     int32_t kind;
     uint32_t layers;
     float radius;
-    float pad0;
+    float bound;           // radius of a sphere around `position` that contains the collider (INFINITY for a plane): set by the host
+                           // (fw_ctx_set_colliders); lets a wave skip a collider none of its rays can reach (fw_cast_ray)
     float position[4];
     float rotation[4];     // xyzw (BOX)
     float normal[4];       // PLANE
@@ -74,8 +75,12 @@ FW_HD bool fw_ray_collider(const FwCollider &c, fw_v3 origin, fw_v3 dir, float m
     // BOX: slabs in the box's own frame
     const fw_q4 q{c.rotation[0], c.rotation[1], c.rotation[2], c.rotation[3]};
     const fw_q4 qi{-q.x, -q.y, -q.z, q.w};  // conjugate = inverse of a unit quaternion
-    const fw_v3 ol = fw_quat_mul_vec3(qi, fw_sub3(origin, cpos));
-    const fw_v3 dl = fw_quat_mul_vec3(qi, dir);
+    // (an axis-aligned box -- the identity rotation, e.g. the ground slab of examples/stress_test_collision.rs -- needs no
+    // rotations: Quat::IDENTITY * v is v itself up to the sign of a zero component, which no comparison or quotient below
+    // depends on (a zero direction component takes the `== 0` arm); the results are the general path's bit for bit)
+    const bool aligned = q.x == 0.0f && q.y == 0.0f && q.z == 0.0f && q.w == 1.0f;
+    const fw_v3 ol = aligned ? fw_sub3(origin, cpos) : fw_quat_mul_vec3(qi, fw_sub3(origin, cpos));
+    const fw_v3 dl = aligned ? dir : fw_quat_mul_vec3(qi, dir);
     // (the three slabs written out one by one, in axis order: indexed arrays of three would live in scratch memory on the device)
     const float hx = c.half_extents[0], hy = c.half_extents[1], hz = c.half_extents[2];
     if (fabsf(ol.x) <= hx && fabsf(ol.y) <= hy && fabsf(ol.z) <= hz) {  // inside (or on) the box
@@ -109,7 +114,7 @@ FW_HD bool fw_ray_collider(const FwCollider &c, fw_v3 origin, fw_v3 dir, float m
     if (axis == 0) nl.x = sign;
     else if (axis == 1) nl.y = sign;
     else nl.z = sign;
-    *hit = FwRayHit{tnear, fw_quat_mul_vec3(q, nl)};
+    *hit = FwRayHit{tnear, aligned ? nl : fw_quat_mul_vec3(q, nl)};
     return true;
 }
 
@@ -117,14 +122,31 @@ FW_HD bool fw_ray_collider(const FwCollider &c, fw_v3 origin, fw_v3 dir, float m
 FW_HD bool fw_cast_ray(const FwCollider *colliders, uint32_t n, uint32_t mask, fw_v3 origin, fw_v3 dir, float max_distance,
                        FwRayHit *best) {
     bool any = false;
+    // (the best hit so far in scalars, written to *best once at the end: a struct updated through a pointer inside the loop
+    // lived in scratch memory on the device)
+    float bd = 0.0f, bnx = 0.0f, bny = 0.0f, bnz = 0.0f;
     for (uint32_t i = 0; i < n; i++) {
         if (!(colliders[i].layers & mask)) continue;
+#ifdef __HIP_DEVICE_COMPILE__
+        {
+            // A collider NO lane of the wave can reach this sub-step is skipped by the whole wave (a uniform branch): its
+            // bounding sphere lies further from every lane's origin than the ray is long.  A ray that meets the collider, or
+            // starts inside it, is closer than bound + max_distance; the factor covers fp32 rounding of the comparison, and a
+            // NaN / infinite operand compares false: no skip.  Skipped colliders report no hit either way, so the result is the
+            // host oracle's, which tests every collider.
+            const fw_v3 dc = fw_sub3(origin, fw_v3{colliders[i].position[0], colliders[i].position[1], colliders[i].position[2]});
+            const float reach = colliders[i].bound + max_distance;
+            const bool far = fw_dot3(dc, dc) > reach * reach * 1.0001f + 1e-12f;
+            if (__ballot(!far) == 0ull) continue;
+        }
+#endif
         FwRayHit h;
-        if (fw_ray_collider(colliders[i], origin, dir, max_distance, &h) && (!any || h.distance < best->distance)) {
-            *best = h;
+        if (fw_ray_collider(colliders[i], origin, dir, max_distance, &h) && (!any || h.distance < bd)) {
+            bd = h.distance, bnx = h.normal.x, bny = h.normal.y, bnz = h.normal.z;
             any = true;
         }
     }
+    *best = FwRayHit{bd, fw_v3{bnx, bny, bnz}};
     return any;
 }
 

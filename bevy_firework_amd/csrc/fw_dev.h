@@ -369,7 +369,7 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
                                                    float4 q2, float4 q3, float age_new, const FwOutWin &W, uint32_t o,
                                                    float4 *rec = nullptr, const fw_v3 *cpos = nullptr,
                                                    const fw_v3 *cvel = nullptr, float *box = nullptr,
-                                                   bool box_on = false, bool full = false) {
+                                                   bool box_on = false, bool full = false, bool use_c = true) {
     if (T.flags & FW_TYPE_NOSPIN) q2 = make_float4(T.const_rot[0], T.const_rot[1], T.const_rot[2], T.const_rot[3]);
     const float lifetime = q3.w;
     const float age_percent = age_new / lifetime;
@@ -377,9 +377,12 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     const float scale = q1.w * scale_factor;
     // explicit Euler with the OLD velocity (core.rs:626-631, 641-643); cpos / cvel: what particle_collision returned
     // for a type with collision settings (core.rs:607-624) -- the velocity update then starts from the new velocity
-    const float ux = cvel ? cvel->x : q1.x, uy = cvel ? cvel->y : q1.y, uz = cvel ? cvel->z : q1.z;
-    const float px = cpos ? cpos->x : q0.x + q1.x * dt, py = cpos ? cpos->y : q0.y + q1.y * dt,
-                pz = cpos ? cpos->z : q0.z + q1.z * dt;
+    // (use_c: a runtime "this type collides" next to pointers that are null or not at compile time -- a pointer SELECTED at
+    // run time between a local's address and null would force the local into scratch memory)
+    const bool uc = cpos != nullptr && cvel != nullptr && use_c;
+    const float ux = uc ? cvel->x : q1.x, uy = uc ? cvel->y : q1.y, uz = uc ? cvel->z : q1.z;
+    const float px = uc ? cpos->x : q0.x + q1.x * dt, py = uc ? cpos->y : q0.y + q1.y * dt,
+                pz = uc ? cpos->z : q0.z + q1.z * dt;
     const float vx = ux + (T.acc[0] - ux * T.lin_drag) * dt;
     const float vy = uy + (T.acc[1] - uy * T.lin_drag) * dt;
     const float vz = uz + (T.acc[2] - uz * T.lin_drag) * dt;

@@ -216,6 +216,7 @@ struct alignas(64) SegHost {
     std::deque<YCohort> gcoh;   // range_dev: cohorts that have joined the old part and may still hold survivors (their bound)
     uint64_t gcoh_sum = 0;
     uint32_t rold_seen = 0;     // the old part's size as of the last exact read (refresh_counts_exact): FwGlobals::rold
+    uint32_t r_young_main = 0;  // range_dev: young tiles the current table keeps in front (the rest: probably idle, at its end)
     uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
     uint32_t r_low[3] = {0, 0, 0};               // frames in a row a role's need has been far below what is provided
     uint32_t r_need[3] = {0, 0, 0};              // what each role needed in the latest frame (the table keeps more: fit())
@@ -1908,6 +1909,11 @@ fw_status fw_ctx_set_colliders(fw_ctx *ctx, const fw_collider *colliders, uint32
         FwCollider &d = ctx->h_coll[slot][i];
         d = FwCollider{};
         d.kind = c.kind, d.layers = c.layers, d.radius = c.radius;
+        // (the sphere around `position` that contains it: a wave skips a collider none of its rays can reach, fw_cast_ray)
+        d.bound = c.kind == 1 ? c.radius
+                  : c.kind == 2 ? std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]) * 1.0001f
+                                : INFINITY;
+        if (!(d.bound >= 0.0f)) d.bound = INFINITY;  // (NaN / negative extents: never skipped)
         memcpy(d.position, c.position, sizeof c.position);
         memcpy(d.rotation, c.rotation, sizeof c.rotation);
         memcpy(d.normal, c.normal, sizeof c.normal);
@@ -2912,6 +2918,16 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 }
             };
             S.r_need[0] = need_old, S.r_need[1] = need_new, S.r_need[2] = need_young;
+            if (S.range_dev) {
+                // the grid covers the ring, but how far behind b the young part reaches is roughly known: the count of the latest
+                // snapshot row (+ a fifth, + what a few frames add).  Tiles beyond that are "probably idle" and go to the end of
+                // the table, where they run while the launch drains (a tile that does hold particles simply updates them
+                // there); the split follows the count in steps of an eighth
+                const uint64_t est = (uint64_t)((double)S.dev_count * 1.2 + 8.0 * (double)S.dev_rate) + 2 * YT;
+                const uint32_t likely = (uint32_t)std::min<uint64_t>(need_young, (est + YT - 1) / YT);
+                if (likely > S.r_young_main || likely + likely / 4 + 8 < S.r_young_main) S.r_young_main = std::min(need_young, likely + likely / 8 + 2), dirty = true;
+                S.r_need[2] = S.r_young_main;
+            }
             fit(S.r_old, need_old, need_old >= 8 ? need_old / 4 : 1u, S.r_low[0]);
             fit(S.r_new, need_new, need_new ? (need_new >= 8 ? need_new / 8 : 1u) : 0u, S.r_low[1]);
             fit(S.r_young, need_young, need_young >= 16 ? need_young / 8 : 1u, S.r_low[2]);

@@ -1048,8 +1048,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpda
         const uint32_t o = wbase + fw_lane_prefix(m);
         if (alive) {
             float4 rec[4];
-            fw_integrate_store(T, s_keys, a.dt, q0, q1, q2, q3, age_new, W, o, inst ? rec : nullptr, coll ? &cpos : nullptr,
-                               coll ? &cvel : nullptr);
+            // (the record is always built and the collision values always passed by address, with run-time flags next to them: a
+            // pointer selected at run time between a local's address and null forces the local into scratch memory)
+            fw_integrate_store(T, s_keys, a.dt, q0, q1, q2, q3, age_new, W, o, rec, &cpos, &cvel, nullptr, false, false, coll);
             if (inst != nullptr && o < inst_cap) {
                 fw_st4(inst, o * 4u + 0u, rec[0]), fw_st4(inst, o * 4u + 1u, rec[1]);
                 fw_st4(inst, o * 4u + 2u, rec[2]), fw_st4(inst, o * 4u + 3u, rec[3]);

@@ -187,8 +187,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         fw_v3 cpos, cvel;
         fw_coll_step<COLL>(g, CA, alive, a.dt, so.q0, so.q1, &cpos, &cvel);
         if (alive) {
-            fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
-                                         (COLL && CA.on) ? &cvel : nullptr, nullptr, false, true);
+            fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, COLL ? &cpos : nullptr,
+                                         COLL ? &cvel : nullptr, nullptr, false, true, CA.on);
             if (F.n_lplanes) fw_init_last_emitted(g, g.segs[F.seg], buf, s, new_ei, so.q3.w);  // (a type other particles' entries emit from)
         } else if (is_new && want_destroyed)  // born and destroyed in the same frame (dt >= lifetime)
             fw_store_destroyed(F.destroyed, buf, C, s, false, T, s_keys, so.q0, so.q1, so.q2, so.q3, age_new, i);
@@ -242,8 +242,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
                     if (WM >= 0 ? (WM & 2) != 0 : W.wr6) fw_st4w<NT != 0>(W.q6, b16, q1c);
                     if (WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) fw_st1w<NT != 0>(W.s4, (s - W.first) * 4u, q1c.w);
                 } else {
-                    fw_integrate_store<true, WM, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
-                                                 (COLL && CA.on) ? &cvel : nullptr, nullptr, false, i >= full_from);
+                    fw_integrate_store<true, WM, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, COLL ? &cpos : nullptr,
+                                                 COLL ? &cvel : nullptr, nullptr, false, i >= full_from, CA.on);
                 }
             }
             fw_fifo_inst_out<INST, NT == 2>(F, inst, s_inst_wave, rec, lane, m, alive, i - n_dead);
@@ -470,8 +470,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
                 fw_v3 cpos, cvel;
                 fw_coll_step<COLL>(g, CA, mine, a.dt, q0v, q1v, &cpos, &cvel);
                 if (mine)
-                    fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0v, q1v, q3v, q3v, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
-                                                     (COLL && CA.on) ? &cvel : nullptr, nullptr, false, yi >= y_full);
+                    fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0v, q1v, q3v, q3v, age_new, W, s, rec, COLL ? &cpos : nullptr,
+                                                     COLL ? &cvel : nullptr, nullptr, false, yi >= y_full, CA.on);
                 if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             }
             if (__any(bad) && lane == 0) fw_raise(g, 7u, seg, blockIdx.x);
@@ -517,8 +517,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             fw_v3 cpos, cvel;
             fw_coll_step<COLL>(g, CA, mine, a.dt, q0c, q1c, &cpos, &cvel);
             if (mine)
-                fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
-                                                 (COLL && CA.on) ? &cvel : nullptr, nullptr, false, yi >= y_full);
+                fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, COLL ? &cpos : nullptr,
+                                                 COLL ? &cvel : nullptr, nullptr, false, yi >= y_full, CA.on);
             if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n, lfc = lfn;
             q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f, lfn = lff;
@@ -567,8 +567,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
             fw_v3 cpos, cvel;
             fw_coll_step<COLL>(g, CA, true, a.dt, so.q0, so.q1, &cpos, &cvel);
-            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
-                                              (COLL && CA.on) ? &cvel : nullptr);
+            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, COLL ? &cpos : nullptr,
+                                              COLL ? &cvel : nullptr, nullptr, false, false, CA.on);
             if (Sp->n_lplanes) fw_init_last_emitted(g, *Sp, buf, s, g.emits[op.emit].emission_index, so.q3.w);  // (other particles' entries emit from it)
         }
         if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, n_old_in + y_exist + kk, false);
@@ -697,8 +697,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         if (alive) {
             uint32_t s = bm1 - od;
             if (s >= C) s -= C;
-            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], W, s, rec, (COLL && CA.on) ? &cpos : nullptr,
-                                              (COLL && CA.on) ? &cvel : nullptr);
+            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], W, s, rec, COLL ? &cpos : nullptr,
+                                              COLL ? &cvel : nullptr, nullptr, false, false, CA.on);
             if (nlp) {
 #pragma unroll
                 for (int j = 0; j < FW_RANGE_LK; j++)

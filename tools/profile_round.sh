@@ -1,6 +1,8 @@
 #!/bin/bash
 export FW_ENABLE_KNOBS=1   # the library honours its A/B switches only with this set
 # Produce the committed profile artefacts of a round (run on the GPU box):  tools/profile_round.sh r02
+# (rounds 2 and 3; round 4 uses tools/profile_r04.sh.  Steps that set FW_DEBUG / FW_HOST_PROF / FW_DERIVED / FW_FIFO_NESTED need the
+# `ab` build since round 4: export FW_LIB_PATH=$PWD/bevy_firework_amd/csrc/libfirework_hip_ab.so first.)
 TAG=${1:-r02}
 R=$PWD; OUT=gpurun_out/profile_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 # 1. the bench line itself (default flags)
@@ -33,7 +35,7 @@ timeout 300 python tools/small_emitters_gpu.py > $OUT/small_emitters.txt 2>&1
 FW_HOST_PROF=1 timeout 300 python tools/small_emitters.py >> $OUT/small_emitters.txt 2>&1
 # 6b. range rings (round 3): same-box A/B against the compacting path and the two knobs that lost, the size sweep, and
 #     rocprofv3 kernel-trace summaries of configs[2] / configs[4]'s share / configs[3] (tools/prof_configs.sh)
-timeout 900 tools/range_ab.sh "" "FW_RANGE=0" "FW_RANGE_DEVREC=1" "FW_RANGE_FOLD=1" > $OUT/range_ab.txt 2>&1
+timeout 900 tools/range_ab.sh "" "FW_RANGE=0" > $OUT/range_ab.txt 2>&1   # (the knobs FW_RANGE_DEVREC / FW_RANGE_FOLD of round 3 lost and are gone)
 (timeout 600 python tools/range_sweep.py; echo "FW_RANGE=0:"; FW_RANGE=0 timeout 600 python tools/range_sweep.py) > $OUT/range_sweep.txt 2>&1
 timeout 1200 tools/prof_configs.sh $TAG > /dev/null 2>&1; cp gpurun_out/prof_configs_$TAG/*_kernel_stats.csv gpurun_out/prof_configs_$TAG/*_trace_summary.txt gpurun_out/prof_configs_$TAG/*_bench.json $OUT/ 2>/dev/null
 timeout 600 python tools/nt_sweep.py > $OUT/nt_sweep.txt 2>&1   # plain against fully non-temporal ring kernels over 0.2-2.6 GB
