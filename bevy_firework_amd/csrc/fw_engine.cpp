@@ -2708,6 +2708,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         const hipStream_t fstream = side ? ctx->fifo_stream : ctx->stream;
         FwFifoArgs fa{};
         FwInlineOps fio;
+        // (with a colliding ring in the context every FIFO launch of it runs the COLL instantiation, whose workgroups cover one
+        // round -- FW_FIFO_COLL_TILE slots -- each: the tile grid of all of them follows)
+        bool fifo_coll = false;
+        for (const SegHost &S : ctx->segs) fifo_coll |= S.in_use && S.fifo && S.collides;
         uint32_t f_ops = 0, f_tiles = 0;
         uint64_t f_bytes = 0;  // what the launch streams, roughly: its tiles x the bytes a particle of the type moves
         auto flush = [&]() -> hipError_t {
@@ -2789,7 +2793,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             // only the device knows: the whole ring, empty tiles leave at once); at least one in all (it publishes the counts)
             const uint32_t n_old = S.fifo_dev ? S.capacity : n_in;
             const uint32_t lo = std::min(S.destroyed ? 0u : dead, n_old), cnt = n_old - lo;
-            const uint32_t ftile = FW_TILE;
+            const uint32_t ftile = fifo_coll ? FW_FIFO_COLL_TILE : FW_TILE;
             const uint32_t ps = (uint32_t)(((uint64_t)S.head + lo) % S.capacity), ring_tiles = S.capacity / ftile;
             const uint32_t ns0 = (uint32_t)(((uint64_t)S.head + (S.fifo_dev ? 0u : n_in)) % S.capacity);  // slot of the first new particle
             F.spawn_a = std::min(n_spawn, S.capacity - ns0);
@@ -2801,7 +2805,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             f_tiles += F.n_tiles;
             f_bytes += (uint64_t)live_tiles * ftile * (S.nospin ? 104u : 164u);
             fa.any_inst |= S.inst != nullptr ? 1u : 0u;
-            fa.any_coll |= S.collides ? 1u : 0u;
+            fa.any_coll |= fifo_coll ? 1u : 0u;
             S.head = (uint32_t)(((uint64_t)S.head + dead) % S.capacity);
             if (!S.fifo_dev) S.ub = n_in + n_spawn - std::min(dead, n_in + n_spawn);  // exact
         }

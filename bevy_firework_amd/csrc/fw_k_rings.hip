@@ -68,12 +68,16 @@ __device__ __forceinline__ void fw_coll_step(const FwGlobals &g, const FwCollArm
 #ifndef FW_FIFO_UNROLL
 #define FW_FIFO_UNROLL 4
 #endif
-template <bool INST, int WM, int NT = 0, bool COLL = false>
+// TR: rounds per workgroup = ring tile / 256.  Four for the streaming instantiations; ONE for the colliding ones (FwFifoArgs::
+// tile): a colliding particle is a few hundred dependent instructions of ray casts per sub-step, the launch is bound by how
+// many waves work at once, not by memory -- the reference's own stress_test_collision (157k particles) is 154 workgroups of
+// four rounds, fewer than the chip has CUs, or 615 of one.
+template <bool INST, int WM, int NT = 0, bool COLL = false, int TR = FW_ROUNDS>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifoArgs a, FwInlineOps inl) {
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
-    constexpr int R = FW_TILE / BLK;  // (smaller ring tiles were measured: 2 rounds 26.7 us, 1 round 26.2 us, 4 rounds 24.6 us)
-    constexpr uint32_t TILE = FW_TILE;
+    constexpr int R = TR;  // (smaller ring tiles were measured for the streaming case: 2 rounds 26.7 us, 1 round 26.2 us, 4 rounds 24.6 us)
+    constexpr uint32_t TILE = (uint32_t)(BLK * TR);
     __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
     __shared__ __attribute__((aligned(16))) float4 s_inst[INST ? NW * 256 : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -124,8 +128,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
     if (!spawner && !defer) {
         q0c = fw_ld4w<NT == 2>(iw0, tid * 16u), q3c = fw_ld4w<NT == 2>(iw3, (tid * 16u) & m2);
         q1c = fw_ld4w<NT == 2>(iw1, tid * 16u), q2c = fw_ld4w<NT == 2>(iw2, (tid * 16u) & m2);
-        q0n = fw_ld4w<NT == 2>(iw0, i1), q3n = fw_ld4w<NT == 2>(iw3, i1 & m2);
-        q1n = fw_ld4w<NT == 2>(iw1, i1), q2n = fw_ld4w<NT == 2>(iw2, i1 & m2);
+        if constexpr (R > 1) {
+            q0n = fw_ld4w<NT == 2>(iw0, i1), q3n = fw_ld4w<NT == 2>(iw3, i1 & m2);
+            q1n = fw_ld4w<NT == 2>(iw1, i1), q2n = fw_ld4w<NT == 2>(iw2, i1 & m2);
+        }
     }
     if (defer) {
         uint32_t i0 = sbase - head;
@@ -133,8 +139,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         if (tis != 0u && !(i0 < n_tot || (i0 + TILE > C && n_tot != 0u))) return;
         q0c = fw_ld4w<NT == 2>(iw0, tid * 16u), q3c = fw_ld4w<NT == 2>(iw3, (tid * 16u) & m2);
         q1c = fw_ld4w<NT == 2>(iw1, tid * 16u), q2c = fw_ld4w<NT == 2>(iw2, (tid * 16u) & m2);
-        q0n = fw_ld4w<NT == 2>(iw0, i1), q3n = fw_ld4w<NT == 2>(iw3, i1 & m2);
-        q1n = fw_ld4w<NT == 2>(iw1, i1), q2n = fw_ld4w<NT == 2>(iw2, i1 & m2);
+        if constexpr (R > 1) {
+            q0n = fw_ld4w<NT == 2>(iw0, i1), q3n = fw_ld4w<NT == 2>(iw3, i1 & m2);
+            q1n = fw_ld4w<NT == 2>(iw1, i1), q2n = fw_ld4w<NT == 2>(iw2, i1 & m2);
+        }
     }
     if (blockIdx.x == 0 && tid == 0) {
         if (a.live_next) *a.live_next = 0ull;
@@ -220,8 +228,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         for (int r = 0; r < R; r++) {
             const uint32_t s = sbase + r * BLK + tid;
             const uint32_t in_ = (uint32_t)(min(r + 2, R - 1) * BLK + (int)tid) * 16u;  // two rounds ahead (the last re-read)
-            const float4 q0f = fw_ld4w<NT == 2>(iw0, in_), q3f = fw_ld4w<NT == 2>(iw3, in_ & m2);
-            const float4 q1f = fw_ld4w<NT == 2>(iw1, in_), q2f = fw_ld4w<NT == 2>(iw2, in_ & m2);
+            float4 q0f = q0c, q3f = q3c, q1f = q1c, q2f = q2c;
+            if constexpr (R > 1) {  // (a one-round workgroup has nothing to prefetch)
+                q0f = fw_ld4w<NT == 2>(iw0, in_), q3f = fw_ld4w<NT == 2>(iw3, in_ & m2);
+                q1f = fw_ld4w<NT == 2>(iw1, in_), q2f = fw_ld4w<NT == 2>(iw2, in_ & m2);
+            }
             if (nospin) q3c = q3s;
             uint32_t i = s - head;  // logical index of the slot
             if (s < head) i += C;
@@ -740,14 +751,15 @@ hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifo
     if (!total_tiles || !a.n_segs) return hipErrorInvalidValue;
     const dim3 grid(total_tiles), block(FW_BLOCK);
     if (a.any_coll) {  // some ring of the launch collides (FwCollArm): generic write mask, plain or fully non-temporal
+        // (one round per workgroup -- ring tiles of FW_FIFO_COLL_TILE slots: the host laid the launch out on that grid)
         if (a.any_inst && nt == 2)
-            FW_LAUNCH_T((fw_k_update_fifo<true, -1, 2, true>), grid, block, s, e0, e1, g, a, inl);
+            FW_LAUNCH_T((fw_k_update_fifo<true, -1, 2, true, 1>), grid, block, s, e0, e1, g, a, inl);
         else if (a.any_inst)
-            FW_LAUNCH_T((fw_k_update_fifo<true, -1, 0, true>), grid, block, s, e0, e1, g, a, inl);
+            FW_LAUNCH_T((fw_k_update_fifo<true, -1, 0, true, 1>), grid, block, s, e0, e1, g, a, inl);
         else if (nt == 2)
-            FW_LAUNCH_T((fw_k_update_fifo<false, -1, 2, true>), grid, block, s, e0, e1, g, a, inl);
+            FW_LAUNCH_T((fw_k_update_fifo<false, -1, 2, true, 1>), grid, block, s, e0, e1, g, a, inl);
         else
-            FW_LAUNCH_T((fw_k_update_fifo<false, -1, 0, true>), grid, block, s, e0, e1, g, a, inl);
+            FW_LAUNCH_T((fw_k_update_fifo<false, -1, 0, true, 1>), grid, block, s, e0, e1, g, a, inl);
         return hipGetLastError();
     }
     if (nt) {  // non-temporal forms (fw_ld4w): the generic write mask only -- beyond the Infinity Cache the compile-time one buys nothing

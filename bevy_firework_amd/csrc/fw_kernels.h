@@ -152,6 +152,7 @@ struct FwFifoSeg {
     unsigned long long *report;
 };
 #define FW_FIFO_PER_LAUNCH 8
+#define FW_FIFO_COLL_TILE FW_BLOCK  // ring tile of a FIFO launch with colliding types: one round per workgroup (fw_k_update_fifo: TR)
 struct FwFifoArgs {
     FwFifoSeg s[FW_FIFO_PER_LAUNCH];
     uint32_t n_segs, parity, epoch, dbg;
