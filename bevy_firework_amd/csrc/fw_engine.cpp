@@ -408,6 +408,7 @@ struct fw_ctx {
     // launch runs on its own stream (fifo_stream) and wins at any size (tools/fifo_threshold.py, tools/mixed_context.py);
     // where it cannot -- attached instance buffers, Nested spawners, a registered live-count ring -- the two launches of
     // a mixed context run one after the other and a small ring costs a few microseconds more than it saves.
+    uint32_t fifo_small_tiles = 384;  // FIFO launches of a context with fewer four-round tiles than this use one-round tiles (FW_FIFO_SMALL)
     uint32_t fifo_min = 32768;
     uint32_t n_fifo = 0;       // FIFO segments in use (at most kMaxFifoSegs: their records travel in kernel arguments)
     std::vector<FwOp> fifo_ops;  // this frame's Global ops that feed FIFO segments (spawned inside fw_k_update_fifo)
@@ -1768,6 +1769,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_SPIN_LIMIT")) ctx->spin_limit = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_FIFO")) ctx->use_fifo = atoi(m) != 0;
     if (const char *m = getenv("FW_FIFO_MIN")) ctx->fifo_min = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_FIFO_SMALL")) ctx->fifo_small_tiles = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_FIFO_STREAM")) ctx->use_fifo_stream = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE")) ctx->use_range = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_MIN")) ctx->range_min = (uint32_t)strtoul(m, nullptr, 10);
@@ -2711,7 +2713,18 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         // (with a colliding ring in the context every FIFO launch of it runs the COLL instantiation, whose workgroups cover one
         // round -- FW_FIFO_COLL_TILE slots -- each: the tile grid of all of them follows)
         bool fifo_coll = false;
-        for (const SegHost &S : ctx->segs) fifo_coll |= S.in_use && S.fifo && S.collides;
+        // ... and so do the launches of a context whose rings hold too few particles to fill the chip with four-round workgroups
+        // (the reference's own stress_test: 157k particles = 154 of them on 256 CUs, each lane working through four particles one
+        // after the other): below FW_FIFO_SMALL four-round tiles in all, one round per workgroup.  Not with a ring whose count
+        // only the device knows (its grid covers its capacity: four times the idle workgroups).
+        uint64_t fifo_particles = 0;
+        bool fifo_any_dev = false;
+        for (const SegHost &S : ctx->segs)
+            if (S.in_use && S.fifo) fifo_coll |= S.collides, fifo_any_dev |= S.fifo_dev, fifo_particles += S.ub;
+        const bool fifo_small = !fifo_any_dev && fifo_particles < (uint64_t)ctx->fifo_small_tiles * FW_TILE;
+        fifo_coll |= fifo_small;  // (the same tile grid; which instantiation runs: FwFifoArgs::any_coll / small_tiles)
+        bool fifo_coll_real = false;
+        for (const SegHost &S : ctx->segs) fifo_coll_real |= S.in_use && S.fifo && S.collides;
         uint32_t f_ops = 0, f_tiles = 0;
         uint64_t f_bytes = 0;  // what the launch streams, roughly: its tiles x the bytes a particle of the type moves
         auto flush = [&]() -> hipError_t {
@@ -2805,7 +2818,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             f_tiles += F.n_tiles;
             f_bytes += (uint64_t)live_tiles * ftile * (S.nospin ? 104u : 164u);
             fa.any_inst |= S.inst != nullptr ? 1u : 0u;
-            fa.any_coll |= fifo_coll ? 1u : 0u;
+            fa.any_coll |= fifo_coll_real ? 1u : 0u;
+            fa.small_tiles = (fifo_coll && !fifo_coll_real) ? 1u : 0u;
             S.head = (uint32_t)(((uint64_t)S.head + dead) % S.capacity);
             if (!S.fifo_dev) S.ub = n_in + n_spawn - std::min(dead, n_in + n_spawn);  // exact
         }

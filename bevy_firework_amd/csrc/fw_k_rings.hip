@@ -762,6 +762,13 @@ hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifo
             FW_LAUNCH_T((fw_k_update_fifo<false, -1, 0, true, 1>), grid, block, s, e0, e1, g, a, inl);
         return hipGetLastError();
     }
+    if (a.small_tiles) {  // a launch of a few hundred four-round workgroups at most: one round each instead (generic write mask)
+        if (a.any_inst)
+            FW_LAUNCH_T((fw_k_update_fifo<true, -1, 0, false, 1>), grid, block, s, e0, e1, g, a, inl);
+        else
+            FW_LAUNCH_T((fw_k_update_fifo<false, -1, 0, false, 1>), grid, block, s, e0, e1, g, a, inl);
+        return hipGetLastError();
+    }
     if (nt) {  // non-temporal forms (fw_ld4w): the generic write mask only -- beyond the Infinity Cache the compile-time one buys nothing
         if (a.any_inst && nt == 2)
             FW_LAUNCH_T((fw_k_update_fifo<true, -1, 2>), grid, block, s, e0, e1, g, a, inl);

@@ -159,6 +159,8 @@ struct FwFifoArgs {
     float dt;
     uint32_t any_inst;
     uint32_t any_coll;  // some segment's particle type has collision settings: the launch runs the COLL instantiation (fw_k_rings.hip: FwCollArm)
+    uint32_t small_tiles;  // 1: the host laid the launch out on ring tiles of FW_FIFO_COLL_TILE slots (one round per workgroup):
+                           // colliding launches, and launches too small to fill the chip with four-round workgroups
     // which optional planes the particle types of this launch write: bit 0 base colour (gradient not constant), bit 1
     // emissive colour, bit 2 scale (curve not constant) when all its segments agree -- the kernel is then compiled for
     // exactly that set of stores; -1: they differ, read the flags from each type

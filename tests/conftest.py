@@ -50,6 +50,12 @@ def fw_path(request, monkeypatch):
         monkeypatch.setenv("FW_FIFO", "1")
         monkeypatch.setenv("FW_FIFO_MIN", "0")
         monkeypatch.setenv("FW_RANGE", "0")
+        # (FIFO launches of fewer than FW_FIFO_SMALL four-round tiles use one-round tiles: nearly every test of the suite would.
+        # The suite keeps the four-round tiles -- what large rings run -- except in tests/test_gpu_fifo.py, which runs both, the
+        # collision tests -- colliding launches always use one-round tiles -- the fuzz's default environments and the product-default
+        # tests of tests/test_gpu_configs.py)
+        if request.module.__name__.split(".")[-1] != "test_gpu_fuzz":
+            monkeypatch.setenv("FW_FIFO_SMALL", "0")
     elif mode == "range":
         monkeypatch.setenv("FW_FIFO", "0")
         monkeypatch.setenv("FW_RANGE", "1")

@@ -14,8 +14,21 @@ DT = np.float32(1.0 / 60.0)
 SEED = workloads.SEED
 
 
+# every test of the file with four-round ring tiles at any size (FW_FIFO_SMALL=0) and with one-round tiles for small launches
+# (the product's default: below 384 four-round tiles in all) -- fw_k_update_fifo<.., TR = 4 / 1>
+@pytest.fixture(params=["four-round tiles", "one-round tiles when small"])
+def tile_rounds(request, monkeypatch, fw_path):
+    if request.param == "four-round tiles":
+        monkeypatch.setenv("FW_FIFO_SMALL", "0")
+    else:
+        if fw_path != "fifo":
+            pytest.skip("no FIFO rings on this path")
+        monkeypatch.delenv("FW_FIFO_SMALL", raising=False)
+    return request.param
+
+
 @pytest.fixture()
-def system(fw_path):
+def system(fw_path, tile_rounds):
     from bevy_firework_amd.system import ParticleSystem
 
     with ParticleSystem(device=0, seed=SEED) as ps:
