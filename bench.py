@@ -57,7 +57,7 @@ def path_bytes(ps):
     return mode, algo, moved
 
 
-def cpu_baseline(args, dt, world=1, check=False):
+def cpu_baseline(args, dt, world=1, check=False, workload="auto"):
     """Reference CPU path restated in C (oracle/), timed on this box: bounded samples of the same workloads.
     world == 1: configs[1] on one thread (the headline) + configs[2]'s emitters on all cores under `many_emitters`.
     world > 1: the workload of that line -- configs[4]'s emitters (8192 live each), one spawner per thread on all host cores,
@@ -96,7 +96,7 @@ def cpu_baseline(args, dt, world=1, check=False):
                       f"{os.cpu_count()} cores",
         }
 
-    if world > 1:
+    if world > 1 or workload == "configs4":
         if check:
             return many(8, 300, 5, 2, "launch check (not a measurement)")
         # (76 frames to the steady state of lifetimes up to 1.2 s; 8192-particle emitters are ~1 ms of one core per frame)
@@ -226,7 +226,7 @@ def assemble_line(args, world, workload, rows, roof, extras, cpu, hist, rccl_ran
                      "range: in-place range rings (fw_k_update_range), with the compacting kernels on the same workload "
                      "under `compacting_path`" if fifo and world == 1 else
                      "one GPU's share of configs[4] (lifetime ranges: in-place range rings), 100 B algorithmic per particle; the "
-                     "share's ~420 MB exceed the 256 MiB Infinity Cache" if world > 1 else
+                     "share's ~420 MB exceed the 256 MiB Infinity Cache" if (world > 1 or workload == "configs4") else
                      "at 1M particles the 200 MB ping-pong working set sits in the 256 MiB Infinity Cache; "
                      "`hbm_resident` is the same kernel on a 16.8M-particle working set"),
             "timing": "hipEvent start/stop attached to each update dispatch on the context's stream "
@@ -301,7 +301,7 @@ def launch_check(args, world, rank):
     roof = roofline_dict(workload, (50.0 + rank) * 1e-6, 100.0 * (rank + 1), 3, "range", 100, 104)
     rows = gather_ranks(dist, world, "cpu", 1.0 + 0.1 * rank, 1000 * (rank + 1), 100 * (rank + 1), roof)
     if rank == 0:
-        cpu = None if args.no_cpu else cpu_baseline(args, 1.0 / 60.0, world, check=True)
+        cpu = None if args.no_cpu else cpu_baseline(args, 1.0 / 60.0, world, check=True, workload=workload)
         out = assemble_line(args, world, workload, rows, roof, {}, cpu, [], dist.get_world_size(), 0.0, args.reduce_every)
         out.update({"launch_check": True, "rccl_ranks": dist.get_world_size(), "ranks_seen": int(t.item()),
                     "self_launched": os.environ.get("FW_BENCH_SELF_LAUNCHED") == "1"})
@@ -547,7 +547,7 @@ def main():
     # the CPU baseline: rank 0, outside the timed region, the other ranks at the barrier below
     cpu = None
     if rank == 0 and not args.no_cpu:
-        cpu = cpu_baseline(args, dt, world)
+        cpu = cpu_baseline(args, dt, world, workload=workload)
     if rank == 0:
         out = assemble_line(args, world, workload, rows, roof, extras, cpu, hist, rccl_ranks, measured_copy,
                             args.reduce_every if dist is not None else None)
