@@ -421,6 +421,11 @@ struct fw_ctx {
     uint32_t range_min = 12288;  // smallest capacity that makes one (FW_RANGE_MIN; the tests use 0): a range ring costs a
                                  // small segment three workgroups where the compacting path needs one
     uint32_t n_range = 0;
+    // A range launch whose rings hold fewer than range_small_tiles four-round tiles in all (FW_RANGE_SMALL; not with a ring whose
+    // count only the device knows), or with a colliding ring, runs on OLD / YOUNG tiles of ONE round (fw_k_update_range: TR): a
+    // quarter of hysteresis, a change re-sends the table.
+    uint32_t range_small_tiles = 384;
+    bool range_small = false;
     std::vector<FwOp> range_ops;  // this frame's Global ops that feed range rings
     // age, BEFORE the current frame's update, of a particle born in frame f -- the same for every segment of the context:
     // born with age 0, then one fp32 addition per frame (core.rs:594), exactly the device's additions
@@ -693,7 +698,8 @@ fw_status ensure_range_arrays(fw_ctx *ctx) {
     size_t tiles = 0;
     for (auto &s : ctx->segs)
         if (s.in_use && s.range)  // OLD tiles of FW_TILE, YOUNG tiles of the build's size, NEW workgroups of FW_BLOCK
-            tiles += (size_t)s.capacity / FW_TILE + 4 + (size_t)s.capacity / fw_range_young_tile() + 4 + (size_t)s.capacity / FW_BLOCK + 2;
+            // (... or, a launch on one-round tiles -- fw_ctx::range_small -- OLD and YOUNG tiles of FW_BLOCK)
+            tiles += 2 * ((size_t)s.capacity / FW_BLOCK + 4) + (size_t)s.capacity / FW_BLOCK + 2;
     if (tiles > ctx->rdesc_cap) {
         fw_status st = sync(ctx);
         if (st) return st;
@@ -1773,6 +1779,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_FIFO_STREAM")) ctx->use_fifo_stream = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE")) ctx->use_range = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_MIN")) ctx->range_min = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_RANGE_SMALL")) ctx->range_small_tiles = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_NOSPIN")) ctx->use_nospin = atoi(m) != 0;
     if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_NT_WO_MB")) ctx->nt_wo_bytes = ctx->nt_wo_bytes_range = (uint64_t)atoll(m) << 20;
@@ -2848,6 +2855,16 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             return i < ctx->birth_age.size() ? ctx->birth_age[i].age : 0.0f;  // this frame's own cohort: born with age 0
         };
         bool dirty = ctx->r_force, all_nospin = true, range_inst = false, range_coll = false;
+        {  // the tile size of this launch (fw_ctx::range_small)
+            uint64_t parts = 0;
+            bool any_dev = false, any_coll_r = false;
+            for (const SegHost &S : ctx->segs)
+                if (S.in_use && S.range) parts += S.ub, any_dev |= S.range_dev, any_coll_r |= S.collides;
+            const uint64_t lim = (uint64_t)ctx->range_small_tiles * FW_TILE;
+            const bool small = any_coll_r || (!any_dev && parts < (ctx->range_small ? lim + lim / 4 : lim));
+            if (small != ctx->range_small) ctx->range_small = small, dirty = true;
+        }
+        const uint32_t OT = ctx->range_small ? (uint32_t)FW_BLOCK : (uint32_t)FW_TILE;  // slots an OLD workgroup covers
         uint64_t r_bytes = 0;  // what the launch streams, roughly (the non-temporal form of the kernel: fw_ctx::nt_bytes)
         size_t oi = 0;
         for (uint32_t si = 0; si < n_seg; si++) {
@@ -2906,18 +2923,18 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             while (oi < ops.size() && ops[oi].seg == si) oi++, Rc.op_n++;
             S.young_n = S.range_dev ? 0u : y_exist + S.frame_spawn;
             // workgroups of each role (bands: the table is re-sent only when a need leaves its band)
-            const uint32_t YT = fw_range_young_tile();
+            const uint32_t YT = ctx->range_small ? (uint32_t)FW_BLOCK : fw_range_young_tile();
             uint32_t need_old, need_new, need_young;
             if (S.range_dev) {
                 // the old part: at most the cohorts that have joined it and may still hold survivors (all sizes known); the young
                 // part: somewhere behind b -- the grid covers the ring, a tile without young particles leaves at once
-                need_old = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((S.gcoh_sum + FW_TILE - 1) / FW_TILE, S.capacity / FW_TILE + 1));
+                need_old = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((S.gcoh_sum + OT - 1) / OT, S.capacity / OT + 1));
                 need_new = 0u;
                 need_young = S.capacity / YT;
             } else {
                 const uint32_t live_before_ub = std::min(S.ub - std::min(S.ub, S.frame_spawn), S.capacity);
                 const uint32_t old_ub = live_before_ub - std::min(live_before_ub, y_exist);
-                need_old = std::max(1u, (old_ub + FW_TILE - 1) / FW_TILE);
+                need_old = std::max(1u, (old_ub + OT - 1) / OT);
                 need_new = mat_frame ? 0u : (S.frame_spawn + FW_BLOCK - 1) / FW_BLOCK;
                 need_young = std::min(S.capacity / YT, (S.young_lo % YT + y_exist + (mat_frame ? S.frame_spawn : 0u) + YT - 1) / YT);
             }
@@ -3051,6 +3068,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             ra.dt = dt;
             ra.any_inst = range_inst ? 1u : 0u;
             ra.any_coll = range_coll ? 1u : 0u;
+            ra.small_tiles = ctx->range_small ? 1u : 0u;
             ra.done_tag = a.done_tag, ra.done_value = a.done_value;
             ra.host_counts = a.host_counts, ra.live_out = a.live_out, ra.live_next = a.live_next;
             ra.ts = ctx->d_rts;

@@ -347,13 +347,18 @@ uint32_t fw_range_young_tile(void) { return FW_RANGE_YR * FW_BLOCK; }
 // new distance from the young part)  -- both known to a tile without waiting for anybody: the records of the frame are
 // d_out[first, first + count) with first = the particles this update destroyed (n_old_in - n_old_out = ndestroyed), in list
 // order.  (An index counted from 0 would need the old part's survivor total, which only its last tile knows.)
-template <bool ALLNOSPIN, bool INST, int NT, bool COLL = false>
+// TR: rounds per workgroup of the OLD and YOUNG roles (their tile = TR * 256 slots).  Four for launches that stream; ONE for
+// launches too small to fill the chip with four-round workgroups and for colliding launches (FwRangeArgs::small_tiles; as for
+// FIFO rings: a single range ring of 156k particles is ~190 four-round workgroups, its old part a chain of 31 tiles of 1024
+// particles each of which waits for the counts of the ones before -- 17 us per frame where the FIFO ring of the same size
+// takes 8).
+template <bool ALLNOSPIN, bool INST, int NT, bool COLL = false, int TR = FW_ROUNDS>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
-    constexpr int R = FW_TILE / BLK;
+    constexpr int R = TR;
     constexpr int LBW = 4;
-    constexpr uint32_t TILE = FW_TILE;
+    constexpr uint32_t TILE = (uint32_t)(BLK * TR);
     __shared__ __attribute__((aligned(16))) float s_keys[FW_KEYS_MAX];
     __shared__ __attribute__((aligned(16))) float4 s_inst[INST ? NW * 256 : 1];  // per wave: 64 records of 4 float4
     __shared__ uint32_t s_cnt[R][NW];
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
 
     if (role == FW_RANGE_YOUNG) {
         // ---- in place: a lane owns its slot from load to store
-        constexpr int YR = FW_RANGE_YR;
+        constexpr int YR = TR == FW_ROUNDS ? FW_RANGE_YR : TR;
         constexpr uint32_t YT = YR * BLK;  // (capacities are multiples of it: the host rounds them, fw_range_young_tile)
         const uint32_t ring_tiles = C / YT;
         const uint32_t need = min(ring_tiles, (b % YT + y_exist + YT - 1u) / YT);
@@ -805,14 +810,27 @@ static void fw_launch_update_range_t(hipStream_t s, const FwGlobals &g, const Fw
                                      hipEvent_t e1) {
     const dim3 grid(a.total_tiles), block(FW_BLOCK);
     if constexpr (NT != 1) {
-        if (a.any_coll) {  // some range ring of the launch collides (FwCollArm)
+        if (a.any_coll) {  // some range ring of the launch collides (FwCollArm): one-round tiles, the host laid the launch out on them
             if (a.any_inst) {
-                if (all_nospin) FW_LAUNCH_T((fw_k_update_range<true, true, NT, true>), grid, block, s, e0, e1, g, a);
-                else FW_LAUNCH_T((fw_k_update_range<false, true, NT, true>), grid, block, s, e0, e1, g, a);
+                if (all_nospin) FW_LAUNCH_T((fw_k_update_range<true, true, NT, true, 1>), grid, block, s, e0, e1, g, a);
+                else FW_LAUNCH_T((fw_k_update_range<false, true, NT, true, 1>), grid, block, s, e0, e1, g, a);
             } else if (all_nospin) {
-                FW_LAUNCH_T((fw_k_update_range<true, false, NT, true>), grid, block, s, e0, e1, g, a);
+                FW_LAUNCH_T((fw_k_update_range<true, false, NT, true, 1>), grid, block, s, e0, e1, g, a);
             } else {
-                FW_LAUNCH_T((fw_k_update_range<false, false, NT, true>), grid, block, s, e0, e1, g, a);
+                FW_LAUNCH_T((fw_k_update_range<false, false, NT, true, 1>), grid, block, s, e0, e1, g, a);
+            }
+            return;
+        }
+    }
+    if constexpr (NT == 0) {
+        if (a.small_tiles) {  // a small launch: one round per workgroup
+            if (a.any_inst) {
+                if (all_nospin) FW_LAUNCH_T((fw_k_update_range<true, true, 0, false, 1>), grid, block, s, e0, e1, g, a);
+                else FW_LAUNCH_T((fw_k_update_range<false, true, 0, false, 1>), grid, block, s, e0, e1, g, a);
+            } else if (all_nospin) {
+                FW_LAUNCH_T((fw_k_update_range<true, false, 0, false, 1>), grid, block, s, e0, e1, g, a);
+            } else {
+                FW_LAUNCH_T((fw_k_update_range<false, false, 0, false, 1>), grid, block, s, e0, e1, g, a);
             }
             return;
         }
@@ -833,6 +851,7 @@ hipError_t fw_launch_update_range(hipStream_t s, const FwGlobals &g, const FwRan
                                   hipEvent_t e0, hipEvent_t e1) {
     if (!a.total_tiles) return hipErrorInvalidValue;
     if (a.any_coll && nt == 1) nt = 0;  // (the collision instantiations exist plain and fully non-temporal)
+    if (a.small_tiles && !a.any_coll) nt = 0;  // (a small launch fits the cache many times over)
     if (nt == 2) fw_launch_update_range_t<2>(s, g, a, all_nospin, e0, e1);
     else if (nt == 1) fw_launch_update_range_t<1>(s, g, a, all_nospin, e0, e1);
     else fw_launch_update_range_t<0>(s, g, a, all_nospin, e0, e1);

@@ -228,6 +228,8 @@ struct FwRangeArgs {
     float dt;
     uint32_t any_inst;              // some segment has a windowed instance buffer attached: the kernels that also write records
     uint32_t any_coll;              // some segment's particle type has collision settings: the COLL instantiation (FwCollArm)
+    uint32_t small_tiles;           // 1: OLD and YOUNG workgroups cover ONE round (256 slots) each: the host laid the launch out so
+                                    // (colliding launches, and launches too small to fill the chip with four-round workgroups)
     unsigned long long *done_tag;   // as in FwUpdateArgs
     unsigned long long done_value;
     unsigned long long *host_counts;

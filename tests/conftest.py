@@ -60,6 +60,10 @@ def fw_path(request, monkeypatch):
         monkeypatch.setenv("FW_FIFO", "0")
         monkeypatch.setenv("FW_RANGE", "1")
         monkeypatch.setenv("FW_RANGE_MIN", "0")
+        # (as for FIFO rings: small range launches use one-round tiles; the suite keeps the four-round tiles except in
+        # tests/test_gpu_range.py, which runs both, the fuzz's default environments and the product-default tests)
+        if request.module.__name__.split(".")[-1] != "test_gpu_fuzz":
+            monkeypatch.setenv("FW_RANGE_SMALL", "0")
     elif mode == "general":
         monkeypatch.setenv("FW_FIFO", "0")
         monkeypatch.setenv("FW_RANGE", "0")

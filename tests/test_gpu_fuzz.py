@@ -308,11 +308,11 @@ def test_every_shortcut_gives_the_state_of_the_plain_path(case, monkeypatch):
                       ("shortcuts, nt", {"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_NOSPIN": "1", "FW_RANGE": "1", "FW_RANGE_MIN": "0", "FW_NT_MB": "0"}),
                       ("rings, nt", {"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_NOSPIN": "0", "FW_RANGE": "1", "FW_RANGE_MIN": "0", "FW_NT_WO_MB": "0"}),
                       ("rings only", {"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_NOSPIN": "0", "FW_RANGE": "0", "FW_FIFO_SMALL": "0"}),
-                      ("range rings only", {"FW_FIFO": "0", "FW_NOSPIN": "0", "FW_RANGE": "1", "FW_RANGE_MIN": "0"}),
+                      ("range rings only", {"FW_FIFO": "0", "FW_NOSPIN": "0", "FW_RANGE": "1", "FW_RANGE_MIN": "0", "FW_RANGE_SMALL": "0"}),
                       ("range rings, no planes", {"FW_FIFO": "0", "FW_NOSPIN": "1", "FW_RANGE": "1", "FW_RANGE_MIN": "0"}),
                       ("no planes only", {"FW_FIFO": "0", "FW_NOSPIN": "1", "FW_RANGE": "0"}),
                       ("plain", {"FW_FIFO": "0", "FW_NOSPIN": "0", "FW_FIFO_STREAM": "0", "FW_RANGE": "0"})):
-        for k in ("FW_FIFO", "FW_FIFO_MIN", "FW_NOSPIN", "FW_FIFO_STREAM", "FW_RANGE", "FW_RANGE_MIN", "FW_NT_MB", "FW_NT_WO_MB", "FW_FIFO_SMALL"):
+        for k in ("FW_FIFO", "FW_FIFO_MIN", "FW_NOSPIN", "FW_FIFO_STREAM", "FW_RANGE", "FW_RANGE_MIN", "FW_NT_MB", "FW_NT_WO_MB", "FW_FIFO_SMALL", "FW_RANGE_SMALL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -16,13 +16,19 @@ DT = np.float32(1.0 / 60.0)
 SEED = workloads.SEED
 
 
-@pytest.fixture()
-def system(monkeypatch):
+# every test of the file with four-round OLD / YOUNG tiles at any size (FW_RANGE_SMALL=0) and with one-round tiles for small
+# launches (the product's default: below 384 four-round tiles in all) -- fw_k_update_range<.., TR = 4 / 1>
+@pytest.fixture(params=["four-round tiles", "one-round tiles when small"])
+def system(monkeypatch, request):
     from bevy_firework_amd.system import ParticleSystem
 
     monkeypatch.setenv("FW_FIFO", "0")
     monkeypatch.setenv("FW_RANGE", "1")
     monkeypatch.setenv("FW_RANGE_MIN", "0")
+    if request.param == "four-round tiles":
+        monkeypatch.setenv("FW_RANGE_SMALL", "0")
+    else:
+        monkeypatch.delenv("FW_RANGE_SMALL", raising=False)
     with ParticleSystem(device=0, seed=SEED) as ps:
         yield ps
 
@@ -344,7 +350,7 @@ def test_an_internal_error_is_sticky_for_its_spawner_until_it_is_rebuilt():
                     failed = e
                     break
             assert failed is not None and "FW_EHIP" in str(failed), failed
-            assert frames > 20                          # the first frames have no third OLD tile: nothing to wait for
+            assert frames > 12                          # the first frames have no third OLD tile: nothing to wait for
             for call in (lambda: ps.step(DT), lambda: victim.counts(), lambda: victim.particles(0), lambda: victim.aabb()):
                 try:
                     call(); raise SystemExit("a call on the invalid spawner went through")

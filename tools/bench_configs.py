@@ -87,3 +87,9 @@ if "cc" in which:  # examples/stress_test_collision.rs: bouncing particles (at t
     run("stress_test_collision rate 80000 (~157k live)", [(sp, tf)], 130, 600, colliders=world)
     sp, tf, world = workloads.stress_test_collision(640000.0)
     run("stress_test_collision rate 640000 (~1.26M live)", [(sp, tf)], 130, 300, colliders=world)
+if "r1" in which:  # the reference's stress_test with a lifetime RANGE (0.8-1.2 s): one mid-size range ring
+    from bevy_firework_amd import settings as _S
+    for rate in (160000.0, 500000.0):
+        sp, tf = workloads.stress_test(rate)
+        sp.particle_settings[0].lifetime = _S.RandF32(0.8, 1.2)
+        run("stress_test with lifetimes 0.8-1.2 s, rate %d" % rate, [(sp, tf)], 90, 600)
