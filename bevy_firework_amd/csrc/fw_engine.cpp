@@ -2157,6 +2157,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // (the same pass notes what the rest of the frame asks of every segment: which Nested-fed ones must grow, whether a
     // particle type collides, whether a compacting segment has an instance buffer attached)
     bool any_coll = false, any_inst_general = false;
+    struct {
+        uint64_t fifo_parts = 0, range_parts = 0;
+        bool fifo_dev = false, fifo_coll = false, range_dev = false, range_coll = false;
+    } ring_stats;
     ctx->grow_scratch.clear();
     for (size_t si = 0, ns = ctx->segs.size(); si < ns; si++) {
         SegHost &S = ctx->segs[si];
@@ -2168,6 +2172,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         if (!S.in_use) continue;
         S.dead_at_end = false;  // (set again below for the segments this frame updates as range rings)
         any_coll |= S.collides && !S.ring();  // (a colliding type in a ring is updated by its ring kernel)
+        // (what decides the tile size of the ring launches -- fifo_small / range_small below -- gathered while the record is hot)
+        if (S.fifo) ring_stats.fifo_parts += S.ub, ring_stats.fifo_dev |= S.fifo_dev, ring_stats.fifo_coll |= S.collides;
+        if (S.range) ring_stats.range_parts += S.ub, ring_stats.range_dev |= S.range_dev, ring_stats.range_coll |= S.collides;
         any_inst_general |= !S.ring() && S.inst != nullptr;
         if (S.nested_fed && nested_fed_wants_growth(S)) ctx->grow_scratch.push_back((uint32_t)si);
         if (!S.win_ok) continue;
@@ -2724,14 +2731,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         // (the reference's own stress_test: 157k particles = 154 of them on 256 CUs, each lane working through four particles one
         // after the other): below FW_FIFO_SMALL four-round tiles in all, one round per workgroup.  Not with a ring whose count
         // only the device knows (its grid covers its capacity: four times the idle workgroups).
-        uint64_t fifo_particles = 0;
-        bool fifo_any_dev = false;
-        for (const SegHost &S : ctx->segs)
-            if (S.in_use && S.fifo) fifo_coll |= S.collides, fifo_any_dev |= S.fifo_dev, fifo_particles += S.ub;
-        const bool fifo_small = !fifo_any_dev && fifo_particles < (uint64_t)ctx->fifo_small_tiles * FW_TILE;
-        fifo_coll |= fifo_small;  // (the same tile grid; which instantiation runs: FwFifoArgs::any_coll / small_tiles)
-        bool fifo_coll_real = false;
-        for (const SegHost &S : ctx->segs) fifo_coll_real |= S.in_use && S.fifo && S.collides;
+        // (counted in the first pass over the segments of this frame; a ring that changed its kind since then: next frame)
+        const bool fifo_small = !ring_stats.fifo_dev && ring_stats.fifo_parts < (uint64_t)ctx->fifo_small_tiles * FW_TILE;
+        const bool fifo_coll_real = ring_stats.fifo_coll;
+        fifo_coll = fifo_coll_real || fifo_small;  // (the same tile grid; which instantiation runs: FwFifoArgs::any_coll / small_tiles)
         uint32_t f_ops = 0, f_tiles = 0;
         uint64_t f_bytes = 0;  // what the launch streams, roughly: its tiles x the bytes a particle of the type moves
         auto flush = [&]() -> hipError_t {
@@ -2856,10 +2859,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         };
         bool dirty = ctx->r_force, all_nospin = true, range_inst = false, range_coll = false;
         {  // the tile size of this launch (fw_ctx::range_small)
-            uint64_t parts = 0;
-            bool any_dev = false, any_coll_r = false;
-            for (const SegHost &S : ctx->segs)
-                if (S.in_use && S.range) parts += S.ub, any_dev |= S.range_dev, any_coll_r |= S.collides;
+            const uint64_t parts = ring_stats.range_parts;
+            const bool any_dev = ring_stats.range_dev, any_coll_r = ring_stats.range_coll;
             const uint64_t lim = (uint64_t)ctx->range_small_tiles * FW_TILE;
             const bool small = any_coll_r || (!any_dev && parts < (ctx->range_small ? lim + lim / 4 : lim));
             if (small != ctx->range_small) ctx->range_small = small, dirty = true;

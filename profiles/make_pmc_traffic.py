@@ -13,7 +13,7 @@ txt = open(src).read()
 # the steady-state kernel of the bench: the in-place FIFO ring update (configs[1]'s particle type has one lifetime value; no
 # attached instance buffers, base / emissive / scale planes all written: write mask 7); with FW_FIFO=0 the streaming
 # kernel of the general path (forecast frames, inline spawn ops, per-tile forecast entries, lone segment)
-for kern in ("fw_k_update_fifo<false, 7, 0, false>", "fw_k_update_fifo<false, 7, 0>", "fw_k_update_fifo<false, 7>", "fw_k_update_stream<1, false, false, true>"):
+for kern in ("fw_k_update_fifo<false, 7, 0, false, 4>", "fw_k_update_fifo<false, 7, 0, false>", "fw_k_update_fifo<false, 7, 0>", "fw_k_update_fifo<false, 7>", "fw_k_update_stream<1, false, false, true>"):
     m = re.search(re.escape(kern) + r"\s+FETCH_SIZE=([0-9.e+]+)", txt)
     if m:
         break
