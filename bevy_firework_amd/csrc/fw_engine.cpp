@@ -2011,6 +2011,8 @@ fw_status fw_spawner_update_settings(fw_ctx *ctx, fw_spawner h, const fw_spawner
         return st;
     }
     ctx->spawners[h].finished_notified = finished_notified;
+    ctx->n_poisoned = 0;  // (fw_step looks for invalid spawners only while some exist)
+    for (const SpawnerHost &x : ctx->spawners) ctx->n_poisoned += (x.alive && x.poisoned) ? 1u : 0u;
     return st;
 }
 
@@ -2027,6 +2029,8 @@ fw_status fw_spawner_destroy(fw_ctx *ctx, fw_spawner h) {
     }
     if ((st = release_spawner_segments(ctx, *sp))) return st;
     *sp = SpawnerHost{};
+    ctx->n_poisoned = 0;
+    for (const SpawnerHost &x : ctx->spawners) ctx->n_poisoned += (x.alive && x.poisoned) ? 1u : 0u;
     return FW_OK;
 }
 
