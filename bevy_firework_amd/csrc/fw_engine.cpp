@@ -418,8 +418,9 @@ struct fw_ctx {
     uint64_t tev_frames = 0;   // frames timed so far (a frame may take several update launches)
     // ---- range rings (SegHost::range)
     bool use_range = true;       // FW_RANGE=0: lifetime-range types take the compacting path (A/B, tests)
-    uint32_t range_min = 12288;  // smallest capacity that makes one (FW_RANGE_MIN; the tests use 0): a range ring costs a
-                                 // small segment three workgroups where the compacting path needs one
+    uint32_t range_min = 8192;   // smallest capacity that makes one (FW_RANGE_MIN; the tests use 0): a range ring costs a
+                                 // small segment three workgroups where the compacting path needs one.  Swept on many equal
+                                 // emitters (profiles/r04/range_min_sweep.txt): 8192 is where the one-round tiles start to win
     uint32_t n_range = 0;
     // A range launch whose rings hold fewer than range_small_tiles four-round tiles in all (FW_RANGE_SMALL; not with a ring whose
     // count only the device knows), or with a colliding ring, runs on OLD / YOUNG tiles of ONE round (fw_k_update_range: TR): a
