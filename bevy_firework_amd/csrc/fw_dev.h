@@ -22,8 +22,15 @@
 
 // an internal error (a check of the host's bookkeeping against the particles failed, a look-back wait ran out): the device
 // flags for whoever synchronises next, and the pinned word the next fw_step looks at (FwGlobals::err_host)
+// sets bits of the device's error flags (FwGlobals::err) and notes in pinned memory that there is something to read there:
+// the host half fetches the flags only then (a blocking 32-byte copy is ~20 us of every synchronising call otherwise)
+__device__ __forceinline__ void fw_flag(const FwGlobals &g, uint32_t bits) {
+    atomicOr(g.err, bits);
+    if (g.err_host) g.err_host[1] = 1ull;
+}
+
 __device__ __forceinline__ void fw_raise(const FwGlobals &g, uint32_t check, uint32_t seg, uint32_t x) {
-    atomicOr(g.err, FW_ERR_FORECAST);
+    fw_flag(g, FW_ERR_FORECAST);
     g.err[5] = check, g.err[6] = seg, g.err[7] = x;
     if (g.err_host) *g.err_host = (1ull << 63) | ((unsigned long long)check << 32) | seg;
 }

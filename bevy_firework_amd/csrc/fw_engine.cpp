@@ -349,7 +349,8 @@ struct fw_ctx {
     // that launch reports through a pinned word (FwUpdateArgs::done_tag).  FW_OPS_ZEROCOPY=0: staged copy + events.
     bool ops_zerocopy = true;
     unsigned long long *h_done = nullptr;      // pinned; written by workgroup 0 of every update launch
-    unsigned long long *h_err = nullptr;       // pinned; FwGlobals::err_host (h_done + 4: the same allocation)
+    unsigned long long *h_err = nullptr;       // pinned; FwGlobals::err_host (h_done + 4: the same allocation); [1]: the device's
+                                               // error flags are set (fw_flag)
     std::string poison_msg;                    // what poll_device_error saw
     uint32_t n_poisoned = 0;                   // spawners ever marked (fw_step scans for live ones only while non-zero)
     uint64_t slot_frame[kParamRing] = {};      // frame that last used the slot through the zero-copy path (+1; 0 = free)
@@ -838,6 +839,9 @@ fw_status poisoned_status(fw_ctx *ctx);
 fw_status check_device_errors(fw_ctx *ctx) {
     // (the stream has been waited for: whatever a kernel reported is in the pinned word by now)
     const bool fresh = poll_device_error(ctx);
+    // (every kernel that sets a flag says so in the pinned word next to err_host -- fw_flag: nothing there, nothing to fetch)
+    if (!*(const volatile unsigned long long *)(ctx->h_err + 1) && !ctx->trace) return FW_OK;
+    ctx->h_err[1] = 0ull;
     uint32_t ev[8] = {};
     FW_HIP(ctx, hipMemcpy(ev, ctx->g.err, sizeof ev, hipMemcpyDeviceToHost));
     const uint32_t e = ev[0];
@@ -1756,7 +1760,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
             return bail("hipEventCreate", e);
     if ((e = hipHostMalloc((void **)&ctx->h_done, 64, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
     *ctx->h_done = 0ull;
-    ctx->h_err = ctx->h_done + 4, *ctx->h_err = 0ull, ctx->g.err_host = ctx->h_err;
+    ctx->h_err = ctx->h_done + 4, ctx->h_err[0] = ctx->h_err[1] = 0ull, ctx->g.err_host = ctx->h_err;
     if ((e = hipMalloc((void **)&ctx->g.err, 64)) != hipSuccess) return bail("hipMalloc", e);
     fw_memset_done(ctx->g.err, 0, 64);
     if ((e = hipMalloc((void **)&ctx->g.stats, 64)) != hipSuccess) return bail("hipMalloc", e);
@@ -1978,7 +1982,7 @@ fw_status fw_spawner_update_settings(fw_ctx *ctx, fw_spawner h, const fw_spawner
     if (sp->poisoned) {
         // everything enqueued on top of the invalid state has finished: what those frames reported again is not news, and the
         // segment slots the report names are about to be reused by the rebuilt spawner
-        *ctx->h_err = 0ull;
+        ctx->h_err[0] = ctx->h_err[1] = 0ull;
         const uint32_t zero = 0;
         FW_HIP(ctx, hipMemcpy(ctx->g.err, &zero, sizeof zero, hipMemcpyHostToDevice));
     }
@@ -2024,7 +2028,7 @@ fw_status fw_spawner_destroy(fw_ctx *ctx, fw_spawner h) {
     fw_status st = sync(ctx);
     if (st) return st;
     if (sp->poisoned) {  // (as in fw_spawner_update_settings)
-        *ctx->h_err = 0ull;
+        ctx->h_err[0] = ctx->h_err[1] = 0ull;
         const uint32_t zero = 0;
         FW_HIP(ctx, hipMemcpy(ctx->g.err, &zero, sizeof zero, hipMemcpyHostToDevice));
     }

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         const uint32_t spawn_room = seg_cap - min(n_in, seg_cap);
         if (n_spawn > spawn_room) {  // (reported here: nothing about it has to stay live through the kernel)
             n_spawn = spawn_room;
-            if (blockIdx.x == first && threadIdx.x == 0) atomicOr(g.err, FW_ERR_CAPACITY);
+            if (blockIdx.x == first && threadIdx.x == 0) fw_flag(g, FW_ERR_CAPACITY);
         }
     }
     const uint32_t n_tot = n_in + n_spawn;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     }
     const bool is_last = tis + 1u == n_act;
     if (tis == 0 && tid == 0 && n_act > seg_tiles) {
-        atomicOr(g.err, FW_ERR_CAPACITY);
+        fw_flag(g, FW_ERR_CAPACITY);
         g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;  // diagnostics
     }
     if (blockIdx.x == 0 && tid == 0 && a.live_next) *a.live_next = 0ull;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             if (timed_out) {
                 // Fallback (never taken when workgroups are dispatched in order): recount the survivors of
                 // the earlier particles of this segment (forecast mode: of the earlier NEW particles only).
-                if (tid == 0) atomicOr(g.err, FW_ERR_LOOKBACK_TIMEOUT);
+                if (tid == 0) fw_flag(g, FW_ERR_LOOKBACK_TIMEOUT);
                 uint32_t c = 0;
                 for (uint32_t i = (use_fc ? n_in : 0u) + tid; i < base; i += BLK) {  // base is a particle index
                     float an, ag = 0.0f, lf;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         const uint32_t spawn_room = seg_cap - min(n_in, seg_cap);
         if (n_spawn > spawn_room) {
             n_spawn = spawn_room;
-            if (blockIdx.x == first && threadIdx.x == 0) atomicOr(g.err, FW_ERR_CAPACITY);
+            if (blockIdx.x == first && threadIdx.x == 0) fw_flag(g, FW_ERR_CAPACITY);
         }
     }
     const uint32_t n_tot = n_in + n_spawn;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     }
     const bool is_last = tis + 1u == n_act;
     if (tis == 0 && tid == 0 && n_act > seg_tiles) {
-        atomicOr(g.err, FW_ERR_CAPACITY);
+        fw_flag(g, FW_ERR_CAPACITY);
         g.err[1] = seg, g.err[2] = n_tot, g.err[3] = seg_tiles, g.err[4] = n_in;  // diagnostics
     }
     if (blockIdx.x == 0 && tid == 0 && a.live_next) *a.live_next = 0ull;
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             bool timed_out = false;
             lb_excl = fw_lookback<BLK, NW, LBW>(g.tile_status, first + t_spawn, tile, a.epoch, a.spin_limit, s_lb, &timed_out);
             if (timed_out) {  // recount the survivors of the earlier NEW particles (never taken in practice)
-                if (tid == 0) atomicOr(g.err, FW_ERR_LOOKBACK_TIMEOUT);
+                if (tid == 0) fw_flag(g, FW_ERR_LOOKBACK_TIMEOUT);
                 uint32_t c = 0;
                 for (uint32_t i = n_in + tid; i < base; i += BLK) {
                     const uint32_t k = i - n_in;

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_spawn(FwGlobals g, FwInlineOps 
     const uint32_t room = base < S.capacity ? S.capacity - base : 0u;
     if (k == 0) {
         atomicAdd(&g.spawned[sidx], min(op.n, room));
-        if (op.n > room) atomicOr(g.err, FW_ERR_CAPACITY);
+        if (op.n > room) fw_flag(g, FW_ERR_CAPACITY);
     }
     if (k >= op.n || k >= room) return;
     const uint32_t head = op.range_ring ? fw_range_head(op.head, g.rold[sidx], S.capacity) : op.head;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
         unsigned long long take = total;
         if (take > room) {
             take = room;
-            atomicOr(g.err, FW_ERR_CAPACITY);
+            fw_flag(g, FW_ERR_CAPACITY);
         }
         g.emit_serial[op.emit_slot] = serial0 + total;
         g.appended[cidx] += (uint32_t)take;

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         __syncthreads();
         const uint32_t kk = k * BLK + tid;
         const bool is_new = kk < n_spawn;
-        if (kk < n_spawn_h && kk == n_spawn) atomicOr(g.err, FW_ERR_CAPACITY);
+        if (kk < n_spawn_h && kk == n_spawn) fw_flag(g, FW_ERR_CAPACITY);
         const unsigned long long mi = (INST && inst != nullptr) ? __ballot(is_new) : 0ull;
         float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(mi) * 4u : nullptr;
         if (!INST && !is_new) return;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     // one GPU's share of configs[4] ran 86.4 us against 85.6 with the tiles in parallel: profiles/r04/range_seq_old_ab.txt)
     const uint32_t base = k * TILE;
     if (k == 0u && tid == 0u && n_old_in > D.n_old * TILE) {  // the host's bound of the old part was not one (internal error)
-        atomicOr(g.err, FW_ERR_CAPACITY);
+        fw_flag(g, FW_ERR_CAPACITY);
         g.err[1] = seg, g.err[2] = n_old_in, g.err[3] = D.n_old, g.err[4] = cnt_in;
     }
     // (the host's young count against the device's own record of the old part: what both derive the list's first slot from)
