@@ -22,7 +22,11 @@
 #include <cstring>
 #include <string>
 #include <deque>
+#include <mutex>
+#include <new>
 #include <vector>
+
+#include <sys/mman.h>
 
 #include "../../include/firework_hip.h"
 #include "../../include/firework_hip_debug.h"
@@ -54,7 +58,115 @@ constexpr uint32_t kMaxFifoSegs = FW_FIFO_PER_LAUNCH;  // FIFO segments per cont
 constexpr size_t kMaxCohorts = 16384;    // spawn cohorts a FIFO segment tracks before it gives the mode up (tiny dt)
 constexpr uint32_t kReportRing = 32768;  // pinned per-frame cohort sizes of a ring that receives Nested children (> kMaxCohorts)
 
-std::string g_create_error;
+thread_local std::string g_create_error;  // (fw_last_error(nullptr): per calling thread, like errno)
+
+// Host memory the per-frame loops of fw_step stream through -- the segment and spawner records, every segment's lifetime
+// window.  As ordinary heap blocks they sit on thousands of 4 KB pages (one window ring per emitter alone): past ~3000
+// emitters the loops missed the TLB on most records (2048 emitters: 28 ns each, 4096: 39 ns).  They come from 2 MB-aligned
+// chunks instead, which the kernel is asked to back with huge pages (madvise: a no-op where transparent huge pages are off).
+// One process-wide pool: blocks of 1536 << k bytes (a window ring of 64 << k entries) on free lists, larger requests mapped
+// on their own; chunks are never returned (destroyed contexts leave their blocks on the lists).  Thread-safe: contexts may be
+// driven from different threads.
+class HugePool {
+public:
+    static void *alloc(size_t bytes) {
+        if (bytes > kMaxBlock) return map(bytes);
+        const int c = cls(bytes);
+        std::lock_guard<std::mutex> lk(mu());
+        Node *&head = lists()[c];
+        if (head) {
+            Node *n = head;
+            head = n->next;
+            return n;
+        }
+        const size_t sz = kBase << c;
+        char *&cur = chunk_cur(), *&end = chunk_end();
+        if (cur == nullptr || (size_t)(end - cur) < sz) {
+            // (what is left of the old chunk goes to the lists of the classes it still fits)
+            while (cur && (size_t)(end - cur) >= kBase) {
+                int k = 0;
+                while (k + 1 < kClasses && (kBase << (k + 1)) <= (size_t)(end - cur)) k++;
+                Node *n = reinterpret_cast<Node *>(cur);
+                n->next = lists()[k], lists()[k] = n;
+                cur += kBase << k;
+            }
+            cur = static_cast<char *>(map(kChunk));
+            if (!cur) return nullptr;
+            end = cur + kChunk;
+        }
+        void *p = cur;
+        cur += sz;
+        return p;
+    }
+    static void free(void *p, size_t bytes) {
+        if (!p) return;
+        if (bytes > kMaxBlock) {
+            munmap(p, (bytes + kHuge - 1) / kHuge * kHuge);
+            return;
+        }
+        std::lock_guard<std::mutex> lk(mu());
+        Node *n = static_cast<Node *>(p);
+        n->next = lists()[cls(bytes)], lists()[cls(bytes)] = n;
+    }
+
+private:
+    struct Node {
+        Node *next;
+    };
+    static constexpr size_t kBase = 1536, kHuge = 2u << 20, kChunk = 8u << 20;
+    static constexpr int kClasses = 11;  // 1.5 KB ... 1.5 MB
+    static constexpr size_t kMaxBlock = kBase << (kClasses - 1);
+    static int cls(size_t bytes) {
+        int c = 0;
+        while ((kBase << c) < bytes) c++;
+        return c;
+    }
+    static std::mutex &mu() {
+        static std::mutex m;
+        return m;
+    }
+    static Node **lists() {
+        static Node *l[kClasses] = {};
+        return l;
+    }
+    static char *&chunk_cur() {
+        static char *p = nullptr;
+        return p;
+    }
+    static char *&chunk_end() {
+        static char *p = nullptr;
+        return p;
+    }
+    // `bytes` rounded up to 2 MB, aligned to 2 MB, huge pages requested
+    static void *map(size_t bytes) {
+        const size_t len = (bytes + kHuge - 1) / kHuge * kHuge;
+        char *raw = static_cast<char *>(mmap(nullptr, len + kHuge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+        if (raw == MAP_FAILED) return nullptr;
+        char *al = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(raw) + kHuge - 1) / kHuge * kHuge);
+        if (al > raw) munmap(raw, (size_t)(al - raw));
+        if (al + len < raw + len + kHuge) munmap(al + len, (size_t)(raw + len + kHuge - (al + len)));
+        madvise(al, len, MADV_HUGEPAGE);
+        return al;
+    }
+};
+
+template <typename T>
+struct HugeAlloc {
+    using value_type = T;
+    HugeAlloc() = default;
+    template <typename U>
+    HugeAlloc(const HugeAlloc<U> &) {}
+    T *allocate(size_t n) {
+        void *p = HugePool::alloc(n * sizeof(T));
+        if (!p) throw std::bad_alloc();
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t n) { HugePool::free(p, n * sizeof(T)); }
+    template <typename U>
+    bool operator==(const HugeAlloc<U> &) const { return true; }
+    template <typename U>
+    bool operator!=(const HugeAlloc<U> &) const { return false; }
+};
 
 struct CurveCopy {
     int32_t kind = 0, n = 0;
@@ -70,19 +182,74 @@ struct TypeHost {
 };
 
 struct EmissionHost {
-    fw_emission_settings es{};
+    // ---- what fw_step's spawner loop touches: this state and the head of `es` (pacing, counts, mode: its first 40 bytes),
+    // next to each other (with thousands of emitters the loop is bound by the cache lines it streams, not its arithmetic)
     // EmissionData (reference src/core.rs:261-267)
     float last_emission = 0.f, time_passed_in_cycle = 0.f;
-    bool enabled = false, emits_on_other_particles = false;
     uint64_t serial = 0;      // RNG stream position (Global entries; Nested ones live on the device)
     uint32_t emit_idx = 0;    // -> FwEmit
     uint32_t emit_slot = 0;   // -> device serial counter (Nested)
-    bool assigned = false;    // emit_idx / emit_slot are owned by this entry
     uint32_t dst_seg = 0;     // segment of es.particle_index (cached: the frame loop then touches only this record)
     float life_lo_safe = 0.f; // TypeHost::life_lo_safe of es.particle_index
+    bool enabled = false, emits_on_other_particles = false;
+    bool assigned = false;    // emit_idx / emit_slot are owned by this entry
+    fw_emission_settings es{};
+};
+
+// The emission entries of a spawner.  ONE entry -- by far the most common spawner -- lives inside the spawner's own record
+// (no heap block, no pointer to chase: the spawner array is then all the frame loop streams); more entries live in a vector.
+struct EmVec {
+    uint32_t n_ = 0;
+    EmissionHost one_;
+    std::vector<EmissionHost> more_;
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    EmissionHost *data() { return n_ > 1 ? more_.data() : &one_; }
+    const EmissionHost *data() const { return n_ > 1 ? more_.data() : &one_; }
+    EmissionHost &operator[](size_t i) { return data()[i]; }
+    const EmissionHost &operator[](size_t i) const { return data()[i]; }
+    EmissionHost *begin() { return data(); }
+    EmissionHost *end() { return data() + n_; }
+    const EmissionHost *begin() const { return data(); }
+    const EmissionHost *end() const { return data() + n_; }
+    void assign(size_t n, const EmissionHost &v) {
+        more_.clear();
+        one_ = v;
+        if (n > 1) more_.assign(n, v);
+        n_ = (uint32_t)n;
+    }
+    void clear() { assign(0, EmissionHost{}); }
 };
 
 struct alignas(64) SegHost {
+    // Lifetime window: a particle is destroyed by the update in which age >= lifetime (core.rs:590-592), and
+    // lifetime <= life_bound, so everything alive was spawned less than life_bound of simulated time ago.  The sum of
+    // the Global spawn counts inside that window bounds the live count without any device feedback.
+    struct Spawned {
+        double t;        // simulated time at the spawn
+        uint64_t n;
+        uint64_t frame;  // frame of the spawn (the device's ages are fp32 sums: the error grows with the steps taken)
+    };
+    // (a ring in one allocation: in the steady state every frame pops one entry and pushes one per segment; a
+    // std::deque pays its chunk bookkeeping for each -- 30 us per frame with 2048 emitters)
+    struct Window {
+        std::vector<Spawned, HugeAlloc<Spawned>> v;
+        uint32_t head = 0, n = 0;
+        bool empty() const { return n == 0; }
+        size_t size() const { return n; }
+        Spawned &front() { return v[head]; }
+        Spawned &back() { return v[(head + n - 1) & (uint32_t)(v.size() - 1)]; }
+        void pop_front() { head = (head + 1) & (uint32_t)(v.size() - 1), n--; }
+        void pop_back() { n--; }
+        void push_back(const Spawned &x) {
+            if (n == v.size()) {  // grow to the next power of two, oldest entry first
+                std::vector<Spawned, HugeAlloc<Spawned>> w(v.empty() ? 64 : v.size() * 2);
+                for (uint32_t i = 0; i < n; i++) w[i] = v[(head + i) & (uint32_t)(v.size() - 1)];
+                v.swap(w), head = 0;
+            }
+            v[(head + n) & (uint32_t)(v.size() - 1)] = x, n++;
+        }
+    };
     // ---- what the per-frame loops of fw_step touch, in ONE cache line (with thousands of segments those loops are
     // bound by how many lines they stream, not by their arithmetic)
     bool in_use = false;
@@ -106,8 +273,13 @@ struct alignas(64) SegHost {
     uint64_t snap_cum = 0;      //   cum_spawn of the frame that row describes: Global particles since then are host-known
     uint64_t cum_spawn = 0;     // Global particles ever appended (host-known)
     uint64_t win_sum = 0;
+    // ---- second line: the window itself and the segment's mode (both per-frame loops look at them)
     double life_bound = 0.0;
     char *inst = nullptr;       // caller-owned device buffer of ParticleInstance records (fw_spawner_attach_instances)
+    Window win;
+    bool fifo = false;          // FIFO ring (below)
+    bool range = false;         // range ring (below)
+    bool fifo_mat = false, fifo_dev = false, range_mat = false, range_dev = false, virt_parent = false;  // (below)
     // ---- the rest
     int spawner = -1, type = -1;
     uint32_t type_idx = 0, n_lplanes = 0;
@@ -118,34 +290,6 @@ struct alignas(64) SegHost {
     char *buf[2] = {nullptr, nullptr};
     char *destroyed = nullptr;
     uint32_t inst_cap = 0;
-    // Lifetime window: a particle is destroyed by the update in which age >= lifetime (core.rs:590-592), and
-    // lifetime <= life_bound, so everything alive was spawned less than life_bound of simulated time ago.  The sum of
-    // the Global spawn counts inside that window bounds the live count without any device feedback.
-    struct Spawned {
-        double t;        // simulated time at the spawn
-        uint64_t n;
-        uint64_t frame;  // frame of the spawn (the device's ages are fp32 sums: the error grows with the steps taken)
-    };
-    // (a ring in one allocation: in the steady state every frame pops one entry and pushes one per segment; a
-    // std::deque pays its chunk bookkeeping for each -- 30 us per frame with 2048 emitters)
-    struct Window {
-        std::vector<Spawned> v;
-        uint32_t head = 0, n = 0;
-        bool empty() const { return n == 0; }
-        size_t size() const { return n; }
-        Spawned &front() { return v[head]; }
-        Spawned &back() { return v[(head + n - 1) & (uint32_t)(v.size() - 1)]; }
-        void pop_front() { head = (head + 1) & (uint32_t)(v.size() - 1), n--; }
-        void pop_back() { n--; }
-        void push_back(const Spawned &x) {
-            if (n == v.size()) {  // grow to the next power of two, oldest entry first
-                std::vector<Spawned> w(v.empty() ? 64 : v.size() * 2);
-                for (uint32_t i = 0; i < n; i++) w[i] = v[(head + i) & (uint32_t)(v.size() - 1)];
-                v.swap(w), head = 0;
-            }
-            v[(head + n) & (uint32_t)(v.size() - 1)] = x, n++;
-        }
-    } win;
     // colours of the type at age 0: what both colour planes are filled with when the buffers are allocated, so that a
     // constant gradient's plane never has to be written by the update (FwOutWin::wr5 / wr6)
     float fill_bc[4] = {0, 0, 0, 0}, fill_em[4] = {0, 0, 0, 0};
@@ -154,7 +298,6 @@ struct alignas(64) SegHost {
     // ONE buffer (buf[0] == buf[1]); logical particle i sits in slot (head + i) mod capacity; `ub` is the EXACT live
     // count.  The host replays the fp32 age of every spawn cohort (same additions as the device), which tells it how
     // many particles each update destroys -- always the oldest ones.
-    bool fifo = false;
     uint32_t head = 0;
     float fifo_life = 0.f;  // the lifetime every particle of the type gets (core.rs:455 with min == max)
     int32_t fifo_wm = 0;    // FwFifoArgs::write_mask of the type
@@ -176,14 +319,12 @@ struct alignas(64) SegHost {
     // their first update (FwFifoSeg::mat).  fifo_dev: the type receives Nested children -- its live count is known to the
     // device only, and the size of each frame's cohort reaches the host through a pinned ring (h_report[frame %
     // kReportRing] = {epoch, added}) long before the host needs it: when the cohort's age reaches the lifetime.
-    bool fifo_mat = false, fifo_dev = false;
     unsigned long long *h_report = nullptr;
     // Range ring (fw_kernels.h: FwRangeRec): a type whose lifetime is a RANGE, Global emission only, no collisions, in a
     // spawner without Nested entries.  ONE buffer (buf[0] == buf[1]) used as a ring: [old survivors | young]; the young
     // part -- slot of its first particle, its size, its spawn cohorts -- is host-known exactly (the host made every spawn
     // count and replays the fp32 age of every cohort: fw_ctx::birth_age); the size of the old part is the device's
     // count minus young_n.  `ub` bounds the total as for any segment (lifetime window, snapshots).
-    bool range = false;
     uint32_t young_lo = 0, young_n = 0;
     float range_life_lo = 0.f;  // every particle outlives an update that leaves its age below this (TypeHost::life_lo_safe)
     struct YCohort {
@@ -199,14 +340,12 @@ struct alignas(64) SegHost {
     //              device only (FW_RREC_DEV).  The host still knows where the young part STARTS: cohorts join the old part a
     //              lifetime.min after they were added, and by then the update of their frame has long left their size in the
     //              pinned ring h_report (as for a FIFO ring that receives children).
-    bool range_mat = false, range_dev = false;
     // A ring type other particles' entries emit from whose Global particles need NOT be in memory for the frame's Nested pass:
     // every Nested entry on it is a CountOverDuration with count > 0 and 0 <= offset_start <= offset_end, and the type's
     // lifetimes are positive -- then compute_emission_count(age 0, last f32::MIN, ..) emits nothing for a particle born this
     // frame (core.rs:553-575: since = min(0, end) - start <= 0) and only leaves `next` in its last_emitted_age, which the lane
     // that spawns the particle inside the ring's update kernel computes itself (fw_init_last_emitted).  Such a type is spawned
     // in its update kernel in EVERY frame: a steady Nested frame is fw_k_nest + the update, without fw_k_spawn.
-    bool virt_parent = false;
     struct DCohort {
         uint64_t frame;
         uint32_t n;
@@ -238,17 +377,10 @@ struct alignas(64) SegHost {
     uint32_t life_plane() const { return (nospin && !fifo) ? n_lplanes : 0xFFFFFFFFu; }
 };
 
-struct SpawnerHost {
+struct alignas(64) SpawnerHost {
+    // ---- first line: what every frame reads of a spawner; the entries follow (EmVec: one entry is inline)
     bool alive = false;
-    uint32_t uid = 0;
-    int32_t starts_enabled = 1;
-    std::vector<TypeHost> types;
-    std::vector<EmissionHost> em;
-    std::vector<uint32_t> seg;  // per type
-    uint64_t manual_queued_count = 0;
     bool initialized = false, finished_notified = false;
-    float origin_pos[3] = {0, 0, 0}, origin_rot[4] = {0, 0, 0, 1}, parent_vel[3] = {0, 0, 0};
-    float mod_scale = 1.f, mod_speed = 1.f;
     // An internal error of an update kernel (FwGlobals::err_host) named one of this spawner's particle types: its particle
     // state can no longer be trusted -- an in-place ring update that went wrong has overwritten its own input and cannot be
     // redone.  Sticky: fw_step refuses to run and every call that reads or writes the spawner's particles returns FW_EHIP
@@ -256,6 +388,15 @@ struct SpawnerHost {
     bool poisoned = false;
     // ... and the rebuilt spawner keeps its particle types off the in-place ring paths
     bool no_rings = false;
+    uint64_t manual_queued_count = 0;
+    float origin_pos[3] = {0, 0, 0}, origin_rot[4] = {0, 0, 0, 1}, parent_vel[3] = {0, 0, 0};
+    float mod_scale = 1.f, mod_speed = 1.f;
+    EmVec em;
+    // ---- the rest
+    uint32_t uid = 0;
+    int32_t starts_enabled = 1;
+    std::vector<TypeHost> types;
+    std::vector<uint32_t> seg;  // per type
 };
 
 template <typename T>
@@ -318,8 +459,8 @@ struct fw_ctx {
     uint32_t spin_limit = 1u << 16;
     uint32_t dbg = 0;  // FW_DEBUG: profiling-only kernel ablations (results are wrong when set)
 
-    std::vector<SpawnerHost> spawners;
-    std::vector<SegHost> segs;
+    std::vector<SpawnerHost, HugeAlloc<SpawnerHost>> spawners;  // (HugePool: huge pages)
+    std::vector<SegHost, HugeAlloc<SegHost>> segs;
     uint32_t n_types = 0, n_emits = 0, n_emit_slots = 0;
     // table slots of destroyed / rebuilt spawners, reused by the next build (a type owns the key window
     // [type_idx * FW_KEYS_MAX, +FW_KEYS_MAX) of the key pool, so windows are recycled with their type)
@@ -1818,6 +1959,9 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
         for (int i = 0; i < 8; i++) fprintf(stderr, "  %s %.0f", names[i], ctx->prof_ns[i] / (double)ctx->prof_frames);
         fprintf(stderr, "\n[fw] table uploads: general %llu, range %llu over %llu frames\n", (unsigned long long)ctx->tab_seq,
                 (unsigned long long)ctx->r_uploads, (unsigned long long)ctx->frame);
+        fprintf(stderr, "[fw] host records: SegHost %zu B, SpawnerHost %zu B (entry at %zu), EmissionHost %zu B, FwOp %zu B\n", sizeof(SegHost),
+                sizeof(SpawnerHost), (size_t)((const char *)&ctx->spawners.data()->em.one_ - (const char *)ctx->spawners.data()),
+                sizeof(EmissionHost), sizeof(FwOp));
     }
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
@@ -2262,7 +2406,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         SpawnerHost &sp = ctx->spawners[h];
         if (h + 8 < ctx->spawners.size()) {  // the entries of a later spawner live on the heap: fetch them ahead of time
             const SpawnerHost &nx = ctx->spawners[h + 8];
-            if (!nx.em.empty()) {
+            if (nx.em.size() > 1) {  // (a single entry is part of the spawner's record: the array is streamed as it is)
                 __builtin_prefetch(nx.em.data());
                 __builtin_prefetch((const char *)nx.em.data() + 128);
             }
@@ -2452,7 +2596,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     size_t n_g = 0, n_n = 0;
     for (auto &L : levels) n_g += L.g.size(), n_n += L.n.size();
     // last thing that can fail before the frame is enqueued: room for the op tables of either form
-    if ((st = ensure_param_ring(ctx, round_up((n_seg + 1) * sizeof(uint32_t), 16) + n_g * sizeof(FwOp) +
+    if ((st = ensure_param_ring(ctx, (size_t)n_seg * 16 + n_g * sizeof(FwOp) +
                                          n_n * sizeof(FwNestOp) + 16)))
         return rollback(st);
     // ---- the frame will run
@@ -2658,7 +2802,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             for (size_t i = 0; i < ops.size(); i++) inl.ops[i] = ops[i];
         } else {
             spawn_form = FW_SPAWN_TABLE;
-            const size_t off_ops = round_up((n_seg + 1) * sizeof(uint32_t), 16);
+            struct OpHdr {  // FwUpdateArgs::seg_op_first: per segment {first op, one past its last, particles they spawn in all, 0}
+                uint32_t o0, o1, n, pad;
+            };
+            const size_t off_ops = (size_t)n_seg * sizeof(OpHdr);
             const size_t bytes = off_ops + ops.size() * sizeof(FwOp);
             if ((st = ensure_param_ring(ctx, bytes))) return st;
             slot = (int)(ctx->ring_seq++ % kParamRing);
@@ -2674,17 +2821,18 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             }
             char *hp = ctx->h_param[slot];
             char *dp = ctx->d_param[slot];
-            uint32_t *sof = (uint32_t *)hp;
+            OpHdr *hdr = (OpHdr *)hp;
             size_t oi = 0;
-            for (uint32_t sgi = 0; sgi <= n_seg; sgi++) {
-                while (oi < ops.size() && ops[oi].seg < sgi) oi++;
-                sof[sgi] = (uint32_t)oi;
+            for (uint32_t sgi = 0; sgi < n_seg; sgi++) {  // (ops are sorted by segment)
+                const size_t b = oi;
+                uint64_t n = 0;
+                while (oi < ops.size() && ops[oi].seg == sgi) n += ops[oi].n, oi++;
+                hdr[sgi] = OpHdr{(uint32_t)b, (uint32_t)oi, (uint32_t)std::min<uint64_t>(n, 0xFFFFFFFFull), 0u};
             }
-            sof[n_seg] = (uint32_t)ops.size();
             memcpy(hp + off_ops, ops.data(), ops.size() * sizeof(FwOp));
             if (ctx->ops_zerocopy) {
                 // pinned host memory is device-visible: the tiles read their few ops over the bus (tens of bytes each)
-                a.seg_op_first = (const uint32_t *)hp;
+                a.seg_op_first = (const uint4 *)hp;
                 a.ops = (const FwOp *)(hp + off_ops);
                 ctx->slot_frame[slot] = ctx->frame + 1;  // free once done_tag >= frame + 1
                 slot = -1;                                // no consumed-event for this slot
@@ -2692,7 +2840,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 FW_HIP(ctx, hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
                 FW_HIP(ctx, hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
                 FW_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
-                a.seg_op_first = (const uint32_t *)dp;
+                a.seg_op_first = (const uint4 *)dp;
                 a.ops = (const FwOp *)(dp + off_ops);
             }
         }

@@ -92,8 +92,8 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             }
         }
     } else if (SPAWN == FW_SPAWN_TABLE) {
-        o0 = a.seg_op_first[seg], o1 = a.seg_op_first[seg + 1];
-        for (uint32_t i = o0; i < o1; i++) n_spawn += a.ops[i].n;
+        const uint4 oh = a.seg_op_first[seg];
+        o0 = oh.x, o1 = oh.y, n_spawn += oh.z;
     }
     // virtual spawns beyond the segment's capacity are dropped (and reported): nothing may be read or written past it
     const uint32_t seg_cap = g.segs[seg].capacity;
@@ -626,9 +626,18 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             }
         }
     } else if (SPAWN == FW_SPAWN_TABLE) {
-        o0 = a.seg_op_first[seg], o1 = a.seg_op_first[seg + 1];
-        for (uint32_t i = o0; i < o1; i++) n_spawn += a.ops[i].n;
+        const uint4 oh = a.seg_op_first[seg];
+        o0 = oh.x, o1 = oh.y, n_spawn += oh.z;
     }
+    // Table form: the ops live in pinned HOST memory -- every field a lane reads there is a trip over the bus (~2 us).  A
+    // segment's few ops are requested once, one word per lane, as soon as the header has named them, and parked in LDS right
+    // before the spawn round needs them (the request is long back by then); segments with more ops read them in place.
+    constexpr uint32_t OPW = sizeof(FwOp) / 4u;
+    __shared__ __attribute__((aligned(16))) uint32_t s_ops[SPAWN == FW_SPAWN_TABLE ? FW_LDS_OPS * OPW : 1];
+    const uint32_t ops_words = (SPAWN == FW_SPAWN_TABLE && o1 - o0 <= FW_LDS_OPS) ? (o1 - o0) * OPW : 0u;  // workgroup-uniform
+    uint32_t opw = 0u;
+    if (SPAWN == FW_SPAWN_TABLE)  // (unconditional, at a clamped index: see the note on predicated loads below)
+        opw = reinterpret_cast<const uint32_t *>(a.ops + (ops_words ? o0 : 0u))[ops_words ? min(tid, ops_words - 1u) : 0u];
     if (SPAWN != FW_SPAWN_NONE) {  // virtual spawns beyond the capacity are dropped (and reported)
         const uint32_t spawn_room = seg_cap - min(n_in, seg_cap);
         if (n_spawn > spawn_room) {
@@ -856,6 +865,13 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     if (SPAWN != FW_SPAWN_NONE && (!loaded_tile || tail_new)) {
         // ---- new-particle tile (or the one extra round of a live tile that carries its segment's few new particles):
         // spawn_particles (src/core.rs:437-469) right before update_particles, per slot
+        const FwOp *opsp = a.ops + o0;  // the segment's first op (a generic pointer: LDS or pinned host memory)
+        if (SPAWN == FW_SPAWN_TABLE && ops_words != 0u) {
+            if (tid < ops_words) s_ops[tid] = opw;
+            __syncthreads();
+            opsp = reinterpret_cast<const FwOp *>(s_ops);
+        }
+#define FW_OPS(i) (SPAWN == FW_SPAWN_INLINE ? inl.ops[i] : opsp[(i) - o0])
         const uint32_t sbase = tail_new ? n_in : base, slim = tail_new ? n_tot : lim;
         const uint32_t srounds = tail_new ? 1u : vt_rounds;
 #pragma unroll 1
@@ -869,8 +885,8 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
                 const uint32_t k = idx - n_in;
                 uint32_t oi = o0;
                 for (uint32_t i = o0; i < o1; i++)
-                    if (k >= FW_OP(i).rel_base && k - FW_OP(i).rel_base < FW_OP(i).n) oi = i;
-                const FwOp &op = FW_OP(oi);
+                    if (k >= FW_OPS(i).rel_base && k - FW_OPS(i).rel_base < FW_OPS(i).n) oi = i;
+                const FwOp &op = FW_OPS(oi);
                 so = fw_spawn_one(g.emits[op.emit], g.seed, op.serial_base + (k - op.rel_base),
                                   fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
                                   fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
@@ -894,6 +910,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
                             ob, W, destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec, box, box_on);
             if (INST && inst != nullptr && !FW_DBG(a.dbg, 2u)) fw_inst_flush(inst, inst_cap, s_inst + wave * 256u, lane, m, wbase);
         }
+#undef FW_OPS
     }
     if (lane == 0) s_part[2][wave] = acc.fa, s_part[3][wave] = acc.fb;
     __syncthreads();

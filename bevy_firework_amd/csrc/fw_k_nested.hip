@@ -276,7 +276,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
 hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *d_ops, const FwOp *h_ops, uint32_t n_ops,
                            uint32_t total_blocks, uint32_t parity) {
     if (!n_ops || !total_blocks) return hipSuccess;
-    static FwInlineOps io;  // (calls on a context are serialised by the caller; the launch copies its arguments)
+    FwInlineOps io{};  // (on the stack: contexts may be driven from different threads; the launch copies its arguments)
     if (!d_ops)
         for (uint32_t i = 0; i < n_ops && i < FW_INLINE_OPS; i++) io.ops[i] = h_ops[i];
     hipLaunchKernelGGL(fw_k_spawn, dim3(total_blocks), dim3(FW_BLOCK), 0, s, g, io, d_ops, n_ops, parity);
@@ -286,7 +286,7 @@ hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *d_ops,
 hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d_ops, const FwNestOp *h_ops, uint32_t n_ops,
                             uint32_t total_tiles, uint32_t parity, uint32_t tag, uint32_t spin_limit, uint32_t dbg) {
     if (!n_ops || !total_tiles) return hipSuccess;
-    static FwNestInline io;
+    FwNestInline io{};
     if (!d_ops)
         for (uint32_t i = 0; i < n_ops && i < FW_INLINE_OPS; i++) io.ops[i] = h_ops[i];
     hipLaunchKernelGGL(fw_k_nest, dim3(total_tiles), dim3(FW_BLOCK), 0, s, g, io, d_ops, n_ops, parity, tag, spin_limit, dbg);

@@ -71,7 +71,9 @@ struct FwUpdateArgs {
     // Global spawn ops fused into the update (virtual particles appended after the live ones);
     // sorted by destination segment, emission order inside a segment
     const FwOp *ops;               // table form (device memory), or null
-    const uint32_t *seg_op_first;  // [n_seg + 1] first op of each segment (table form)
+    const uint4 *seg_op_first;     // [n_seg] per segment {first op, one past its last op, particles they spawn in all, 0} (table
+                                   // form; pinned host memory: ONE bus round trip tells a tile its role -- summing the ops' counts
+                                   // over the bus was a second, dependent one)
     uint32_t n_ops;                // ops this frame (inline form: entries of FwInlineOps used)
     uint32_t dbg;                  // FW_DEBUG (profiling only, results wrong): 1 = no look-back, 2 = no integrate
     // survivor forecast (fw_k_update header): table written last frame / table to write this frame
@@ -152,6 +154,7 @@ struct FwFifoSeg {
     unsigned long long *report;
 };
 #define FW_FIFO_PER_LAUNCH 8
+#define FW_LDS_OPS 4u  // ops of one segment fw_k_update_stream parks in LDS (table form: pinned host memory otherwise)
 #define FW_FIFO_COLL_TILE FW_BLOCK  // ring tile of a FIFO launch with colliding types: one round per workgroup (fw_k_update_fifo: TR)
 struct FwFifoArgs {
     FwFifoSeg s[FW_FIFO_PER_LAUNCH];

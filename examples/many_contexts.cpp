@@ -1,0 +1,112 @@
+// many_contexts.cpp -- many small emitters, the regime where the HOST half of a frame (emission clocks, spawn counts, op
+// records: ~30 ns per emitter on one thread) is what bounds the frame rate.  The reference walks its spawners in parallel
+// (update_particles: par_iter_mut, core.rs:583-585); the counterpart here is one context per worker thread: contexts share
+// nothing (calls on ONE context are serialised by its owner, different contexts may be driven concurrently), each has its own
+// HIP stream, and the device runs their launches side by side.
+//
+//   make -C examples
+//   ./examples/many_contexts [emitters] [live per emitter] [threads] [frames] [free]
+// Frames are synchronous by default (every thread steps its context once, then all meet at a barrier: one frame of a game
+// loop); a fifth argument lets every thread run free instead.  Prints microseconds per frame for the whole set.
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "firework.hpp"
+
+using namespace firework;
+
+// the emitters of configs[2] / configs[4] (bevy_firework_amd/workloads.py: many_emitters): Sphere emission, radial velocity,
+// lifetimes in [0.8, 1.2] s, per-emitter constants
+static ParticleSpawner make_emitter(int e, float live) {
+    const float k = (float)(e % 7);
+    ParticleSpawner sp;
+    ParticleSettings &ps = sp.particle_settings[0];
+    ps.lifetime = {0.8f, 1.2f};
+    ps.initial_scale = {0.02f, 0.06f};
+    ps.scale_curve = FireworkCurve::even_samples({1.0f, 1.5f + 0.1f * k, 0.2f});
+    ps.acceleration = {0.1f * k, -9.81f + 0.5f * k, -0.05f * k};
+    ps.linear_drag = 0.1f + 0.02f * k;
+    ps.base_color = FireworkGradient::uneven_samples(
+        {{0.0f, {4.0f + k, 2.0f, 0.5f * k, 1.0f}}, {0.5f + 0.05f * k, {1.0f, 0.5f + 0.1f * k, 0.2f, 1.0f}}, {1.0f, {0.1f, 0.1f, 0.1f, 0.0f}}});
+    ps.emissive_color = FireworkGradient::even_samples({{2.0f, 1.0f + 0.1f * k, 0.0f, 1.0f}, {0.0f, 0.0f, 0.0f, 1.0f}});
+    EmissionSettings &es = sp.emission_settings[0];
+    es.emission_pacing = EmissionPacing::rate(live);
+    es.emission_shape = EmissionShape::Sphere(1.0f);
+    es.initial_velocity = RandVec3::constant({0.0f, 0.0f, 0.0f});
+    es.initial_velocity_radial = {1.0f, 4.0f};
+    return sp;
+}
+
+struct SpinBarrier {  // (frames are tens of microseconds: a futex barrier's wake-up would be most of one)
+    explicit SpinBarrier(int n) : n_(n) {}
+    void wait() {
+        const unsigned gen = gen_.load(std::memory_order_acquire);
+        if (count_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
+            count_.store(0, std::memory_order_relaxed);
+            gen_.store(gen + 1, std::memory_order_release);
+        } else {
+            while (gen_.load(std::memory_order_acquire) == gen) __builtin_ia32_pause();
+        }
+    }
+    const int n_;
+    std::atomic<int> count_{0};
+    std::atomic<unsigned> gen_{0};
+};
+
+int main(int argc, char **argv) {
+    const int n_em = argc > 1 ? atoi(argv[1]) : 2048;
+    const float live = argc > 2 ? (float)atof(argv[2]) : 200.0f;
+    const int n_thr = argc > 3 ? std::max(1, atoi(argv[3])) : 4;
+    const int frames = argc > 4 ? atoi(argv[4]) : 2000;
+    const bool free_run = argc > 5;
+    const float dt = 1.0f / 60.0f;
+    const int side = std::max(1, (int)std::ceil(std::sqrt((double)n_em)));
+    SpinBarrier bar(n_thr + 1);
+    std::atomic<int> failed{0};
+    std::vector<uint64_t> live_out(n_thr, 0);
+    std::vector<std::thread> workers;
+    for (int t = 0; t < n_thr; t++)
+        workers.emplace_back([&, t]() {
+            try {
+                ParticleSystemPlugin app(0, /*seed*/ 0x00C0FFEE + (uint32_t)t);
+                for (int e = t; e < n_em; e += n_thr)  // emitter e -> context e mod T (the rule of sharding.py across GPUs)
+                    app.spawn(make_emitter(e, live), Transform{{3.0f * (float)(e % side), 0.0f, 3.0f * (float)(e / side)}, {}}, (uint32_t)e);
+                app.update(dt);
+                for (int i = 0; i < 80; i++) app.step(dt);  // fill (lifetimes up to 1.2 s)
+                app.synchronize();
+                bar.wait();  // -> t0
+                for (int i = 0; i < frames; i++) {
+                    app.step(dt);
+                    if (!free_run) bar.wait();
+                }
+                app.synchronize();
+                if (free_run) bar.wait();
+                bar.wait();  // -> t1
+                live_out[t] = app.live_count();
+            } catch (const Error &e) {
+                std::fprintf(stderr, "firework error %d in context %d: %s\n", (int)e.status, t, e.what());
+                failed++;
+                std::exit(1);
+            }
+        });
+    bar.wait();
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!free_run)
+        for (int i = 0; i < frames; i++) bar.wait();
+    else
+        bar.wait();
+    bar.wait();
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    for (auto &w : workers) w.join();
+    uint64_t total = 0;
+    for (uint64_t v : live_out) total += v;
+    std::printf("%d emitters x %.0f live on %d context(s) / thread(s), %s frames: %.1f us per frame, %llu live, %.3e particles/s\n", n_em,
+                live, n_thr, free_run ? "free-running" : "synchronous", us / frames, (unsigned long long)total, (double)total * frames / (us * 1e-6));
+    return failed ? 1 : 0;
+}

@@ -18,8 +18,13 @@
  *    reference's panics (zero-key curve curve.rs:45,61,211,227; out-of-range
  *    particle_index / target_particle_type core.rs:392,453,488) become FW_EINVAL
  *    at create time.
- *  - one context per GPU; calls on one context must be serialised by the caller
- *    (the reference chain is sequential too).  fw_step only ENQUEUES work on the
+ *  - calls on ONE context must be serialised by the caller (the reference chain is sequential too).  Contexts share no
+ *    state: different contexts -- on one GPU or on several -- may be driven from different threads at the same time.
+ *    One context per GPU is the normal arrangement; a host with thousands of small emitters, whose frame is bound by the
+ *    host half of fw_step (~30 ns per emitter on one thread), spreads them over a few contexts on the same GPU, one per
+ *    worker thread -- the counterpart of the reference's par_iter_mut over spawners (core.rs:583-585); the device runs
+ *    their launches side by side (examples/many_contexts.cpp).  fw_last_error(NULL) is per calling thread.
+ *  - fw_step only ENQUEUES work on the
  *    context's HIP stream; readers synchronise that stream.  A context created on a CALLER-SUPPLIED stream keeps the
  *    whole frame on that stream: work the caller orders behind fw_step on it (or hipStreamSynchronize of it) covers
  *    the frame.  A context that owns its stream (stream = NULL at fw_ctx_create) may run part of a frame on a second,

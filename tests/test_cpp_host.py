@@ -127,7 +127,10 @@ def test_native_sharded_host_matches_the_python_sharding(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     outs = []
     for how in (["--gpus", "1"], ["--rank", "0", "--world", "1", "--id-file", str(tmp_path / "nccl_id")]):
-        r = subprocess.run([exe] + how + common, capture_output=True, text=True, timeout=300, env=env)
+        try:
+            r = subprocess.run([exe] + how + common, capture_output=True, text=True, timeout=120, env=env)
+        except subprocess.TimeoutExpired:  # (RCCL's communicator set-up has hung once on a fresh box: one more try)
+            r = subprocess.run([exe] + how + common, capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines())
     assert outs[0][:45] == outs[1][:45]

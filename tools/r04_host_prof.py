@@ -3,7 +3,7 @@ import os, sys, time
 os.environ["FW_ENABLE_KNOBS"] = "1"
 os.environ["FW_HOST_PROF"] = "100"
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-os.environ["FW_LIB_PATH"] = os.path.join(root, "bevy_firework_amd/csrc/libfirework_hip_ab.so")
+os.environ.setdefault("FW_LIB_PATH", os.path.join(root, "bevy_firework_amd/csrc/libfirework_hip_ab.so"))
 import numpy as np
 sys.path.insert(0, root)
 from bevy_firework_amd import workloads
