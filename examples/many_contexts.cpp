@@ -74,7 +74,7 @@ int main(int argc, char **argv) {
     for (int t = 0; t < n_thr; t++)
         workers.emplace_back([&, t]() {
             try {
-                ParticleSystemPlugin app(0, /*seed*/ 0x00C0FFEE + (uint32_t)t);
+                ParticleSystemPlugin app(0, /*seed*/ 0x00C0FFEE);  // (one seed: emitter e draws the same numbers wherever it lives -- uid e)
                 for (int e = t; e < n_em; e += n_thr)  // emitter e -> context e mod T (the rule of sharding.py across GPUs)
                     app.spawn(make_emitter(e, live), Transform{{3.0f * (float)(e % side), 0.0f, 3.0f * (float)(e / side)}, {}}, (uint32_t)e);
                 app.update(dt);

@@ -153,3 +153,29 @@ def test_native_sharded_host_matches_the_python_sharding(tmp_path):
             h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert f"{h:016x}" == cpp_digest
     sh.system.close()
+
+
+@pytest.mark.gpu
+def test_cpp_many_contexts_one_per_thread():
+    """examples/many_contexts.cpp: emitters spread over contexts, one per worker thread, stepped frame-synchronously -- the same
+    emitters end up with the same live total however many contexts (and threads) hold them (emitter e keeps uid e)"""
+    build()
+    exe = os.path.join(ROOT, "examples", "many_contexts")
+    totals = []
+    for threads in ("1", "2", "3"):
+        r = subprocess.run([exe, "96", "400", threads, "150"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        m = re.search(r"on (\d+) context\(s\).*?([\d.]+) us per frame, (\d+) live", r.stdout)
+        assert m and m.group(1) == threads, r.stdout
+        totals.append(int(m.group(3)))
+    assert totals[0] > 30000 and totals[0] == totals[1] == totals[2], totals
+
+
+def test_cpp_many_contexts_fails_loudly_without_gpu():
+    build()
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([os.path.join(ROOT, "examples", "many_contexts"), "8", "100", "2", "2"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
