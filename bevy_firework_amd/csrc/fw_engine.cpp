@@ -221,6 +221,30 @@ struct EmVec {
     void clear() { assign(0, EmissionHost{}); }
 };
 
+// A queue in ONE pooled allocation (HugePool), a power of two of entries: in the steady state every frame pops one entry and
+// pushes one per segment; a std::deque pays its chunk bookkeeping and two dependent pointer hops for each -- 30 us per frame
+// with 2048 emitters.
+template <typename T>
+struct Ring {
+    std::vector<T, HugeAlloc<T>> v;
+    uint32_t head = 0, n = 0;
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+    T &front() { return v[head]; }
+    T &back() { return v[(head + n - 1) & (uint32_t)(v.size() - 1)]; }
+    void pop_front() { head = (head + 1) & (uint32_t)(v.size() - 1), n--; }
+    void pop_back() { n--; }
+    void clear() { head = n = 0; }
+    void push_back(const T &x) {
+        if (n == v.size()) {  // grow to the next power of two, oldest entry first
+            std::vector<T, HugeAlloc<T>> w(v.empty() ? 64 : v.size() * 2);
+            for (uint32_t i = 0; i < n; i++) w[i] = v[(head + i) & (uint32_t)(v.size() - 1)];
+            v.swap(w), head = 0;
+        }
+        v[(head + n) & (uint32_t)(v.size() - 1)] = x, n++;
+    }
+};
+
 struct alignas(64) SegHost {
     // Lifetime window: a particle is destroyed by the update in which age >= lifetime (core.rs:590-592), and
     // lifetime <= life_bound, so everything alive was spawned less than life_bound of simulated time ago.  The sum of
@@ -230,26 +254,7 @@ struct alignas(64) SegHost {
         uint64_t n;
         uint64_t frame;  // frame of the spawn (the device's ages are fp32 sums: the error grows with the steps taken)
     };
-    // (a ring in one allocation: in the steady state every frame pops one entry and pushes one per segment; a
-    // std::deque pays its chunk bookkeeping for each -- 30 us per frame with 2048 emitters)
-    struct Window {
-        std::vector<Spawned, HugeAlloc<Spawned>> v;
-        uint32_t head = 0, n = 0;
-        bool empty() const { return n == 0; }
-        size_t size() const { return n; }
-        Spawned &front() { return v[head]; }
-        Spawned &back() { return v[(head + n - 1) & (uint32_t)(v.size() - 1)]; }
-        void pop_front() { head = (head + 1) & (uint32_t)(v.size() - 1), n--; }
-        void pop_back() { n--; }
-        void push_back(const Spawned &x) {
-            if (n == v.size()) {  // grow to the next power of two, oldest entry first
-                std::vector<Spawned, HugeAlloc<Spawned>> w(v.empty() ? 64 : v.size() * 2);
-                for (uint32_t i = 0; i < n; i++) w[i] = v[(head + i) & (uint32_t)(v.size() - 1)];
-                v.swap(w), head = 0;
-            }
-            v[(head + n) & (uint32_t)(v.size() - 1)] = x, n++;
-        }
-    };
+    using Window = Ring<Spawned>;
     // ---- what the per-frame loops of fw_step touch, in ONE cache line (with thousands of segments those loops are
     // bound by how many lines they stream, not by their arithmetic)
     bool in_use = false;
@@ -325,13 +330,18 @@ struct alignas(64) SegHost {
     // part -- slot of its first particle, its size, its spawn cohorts -- is host-known exactly (the host made every spawn
     // count and replays the fp32 age of every cohort: fw_ctx::birth_age); the size of the old part is the device's
     // count minus young_n.  `ub` bounds the total as for any segment (lifetime window, snapshots).
+    // (what the range pass of every frame reads and writes, next to each other)
     uint32_t young_lo = 0, young_n = 0;
     float range_life_lo = 0.f;  // every particle outlives an update that leaves its age below this (TypeHost::life_lo_safe)
     struct YCohort {
         uint64_t frame;  // frame of the spawn
         uint32_t n;
     };
-    std::deque<YCohort> ycoh;  // the young cohorts, oldest first
+    Ring<YCohort> ycoh;  // the young cohorts, oldest first
+    uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
+    uint32_t r_low[3] = {0, 0, 0};               // frames in a row a role's need has been far below what is provided
+    uint32_t r_need[3] = {0, 0, 0};              // what each role needed in the latest frame (the table keeps more: fit())
+    uint32_t r_status_base = 0;                  // first look-back word of its OLD workgroups in the current table
     // ... in a spawner WITH Nested entries (core.rs:471-546):
     //   range_mat  other particles' entries emit FROM this type: in frames that run a Nested pass its Global particles are
     //              materialised behind the young part by fw_k_spawn before the pass (core.rs:488) and fw_k_update_range
@@ -356,10 +366,6 @@ struct alignas(64) SegHost {
     uint64_t gcoh_sum = 0;
     uint32_t rold_seen = 0;     // the old part's size as of the last exact read (refresh_counts_exact): FwGlobals::rold
     uint32_t r_young_main = 0;  // range_dev: young tiles the current table keeps in front (the rest: probably idle, at its end)
-    uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
-    uint32_t r_low[3] = {0, 0, 0};               // frames in a row a role's need has been far below what is provided
-    uint32_t r_need[3] = {0, 0, 0};              // what each role needed in the latest frame (the table keeps more: fit())
-    uint32_t r_status_base = 0;                  // first look-back word of its OLD workgroups in the current table
     bool ring() const { return fifo || range; }  // one buffer, particle 0 not in slot 0
     // FW_TYPE_DERIVED (fw_device.h): an instance buffer is attached -- its records carry scale and colours, the planes S4 / Q5 /
     // Q6 are not stored by the update; every reader evaluates them from age / lifetime / initial_scale
