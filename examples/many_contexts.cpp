@@ -92,7 +92,8 @@ int main(int argc, char **argv) {
             } catch (const Error &e) {
                 std::fprintf(stderr, "firework error %d in context %d: %s\n", (int)e.status, t, e.what());
                 failed++;
-                std::exit(1);
+                std::fflush(stderr);
+                std::_Exit(1);  // (not exit(): static destructors must not run under the other workers' feet)
             }
         });
     bar.wait();
