@@ -137,3 +137,137 @@ def stress_test_collision(rate: float = 80000.0):
         Collider.Box((0.0, 0.5, 0.0), (0.5, 0.5, 0.5), cube_rot),      # Collider::cuboid(1., 1., 1.), the angled cube
     ]
     return ParticleSpawner([ps], [es]), tf, colliders
+
+
+# ---- the reference's remaining examples (examples/*.rs), settings only: what a user of the crate actually runs ---------------
+SPARKS_GRADIENT = [  # examples/sparks.rs:58-64, examples/on_demand.rs:62-68
+    (0.0, (150.0, 100.0, 15.0, 1.0)), (0.7, (3.0, 1.0, 1.0, 1.0)), (0.8, (1.0, 0.3, 0.3, 1.0)),
+    (0.9, (0.3, 0.3, 0.3, 1.0)), (1.0, (0.1, 0.1, 0.1, 0.0)),
+]
+SMOKE_GRADIENT = [(0.0, (0.6, 0.3, 0.0, 0.0)), (0.1, (0.6, 0.3, 0.0, 0.35)), (1.0, (0.6, 0.3, 0.0, 0.0))]  # pbr.rs:58-62, one_shot.rs:101-105
+
+
+def _quat_from_arc(a, b):
+    """glam Quat::from_rotation_arc for two unit vectors that are not (anti)parallel: (a x b, 1 + a.b), normalised"""
+    cx, cy, cz = a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]
+    w = 1.0 + a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+    n = math.sqrt(cx * cx + cy * cy + cz * cz + w * w)
+    return (cx / n, cy / n, cz / n, w / n)
+
+
+def example_sparks(pacing: EmissionPacing = None, lifetime: float = 0.75) -> Tuple[ParticleSpawner, Transform]:
+    """examples/sparks.rs:48-85 (rate 1000/s, lifetime 0.75 s); examples/on_demand.rs:56-96 is the same spawner with
+    EmissionPacing::OnDemand (`pacing`), fed one particle per mouse click (on_demand.rs:130-141)."""
+    ps = ParticleSettings(
+        lifetime=RandF32.constant(lifetime), initial_scale=RandF32(0.02, 0.08), scale_curve=FireworkCurve.constant(1.0),
+        base_color=FireworkGradient.uneven_samples(SPARKS_GRADIENT), linear_drag=0.1, pbr=False,
+    )
+    es = EmissionSettings(
+        emission_pacing=pacing or EmissionPacing.rate(1000.0), emission_shape=EmissionShape.Circle((0.0, 1.0, 0.0), 0.3),
+        inherit_parent_velocity=True,
+        initial_velocity=RandVec3(RandF32(0.0, 10.0), (0.0, 1.0, 0.0), 30.0 / 180.0 * math.pi),
+    )
+    return ParticleSpawner([ps], [es]), Transform((0.0, 0.1, 0.0))
+
+
+def example_on_demand() -> Tuple[ParticleSpawner, Transform]:
+    return example_sparks(EmissionPacing.OnDemand())
+
+
+def example_pbr() -> Tuple[ParticleSpawner, Transform]:
+    """examples/pbr.rs:49-84: slow smoke -- rate 150/s, lifetime 5 s, a wide Circle, NO initial velocity, a small upward
+    acceleration against drag 0.7, a 2-key scale curve and a 3-key alpha gradient."""
+    ps = ParticleSettings(
+        lifetime=RandF32.constant(5.0), scale_curve=FireworkCurve.even_samples([1.0, 2.0]), initial_scale=RandF32(0.5, 1.3),
+        acceleration=(0.0, 0.3, 0.0), linear_drag=0.7, base_color=FireworkGradient.uneven_samples(SMOKE_GRADIENT),
+        emissive_color=FireworkGradient.constant((0.0, 0.0, 0.0, 1.0)), fade_scene=3.5, pbr=True,
+    )
+    es = EmissionSettings(
+        particle_index=0, emission_pacing=EmissionPacing.rate(150.0), emission_shape=EmissionShape.Circle((0.0, 1.0, 0.0), 3.5),
+        initial_velocity=RandVec3.constant((0.0, 0.0, 0.0)), initial_velocity_radial=RandF32.constant(0.0),
+        inherit_parent_velocity=True,
+    )
+    return ParticleSpawner([ps], [es]), Transform((0.0, 0.1, 0.0))
+
+
+def example_collision():
+    """examples/collision.rs:43-112: rate 100/s, lifetime 6.75 s, a 3-key uneven scale curve, a constant base colour and a 4-key
+    emissive gradient, bouncing (restitution 0.6, friction 0.2) off the ground slab and the angled cube -- the scene
+    stress_test_collision scales up.  Returns (spawner, transform, colliders)."""
+    ps = ParticleSettings(
+        lifetime=RandF32.constant(6.75), scale_curve=FireworkCurve.uneven_samples([(0.0, 1.0), (0.8, 1.0), (1.0, 0.0)]),
+        initial_scale=RandF32(0.02, 0.08), linear_drag=0.15, base_color=FireworkGradient.constant((0.1, 0.1, 0.1, 1.0)),
+        emissive_color=FireworkGradient.uneven_samples([
+            (0.0, (30.0, 21.0, 1.0, 1.0)), (0.7, (3.0, 1.0, 1.0, 1.0)), (0.75, (1.0, 0.3, 0.3, 1.0)), (0.8, (0.0, 0.0, 0.0, 1.0))]),
+        pbr=True, collision_settings=ParticleCollisionSettings(restitution=0.6, friction=0.2, destroy_on_collision=False),
+    )
+    es = EmissionSettings(
+        particle_index=0, emission_pacing=EmissionPacing.rate(100.0), emission_shape=EmissionShape.Circle((0.0, 1.0, 0.0), 0.3),
+        initial_velocity=RandVec3(RandF32(6.0, 8.0), (0.0, 1.0, 0.0), 30.0 / 180.0 * math.pi), inherit_parent_velocity=True,
+    )
+    _, tf, colliders = stress_test_collision()  # (the same emitter pose, slab and cube: collision.rs:45-49, 95-112)
+    return ParticleSpawner([ps], [es]), tf, colliders
+
+
+def example_one_shot(impulse: float = 4.0, normal=(0.0, 1.0, 0.0), translation=(0.0, -2.0, 0.0)) -> Tuple[ParticleSpawner, Transform]:
+    """examples/one_shot.rs:91-136: the dust puff a bouncing ball leaves at a contact -- OneShot(20) in
+    SpawnTransformMode::Local, the scale range derived from the contact impulse, the emitter rotated onto the contact
+    normal; the spawner entity is despawned on ParticleSpawnerFinished (one_shot.rs:138-142)."""
+    from .settings import SpawnTransformMode
+
+    ps = ParticleSettings(
+        lifetime=RandF32.constant(2.5), initial_scale=RandF32(max(impulse / 10.0 - 0.1, 0.0), min(impulse / 10.0 + 0.1, 1.0)),
+        scale_curve=FireworkCurve.even_samples([1.0, 2.0]), base_color=FireworkGradient.uneven_samples(SMOKE_GRADIENT),
+        linear_drag=0.7, pbr=True, acceleration=(0.0, -1.5, 0.0), fade_scene=3.5,
+    )
+    es = EmissionSettings(
+        emission_pacing=EmissionPacing.OneShot(20), emission_shape=EmissionShape.Circle((0.0, 1.0, 0.0), 0.4),
+        inherit_parent_velocity=True, initial_velocity=RandVec3(RandF32(0.0, 2.0), (0.0, 1.0, 0.0), 0.0),
+        initial_velocity_radial=RandF32(0.0, 2.5),
+    )
+    n = math.sqrt(sum(c * c for c in normal))
+    normal = tuple(c / n for c in normal)
+    rot = (0.0, 0.0, 0.0, 1.0) if normal == (0.0, 1.0, 0.0) else _quat_from_arc((0.0, 1.0, 0.0), normal)
+    return ParticleSpawner([ps], [es], spawn_transform_mode=SpawnTransformMode.Local), Transform(tuple(translation), rot)
+
+
+def example_textures(with_world: bool = True):
+    """examples/textures.rs:53-173: bullet cases (rate 12/s, lifetime 5 s, initial rotation + a spin that angular_drag 0.85
+    slows, bouncing with restitution 0.4 / friction 0.35) that each leave six smoke puffs in the first tenth of their life
+    (a Nested CountOverDuration entry; its `duration` 0 is never read: core.rs:474-479), SpawnTransformMode::Local, the
+    emitter turned from +Y onto +X.  Returns (spawner, transform, colliders).  The example's colliders are an avian cylinder
+    (radius 4, height 0.2: textures.rs:191-196) and a cone (textures.rs:198-212); this backend's analytic set is planes,
+    spheres and boxes, so the world here is STAND-INS: a slab with the cylinder's top face and a sphere where
+    the cone stands."""
+    from .settings import SpawnTransformMode
+
+    s = math.sin(math.pi / 4.0)
+    cases = ParticleSettings(
+        lifetime=RandF32.constant(5.0), scale_curve=FireworkCurve.constant(1.0), initial_scale=RandF32.constant(0.3),
+        linear_drag=0.3, angular_drag=0.85,
+        base_color=FireworkGradient.uneven_samples([(0.0, (1.0, 1.0, 1.0, 1.0)), (0.9, (1.0, 1.0, 1.0, 1.0)), (1.0, (1.0, 1.0, 1.0, 0.0))]),
+        emissive_color=FireworkGradient.constant((0.0, 0.0, 0.0, 1.0)), fade_scene=0.0, fade_edge=0.0, pbr=True,
+        collision_settings=ParticleCollisionSettings(restitution=0.4, friction=0.35, destroy_on_collision=False),
+    )
+    smoke = ParticleSettings(
+        lifetime=RandF32.constant(2.0), scale_curve=FireworkCurve.even_samples([1.0, 2.0]), initial_scale=RandF32(0.5, 0.8),
+        acceleration=(0.0, 0.3, 0.0), linear_drag=0.7,
+        base_color=FireworkGradient.uneven_samples([(0.0, (0.1, 0.1, 0.1, 0.0)), (0.1, (0.1, 0.1, 0.1, 0.15)), (1.0, (0.1, 0.1, 0.1, 0.0))]),
+        emissive_color=FireworkGradient.constant((0.0, 0.0, 0.0, 1.0)), fade_scene=3.5, pbr=True,
+    )
+    e_cases = EmissionSettings(
+        particle_index=0, emission_mode=EmissionMode.Global(), emission_pacing=EmissionPacing.rate(12.0),
+        emission_shape=EmissionShape.Point(), initial_velocity=RandVec3(RandF32(2.0, 5.0), (0.0, 1.0, 0.0), 0.4),
+        initial_velocity_radial=RandF32.constant(0.0), inherit_parent_velocity=True,
+        initial_rotation=(0.0, s, 0.0, s),  # Quat::from_rotation_y(FRAC_PI_2)
+        initial_angular_velocity=RandVec3(RandF32(5.0, 15.0), (0.0, -1.0, 0.0), 0.0),
+    )
+    e_smoke = EmissionSettings(
+        particle_index=1, emission_mode=EmissionMode.Nested(0),
+        emission_pacing=EmissionPacing.CountOverDuration(6.0, 0.0, 0.0, 0.1), emission_shape=EmissionShape.Point(),
+        initial_velocity=RandVec3.constant((0.0, 0.0, 0.0)), initial_velocity_radial=RandF32.constant(0.0),
+        inherit_parent_velocity=False, initial_angular_velocity=RandVec3.constant((0.0, 0.0, 0.0)),
+    )
+    tf = Transform((-2.0, 2.0, 0.0), _quat_from_arc((0.0, 1.0, 0.0), (1.0, 0.0, 0.0)))
+    colliders = [Collider.Box((0.0, 0.0, 0.0), (4.0, 0.1, 4.0)), Collider.Sphere((0.0, 0.5, 0.0), 0.5)] if with_world else []
+    return ParticleSpawner([cases, smoke], [e_cases, e_smoke], spawn_transform_mode=SpawnTransformMode.Local), tf, colliders
