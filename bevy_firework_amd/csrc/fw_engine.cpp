@@ -338,6 +338,7 @@ struct alignas(64) SegHost {
         uint32_t n;
     };
     Ring<YCohort> ycoh;  // the young cohorts, oldest first
+    bool few_ring = false;  // a range ring below fw_ctx::range_min: only because the context holds few segments (fw_ctx::range_few)
     uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
     uint32_t r_low[3] = {0, 0, 0};               // frames in a row a role's need has been far below what is provided
     uint32_t r_need[3] = {0, 0, 0};              // what each role needed in the latest frame (the table keeps more: fit())
@@ -570,6 +571,15 @@ struct fw_ctx {
                                  // small segment three workgroups where the compacting path needs one.  Swept on many equal
                                  // emitters (profiles/r04/range_min_sweep.txt): 8192 is where the one-round tiles start to win
     uint32_t n_range = 0;
+    // A context with FEW segments -- the reference's own regime: examples/sparks.rs is one spawner of ~730 particles -- runs a small
+    // type on a range ring too: one emitter of 733 particles 13.2 -> 9.1 us per frame, 8-64 such emitters 16 -> 10-11
+    // (profiles/r04/few_small_emitters.txt), where with thousands of small emitters the compacting path wins (range_min above).
+    // Up to range_few segments in use, no FIFO ring among them (a FIFO launch and a range launch run one after the other), such a
+    // type becomes a range ring whatever its size (SegHost::few_ring); the spawner that takes the context past either condition
+    // sends those rings to the compacting path (drop_few_rings: build time, the context is synchronised).  FW_RANGE_FEW; 0: off
+    uint32_t range_few = 64;
+    uint32_t n_few = 0;     // SegHost::few_ring segments
+    uint32_t n_in_use = 0;  // SegHost::in_use segments
     // A range launch whose rings hold fewer than range_small_tiles four-round tiles in all (FW_RANGE_SMALL; not with a ring whose
     // count only the device knows), or with a colliding ring, runs on OLD / YOUNG tiles of ONE round (fw_k_update_range: TR): a
     // quarter of hysteresis, a change re-sends the table.
@@ -1039,6 +1049,7 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
         s.range = false, s.ycoh.clear(), s.dcoh.clear(), s.gcoh.clear(), s.gcoh_sum = 0, s.young_lo = s.young_n = 0;
         s.range_mat = s.range_dev = false;
         ctx->n_range--;
+        if (s.few_ring) s.few_ring = false, ctx->n_few--;
         ctx->tab_force = true, ctx->r_force = true;
         ctx->seg_kind_changed = true;
     }
@@ -1046,6 +1057,7 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
     if (st) {
         if (old.fifo && !s.fifo) ctx->n_fifo++;
         if (old.range && !s.range) ctx->n_range++;
+        if (old.few_ring && !s.few_ring) ctx->n_few++;
         s = old;
         return st;
     }
@@ -1124,6 +1136,16 @@ bool nested_fed_wants_growth(const SegHost &S) {
 fw_status fifo_to_general(fw_ctx *ctx, uint32_t si) {
     if (!ctx->segs[si].ring()) return FW_OK;
     return realloc_segment(ctx, si, ctx->segs[si].capacity, true);
+}
+
+// every SegHost::few_ring segment leaves its ring (fw_ctx::range_few), particles and order kept
+fw_status drop_few_rings(fw_ctx *ctx) {
+    for (uint32_t si = 0; si < ctx->segs.size() && ctx->n_few; si++) {
+        if (!ctx->segs[si].in_use || !ctx->segs[si].few_ring) continue;
+        const fw_status st = fifo_to_general(ctx, si);  // (realloc_segment clears the flag and the count)
+        if (st) return st;
+    }
+    return FW_OK;
 }
 
 // A type stops being FW_TYPE_NOSPIN (the caller rewrites its particles, a non-finite dt is stepped): the rotation plane,
@@ -1423,6 +1445,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         SegHost &S = ctx->segs[si];
         S = SegHost{};
         S.in_use = true, S.spawner = h, S.type = (int)t, S.type_idx = type_idx;
+        ctx->n_in_use++;
         S.keys_off = dt.keys_off, S.keys_len = dt.keys_len, S.keys_cap = kwin_cap, S.bigkeys = bigkeys;
         S.nospin = nospin, S.n_xplanes = nospin ? 1u : 0u;
         memcpy(S.const_rot, dt.const_rot, sizeof S.const_rot);
@@ -1486,9 +1509,11 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             // most two last_emitted_age planes (the old tiles carry them in registers).
             S.range = ctx->use_range && !sp.no_rings && !S.fifo && !self_nested && !mixed_feed && S.n_lplanes <= 2 &&
                       (!S.collides || S.coll_inplace) && std::isfinite(p.lifetime.min) &&
-                      std::isfinite(p.lifetime.max) && T.life_lo_safe > 0.0f && caps[t] >= ctx->range_min &&
+                      std::isfinite(p.lifetime.max) && T.life_lo_safe > 0.0f &&
+                      (caps[t] >= ctx->range_min || (ctx->range_few != 0 && ctx->n_in_use <= ctx->range_few && ctx->n_fifo == 0)) &&
                       caps[t] <= FW_RANGE_MAX_CAPACITY;
             if (S.range) {
+                if (caps[t] < ctx->range_min) S.few_ring = true, ctx->n_few++;  // (fw_ctx::range_few)
                 ctx->n_range++;
                 S.range_life_lo = T.life_lo_safe;
                 ctx->range_life_max = std::max(ctx->range_life_max, S.range_life_lo);
@@ -1589,7 +1614,11 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
     }
     sp.initialized = true;
     if ((st = ensure_range_arrays(ctx))) return st;
-    return ensure_tile_arrays(ctx);
+    if ((st = ensure_tile_arrays(ctx))) return st;
+    // the context is no longer one of few segments without a FIFO ring: its small range rings continue on the compacting path
+    // (fw_ctx::range_few; callers of build_spawner have synchronised the context)
+    if (ctx->n_few && (ctx->n_fifo != 0 || ctx->n_in_use > ctx->range_few)) return drop_few_rings(ctx);
+    return FW_OK;
 }
 
 fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
@@ -1610,6 +1639,8 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
         if (S.keys_cap) ctx->free_keys.push_back({S.keys_off, S.keys_cap});
         if (S.fifo) ctx->n_fifo--;
         if (S.range) ctx->n_range--, ctx->r_force = true;
+        if (S.few_ring) ctx->n_few--;
+        ctx->n_in_use--;
         if (S.h_report) hipHostFree(S.h_report);
         if (S.buf[0]) FW_HIP(ctx, hipFree(S.buf[0]));
         if (S.destroyed) FW_HIP(ctx, hipFree(S.destroyed));
@@ -1931,6 +1962,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_FIFO_STREAM")) ctx->use_fifo_stream = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE")) ctx->use_range = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_MIN")) ctx->range_min = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_RANGE_FEW")) ctx->range_few = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_RANGE_SMALL")) ctx->range_small_tiles = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_NOSPIN")) ctx->use_nospin = atoi(m) != 0;
     if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;

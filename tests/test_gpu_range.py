@@ -373,3 +373,104 @@ def test_an_internal_error_is_sticky_for_its_spawner_until_it_is_rebuilt():
                FW_SPIN_LIMIT="4")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "STICKY-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+# ---- fw_ctx::range_few: in a context of few segments a small type runs on a range ring too ------------------------------------
+def _defaults(monkeypatch, **env):
+    for k in ("FW_ENABLE_KNOBS", "FW_FIFO", "FW_FIFO_MIN", "FW_RANGE", "FW_RANGE_MIN", "FW_RANGE_SMALL", "FW_RANGE_FEW", "FW_NOSPIN"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+
+
+def test_few_small_types_run_on_range_rings_by_default(monkeypatch):
+    """no knob set: the reference's own regime -- a handful of spawners of a few hundred particles (examples/sparks.rs) -- on
+    range rings, whatever the lifetime (one value or a range); against the oracle through deaths.  (A type that receives Nested
+    children gets a FIFO ring at any size -- its derived capacity is large -- and a FIFO ring ends the rule: the third test below)"""
+    from bevy_firework_amd.system import ParticleSystem
+
+    _defaults(monkeypatch)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        sparks, tf = workloads.example_sparks()
+        two = S.ParticleSpawner([_settings(lifetime=S.RandF32.constant(0.4)), _settings(lifetime=S.RandF32(0.1, 0.6))],
+                                [_emission(900.0), _emission(1400.0, particle_index=1, emission_shape=S.EmissionShape.Sphere(0.5))])
+        pairs = [Pair(system, sparks, tf, seed=SEED, uid=700),
+                 Pair(system, S.ParticleSpawner([_settings(lifetime=S.RandF32(0.2, 0.5))], [_emission(1500.0)]), seed=SEED, uid=701),
+                 Pair(system, two, seed=SEED, uid=702)]
+        assert [p.gpu.update_path(0)[0] for p in pairs] == ["range", "range", "range"]
+        assert pairs[2].gpu.update_path(1)[0] == "range"
+        rng = np.random.default_rng(3)
+        for fr in range(160):
+            dt = np.float32(DT if fr < 70 else rng.uniform(0.004, 0.03))
+            system.update(dt)
+            for p in pairs:
+                p.step_cpu(dt)
+            if fr % 10 == 9:
+                for k, p in enumerate(pairs):
+                    p.check(what=f"frame {fr} spawner {k}")
+        assert pairs[0].gpu.count(0) > 500 and pairs[2].gpu.count(1) > 300
+
+
+def test_small_rings_leave_when_the_context_is_no_longer_one_of_few_segments(monkeypatch):
+    """the spawner that takes the context past fw_ctx::range_few segments (here 5 instead of 64) sends every small range ring to
+    the compacting path, particles and order kept; spawners created after that follow the usual thresholds; despawning does not
+    bring rings back by itself, a NEW small type in a context that is small again does get one"""
+    from bevy_firework_amd.system import ParticleSystem
+
+    _defaults(monkeypatch, FW_ENABLE_KNOBS="1", FW_RANGE_FEW="5")
+    with ParticleSystem(device=0, seed=SEED) as system:
+        def small(uid, lo=0.2, hi=0.5):
+            return Pair(system, S.ParticleSpawner([_settings(lifetime=S.RandF32(lo, hi))], [_emission(2500.0)]),
+                        S.Transform((float(uid % 7), 0.5, 0.0)), seed=SEED, uid=uid)
+
+        pairs = [small(710 + k) for k in range(5)]
+        assert all(p.gpu.update_path(0)[0] == "range" for p in pairs)
+
+        def run(n, what):
+            for fr in range(n):
+                system.update(DT)
+                for p in pairs:
+                    p.step_cpu(DT)
+                if fr % 8 == 7 or fr == n - 1:
+                    for k, p in enumerate(pairs):
+                        p.check(exact_all=True, what=f"{what} frame {fr} spawner {k}")
+
+        run(40, "five rings")
+        pairs.append(small(720, 0.3, 0.3))  # the sixth segment: rings with live particles become compacting segments
+        assert all(p.gpu.update_path(0)[0] == "general" for p in pairs)
+        for k, p in enumerate(pairs):
+            p.check(exact_all=True, what=f"right after the change, spawner {k}")
+        run(50, "six compacting segments")
+        for p in pairs[:3]:
+            system.despawn(p.gpu)
+        del pairs[:3]
+        pairs.append(small(730))  # four segments in use again
+        assert [p.gpu.update_path(0)[0] for p in pairs] == ["general", "general", "general", "range"]
+        run(50, "three compacting segments and a ring")
+        assert all(p.gpu.count(0) > 400 for p in pairs)
+
+
+def test_small_rings_leave_when_a_fifo_ring_arrives(monkeypatch):
+    """a FIFO launch and a range launch run one after the other, a FIFO launch and the compacting launch side by side: when a large
+    one-lifetime type joins a context of small range rings, those continue on the compacting path"""
+    from bevy_firework_amd.system import ParticleSystem
+
+    _defaults(monkeypatch)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        pairs = [Pair(system, S.ParticleSpawner([_settings(lifetime=S.RandF32(0.2, 0.5))], [_emission(3000.0)]), seed=SEED, uid=740),
+                 Pair(system, S.ParticleSpawner([_settings(lifetime=S.RandF32.constant(0.4))], [_emission(1000.0)]), seed=SEED, uid=741)]
+        assert [p.gpu.update_path(0)[0] for p in pairs] == ["range", "range"]
+        for fr in range(45):
+            system.update(DT)
+            for p in pairs:
+                p.step_cpu(DT)
+        pairs.append(Pair(system, S.ParticleSpawner([_settings(lifetime=S.RandF32.constant(0.6))], [_emission(90000.0)]), seed=SEED, uid=742))
+        assert [p.gpu.update_path(0)[0] for p in pairs] == ["general", "general", "fifo"]
+        for fr in range(80):
+            system.update(DT)
+            for p in pairs:
+                p.step_cpu(DT)
+            if fr % 10 == 9:
+                for k, p in enumerate(pairs):
+                    p.check(exact_all=True, what=f"frame {fr} spawner {k}")
+        assert pairs[2].gpu.count(0) > 40000 and pairs[0].gpu.count(0) > 500
