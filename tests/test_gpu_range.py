@@ -474,3 +474,31 @@ def test_small_rings_leave_when_a_fifo_ring_arrives(monkeypatch):
                 for k, p in enumerate(pairs):
                     p.check(exact_all=True, what=f"frame {fr} spawner {k}")
         assert pairs[2].gpu.count(0) > 40000 and pairs[0].gpu.count(0) > 500
+
+
+def test_a_small_nested_spawner_stays_on_range_rings_in_a_context_of_few_segments(monkeypatch):
+    """examples/textures.rs (55 bullet cases that leave 110 puffs) with no knob set: the type that receives the children has a
+    derived capacity past the FIFO threshold (parents' CAPACITY x children), but next to its small parent type it takes a range
+    ring too -- a frame is the Nested pass + ONE update launch -- against the oracle through the deaths of both types; a
+    configs[3]-sized spawner (derived capacity in the millions) keeps its FIFO rings"""
+    from bevy_firework_amd.system import ParticleSystem
+
+    _defaults(monkeypatch)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        tex, tf, _ = workloads.example_textures(with_world=False)
+        small, tfs = workloads.nested(spark_rate=300.0, smoke_per_spark=5.0)
+        pairs = [Pair(system, tex, tf, seed=SEED, uid=760), Pair(system, small, tfs, seed=SEED, uid=761)]
+        assert [(p.gpu.update_path(0)[0], p.gpu.update_path(1)[0]) for p in pairs] == [("range", "range")] * 2
+        for fr in range(330):
+            system.update(DT)
+            for p in pairs:
+                p.step_cpu(DT)
+            if fr % 15 == 14:
+                for k, p in enumerate(pairs):
+                    p.check(what=f"frame {fr} spawner {k}")
+                    assert np.array_equal(p.gpu.last_emitted(0, 1), p.cpu.last_emitted(0, 1))
+        assert pairs[0].gpu.count(1) > 90 and pairs[1].gpu.count(1) > 2000
+    with ParticleSystem(device=0, seed=SEED) as system:
+        big, tfb = workloads.nested(spark_rate=20000.0, smoke_per_spark=20.0)
+        d = system.spawn(big, tfb, uid=762)
+        assert (d.update_path(0)[0], d.update_path(1)[0]) == ("fifo", "fifo")
