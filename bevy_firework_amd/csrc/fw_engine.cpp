@@ -1491,10 +1491,11 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             // host cannot bound their number -- and passes fifo_min for a handful of parents already (examples/textures.rs: 55
             // bullet cases, 110 puffs, 32 768 slots): in a context of few segments such a type stays with its small parent type on
             // range rings (one kind of launch per frame) unless its derived capacity is really large
+            bool few_nested = false;  // ... a range ring only because of that: it leaves with the other small rings (drop_few_rings)
             if (S.fifo && S.nested_fed && ctx->use_range && ctx->range_few != 0 && ctx->n_in_use <= ctx->range_few && ctx->n_fifo == 0 &&
                 caps[t] < 8u * ctx->fifo_min && caps[t] < ctx->range_min * 32u &&
                 S.n_lplanes <= 2 && T.life_lo_safe > 0.0f && caps[t] <= FW_RANGE_MAX_CAPACITY)  // (it does qualify for a range ring)
-                S.fifo = false;
+                S.fifo = false, few_nested = true;
             if (S.fifo) {
                 ctx->n_fifo++;
                 S.win_ok = false;
@@ -1521,7 +1522,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
                       (caps[t] >= ctx->range_min || (ctx->range_few != 0 && ctx->n_in_use <= ctx->range_few && ctx->n_fifo == 0)) &&
                       caps[t] <= FW_RANGE_MAX_CAPACITY;
             if (S.range) {
-                if (caps[t] < ctx->range_min || (S.nested_fed && caps[t] < 8u * ctx->fifo_min)) S.few_ring = true, ctx->n_few++;  // (fw_ctx::range_few)
+                if (caps[t] < ctx->range_min || few_nested) S.few_ring = true, ctx->n_few++;  // (fw_ctx::range_few)
                 ctx->n_range++;
                 S.range_life_lo = T.life_lo_safe;
                 ctx->range_life_max = std::max(ctx->range_life_max, S.range_life_lo);
