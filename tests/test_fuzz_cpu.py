@@ -100,3 +100,71 @@ def test_oracle_and_numpy_restatement_agree_on_random_nested_topologies(case):
                 for k, e in enumerate(entries):
                     assert np.array_equal(o.last_emitted(t, k), n.particles[t]["last_emitted_age"][:, k]), (case, i, t, k)
     assert sum(o.counts()) >= 0
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_oracle_and_numpy_restatement_agree_on_random_colliding_spawners(case):
+    """particle_collision (core.rs:744-800) + the analytic ray casts inside whole simulations: one to three types (colliding or
+    not, destroy_on_collision now and then, layer masks), one to four random planes / spheres / rotated boxes replaced half way, a
+    parent velocity that changes every frame.  Built like tests/test_gpu_fuzz.py's colliding scenes without a single libm call, so
+    the two restatements must agree on EVERY field bit for bit -- live particles and the records of the destroyed ones"""
+    np_sim, fz = _mods()
+    rng = np.random.default_rng(43000 + case)
+    n_types = int(rng.integers(1, 4))
+    types, emissions = [], []
+    for t in range(n_types):
+        lo = float(rng.uniform(0.2, 0.9))
+        cs = S.ParticleCollisionSettings(float(rng.uniform(0.0, 1.0)), float(rng.uniform(0.0, 1.0)), bool(rng.random() < 0.3),
+                                         int(rng.choice([0xFFFFFFFF, 1, 2, 3]))) if (t == 0 or rng.random() < 0.5) else None
+        types.append(S.ParticleSettings(
+            lifetime=S.RandF32(lo, float(lo + rng.uniform(0.0, 0.8))) if rng.random() < 0.7 else S.RandF32.constant(lo),
+            scale_curve=fz._curve(rng), initial_scale=S.RandF32(0.01, 0.05), acceleration=tuple(float(c) for c in rng.uniform(-10.0, 3.0, size=3)),
+            linear_drag=float(rng.uniform(0.0, 0.5)), base_color=fz._gradient(rng), collision_settings=cs, particles_destroyed=lambda dead: None))
+        for _ in range(int(rng.integers(1, 3))):
+            d = rng.normal(size=3) + np.array([0.0, -1.0, 0.0])
+            emissions.append(S.EmissionSettings(
+                particle_index=t, emission_pacing=S.EmissionPacing.rate(float(rng.uniform(200.0, 1500.0))),
+                initial_velocity=S.RandVec3(S.RandF32(0.5, float(rng.uniform(1.0, 9.0))), tuple(float(c) for c in d / np.linalg.norm(d)), 0.0),
+                inherit_parent_velocity=bool(rng.random() < 0.7)))
+    if n_types >= 2 and rng.random() < 0.5:
+        emissions.append(S.EmissionSettings(
+            particle_index=1, emission_mode=S.EmissionMode.Nested(0),
+            emission_pacing=S.EmissionPacing.CountOverDuration(float(rng.uniform(2.0, 6.0)), 1.0, 0.0, float(rng.uniform(0.3, 1.0))),
+            initial_velocity=S.RandVec3(S.RandF32(0.0, 2.0), (0.0, -1.0, 0.0), 0.0), inherit_parent_velocity=bool(rng.random() < 0.5)))
+    worlds = [[fz._collider(rng) for _ in range(int(rng.integers(1, 5)))] for _ in range(2)]
+    spawner = S.ParticleSpawner(types, emissions)
+    tf = S.Transform(tuple(float(c) for c in rng.uniform(-0.5, 0.5, size=3) + np.array([0.0, 2.0, 0.0])))
+    o = oracle.OracleSpawner(spawner, seed=SEED, uid=700 + case, transform=tf)
+    n = np_sim.Spawner(spawner, SEED, 700 + case, tf)
+    o.set_colliders(worlds[0])
+    n.colliders = list(worlds[0])
+    hits = 0
+    for i, dt in enumerate(fz._steps(rng, 40)):
+        dt = np.float32(dt)
+        if i == 20:
+            o.set_colliders(worlds[1])
+            n.colliders = list(worlds[1])
+        pv = tuple(float(np.float32(c)) for c in rng.uniform(-1.0, 1.0, size=3))
+        o.set_parent_velocity(pv)
+        n.parent_velocity = np.asarray(pv, dtype=np.float32)
+        o.step(dt), n.step(dt)
+        assert o.counts() == [n.count(t) for t in range(n_types)], (case, i)
+        for t in range(n_types):
+            got, dead = o.particles(t), o.destroyed(t)
+            for f in ("position", "velocity", "rotation", "angular_velocity", "age", "lifetime", "initial_scale", "scale", "base_color", "emissive_color"):
+                assert np.array_equal(got[f], n.particles[t][f]), (case, i, t, f)
+            assert len(dead) == len(n.destroyed[t]["age"]), (case, i, t)
+            for f in ("position", "velocity", "age", "lifetime", "scale"):
+                assert np.array_equal(dead[f], n.destroyed[t][f]), (case, i, t, "destroyed", f)
+            hits += int(np.count_nonzero(dead["age"] < dead["lifetime"]))  # destroyed by a collision, not by age
+    test_oracle_and_numpy_restatement_agree_on_random_colliding_spawners.hits[case] = hits
+
+
+test_oracle_and_numpy_restatement_agree_on_random_colliding_spawners.hits = {}
+
+
+def test_the_colliding_cases_destroyed_particles_on_contact():
+    hits = test_oracle_and_numpy_restatement_agree_on_random_colliding_spawners.hits
+    if not hits:
+        pytest.skip("the colliding cases did not run in this session")
+    assert sum(hits.values()) > 50, hits
