@@ -44,7 +44,6 @@ def _as_records(p, like):
 
 
 def _check(o, n, what, young_age=None):
-    n_em = len(o.spawner.emission_settings) if hasattr(o, "spawner") else n.n_em
     for t in range(len(n.particles)):
         got = o.particles(t)
         want = _as_records(n.particles[t], got)
