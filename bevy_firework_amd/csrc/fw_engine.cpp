@@ -579,6 +579,8 @@ struct fw_ctx {
     // sends those rings to the compacting path (drop_few_rings: build time, the context is synchronised).  FW_RANGE_FEW; 0: off
     uint32_t range_few = 64;
     uint32_t n_few = 0;     // SegHost::few_ring segments
+    bool few_blocked = false;  // the context has outgrown the rule: no new small rings until it is back at half of range_few (a
+                               // context whose spawners come and go around the limit would convert rings at every crossing)
     uint32_t n_in_use = 0;  // SegHost::in_use segments
     // A range launch whose rings hold fewer than range_small_tiles four-round tiles in all (FW_RANGE_SMALL; not with a ring whose
     // count only the device knows), or with a colliding ring, runs on OLD / YOUNG tiles of ONE round (fw_k_update_range: TR): a
@@ -1492,7 +1494,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             // bullet cases, 110 puffs, 32 768 slots): in a context of few segments such a type stays with its small parent type on
             // range rings (one kind of launch per frame) unless its derived capacity is really large
             bool few_nested = false;  // ... a range ring only because of that: it leaves with the other small rings (drop_few_rings)
-            if (S.fifo && S.nested_fed && ctx->use_range && ctx->range_few != 0 && ctx->n_in_use <= ctx->range_few && ctx->n_fifo == 0 &&
+            if (S.fifo && S.nested_fed && ctx->use_range && ctx->range_few != 0 && !ctx->few_blocked && ctx->n_in_use <= ctx->range_few && ctx->n_fifo == 0 &&
                 caps[t] < 8u * ctx->fifo_min && caps[t] < ctx->range_min * 32u &&
                 S.n_lplanes <= 2 && T.life_lo_safe > 0.0f && caps[t] <= FW_RANGE_MAX_CAPACITY)  // (it does qualify for a range ring)
                 S.fifo = false, few_nested = true;
@@ -1519,7 +1521,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             S.range = ctx->use_range && !sp.no_rings && !S.fifo && !self_nested && !mixed_feed && S.n_lplanes <= 2 &&
                       (!S.collides || S.coll_inplace) && std::isfinite(p.lifetime.min) &&
                       std::isfinite(p.lifetime.max) && T.life_lo_safe > 0.0f &&
-                      (caps[t] >= ctx->range_min || (ctx->range_few != 0 && ctx->n_in_use <= ctx->range_few && ctx->n_fifo == 0)) &&
+                      (caps[t] >= ctx->range_min || (ctx->range_few != 0 && !ctx->few_blocked && ctx->n_in_use <= ctx->range_few && ctx->n_fifo == 0)) &&
                       caps[t] <= FW_RANGE_MAX_CAPACITY;
             if (S.range) {
                 if (caps[t] < ctx->range_min || few_nested) S.few_ring = true, ctx->n_few++;  // (fw_ctx::range_few)
@@ -1626,6 +1628,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
     if ((st = ensure_tile_arrays(ctx))) return st;
     // the context is no longer one of few segments without a FIFO ring: its small range rings continue on the compacting path
     // (fw_ctx::range_few; callers of build_spawner have synchronised the context)
+    if (ctx->n_in_use > ctx->range_few) ctx->few_blocked = true;
     if (ctx->n_few && (ctx->n_fifo != 0 || ctx->n_in_use > ctx->range_few)) return drop_few_rings(ctx);
     return FW_OK;
 }
@@ -1650,6 +1653,7 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
         if (S.range) ctx->n_range--, ctx->r_force = true;
         if (S.few_ring) ctx->n_few--;
         ctx->n_in_use--;
+        if (ctx->n_in_use <= ctx->range_few / 2) ctx->few_blocked = false;
         if (S.h_report) hipHostFree(S.h_report);
         if (S.buf[0]) FW_HIP(ctx, hipFree(S.buf[0]));
         if (S.destroyed) FW_HIP(ctx, hipFree(S.destroyed));

@@ -414,7 +414,7 @@ def test_few_small_types_run_on_range_rings_by_default(monkeypatch):
 def test_small_rings_leave_when_the_context_is_no_longer_one_of_few_segments(monkeypatch):
     """the spawner that takes the context past fw_ctx::range_few segments (here 5 instead of 64) sends every small range ring to
     the compacting path, particles and order kept; spawners created after that follow the usual thresholds; despawning does not
-    bring rings back by itself, a NEW small type in a context that is small again does get one"""
+    bring rings back by itself, a NEW small type gets one once the context is back at half the limit"""
     from bevy_firework_amd.system import ParticleSystem
 
     _defaults(monkeypatch, FW_ENABLE_KNOBS="1", FW_RANGE_FEW="5")
@@ -444,9 +444,14 @@ def test_small_rings_leave_when_the_context_is_no_longer_one_of_few_segments(mon
         for p in pairs[:3]:
             system.despawn(p.gpu)
         del pairs[:3]
-        pairs.append(small(730))  # four segments in use again
-        assert [p.gpu.update_path(0)[0] for p in pairs] == ["general", "general", "general", "range"]
-        run(50, "three compacting segments and a ring")
+        pairs.append(small(729))  # four segments in use: still past HALF the limit, where the rule comes back (no ping-pong at the limit)
+        assert [p.gpu.update_path(0)[0] for p in pairs] == ["general"] * 4
+        for p in pairs[:2]:
+            system.despawn(p.gpu)
+        del pairs[:2]
+        pairs.append(small(730))  # two were left: the context is one of few segments again
+        assert [p.gpu.update_path(0)[0] for p in pairs] == ["general", "general", "range"]
+        run(50, "two compacting segments and a ring")
         assert all(p.gpu.count(0) > 400 for p in pairs)
 
 
