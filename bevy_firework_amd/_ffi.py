@@ -258,10 +258,13 @@ SYMBOLS = [
     ("fw_debug_read_launches", C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
     ("fw_debug_read_range_timestamps", C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("fw_debug_update_path", C.c_int, [_P, C.c_int, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("fw_debug_nest_frames", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("fw_compute_emission_count", C.c_uint64,
      [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]),
 ]
 
+# measurement hooks (firework_hip_debug.h, not the ABI) added after round 4: absent from the older builds the A/B tools load
+NEWER_DEBUG_HOOKS = {"fw_debug_nest_frames"}
 _lib = None
 
 
@@ -277,6 +280,8 @@ def load() -> C.CDLL:
         )
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
+        if os.environ.get("FW_LIB_PATH") and name in NEWER_DEBUG_HOOKS and not hasattr(lib, name):
+            continue  # an OLDER build loaded for an A/B measurement (tools/): it may lack the newest measurement hooks
         fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
         fn.restype = res
         fn.argtypes = args

@@ -339,6 +339,7 @@ struct alignas(64) SegHost {
     };
     Ring<YCohort> ycoh;  // the young cohorts, oldest first
     bool few_ring = false;  // a range ring below fw_ctx::range_min: only because the context holds few segments (fw_ctx::range_few)
+    bool spilled = false;   // a range ring that qualifies for a FIFO ring: the context holds more such types than one FIFO launch (fw_ctx::n_spilled)
     uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
     uint32_t r_low[3] = {0, 0, 0};               // frames in a row a role's need has been far below what is provided
     uint32_t r_need[3] = {0, 0, 0};              // what each role needed in the latest frame (the table keeps more: fit())
@@ -560,6 +561,12 @@ struct fw_ctx {
     uint32_t fifo_small_tiles = 384;  // FIFO launches of a context with fewer four-round tiles than this use one-round tiles (FW_FIFO_SMALL)
     uint32_t fifo_min = 32768;
     uint32_t n_fifo = 0;       // FIFO segments in use (at most kMaxFifoSegs: their records travel in kernel arguments)
+    // A context with MORE one-lifetime types than one FIFO launch holds (round 5).  The ninth used to land on a range ring next to
+    // eight FIFO rings: two kinds of launch per frame, one after the other -- 9 emitters of 22 000 particles 20.7 us per frame
+    // where nine range rings take 13.2 (profiles/r04/few_small_emitters.txt).  Now the type that does not fit takes a range ring
+    // AND every FIFO ring of the context becomes one where it stands (fifo_to_range: no copy, particles and order kept; build time,
+    // the context is synchronised): one kind of launch again.  While such rings exist, further one-lifetime types join them.
+    uint32_t n_spilled = 0;    // SegHost::spilled segments
     std::vector<FwOp> fifo_ops;  // this frame's Global ops that feed FIFO segments (spawned inside fw_k_update_fifo)
     std::vector<std::pair<uint32_t, FwOp>> range_mat_ops;  // the same for range rings other particles' entries emit from
     std::vector<std::pair<uint32_t, FwOp>> fifo_mat_ops;  // {emission index, op}: rings of spawners with Nested entries -- the
@@ -626,6 +633,10 @@ struct fw_ctx {
     uint64_t r_uploads = 0;  // times the range table was re-sent (FW_HOST_PROF prints it)
 
     uint32_t nest_seq = 0;  // launches of fw_k_nest so far (tag of their look-back words)
+    // Nested entries whose two particle types live in FIFO rings of one launch run INSIDE that launch (fw_kernels.h: FwFifoNest):
+    // a steady configs[3] frame is ONE launch instead of fw_k_nest + a gap + the update.  FW_NEST_FUSE=0: always the separate pass
+    bool nest_fuse = true;
+    uint64_t fused_nest_frames = 0, nest_pass_frames = 0;  // frames of either kind so far (fw_debug_nest_frames)
     // FW_HOST_PROF=1: time spent in the sections of fw_step's host half (printed when the context is destroyed)
     bool trace = false;  // FW_TRACE
     bool host_prof = false;
@@ -1052,6 +1063,7 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
         s.range_mat = s.range_dev = false;
         ctx->n_range--;
         if (s.few_ring) s.few_ring = false, ctx->n_few--;
+        if (s.spilled) s.spilled = false, ctx->n_spilled--;
         ctx->tab_force = true, ctx->r_force = true;
         ctx->seg_kind_changed = true;
     }
@@ -1060,6 +1072,7 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
         if (old.fifo && !s.fifo) ctx->n_fifo++;
         if (old.range && !s.range) ctx->n_range++;
         if (old.few_ring && !s.few_ring) ctx->n_few++;
+        if (old.spilled && !s.spilled) ctx->n_spilled++;
         s = old;
         return st;
     }
@@ -1145,6 +1158,101 @@ fw_status drop_few_rings(fw_ctx *ctx) {
     for (uint32_t si = 0; si < ctx->segs.size() && ctx->n_few; si++) {
         if (!ctx->segs[si].in_use || !ctx->segs[si].few_ring) continue;
         const fw_status st = fifo_to_general(ctx, si);  // (realloc_segment clears the flag and the count)
+        if (st) return st;
+    }
+    return FW_OK;
+}
+
+// can this FIFO ring continue as a RANGE ring (build_spawner's rule for range rings, for a type that is a FIFO ring already)
+bool fifo_may_become_range(const fw_ctx *ctx, const SegHost &S) {
+    if (!S.in_use || !S.fifo || !ctx->use_range || S.spawner < 0) return false;
+    const SpawnerHost &sp = ctx->spawners[S.spawner];
+    return !sp.no_rings && S.n_lplanes <= 2 && sp.types[S.type].life_lo_safe > 0.0f && S.capacity <= FW_RANGE_MAX_CAPACITY &&
+           S.capacity % std::max<uint32_t>(FW_TILE, fw_range_young_tile()) == 0u && !(S.inst != nullptr && !S.inst_window);
+}
+
+// A FIFO ring becomes a RANGE ring where it stands (fw_ctx::n_spilled): the same buffer, the same slots, nothing copied.  A FIFO
+// ring is a range ring whose particles are all "young" -- nobody has been told yet that it may die -- with an empty old part: the
+// slot of the first young particle is the head, the young cohorts are the FIFO cohorts (frame of birth + size; sizes the device
+// alone knows stay in the pinned report ring), their ages -- one table for all range rings of the context, fw_ctx::birth_age -- are
+// the ages the FIFO replay kept per cohort: the same fp32 additions, bit for bit.  The next fw_step moves the cohorts that may
+// die in it to the old part as for any range ring.  The context is synchronised (build time).
+fw_status fifo_to_range(fw_ctx *ctx, uint32_t si) {
+    if (!fifo_may_become_range(ctx, ctx->segs[si])) return FW_OK;
+    fw_status st = refresh_counts_exact(ctx);  // (a ring that receives Nested children: only the device knows its count)
+    if (st) return st;
+    SegHost &S = ctx->segs[si];
+    const TypeHost &T = ctx->spawners[S.spawner].types[S.type];
+    ctx->fc_ok = false, ctx->boxes_epoch = 0;
+    // ---- the ages of the frames its cohorts were born in: fw_ctx::birth_age holds one entry per frame, contiguous up to the
+    // current frame; it is extended backwards to the oldest cohort.  Frames in which this ring received nothing get the age of
+    // the next older cohort (never asked for by it; at least as old as the true one, so the pruning order holds) -- and are
+    // overwritten with the exact value by whichever ring does hold a cohort of that frame.
+    if (!S.coh.empty()) {
+        auto &B = ctx->birth_age;
+        const uint64_t have_from = B.empty() ? ctx->frame : B.front().frame;
+        if (S.coh.front().frame < have_from) {
+            std::vector<fw_ctx::BirthAge> pre;
+            size_t ci = 0;
+            float age = S.coh.front().age;
+            for (uint64_t f = S.coh.front().frame; f < have_from; f++) {
+                while (ci < S.coh.size() && S.coh[ci].frame < f) ci++;
+                if (ci < S.coh.size() && S.coh[ci].frame == f) age = S.coh[ci].age;
+                pre.push_back(fw_ctx::BirthAge{f, age});
+            }
+            B.insert(B.begin(), pre.begin(), pre.end());
+        }
+        for (const SegHost::Cohort &c : S.coh)
+            if (!B.empty() && c.frame >= B.front().frame && c.frame - B.front().frame < B.size()) B[(size_t)(c.frame - B.front().frame)].age = c.age;
+    }
+    // ---- the ring's own bookkeeping
+    S.fifo = false, ctx->n_fifo--;
+    S.range = true, ctx->n_range++;
+    S.spilled = true, ctx->n_spilled++;
+    S.young_lo = S.head, S.head = 0;
+    S.range_life_lo = T.life_lo_safe;
+    ctx->range_life_max = std::max(ctx->range_life_max, S.range_life_lo);
+    S.range_mat = S.n_lplanes != 0, S.range_dev = S.nested_fed;
+    S.ycoh.clear(), S.dcoh.clear(), S.gcoh.clear(), S.gcoh_sum = 0, S.rold_seen = 0, S.r_young_main = 0;
+    S.r_old = S.r_new = S.r_young = 0;
+    S.win.clear(), S.win_sum = 0, S.win_ok = false;
+    if (S.range_dev) {
+        S.young_n = 0;
+        ctx->range_age_keep = std::max(ctx->range_age_keep, (float)(S.life_bound * 1.01 + 1e-3));
+        for (const SegHost::Cohort &c : S.coh) S.dcoh.push_back(SegHost::DCohort{c.frame, c.known ? c.n : 0u, c.known});
+        // (h_report stays: the update of a range ring that receives children leaves each frame's cohort size in the same ring)
+    } else {
+        uint64_t sum = 0;
+        for (const SegHost::Cohort &c : S.coh) {
+            if (!c.n) continue;
+            S.ycoh.push_back(SegHost::YCohort{c.frame, c.n});
+            // the lifetime window (the bound of the old part follows it): the time of the spawn from the cohort's age -- an fp32
+            // running sum, whose distance from the exact time the window's horizon allows for (fw_step)
+            S.win.push_back(SegHost::Spawned{ctx->sim_time - (double)c.age, c.n, c.frame});
+            sum += c.n;
+        }
+        S.young_n = (uint32_t)sum;  // (= the exact live count: everybody is young)
+        S.win_sum = sum, S.win_ok = std::isfinite(S.life_bound);
+        if (S.h_report) hipHostFree(S.h_report), S.h_report = nullptr;
+    }
+    S.coh.clear();
+    S.fifo_mat = S.fifo_dev = false;
+    // ---- the device's share: the old part is empty; a type that cannot turn keeps its lifetimes in a plane of their own on
+    // this path (a FIFO ring has one value and no plane)
+    const uint32_t zero = 0;
+    for (int r = 0; r < 2; r++) FW_HIP(ctx, hipMemcpy(ctx->g.rold + (size_t)r * ctx->max_seg + si, &zero, 4, hipMemcpyHostToDevice));
+    if (S.nospin) {
+        FW_HIP(ctx, fw_launch_fill_plane1(ctx->stream, S.buf[0], nullptr, FW_OFF_L((size_t)S.capacity, S.n_lplanes), S.capacity, S.fifo_life));
+        FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->tab_force = true, ctx->r_force = true;
+    return ensure_range_arrays(ctx);
+}
+
+// every FIFO ring of the context that may becomes a range ring (fw_ctx::n_spilled)
+fw_status spill_fifo_rings(fw_ctx *ctx) {
+    for (uint32_t si = 0; si < ctx->segs.size() && ctx->n_fifo; si++) {
+        const fw_status st = fifo_to_range(ctx, si);
         if (st) return st;
     }
     return FW_OK;
@@ -1486,9 +1594,13 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             // tables from memory)
             S.fifo = ctx->use_fifo && !sp.no_rings && !self_nested && !mixed_feed && (!S.collides || S.coll_inplace) && p.lifetime.min == p.lifetime.max &&
                      n_global_feed <= FW_INLINE_OPS &&
-                     std::isfinite(p.lifetime.min) && ctx->n_fifo < kMaxFifoSegs &&
+                     std::isfinite(p.lifetime.min) &&
                      caps[t] >= ctx->fifo_min && caps[t] < 0x40000000u &&  // (head + index stays far from 2^32)
                      (!any_nested || ctx->fifo_nested);
+            // more such types than one FIFO launch holds (fw_ctx::n_spilled): this one takes a range ring -- if it qualifies for
+            // one: the rule below -- and the FIFO rings of the context follow it at the end of the build
+            const bool spill = S.fifo && (ctx->n_spilled != 0 || ctx->n_fifo >= kMaxFifoSegs);
+            if (spill) S.fifo = false;
             // (fw_ctx::range_few) the capacity of a type that receives Nested children is derived from its parents' CAPACITY -- the
             // host cannot bound their number -- and passes fifo_min for a handful of parents already (examples/textures.rs: 55
             // bullet cases, 110 puffs, 32 768 slots): in a context of few segments such a type stays with its small parent type on
@@ -1525,6 +1637,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
                       caps[t] <= FW_RANGE_MAX_CAPACITY;
             if (S.range) {
                 if (caps[t] < ctx->range_min || few_nested) S.few_ring = true, ctx->n_few++;  // (fw_ctx::range_few)
+                if (spill) S.spilled = true, ctx->n_spilled++;
                 ctx->n_range++;
                 S.range_life_lo = T.life_lo_safe;
                 ctx->range_life_max = std::max(ctx->range_life_max, S.range_life_lo);
@@ -1628,8 +1741,14 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
     if ((st = ensure_tile_arrays(ctx))) return st;
     // the context is no longer one of few segments without a FIFO ring: its small range rings continue on the compacting path
     // (fw_ctx::range_few; callers of build_spawner have synchronised the context)
+    if (ctx->n_spilled && ctx->n_fifo && (st = spill_fifo_rings(ctx))) return st;  // (fw_ctx::n_spilled)
     if (ctx->n_in_use > ctx->range_few) ctx->few_blocked = true;
-    if (ctx->n_few && (ctx->n_fifo != 0 || ctx->n_in_use > ctx->range_few)) return drop_few_rings(ctx);
+    if (ctx->n_few && (ctx->n_fifo != 0 || ctx->n_in_use > ctx->range_few)) {
+        // (the hysteresis covers the arrival of a FIFO ring as well: a context in which one comes and goes would otherwise
+        // convert its small rings at every arrival -- ADVICE r04)
+        ctx->few_blocked = true;
+        return drop_few_rings(ctx);
+    }
     return FW_OK;
 }
 
@@ -1652,6 +1771,7 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
         if (S.fifo) ctx->n_fifo--;
         if (S.range) ctx->n_range--, ctx->r_force = true;
         if (S.few_ring) ctx->n_few--;
+        if (S.spilled) ctx->n_spilled--;
         ctx->n_in_use--;
         if (ctx->n_in_use <= ctx->range_few / 2) ctx->few_blocked = false;
         if (S.h_report) hipHostFree(S.h_report);
@@ -1978,6 +2098,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_RANGE_FEW")) ctx->range_few = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_RANGE_SMALL")) ctx->range_small_tiles = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_NOSPIN")) ctx->use_nospin = atoi(m) != 0;
+    if (const char *m = getenv("FW_NEST_FUSE")) ctx->nest_fuse = atoi(m) != 0;
     if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_NT_WO_MB")) ctx->nt_wo_bytes = ctx->nt_wo_bytes_range = (uint64_t)atoll(m) << 20;
 #ifdef FW_AB
@@ -2363,7 +2484,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     bool any_coll = false, any_inst_general = false;
     struct {
         uint64_t fifo_parts = 0, range_parts = 0;
-        bool fifo_dev = false, fifo_coll = false, range_dev = false, range_coll = false;
+        bool fifo_dev = false, fifo_coll = false, fifo_inst = false, range_dev = false, range_coll = false;
     } ring_stats;
     ctx->grow_scratch.clear();
     for (size_t si = 0, ns = ctx->segs.size(); si < ns; si++) {
@@ -2377,7 +2498,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         S.dead_at_end = false;  // (set again below for the segments this frame updates as range rings)
         any_coll |= S.collides && !S.ring();  // (a colliding type in a ring is updated by its ring kernel)
         // (what decides the tile size of the ring launches -- fifo_small / range_small below -- gathered while the record is hot)
-        if (S.fifo) ring_stats.fifo_parts += S.ub, ring_stats.fifo_dev |= S.fifo_dev, ring_stats.fifo_coll |= S.collides;
+        if (S.fifo) ring_stats.fifo_parts += S.ub, ring_stats.fifo_dev |= S.fifo_dev, ring_stats.fifo_coll |= S.collides, ring_stats.fifo_inst |= S.inst != nullptr;
         if (S.range) ring_stats.range_parts += S.ub, ring_stats.range_dev |= S.range_dev, ring_stats.range_coll |= S.collides;
         any_inst_general |= !S.ring() && S.inst != nullptr;
         if (S.nested_fed && nested_fed_wants_growth(S)) ctx->grow_scratch.push_back((uint32_t)si);
@@ -2636,6 +2757,42 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             for (FwOp &op : L.g)
                 if (op.range_ring && !ctx->segs[op.seg].range) op.range_ring = 0u, op.head = 0u;
     }
+    // ---- Nested entries run INSIDE the FIFO launch (fw_kernels.h: FwFifoNest; core.rs:471-546).  Every Nested entry of the frame
+    // must qualify -- parents in a FIFO ring the host knows the count of (Global-fed), spawned inside the update kernel
+    // (virt_parent), no other entry emitting from them; children received by a FIFO ring nothing else feeds and nothing emits from;
+    // both in the one FIFO launch of the context, parents first; no instance buffers, no colliders -- and no ring may wait for
+    // fw_k_spawn (the ops left at the levels then belong to compacting segments, which no Nested entry of the frame touches: the
+    // general launch spawns them itself).  Otherwise the frame runs the separate passes (fw_k_spawn / fw_k_nest), as before.
+    FwNestOp fuse_plan[FW_FIFO_NEST_MAX];
+    uint32_t n_fuse = 0;
+    bool fuse = false;
+    if (nested_frame && ctx->nest_fuse && !any_coll && !ctx->seg_kind_changed && ctx->update_mode == FW_MODE_FUSED && ctx->n_fifo != 0 &&
+        ctx->n_fifo <= FW_FIFO_PER_LAUNCH && ctx->fifo_ops.size() <= FW_INLINE_OPS && !ring_stats.fifo_coll && !ring_stats.fifo_inst &&
+        dt >= 0.0f && std::isfinite(dt)) {
+        fuse = true;
+        for (auto &L : levels) {
+            for (const FwOp &op : L.g) fuse &= !ctx->segs[op.seg].ring();
+            for (const FwNestOp &op : L.n) {
+                if (!fuse || n_fuse == FW_FIFO_NEST_MAX) {
+                    fuse = false;
+                    break;
+                }
+                const SegHost &P = ctx->segs[op.parent_seg], &Cs = ctx->segs[op.child_seg];
+                const uint32_t p_in = P.ub - std::min(P.ub, P.frame_spawn);  // (a Global-fed FIFO ring: `ub` is exact)
+                fuse = P.fifo && !P.fifo_dev && P.virt_parent && P.n_lplanes == 1 && Cs.fifo && Cs.fifo_dev && Cs.n_lplanes == 0 &&
+                       op.parent_seg < op.child_seg && Cs.capacity <= FW_RANGE_MAX_CAPACITY &&
+                       // the ring must not wrap into its head tile: the tiles' ranks are then the list order
+                       (uint64_t)(P.head % FW_TILE) + p_in <= P.capacity;
+                for (uint32_t k = 0; k < n_fuse; k++)
+                    fuse &= fuse_plan[k].parent_seg != op.parent_seg && fuse_plan[k].parent_seg != op.child_seg &&
+                            fuse_plan[k].child_seg != op.parent_seg && fuse_plan[k].child_seg != op.child_seg;
+                if (fuse) fuse_plan[n_fuse++] = op;
+            }
+            if (!fuse) break;
+        }
+        fuse = fuse && n_fuse != 0;
+    }
+    if (nested_frame) (fuse ? ctx->fused_nest_frames : ctx->nest_pass_frames)++;
     // ---- segment -> tile table (device resident, re-uploaded only when a bound moves out of its band)
     prof(1);
     const uint32_t n_seg = (uint32_t)ctx->segs.size();
@@ -2658,7 +2815,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     if (ctx->seg_kind_changed)  // (a colliding ring that left its mode inside the spawner loop is a compacting segment from this frame on)
         for (const SegHost &S : ctx->segs) any_coll |= S.in_use && S.collides && !S.ring();
     const int frame_mode = any_coll ? FW_MODE_SPLIT_COLL : ctx->update_mode;
-    const bool legacy = n_n != 0 || frame_mode != FW_MODE_FUSED;
+    const bool legacy = (n_n != 0 && !fuse) || frame_mode != FW_MODE_FUSED;  // (fuse: the Nested entries run inside the FIFO launch)
 
     FwUpdateArgs a{};
     a.seg_tile_first = ctx->d_tile_first;
@@ -2945,6 +3102,11 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         fifo_coll = fifo_coll_real || fifo_small;  // (the same tile grid; which instantiation runs: FwFifoArgs::any_coll / small_tiles)
         uint32_t f_ops = 0, f_tiles = 0;
         uint64_t f_bytes = 0;  // what the launch streams, roughly: its tiles x the bytes a particle of the type moves
+        uint32_t nest_status_next = 0;  // look-back words handed to the Nested entries of this launch so far (FwFifoNest::status_first)
+        if (fuse) {
+            ctx->nest_seq = (ctx->nest_seq + 1u) & 0x3FFFFFFFu;
+            if (!ctx->nest_seq) ctx->nest_seq = 1u;
+        }
         auto flush = [&]() -> hipError_t {
             if (!fa.n_segs) return hipSuccess;
             fa.parity = p, fa.epoch = a.epoch, fa.dbg = ctx->dbg, fa.dt = dt;
@@ -3023,7 +3185,14 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             // when their records are wanted, the first survivor otherwise) to the last old particle (a type whose count
             // only the device knows: the whole ring, empty tiles leave at once); at least one in all (it publishes the counts)
             const uint32_t n_old = S.fifo_dev ? S.capacity : n_in;
-            const uint32_t lo = std::min(S.destroyed ? 0u : dead, n_old), cnt = n_old - lo;
+            // (... or a ring whose particles a Nested entry of this launch emits from: the ones about to die still emit, and the
+            // tiles' ranks count from the ring's head)
+            int nest_parent = -1, nest_child = -1;
+            for (uint32_t k = 0; fuse && k < n_fuse; k++) {
+                if (fuse_plan[k].parent_seg == si) nest_parent = (int)k;
+                if (fuse_plan[k].child_seg == si) nest_child = (int)k;
+            }
+            const uint32_t lo = std::min((S.destroyed || nest_parent >= 0) ? 0u : dead, n_old), cnt = n_old - lo;
             const uint32_t ftile = fifo_coll ? FW_FIFO_COLL_TILE : FW_TILE;
             const uint32_t ps = (uint32_t)(((uint64_t)S.head + lo) % S.capacity), ring_tiles = S.capacity / ftile;
             const uint32_t ns0 = (uint32_t)(((uint64_t)S.head + (S.fifo_dev ? 0u : n_in)) % S.capacity);  // slot of the first new particle
@@ -3034,6 +3203,23 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             F.n_tiles = std::max(1u, F.n_vt_a + F.n_vt_b + live_tiles);
             F.tile_first = f_tiles;
             f_tiles += F.n_tiles;
+            F.nest = 0u;
+            if (nest_parent >= 0) {
+                const FwNestOp &op = fuse_plan[nest_parent];
+                FwFifoNest &N = fa.nest[nest_parent];
+                F.nest = (uint32_t)nest_parent + 1u;
+                N.parent = fa.n_segs - 1u;
+                N.emit = op.emit, N.emit_slot = op.emit_slot, N.parent_lplane = op.parent_lplane;
+                N.n_count = op.n_count, N.n_start = op.n_start, N.n_end = op.n_end, N.speed = op.speed, N.scale = op.scale;
+                N.status_first = nest_status_next, N.n_ptiles = F.n_tiles - (F.n_vt_a + F.n_vt_b);
+                nest_status_next += N.n_ptiles;
+                N.tag = ctx->nest_seq, N.spin_limit = ctx->spin_limit;
+                fa.n_nest = n_fuse;
+            }
+            if (nest_child >= 0) {
+                F.nest = ((uint32_t)nest_child + 1u) | FW_FIFO_NEST_CHILD;
+                fa.nest[nest_child].child = fa.n_segs - 1u;
+            }
             f_bytes += (uint64_t)live_tiles * ftile * (S.nospin ? 104u : 164u);
             fa.any_inst |= S.inst != nullptr ? 1u : 0u;
             fa.any_coll |= fifo_coll_real ? 1u : 0u;
@@ -3892,6 +4078,14 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t
     if (S.inst != nullptr) moved += 64u, algo += 64u;
     if (moved_bytes) *moved_bytes = moved;
     if (algorithmic_bytes) *algorithmic_bytes = algo;
+    return FW_OK;
+}
+// frames with Nested entries so far: those whose entries ran inside the FIFO launch (FwFifoNest) / those that ran the separate
+// fw_k_spawn / fw_k_nest passes
+fw_status fw_debug_nest_frames(fw_ctx *ctx, uint64_t *fused, uint64_t *separate) {
+    if (!ctx) return FW_EINVAL;
+    if (fused) *fused = ctx->fused_nest_frames;
+    if (separate) *separate = ctx->nest_pass_frames;
     return FW_OK;
 }
 fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_t max_tiles, uint64_t *n_tiles) {

@@ -64,6 +64,156 @@ __device__ __forceinline__ void fw_coll_step(const FwGlobals &g, const FwCollArm
     }
 }
 
+// ---- Nested emission inside the FIFO launch (fw_kernels.h: FwFifoNest; core.rs:471-546) -------------------------------------
+// Called by a ring tile of the PARENTS' ring (rank = its distance from the ring's head tile = list order) before it updates its
+// slots: what fw_k_nest does for a tile of parents -- per-parent compute_emission_count (device fp32, bit-exact), the advanced
+// last_emitted_age stored (core.rs:490-500), the tile's child total published, its exclusive prefix from a decoupled look-back
+// over the tiles of lower rank (lower workgroup indices), children written wave-cooperatively in parent-major order
+// (core.rs:488-544) -- except that a child is not parked in memory for a later update: it gets its first update here (the frame's
+// update_particles, core.rs:577-659, would visit it next) and is stored once, in the slot it will live in.  Parents the update
+// is about to destroy still emit (spawn_particles runs first, plugin.rs:46-60).  Nothing is committed here: the child ring's
+// bookkeeping workgroup reads the entry's total from the status words (fw_k_update_fifo, end).
+template <int R, int NT>
+__device__ __forceinline__ void fw_fifo_nest_parents(const FwGlobals &g, const FwFifoArgs &a, const FwFifoNest &N, const FwFifoSeg &F,
+                                                     const FwFifoSeg &Fc, uint32_t rank, uint32_t sbase, uint32_t n_in) {
+    constexpr int BLK = FW_BLOCK, NW = BLK / 64, LBW = 4;
+    __shared__ uint32_t s_w[R][NW];
+    __shared__ uint32_t s_lb[2 * LBW * NW];
+    __shared__ uint32_t s_inc[NW][64];
+    __shared__ __attribute__((aligned(16))) float4 s_par[NW][3][64];
+    __shared__ __attribute__((aligned(16))) float s_ckeys[FW_KEYS_MAX];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t C = F.capacity, head = F.head, Cc = Fc.capacity;
+    char *pb = F.buf;
+    // (window addressing as everywhere in this kernel: the tile's first slot on the scalar unit, 32-bit offsets per lane)
+    const char *w0 = pb + FW_OFF_Q0(C) + (size_t)sbase * 16u, *w1 = pb + FW_OFF_Q1(C) + (size_t)sbase * 16u;
+    const char *w2 = pb + FW_OFF_Q2(C) + (size_t)sbase * 16u;
+    char *wl = pb + FW_OFF_L(C, N.parent_lplane) + (size_t)sbase * 4u;
+    const bool pnospin = (F.type_idx & FW_TYPE_IDX_NOSPIN) != 0u;
+    float p_age[R], p_lea[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t o = (uint32_t)(r * BLK) + tid;
+        p_age[r] = fw_ld1w(w0, o * 16u + 12u);
+        p_lea[r] = fw_ld1w(wl, o * 4u);
+    }
+    const uint32_t cidx = a.parity * g.max_seg + Fc.seg;
+    const uint32_t cbase = g.count[cidx] + g.spawned[cidx] + g.appended[cidx];  // first child slot of the entry (list index)
+    const unsigned long long serial0 = g.emit_serial[N.emit_slot];
+    const FwEmit &e = g.emits[N.emit];
+    const FwType Tc = g.types[Fc.type_idx & ~FW_TYPE_IDX_NOSPIN];
+    for (uint32_t i = tid; i < Fc.keys_len; i += BLK) s_ckeys[i] = g.keys[Fc.keys_off + i];
+    uint32_t n[R], inc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t o = (uint32_t)(r * BLK) + tid, s = sbase + o;
+        uint32_t i = s - head;  // list index of the slot
+        if (s < head) i += C;
+        n[r] = 0;
+        if (i < n_in) {
+            float next;
+            const uint64_t cnt = fw_emission_count(p_age[r], p_lea[r], F.life, N.n_start, N.n_end, N.n_count, &next);
+            n[r] = cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cnt;  // core.rs:490-498
+            fw_st1w(wl, o * 4u, next);                                 // other_particle.last_emitted_age[i] = next (core.rs:500)
+        }
+        uint32_t x = n[r];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u = __shfl_up(x, d, 64);
+            if (lane >= (uint32_t)d) x = (x + u < x) ? 0xFFFFFFFFu : x + u;  // saturating
+        }
+        inc[r] = x;
+        if (lane == 63) s_w[r][wave] = x;
+    }
+    __syncthreads();
+    unsigned long long tot64 = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int w = 0; w < NW; w++) tot64 += s_w[r][w];
+    uint32_t tile_total = tot64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot64;
+    // The child ring's bookkeeping workgroup books the entry's RNG serial once its look-back has seen the status word of every
+    // parent tile: a tile must have READ the serial (and the child base) before it publishes.  A data dependency, as in fw_k_nest.
+    {
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(cbase), d1 = __builtin_amdgcn_readfirstlane((uint32_t)serial0),
+                       d2 = __builtin_amdgcn_readfirstlane((uint32_t)(serial0 >> 32));
+        asm volatile("; fw_fifo_nest_parents: counters read before the tile publishes" : "+v"(tile_total) : "s"(d0), "s"(d1), "s"(d2));
+    }
+    const uint32_t tile = N.status_first + rank;
+    const bool lb_needed = rank != 0u;
+    if (lb_needed && tid == 0) __hip_atomic_store(&g.nest_status[tile], fw_pack_status(N.tag, FW_ST_AGG, tile_total), RLX, AGENT);
+    uint32_t excl = 0;
+    if (lb_needed) {
+        bool timed_out = false;
+        excl = fw_lookback<BLK, NW, LBW>(g.nest_status, N.status_first, tile, N.tag, N.spin_limit * 64u + 1024u, s_lb, &timed_out);
+        // (no recount is possible: the tiles of lower rank have already advanced their parents' last_emitted_age.  They have lower
+        // workgroup indices, so they are resident or done: the wait is bounded.)
+        if (timed_out && tid == 0) fw_raise(g, 6u, F.seg, tile);
+    }
+    const unsigned long long incl64 = (unsigned long long)excl + tile_total;
+    if (tid == 0)
+        __hip_atomic_store(&g.nest_status[tile], fw_pack_status(N.tag, FW_ST_INCL, incl64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)incl64), RLX, AGENT);
+    if (tile_total == 0u) return;  // (workgroup-uniform: most tiles of a ring hold parents past their emission window)
+    // ---- children, wave-cooperatively (parent-major order), spawned and given their first update
+    const FwOutWin Wc = fw_out_window(Fc.buf, Cc, 0u, Tc, 0u);  // (child capacity <= FW_RANGE_MAX_CAPACITY: 32-bit byte offsets, the host checks)
+    float4 prot = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    if (pnospin) {
+        const FwType &Tp = g.types[F.type_idx & ~FW_TYPE_IDX_NOSPIN];
+        prot = make_float4(Tp.const_rot[0], Tp.const_rot[1], Tp.const_rot[2], Tp.const_rot[3]);
+    }
+    uint32_t run = excl;  // children of the entry before (round r, wave 0)
+#pragma unroll 1
+    for (int r = 0; r < R; r++) {
+        uint32_t woff = run;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            if ((uint32_t)w < wave) woff += s_w[r][w];
+            run += s_w[r][w];
+        }
+        const uint32_t tw = s_w[r][wave];  // wave-uniform
+        if (tw == 0) continue;
+        // (R is a compile-time constant but the loop is rolled: n / inc are indexed through a select chain, no scratch)
+        uint32_t nr = n[0], incr = inc[0];
+#pragma unroll
+        for (int q = 1; q < R; q++)
+            if (q == r) nr = n[q], incr = inc[q];
+        s_inc[wave][lane] = incr;
+        if (nr != 0) {
+            const uint32_t o16 = ((uint32_t)(r * BLK) + tid) * 16u;
+            s_par[wave][0][lane] = fw_ld4w(w0, o16);
+            s_par[wave][1][lane] = fw_ld4w(w1, o16);
+            s_par[wave][2][lane] = pnospin ? prot : fw_ld4w(w2, o16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t c0 = 0; c0 < tw; c0 += 64u) {
+            const uint32_t c = c0 + lane;
+            if (c < tw) {
+                uint32_t lo = 0, hi = 63;  // first lane whose inclusive prefix exceeds c
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_inc[wave][mid] > c) hi = mid;
+                    else lo = mid + 1;
+                }
+                const unsigned long long j = (unsigned long long)woff + c;  // child index within the entry
+                const unsigned long long slotl = (unsigned long long)cbase + j;
+                if (slotl < Cc) {  // (what does not fit is dropped; the child ring's bookkeeping reports FW_ERR_CAPACITY)
+                    const float4 pq0 = s_par[wave][0][lo], pq1 = s_par[wave][1][lo], pq2 = s_par[wave][2][lo];
+                    const FwSpawnOut so = fw_spawn_one(e, g.seed, serial0 + j, fw_v3{pq0.x, pq0.y, pq0.z}, fw_q4{pq2.x, pq2.y, pq2.z, pq2.w},
+                                                       fw_v3{pq1.x, pq1.y, pq1.z}, N.speed, N.scale);
+                    float age_new;
+                    fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);  // (the host keeps a step as long as the child lifetime off this path)
+                    fw_integrate_store<true, -1, NT>(Tc, s_ckeys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, Wc,
+                                                     fw_ring_slot(Fc.head, (uint32_t)slotl, Cc), nullptr, nullptr, nullptr, nullptr, false, true, false);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the wave's LDS rows are reused by the next round
+    }
+}
+
 // WM: the optional planes this launch's particle types write (fw_integrate_store), or -1 = read from the type
 #ifndef FW_FIFO_UNROLL
 #define FW_FIFO_UNROLL 4
@@ -72,8 +222,9 @@ __device__ __forceinline__ void fw_coll_step(const FwGlobals &g, const FwCollArm
 // tile): a colliding particle is a few hundred dependent instructions of ray casts per sub-step, the launch is bound by how
 // many waves work at once, not by memory -- the reference's own stress_test_collision (157k particles) is 154 workgroups of
 // four rounds, fewer than the chip has CUs, or 615 of one.
-template <bool INST, int WM, int NT = 0, bool COLL = false, int TR = FW_ROUNDS>
-__global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifoArgs a, FwInlineOps inl) {
+// NEST: some Nested entry runs inside this launch (FwFifoArgs::nest): the parents' ring tiles run fw_fifo_nest_parents first
+template <bool INST, int WM, int NT, bool COLL, int TR, bool NEST>
+__device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const FwFifoArgs &a, const FwInlineOps &inl) {
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
     constexpr int R = TR;  // (smaller ring tiles were measured for the streaming case: 2 rounds 26.7 us, 1 round 26.2 us, 4 rounds 24.6 us)
@@ -125,6 +276,14 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
     const float4 q3s = make_float4(0.0f, 0.0f, 0.0f, F.life);
     const bool defer = F.mat != 0u && F.n_in == 0xFFFFFFFFu;
     const uint32_t i1 = (uint32_t)(min(1, R - 1) * BLK + (int)tid) * 16u;
+    if constexpr (NEST) {
+        // a tile of a ring whose particles a Nested entry emits from: the entry's pass over the tile's own slots, before anything
+        // of them is loaded for the update (workgroup-uniform branch)
+        if (!spawner && F.nest != 0u && !(F.nest & FW_FIFO_NEST_CHILD)) {
+            const FwFifoNest &N = a.nest[F.nest - 1u];
+            fw_fifo_nest_parents<R, NT>(g, a, N, F, a.s[N.child], tis - n_vt, sbase, n_in);
+        }
+    }
     if (!spawner && !defer) {
         q0c = fw_ld4w<NT == 2>(iw0, tid * 16u), q3c = fw_ld4w<NT == 2>(iw3, (tid * 16u) & m2);
         q1c = fw_ld4w<NT == 2>(iw1, tid * 16u), q2c = fw_ld4w<NT == 2>(iw2, (tid * 16u) & m2);
@@ -263,20 +422,57 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
         }
     }
     if (__any(bad) && lane == 0) fw_raise(g, 4u, F.seg, blockIdx.x);
+    // a ring that RECEIVES the children of a Nested entry run inside this launch: the entry's total = the inclusive prefix of the
+    // parents' last tile, read from the same status words (every parent tile has a lower workgroup index: resident or done)
+    uint32_t nest_total = 0u;
+    if constexpr (NEST) {
+        if (tis == 0u && (F.nest & FW_FIFO_NEST_CHILD) != 0u) {  // (workgroup-uniform)
+            __shared__ uint32_t s_lbc[2 * 4 * NW];
+            const FwFifoNest &N = a.nest[(F.nest & ~FW_FIFO_NEST_CHILD) - 1u];
+            bool timed_out = false;
+            if (N.n_ptiles)
+                nest_total = fw_lookback<BLK, NW, 4>(g.nest_status, N.status_first, N.status_first + N.n_ptiles, N.tag,
+                                                     N.spin_limit * 64u + 1024u, s_lbc, &timed_out);
+            if (timed_out && tid == 0) fw_raise(g, 6u, F.seg, N.status_first + N.n_ptiles);
+        }
+    }
     if (tis == 0 && tid == 0) {
         const uint32_t oidx = (a.parity ^ 1u) * g.max_seg + F.seg;
         if (F.mat ? (F.n_in != 0xFFFFFFFFu && F.n_in != n_in) : g.count[sidx] != n_in)
             fw_raise(g, 5u, F.seg, n_in);
-        if (F.report) *F.report = ((unsigned long long)a.epoch << 32) | c_new;
-        const uint32_t nc = n_tot - min(n_dead, n_tot);
+        uint32_t n_all = n_tot, added = c_new;
+        if constexpr (NEST) {
+            if ((F.nest & FW_FIFO_NEST_CHILD) != 0u) {
+                const FwFifoNest &N = a.nest[(F.nest & ~FW_FIFO_NEST_CHILD) - 1u];
+                const uint32_t room = C - min(C, n_tot);  // (the parents' tiles dropped the children beyond it)
+                if (nest_total > room) fw_flag(g, FW_ERR_CAPACITY);
+                const uint32_t take = min(nest_total, room);
+                g.emit_serial[N.emit_slot] += (unsigned long long)nest_total;  // (every parent tile read it before it published)
+                n_all += take, added += take;
+            }
+        }
+        if (F.report) *F.report = ((unsigned long long)a.epoch << 32) | added;
+        const uint32_t nc = n_all - min(n_dead, n_all);
         g.count[oidx] = nc;
         g.spawned[oidx] = 0;
         g.appended[oidx] = 0;
-        g.ndestroyed[F.seg] = n_tot - nc;
+        g.ndestroyed[F.seg] = n_all - nc;
         if (a.host_counts) a.host_counts[F.seg] = ((unsigned long long)a.epoch << 32) | nc;
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);
+        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)n_all);
     }
+}
+
+template <bool INST, int WM, int NT = 0, bool COLL = false, int TR = FW_ROUNDS>
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifoArgs a, FwInlineOps inl) {
+    fw_update_fifo_body<INST, WM, NT, COLL, TR, false>(g, a, inl);
+}
+// ... with Nested entries inside the launch (FwFifoNest).  A kernel of its own so that the plain instantiations keep their code
+// and their register budget; pinned at 4 waves per SIMD (the nest phase took the four-round form to 133 VGPRs: the bulk of such
+// a launch is the child ring's streaming tiles, which want the fourth workgroup per CU)
+template <int NT, int TR>
+__global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void fw_k_update_fifo_nest(FwGlobals g, FwFifoArgs a, FwInlineOps inl) {
+    fw_update_fifo_body<false, -1, NT, false, TR, true>(g, a, inl);
 }
 
 
@@ -755,6 +951,17 @@ hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifo
                                  uint32_t total_tiles, int nt, hipEvent_t e0, hipEvent_t e1) {
     if (!total_tiles || !a.n_segs) return hipErrorInvalidValue;
     const dim3 grid(total_tiles), block(FW_BLOCK);
+    if (a.n_nest) {  // Nested entries inside the launch (FwFifoNest): generic write mask; the host keeps instance buffers and colliders out
+        // (... and such a launch holds a ring whose count only the device knows: never laid out on one-round tiles)
+        if (a.any_inst || a.any_coll || a.small_tiles) return hipErrorInvalidValue;
+        if (nt == 2)
+            FW_LAUNCH_T((fw_k_update_fifo_nest<2, FW_ROUNDS>), grid, block, s, e0, e1, g, a, inl);
+        else if (nt == 1)
+            FW_LAUNCH_T((fw_k_update_fifo_nest<1, FW_ROUNDS>), grid, block, s, e0, e1, g, a, inl);
+        else
+            FW_LAUNCH_T((fw_k_update_fifo_nest<0, FW_ROUNDS>), grid, block, s, e0, e1, g, a, inl);
+        return hipGetLastError();
+    }
     if (a.any_coll) {  // some ring of the launch collides (FwCollArm): generic write mask, plain or fully non-temporal
         // (one round per workgroup -- ring tiles of FW_FIFO_COLL_TILE slots: the host laid the launch out on that grid)
         if (a.any_inst && nt == 2)

@@ -151,9 +151,36 @@ struct FwFifoSeg {
     // how the host learns the size of each cohort of children, long before it needs it (when the cohort dies)
     uint32_t mat;
     uint32_t n_lplanes;  // FwSeg::n_lplanes (new particles spawned here initialise those planes: fw_init_last_emitted)
+    // a Nested entry run INSIDE this launch (FwFifoNest, round 5): 0 = none; otherwise 1 + its index in FwFifoArgs::nest, with
+    // FW_FIFO_NEST_CHILD set in the record of the ring that RECEIVES the children (the other one is the parents' ring)
+    uint32_t nest;
     unsigned long long *report;
 };
 #define FW_FIFO_PER_LAUNCH 8
+// Nested emission (core.rs:471-546) inside the FIFO launch (round 5; the frame of configs[3] used to be fw_k_nest -- 13.6 us of
+// one dependent chain on 192 workgroups moving 4 % of the frame's bytes -- a launch gap, then the update).  When both rings of a
+// Nested entry are FIFO rings of the same launch -- parents fed by Global entries only (the host knows their count), spawned
+// inside the update kernel (SegHost::virt_parent); children received by a ring nothing else feeds -- the parents' ring tiles do
+// the entry's per-parent pass for their own slots BEFORE they update them (no workgroup reads what another one overwrites):
+// compute_emission_count per parent, the advanced last_emitted_age stored, the tile's child total published and its exclusive
+// prefix taken from a decoupled look-back over the tiles of lower rank (rank = distance from the ring's head tile = list order,
+// core.rs:488-544 keeps children parent-major), children spawned wave-cooperatively and given their FIRST UPDATE right there,
+// stored once, in the slot they will live in (behind the child ring's live particles).  The child ring's own tiles never see
+// them; its bookkeeping workgroup takes the entry's total from the same status words (one more look-back, over all the parent
+// tiles -- they have lower workgroup indices) and books count, RNG serial and the cohort report.
+struct FwFifoNest {
+    uint32_t parent, child;      // indices into FwFifoArgs::s (parent < child: the parents' workgroups come first)
+    uint32_t emit, emit_slot;    // -> FwEmit, -> FwGlobals::emit_serial
+    uint32_t status_first;       // first look-back word of the entry in FwGlobals::nest_status (tile of rank r: status_first + r)
+    uint32_t n_ptiles;           // ring tiles of the parents' ring that take part (ranks 0 .. n_ptiles - 1)
+    uint32_t parent_lplane;      // which last_emitted_age plane of the parent type belongs to the entry
+    uint32_t tag;                // tag of the look-back words of this launch (fw_ctx::nest_seq)
+    float n_count, n_start, n_end;  // CountOverDuration of the entry (core.rs:474-481)
+    float speed, scale;          // EffectModifier
+    uint32_t spin_limit;
+};
+#define FW_FIFO_NEST_MAX 4
+#define FW_FIFO_NEST_CHILD 0x80000000u
 #define FW_LDS_OPS 4u  // ops of one segment fw_k_update_stream parks in LDS (table form: pinned host memory otherwise)
 #define FW_FIFO_COLL_TILE FW_BLOCK  // ring tile of a FIFO launch with colliding types: one round per workgroup (fw_k_update_fifo: TR)
 struct FwFifoArgs {
@@ -172,6 +199,8 @@ struct FwFifoArgs {
     unsigned long long done_value;
     unsigned long long *host_counts;
     unsigned long long *live_out, *live_next;
+    uint32_t n_nest, pad_nest;         // Nested entries run inside this launch (the NEST instantiations of fw_k_update_fifo)
+    FwFifoNest nest[FW_FIFO_NEST_MAX];
 };
 
 // ---- range rings: particle types whose lifetime is a RANGE, updated in place ---------------------------------------

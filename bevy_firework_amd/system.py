@@ -311,6 +311,12 @@ class ParticleSystem:
         self._check(self._lib.fw_ctx_kernel_timing_overhead(self._ctx, C.byref(out)))
         return out.value * 1e3
 
+    def nest_frames(self):
+        """(frames whose Nested entries ran inside the FIFO ring launch, frames that ran the separate fw_k_spawn / fw_k_nest passes)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.fw_debug_nest_frames(self._ctx, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def measure_copy_bandwidth(self, nbytes: int = 1 << 30, iters: int = 20) -> float:
         out = C.c_double()
         self._check(self._lib.fw_ctx_measure_copy_bandwidth(self._ctx, int(nbytes), int(iters), C.byref(out)))

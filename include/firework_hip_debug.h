@@ -46,6 +46,10 @@ fw_status fw_debug_read_range_timestamps(fw_ctx *ctx, unsigned long long *out, u
 fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner spawner, uint32_t type, int32_t *mode, uint32_t *moved_bytes,
                                uint32_t *algorithmic_bytes);
 
+/* frames with Nested entries stepped so far: those whose entries ran INSIDE the FIFO ring launch (one launch per frame, DESIGN.md
+ * 4.0) and those that ran the separate fw_k_spawn / fw_k_nest passes first */
+fw_status fw_debug_nest_frames(fw_ctx *ctx, uint64_t *fused, uint64_t *separate);
+
 #ifdef __cplusplus
 }
 #endif

@@ -285,6 +285,45 @@ def test_nested_spawner_on_rings_bit_exact(system):
     assert pair.gpu.count(0) > 1000 and pair.gpu.count(1) > 10000
 
 
+@pytest.mark.parametrize("fuse", ["inside the FIFO launch", "separate passes"])
+def test_nested_entry_inside_the_fifo_launch(fw_path, monkeypatch, fuse):
+    """round 5: a Nested entry whose parents and children both live in FIFO rings runs INSIDE the ring launch (fw_kernels.h:
+    FwFifoNest) -- the parents' tiles count, look back and spawn the children with their first update, the child ring's
+    bookkeeping workgroup books the total -- instead of fw_k_nest + a second launch.  Sparks in a ring with a caller-given
+    capacity that their live count nearly fills: in the frames in which the ring wraps into its head tile (the tiles' ranks
+    are then not the list order) the library falls back to the separate pass, so fused and separate frames alternate and
+    hand each other the device counters; irregular steps, zero steps.  The whole state, the destroyed stream and
+    last_emitted_age against the oracle bit for bit, both ways (FW_NEST_FUSE=0: the separate passes throughout)."""
+    from bevy_firework_amd.system import ParticleSystem
+
+    if fw_path != "fifo":
+        pytest.skip("no FIFO rings on this path")
+    monkeypatch.setenv("FW_NEST_FUSE", "1" if fuse == "inside the FIFO launch" else "0")
+    sp = _nested_rings(spark_rate=31400.0, per_spark=12.0, particles_destroyed=lambda dead: None)  # (~15 700 sparks in 16 384 slots)
+    sp.particle_settings[0].capacity = 16384
+    sp.particle_settings[0].particles_destroyed = lambda dead: None
+    rng = np.random.default_rng(5)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        pair = Pair(system, sp, S.Transform((0.0, 1.0, 0.0)), seed=SEED, uid=17)
+        assert [pair.gpu.update_path(t)[0] for t in (0, 1)] == ["fifo", "fifo"]
+        for fr in range(140):
+            dt = np.float32(DT if fr < 70 else (0.0 if fr % 17 == 0 else rng.uniform(0.004, 0.03)))
+            system.update(dt)
+            pair.step_cpu(dt)
+            if fr % 4 == 3 or fr < 4:
+                pair.check(exact_all=True, what=f"frame {fr}")
+                for t in (0, 1):
+                    assert_particles_match(pair.gpu.destroyed(t), pair.cpu.destroyed(t), True, f"destroyed type {t} frame {fr}")
+                assert np.array_equal(pair.gpu.last_emitted(0, 1), pair.cpu.last_emitted(0, 1)), f"last_emitted frame {fr}"
+        fused, separate = system.nest_frames()
+        assert [pair.gpu.update_path(t)[0] for t in (0, 1)] == ["fifo", "fifo"]
+        assert pair.gpu.count(0) > 12000 and pair.gpu.count(1) > 100000, pair.gpu.counts()
+        if fuse == "inside the FIFO launch":
+            assert fused > 60 and separate > 3, (fused, separate)  # (the frames in which the ring reached into its head tile fell back)
+        else:
+            assert fused == 0 and separate == 140, (fused, separate)
+
+
 def test_nested_rings_with_attached_instances_and_idle_frames(system):
     """the child ring's render hand-off (records in particle order from a count the kernel reads on the device) and a step
     longer than both lifetimes: every spark dies, this frame's included (the host knows their number); the smoke type,
