@@ -15,9 +15,9 @@ struct alignas(16) FwCollider {
     float bound;           // radius of a sphere around `position` that contains the collider (INFINITY for a plane): set by the host
                            // (fw_ctx_set_colliders); lets a wave skip a collider none of its rays can reach (fw_cast_ray)
     float position[4];
-    float rotation[4];     // xyzw (BOX)
+    float rotation[4];     // xyzw (BOX, CYLINDER, CONE)
     float normal[4];       // PLANE
-    float half_extents[4]; // BOX
+    float half_extents[4]; // BOX; [1] = half the height of a CYLINDER / CONE (their axis is the local Y axis)
 };
 
 struct FwRayHit {
@@ -72,9 +72,97 @@ FW_HD bool fw_ray_collider(const FwCollider &c, fw_v3 origin, fw_v3 dir, float m
         *hit = FwRayHit{t, fw_normalize3(p)};
         return true;
     }
-    // BOX: slabs in the box's own frame
     const fw_q4 q{c.rotation[0], c.rotation[1], c.rotation[2], c.rotation[3]};
     const fw_q4 qi{-q.x, -q.y, -q.z, q.w};  // conjugate = inverse of a unit quaternion
+    if (c.kind == 3) {  // CYLINDER (avian Collider::cylinder(radius, height): axis = local Y, examples/textures.rs:195): the slab
+                        // |y| <= half height intersected with the infinite cylinder x^2 + z^2 <= r^2, in the collider's frame
+        const fw_v3 ol = fw_quat_mul_vec3(qi, fw_sub3(origin, cpos)), dl = fw_quat_mul_vec3(qi, dir);
+        const float hh = c.half_extents[1], rr = c.radius * c.radius;
+        const float c2 = (ol.x * ol.x + ol.z * ol.z) - rr;
+        if (fabsf(ol.y) <= hh && c2 <= 0.0f) {  // inside (or on) the solid
+            *hit = FwRayHit{0.0f, fw_v3{0.0f, 0.0f, 0.0f}};
+            return true;
+        }
+        float tnear = -INFINITY, tfar = INFINITY, sign = 0.0f;
+        int side = 0;  // what the ray enters through: 0 a cap, 1 the lateral surface
+        if (dl.y == 0.0f) {
+            if (fabsf(ol.y) > hh) return false;
+        } else {
+            const float inv = 1.0f / dl.y;
+            float t1 = (-hh - ol.y) * inv, t2 = (hh - ol.y) * inv, sg = -1.0f;
+            if (t1 > t2) {
+                const float tmp = t1;
+                t1 = t2, t2 = tmp, sg = 1.0f;
+            }
+            if (t1 > tnear) tnear = t1, side = 0, sign = sg;
+            if (t2 < tfar) tfar = t2;
+            if (tnear > tfar) return false;
+        }
+        const float a = dl.x * dl.x + dl.z * dl.z, b = ol.x * dl.x + ol.z * dl.z;
+        if (a == 0.0f) {
+            if (c2 > 0.0f) return false;
+        } else {
+            const float disc = b * b - a * c2;
+            if (!(disc >= 0.0f)) return false;
+            const float sq = sqrtf(disc);
+            const float t1 = (-b - sq) / a, t2 = (-b + sq) / a;
+            if (t1 > tnear) tnear = t1, side = 1;
+            if (t2 < tfar) tfar = t2;
+            if (tnear > tfar) return false;
+        }
+        if (!(tnear >= 0.0f && tnear <= max_distance)) return false;
+        const fw_v3 nl = side == 0 ? fw_v3{0.0f, sign, 0.0f} : fw_normalize3(fw_v3{ol.x + dl.x * tnear, 0.0f, ol.z + dl.z * tnear});
+        *hit = FwRayHit{tnear, fw_quat_mul_vec3(q, nl)};
+        return true;
+    }
+    if (c.kind == 4) {  // CONE (avian Collider::cone(radius, height): base disc at local y = -h/2, apex at y = +h/2, examples/textures.rs:211):
+                        // w = p - apex; the solid is  w.y <= 0,  y >= -h/2,  w.x^2 + w.z^2 <= k^2 w.y^2  with k = radius / height
+        const fw_v3 ol = fw_quat_mul_vec3(qi, fw_sub3(origin, cpos)), dl = fw_quat_mul_vec3(qi, dir);
+        const float hh = c.half_extents[1], rr = c.radius * c.radius;
+        const float k = c.radius / (hh + hh), k2 = k * k;
+        const float wy = ol.y - hh;
+        const float cq = (ol.x * ol.x + ol.z * ol.z) - k2 * (wy * wy);
+        if (ol.y >= -hh && wy <= 0.0f && cq <= 0.0f) {  // inside (or on) the solid
+            *hit = FwRayHit{0.0f, fw_v3{0.0f, 0.0f, 0.0f}};
+            return true;
+        }
+        // the boundary of the solid is the base disc and the part of the lower nappe between base and apex: the first crossing of
+        // either along the ray is where a ray from outside enters
+        float best = INFINITY;
+        int side = -1;  // 0 the base disc, 1 the lateral surface
+        if (dl.y > 0.0f && ol.y < -hh) {
+            const float tb = (-hh - ol.y) / dl.y;
+            const float px = ol.x + dl.x * tb, pz = ol.z + dl.z * tb;
+            if (px * px + pz * pz <= rr) best = tb, side = 0;
+        }
+        const float a = (dl.x * dl.x + dl.z * dl.z) - k2 * (dl.y * dl.y);
+        const float b = (ol.x * dl.x + ol.z * dl.z) - k2 * (wy * dl.y);
+        float ta = INFINITY, tb2 = INFINITY;  // (INFINITY: no such root)
+        if (a == 0.0f) {
+            if (b != 0.0f) ta = -cq / (b + b);
+        } else {
+            const float disc = b * b - a * cq;
+            if (disc >= 0.0f) {
+                const float sq = sqrtf(disc);
+                ta = (-b - sq) / a, tb2 = (-b + sq) / a;
+            }
+        }
+        {
+            const float ya = ol.y + dl.y * ta, yb = ol.y + dl.y * tb2;
+            if (ta >= 0.0f && ta < INFINITY && ya >= -hh && ya <= hh && ta < best) best = ta, side = 1;
+            if (tb2 >= 0.0f && tb2 < INFINITY && yb >= -hh && yb <= hh && tb2 < best) best = tb2, side = 1;
+        }
+        if (side < 0 || !(best <= max_distance)) return false;
+        fw_v3 nl{0.0f, -1.0f, 0.0f};
+        if (side == 1) {
+            const fw_v3 w{ol.x + dl.x * best, (ol.y + dl.y * best) - hh, ol.z + dl.z * best};
+            const fw_v3 g{w.x, -(k2 * w.y), w.z};  // gradient of x^2 + z^2 - k^2 y^2: outward on the lower nappe
+            nl = (g.x == 0.0f && g.y == 0.0f && g.z == 0.0f) ? fw_v3{0.0f, 1.0f, 0.0f} : fw_normalize3(g);
+        }
+        *hit = FwRayHit{best, fw_quat_mul_vec3(q, nl)};
+        return true;
+    }
+    // BOX: slabs in the box's own frame
     // (an axis-aligned box -- the identity rotation, e.g. the ground slab of examples/stress_test_collision.rs -- needs no
     // rotations: Quat::IDENTITY * v is v itself up to the sign of a zero component, which no comparison or quotient below
     // depends on (a zero direction component takes the `== 0` arm); the results are the general path's bit for bit)

@@ -2208,7 +2208,7 @@ fw_status fw_ctx_set_colliders(fw_ctx *ctx, const fw_collider *colliders, uint32
     if (!ctx || (n && !colliders)) return fail(ctx, FW_EINVAL, "bad collider set");
     hipSetDevice(ctx->device);
     for (uint32_t i = 0; i < n; i++)
-        if (colliders[i].kind < FW_COLLIDER_PLANE || colliders[i].kind > FW_COLLIDER_BOX)
+        if (colliders[i].kind < FW_COLLIDER_PLANE || colliders[i].kind > FW_COLLIDER_CONE)
             return fail(ctx, FW_EINVAL, "unknown collider kind");
     // The reference asks the live physics world every frame (core.rs:756-765): a set that changes every frame must not
     // stall the frames in flight.  The new set is staged in pinned memory and copied by the stream itself.
@@ -2242,6 +2242,7 @@ fw_status fw_ctx_set_colliders(fw_ctx *ctx, const fw_collider *colliders, uint32
         // (the sphere around `position` that contains it: a wave skips a collider none of its rays can reach, fw_cast_ray)
         d.bound = c.kind == 1 ? c.radius
                   : c.kind == 2 ? std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]) * 1.0001f
+                  : (c.kind == 3 || c.kind == 4) ? std::sqrt(c.radius * c.radius + c.half_extents[1] * c.half_extents[1]) * 1.0001f  // (the rim of a cap / of the base)
                                 : INFINITY;
         if (!(d.bound >= 0.0f)) d.bound = INFINITY;  // (NaN / negative extents: never skipped)
         memcpy(d.position, c.position, sizeof c.position);

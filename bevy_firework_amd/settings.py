@@ -225,7 +225,7 @@ class ParticleCollisionSettings:
     filter_mask: int = 0xFFFFFFFF
 
 
-COLLIDER_PLANE, COLLIDER_SPHERE, COLLIDER_BOX = 0, 1, 2
+COLLIDER_PLANE, COLLIDER_SPHERE, COLLIDER_BOX, COLLIDER_CYLINDER, COLLIDER_CONE = 0, 1, 2, 3, 4
 
 
 @dataclass(frozen=True)
@@ -257,6 +257,18 @@ class Collider:
     def Box(center: Vec3, half_extents: Vec3, rotation: Quat = QUAT_IDENTITY, layers: int = 1) -> "Collider":
         return Collider(COLLIDER_BOX, tuple(float(c) for c in center), tuple(float(c) for c in rotation),
                         half_extents=tuple(float(c) for c in half_extents), layers=layers)
+
+    @staticmethod
+    def Cylinder(center: Vec3, radius: float, height: float, rotation: Quat = QUAT_IDENTITY, layers: int = 1) -> "Collider":
+        """avian's Collider::cylinder(radius, height) (examples/textures.rs:195): the axis is the collider's local Y"""
+        return Collider(COLLIDER_CYLINDER, tuple(float(c) for c in center), tuple(float(c) for c in rotation), radius=float(radius),
+                        half_extents=(0.0, float(height) * 0.5, 0.0), layers=layers)
+
+    @staticmethod
+    def Cone(center: Vec3, radius: float, height: float, rotation: Quat = QUAT_IDENTITY, layers: int = 1) -> "Collider":
+        """avian's Collider::cone(radius, height) (examples/textures.rs:211): base disc at local y = -height / 2, apex at +height / 2"""
+        return Collider(COLLIDER_CONE, tuple(float(c) for c in center), tuple(float(c) for c in rotation), radius=float(radius),
+                        half_extents=(0.0, float(height) * 0.5, 0.0), layers=layers)
 
 
 @dataclass

@@ -235,10 +235,9 @@ def example_textures(with_world: bool = True):
     """examples/textures.rs:53-173: bullet cases (rate 12/s, lifetime 5 s, initial rotation + a spin that angular_drag 0.85
     slows, bouncing with restitution 0.4 / friction 0.35) that each leave six smoke puffs in the first tenth of their life
     (a Nested CountOverDuration entry; its `duration` 0 is never read: core.rs:474-479), SpawnTransformMode::Local, the
-    emitter turned from +Y onto +X.  Returns (spawner, transform, colliders).  The example's colliders are an avian cylinder
-    (radius 4, height 0.2: textures.rs:191-196) and a cone (textures.rs:198-212); this backend's analytic set is planes,
-    spheres and boxes, so the world here is STAND-INS: a slab with the cylinder's top face and a sphere where
-    the cone stands."""
+    emitter turned from +Y onto +X.  Returns (spawner, transform, colliders): the example's own world -- the circular base, an avian
+    Collider::cylinder(4., 0.2) at the origin (textures.rs:191-196), and a Collider::cone(0.5, 1.) at (0, 0.5, 0)
+    (textures.rs:198-212) -- as this backend's analytic cylinder and cone (round 5; stand-ins until then)."""
     from .settings import SpawnTransformMode
 
     s = math.sin(math.pi / 4.0)
@@ -269,5 +268,5 @@ def example_textures(with_world: bool = True):
         inherit_parent_velocity=False, initial_angular_velocity=RandVec3.constant((0.0, 0.0, 0.0)),
     )
     tf = Transform((-2.0, 2.0, 0.0), _quat_from_arc((0.0, 1.0, 0.0), (1.0, 0.0, 0.0)))
-    colliders = [Collider.Box((0.0, 0.0, 0.0), (4.0, 0.1, 4.0)), Collider.Sphere((0.0, 0.5, 0.0), 0.5)] if with_world else []
+    colliders = [Collider.Cylinder((0.0, 0.0, 0.0), 4.0, 0.2), Collider.Cone((0.0, 0.5, 0.0), 0.5, 1.0)] if with_world else []
     return ParticleSpawner([cases, smoke], [e_cases, e_smoke], spawn_transform_mode=SpawnTransformMode.Local), tf, colliders

@@ -168,6 +168,15 @@ struct Collider {
         Collider c; c.kind = FW_COLLIDER_BOX, c.position = center, c.half_extents = half_extents, c.rotation = rotation;
         c.layers = layers; return c;
     }
+    // avian's Collider::cylinder(radius, height) / Collider::cone(radius, height) (examples/textures.rs:195, 211): axis = local Y
+    static Collider Cylinder(Vec3 center, float radius, float height, Quat rotation = {}, uint32_t layers = 1) {
+        Collider c; c.kind = FW_COLLIDER_CYLINDER, c.position = center, c.radius = radius, c.half_extents = Vec3{0, height * 0.5f, 0};
+        c.rotation = rotation, c.layers = layers; return c;
+    }
+    static Collider Cone(Vec3 center, float radius, float height, Quat rotation = {}, uint32_t layers = 1) {
+        Collider c; c.kind = FW_COLLIDER_CONE, c.position = center, c.radius = radius, c.half_extents = Vec3{0, height * 0.5f, 0};
+        c.rotation = rotation, c.layers = layers; return c;
+    }
 };
 
 struct ParticleSettings {  // core.rs:99-142, defaults core.rs:187-211

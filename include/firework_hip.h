@@ -113,18 +113,23 @@ typedef struct fw_particle_settings {
  *   PLANE   the half-space n.(x - position) <= 0 is solid; `normal` must be a unit vector
  *   SPHERE  |x - position| <= radius is solid
  *   BOX     |R^-1 (x - position)|_i <= half_extents_i is solid (R = rotation, xyzw)
+ *   CYLINDER  avian's Collider::cylinder(radius, height) (examples/textures.rs:195): in the collider's frame (R, position) the
+ *           axis is Y; |y| <= half_extents[1] (= height / 2) and x^2 + z^2 <= radius^2 is solid; a hit on a cap reports +-Y, a hit
+ *           on the lateral surface the radial direction (both rotated by R)
+ *   CONE    avian's Collider::cone(radius, height) (examples/textures.rs:211): base disc of `radius` at y = -half_extents[1], apex
+ *           at y = +half_extents[1]; solid between them; the base reports -Y, the lateral surface its outward normal
  *   a ray that starts inside a solid hits it at distance 0 with a ZERO normal (core.rs:762-771 handles that case);
  *   otherwise the hit is the entry point, its normal the outward surface normal; the nearest hit over all colliders
  *   that pass the filter wins (lowest index on ties). */
-enum { FW_COLLIDER_PLANE = 0, FW_COLLIDER_SPHERE = 1, FW_COLLIDER_BOX = 2 };
+enum { FW_COLLIDER_PLANE = 0, FW_COLLIDER_SPHERE = 1, FW_COLLIDER_BOX = 2, FW_COLLIDER_CYLINDER = 3, FW_COLLIDER_CONE = 4 };
 typedef struct fw_collider {
     int32_t kind;
     uint32_t layers;        /* collision layers (membership bits) */
     float position[3];
-    float rotation[4];      /* xyzw; BOX only */
+    float rotation[4];      /* xyzw; BOX, CYLINDER, CONE */
     float normal[3];        /* PLANE only */
-    float radius;           /* SPHERE only */
-    float half_extents[3];  /* BOX only */
+    float radius;           /* SPHERE, CYLINDER, CONE */
+    float half_extents[3];  /* BOX; [1] = half the height of a CYLINDER / CONE */
 } fw_collider;
 
 enum { FW_PACING_ONESHOT = 0, FW_PACING_ONDEMAND = 1, FW_PACING_COUNT_OVER_DURATION = 2 }; /* core.rs:12-29 */

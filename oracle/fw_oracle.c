@@ -394,11 +394,104 @@ static int ray_collider(const fwo_collider *c, const float o[3], const float d[3
         *dist = t;
         return 1;
     }
-    /* BOX: slab test in the box frame */
     float qi[4] = {-c->rotation[0], -c->rotation[1], -c->rotation[2], c->rotation[3]};
     float rel[3] = {o[0] - c->position[0], o[1] - c->position[1], o[2] - c->position[2]}, ol[3], dl[3];
     fwo_quat_mul_vec3(qi, rel, ol);
     fwo_quat_mul_vec3(qi, d, dl);
+    if (c->kind == FWO_COLLIDER_CYLINDER) {
+        /* avian Collider::cylinder(radius, height) (examples/textures.rs:195): axis = local Y; the slab |y| <= half height
+         * intersected with the infinite cylinder x^2 + z^2 <= r^2 */
+        float hh = c->half_extents[1], rr = c->radius * c->radius;
+        float c2 = (ol[0] * ol[0] + ol[2] * ol[2]) - rr;
+        if (fabsf(ol[1]) <= hh && c2 <= 0.0f) {
+            *dist = 0.0f, normal[0] = normal[1] = normal[2] = 0.0f;
+            return 1;
+        }
+        float tnear = -INFINITY, tfar = INFINITY, sign = 0.0f;
+        int side = 0; /* 0: a cap, 1: the lateral surface */
+        if (dl[1] == 0.0f) {
+            if (fabsf(ol[1]) > hh) return 0;
+        } else {
+            float inv = 1.0f / dl[1];
+            float t1 = (-hh - ol[1]) * inv, t2 = (hh - ol[1]) * inv, sg = -1.0f;
+            if (t1 > t2) {
+                float tmp = t1;
+                t1 = t2, t2 = tmp, sg = 1.0f;
+            }
+            if (t1 > tnear) tnear = t1, side = 0, sign = sg;
+            if (t2 < tfar) tfar = t2;
+            if (tnear > tfar) return 0;
+        }
+        float a = dl[0] * dl[0] + dl[2] * dl[2], b = ol[0] * dl[0] + ol[2] * dl[2];
+        if (a == 0.0f) {
+            if (c2 > 0.0f) return 0;
+        } else {
+            float disc = b * b - a * c2;
+            if (!(disc >= 0.0f)) return 0;
+            float sq = sqrtf(disc);
+            float t1 = (-b - sq) / a, t2 = (-b + sq) / a;
+            if (t1 > tnear) tnear = t1, side = 1;
+            if (t2 < tfar) tfar = t2;
+            if (tnear > tfar) return 0;
+        }
+        if (!(tnear >= 0.0f && tnear <= max_distance)) return 0;
+        float nl[3] = {0.0f, sign, 0.0f};
+        if (side == 1) {
+            float p[3] = {ol[0] + dl[0] * tnear, 0.0f, ol[2] + dl[2] * tnear};
+            v3_normalize(p, nl);
+        }
+        fwo_quat_mul_vec3(c->rotation, nl, normal);
+        *dist = tnear;
+        return 1;
+    }
+    if (c->kind == FWO_COLLIDER_CONE) {
+        /* avian Collider::cone(radius, height) (examples/textures.rs:211): base disc at local y = -h/2, apex at y = +h/2.
+         * w = p - apex; the solid is  w.y <= 0,  y >= -h/2,  w.x^2 + w.z^2 <= k^2 w.y^2  with k = radius / height */
+        float hh = c->half_extents[1], rr = c->radius * c->radius;
+        float k = c->radius / (hh + hh), k2 = k * k;
+        float wy = ol[1] - hh;
+        float cq = (ol[0] * ol[0] + ol[2] * ol[2]) - k2 * (wy * wy);
+        if (ol[1] >= -hh && wy <= 0.0f && cq <= 0.0f) {
+            *dist = 0.0f, normal[0] = normal[1] = normal[2] = 0.0f;
+            return 1;
+        }
+        float best = INFINITY;
+        int side = -1; /* 0: the base disc, 1: the lateral surface */
+        if (dl[1] > 0.0f && ol[1] < -hh) {
+            float tb = (-hh - ol[1]) / dl[1];
+            float px = ol[0] + dl[0] * tb, pz = ol[2] + dl[2] * tb;
+            if (px * px + pz * pz <= rr) best = tb, side = 0;
+        }
+        float a = (dl[0] * dl[0] + dl[2] * dl[2]) - k2 * (dl[1] * dl[1]);
+        float b = (ol[0] * dl[0] + ol[2] * dl[2]) - k2 * (wy * dl[1]);
+        float ta = INFINITY, tb2 = INFINITY;
+        if (a == 0.0f) {
+            if (b != 0.0f) ta = -cq / (b + b);
+        } else {
+            float disc = b * b - a * cq;
+            if (disc >= 0.0f) {
+                float sq = sqrtf(disc);
+                ta = (-b - sq) / a, tb2 = (-b + sq) / a;
+            }
+        }
+        {
+            float ya = ol[1] + dl[1] * ta, yb = ol[1] + dl[1] * tb2;
+            if (ta >= 0.0f && ta < INFINITY && ya >= -hh && ya <= hh && ta < best) best = ta, side = 1;
+            if (tb2 >= 0.0f && tb2 < INFINITY && yb >= -hh && yb <= hh && tb2 < best) best = tb2, side = 1;
+        }
+        if (side < 0 || !(best <= max_distance)) return 0;
+        float nl[3] = {0.0f, -1.0f, 0.0f};
+        if (side == 1) {
+            float w[3] = {ol[0] + dl[0] * best, (ol[1] + dl[1] * best) - hh, ol[2] + dl[2] * best};
+            float g[3] = {w[0], -(k2 * w[1]), w[2]};
+            if (g[0] == 0.0f && g[1] == 0.0f && g[2] == 0.0f) nl[0] = 0.0f, nl[1] = 1.0f, nl[2] = 0.0f;
+            else v3_normalize(g, nl);
+        }
+        fwo_quat_mul_vec3(c->rotation, nl, normal);
+        *dist = best;
+        return 1;
+    }
+    /* BOX: slab test in the box frame */
     int inside = 1;
     for (int i = 0; i < 3; i++) inside = inside && fabsf(ol[i]) <= c->half_extents[i];
     if (inside) {

@@ -85,7 +85,7 @@ typedef struct {
 
 /* the analytic collider set the oracle's ray cast runs against (stands in for avian's SpatialQuery; semantics in
  * include/firework_hip.h: fw_collider).  "Parity unpinned": the reference's world is arbitrary parry shapes. */
-enum { FWO_COLLIDER_PLANE = 0, FWO_COLLIDER_SPHERE = 1, FWO_COLLIDER_BOX = 2 };
+enum { FWO_COLLIDER_PLANE = 0, FWO_COLLIDER_SPHERE = 1, FWO_COLLIDER_BOX = 2, FWO_COLLIDER_CYLINDER = 3, FWO_COLLIDER_CONE = 4 };
 typedef struct {
     int32_t kind;
     uint32_t layers;

@@ -363,6 +363,99 @@ def cast_ray(colliders, mask, origin, d, max_distance):
                 hit = inside | ok
                 t = np.where(inside, ZERO, tt).astype(f32)
                 nrm = np.where(ok[:, None], _normalize3(p_), ZERO).astype(f32)
+            elif c.kind == 3:  # cylinder (avian Collider::cylinder(radius, height), examples/textures.rs:195): axis = local Y
+                q = _a(c.rotation)
+                qi = np.broadcast_to(np.array([-q[0], -q[1], -q[2], q[3]], dtype=f32), (n, 4))
+                ol = quat_mul_vec3(qi, (origin - cpos).astype(f32))
+                dl = quat_mul_vec3(qi, d)
+                hh, rr = f32(c.half_extents[1]), f32(f32(c.radius) * f32(c.radius))
+                ox, oy, oz, dx, dy, dz = ol[:, 0], ol[:, 1], ol[:, 2], dl[:, 0], dl[:, 1], dl[:, 2]
+                c2 = (((ox * ox).astype(f32) + (oz * oz).astype(f32)).astype(f32) - rr).astype(f32)
+                inside = (np.abs(oy) <= hh) & (c2 <= 0)
+                tnear = np.full(n, -np.inf, dtype=f32)
+                tfar = np.full(n, np.inf, dtype=f32)
+                side = np.zeros(n, dtype=np.int64)
+                sign = np.zeros(n, dtype=f32)
+                par = dy == 0
+                dead = par & (np.abs(oy) > hh)
+                inv = (ONE / dy).astype(f32)
+                t1 = ((-hh - oy).astype(f32) * inv).astype(f32)
+                t2 = ((hh - oy).astype(f32) * inv).astype(f32)
+                sw = t1 > t2
+                lo_, hi_ = np.where(sw, t2, t1), np.where(sw, t1, t2)
+                live = ~dead & ~par
+                upd = live & (lo_ > tnear)
+                tnear = np.where(upd, lo_, tnear).astype(f32)
+                sign = np.where(upd, np.where(sw, ONE, f32(-1.0)), sign).astype(f32)
+                tfar = np.where(live & (hi_ < tfar), hi_, tfar).astype(f32)
+                dead |= live & (tnear > tfar)
+                a_ = ((dx * dx).astype(f32) + (dz * dz).astype(f32)).astype(f32)
+                b_ = ((ox * dx).astype(f32) + (oz * dz).astype(f32)).astype(f32)
+                apar = a_ == 0
+                dead |= ~dead & apar & (c2 > 0)
+                disc = ((b_ * b_).astype(f32) - (a_ * c2).astype(f32)).astype(f32)
+                live = ~dead & ~apar
+                dead |= live & ~(disc >= 0)
+                live = ~dead & ~apar
+                sq = np.sqrt(np.maximum(disc, ZERO)).astype(f32)
+                s1 = (((-b_).astype(f32) - sq).astype(f32) / a_).astype(f32)
+                s2 = (((-b_).astype(f32) + sq).astype(f32) / a_).astype(f32)
+                upd = live & (s1 > tnear)
+                tnear = np.where(upd, s1, tnear).astype(f32)
+                side = np.where(upd, 1, side)
+                tfar = np.where(live & (s2 < tfar), s2, tfar).astype(f32)
+                dead |= live & (tnear > tfar)
+                ok = ~inside & ~dead & (tnear >= 0) & (tnear <= max_distance)
+                rad = np.stack([(ox + (dx * tnear).astype(f32)).astype(f32), np.zeros(n, dtype=f32), (oz + (dz * tnear).astype(f32)).astype(f32)], axis=1)
+                cap = np.stack([np.zeros(n, dtype=f32), sign, np.zeros(n, dtype=f32)], axis=1)
+                nl = np.where((side == 1)[:, None], _normalize3(rad), cap).astype(f32)
+                hit = inside | ok
+                t = np.where(inside, ZERO, tnear).astype(f32)
+                nrm = np.where(ok[:, None], quat_mul_vec3(np.broadcast_to(q, (n, 4)), nl), ZERO).astype(f32)
+            elif c.kind == 4:  # cone (avian Collider::cone(radius, height), examples/textures.rs:211): base at y = -h/2, apex at +h/2
+                q = _a(c.rotation)
+                qi = np.broadcast_to(np.array([-q[0], -q[1], -q[2], q[3]], dtype=f32), (n, 4))
+                ol = quat_mul_vec3(qi, (origin - cpos).astype(f32))
+                dl = quat_mul_vec3(qi, d)
+                hh, rr = f32(c.half_extents[1]), f32(f32(c.radius) * f32(c.radius))
+                k = f32(f32(c.radius) / f32(hh + hh))
+                k2 = f32(k * k)
+                ox, oy, oz, dx, dy, dz = ol[:, 0], ol[:, 1], ol[:, 2], dl[:, 0], dl[:, 1], dl[:, 2]
+                wy = (oy - hh).astype(f32)
+                cq = (((ox * ox).astype(f32) + (oz * oz).astype(f32)).astype(f32) - (k2 * (wy * wy).astype(f32)).astype(f32)).astype(f32)
+                inside = (oy >= -hh) & (wy <= 0) & (cq <= 0)
+                best = np.full(n, np.inf, dtype=f32)
+                side = np.full(n, -1, dtype=np.int64)
+                tb = ((-hh - oy).astype(f32) / dy).astype(f32)
+                px, pz = (ox + (dx * tb).astype(f32)).astype(f32), (oz + (dz * tb).astype(f32)).astype(f32)
+                base = (dy > 0) & (oy < -hh) & (((px * px).astype(f32) + (pz * pz).astype(f32)).astype(f32) <= rr)
+                best = np.where(base, tb, best).astype(f32)
+                side = np.where(base, 0, side)
+                a_ = (((dx * dx).astype(f32) + (dz * dz).astype(f32)).astype(f32) - (k2 * (dy * dy).astype(f32)).astype(f32)).astype(f32)
+                b_ = (((ox * dx).astype(f32) + (oz * dz).astype(f32)).astype(f32) - (k2 * (wy * dy).astype(f32)).astype(f32)).astype(f32)
+                lin = a_ == 0
+                disc = ((b_ * b_).astype(f32) - (a_ * cq).astype(f32)).astype(f32)
+                sq = np.sqrt(np.maximum(disc, ZERO)).astype(f32)
+                quad = ~lin & (disc >= 0)
+                ta = np.where(lin, np.where(b_ != 0, ((-cq).astype(f32) / (b_ + b_).astype(f32)).astype(f32), f32(np.inf)),
+                              np.where(quad, (((-b_).astype(f32) - sq).astype(f32) / a_).astype(f32), f32(np.inf))).astype(f32)
+                tb2 = np.where(quad, (((-b_).astype(f32) + sq).astype(f32) / a_).astype(f32), f32(np.inf)).astype(f32)
+                for tt in (ta, tb2):
+                    yy = (oy + (dy * tt).astype(f32)).astype(f32)
+                    good = (tt >= 0) & (tt < np.inf) & (yy >= -hh) & (yy <= hh) & (tt < best)
+                    best = np.where(good, tt, best).astype(f32)
+                    side = np.where(good, 1, side)
+                ok = ~inside & (side >= 0) & (best <= max_distance)
+                w = np.stack([(ox + (dx * best).astype(f32)).astype(f32), ((oy + (dy * best).astype(f32)).astype(f32) - hh).astype(f32),
+                              (oz + (dz * best).astype(f32)).astype(f32)], axis=1)
+                g = np.stack([w[:, 0], (-(k2 * w[:, 1]).astype(f32)).astype(f32), w[:, 2]], axis=1)
+                gz = (g == 0).all(axis=1)
+                up = np.broadcast_to(np.array([0.0, 1.0, 0.0], dtype=f32), (n, 3))
+                down = np.broadcast_to(np.array([0.0, -1.0, 0.0], dtype=f32), (n, 3))
+                nl = np.where((side == 1)[:, None], np.where(gz[:, None], up, _normalize3(g)), down).astype(f32)
+                hit = inside | ok
+                t = np.where(inside, ZERO, best).astype(f32)
+                nrm = np.where(ok[:, None], quat_mul_vec3(np.broadcast_to(q, (n, 4)), nl), ZERO).astype(f32)
             else:  # box
                 q = _a(c.rotation)
                 qi = np.broadcast_to(np.array([-q[0], -q[1], -q[2], q[3]], dtype=f32), (n, 4))

@@ -103,8 +103,9 @@ def deaths_everywhere():
 
 
 def bouncing_colliders():
-    """particle_collision (core.rs:607-624, 744-800) against the analytic collider set: a tilted ground plane, a sphere
-    and a rotated box; type 0 bounces (restitution, friction), type 1 is destroyed on contact, type 2 only collides
+    """particle_collision (core.rs:607-624, 744-800) against the analytic collider set: a tilted ground plane, a sphere,
+    a rotated box, a tilted cylinder and a cone (the two kinds examples/textures.rs:195, 211 bounces its cases off; round 5);
+    type 0 bounces (restitution, friction), type 1 is destroyed on contact, type 2 only collides
     with layer 2 (the small sphere high up); fast particles take several bounce sub-steps per frame.  No libm call
     anywhere in the collision arithmetic (sqrt and division are correctly rounded everywhere): bit-exact."""
     bounce = S.ParticleSettings(lifetime=S.RandF32(1.5, 3.0), linear_drag=0.05, initial_scale=S.RandF32(0.02, 0.05),
@@ -123,7 +124,9 @@ def bouncing_colliders():
                             initial_velocity=S.RandVec3(S.RandF32(0.5, 3.0), (0.0, 1.0, 0.0), 0.0))
     colliders = [S.Collider.Plane((0.0, -1.0, 0.0), (0.1, 1.0, 0.05)), S.Collider.Sphere((1.0, 0.0, 0.2), 0.8),
                  S.Collider.Box((-1.2, -0.2, 0.3), (0.7, 0.4, 0.9), (0.0, math.sin(0.35), 0.0, math.cos(0.35))),
-                 S.Collider.Sphere((0.0, 4.5, 0.0), 0.6, layers=2)]
+                 S.Collider.Sphere((0.0, 4.5, 0.0), 0.6, layers=2),
+                 S.Collider.Cylinder((0.3, 0.2, -0.4), 0.6, 0.5, (math.sin(0.2), 0.0, 0.0, math.cos(0.2))),
+                 S.Collider.Cone((-0.3, 0.6, 0.5), 0.5, 1.0)]
     return dict(spawner=S.ParticleSpawner([bounce, fragile, picky], [e0, e1, e2]), transform=S.Transform((0.0, 2.0, 0.0)),
                 modifier=None, parent_velocity=(0.0, 0.0, 0.0), uid=21, dts=[1 / 60] * 30 + [1 / 30, 1 / 120, 0.05],
                 frames=160, checkpoints=[0, 25, 80, 159], exact=True, colliders=colliders)

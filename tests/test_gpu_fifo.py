@@ -290,9 +290,10 @@ def test_nested_entry_inside_the_fifo_launch(fw_path, monkeypatch, fuse):
     """round 5: a Nested entry whose parents and children both live in FIFO rings runs INSIDE the ring launch (fw_kernels.h:
     FwFifoNest) -- the parents' tiles count, look back and spawn the children with their first update, the child ring's
     bookkeeping workgroup books the total -- instead of fw_k_nest + a second launch.  Sparks in a ring with a caller-given
-    capacity that their live count nearly fills: in the frames in which the ring wraps into its head tile (the tiles' ranks
-    are then not the list order) the library falls back to the separate pass, so fused and separate frames alternate and
-    hand each other the device counters; irregular steps, zero steps.  The whole state, the destroyed stream and
+    capacity that their live count nearly fills (a frame in which the ring wraps into its head tile -- the tiles' ranks are then
+    not the list order -- falls back to the separate pass), and an instance buffer attached to the child type for two stretches
+    of frames (it keeps the entry out of the launch): fused and separate frames alternate and hand each other the device
+    counters; irregular steps, zero steps.  The whole state, the destroyed stream and
     last_emitted_age against the oracle bit for bit, both ways (FW_NEST_FUSE=0: the separate passes throughout)."""
     from bevy_firework_amd.system import ParticleSystem
 
@@ -306,8 +307,17 @@ def test_nested_entry_inside_the_fifo_launch(fw_path, monkeypatch, fuse):
     with ParticleSystem(device=0, seed=SEED) as system:
         pair = Pair(system, sp, S.Transform((0.0, 1.0, 0.0)), seed=SEED, uid=17)
         assert [pair.gpu.update_path(t)[0] for t in (0, 1)] == ["fifo", "fifo"]
+        import torch
+
+        buf = torch.full((200000 * 16,), float("nan"), dtype=torch.float32, device="cuda")
         for fr in range(140):
             dt = np.float32(DT if fr < 70 else (0.0 if fr % 17 == 0 else rng.uniform(0.004, 0.03)))
+            # frames 40-59 and 100-109: an instance buffer on the child type keeps the entry out of the FIFO launch (the separate
+            # passes run); detached, it goes back in -- the two forms hand each other the device counters both ways
+            if fr in (40, 100):
+                pair.gpu.attach_instances(buf.data_ptr(), 200000, particle_type=1)
+            if fr in (60, 110):
+                pair.gpu.attach_instances(0, 0, particle_type=1)
             system.update(dt)
             pair.step_cpu(dt)
             if fr % 4 == 3 or fr < 4:
@@ -319,7 +329,7 @@ def test_nested_entry_inside_the_fifo_launch(fw_path, monkeypatch, fuse):
         assert [pair.gpu.update_path(t)[0] for t in (0, 1)] == ["fifo", "fifo"]
         assert pair.gpu.count(0) > 12000 and pair.gpu.count(1) > 100000, pair.gpu.counts()
         if fuse == "inside the FIFO launch":
-            assert fused > 60 and separate > 3, (fused, separate)  # (the frames in which the ring reached into its head tile fell back)
+            assert fused >= 100 and separate >= 30, (fused, separate)  # (the frames with the instance buffer attached, and any in which the ring reached into its head tile)
         else:
             assert fused == 0 and separate == 140, (fused, separate)
 

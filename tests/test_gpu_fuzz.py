@@ -341,8 +341,13 @@ test_every_shortcut_gives_the_state_of_the_plain_path.sizes = {}
 
 
 def _collider(rng):
-    k = int(rng.integers(0, 3))
+    k = int(rng.integers(0, 5))
     layers = int(rng.choice([1, 1, 2, 3]))
+    if k >= 3:  # cylinder / cone (examples/textures.rs:195, 211), tilted
+        q = rng.normal(size=4)
+        make = S.Collider.Cylinder if k == 3 else S.Collider.Cone
+        return make(tuple(float(c) for c in rng.uniform(-2.0, 2.0, size=3)), float(rng.uniform(0.3, 1.2)), float(rng.uniform(0.2, 1.6)),
+                    tuple(float(c) for c in q / np.linalg.norm(q)), layers)
     if k == 0:
         return S.Collider.Plane(tuple(float(c) for c in rng.uniform(-1.0, 0.5, size=3)),
                                 tuple(float(c) for c in (rng.normal(size=3) * 0.3 + np.array([0.0, 1.0, 0.0]))), layers)
@@ -356,7 +361,7 @@ def _collider(rng):
 @pytest.mark.parametrize("case", range(OFF, OFF + 16 + EXTRA // 4))
 def test_random_colliding_spawner_matches_the_oracle_bit_for_bit(case):
     """particle_collision (core.rs:744-800) under random settings: one to four random colliders (planes, spheres, rotated
-    boxes, on different layers), random restitution / friction / destroy_on_collision / filter mask, one or two colliding
+    boxes, tilted cylinders and cones, on different layers), random restitution / friction / destroy_on_collision / filter mask, one or two colliding
     types next to a plain one, a Nested entry now and then, colliders replaced half way.  A bounce amplifies any
     difference, so the scene is built without a single libm call (Point emission, zero spread: directions vary through the
     entries and a parent velocity that changes every frame) and EVERY field is compared bit for bit."""

@@ -507,3 +507,58 @@ def test_a_small_nested_spawner_stays_on_range_rings_in_a_context_of_few_segment
         big, tfb = workloads.nested(spark_rate=20000.0, smoke_per_spark=20.0)
         d = system.spawn(big, tfb, uid=762)
         assert (d.update_path(0)[0], d.update_path(1)[0]) == ("fifo", "fifo")
+
+
+def test_more_one_lifetime_types_than_one_fifo_launch_holds(monkeypatch):
+    """product defaults (round 5, fw_ctx::n_spilled): eight large one-lifetime types are eight FIFO rings -- one launch; the NINTH
+    takes a range ring and the eight follow it WHERE THEY STAND (fifo_to_range: the ring's head becomes the slot of the first
+    young particle, the FIFO cohorts become the young cohorts, nothing is copied): one kind of launch per frame instead of two.
+    Live particles in every ring at the moment of the change -- some of them a step from death -- irregular steps afterwards,
+    types that spin and types that cannot turn (their lifetimes move into a plane), a type that reports its destroyed particles;
+    despawning back to eight types and below brings no FIFO ring back while converted rings exist; when the last of them is
+    gone a new large type is a FIFO ring again.  Whole state against the oracle throughout (exact fields bit for bit)."""
+    from bevy_firework_amd.system import ParticleSystem
+
+    _defaults(monkeypatch)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        def big(uid, life, spin=False, destroyed=False):
+            ps = _settings(lifetime=S.RandF32.constant(life), particles_destroyed=(lambda dead: None) if destroyed else None)
+            em = _emission(90000.0 + 1000.0 * (uid % 5), initial_angular_velocity=S.RandVec3(S.RandF32(1.0, 4.0), (0.0, 1.0, 0.0), 0.0)) if spin \
+                else _emission(90000.0 + 1000.0 * (uid % 5))
+            return Pair(system, S.ParticleSpawner([ps], [em]), S.Transform((float(uid % 9), 0.5, 0.0)), seed=SEED, uid=uid)
+
+        pairs = [big(800 + k, 0.5 + 0.01 * k, spin=k % 3 == 0, destroyed=k % 4 == 1) for k in range(8)]
+        assert [p.gpu.update_path(0)[0] for p in pairs] == ["fifo"] * 8
+        rng = np.random.default_rng(8)
+
+        def run(n, what, irregular=False):
+            for fr in range(n):
+                dt = np.float32(rng.uniform(0.004, 0.03)) if irregular and fr % 3 else DT
+                system.update(dt)
+                for p in pairs:
+                    p.step_cpu(dt)
+                if fr % 10 == 9 or fr == n - 1:
+                    for k, p in enumerate(pairs):
+                        p.check(what=f"{what} frame {fr} spawner {k}")
+                        if p.spawner.particle_settings[0].particles_destroyed is not None:
+                            assert_particles_match(p.gpu.destroyed(0), p.cpu.destroyed(0), False, f"{what} frame {fr} spawner {k}: destroyed")
+
+        run(45, "eight FIFO rings")  # (lifetimes 0.50-0.57 s = 30-34 frames: deaths in every ring by now)
+        pairs.append(big(820, 0.45))
+        assert [p.gpu.update_path(0)[0] for p in pairs] == ["range"] * 9
+        for k, p in enumerate(pairs):
+            p.check(what=f"right after the change, spawner {k}")
+        run(60, "nine range rings", irregular=True)
+        for p in pairs[:2]:
+            system.despawn(p.gpu)
+        del pairs[:2]
+        pairs.append(big(821, 0.4, spin=True))  # eight types again: it joins the converted rings (no second kind of launch)
+        assert [p.gpu.update_path(0)[0] for p in pairs] == ["range"] * 8
+        run(40, "eight range rings")
+        for p in pairs:
+            system.despawn(p.gpu)
+        pairs.clear()
+        pairs.append(big(830, 0.5))  # nothing converted is left: FIFO rings are back
+        assert pairs[0].gpu.update_path(0)[0] == "fifo"
+        run(40, "one FIFO ring")
+        assert pairs[0].gpu.count(0) > 40000

@@ -282,6 +282,82 @@ def test_particle_collision_against_the_numpy_restatement():
     assert np.allclose(p, (0, -9, 0.8), atol=1e-5) and np.array_equal(v, np.float32((0, -10, 1)))
 
 
+def test_cylinder_and_cone_ray_casts_against_the_numpy_restatement():
+    """the two collider kinds the reference's Nested example bounces off (examples/textures.rs:195 Collider::cylinder(4., 0.2),
+    :211 Collider::cone(0.5, 1.)): the C oracle and the numpy restatement bit for bit on random rays -- long and short ones,
+    starts inside the solids, rays along and across the axis, onto the caps / the base / the lateral surfaces / the apex --
+    against upright and rotated instances, and the geometry itself: a hit point lies on the surface it names, its normal is
+    the outward unit normal there, nothing is hit from inside out"""
+    import math
+    import sys
+
+    sys.path.insert(0, G)
+    import np_sim
+
+    rng = np.random.default_rng(23)
+    q = rng.normal(size=4)
+    q = tuple(float(c) for c in (q / np.linalg.norm(q)).astype(np.float32))
+    worlds = [[S.Collider.Cylinder((0.0, 0.0, 0.0), 4.0, 0.2)], [S.Collider.Cone((0.0, 0.5, 0.0), 0.5, 1.0)],  # the example's own
+              [S.Collider.Cylinder((0.4, -0.2, 0.1), 0.7, 1.6, q)], [S.Collider.Cone((-0.3, 0.1, 0.2), 0.9, 1.3, q)],
+              [S.Collider.Cylinder((0.4, -0.2, 0.1), 0.7, 1.6, q), S.Collider.Cone((-0.9, 0.3, 0.2), 0.9, 1.3, q, layers=3),
+               S.Collider.Plane((0, -1.5, 0), (0, 1, 0)), S.Collider.Cone((1.5, 0.0, 0.0), 0.4, 0.8)]]
+    n = 4000
+    pos = rng.uniform(-2.5, 2.5, size=(n, 3)).astype(np.float32)
+    pos[: n // 8] *= np.float32(0.2)  # a good share of the starts inside the solids
+    vel = (rng.normal(size=(n, 3)) * rng.choice([0, 0.5, 5, 30], size=(n, 1))).astype(np.float32)
+    vel[n // 8: n // 4, 0] = 0.0
+    vel[n // 8: n // 4, 2] = 0.0          # along the axis of the upright ones
+    vel[n // 4: n // 4 + n // 8, 1] = 0.0  # across it
+    changed = 0
+    for world in worlds:
+        for cs in (S.ParticleCollisionSettings(0.6, 0.3), S.ParticleCollisionSettings(0.2, 0.9, True)):
+            for dt in (1 / 60, 0.25):
+                p2, v2, k2 = np_sim.particle_collision(pos, vel, np.float32(dt), cs, world)
+                for i in range(0, n, 3):
+                    p, v, k = oracle.particle_collision(pos[i], vel[i], np.float32(dt), cs, world)
+                    assert np.array_equal(p, p2[i]) and np.array_equal(v, v2[i]) and k == bool(k2[i]), (world[0].kind, dt, i, p, p2[i], v, v2[i])
+                changed += int((np.abs(p2 - (pos + vel * np.float32(dt))) > 1e-6).any(axis=1).sum())
+    assert changed > 8000
+    # ---- the geometry, on the first hit of single rays (numpy cast_ray: hit mask, distance, unit normal)
+    m = 6000  # rays from a shell around the solids towards points near them, and a share of starts inside
+    o = rng.normal(size=(m, 3))
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * rng.uniform(1.5, 3.0, size=(m, 1))
+    o[: m // 6] = rng.uniform(-0.3, 0.3, size=(m // 6, 3))
+    tgt = rng.uniform(-0.8, 0.8, size=(m, 3))
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    o = o.astype(np.float32)
+    for c in (S.Collider.Cylinder((0.0, 0.0, 0.0), 0.7, 1.6), S.Collider.Cone((0.0, 0.0, 0.0), 0.9, 1.3)):
+        hit, t, nrm = np_sim.cast_ray([c], 0xFFFFFFFF, o, d, np.float32(10.0))
+        o64, d64 = o.astype(np.float64), d.astype(np.float64)
+        pt = o64 + d64 * np.where(hit, t, 0.0).astype(np.float64)[:, None]
+        hh, r = c.half_extents[1], c.radius
+        rho = np.hypot(pt[:, 0], pt[:, 2])
+        outside = hit & (t > 0)
+        assert outside.sum() > 300 and (hit & (t == 0)).sum() > 50
+        assert np.allclose(np.linalg.norm(nrm[outside], axis=1), 1.0, atol=1e-5)
+        assert ((nrm[outside].astype(np.float64) * d64[outside]).sum(axis=1) < 1e-5).all()  # entered against the normal
+        if c.kind == S.COLLIDER_CYLINDER:
+            cap = outside & (np.abs(nrm[:, 1]) > 0.5)
+            side = outside & ~cap
+            assert cap.sum() > 50 and side.sum() > 50
+            assert np.allclose(np.abs(pt[cap, 1]), hh, atol=1e-4) and (rho[cap] <= r + 1e-4).all()
+            assert np.allclose(rho[side], r, atol=1e-4) and (np.abs(pt[side, 1]) <= hh + 1e-4).all()
+            assert np.allclose(nrm[side][:, [0, 2]], pt[side][:, [0, 2]] / rho[side, None], atol=1e-4)
+            inside = (np.abs(o64[:, 1]) <= hh) & (np.hypot(o64[:, 0], o64[:, 2]) <= r)
+        else:
+            base = outside & (nrm[:, 1] < -0.99)
+            side = outside & ~base
+            assert base.sum() > 30 and side.sum() > 50
+            assert np.allclose(pt[base, 1], -hh, atol=1e-4) and (rho[base] <= r + 1e-4).all()
+            assert np.allclose(rho[side], r * (hh - pt[side, 1]) / (2 * hh), atol=2e-4) and (np.abs(pt[side, 1]) <= hh + 1e-4).all()
+            slope = np.array([2 * hh, r]) / math.hypot(2 * hh, r)  # outward normal of the lateral surface: (radial, y) components
+            assert np.allclose(nrm[side][:, 1], slope[1], atol=1e-3)
+            inside = (o64[:, 1] >= -hh) & (o64[:, 1] <= hh) & (np.hypot(o64[:, 0], o64[:, 2]) <= r * (hh - o64[:, 1]) / (2 * hh))
+        assert (t[inside & hit] == 0).all() and (hit[inside]).all()            # solid = true: a start inside hits at distance 0
+        assert (nrm[hit & (t == 0)] == 0).all()                                 # ... with a zero normal (core.rs:762-771)
+
+
 def test_one_lifetime_value_means_the_destroyed_are_always_the_oldest():
     """the premise of the backend's in-place FIFO path, checked on the oracle: with lifetime.min ==
     lifetime.max and any sequence of dt >= 0 -- zero steps, steps longer than the lifetime, several entries feeding the
