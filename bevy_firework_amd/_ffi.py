@@ -229,6 +229,9 @@ SYMBOLS = [
     ("fw_spawner_set_parent_velocity", C.c_int, [_P, C.c_int32, _F3]),
     ("fw_spawner_set_modifier", C.c_int, [_P, C.c_int32, C.c_float, C.c_float]),
     ("fw_spawner_queue", C.c_int, [_P, C.c_int32, C.c_uint64]),
+    ("fw_ctx_set_parent_velocities", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_int32), _F3]),
+    ("fw_ctx_set_modifiers", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_int32), _F3, _F3]),
+    ("fw_ctx_queue", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     ("fw_step", C.c_int, [_P, C.c_float]),
     ("fw_spawner_counts", C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint32), C.c_uint32]),
     ("fw_spawner_active", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32)]),
@@ -263,8 +266,8 @@ SYMBOLS = [
      [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]),
 ]
 
-# measurement hooks (firework_hip_debug.h, not the ABI) added after round 4: absent from the older builds the A/B tools load
-NEWER_DEBUG_HOOKS = {"fw_debug_nest_frames"}
+# entry points added after round 4 (ABI 5 + a measurement hook): absent from the older builds the A/B tools load through FW_LIB_PATH
+NEWER_THAN_R04 = {"fw_debug_nest_frames", "fw_ctx_set_parent_velocities", "fw_ctx_set_modifiers", "fw_ctx_queue"}
 _lib = None
 
 
@@ -280,12 +283,12 @@ def load() -> C.CDLL:
         )
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
-        if os.environ.get("FW_LIB_PATH") and name in NEWER_DEBUG_HOOKS and not hasattr(lib, name):
-            continue  # an OLDER build loaded for an A/B measurement (tools/): it may lack the newest measurement hooks
+        if os.environ.get("FW_LIB_PATH") and name in NEWER_THAN_R04 and not hasattr(lib, name):
+            continue  # an OLDER build loaded for an A/B measurement (tools/): it lacks what was added since
         fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.fw_abi_version() != 4:
+    if lib.fw_abi_version() != 5 and not os.environ.get("FW_LIB_PATH"):  # (an older build loaded for an A/B measurement: tools/)
         raise ImportError("libfirework_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -1024,22 +1024,24 @@ fw_status check_device_errors(fw_ctx *ctx) {
     if (!e) return FW_OK;
     uint32_t zero = 0;
     FW_HIP(ctx, hipMemcpy(ctx->g.err, &zero, sizeof zero, hipMemcpyHostToDevice));
-    if (e & FW_ERR_FORECAST) {
+    // (the two bits are looked at independently -- a word with both set used to lose the capacity report when the internal
+    // error was not news: ADVICE r04 -- and the more severe status wins)
+    fw_status cap = FW_OK;
+    if (e & FW_ERR_CAPACITY)
+        cap = fail(ctx, FW_ECAPACITY,
+                   "a particle type overflowed its device capacity; particles were dropped "
+                   "(raise fw_particle_settings.capacity) [device flags " + std::to_string(e) + ", segment " +
+                       std::to_string(ev[1]) + ": " + std::to_string(ev[2]) + " particles (" + std::to_string(ev[4]) +
+                       " resident), " + std::to_string(ev[3]) + " tiles launched]");
+    if ((e & FW_ERR_FORECAST) && fresh) {
         // An internal check of an update kernel failed.  The spawner it names is marked (poll_device_error): its own calls
         // refuse from now on.  Whoever synchronises first is told once; later synchronisations -- of healthy spawners -- are
         // not failed again for an error that has been reported and contained.
-        if (!fresh) return FW_OK;
         ctx->poison_msg += " [device flags " + std::to_string(e) + ", check " + std::to_string(ev[5]) + ": " + std::to_string(ev[6]) +
                            " " + std::to_string(ev[7]) + "]";
         return poisoned_status(ctx);
     }
-    if (e & FW_ERR_CAPACITY)
-        return fail(ctx, FW_ECAPACITY,
-                    "a particle type overflowed its device capacity; particles were dropped "
-                    "(raise fw_particle_settings.capacity) [device flags " + std::to_string(e) + ", segment " +
-                        std::to_string(ev[1]) + ": " + std::to_string(ev[2]) + " particles (" + std::to_string(ev[4]) +
-                        " resident), " + std::to_string(ev[3]) + " tiles launched]");
-    return FW_OK;  // FW_ERR_LOOKBACK_TIMEOUT is informational: the fallback path produced the same result
+    return cap;  // FW_ERR_LOOKBACK_TIMEOUT is informational: the fallback path produced the same result
 }
 
 // moves a segment into freshly allocated buffers of `ncap` slots: its live particles, in order, from slot 0 (a FIFO ring
@@ -1922,6 +1924,24 @@ bool poll_device_error(fw_ctx *ctx) {
     return true;
 }
 fw_status poisoned_status(fw_ctx *ctx) { return fail(ctx, FW_EHIP, ctx->poison_msg.empty() ? "spawner poisoned by an earlier internal error" : ctx->poison_msg); }
+// A check of the HOST half of fw_step failed after the frame's bookkeeping was committed (clocks, RNG serials, cohorts, ring heads
+// have advanced; a launch may be out): nothing can be rolled back, so the spawner the segment belongs to (every spawner, when no
+// segment is named) is treated like one a kernel's check failed for -- sticky until rebuilt or destroyed
+fw_status poison_segment(fw_ctx *ctx, uint32_t si, const std::string &what) {
+    bool one = false;
+    if (si < ctx->segs.size() && ctx->segs[si].in_use && ctx->segs[si].spawner >= 0 && (size_t)ctx->segs[si].spawner < ctx->spawners.size()) {
+        SpawnerHost &sp = ctx->spawners[ctx->segs[si].spawner];
+        if (!sp.poisoned) sp.poisoned = true, ctx->n_poisoned++;
+        one = true;
+    }
+    if (!one)
+        for (auto &sp : ctx->spawners)
+            if (sp.alive && !sp.poisoned) sp.poisoned = true, ctx->n_poisoned++;
+    ctx->poison_msg = "internal error: " + what + (one ? " (segment " + std::to_string(si) + ")" : std::string()) +
+                      "; the particle state of the spawner is invalid -- rebuild it with fw_spawner_update_settings (drops its "
+                      "particles) or destroy it";
+    return poisoned_status(ctx);
+}
 
 SpawnerHost *get_spawner(fw_ctx *ctx, fw_spawner h) {
     if (!ctx || h < 0 || (size_t)h >= ctx->spawners.size() || !ctx->spawners[h].alive) {
@@ -2299,6 +2319,9 @@ fw_status fw_spawner_update_settings(fw_ctx *ctx, fw_spawner h, const fw_spawner
     if (sp->poisoned) {
         // everything enqueued on top of the invalid state has finished: what those frames reported again is not news, and the
         // segment slots the report names are about to be reused by the rebuilt spawner
+        // (... but the word may by now name ANOTHER spawner, healthy so far -- one word, the last writer wins: mark it before the
+        // report is dropped)
+        poll_device_error(ctx);
         ctx->h_err[0] = ctx->h_err[1] = 0ull;
         const uint32_t zero = 0;
         FW_HIP(ctx, hipMemcpy(ctx->g.err, &zero, sizeof zero, hipMemcpyHostToDevice));
@@ -2345,6 +2368,7 @@ fw_status fw_spawner_destroy(fw_ctx *ctx, fw_spawner h) {
     fw_status st = sync(ctx);
     if (st) return st;
     if (sp->poisoned) {  // (as in fw_spawner_update_settings)
+        poll_device_error(ctx);
         ctx->h_err[0] = ctx->h_err[1] = 0ull;
         const uint32_t zero = 0;
         FW_HIP(ctx, hipMemcpy(ctx->g.err, &zero, sizeof zero, hipMemcpyHostToDevice));
@@ -2395,6 +2419,33 @@ fw_status fw_spawner_queue(fw_ctx *ctx, fw_spawner h, uint64_t count) {
     SpawnerHost *sp = get_spawner(ctx, h);
     if (!sp) return FW_EINVAL;
     sp->manual_queued_count += count;  // core.rs:284-286
+    return FW_OK;
+}
+
+fw_status fw_ctx_set_parent_velocities(fw_ctx *ctx, uint32_t n, const fw_spawner *handles, const float *velocities) {
+    if (!ctx || (n && (!handles || !velocities))) return FW_EINVAL;
+    for (uint32_t i = 0; i < n; i++)
+        if (!get_spawner(ctx, handles[i])) return fail(ctx, FW_EINVAL, "fw_ctx_set_parent_velocities: invalid spawner handle");
+    for (uint32_t i = 0; i < n; i++) memcpy(ctx->spawners[(size_t)handles[i]].parent_vel, velocities + (size_t)i * 3, 3 * sizeof(float));
+    return FW_OK;
+}
+
+fw_status fw_ctx_set_modifiers(fw_ctx *ctx, uint32_t n, const fw_spawner *handles, const float *scales, const float *speeds) {
+    if (!ctx || (n && (!handles || !scales || !speeds))) return FW_EINVAL;
+    for (uint32_t i = 0; i < n; i++)
+        if (!get_spawner(ctx, handles[i])) return fail(ctx, FW_EINVAL, "fw_ctx_set_modifiers: invalid spawner handle");
+    for (uint32_t i = 0; i < n; i++) {
+        SpawnerHost &sp = ctx->spawners[(size_t)handles[i]];
+        sp.mod_scale = scales[i], sp.mod_speed = speeds[i];
+    }
+    return FW_OK;
+}
+
+fw_status fw_ctx_queue(fw_ctx *ctx, uint32_t n, const fw_spawner *handles, const uint64_t *counts) {
+    if (!ctx || (n && (!handles || !counts))) return FW_EINVAL;
+    for (uint32_t i = 0; i < n; i++)
+        if (!get_spawner(ctx, handles[i])) return fail(ctx, FW_EINVAL, "fw_ctx_queue: invalid spawner handle");
+    for (uint32_t i = 0; i < n; i++) ctx->spawners[(size_t)handles[i]].manual_queued_count += counts[i];  // core.rs:284-286
     return FW_OK;
 }
 
@@ -3131,7 +3182,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             uint32_t k_ops = 0;
             for (const FwOp &op : ctx->fifo_ops) k_ops += op.seg == si ? 1u : 0u;
             if (k_ops > FW_INLINE_OPS)  // (build_spawner never makes such a type a ring)
-                return fail(ctx, FW_EHIP, "internal error: a FIFO ring with more spawn ops than its launch can carry");
+                return poison_segment(ctx, si, "a FIFO ring with more spawn ops than its launch can carry");
             if (fa.n_segs == FW_FIFO_PER_LAUNCH || f_ops + k_ops > FW_INLINE_OPS) FW_HIP(ctx, flush());
             const int32_t wm = S.derived ? 0 : S.fifo_wm;  // (FW_TYPE_DERIVED: none of the optional planes is stored)
             if (!fa.n_segs) fa.write_mask = wm;
@@ -3161,7 +3212,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     const volatile unsigned long long *row = S.h_report + (c.frame % kReportRing);
                     for (int spin = 0; (uint32_t)(*row >> 32) != ep && spin < 100000; spin++) __builtin_ia32_pause();
                     if ((uint32_t)(*row >> 32) != ep) FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                    if ((uint32_t)(*row >> 32) != ep) return fail(ctx, FW_EHIP, "internal error: cohort report missing");
+                    if ((uint32_t)(*row >> 32) != ep) return poison_segment(ctx, si, "cohort report missing");
                     c.n = (uint32_t)*row, c.known = true;
                 }
                 dead += c.n;
@@ -3294,7 +3345,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                         const volatile unsigned long long *row = S.h_report + (c.frame % kReportRing);
                         for (int spin = 0; (uint32_t)(*row >> 32) != ep && spin < 100000; spin++) __builtin_ia32_pause();
                         if ((uint32_t)(*row >> 32) != ep) FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                        if ((uint32_t)(*row >> 32) != ep) return fail(ctx, FW_EHIP, "internal error: cohort report missing (range ring)");
+                        if ((uint32_t)(*row >> 32) != ep) return poison_segment(ctx, si, "cohort report missing (range ring)");
                         c.n = (uint32_t)*row, c.known = true;
                     }
                     grad += c.n;
@@ -3443,7 +3494,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             // (86.4 against 86.5 us), 2.5 % slower at configs[2]: profiles/r04/range_xcd_order_ab.txt)
             for (size_t i = 0; i < nr && ok; i++) put_old(rs[i]), put_rest(rs[i]);
             for (size_t i = 0; i < nr && ok; i++) put_tail(rs[i]);
-            if (!ok) return fail(ctx, FW_EHIP, "internal error: range table overflow");
+            if (!ok) return poison_segment(ctx, kNoSeg, "range table overflow");
             ctx->r_total = (uint32_t)t;
             if (t) FW_HIP(ctx, hipMemcpyAsync(ctx->d_rdesc, ctx->h_rdesc, t * sizeof(FwRangeDesc), hipMemcpyHostToDevice, ctx->stream));
             FW_HIP(ctx, hipEventRecord(ctx->ev_rtab, ctx->stream));

@@ -79,7 +79,10 @@ __device__ __forceinline__ void fw_fifo_nest_parents(const FwGlobals &g, const F
     constexpr int BLK = FW_BLOCK, NW = BLK / 64, LBW = 4;
     __shared__ uint32_t s_w[R][NW];
     __shared__ uint32_t s_lb[2 * LBW * NW];
-    __shared__ uint32_t s_inc[NW][64];
+    // (per-parent counts and their inclusive prefix within the wave, for every round: in LDS rather than in 2 R registers that would
+    // be live across the whole spawn + first-update of the children -- the four-round form sat at 133 VGPRs with them)
+    __shared__ uint32_t s_inc[R][NW][64];
+    __shared__ uint32_t s_n[R][BLK];
     __shared__ __attribute__((aligned(16))) float4 s_par[NW][3][64];
     __shared__ __attribute__((aligned(16))) float s_ckeys[FW_KEYS_MAX];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -103,26 +106,25 @@ __device__ __forceinline__ void fw_fifo_nest_parents(const FwGlobals &g, const F
     const FwEmit &e = g.emits[N.emit];
     const FwType Tc = g.types[Fc.type_idx & ~FW_TYPE_IDX_NOSPIN];
     for (uint32_t i = tid; i < Fc.keys_len; i += BLK) s_ckeys[i] = g.keys[Fc.keys_off + i];
-    uint32_t n[R], inc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const uint32_t o = (uint32_t)(r * BLK) + tid, s = sbase + o;
         uint32_t i = s - head;  // list index of the slot
         if (s < head) i += C;
-        n[r] = 0;
+        uint32_t nr = 0;
         if (i < n_in) {
             float next;
             const uint64_t cnt = fw_emission_count(p_age[r], p_lea[r], F.life, N.n_start, N.n_end, N.n_count, &next);
-            n[r] = cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cnt;  // core.rs:490-498
-            fw_st1w(wl, o * 4u, next);                                 // other_particle.last_emitted_age[i] = next (core.rs:500)
+            nr = cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cnt;  // core.rs:490-498
+            fw_st1w(wl, o * 4u, next);                               // other_particle.last_emitted_age[i] = next (core.rs:500)
         }
-        uint32_t x = n[r];
+        uint32_t x = nr;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t u = __shfl_up(x, d, 64);
             if (lane >= (uint32_t)d) x = (x + u < x) ? 0xFFFFFFFFu : x + u;  // saturating
         }
-        inc[r] = x;
+        s_n[r][tid] = nr, s_inc[r][wave][lane] = x;
         if (lane == 63) s_w[r][wave] = x;
     }
     __syncthreads();
@@ -172,13 +174,7 @@ __device__ __forceinline__ void fw_fifo_nest_parents(const FwGlobals &g, const F
         }
         const uint32_t tw = s_w[r][wave];  // wave-uniform
         if (tw == 0) continue;
-        // (R is a compile-time constant but the loop is rolled: n / inc are indexed through a select chain, no scratch)
-        uint32_t nr = n[0], incr = inc[0];
-#pragma unroll
-        for (int q = 1; q < R; q++)
-            if (q == r) nr = n[q], incr = inc[q];
-        s_inc[wave][lane] = incr;
-        if (nr != 0) {
+        if (s_n[r][tid] != 0) {
             const uint32_t o16 = ((uint32_t)(r * BLK) + tid) * 16u;
             s_par[wave][0][lane] = fw_ld4w(w0, o16);
             s_par[wave][1][lane] = fw_ld4w(w1, o16);
@@ -193,7 +189,7 @@ __device__ __forceinline__ void fw_fifo_nest_parents(const FwGlobals &g, const F
                 uint32_t lo = 0, hi = 63;  // first lane whose inclusive prefix exceeds c
                 while (lo < hi) {
                     const uint32_t mid = (lo + hi) >> 1;
-                    if (s_inc[wave][mid] > c) hi = mid;
+                    if (s_inc[r][wave][mid] > c) hi = mid;
                     else lo = mid + 1;
                 }
                 const unsigned long long j = (unsigned long long)woff + c;  // child index within the entry
@@ -812,19 +808,43 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     }
     const uint32_t lim = min(base + TILE, n_old_in);
     const uint32_t bm1 = b + C - 1u;
-    float4 q0[R], q1[R], q2[R], q3[R];
+    // The tile holds position + age and velocity + initial_scale of its R rounds in registers (and each particle's lifetime);
+    // rotation and angular velocity of a type that can turn are PARKED IN LDS until the store loop (round 5): with them in
+    // registers as well the kernels of launches with such a type took 150-157 VGPRs -- 3 waves per SIMD for every workgroup of
+    // the launch, the streaming YOUNG ones included -- against 116 for the launches in which nothing turns.  A lane writes and
+    // reads its own entries only; the writes sit before the barrier in front of the published count, so the loads they consume
+    // have returned by then.
+    __shared__ __attribute__((aligned(16))) float4 s_q2[ALLNOSPIN ? 1 : TILE], s_q3[ALLNOSPIN ? 1 : TILE];
+    float4 q0[R], q1[R];
+    float lifev[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const uint32_t d = min(base + r * BLK + tid, lim - 1u);
         uint32_t s = bm1 - d;  // in [0, 2 C)
         if (s >= C) s -= C;
         q0[r] = fw_ld4w<NT == 2>(p0, s * 16u);
-        q3[r] = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p3, (s * 16u) & m2);
+        const float4 q3v = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p3, (s * 16u) & m2);
         const float lf = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : s * 4u);
         q1[r] = fw_ld4w<NT == 2>(p1, s * 16u);
-        q2[r] = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p2, (s * 16u) & m2);
-        if (nospin) q3[r] = make_float4(0.0f, 0.0f, 0.0f, lf);
+        const float4 q2v = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p2, (s * 16u) & m2);
+        lifev[r] = nospin ? lf : q3v.w;
+        if constexpr (!ALLNOSPIN) {
+            if (!nospin) s_q2[r * BLK + tid] = q2v, s_q3[r * BLK + tid] = q3v;  // (workgroup-uniform branch)
+        }
     }
+    // (rotation / angular velocity + lifetime of round r: from LDS, or -- a type that cannot turn -- nothing and the lifetime)
+    auto old_q2 = [&](int r) -> float4 {
+        if constexpr (!ALLNOSPIN) {
+            if (!nospin) return s_q2[r * BLK + tid];
+        }
+        return make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    };
+    auto old_q3 = [&](int r) -> float4 {
+        if constexpr (!ALLNOSPIN) {
+            if (!nospin) return s_q3[r * BLK + tid];
+        }
+        return make_float4(0.0f, 0.0f, 0.0f, lifev[r]);
+    };
     // a type other particles' entries emit from (Nested, core.rs:471-546) carries last_emitted_age per entry: those planes
     // move with the survivors (at most FW_RANGE_LK of them: the host keeps types with more off the range path)
     constexpr int FW_RANGE_LK = 2;
@@ -858,11 +878,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const bool valid = base + r * BLK + tid < lim;
-        const bool alive = valid && fw_survives(q0[r].w, a.dt, q3[r].w, &age_new[r]);
+        const bool alive = valid && fw_survives(q0[r].w, a.dt, lifev[r], &age_new[r]);
         m[r] = __ballot(alive);
         uint32_t c = (uint32_t)__popcll(m[r]);
         asm volatile("; fw_k_update_range: input held before the count is published"
-                     : "+v"(c) : "v"(q0[r].x), "v"(q1[r].x), "v"(q2[r].x), "v"(q3[r].w));
+                     : "+v"(c) : "v"(q0[r].x), "v"(q1[r].x), "v"(lifev[r]));
         if (nlp) asm volatile("; ... and the last_emitted_age planes" : "+v"(c) : "v"(lkv[0][r]), "v"(lkv[1][r]));
         if (lane == 0) s_cnt[r][wave] = c;
     }
@@ -909,7 +929,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
         if (alive) {
             uint32_t s = bm1 - od;
             if (s >= C) s -= C;
-            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, q0[r], q1[r], q2[r], q3[r], age_new[r], W, s, rec, COLL ? &cpos : nullptr,
+            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, q0[r], q1[r], old_q2(r), old_q3(r), age_new[r], W, s, rec, COLL ? &cpos : nullptr,
                                               COLL ? &cvel : nullptr, nullptr, false, false, CA.on);
             if (nlp) {
 #pragma unroll
@@ -924,13 +944,13 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
             // just loaded: evaluated again here (same functions, same inputs) instead of being read -- the slot may
             // already belong to somebody else.  Records are filled from the END of the buffer (the youngest dead first):
             // fw_spawner_read_destroyed reads the last `ndestroyed` records, which are then in list order.
-            const float ap = q0[r].w / q3[r].w;
+            const float ap = q0[r].w / lifev[r];
             float bc[4], em[4];
             fw_gradient_sample(T.bc_kind, T.bc_n, s_keys + T.o_bc_t, s_keys + T.o_bc_v, ap, bc);
             fw_gradient_sample(T.em_kind, T.em_n, s_keys + T.o_em_t, s_keys + T.o_em_v, ap, em);
             const float sc = q1[r].w * fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, ap);
             const uint32_t dead_rank = d - od;  // the dead nearer to the young part
-            fw_store_destroyed_vals(Sp->destroyed, (size_t)(C - 1u - dead_rank), T, q0[r], q1[r], q2[r], q3[r], q0[r].w + a.dt, bc, em, sc);
+            fw_store_destroyed_vals(Sp->destroyed, (size_t)(C - 1u - dead_rank), T, q0[r], q1[r], old_q2(r), old_q3(r), q0[r].w + a.dt, bc, em, sc);
         }
     }
     if (lim == n_old_in && tid == 0) {  // the tile furthest from the young part knows the totals

@@ -256,6 +256,27 @@ class ParticleSystem:
             ro[4 * i:4 * i + 4] = [float(c) for c in t.rotation]
         self._check(self._lib.fw_ctx_set_origins(self._ctx, n, handles, tr, ro))
 
+    # the other per-frame inputs of MANY spawners in one FFI call each (ABI 5): what sync_parent_velocity (core.rs:706-736),
+    # propagate_particle_spawner_modifier (core.rs:690-703) and a gameplay system that queues on its OnDemand spawners write
+    def set_parent_velocities(self, spawners, velocities) -> None:
+        n = len(spawners)
+        handles = (C.c_int32 * max(n, 1))(*[d.handle for d in spawners])
+        v = (C.c_float * max(3 * n, 1))(*[float(c) for vel in velocities for c in vel])
+        self._check(self._lib.fw_ctx_set_parent_velocities(self._ctx, n, handles, v))
+
+    def set_modifiers(self, spawners, modifiers) -> None:
+        n = len(spawners)
+        handles = (C.c_int32 * max(n, 1))(*[d.handle for d in spawners])
+        sc = (C.c_float * max(n, 1))(*[float(m.scale) for m in modifiers])
+        sp = (C.c_float * max(n, 1))(*[float(m.speed) for m in modifiers])
+        self._check(self._lib.fw_ctx_set_modifiers(self._ctx, n, handles, sc, sp))
+
+    def queue_particles(self, spawners, counts) -> None:
+        n = len(spawners)
+        handles = (C.c_int32 * max(n, 1))(*[d.handle for d in spawners])
+        cn = (C.c_uint64 * max(n, 1))(*[int(c) for c in counts])
+        self._check(self._lib.fw_ctx_queue(self._ctx, n, handles, cn))
+
     def step(self, dt: float) -> None:
         """Enqueue one frame (spawn_particles + update_particles) without touching transforms or callbacks."""
         self._check(self._lib.fw_step(self._ctx, float(dt)))

@@ -393,6 +393,25 @@ class ParticleSystemPlugin {
         }
     }
     void step(float dt) { check(fw_step(ctx_, dt)); }  // enqueue only: no transforms, no callbacks
+    // the other per-frame inputs of MANY spawners in one FFI call each (ABI 5): sync_parent_velocity (core.rs:706-736),
+    // propagate_particle_spawner_modifier (core.rs:690-703), queue_particles (core.rs:284-286) on a set of OnDemand spawners
+    void set_parent_velocities(const std::vector<ParticleSpawnerData *> &ds, const std::vector<Vec3> &vs) {
+        std::vector<fw_spawner> h;
+        std::vector<float> v;
+        for (size_t i = 0; i < ds.size(); i++) h.push_back(ds[i]->handle), v.insert(v.end(), {vs[i].x, vs[i].y, vs[i].z});
+        check(fw_ctx_set_parent_velocities(ctx_, (uint32_t)h.size(), h.data(), v.data()));
+    }
+    void set_modifiers(const std::vector<ParticleSpawnerData *> &ds, const std::vector<EffectModifier> &ms) {
+        std::vector<fw_spawner> h;
+        std::vector<float> sc, sp;
+        for (size_t i = 0; i < ds.size(); i++) h.push_back(ds[i]->handle), sc.push_back(ms[i].scale), sp.push_back(ms[i].speed);
+        check(fw_ctx_set_modifiers(ctx_, (uint32_t)h.size(), h.data(), sc.data(), sp.data()));
+    }
+    void queue_particles(const std::vector<ParticleSpawnerData *> &ds, const std::vector<uint64_t> &counts) {
+        std::vector<fw_spawner> h;
+        for (auto *d : ds) h.push_back(d->handle);
+        check(fw_ctx_queue(ctx_, (uint32_t)h.size(), h.data(), counts.data()));
+    }
     void synchronize() { check(fw_ctx_synchronize(ctx_)); }
     uint64_t live_count() {
         uint64_t n = 0;

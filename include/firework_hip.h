@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 4
+#define FW_ABI_VERSION 5
 /* (no FW_MAX_TYPES / FW_MAX_EMISSIONS / FW_MAX_KEYS / FW_MAX_COLLIDERS: the reference's Vec<ParticleSettings>,
  * Vec<EmissionSettings> (core.rs:178-185), curve sample vectors (curve.rs:40-75) and collider world are unbounded, and so
  * are the descriptors below -- FW_EINVAL is for input the reference itself rejects.  Curves and gradients of up to
@@ -220,6 +220,15 @@ fw_status fw_ctx_set_origins(fw_ctx *ctx, uint32_t n, const fw_spawner *handles,
 fw_status fw_spawner_set_parent_velocity(fw_ctx *ctx, fw_spawner h, const float v[3]); /* core.rs:276,444-448 */
 fw_status fw_spawner_set_modifier(fw_ctx *ctx, fw_spawner h, float scale, float speed); /* EffectModifier core.rs:323-327 */
 fw_status fw_spawner_queue(fw_ctx *ctx, fw_spawner h, uint64_t count);                  /* queue_particles core.rs:284-286 */
+/* ... and the same three for MANY spawners in one call each (ABI 5).  The reference rewrites these inputs for whole sets of
+ * spawners every frame -- sync_parent_velocity walks every spawner under a rigid body (core.rs:706-736),
+ * propagate_particle_spawner_modifier every spawner under an EffectModifier (core.rs:690-703), a gameplay system queues
+ * particles on every OnDemand spawner it owns -- and a host with thousands of emitters would cross the FFI once per spawner
+ * per frame for each.  handles[n]; velocities[n][3]; scales[n], speeds[n]; counts[n] (added to what is queued, core.rs:284-286).
+ * All-or-nothing like fw_ctx_set_origins: one invalid handle -> FW_EINVAL and nothing changes. */
+fw_status fw_ctx_set_parent_velocities(fw_ctx *ctx, uint32_t n, const fw_spawner *handles, const float *velocities);
+fw_status fw_ctx_set_modifiers(fw_ctx *ctx, uint32_t n, const fw_spawner *handles, const float *scales, const float *speeds);
+fw_status fw_ctx_queue(fw_ctx *ctx, uint32_t n, const fw_spawner *handles, const uint64_t *counts);
 
 /* ---- the frame: spawn_particles then update_particles for every spawner -------- */
 fw_status fw_step(fw_ctx *ctx, float dt); /* core.rs:367-551 + 577-670 */

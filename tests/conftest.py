@@ -42,6 +42,21 @@ def pytest_generate_tests(metafunc):
         metafunc.parametrize("fw_path", ["fifo", "range", "general"], indirect=True)
 
 
+def _four_round_tiles(request) -> bool:
+    """Ring launches of fewer than FW_FIFO_SMALL / FW_RANGE_SMALL four-round tiles in all run on one-round tiles (TR = 1) -- what
+    the product picks for nearly every test of the suite, whose rings are small; large rings run the four-round kernels
+    (TR = 4).  Both instantiations need the suite: every test FUNCTION is assigned one of the two, by a hash of its name (stable
+    across runs and paths), so about half of the parity / limits / examples / golden tests exercise the kernels the product
+    itself would pick at their size and the other half the ones it picks at BASELINE sizes (the suite used to force
+    four-round tiles nearly everywhere).  tests/test_gpu_fifo.py and tests/test_gpu_range.py run both forms of every test of
+    theirs; the fuzz and tests/test_gpu_lifecycle.py use the product's choice."""
+    import zlib
+
+    if request.module.__name__.split(".")[-1] == "test_gpu_fuzz":
+        return False
+    return (zlib.crc32(request.node.originalname.encode() if getattr(request.node, "originalname", None) else request.node.name.encode()) & 1) == 0
+
+
 @pytest.fixture(autouse=True)
 def fw_path(request, monkeypatch):
     mode = getattr(request, "param", None)
@@ -50,19 +65,13 @@ def fw_path(request, monkeypatch):
         monkeypatch.setenv("FW_FIFO", "1")
         monkeypatch.setenv("FW_FIFO_MIN", "0")
         monkeypatch.setenv("FW_RANGE", "0")
-        # (FIFO launches of fewer than FW_FIFO_SMALL four-round tiles use one-round tiles: nearly every test of the suite would.
-        # The suite keeps the four-round tiles -- what large rings run -- except in tests/test_gpu_fifo.py, which runs both, the
-        # collision tests -- colliding launches always use one-round tiles -- the fuzz's default environments and the product-default
-        # tests of tests/test_gpu_configs.py)
-        if request.module.__name__.split(".")[-1] != "test_gpu_fuzz":
+        if _four_round_tiles(request):
             monkeypatch.setenv("FW_FIFO_SMALL", "0")
     elif mode == "range":
         monkeypatch.setenv("FW_FIFO", "0")
         monkeypatch.setenv("FW_RANGE", "1")
         monkeypatch.setenv("FW_RANGE_MIN", "0")
-        # (as for FIFO rings: small range launches use one-round tiles; the suite keeps the four-round tiles except in
-        # tests/test_gpu_range.py, which runs both, the fuzz's default environments and the product-default tests)
-        if request.module.__name__.split(".")[-1] != "test_gpu_fuzz":
+        if _four_round_tiles(request):
             monkeypatch.setenv("FW_RANGE_SMALL", "0")
     elif mode == "general":
         monkeypatch.setenv("FW_FIFO", "0")

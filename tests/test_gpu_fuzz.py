@@ -341,21 +341,21 @@ test_every_shortcut_gives_the_state_of_the_plain_path.sizes = {}
 
 
 def _collider(rng):
-    k = int(rng.integers(0, 5))
+    k = int(rng.choice([0, 0, 1, 2, 3, 4]))  # (planes twice as often: the collider most particles meet)
     layers = int(rng.choice([1, 1, 2, 3]))
+    # (solids sit where the particles pass: the emitters are around (0, 2, 0) and mostly point down)
+    centre = lambda: (float(rng.uniform(-1.3, 1.3)), float(rng.uniform(-1.5, 1.8)), float(rng.uniform(-1.3, 1.3)))
     if k >= 3:  # cylinder / cone (examples/textures.rs:195, 211), tilted
         q = rng.normal(size=4)
         make = S.Collider.Cylinder if k == 3 else S.Collider.Cone
-        return make(tuple(float(c) for c in rng.uniform(-2.0, 2.0, size=3)), float(rng.uniform(0.3, 1.2)), float(rng.uniform(0.2, 1.6)),
-                    tuple(float(c) for c in q / np.linalg.norm(q)), layers)
+        return make(centre(), float(rng.uniform(0.4, 1.4)), float(rng.uniform(0.2, 1.6)), tuple(float(c) for c in q / np.linalg.norm(q)), layers)
     if k == 0:
         return S.Collider.Plane(tuple(float(c) for c in rng.uniform(-1.0, 0.5, size=3)),
                                 tuple(float(c) for c in (rng.normal(size=3) * 0.3 + np.array([0.0, 1.0, 0.0]))), layers)
     if k == 1:
-        return S.Collider.Sphere(tuple(float(c) for c in rng.uniform(-2.0, 2.0, size=3)), float(rng.uniform(0.2, 1.2)), layers)
+        return S.Collider.Sphere(centre(), float(rng.uniform(0.2, 1.2)), layers)
     q = rng.normal(size=4)
-    return S.Collider.Box(tuple(float(c) for c in rng.uniform(-2.0, 2.0, size=3)),
-                          tuple(float(c) for c in rng.uniform(0.2, 1.0, size=3)), tuple(float(c) for c in q / np.linalg.norm(q)), layers)
+    return S.Collider.Box(centre(), tuple(float(c) for c in rng.uniform(0.2, 1.0, size=3)), tuple(float(c) for c in q / np.linalg.norm(q)), layers)
 
 
 @pytest.mark.parametrize("case", range(OFF, OFF + 16 + EXTRA // 4))

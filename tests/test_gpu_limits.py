@@ -61,29 +61,47 @@ def test_eleven_particle_types_and_fourteen_emission_entries(system):
 
 
 def test_more_ring_types_than_one_fifo_launch_holds(monkeypatch):
-    """twelve one-lifetime types in a context: eight FIFO rings (their records ride in one launch's arguments), the rest on
-    range rings -- none falls back to the compacting path"""
+    """twelve one-lifetime types in a context.  Eight are eight FIFO rings (their records ride in one launch's arguments); the
+    ninth takes a range ring and -- round 5, fw_ctx::n_spilled -- the eight FIFO rings, full of particles by then, become range
+    rings where they stand (fifo_to_range: nothing copied), so that a frame stays ONE kind of launch; none falls back to the
+    compacting path.  (The same at product thresholds: tests/test_gpu_range.py, tests/test_gpu_lifecycle.py.)"""
     from bevy_firework_amd.system import ParticleSystem
 
     monkeypatch.setenv("FW_FIFO", "1"), monkeypatch.setenv("FW_FIFO_MIN", "0")
     monkeypatch.setenv("FW_RANGE", "1"), monkeypatch.setenv("FW_RANGE_MIN", "0")
     with ParticleSystem(device=0, seed=SEED) as system:
         pairs = []
-        for k in range(12):
+
+        def add(k):
             ps = S.ParticleSettings(lifetime=S.RandF32.constant(0.3 + 0.02 * k), linear_drag=0.2,
                                     base_color=S.FireworkGradient.uneven_samples(workloads.STRESS_GRADIENT))
             es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(4000.0 + 500.0 * k),
                                     initial_velocity=S.RandVec3(S.RandF32(1.0, 5.0), (0.0, 1.0, 0.0), 0.0))
             pairs.append(Pair(system, S.ParticleSpawner([ps], [es]), S.Transform((float(k), 0.0, 0.0)), seed=SEED, uid=300 + k))
-        modes = [p.gpu.update_path(0)[0] for p in pairs]
-        assert modes.count("fifo") == 8 and modes.count("range") == 4, modes
-        for fr in range(70):
-            system.update(DT)
-            for p in pairs:
-                p.step_cpu(DT)
-            if fr % 10 == 9:
-                for k, p in enumerate(pairs):
-                    p.check(exact_all=True, what=f"frame {fr} spawner {k}")
+
+        def run(n, what):
+            for fr in range(n):
+                system.update(DT)
+                for p in pairs:
+                    p.step_cpu(DT)
+                if fr % 10 == 9 or fr == n - 1:
+                    for k, p in enumerate(pairs):
+                        p.check(exact_all=True, what=f"{what}, frame {fr} spawner {k}")
+
+        for k in range(8):
+            add(k)
+        assert [p.gpu.update_path(0)[0] for p in pairs] == ["fifo"] * 8
+        run(27, "eight FIFO rings")  # (lifetimes 0.30-0.44 s: the first rings lose particles by now, the last are a few frames from it)
+        add(8)
+        assert [p.gpu.update_path(0)[0] for p in pairs] == ["range"] * 9
+        for k, p in enumerate(pairs):
+            p.check(exact_all=True, what=f"right after the ninth type, spawner {k}")
+        run(6, "nine range rings")
+        for k in range(9, 12):
+            add(k)
+        assert [p.gpu.update_path(0)[0] for p in pairs] == ["range"] * 12
+        run(50, "twelve range rings")
+        assert all(p.gpu.count(0) > 1000 for p in pairs)
 
 
 @pytest.mark.parametrize("defaults", [False, True])
@@ -169,6 +187,51 @@ def test_a_hundred_colliders_that_move_every_frame(system):
         if fr % 12 == 11:
             pair.check(exact_all=True, what=f"frame {fr}")
     assert pair.gpu.count(0) > 4000
+
+
+def test_batched_parent_velocities_modifiers_and_queues(system):
+    """fw_ctx_set_parent_velocities / fw_ctx_set_modifiers / fw_ctx_queue (ABI 5: what sync_parent_velocity, core.rs:706-736,
+    propagate_particle_spawner_modifier, core.rs:690-703, and a gameplay system write for whole sets of spawners every frame):
+    the same effect as one call per spawner; one invalid handle -> FW_EINVAL and nothing changes"""
+    import ctypes as C
+
+    from bevy_firework_amd import _ffi
+
+    rng = np.random.default_rng(12)
+    pairs = []
+    for k in range(6):
+        sp, _ = workloads.stress_test(rate=3000.0)
+        if k % 2:
+            sp.emission_settings[0].emission_pacing = S.EmissionPacing.OnDemand()
+        pairs.append(Pair(system, sp, S.Transform((float(k), 0.1, 0.0)), seed=SEED, uid=520 + k))
+    gpus = [p.gpu for p in pairs]
+    for fr in range(30):
+        vs = [tuple(float(np.float32(c)) for c in rng.uniform(-2.0, 2.0, size=3)) for _ in pairs]
+        ms = [S.EffectModifier(float(np.float32(rng.uniform(0.5, 2.0))), float(np.float32(rng.uniform(0.5, 2.0)))) for _ in pairs]
+        qs = [int(rng.integers(0, 300)) if k % 2 else 0 for k in range(len(pairs))]
+        system.set_parent_velocities(gpus, vs)
+        system.set_modifiers(gpus, ms)
+        system.queue_particles(gpus, qs)
+        for p, v, m, q in zip(pairs, vs, ms, qs):
+            p.cpu.set_parent_velocity(v), p.cpu.set_modifier(m), p.cpu.queue_particles(q)
+        system.update(DT)
+        for p in pairs:
+            p.step_cpu(DT)
+    lib, ctx = system._lib, system._ctx
+    n = len(pairs)
+    handles = (C.c_int32 * n)(*[p.gpu.handle for p in pairs])
+    handles[4] = 9999  # not a spawner
+    big3, big1, cnt = (C.c_float * (3 * n))(*([50.0] * (3 * n))), (C.c_float * n)(*([9.0] * n)), (C.c_uint64 * n)(*([100000] * n))
+    assert lib.fw_ctx_set_parent_velocities(ctx, n, handles, big3) == _ffi.FW_EINVAL
+    assert lib.fw_ctx_set_modifiers(ctx, n, handles, big1, big1) == _ffi.FW_EINVAL
+    assert lib.fw_ctx_queue(ctx, n, handles, cnt) == _ffi.FW_EINVAL
+    for fr in range(30, 50):  # nothing of the refused calls took effect
+        system.update(DT)
+        for p in pairs:
+            p.step_cpu(DT)
+    for k, p in enumerate(pairs):
+        p.check(what=f"spawner {k}")
+    assert all(p.gpu.counts()[0] > 1000 for p in pairs[::2]) and sum(p.gpu.counts()[0] for p in pairs[1::2]) > 1000
 
 
 def test_batched_origins_are_all_or_nothing(system):
