@@ -72,11 +72,23 @@ FW_HD bool fw_ray_collider(const FwCollider &c, fw_v3 origin, fw_v3 dir, float m
         *hit = FwRayHit{t, fw_normalize3(p)};
         return true;
     }
+    // BOX, CYLINDER, CONE: solids with a frame of their own.  The ray is taken into that frame ONCE, each kind finds where the ray
+    // enters (distance + the surface normal there, in the frame), and the normal is taken back ONCE: three inlined copies of the
+    // rotations took the colliding ring kernels from 113 to 141 VGPRs (4 -> 3 waves per SIMD).
     const fw_q4 q{c.rotation[0], c.rotation[1], c.rotation[2], c.rotation[3]};
     const fw_q4 qi{-q.x, -q.y, -q.z, q.w};  // conjugate = inverse of a unit quaternion
-    if (c.kind == 3) {  // CYLINDER (avian Collider::cylinder(radius, height): axis = local Y, examples/textures.rs:195): the slab
-                        // |y| <= half height intersected with the infinite cylinder x^2 + z^2 <= r^2, in the collider's frame
-        const fw_v3 ol = fw_quat_mul_vec3(qi, fw_sub3(origin, cpos)), dl = fw_quat_mul_vec3(qi, dir);
+    // (an axis-aligned solid -- the identity rotation, e.g. the ground slab of examples/stress_test_collision.rs, the cylinder and
+    // the cone of examples/textures.rs -- needs no rotations: Quat::IDENTITY * v is v itself up to the sign of a zero component,
+    // which no comparison or quotient below depends on (a zero direction component takes the `== 0` arm); the results are the
+    // general path's, numerically equal)
+    const bool aligned = q.x == 0.0f && q.y == 0.0f && q.z == 0.0f && q.w == 1.0f;
+    const fw_v3 ol = aligned ? fw_sub3(origin, cpos) : fw_quat_mul_vec3(qi, fw_sub3(origin, cpos));
+    const fw_v3 dl = aligned ? dir : fw_quat_mul_vec3(qi, dir);
+    float t_hit;
+    fw_v3 nl{0.0f, 0.0f, 0.0f};
+    if (c.kind == 3) {
+        // CYLINDER (avian Collider::cylinder(radius, height): axis = local Y, examples/textures.rs:195): the slab |y| <= half height
+        // intersected with the infinite cylinder x^2 + z^2 <= r^2
         const float hh = c.half_extents[1], rr = c.radius * c.radius;
         const float c2 = (ol.x * ol.x + ol.z * ol.z) - rr;
         if (fabsf(ol.y) <= hh && c2 <= 0.0f) {  // inside (or on) the solid
@@ -111,13 +123,11 @@ FW_HD bool fw_ray_collider(const FwCollider &c, fw_v3 origin, fw_v3 dir, float m
             if (tnear > tfar) return false;
         }
         if (!(tnear >= 0.0f && tnear <= max_distance)) return false;
-        const fw_v3 nl = side == 0 ? fw_v3{0.0f, sign, 0.0f} : fw_normalize3(fw_v3{ol.x + dl.x * tnear, 0.0f, ol.z + dl.z * tnear});
-        *hit = FwRayHit{tnear, fw_quat_mul_vec3(q, nl)};
-        return true;
-    }
-    if (c.kind == 4) {  // CONE (avian Collider::cone(radius, height): base disc at local y = -h/2, apex at y = +h/2, examples/textures.rs:211):
-                        // w = p - apex; the solid is  w.y <= 0,  y >= -h/2,  w.x^2 + w.z^2 <= k^2 w.y^2  with k = radius / height
-        const fw_v3 ol = fw_quat_mul_vec3(qi, fw_sub3(origin, cpos)), dl = fw_quat_mul_vec3(qi, dir);
+        t_hit = tnear;
+        nl = side == 0 ? fw_v3{0.0f, sign, 0.0f} : fw_normalize3(fw_v3{ol.x + dl.x * tnear, 0.0f, ol.z + dl.z * tnear});
+    } else if (c.kind == 4) {
+        // CONE (avian Collider::cone(radius, height): base disc at local y = -h/2, apex at y = +h/2, examples/textures.rs:211):
+        // w = p - apex; the solid is  w.y <= 0,  y >= -h/2,  w.x^2 + w.z^2 <= k^2 w.y^2  with k = radius / height
         const float hh = c.half_extents[1], rr = c.radius * c.radius;
         const float k = c.radius / (hh + hh), k2 = k * k;
         const float wy = ol.y - hh;
@@ -153,31 +163,24 @@ FW_HD bool fw_ray_collider(const FwCollider &c, fw_v3 origin, fw_v3 dir, float m
             if (tb2 >= 0.0f && tb2 < INFINITY && yb >= -hh && yb <= hh && tb2 < best) best = tb2, side = 1;
         }
         if (side < 0 || !(best <= max_distance)) return false;
-        fw_v3 nl{0.0f, -1.0f, 0.0f};
+        t_hit = best;
+        nl = fw_v3{0.0f, -1.0f, 0.0f};
         if (side == 1) {
             const fw_v3 w{ol.x + dl.x * best, (ol.y + dl.y * best) - hh, ol.z + dl.z * best};
             const fw_v3 g{w.x, -(k2 * w.y), w.z};  // gradient of x^2 + z^2 - k^2 y^2: outward on the lower nappe
             nl = (g.x == 0.0f && g.y == 0.0f && g.z == 0.0f) ? fw_v3{0.0f, 1.0f, 0.0f} : fw_normalize3(g);
         }
-        *hit = FwRayHit{best, fw_quat_mul_vec3(q, nl)};
-        return true;
-    }
-    // BOX: slabs in the box's own frame
-    // (an axis-aligned box -- the identity rotation, e.g. the ground slab of examples/stress_test_collision.rs -- needs no
-    // rotations: Quat::IDENTITY * v is v itself up to the sign of a zero component, which no comparison or quotient below
-    // depends on (a zero direction component takes the `== 0` arm); the results are the general path's bit for bit)
-    const bool aligned = q.x == 0.0f && q.y == 0.0f && q.z == 0.0f && q.w == 1.0f;
-    const fw_v3 ol = aligned ? fw_sub3(origin, cpos) : fw_quat_mul_vec3(qi, fw_sub3(origin, cpos));
-    const fw_v3 dl = aligned ? dir : fw_quat_mul_vec3(qi, dir);
-    // (the three slabs written out one by one, in axis order: indexed arrays of three would live in scratch memory on the device)
-    const float hx = c.half_extents[0], hy = c.half_extents[1], hz = c.half_extents[2];
-    if (fabsf(ol.x) <= hx && fabsf(ol.y) <= hy && fabsf(ol.z) <= hz) {  // inside (or on) the box
-        *hit = FwRayHit{0.0f, fw_v3{0.0f, 0.0f, 0.0f}};
-        return true;
-    }
-    float tnear = -INFINITY, tfar = INFINITY;
-    int axis = 0;
-    float sign = 0.0f;
+    } else {
+        // BOX: slabs in the box's own frame
+        // (the three slabs written out one by one, in axis order: indexed arrays of three would live in scratch memory on the device)
+        const float hx = c.half_extents[0], hy = c.half_extents[1], hz = c.half_extents[2];
+        if (fabsf(ol.x) <= hx && fabsf(ol.y) <= hy && fabsf(ol.z) <= hz) {  // inside (or on) the box
+            *hit = FwRayHit{0.0f, fw_v3{0.0f, 0.0f, 0.0f}};
+            return true;
+        }
+        float tnear = -INFINITY, tfar = INFINITY;
+        int axis = 0;
+        float sign = 0.0f;
 #define FW_SLAB(o, d, h, i)                                                              \
     if ((d) == 0.0f) {                                                                   \
         if (fabsf(o) > (h)) return false;                                                \
@@ -193,16 +196,17 @@ FW_HD bool fw_ray_collider(const FwCollider &c, fw_v3 origin, fw_v3 dir, float m
         if (t2 < tfar) tfar = t2;                                                        \
         if (tnear > tfar) return false;                                                  \
     }
-    FW_SLAB(ol.x, dl.x, hx, 0)
-    FW_SLAB(ol.y, dl.y, hy, 1)
-    FW_SLAB(ol.z, dl.z, hz, 2)
+        FW_SLAB(ol.x, dl.x, hx, 0)
+        FW_SLAB(ol.y, dl.y, hy, 1)
+        FW_SLAB(ol.z, dl.z, hz, 2)
 #undef FW_SLAB
-    if (!(tnear >= 0.0f && tnear <= max_distance)) return false;
-    fw_v3 nl{0.0f, 0.0f, 0.0f};
-    if (axis == 0) nl.x = sign;
-    else if (axis == 1) nl.y = sign;
-    else nl.z = sign;
-    *hit = FwRayHit{tnear, aligned ? nl : fw_quat_mul_vec3(q, nl)};
+        if (!(tnear >= 0.0f && tnear <= max_distance)) return false;
+        t_hit = tnear;
+        if (axis == 0) nl.x = sign;
+        else if (axis == 1) nl.y = sign;
+        else nl.z = sign;
+    }
+    *hit = FwRayHit{t_hit, aligned ? nl : fw_quat_mul_vec3(q, nl)};
     return true;
 }
 

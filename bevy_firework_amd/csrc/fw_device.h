@@ -174,7 +174,8 @@ struct alignas(16) FwNestOp {
     float parent_rot[4];
     uint32_t parent_range, child_range;  // 1: the segment is a RANGE ring -- its `head` above is the slot of its first young
                                          // particle, particle 0 sits FwGlobals::rold slots before it (fw_ring_head)
-    uint32_t pad2[2];
+    uint32_t ticket_base;    // value of FwGlobals::nest_start[emit_slot] when the launch starts (fw_kernels.h: START tickets)
+    uint32_t pad2;
 };
 
 // decoupled look-back status word: {epoch:30 | state:2 | value:32}

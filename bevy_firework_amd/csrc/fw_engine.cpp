@@ -344,6 +344,7 @@ struct alignas(64) SegHost {
     uint32_t r_low[3] = {0, 0, 0};               // frames in a row a role's need has been far below what is provided
     uint32_t r_need[3] = {0, 0, 0};              // what each role needed in the latest frame (the table keeps more: fit())
     uint32_t r_status_base = 0;                  // first look-back word of its OLD workgroups in the current table
+    uint32_t ticket_base = 0;                    // value of FwGlobals::range_ticket[segment] at the start of the next launch (START tickets)
     // ... in a spawner WITH Nested entries (core.rs:471-546):
     //   range_mat  other particles' entries emit FROM this type: in frames that run a Nested pass its Global particles are
     //              materialised behind the young part by fw_k_spawn before the pass (core.rs:488) and fw_k_update_range
@@ -484,6 +485,8 @@ struct fw_ctx {
     DevArray<float> d_keys;
     DevArray<FwEmit> d_emits;
     DevArray<unsigned long long> d_emit_serial;
+    DevArray<uint32_t> d_nest_start;             // FwGlobals::nest_start: START tickets of the Nested entries (one per emit slot)
+    std::vector<uint32_t> nest_ticket_base;      // ... and the value each has at the start of the next launch that uses it
     uint32_t max_seg = 0;
     size_t tiles_cap = 0, nest_tiles_cap = 0, nest_ops_cap = 0;
 
@@ -594,6 +597,11 @@ struct fw_ctx {
     // quarter of hysteresis, a change re-sends the table.
     uint32_t range_small_tiles = 384;
     bool range_small = false;
+    // Rounds of the YOUNG workgroups of a four-round launch, chosen per launch (round 5): tiles of 512 slots (2) when the range
+    // rings of the context hold range_young_big particles each or more on average (hysteresis of a quarter; a change re-sends the
+    // table), 1024 (4) otherwise and always with an attached instance buffer.  FW_RANGE_YOUNG_BIG=n (0: never)
+    uint32_t range_young_rounds = 4;
+    uint32_t range_young_big = 32768;
     std::vector<FwOp> range_ops;  // this frame's Global ops that feed range rings
     // age, BEFORE the current frame's update, of a particle born in frame f -- the same for every segment of the context:
     // born with age 0, then one fp32 addition per frame (core.rs:594), exactly the device's additions
@@ -770,6 +778,16 @@ fw_status ensure_max_seg(fw_ctx *ctx, uint32_t need) {
         if (ctx->h_snap) FW_HIP(ctx, hipHostFree(ctx->h_snap));
         ctx->h_snap = nh;
         for (int i = 0; i < kSnapRing; i++) ctx->snap_pending[i] = false;
+    }
+    {
+        uint32_t *np = nullptr;
+        FW_HIP(ctx, hipMalloc((void **)&np, (size_t)nmax * sizeof(uint32_t)));
+        FW_HIP(ctx, fw_memset_done(np, 0, (size_t)nmax * sizeof(uint32_t)));
+        if (ctx->g.range_ticket) {
+            FW_HIP(ctx, hipMemcpy(np, ctx->g.range_ticket, ctx->max_seg * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+            FW_HIP(ctx, hipFree(ctx->g.range_ticket));
+        }
+        ctx->g.range_ticket = np;
     }
     if (ctx->d_segids) FW_HIP(ctx, hipFree(ctx->d_segids));
     FW_HIP(ctx, hipMalloc((void **)&ctx->d_segids, (size_t)nmax * sizeof(uint32_t)));
@@ -1449,11 +1467,13 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
     if ((st = dev_reserve(ctx, ctx->d_type_coll, ctx->n_types + nt, ctx->n_types))) return st;
     if ((st = dev_reserve(ctx, ctx->d_emits, ctx->n_emits + ne, ctx->n_emits))) return st;
     if ((st = dev_reserve(ctx, ctx->d_emit_serial, ctx->n_emit_slots + ne, ctx->n_emit_slots))) return st;
+    if ((st = dev_reserve(ctx, ctx->d_nest_start, ctx->n_emit_slots + ne, ctx->n_emit_slots))) return st;
+    if (ctx->nest_ticket_base.size() < ctx->n_emit_slots + ne) ctx->nest_ticket_base.resize(ctx->n_emit_slots + ne, 0u);
     if ((st = dev_reserve(ctx, ctx->d_segs, ctx->segs.size() + nt, ctx->segs.size()))) return st;
     if ((st = ensure_max_seg(ctx, (uint32_t)ctx->segs.size() + nt))) return st;
     ctx->g.type_coll = ctx->d_type_coll.d;
     ctx->g.types = ctx->d_types.d, ctx->g.emits = ctx->d_emits.d, ctx->g.keys = ctx->d_keys.d;
-    ctx->g.segs = ctx->d_segs.d, ctx->g.emit_serial = ctx->d_emit_serial.d;
+    ctx->g.segs = ctx->d_segs.d, ctx->g.emit_serial = ctx->d_emit_serial.d, ctx->g.nest_start = ctx->d_nest_start.d;
 
     std::vector<uint32_t> caps(nt, 0);
     for (int pass = 0; pass < 2; pass++)
@@ -1669,6 +1689,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             FW_HIP(ctx, hipMemcpy(ctx->g.rold + (size_t)r * ctx->max_seg + si, zero2, 4, hipMemcpyHostToDevice));
         }
         FW_HIP(ctx, hipMemcpy(ctx->g.ndestroyed + si, zero2, 4, hipMemcpyHostToDevice));
+        FW_HIP(ctx, hipMemcpy(ctx->g.range_ticket + si, zero2, 4, hipMemcpyHostToDevice));  // (S.ticket_base is 0: a fresh SegHost)
     }
 
     for (uint32_t i = 0; i < ne; i++) {
@@ -1719,6 +1740,9 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         FW_HIP(ctx, hipMemcpy(ctx->d_emits.d + E.emit_idx, &de, sizeof de, hipMemcpyHostToDevice));
         const unsigned long long s0 = E.serial;
         FW_HIP(ctx, hipMemcpy(ctx->d_emit_serial.d + E.emit_slot, &s0, sizeof s0, hipMemcpyHostToDevice));
+        const uint32_t t0 = 0u;
+        FW_HIP(ctx, hipMemcpy(ctx->d_nest_start.d + E.emit_slot, &t0, sizeof t0, hipMemcpyHostToDevice));
+        ctx->nest_ticket_base[E.emit_slot] = 0u;
     }
     // ring types other particles' entries emit from that need no materialisation (SegHost::virt_parent)
     for (uint32_t t = 0; t < nt; t++) {
@@ -2117,6 +2141,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_RANGE_MIN")) ctx->range_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_RANGE_FEW")) ctx->range_few = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_RANGE_SMALL")) ctx->range_small_tiles = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_RANGE_YOUNG_BIG")) ctx->range_young_big = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_NOSPIN")) ctx->use_nospin = atoi(m) != 0;
     if (const char *m = getenv("FW_NEST_FUSE")) ctx->nest_fuse = atoi(m) != 0;
     if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;
@@ -2165,7 +2190,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
         if (S.h_report) hipHostFree(S.h_report);
     }
     void *frees[] = {ctx->d_type_coll.d, ctx->d_segs.d,       ctx->d_types.d,       ctx->d_keys.d,        ctx->d_emits.d,
-                     ctx->d_emit_serial.d, ctx->g.count,        ctx->g.spawned,       ctx->g.appended,     ctx->g.rold,
+                     ctx->d_emit_serial.d, ctx->d_nest_start.d, ctx->g.range_ticket, ctx->g.count,        ctx->g.spawned,       ctx->g.appended,     ctx->g.rold,
                      ctx->g.ndestroyed,   ctx->g.tile_cnt,      ctx->g.tile_off,      ctx->g.tile_status,
                      ctx->g.err,          ctx->g.stats,         ctx->g.nest_status,   ctx->g.nest_ticket,
                      ctx->d_aabb,         ctx->d_total,         ctx->d_segids,        ctx->g.dbg_ts,
@@ -2536,7 +2561,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     bool any_coll = false, any_inst_general = false;
     struct {
         uint64_t fifo_parts = 0, range_parts = 0;
-        bool fifo_dev = false, fifo_coll = false, fifo_inst = false, range_dev = false, range_coll = false;
+        bool fifo_dev = false, fifo_coll = false, fifo_inst = false, range_dev = false, range_coll = false, range_inst = false;
     } ring_stats;
     ctx->grow_scratch.clear();
     for (size_t si = 0, ns = ctx->segs.size(); si < ns; si++) {
@@ -2551,7 +2576,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         any_coll |= S.collides && !S.ring();  // (a colliding type in a ring is updated by its ring kernel)
         // (what decides the tile size of the ring launches -- fifo_small / range_small below -- gathered while the record is hot)
         if (S.fifo) ring_stats.fifo_parts += S.ub, ring_stats.fifo_dev |= S.fifo_dev, ring_stats.fifo_coll |= S.collides, ring_stats.fifo_inst |= S.inst != nullptr;
-        if (S.range) ring_stats.range_parts += S.ub, ring_stats.range_dev |= S.range_dev, ring_stats.range_coll |= S.collides;
+        if (S.range) ring_stats.range_parts += S.ub, ring_stats.range_dev |= S.range_dev, ring_stats.range_coll |= S.collides, ring_stats.range_inst |= S.inst != nullptr;
         any_inst_general |= !S.ring() && S.inst != nullptr;
         if (S.nested_fed && nested_fed_wants_growth(S)) ctx->grow_scratch.push_back((uint32_t)si);
         if (!S.win_ok) continue;
@@ -3007,6 +3032,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     // (its lifetimes: the lifetime plane of a compacting segment, one value for a ring)
                     op.parent_life_plane = ctx->segs[op.parent_seg].fifo ? 0xFFFFFFFFu : ctx->segs[op.parent_seg].n_lplanes;
                     op.parent_life_const = ctx->segs[op.parent_seg].fifo_life;
+                    // (START tickets, fw_kernels.h: every workgroup of the op takes one)
+                    op.ticket_base = ctx->nest_ticket_base[op.emit_slot], ctx->nest_ticket_base[op.emit_slot] += op.n_tiles;
                     h_nops[ni++] = op;
                 }
                 launches.push_back(Launch{true, first, ni - first, tiles});
@@ -3265,6 +3292,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 N.n_count = op.n_count, N.n_start = op.n_start, N.n_end = op.n_end, N.speed = op.speed, N.scale = op.scale;
                 N.status_first = nest_status_next, N.n_ptiles = F.n_tiles - (F.n_vt_a + F.n_vt_b);
                 nest_status_next += N.n_ptiles;
+                N.ticket_base = ctx->nest_ticket_base[op.emit_slot], ctx->nest_ticket_base[op.emit_slot] += N.n_ptiles;
                 N.tag = ctx->nest_seq, N.spin_limit = ctx->spin_limit;
                 fa.n_nest = n_fuse;
             }
@@ -3310,6 +3338,13 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             const uint64_t lim = (uint64_t)ctx->range_small_tiles * FW_TILE;
             const bool small = any_coll_r || (!any_dev && parts < (ctx->range_small ? lim + lim / 4 : lim));
             if (small != ctx->range_small) ctx->range_small = small, dirty = true;
+            // ... and of its YOUNG workgroups (fw_ctx::range_young_rounds)
+            const uint64_t mean = parts / std::max<uint32_t>(1u, ctx->n_range), big = ctx->range_young_big;
+            uint32_t yr = ctx->range_young_rounds;
+            if (small || any_dev || ring_stats.range_inst || big == 0) yr = 4;
+            else if (yr == 4 && mean >= big) yr = 2;
+            else if (yr == 2 && mean < big - big / 4) yr = 4;
+            if (yr != ctx->range_young_rounds) ctx->range_young_rounds = yr, dirty = true;
         }
         const uint32_t OT = ctx->range_small ? (uint32_t)FW_BLOCK : (uint32_t)FW_TILE;  // slots an OLD workgroup covers
         uint64_t r_bytes = 0;  // what the launch streams, roughly (the non-temporal form of the kernel: fw_ctx::nt_bytes)
@@ -3363,14 +3398,14 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             const uint32_t y_exist = S.range_dev ? 0u : S.young_n - std::min(S.young_n, grad);
             FwRangeRec &Rc = recs[si];
             Rc.b = S.young_lo, Rc.y_exist = y_exist, Rc.n_spawn = (mat_frame || S.range_dev) ? 0u : S.frame_spawn;
-            Rc.grad = grad, Rc.flags = (mat_frame ? FW_RREC_MAT : 0u) | (S.range_dev ? (FW_RREC_MAT | FW_RREC_DEV) : 0u), Rc.pad = 0;
+            Rc.grad = grad, Rc.flags = (mat_frame ? FW_RREC_MAT : 0u) | (S.range_dev ? (FW_RREC_MAT | FW_RREC_DEV) : 0u);
             Rc.report = S.range_dev ? S.h_report + (ctx->frame % kReportRing) : nullptr, Rc.pad2 = 0;
             while (oi < ops.size() && ops[oi].seg < si) oi++;
             Rc.op0 = (uint32_t)oi, Rc.op_n = 0;
             while (oi < ops.size() && ops[oi].seg == si) oi++, Rc.op_n++;
             S.young_n = S.range_dev ? 0u : y_exist + S.frame_spawn;
             // workgroups of each role (bands: the table is re-sent only when a need leaves its band)
-            const uint32_t YT = ctx->range_small ? (uint32_t)FW_BLOCK : fw_range_young_tile();
+            const uint32_t YT = ctx->range_small ? (uint32_t)FW_BLOCK : ctx->range_young_rounds * (uint32_t)FW_BLOCK;
             uint32_t need_old, need_new, need_young;
             if (S.range_dev) {
                 // the old part: at most the cohorts that have joined it and may still hold survivors (all sizes known); the young
@@ -3414,6 +3449,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             fit(S.r_new, need_new, need_new ? (need_new >= 8 ? need_new / 8 : 1u) : 0u, S.r_low[1]);
             fit(S.r_young, need_young, need_young >= 16 ? need_young / 8 : 1u, S.r_low[2]);
             S.r_young = std::min(S.r_young, S.capacity / YT);
+            // (START tickets, fw_kernels.h: every OLD workgroup the table provides for the segment takes one per launch -- r_old of
+            // them, whether the table is re-sent this frame or not: fit() changes the number only together with `dirty`)
+            Rc.ticket_base = S.ticket_base, S.ticket_base += S.r_old;
         }
         if (dirty) {
             if (ctx->rtab_pending) {  // (one staging buffer: the previous upload must have left it)
@@ -3516,6 +3554,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             ra.any_inst = range_inst ? 1u : 0u;
             ra.any_coll = range_coll ? 1u : 0u;
             ra.small_tiles = ctx->range_small ? 1u : 0u;
+            ra.young_rounds = ctx->range_young_rounds;
             ra.done_tag = a.done_tag, ra.done_value = a.done_value;
             ra.host_counts = a.host_counts, ra.live_out = a.live_out, ra.live_next = a.live_next;
             ra.ts = ctx->d_rts;

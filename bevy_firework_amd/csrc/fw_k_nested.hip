@@ -96,18 +96,26 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
     __shared__ uint32_t s_lb[2 * LBW * NW];
     __shared__ uint32_t s_inc[NW][64];
     __shared__ __attribute__((aligned(16))) float4 s_par[NW][3][64];
-    const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t oi = 0;
     FwNestOp op = inl.ops[0];
     if (ops) {
-        oi = fw_find_nest_op(ops, n_ops, tile);
+        oi = fw_find_nest_op(ops, n_ops, wg);
         op = ops[oi];
     } else {
 #pragma unroll  // constant indices: the record stays in scalar registers (a dynamic index would go through scratch)
         for (uint32_t i = 1; i < FW_INLINE_OPS; i++)
-            if (i < n_ops && inl.ops[i].first_tile <= tile) oi = i, op = inl.ops[i];
+            if (i < n_ops && inl.ops[i].first_tile <= wg) oi = i, op = inl.ops[i];
     }
     const uint32_t sidx = parity * g.max_seg + op.parent_seg, cidx = parity * g.max_seg + op.child_seg;
+    // which tile of the op's parents this workgroup takes -- its rank in the op's look-back -- is a START ticket (fw_kernels.h):
+    // every workgroup of the op takes exactly one, whoever holds a lower one has started
+    __shared__ uint32_t s_rank;
+    if (FW_TICKETS) {
+        if (threadIdx.x == 0u) s_rank = atomicAdd(&g.nest_start[op.emit_slot], 1u) - op.ticket_base;
+        __syncthreads();
+    }
+    const uint32_t tile = FW_TICKETS ? op.first_tile + s_rank : wg;
     // (a RANGE ring is addressed through the size of its old part, which only the device knows: one dependent hop more before
     // the parents can be requested)
     const uint32_t parent_head = op.parent_range ? fw_range_head(op.parent_head, g.rold[sidx], op.parent_cap) : op.parent_head;

@@ -255,9 +255,6 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
     if (spawner && sbase >= C) sbase -= C;  // (head + n_in + k0 < 3 C)
     const float key0 = tid < F.keys_len ? g.keys[F.keys_off + tid] : 0.0f;
     char *buf = F.buf;
-    const size_t sfirst = (size_t)sbase * 16u;
-    const char *iw0 = buf + FW_OFF_Q0(C) + sfirst, *iw1 = buf + FW_OFF_Q1(C) + sfirst;
-    const char *iw2 = buf + FW_OFF_Q2(C) + sfirst, *iw3 = buf + FW_OFF_Q3(C) + sfirst;
     // round 0 of a live tile (every slot of a tile exists -- the capacity is a multiple of FW_TILE -- so the loads
     // need no bounds; a spawning workgroup loads nothing)
     float4 q0c, q1c, q2c, q3c, q0n, q1n, q2n, q3n;  // rounds 0 and 1: the loop keeps two rounds of loads in flight
@@ -277,9 +274,22 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
         // of them is loaded for the update (workgroup-uniform branch)
         if (!spawner && F.nest != 0u && !(F.nest & FW_FIFO_NEST_CHILD)) {
             const FwFifoNest &N = a.nest[F.nest - 1u];
-            fw_fifo_nest_parents<R, NT>(g, a, N, F, a.s[N.child], tis - n_vt, sbase, n_in);
+            // the tile's rank among the parents' tiles -- which ring tile it works on -- is a START ticket (fw_kernels.h)
+            __shared__ uint32_t s_prank;
+            if (FW_TICKETS) {
+                if (tid == 0u) s_prank = atomicAdd(&g.nest_start[N.emit_slot], 1u) - N.ticket_base;
+                __syncthreads();
+            }
+            const uint32_t prank = FW_TICKETS ? s_prank : tis - n_vt;
+            pt = F.tile0 + prank;
+            if (pt >= ring_tiles) pt -= ring_tiles;
+            sbase = pt * TILE;
+            fw_fifo_nest_parents<R, NT>(g, a, N, F, a.s[N.child], prank, sbase, n_in);
         }
     }
+    const size_t sfirst = (size_t)sbase * 16u;
+    const char *iw0 = buf + FW_OFF_Q0(C) + sfirst, *iw1 = buf + FW_OFF_Q1(C) + sfirst;
+    const char *iw2 = buf + FW_OFF_Q2(C) + sfirst, *iw3 = buf + FW_OFF_Q3(C) + sfirst;
     if (!spawner && !defer) {
         q0c = fw_ld4w<NT == 2>(iw0, tid * 16u), q3c = fw_ld4w<NT == 2>(iw3, (tid * 16u) & m2);
         q1c = fw_ld4w<NT == 2>(iw1, tid * 16u), q2c = fw_ld4w<NT == 2>(iw2, (tid * 16u) & m2);
@@ -544,8 +554,18 @@ uint32_t fw_range_young_tile(void) { return FW_RANGE_YR * FW_BLOCK; }
 // FIFO rings: a single range ring of 156k particles is ~190 four-round workgroups, its old part a chain of 31 tiles of 1024
 // particles each of which waits for the counts of the ones before -- 17 us per frame where the FIFO ring of the same size
 // takes 8).
-template <bool ALLNOSPIN, bool INST, int NT, bool COLL = false, int TR = FW_ROUNDS>
-__global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
+// YRP: rounds of a YOUNG workgroup of a four-round launch (FwRangeArgs::young_rounds): FW_RANGE_YR, or 2 -- young tiles of 512
+// slots -- for launches of large segments (round 3 measured the fixed choices: +4 % at 16M particles in 64 Ki-particle segments,
+// -18 % on 8192-particle segments; the host now chooses per launch from the mean segment size)
+template <bool ALLNOSPIN, bool INST, int NT, bool COLL = false, int TR = FW_ROUNDS, int YRP = FW_RANGE_YR>
+// (launches with a type that can turn, four-round tiles: pinned at 4 waves per SIMD -- with the OLD tiles' rotation planes parked in
+// LDS the kernel is 6 registers past the step and fits when asked to; not the forms that also write instance records: their 50 KB of
+// LDS allow three workgroups per CU anyway)
+#ifndef FW_RANGE_SPIN_WAVES
+#define FW_RANGE_SPIN_WAVES 4  // (1: no pin -- 134 VGPRs, 3 waves per SIMD; the A/B of profiles/r05/range_ab.txt)
+#endif
+__global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu((!ALLNOSPIN && !INST && !COLL && TR == FW_ROUNDS) ? FW_RANGE_SPIN_WAVES : 1)))
+void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
     constexpr int BLK = FW_BLOCK;
     constexpr int NW = BLK / 64;
     constexpr int R = TR;
@@ -557,7 +577,12 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     __shared__ uint32_t s_lb[2 * LBW * NW];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const FwRangeDesc &D = a.desc[blockIdx.x];  // block-uniform: scalar loads
-    const uint32_t seg = D.seg, role = D.role_k >> 30, k = D.role_k & 0x3FFFFFFFu;
+    const uint32_t seg = D.seg, role = D.role_k >> 30;
+    uint32_t k = D.role_k & 0x3FFFFFFFu;
+    // an OLD workgroup waits for the OLD workgroups of lower rank: its rank is a START ticket (fw_kernels.h), requested before
+    // anything else so that it travels together with the record and the counters
+    uint32_t ticket = 0u;
+    if (FW_TICKETS && role == FW_RANGE_OLD && threadIdx.x == 0u) ticket = atomicAdd(&g.range_ticket[seg], 1u);
 #ifdef FW_RANGE_SLEEP  // (experiment: what a microsecond more of dead time per workgroup costs)
     __builtin_amdgcn_s_sleep(FW_RANGE_SLEEP);
 #endif
@@ -607,7 +632,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
 
     if (role == FW_RANGE_YOUNG) {
         // ---- in place: a lane owns its slot from load to store
-        constexpr int YR = TR == FW_ROUNDS ? FW_RANGE_YR : TR;
+        constexpr int YR = TR == FW_ROUNDS ? YRP : TR;
         constexpr uint32_t YT = YR * BLK;  // (capacities are multiples of it: the host rounds them, fw_range_young_tile)
         const uint32_t ring_tiles = C / YT;
         const uint32_t need = min(ring_tiles, (b % YT + y_exist + YT - 1u) / YT);
@@ -784,6 +809,12 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_range(FwGlobals g, FwRan
     }
 
     // ---- OLD: in-place compaction towards the young part.  Distance d from the young part: slot = b - 1 - d.
+    if (FW_TICKETS) {
+        __shared__ uint32_t s_rank;
+        if (tid == 0u) s_rank = ticket - Rc.ticket_base;  // (every provisioned OLD workgroup of the segment takes exactly one per launch)
+        __syncthreads();
+        k = s_rank;
+    }
     // (ONE workgroup walking the few tiles of a small old part itself -- no status words, no waiting, no provisioned-but-idle
     // workgroups -- was built and measured in round 4: the tile loop costs the kernel 9-35 VGPRs, and even at equal occupancy
     // one GPU's share of configs[4] ran 86.4 us against 85.6 with the tiles in parallel: profiles/r04/range_seq_old_ab.txt)
@@ -1061,6 +1092,11 @@ static void fw_launch_update_range_t(hipStream_t s, const FwGlobals &g, const Fw
             }
             return;
         }
+    }
+    if (a.young_rounds == 2u && !a.any_inst) {  // young tiles of 512 slots (the host laid the launch out on them; never with records)
+        if (all_nospin) FW_LAUNCH_T((fw_k_update_range<true, false, NT, false, FW_ROUNDS, 2>), grid, block, s, e0, e1, g, a);
+        else FW_LAUNCH_T((fw_k_update_range<false, false, NT, false, FW_ROUNDS, 2>), grid, block, s, e0, e1, g, a);
+        return;
     }
     if (a.any_inst) {
         if (all_nospin)

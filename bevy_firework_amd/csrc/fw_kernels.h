@@ -48,6 +48,24 @@ struct FwGlobals {
     unsigned long long *emit_serial; // RNG serials of Nested emission entries
     unsigned long long *nest_status; // [nested tiles] look-back words of fw_k_nest, tagged with the launch's sequence number
     unsigned long long *nest_ticket; // [n_ops] {workgroups of the op that have finished, children of the op}: the last one commits, then zeroes
+    // START tickets (round 5): a workgroup that will wait for workgroups of lower rank -- an OLD tile of a range ring, a tile of
+    // parents of a Nested entry -- takes its rank from an atomic counter FIRST THING instead of from its workgroup index, so that
+    // "whoever has a lower rank has started" (hence publishes its status word without waiting for anybody of higher rank) is a
+    // fact of the program, not a habit of the dispatcher.  Counters only ever grow; the host, which knows how many workgroups of
+    // each launch take a ticket, sends the value each counter has when the launch starts (FwRangeRec / FwNestOp / FwFifoNest::
+    // ticket_base): no reset, no second pass.  range_ticket: one per segment; nest_start: one per Nested entry (emit slot).
+    uint32_t *range_ticket;
+    uint32_t *nest_start;
+    // MEASURED AND NOT SHIPPED (profiles/r05/tickets_ab.txt, same box, interleaved): the ticket is one more dependent hop in front
+    // of everything a latency-bound workgroup does -- configs[2] +1.0 %, one GPU's share of configs[4] +4.5 % (88.4 against 84.6 us),
+    // configs[3] +8.6 % with the Nested entry inside the FIFO launch (62.9 against 57.9 us) and +14 % with the separate pass (76.7
+    // against 67.0) -- far past the 2 % the guarantee was judged worth.  The product build takes ranks from workgroup indices
+    // (FW_TICKETS = 0); the wait stays bounded by the dispatcher's habit of starting lower indices first, and a wait that does run
+    // out raises the sticky per-spawner error of DESIGN.md section 11.  `tools/build_variant.sh tickets -DFW_TICKETS=1` builds the
+    // guaranteed form (the whole GPU suite passes on it).
+#ifndef FW_TICKETS
+#define FW_TICKETS 0
+#endif
     const FwCollider *colliders;         // the world particle_collision casts its rays into (fw_ctx_set_colliders)
     uint32_t n_colliders;
 };
@@ -175,9 +193,10 @@ struct FwFifoNest {
     uint32_t n_ptiles;           // ring tiles of the parents' ring that take part (ranks 0 .. n_ptiles - 1)
     uint32_t parent_lplane;      // which last_emitted_age plane of the parent type belongs to the entry
     uint32_t tag;                // tag of the look-back words of this launch (fw_ctx::nest_seq)
+    uint32_t ticket_base;        // value of FwGlobals::nest_start[emit_slot] when this launch starts (the tile of rank r holds ticket_base + r)
     float n_count, n_start, n_end;  // CountOverDuration of the entry (core.rs:474-481)
     float speed, scale;          // EffectModifier
-    uint32_t spin_limit;
+    uint32_t spin_limit, pad;
 };
 #define FW_FIFO_NEST_MAX 4
 #define FW_FIFO_NEST_CHILD 0x80000000u
@@ -225,7 +244,7 @@ struct alignas(16) FwRangeRec {  // per segment, per frame: pinned host memory, 
     uint32_t op0, op_n; // their spawn ops in FwRangeArgs::ops
     uint32_t grad;      // particles that joined the old part this frame (b moved by so many slots): old part = rold + grad
     uint32_t flags;     // FW_RREC_*
-    uint32_t pad;
+    uint32_t ticket_base;  // value of FwGlobals::range_ticket[segment] when this launch starts (its OLD workgroup of rank k holds ticket_base + k)
     unsigned long long *report;  // FW_RREC_DEV: pinned host word that receives {epoch << 32 | particles added this frame}
     unsigned long long pad2;
 };
@@ -262,6 +281,7 @@ struct FwRangeArgs {
     uint32_t any_coll;              // some segment's particle type has collision settings: the COLL instantiation (FwCollArm)
     uint32_t small_tiles;           // 1: OLD and YOUNG workgroups cover ONE round (256 slots) each: the host laid the launch out so
                                     // (colliding launches, and launches too small to fill the chip with four-round workgroups)
+    uint32_t young_rounds;          // rounds of a YOUNG workgroup of a four-round launch: 4, or 2 (launches of large segments, no records)
     unsigned long long *done_tag;   // as in FwUpdateArgs
     unsigned long long done_value;
     unsigned long long *host_counts;

@@ -40,6 +40,9 @@ def test_library_exports_every_declared_symbol():
     # the Rust `extern "C"` block of INTEGRATION.md lists the same functions (three mirrors of one header: keep them in step)
     rust = set(re.findall(r"pub fn (fw_[a-z0-9_]+)\(", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
     assert rust == product, rust ^ product
+    # ... and so does the shim's source form (rust/src/hip/ffi.rs: unverified Rust, but the same list)
+    shim = set(re.findall(r"pub fn (fw_[a-z0-9_]+)\(", open(os.path.join(ROOT, "rust", "src", "hip", "ffi.rs")).read()))
+    assert shim == product, shim ^ product
     # ... and the library exports no fw_* function the header does not declare
     import subprocess
 
