@@ -340,6 +340,11 @@ struct alignas(64) SegHost {
     Ring<YCohort> ycoh;  // the young cohorts, oldest first
     bool few_ring = false;  // a range ring below fw_ctx::range_min: only because the context holds few segments (fw_ctx::range_few)
     bool spilled = false;   // a range ring that qualifies for a FIFO ring: the context holds more such types than one FIFO launch (fw_ctx::n_spilled)
+    // A SMALL type (fw_k_small.hip, round 5): a few hundred particles, updated by ONE WAVE (four types per workgroup) instead of a
+    // workgroup of the compacting kernels -- no tile table entry, no forecast.  Same buffers and layout as a compacting segment:
+    // entering and leaving the mode is this flag (fw_ctx::n_small, small_eligible / leave_small).
+    bool small = false;
+    float expect_live = 0.f;  // live particles the emitters that feed the type sustain (what derive_capacity derives the capacity from)
     uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
     uint32_t r_low[3] = {0, 0, 0};               // frames in a row a role's need has been far below what is provided
     uint32_t r_need[3] = {0, 0, 0};              // what each role needed in the latest frame (the table keeps more: fit())
@@ -570,6 +575,19 @@ struct fw_ctx {
     // AND every FIFO ring of the context becomes one where it stands (fifo_to_range: no copy, particles and order kept; build time,
     // the context is synchronised): one kind of launch again.  While such rings exist, further one-lifetime types join them.
     uint32_t n_spilled = 0;    // SegHost::spilled segments
+    // ---- small types (SegHost::small): the wave-per-type kernel.  A type is one when it is built (or when it leaves a small ring:
+    // drop_few_rings) if the emitters that feed it sustain at most small_max / 2 particles and nothing else claims it (no ring, no
+    // Nested entry on or from it, no collisions, no instance buffer, no per-tile AABBs); it leaves for good when its live bound
+    // passes small_max (it simply becomes a compacting segment: same buffers).  FW_SMALL=0 / FW_SMALL_MAX=n
+    bool use_small = true;
+    uint32_t small_max = 768;
+    uint32_t n_small = 0;
+    std::vector<uint32_t> small_list;   // the segments, ascending (rebuilt when small_dirty)
+    bool small_dirty = true;
+    uint32_t *d_small = nullptr, *h_small = nullptr;  // device list / pinned staging
+    size_t small_cap = 0;
+    hipEvent_t ev_small = nullptr;
+    bool small_pending = false;
     std::vector<FwOp> fifo_ops;  // this frame's Global ops that feed FIFO segments (spawned inside fw_k_update_fifo)
     std::vector<std::pair<uint32_t, FwOp>> range_mat_ops;  // the same for range rings other particles' entries emit from
     std::vector<std::pair<uint32_t, FwOp>> fifo_mat_ops;  // {emission index, op}: rings of spawners with Nested entries -- the
@@ -803,7 +821,7 @@ uint32_t seg_live_tiles(const SegHost &s) {
     return (live_ub + FW_TILE - 1) / FW_TILE;
 }
 uint32_t seg_tiles(const SegHost &s, uint32_t vt_rounds = 1) {
-    if (!s.in_use || s.ring()) return 0;  // (rings have their own launches: fw_k_update_fifo, fw_k_update_range)
+    if (!s.in_use || s.ring() || s.small) return 0;  // (rings and small types have their own launches: fw_k_update_fifo / _range / _small)
     const uint32_t vtile = vt_rounds * FW_VTILE;
     if (!s.nested_fed && s.frame_spawn <= FW_VTILE) {
         // At most one round of new particles: they ride in the last live tile whenever it has room for them (both
@@ -1173,12 +1191,30 @@ fw_status fifo_to_general(fw_ctx *ctx, uint32_t si) {
     return realloc_segment(ctx, si, ctx->segs[si].capacity, true);
 }
 
+// SegHost::small: may this compacting segment be updated by the wave-per-type kernel?
+bool small_eligible(const fw_ctx *ctx, const SegHost &S) {
+    return ctx->use_small && S.in_use && !S.ring() && !S.nested_fed && S.n_lplanes == 0 && !S.collides && S.inst == nullptr && !ctx->track_aabb &&
+           !S.colors_dirty && S.expect_live * 2.0f <= (float)ctx->small_max;
+}
+void enter_small(fw_ctx *ctx, SegHost &S) {
+    if (S.small) return;
+    S.small = true, ctx->n_small++, ctx->small_dirty = true;
+    ctx->tab_force = true, ctx->fc_ok = false, ctx->boxes_epoch = 0;
+}
+// ... and back: the segment is a compacting segment again (the same buffers; the tile table is re-sent)
+void leave_small(fw_ctx *ctx, SegHost &S) {
+    if (!S.small) return;
+    S.small = false, ctx->n_small--, ctx->small_dirty = true;
+    ctx->tab_force = true, ctx->fc_ok = false, ctx->boxes_epoch = 0;
+}
+
 // every SegHost::few_ring segment leaves its ring (fw_ctx::range_few), particles and order kept
 fw_status drop_few_rings(fw_ctx *ctx) {
     for (uint32_t si = 0; si < ctx->segs.size() && ctx->n_few; si++) {
         if (!ctx->segs[si].in_use || !ctx->segs[si].few_ring) continue;
         const fw_status st = fifo_to_general(ctx, si);  // (realloc_segment clears the flag and the count)
         if (st) return st;
+        if (small_eligible(ctx, ctx->segs[si])) enter_small(ctx, ctx->segs[si]);  // (a small type: the wave-per-type kernel from here on)
     }
     return FW_OK;
 }
@@ -1414,10 +1450,10 @@ fw_status validate_desc(fw_ctx *ctx, const fw_spawner_desc *d) {
 }
 
 // capacity heuristic: expected live count from the emitters feeding a type, x1.25 + slack
-uint32_t derive_capacity(const fw_spawner_desc *d, uint32_t t, const std::vector<uint32_t> &caps) {
+uint32_t derive_capacity(const fw_spawner_desc *d, uint32_t t, const std::vector<uint32_t> &caps, double *expect_live = nullptr) {
     const fw_particle_settings &p = d->particle_settings[t];
     const uint32_t FW_CAP_ROUND = std::max<uint32_t>(FW_TILE, fw_range_young_tile());  // every kernel's tile divides a capacity
-    if (p.capacity) return round_up(std::max<uint32_t>(p.capacity, FW_TILE), FW_CAP_ROUND);
+    if (p.capacity && !expect_live) return round_up(std::max<uint32_t>(p.capacity, FW_TILE), FW_CAP_ROUND);
     const double life = std::max(0.0, (double)std::max(p.lifetime.min, p.lifetime.max));
     double need = 0;
     for (uint32_t i = 0; i < d->n_emission_settings; i++) {
@@ -1435,6 +1471,8 @@ uint32_t derive_capacity(const fw_spawner_desc *d, uint32_t t, const std::vector
             need += pcap * (double)e.count * std::max(1.0, life / plife + 0.1);
         }
     }
+    if (expect_live) *expect_live = need;  // (what the emitters sustain: SegHost::expect_live)
+    if (p.capacity) return round_up(std::max<uint32_t>(p.capacity, FW_TILE), FW_CAP_ROUND);
     need = need * 1.25 + kMinCapacity;
     if (need > 3.0e9) need = 3.0e9;
     return round_up((uint32_t)need, FW_CAP_ROUND);
@@ -1679,7 +1717,13 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             S.fill_em[c] = T.emis.values.empty() ? 0.f : T.emis.values[c];
         }
         S.colors_dirty = false;
+        {
+            double expect = 0.0;
+            derive_capacity(d, t, caps, &expect);
+            S.expect_live = (float)std::min(expect, 3.0e9);
+        }
         if ((st = alloc_seg_buffers(ctx, S, caps[t], p.report_destroyed != 0))) return st;
+        if (small_eligible(ctx, S)) enter_small(ctx, S);  // (fw_ctx::n_small: the wave-per-type kernel)
         if ((st = upload_seg(ctx, si))) return st;
         const uint32_t zero2[2] = {0, 0};
         for (int r = 0; r < 2; r++) {
@@ -1765,6 +1809,16 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
     sp.initialized = true;
     if ((st = ensure_range_arrays(ctx))) return st;
     if ((st = ensure_tile_arrays(ctx))) return st;
+    if (ctx->segs.size() > ctx->small_cap) {  // the small-type list (fw_ctx::d_small): room for every segment slot; fw_step never allocates
+        if ((st = sync(ctx))) return st;
+        const size_t ncap = ctx->segs.size() * 2 + 256;
+        if (ctx->d_small) hipFree(ctx->d_small);
+        if (ctx->h_small) hipHostFree(ctx->h_small);
+        ctx->d_small = nullptr, ctx->h_small = nullptr, ctx->small_cap = 0, ctx->small_pending = false;
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_small, ncap * sizeof(uint32_t)));
+        FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_small, ncap * sizeof(uint32_t), hipHostMallocDefault));
+        ctx->small_cap = ncap, ctx->small_dirty = true;
+    }
     // the context is no longer one of few segments without a FIFO ring: its small range rings continue on the compacting path
     // (fw_ctx::range_few; callers of build_spawner have synchronised the context)
     if (ctx->n_spilled && ctx->n_fifo && (st = spill_fifo_rings(ctx))) return st;  // (fw_ctx::n_spilled)
@@ -1798,6 +1852,7 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
         if (S.range) ctx->n_range--, ctx->r_force = true;
         if (S.few_ring) ctx->n_few--;
         if (S.spilled) ctx->n_spilled--;
+        if (S.small) ctx->n_small--, ctx->small_dirty = true;
         ctx->n_in_use--;
         if (ctx->n_in_use <= ctx->range_few / 2) ctx->few_blocked = false;
         if (S.h_report) hipHostFree(S.h_report);
@@ -1818,6 +1873,13 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
 // need leaves the band [need, need * 5/4 + 8], so steady-state frames upload nothing.
 fw_status update_tile_table(fw_ctx *ctx) {
     const uint32_t n_seg = (uint32_t)ctx->segs.size();
+    // (a context of rings and small types only -- thousands of small emitters: nothing for the compacting launch, whose table is
+    // empty already: not a pass over every segment record per frame)
+    if (!ctx->tab_force && ctx->total_tiles_dev == 0 && ctx->d_tile_first && ctx->tiles_dev.size() == n_seg &&
+        ctx->n_in_use == ctx->n_fifo + ctx->n_range + ctx->n_small) {
+        ctx->vt_rounds = 1u;
+        return FW_OK;
+    }
     bool dirty = ctx->tiles_dev.size() != n_seg || ctx->tab_force;  // descriptors carry per-segment type indices
     ctx->tab_force = false;
     ctx->tiles_dev.resize(n_seg, 0);
@@ -1826,7 +1888,7 @@ fw_status update_tile_table(fw_ctx *ctx) {
     uint64_t act1 = 0, act2 = 0;
     for (uint32_t i = 0; i < n_seg; i++) {
         const SegHost &S = ctx->segs[i];
-        if (S.in_use && !S.ring()) {
+        if (S.in_use && !S.ring() && !S.small) {
             const uint32_t live = seg_live_tiles(S);
             act1 += live + (S.frame_spawn + FW_VTILE - 1) / FW_VTILE;
             act2 += live + (S.frame_spawn + 2 * FW_VTILE - 1) / (2 * FW_VTILE);
@@ -1835,7 +1897,7 @@ fw_status update_tile_table(fw_ctx *ctx) {
         // the device from exact counts and may use the smaller tiles when the host, with looser bounds, would not
         const uint32_t need = seg_tiles(S, 1);
         uint32_t &have = ctx->tiles_dev[i];
-        if (!S.in_use || S.ring()) {
+        if (!S.in_use || S.ring() || S.small) {
             if (have) have = 0, dirty = true;
             continue;
         }
@@ -2102,6 +2164,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
         return bail("hipStreamCreate(rings)", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_rtab, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_small, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming)) != hipSuccess)
         return bail("hipEventCreate", e);
     for (int i = 0; i < kParamRing; i++) {
@@ -2144,6 +2207,8 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_RANGE_YOUNG_BIG")) ctx->range_young_big = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_NOSPIN")) ctx->use_nospin = atoi(m) != 0;
     if (const char *m = getenv("FW_NEST_FUSE")) ctx->nest_fuse = atoi(m) != 0;
+    if (const char *m = getenv("FW_SMALL")) ctx->use_small = atoi(m) != 0;
+    if (const char *m = getenv("FW_SMALL_MAX")) ctx->small_max = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_NT_WO_MB")) ctx->nt_wo_bytes = ctx->nt_wo_bytes_range = (uint64_t)atoll(m) << 20;
 #ifdef FW_AB
@@ -2223,6 +2288,9 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     if (ctx->fifo_stream) hipStreamDestroy(ctx->fifo_stream);
     if (ctx->ev_side) hipEventDestroy(ctx->ev_side);
     if (ctx->ev_rtab) hipEventDestroy(ctx->ev_rtab);
+    if (ctx->ev_small) hipEventDestroy(ctx->ev_small);
+    if (ctx->d_small) hipFree(ctx->d_small);
+    if (ctx->h_small) hipHostFree(ctx->h_small);
     for (int i = 0; i < 2; i++) {
         if (ctx->ev_coll[i]) hipEventDestroy(ctx->ev_coll[i]);
         if (ctx->h_coll[i]) hipHostFree(ctx->h_coll[i]);
@@ -2754,6 +2822,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 E.serial += n;
                 S.frame_spawn += (uint32_t)n;
                 S.ub = (uint32_t)std::min<uint64_t>((uint64_t)S.ub + n, 0xFFFFFFFFull);
+                if (S.small && S.ub > ctx->small_max) leave_small(ctx, S);  // (no longer a few hundred particles: a compacting segment from this frame on)
                 note_spawned(S, n);
             } else {
                 if (es.pacing_kind != FW_PACING_COUNT_OVER_DURATION) continue;  // warn_once + continue core.rs:474-485
@@ -2963,6 +3032,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     if ((ctx->frame % ctx->snap_every) == 0)
         for (int k = 0; k < kSnapRing && snap < 0; k++)
             if (!ctx->snap_pending[k]) snap = k;
+    // (small types are bounded by their lifetime windows and have no grid to size: a context of nothing else takes no snapshots --
+    // a row is a pass over every segment record on the host and a store over the bus per segment on the device)
+    if (ctx->n_in_use == ctx->n_small) snap = -1;
     const bool take_snap = snap >= 0;
     a.host_counts = take_snap ? ctx->h_snap + (size_t)snap * ctx->max_seg : nullptr;
 
@@ -3084,7 +3156,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         if (!std::is_sorted(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; }))
             std::stable_sort(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; });
         a.n_ops = (uint32_t)ops.size();
-        if (ops.size() <= FW_INLINE_OPS) {
+        if (ops.size() <= FW_INLINE_OPS && (ops.empty() || !ctx->n_small)) {  // (small types read their ops from the table: fw_k_update_small)
             spawn_form = ops.empty() ? FW_SPAWN_NONE : FW_SPAWN_INLINE;
             for (size_t i = 0; i < ops.size(); i++) inl.ops[i] = ops[i];
         } else {
@@ -3565,7 +3637,37 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             range_launched = true;
         }
     }
-    if (total_tiles || !(fifo_launched || range_launched)) {
+    // ---- small types: one wave each (fw_k_small.hip)
+    bool small_launched = false;
+    if (ctx->n_small) {
+        if (ctx->small_dirty) {  // the list changed (a spawner built or destroyed, a type that outgrew the mode): re-sent through the stream
+            ctx->small_list.clear();
+            for (uint32_t si = 0; si < n_seg; si++)
+                if (ctx->segs[si].in_use && ctx->segs[si].small) ctx->small_list.push_back(si);
+            if (ctx->small_list.size() > ctx->small_cap) return poison_segment(ctx, kNoSeg, "small-type list overflow");
+            if (ctx->small_pending) {
+                FW_HIP(ctx, hipEventSynchronize(ctx->ev_small));
+                ctx->small_pending = false;
+            }
+            memcpy(ctx->h_small, ctx->small_list.data(), ctx->small_list.size() * sizeof(uint32_t));
+            FW_HIP(ctx, hipMemcpyAsync(ctx->d_small, ctx->h_small, ctx->small_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            FW_HIP(ctx, hipEventRecord(ctx->ev_small, ctx->stream));
+            ctx->small_pending = true, ctx->small_dirty = false;
+        }
+        FwSmallArgs sa{};
+        sa.list = ctx->d_small, sa.n = (uint32_t)ctx->small_list.size(), sa.parity = p, sa.epoch = a.epoch, sa.dt = dt;
+        sa.seg_op_first = spawn_form == FW_SPAWN_TABLE ? a.seg_op_first : nullptr, sa.ops = a.ops;
+        sa.force_colors = a.force_colors, sa.dbg = ctx->dbg;
+        sa.done_tag = a.done_tag, sa.done_value = a.done_value;
+        sa.host_counts = a.host_counts, sa.live_out = a.live_out, sa.live_next = a.live_next;
+        if (sa.n) {
+            hipEvent_t e0, e1;
+            next_timing_pair(&e0, &e1);
+            FW_HIP(ctx, fw_launch_update_small(ctx->stream, ctx->g, sa, e0, e1));
+            small_launched = true;
+        }
+    }
+    if (total_tiles || !(fifo_launched || range_launched || small_launched)) {
         hipEvent_t e0, e1;
         next_timing_pair(&e0, &e1);
         FW_HIP(ctx, fw_launch_update(ctx->stream, ctx->g, a, spawn_form == FW_SPAWN_INLINE ? &inl : nullptr, spawn_form,
@@ -3754,6 +3856,7 @@ fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, c
     const uint32_t si = sp->seg[type];
     ctx->fc_ok = false, ctx->boxes_epoch = 0;
     if ((st = fifo_to_general(ctx, si))) return st;  // ages and lifetimes will be whatever the caller writes
+    leave_small(ctx, ctx->segs[si]);                  // (any number of particles, any colours: the compacting kernels take it from here)
     if ((st = leave_nospin(ctx, si))) return st;      // ... and so will rotations and angular velocities
     // ... and scales and colours: the planes are stored and read again until every particle has been through an update
     // (an attached buffer keeps receiving records; the mode comes back after the next step)
@@ -3859,6 +3962,7 @@ static fw_status attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void
         if ((st = fifo_to_general(ctx, sp->seg[type]))) return st;
     }
     SegHost &S = ctx->segs[sp->seg[type]];
+    if (d_out) leave_small(ctx, S);  // (instance records are written by the compacting kernels)
     S.inst = (char *)d_out;
     S.inst_cap = d_out ? (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull) : 0u;
     S.inst_window = d_out != nullptr && window;
@@ -3982,6 +4086,9 @@ fw_status fw_ctx_track_aabbs(fw_ctx *ctx, int32_t enable) {
     if (!ctx) return FW_EINVAL;
     ctx->track_aabb = enable != 0;
     if (!enable) ctx->boxes_epoch = 0;
+    if (enable)  // (per-tile boxes are left by the compacting kernels' tiles)
+        for (SegHost &S : ctx->segs)
+            if (S.in_use) leave_small(ctx, S);
     return FW_OK;
 }
 
@@ -4134,7 +4241,7 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t
     if (!sp || type >= sp->seg.size()) return FW_EINVAL;
     const SegHost &S = ctx->segs[sp->seg[type]];
     const TypeHost &T = sp->types[type];
-    if (mode) *mode = S.fifo ? 1 : (S.range ? 2 : 0);
+    if (mode) *mode = S.fifo ? 1 : (S.range ? 2 : (S.small ? 3 : 0));
     const uint32_t colours = (T.base.kind != 0 ? 16u : 0u) + (T.emis.kind != 0 ? 16u : 0u);  // one-key gradients: never rewritten
     uint32_t moved, algo;
     if (S.ring()) {

@@ -290,6 +290,26 @@ struct FwRangeArgs {
 };
 #define FW_RANGE_MAX_CAPACITY 0x10000000u  // slots are addressed as 32-bit byte offsets into a float4 plane
 
+// ---- small particle types: one WAVE per (spawner, particle type) (fw_k_small.hip, round 5) ---------------------------------
+// A type of a few hundred particles needs no workgroup, no tile table, no look-back and no forecast: a wave walks its list in
+// rounds of 64, a ballot + a running count give the stable compaction (core.rs:589-659), its uniform values live in the wave's own
+// scalar registers -- four types per workgroup, thousands of emitters resident at once.  Same ping-pong layout as the compacting
+// path: a type enters and leaves the mode by a host flag (SegHost::small).
+struct FwSmallArgs {
+    const uint32_t *list;          // [n] segments of the launch (device)
+    uint32_t n, parity, epoch;
+    float dt;
+    const uint4 *seg_op_first;     // as FwUpdateArgs (table form: pinned host memory), or null: no virtual spawns this frame
+    const FwOp *ops;
+    uint32_t force_colors, dbg;
+    unsigned long long *done_tag;  // as in FwUpdateArgs
+    unsigned long long done_value;
+    unsigned long long *host_counts;
+    unsigned long long *live_out, *live_next;
+};
+hipError_t fw_launch_update_small(hipStream_t s, const FwGlobals &g, const FwSmallArgs &a, hipEvent_t ev_start = nullptr,
+                                  hipEvent_t ev_stop = nullptr);
+
 enum { FW_SPAWN_NONE = 0, FW_SPAWN_INLINE = 1, FW_SPAWN_TABLE = 2 };
 
 enum { FW_MODE_FUSED = 0, FW_MODE_SPLIT = 1, FW_MODE_SPLIT_COLL = 2 };  // SPLIT_COLL: frames with colliding particle types

@@ -148,12 +148,12 @@ class SpawnerData:
         return int(first.value), int(count.value)
 
     def update_path(self, particle_type: int = 0):
-        """("fifo" | "range" | "general", bytes one update of a live particle moves, of which algorithmic) -- which kernel family
+        """("fifo" | "range" | "general" | "small" (one wave per type, the compacting layout), bytes one update of a live particle moves, of which algorithmic) -- which kernel family
         updates this type and what it costs per particle (bench.py's roofline accounting)"""
         mode, moved, algo = C.c_int32(), C.c_uint32(), C.c_uint32()
         self._sys._check(self._sys._lib.fw_debug_update_path(self._sys._ctx, self.handle, particle_type, C.byref(mode),
                                                              C.byref(moved), C.byref(algo)))
-        return {0: "general", 1: "fifo", 2: "range"}[mode.value], int(moved.value), int(algo.value)
+        return {0: "general", 1: "fifo", 2: "range", 3: "small"}[mode.value], int(moved.value), int(algo.value)
 
     def aabb(self):
         """(any, min, max) of position -/+ scale over all particle types (render.rs:677-703)."""

@@ -30,6 +30,9 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+# (round 5: ... and a fourth time with every type that qualifies -- nothing emits on or from it, no collisions, no instance
+# buffer -- on the wave-per-type kernel of small types, fw_k_small.hip, WHATEVER its size: FW_SMALL_MAX huge; the other three
+# paths switch that kernel off, so "general" still means the compacting kernels at every size)
 # Every GPU test runs three times: with constant-lifetime particle types on the in-place FIFO ring path (whatever their
 # size: FW_FIFO_MIN=0), with every eligible particle type -- any lifetime range, no Nested entries in its spawner, no
 # collisions -- on an in-place RANGE ring (FW_RANGE_MIN=0; FIFO rings off, so constant lifetimes take it too), and with
@@ -39,7 +42,7 @@ def pytest_generate_tests(metafunc):
     if metafunc.module.__name__.split(".")[-1] in ("test_gpu_range", "test_gpu_lifecycle"):
         return  # (set their own knobs: every test of test_gpu_range is about one path, test_gpu_lifecycle runs without any knob)
     if metafunc.definition.get_closest_marker("gpu") and "fw_path" in metafunc.fixturenames:
-        metafunc.parametrize("fw_path", ["fifo", "range", "general"], indirect=True)
+        metafunc.parametrize("fw_path", ["fifo", "range", "general", "small"], indirect=True)
 
 
 def _four_round_tiles(request) -> bool:
@@ -61,6 +64,13 @@ def _four_round_tiles(request) -> bool:
 def fw_path(request, monkeypatch):
     mode = getattr(request, "param", None)
     monkeypatch.setenv("FW_ENABLE_KNOBS", "1")  # the library reads its A/B switches only with this set (firework_hip_debug.h)
+    if mode in ("fifo", "range", "general"):
+        monkeypatch.setenv("FW_SMALL", "0")
+    if mode == "small":
+        monkeypatch.setenv("FW_FIFO", "0")
+        monkeypatch.setenv("FW_RANGE", "0")
+        monkeypatch.setenv("FW_SMALL", "1")
+        monkeypatch.setenv("FW_SMALL_MAX", "2000000000")
     if mode == "fifo":
         monkeypatch.setenv("FW_FIFO", "1")
         monkeypatch.setenv("FW_FIFO_MIN", "0")

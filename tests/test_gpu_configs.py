@@ -302,6 +302,7 @@ def test_the_two_update_paths_agree_bit_for_bit_at_full_size(which, monkeypatch)
         monkeypatch.setenv("FW_FIFO_MIN", "0")
         monkeypatch.setenv("FW_RANGE", "1" if mode == "range" else "0")
         monkeypatch.setenv("FW_RANGE_MIN", "0")
+        monkeypatch.setenv("FW_SMALL", "0")
         with ParticleSystem(device=0, seed=SEED) as ps:
             sp, tf = make()
             h = ps.spawn(sp, tf, uid=5)

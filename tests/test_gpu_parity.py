@@ -458,7 +458,8 @@ def test_attached_instances_replace_the_scale_and_colour_planes(system):
             # continues on the compacting path once records are wanted)
             # (a range ring continues on the compacting path once records are wanted: 4 B more for the lifetime plane it rewrites)
             # (+ the 64-byte record itself, which the update now writes per survivor)
-            assert attached[0][1] == before[0] - 36 + 64 + (4 if attached[0][0] != pair_path0 else 0), (before, attached)
+            # (a small type -- one wave, fw_k_small.hip -- continues on the compacting kernels too: the same layout, the same bytes)
+            assert attached[0][1] == before[0] - 36 + 64 + (4 if attached[0][0] != pair_path0 and pair_path0 != "small" else 0), (before, attached)
         if fr == 100:
             for t in (0, 1):
                 pair.gpu.attach_instances(0, 0, particle_type=t)
@@ -498,7 +499,8 @@ def test_windowed_attach_is_the_plain_attach_where_the_list_starts_at_record_zer
     paths = [pair.gpu.update_path(t)[0] for t in (0, 1)]
     for t in (0, 1):
         pair.gpu.attach_instances_window(bufs[t].data_ptr(), 32768, particle_type=t)
-    assert [pair.gpu.update_path(t)[0] for t in (0, 1)] == paths  # nobody changes path for a windowed buffer
+    # nobody changes path for a windowed buffer (a type updated by one wave continues on the compacting kernels, which write records)
+    assert [pair.gpu.update_path(t)[0] for t in (0, 1)] == ["general" if x == "small" else x for x in paths]
     for fr in range(90):
         system.update(DT)
         pair.step_cpu(DT)
@@ -598,7 +600,7 @@ def test_types_that_cannot_turn_keep_no_rotation_plane(system):
     pair = Pair(system, S.ParticleSpawner([ps], [e0, e1]), S.Transform((1.0, 2.0, 3.0)), seed=SEED, uid=61)
     mode, moved, _ = pair.gpu.update_path(0)
     # constant emissive; no rotation plane, and the lifetimes in a 4-byte plane instead of Q3: 164 - 16 - 32 - 32 + 8
-    assert moved == (92 if mode == "general" else None) or mode in ("fifo", "range")
+    assert moved == (92 if mode in ("general", "small") else None) or mode in ("fifo", "range")
     for fr in range(60):
         system.update(DT)
         pair.step_cpu(DT)
@@ -645,7 +647,7 @@ def test_a_non_finite_step_brings_the_rotation_plane_back(system):
         before += 164 - 32 - 56 - (32 + 4 + 32)
     system.update(np.float32("nan"))
     pair.step_cpu(np.float32("nan"))
-    assert before == 164 - 32 - 56 and pair.gpu.update_path(0)[1] == 164 - 32 and pair.gpu.update_path(0)[0] == "general"
+    assert before == 164 - 32 - 56 and pair.gpu.update_path(0)[1] == 164 - 32 and pair.gpu.update_path(0)[0] in ("general", "small")
     g, c = pair.gpu.particles(0), pair.cpu.particles(0)
     assert len(g) == len(c) == 5000
     for f in ("age", "position", "angular_velocity", "rotation"):

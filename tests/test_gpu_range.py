@@ -25,6 +25,7 @@ def system(monkeypatch, request):
     monkeypatch.setenv("FW_FIFO", "0")
     monkeypatch.setenv("FW_RANGE", "1")
     monkeypatch.setenv("FW_RANGE_MIN", "0")
+    monkeypatch.setenv("FW_SMALL", "0")  # (a type that leaves its ring continues on the compacting kernels: what these tests are about)
     if request.param == "four-round tiles":
         monkeypatch.setenv("FW_RANGE_SMALL", "0")
     else:
@@ -223,7 +224,7 @@ def test_product_defaults_put_each_type_on_its_path(monkeypatch):
     with ParticleSystem(device=0, seed=SEED) as system:
         big_const = S.ParticleSpawner([_settings(lifetime=S.RandF32.constant(0.6))], [_emission(90000.0)])
         big_range = S.ParticleSpawner([_settings(lifetime=S.RandF32(0.4, 0.9))], [_emission(40000.0, emission_shape=S.EmissionShape.Sphere(0.5))])
-        small = S.ParticleSpawner([_settings(lifetime=S.RandF32(0.2, 0.5))], [_emission(2000.0)])
+        small = S.ParticleSpawner([_settings(lifetime=S.RandF32(0.2, 0.5))], [_emission(2000.0)])  # (~700 live: past the wave kernel's bound)
         sparks, tf = workloads.nested(spark_rate=3000.0, smoke_per_spark=8.0)
         pairs = [Pair(system, sp, S.Transform((float(i), 0.5, 0.0)), seed=SEED, uid=500 + i) for i, sp in enumerate((big_const, big_range, small))]
         pairs.append(Pair(system, sparks, tf, seed=SEED, uid=510))
@@ -359,7 +360,7 @@ def test_an_internal_error_is_sticky_for_its_spawner_until_it_is_rebuilt():
             n_by = bystander.gpu.count(0)               # the neighbour is readable and was not touched by the refused frames
             assert n_by > 0
             victim.update_settings(spawner(0.3, 1.5, 40000.0))   # fw_spawner_update_settings
-            assert victim.update_path(0)[0] == "general" and victim.counts() == [0]
+            assert victim.update_path(0)[0] in ("general", "small") and victim.counts() == [0]
             for fr in range(120):
                 ps.update(DT)
             g = victim.particles(0)   # (its RNG streams go on where they were -- they never replay -- so no fresh oracle matches it)
@@ -437,7 +438,7 @@ def test_small_rings_leave_when_the_context_is_no_longer_one_of_few_segments(mon
 
         run(40, "five rings")
         pairs.append(small(720, 0.3, 0.3))  # the sixth segment: rings with live particles become compacting segments
-        assert all(p.gpu.update_path(0)[0] == "general" for p in pairs)
+        assert all(p.gpu.update_path(0)[0] in ("general", "small") for p in pairs)  # (off their rings: compacting layout, by a workgroup or by a wave)
         for k, p in enumerate(pairs):
             p.check(exact_all=True, what=f"right after the change, spawner {k}")
         run(50, "six compacting segments")
@@ -445,12 +446,12 @@ def test_small_rings_leave_when_the_context_is_no_longer_one_of_few_segments(mon
             system.despawn(p.gpu)
         del pairs[:3]
         pairs.append(small(729))  # four segments in use: still past HALF the limit, where the rule comes back (no ping-pong at the limit)
-        assert [p.gpu.update_path(0)[0] for p in pairs] == ["general"] * 4
+        assert all(p.gpu.update_path(0)[0] in ("general", "small") for p in pairs) and len(pairs) == 4
         for p in pairs[:2]:
             system.despawn(p.gpu)
         del pairs[:2]
         pairs.append(small(730))  # two were left: the context is one of few segments again
-        assert [p.gpu.update_path(0)[0] for p in pairs] == ["general", "general", "range"]
+        assert [p.gpu.update_path(0)[0] in ("general", "small") for p in pairs[:2]] == [True, True] and pairs[2].gpu.update_path(0)[0] == "range"
         run(50, "two compacting segments and a ring")
         assert all(p.gpu.count(0) > 400 for p in pairs)
 
@@ -470,7 +471,7 @@ def test_small_rings_leave_when_a_fifo_ring_arrives(monkeypatch):
             for p in pairs:
                 p.step_cpu(DT)
         pairs.append(Pair(system, S.ParticleSpawner([_settings(lifetime=S.RandF32.constant(0.6))], [_emission(90000.0)]), seed=SEED, uid=742))
-        assert [p.gpu.update_path(0)[0] for p in pairs] == ["general", "general", "fifo"]
+        assert [p.gpu.update_path(0)[0] in ("general", "small") for p in pairs[:2]] == [True, True] and pairs[2].gpu.update_path(0)[0] == "fifo"
         for fr in range(80):
             system.update(DT)
             for p in pairs:
