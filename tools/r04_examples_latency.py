@@ -16,7 +16,7 @@ cases = {
     "sparks (1000/s x 0.75 s)": lambda: workloads.example_sparks() + ([],),
     "pbr (150/s x 5 s)": lambda: workloads.example_pbr() + ([],),
     "collision (100/s x 6.75 s, slab + cube)": workloads.example_collision,
-    "textures (12/s x 5 s + 6 puffs each, stand-in world)": workloads.example_textures,
+    "textures (12/s x 5 s + 6 puffs each, cylinder + cone)": workloads.example_textures,
     "stress_test (160k/s x 1 s)": lambda: workloads.stress_test() + ([],),
     "stress_test_collision (80k/s x 2 s)": workloads.stress_test_collision,
     "sparks at 10k/s": lambda: sparks_at(1e4), "sparks at 100k/s": lambda: sparks_at(1e5),
