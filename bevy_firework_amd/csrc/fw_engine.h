@@ -277,6 +277,8 @@ struct alignas(64) SegHost {
     bool win_ok = false;
     bool dead_at_end = false;   // the last step left this type's destroyed records at the END of its buffer (a range ring's
                                 // update fills them from there, the youngest dead first: fw_k_update_range)
+    bool solo = false;          // a small type ONE Global entry feeds: its frame-begin work (lifetime window, bound) happens where
+                                // fw_step's spawner loop makes its op -- the record is streamed once per frame, not twice (fw_ctx::n_solo)
     uint32_t capacity = 0;
     uint32_t ub = 0;            // upper bound of the device count (after this frame's spawns)
     uint32_t frame_spawn = 0;   // Global particles appended this frame
@@ -353,6 +355,7 @@ struct alignas(64) SegHost {
     // workgroup of the compacting kernels -- no tile table entry, no forecast.  Same buffers and layout as a compacting segment:
     // entering and leaving the mode is this flag (fw_ctx::n_small, small_eligible / leave_small).
     bool small = false;
+    bool one_feeder = false;  // exactly one emission entry (a Global one) spawns into the type (SegHost::solo)
     float expect_live = 0.f;  // live particles the emitters that feed the type sustain (what derive_capacity derives the capacity from)
     uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
     uint32_t r_low[3] = {0, 0, 0};               // frames in a row a role's need has been far below what is provided
@@ -431,14 +434,59 @@ struct DevArray {
 }  // namespace fwh
 using namespace fwh;
 
+// The Global ops of one emission index: a growable array that owns its storage -- or, in a frame that will most likely hand the
+// kernels an op TABLE (small types: fw_k_update_small reads its ops from pinned host memory), writes straight into the pinned
+// parameter slot the kernels will read (fw_step: `pre_slot`): 96 bytes per emitter that are written once instead of written,
+// read and written again.
+struct OpList {
+    FwOp *p = nullptr;
+    size_t n = 0, cap = 0;
+    bool lent = false;  // p points into a parameter slot, not into `own`
+    std::vector<FwOp> own;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    FwOp *begin() { return p; }
+    FwOp *end() { return p + n; }
+    const FwOp *begin() const { return p; }
+    const FwOp *end() const { return p + n; }
+    FwOp *data() { return p; }
+    FwOp &operator[](size_t i) { return p[i]; }
+    const FwOp &operator[](size_t i) const { return p[i]; }
+    void clear() {
+        n = 0;
+        if (lent) lent = false, p = own.data(), cap = own.size();
+    }
+    void borrow(FwOp *mem, size_t c) { p = mem, cap = c, n = 0, lent = true; }  // (of an empty list)
+    void reserve_own(size_t c) {  // contents move into (larger) storage of the list's own
+        c = std::max<size_t>(std::max<size_t>(c, n), 64);
+        if (!lent) {
+            if (c <= cap) return;
+            own.resize(c);  // (keeps the contents)
+        } else {
+            if (own.size() < c) own.resize(c);
+            if (n) memcpy(own.data(), p, n * sizeof(FwOp));
+            lent = false;
+        }
+        p = own.data(), cap = own.size();
+    }
+    FwOp &push_slot() {  // the next op, to be filled in place (NOT zeroed)
+        if (n == cap) reserve_own(cap * 2);
+        return p[n++];
+    }
+    void push_back(const FwOp &x) { push_slot() = x; }
+    void append(const FwOp *b, const FwOp *e) {
+        for (; b != e; ++b) push_back(*b);
+    }
+};
+
 struct FwLevel {  // ops of one emission index (spawn order inside a frame: core.rs:377-428)
-    std::vector<FwOp> g;
+    OpList g;
     std::vector<FwNestOp> n;
 };
 
 struct fw_ctx {
     std::vector<FwLevel> levels;  // per-frame scratch of fw_step: one entry per emission index in use
-    std::vector<FwOp> ops_scratch;
+    OpList ops_scratch;
     std::vector<uint32_t> grow_scratch;  // fw_step: Nested-fed segments past half their capacity
     // device staging of the record-format copies (read_particles / write_particles / pack_instances): ONE allocation that
     // only ever grows, instead of a hipMalloc + hipFree pair per call (each a device-wide synchronisation and an address-
@@ -592,6 +640,17 @@ struct fw_ctx {
     bool use_small = true;
     uint32_t small_max = 768;
     uint32_t n_small = 0;
+    // ... and the host half of their frames (thousands of emitters: the frame is bound by the cache lines fw_step streams).
+    // A SOLO segment (SegHost::solo: a small type with one Global feeder) is not visited by the per-segment pass at the start of a
+    // frame: what that pass does for it -- expire the lifetime window, tighten the bound -- happens in the spawner loop, right
+    // before its op is made, and its frame_spawn stays 0 (its one op of the frame carries the count).  The pass walks `big_list`
+    // (every other segment in use) instead of the segment array.  A segment becomes solo in the first frame-begin pass after it
+    // became small, never before (the pass still owes it one ordinary frame begin).  FW_HOST_FAST=0: no solo segments, no ops
+    // written in place (OpList).
+    bool host_fast = true;
+    uint32_t n_solo = 0;
+    std::vector<uint32_t> big_list;
+    bool big_dirty = true;
     std::vector<uint32_t> small_list;   // the segments, ascending (rebuilt when small_dirty)
     bool small_dirty = true;
     uint32_t *d_small = nullptr, *h_small = nullptr;  // device list / pinned staging

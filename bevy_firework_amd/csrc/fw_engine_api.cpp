@@ -108,6 +108,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_NEST_FUSE")) ctx->nest_fuse = atoi(m) != 0;
     if (const char *m = getenv("FW_SMALL")) ctx->use_small = atoi(m) != 0;
     if (const char *m = getenv("FW_SMALL_MAX")) ctx->small_max = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_HOST_FAST")) ctx->host_fast = atoi(m) != 0;
     if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_NT_WO_MB")) ctx->nt_wo_bytes = ctx->nt_wo_bytes_range = (uint64_t)atoll(m) << 20;
 #ifdef FW_AB

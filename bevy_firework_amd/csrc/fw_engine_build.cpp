@@ -239,7 +239,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         SegHost &S = ctx->segs[si];
         S = SegHost{};
         S.in_use = true, S.spawner = h, S.type = (int)t, S.type_idx = type_idx;
-        ctx->n_in_use++;
+        ctx->n_in_use++, ctx->big_dirty = true;
         S.keys_off = dt.keys_off, S.keys_len = dt.keys_len, S.keys_cap = kwin_cap, S.bigkeys = bigkeys;
         S.nospin = nospin, S.n_xplanes = nospin ? 1u : 0u;
         memcpy(S.const_rot, dt.const_rot, sizeof S.const_rot);
@@ -345,6 +345,10 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
             double expect = 0.0;
             derive_capacity(d, t, caps, &expect);
             S.expect_live = (float)std::min(expect, 3.0e9);
+            uint32_t feeders = 0, global_feeders = 0;
+            for (uint32_t i = 0; i < d->n_emission_settings; i++)
+                if ((uint32_t)d->emission_settings[i].particle_index == t) feeders++, global_feeders += d->emission_settings[i].mode == FW_MODE_GLOBAL ? 1u : 0u;
+            S.one_feeder = feeders == 1 && global_feeders == 1;
         }
         if ((st = alloc_seg_buffers(ctx, S, caps[t], p.report_destroyed != 0))) return st;
         if (small_eligible(ctx, S)) enter_small(ctx, S);  // (fw_ctx::n_small: the wave-per-type kernel)
@@ -477,7 +481,8 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
         if (S.few_ring) ctx->n_few--;
         if (S.spilled) ctx->n_spilled--;
         if (S.small) ctx->n_small--, ctx->small_dirty = true;
-        ctx->n_in_use--;
+        if (S.solo) ctx->n_solo--;
+        ctx->n_in_use--, ctx->big_dirty = true;
         if (ctx->n_in_use <= ctx->range_few / 2) ctx->few_blocked = false;
         if (S.h_report) hipHostFree(S.h_report);
         if (S.buf[0]) FW_HIP(ctx, hipFree(S.buf[0]));

@@ -129,6 +129,8 @@ void enter_small(fw_ctx *ctx, SegHost &S) {
 void leave_small(fw_ctx *ctx, SegHost &S) {
     if (!S.small) return;
     S.small = false, ctx->n_small--, ctx->small_dirty = true;
+    if (S.solo) S.solo = false, ctx->n_solo--;  // (fw_step's frame-begin pass visits it again: fw_ctx::big_list)
+    ctx->big_dirty = true;
     ctx->tab_force = true, ctx->fc_ok = false, ctx->boxes_epoch = 0;
 }
 

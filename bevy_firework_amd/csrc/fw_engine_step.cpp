@@ -94,10 +94,33 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         bool fifo_dev = false, fifo_coll = false, fifo_inst = false, range_dev = false, range_coll = false, range_inst = false;
     } ring_stats;
     ctx->grow_scratch.clear();
-    for (size_t si = 0, ns = ctx->segs.size(); si < ns; si++) {
+    // the lifetime window of a segment: drop the spawns that must have expired, tighten the bound with what is left
+    // (an age is an fp32 running sum of the dt values: up to half an ulp of the age per step taken, i.e. a relative
+    // error below steps * 6e-8; the horizon carries that (with a factor 4) on top of a fixed 1e-3)
+    auto expire_window = [&](SegHost &S) {
+        while (!S.win.empty() &&
+               ctx->sim_time - S.win.front().t >=
+                   S.life_bound * (1.0 + 1e-3 + 2.4e-7 * (double)(ctx->frame - S.win.front().frame)) + 1e-6) {
+            S.win_sum -= S.win.front().n;
+            S.win.pop_front();
+        }
+        if (S.win_sum < S.ub) S.ub = (uint32_t)S.win_sum;
+    };
+    // (solo segments -- small types with one feeder, thousands of them -- are not visited: the spawner loop below does this for
+    // them where it makes their op; fw_ctx::big_list holds everybody else)
+    const bool by_list = ctx->n_solo != 0;
+    if (by_list && ctx->big_dirty) {
+        ctx->big_list.clear();
+        for (uint32_t si = 0; si < ctx->segs.size(); si++)
+            if (ctx->segs[si].in_use && !ctx->segs[si].solo) ctx->big_list.push_back(si);
+        ctx->big_dirty = false;
+    }
+    const bool solo_ok = ctx->host_fast && ctx->use_small;
+    for (size_t k = 0, ns = by_list ? ctx->big_list.size() : ctx->segs.size(); k < ns; k++) {
+        const size_t si = by_list ? ctx->big_list[k] : k;
         SegHost &S = ctx->segs[si];
-        if (si + 8 < ns) {  // the oldest window entry of a later segment: a heap line of its own, fetched ahead of time
-            const SegHost &N = ctx->segs[si + 8];
+        if (k + 8 < ns) {  // the oldest window entry of a later segment: a heap line of its own, fetched ahead of time
+            const SegHost &N = ctx->segs[by_list ? ctx->big_list[k + 8] : k + 8];
             if (N.win.n) __builtin_prefetch(&N.win.v[N.win.head]);
         }
         S.frame_spawn = 0;
@@ -109,16 +132,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         if (S.range) ring_stats.range_parts += S.ub, ring_stats.range_dev |= S.range_dev, ring_stats.range_coll |= S.collides, ring_stats.range_inst |= S.inst != nullptr;
         any_inst_general |= !S.ring() && S.inst != nullptr;
         if (S.nested_fed && nested_fed_wants_growth(S)) ctx->grow_scratch.push_back((uint32_t)si);
-        if (!S.win_ok) continue;
-        // an age is an fp32 running sum of the dt values: up to half an ulp of the age per step taken, i.e. a relative
-        // error below steps * 6e-8; the horizon carries that (with a factor 4) on top of a fixed 1e-3
-        while (!S.win.empty() &&
-               ctx->sim_time - S.win.front().t >=
-                   S.life_bound * (1.0 + 1e-3 + 2.4e-7 * (double)(ctx->frame - S.win.front().frame)) + 1e-6) {
-            S.win_sum -= S.win.front().n;
-            S.win.pop_front();
-        }
-        if (S.win_sum < S.ub) S.ub = (uint32_t)S.win_sum;
+        if (S.win_ok) expire_window(S);
+        // a small type with one feeder: solo from here on (this was its last visit by this pass)
+        if (S.small && S.one_feeder && solo_ok) S.solo = true, ctx->n_solo++, ctx->big_dirty = true;
     }
 
     // Nested-fed segments whose count (or its growth) nears their derived capacity: nested_fed_wants_growth.  By half again,
@@ -148,6 +164,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         auto forget = [&](const FwOp &op) {
             SegHost &S = ctx->segs[op.seg];
             S.cum_spawn -= op.n;
+            if (S.solo) S.ub -= std::min(S.ub, op.n);  // (its frame_spawn stays 0: the loop over the segments below does nothing for it)
             if (S.fifo || !S.win_ok || S.win.empty() || S.win.back().t != ctx->sim_time) return;
             S.win_sum -= op.n;
             if ((S.win.back().n -= op.n) == 0) S.win.pop_back();
@@ -179,6 +196,67 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         S.win_sum += n;
     };
 
+    // A parameter slot of the ring (pinned host memory the kernels read in place, or stage from): free once the frame that used
+    // it last has been consumed.
+    auto acquire_slot = [&](int *out) -> fw_status {
+        const int slot = (int)(ctx->ring_seq++ % kParamRing);
+        if (ctx->consumed_pending[slot]) {
+            FW_HIP(ctx, hipEventSynchronize(ctx->ev_consumed[slot]));
+            ctx->consumed_pending[slot] = false;
+        }
+        if (ctx->slot_frame[slot]) {  // zero-copy use: wait until a launch AFTER that frame has started
+            const volatile unsigned long long *tag = ctx->h_done;
+            for (int spin = 0; *tag < ctx->slot_frame[slot] && spin < 200000; spin++) __builtin_ia32_pause();
+            if (*tag < ctx->slot_frame[slot]) FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->slot_frame[slot] = 0;
+        }
+        *out = slot;
+        return FW_OK;
+    };
+    // Frames of a context with small types hand their Global ops to the kernels as a TABLE in a parameter slot ({first op, one past
+    // the last, particles} per segment, then the ops): the spawner loop writes both IN PLACE (OpList::borrow) -- with thousands of
+    // emitters the ops are 200-400 KB a frame, and writing them to a list, reading the list and writing the table was a tenth of the
+    // host's frame.  The headers are kept while the ops arrive (segments ascending, each one's ops next to each other: what a
+    // context whose spawners were built in order delivers); anything else -- an op routed later, a list that outgrows the slot, a
+    // frame that turns out to need the separate spawn passes -- falls back to the sort + header pass further down, over the same
+    // memory or the list's own.
+    struct OpHdr {  // FwUpdateArgs::seg_op_first: per segment {first op, one past its last, particles they spawn in all, 0}
+        uint32_t o0, o1, n, pad;
+    };
+    int pre_slot = -1;
+    OpHdr *pre_hdr = nullptr;
+    size_t pre_tracked = 0;     // ops of levels[0].g whose headers are up to date
+    bool pre_hdr_ok = false;
+    uint32_t pre_last_seg = 0;
+    if (ctx->host_fast && ctx->n_small != 0 && ctx->update_mode == FW_MODE_FUSED && !levels.empty()) {
+        const size_t n_seg0 = ctx->segs.size(), off_ops0 = n_seg0 * sizeof(OpHdr);
+        const size_t want_ops = (size_t)ctx->n_in_use + 16;
+        fw_status pst = FW_OK;
+        if (ctx->param_bytes < off_ops0 + want_ops * sizeof(FwOp)) pst = ensure_param_ring(ctx, off_ops0 + (want_ops * 2 + 64) * sizeof(FwOp));
+        if (!pst) pst = acquire_slot(&pre_slot);
+        if (pst) return pst;  // (nothing of the frame has been entered anywhere yet)
+        pre_hdr = (OpHdr *)ctx->h_param[pre_slot];
+        memset(pre_hdr, 0, off_ops0);
+        levels[0].g.borrow((FwOp *)(ctx->h_param[pre_slot] + off_ops0), (ctx->param_bytes - off_ops0) / sizeof(FwOp));
+        pre_hdr_ok = true;
+    }
+    // (the ring may be re-allocated when a frame needs more than it holds: a list that lives in it moves out first)
+    auto ensure_ring = [&](size_t bytes) -> fw_status {
+        if (bytes > ctx->param_bytes && pre_slot >= 0) {
+            levels[0].g.reserve_own(levels[0].g.size());
+            pre_slot = -1, pre_hdr = nullptr, pre_hdr_ok = false;
+        }
+        return ensure_param_ring(ctx, bytes);
+    };
+    // a refresh of the exact counts drops this frame's appends from every bound: back in they go
+    auto readd_frame_spawns = [&]() {
+        for (auto &X : ctx->segs) X.ub += X.frame_spawn;
+        if (ctx->n_solo)  // (a solo segment's appends of the frame are in its op)
+            for (auto &L : ctx->levels)
+                for (const FwOp &op : L.g)
+                    if (ctx->segs[op.seg].solo) ctx->segs[op.seg].ub += op.n;
+    };
+
     prof(0);
     // spawn_particles, host half (core.rs:377-428): emission clocks and Global counts
     for (size_t h = 0; h < ctx->spawners.size(); h++) {
@@ -190,6 +268,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 __builtin_prefetch((const char *)nx.em.data() + 128);
             }
         }
+        // (solo segments -- visited here and nowhere else in the frame -- fetched a few spawners ahead of time, record first, then the
+        // two ends of the lifetime window: built and measured, 38.5 -> 42 us per frame at 2048 x 200, the loop is bound by its
+        // instructions and stores by now, not by the latency of its loads: profiles/r05/host_fast_prefetch.txt)
         if (!sp.alive) continue;
         // `if data.active()` (core.rs:378): an entry that emits on other particles contributes only when
         // some particle exists; with no particle at all the Nested arm below is a no-op anyway, so the
@@ -224,6 +305,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 if (n > kMaxSpawnPerOp)
                     return rollback(fail(ctx, FW_ECAPACITY, "emission count exceeds 2^30 particles in one frame"));
                 SegHost &S = ctx->segs[dst];
+                if (S.solo && S.win_ok) expire_window(S);  // its frame begins here (fw_ctx::n_solo)
                 if (S.nested_fed && S.auto_capacity && S.capacity < 0x70000000u) {
                     // A type that receives Nested children too: its children are counted on the device, but its Global
                     // particles are counted right here.  Count of the latest snapshot row + every Global particle since
@@ -236,7 +318,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                         fw_status st = grow_segment(ctx, dst, (uint32_t)std::min<uint64_t>(est * 2, 0x70000000ull));
                         if (!st) st = grow_nested_children(ctx, sp, (uint32_t)es.particle_index);
                         // (the growth refreshed every bound from the device's exact counts, without this frame's appends)
-                        for (auto &X : ctx->segs) X.ub += X.frame_spawn;
+                        readd_frame_spawns();
                         if (st) return rollback(st);
                         S.snap_count = S.ub - std::min(S.ub, S.frame_spawn), S.snap_cum = S.cum_spawn - S.frame_spawn;
                         S.dev_count = 0;
@@ -246,7 +328,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     fw_status st = refresh_counts_exact(ctx);
                     if (st) return rollback(st);
                     // the refresh dropped this frame's earlier appends from ub: add them back
-                    for (auto &X : ctx->segs) X.ub += X.frame_spawn;
+                    readd_frame_spawns();
                     if ((uint64_t)S.ub + n > S.capacity) {
                         if ((uint64_t)S.ub + n > 0xF0000000ull)
                             return rollback(fail(ctx, FW_ECAPACITY, "particle type too large"));
@@ -257,34 +339,54 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                         const uint32_t settled = S.ub;
                         st = grow_segment(ctx, dst, (uint32_t)(settled + fs + n));
                         if (!st) st = grow_nested_children(ctx, sp, (uint32_t)es.particle_index);
-                        for (auto &X : ctx->segs) X.ub += X.frame_spawn;
+                        readd_frame_spawns();
                         if (st) return rollback(st);
                     }
                 }
                 // does every particle of this op outlive the step?  (TypeHost::life_lo_safe; false for NaN)
                 if (!S.ring() && !(dt < E.life_lo_safe)) new_static = false;
-                FwOp op{};
-                op.seg = dst, op.emit = E.emit_idx, op.n = (uint32_t)n;
-                op.rel_base = S.frame_spawn;
-                op.serial_base = E.serial;
-                memcpy(op.origin_pos, sp.origin_pos, sizeof sp.origin_pos);
-                memcpy(op.origin_rot, sp.origin_rot, sizeof sp.origin_rot);
-                memcpy(op.parent_vel, sp.parent_vel, sizeof sp.parent_vel);
-                op.speed = sp.mod_speed, op.scale = sp.mod_scale;
-                if (S.fifo && S.fifo_mat && !S.virt_parent)
-                    ctx->fifo_mat_ops.push_back({(uint32_t)i, op});  // routed below, once the frame's Nested ops are known
-                else if (S.fifo)
-                    ctx->fifo_ops.push_back(op);  // spawned inside fw_k_update_fifo, whatever else the frame holds
-                else if (S.range && S.range_mat && !S.virt_parent)
-                    ctx->range_mat_ops.push_back({(uint32_t)i, op});  // routed below, once the frame's Nested ops are known
-                else if (S.range)
-                    ctx->range_ops.push_back(op);  // spawned inside fw_k_update_range
-                else
-                    levels[i].g.push_back(op);
+                auto fill = [&](FwOp &op) {
+                    memset(&op, 0, sizeof op);
+                    op.seg = dst, op.emit = E.emit_idx, op.n = (uint32_t)n;
+                    op.rel_base = S.frame_spawn;
+                    op.serial_base = E.serial;
+                    memcpy(op.origin_pos, sp.origin_pos, sizeof sp.origin_pos);
+                    memcpy(op.origin_rot, sp.origin_rot, sizeof sp.origin_rot);
+                    memcpy(op.parent_vel, sp.parent_vel, sizeof sp.parent_vel);
+                    op.speed = sp.mod_speed, op.scale = sp.mod_scale;
+                };
+                if (!S.ring()) {
+                    // a compacting or small segment: the op goes to its emission level, written where it will stay
+                    OpList &G = levels[i].g;
+                    if (i == 0 && pre_hdr_ok) {  // ... and, in a list that lives in a parameter slot, into the segment's header
+                        const uint32_t idx = (uint32_t)G.size();
+                        OpHdr &H = pre_hdr[dst];
+                        if (H.o1 == 0 && dst >= pre_last_seg) H.o0 = idx, H.o1 = idx + 1u, H.n = (uint32_t)n;
+                        else if (H.o1 == idx && H.o1 != 0) H.o1 = idx + 1u, H.n = (uint32_t)std::min<uint64_t>((uint64_t)H.n + n, 0xFFFFFFFFull);
+                        else pre_hdr_ok = false;  // (out of segment order: the sort + header pass below)
+                        pre_last_seg = dst, pre_tracked = idx + 1u;
+                    }
+                    fill(G.push_slot());
+                } else {
+                    FwOp op;
+                    fill(op);
+                    if (S.fifo && S.fifo_mat && !S.virt_parent)
+                        ctx->fifo_mat_ops.push_back({(uint32_t)i, op});  // routed below, once the frame's Nested ops are known
+                    else if (S.fifo)
+                        ctx->fifo_ops.push_back(op);  // spawned inside fw_k_update_fifo, whatever else the frame holds
+                    else if (S.range_mat && !S.virt_parent)
+                        ctx->range_mat_ops.push_back({(uint32_t)i, op});  // routed below, once the frame's Nested ops are known
+                    else
+                        ctx->range_ops.push_back(op);  // spawned inside fw_k_update_range
+                }
                 E.serial += n;
-                S.frame_spawn += (uint32_t)n;
+                if (!S.solo) S.frame_spawn += (uint32_t)n;  // (a solo segment's one op of the frame carries the count)
                 S.ub = (uint32_t)std::min<uint64_t>((uint64_t)S.ub + n, 0xFFFFFFFFull);
-                if (S.small && S.ub > ctx->small_max) leave_small(ctx, S);  // (no longer a few hundred particles: a compacting segment from this frame on)
+                if (S.small && S.ub > ctx->small_max) {  // no longer a few hundred particles: a compacting segment from this frame on
+                    const bool was_solo = S.solo;
+                    leave_small(ctx, S);
+                    if (was_solo) S.frame_spawn = (uint32_t)n;
+                }
                 note_spawned(S, n);
             } else {
                 if (es.pacing_kind != FW_PACING_COUNT_OVER_DURATION) continue;  // warn_once + continue core.rs:474-485
@@ -412,9 +514,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     size_t n_g = 0, n_n = 0;
     for (auto &L : levels) n_g += L.g.size(), n_n += L.n.size();
     // last thing that can fail before the frame is enqueued: room for the op tables of either form
-    if ((st = ensure_param_ring(ctx, (size_t)n_seg * 16 + n_g * sizeof(FwOp) +
-                                         n_n * sizeof(FwNestOp) + 16)))
-        return rollback(st);
+    if ((st = ensure_ring((size_t)n_seg * 16 + n_g * sizeof(FwOp) + n_n * sizeof(FwNestOp) + 16))) return rollback(st);
     // ---- the frame will run
     prof(3);
     const uint32_t p = ctx->parity;
@@ -510,18 +610,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         // per-parent pass reads them (core.rs:488), so Global ops are materialised by fw_k_spawn, level by level.
         const size_t off_nops = n_g * sizeof(FwOp);
         const size_t bytes = off_nops + n_n * sizeof(FwNestOp) + 16;
-        if ((st = ensure_param_ring(ctx, bytes))) return st;
-        slot = (int)(ctx->ring_seq++ % kParamRing);
-        if (ctx->consumed_pending[slot]) {
-            FW_HIP(ctx, hipEventSynchronize(ctx->ev_consumed[slot]));
-            ctx->consumed_pending[slot] = false;
-        }
-        if (ctx->slot_frame[slot]) {  // zero-copy use: wait until a launch AFTER that frame has started
-            const volatile unsigned long long *tag = ctx->h_done;
-            for (int spin = 0; *tag < ctx->slot_frame[slot] && spin < 200000; spin++) __builtin_ia32_pause();
-            if (*tag < ctx->slot_frame[slot]) FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            ctx->slot_frame[slot] = 0;
-        }
+        if ((st = ensure_ring(bytes))) return st;
+        if ((st = acquire_slot(&slot))) return st;
         char *hp = ctx->h_param[slot];
         char *dp = ctx->d_param[slot];  // staged copy here: the few workgroups of the small spawn / nest kernels would
                                         // wait for the bus on their critical path (measured: no gain from reading in place)
@@ -602,20 +692,23 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         // Global-only frame: spawn is fused into the update kernel (virtual particles).  Ops sorted by segment;
         // the order inside a segment stays the emission order (rel_base was assigned in that order).
         // (one emission level holds all of them most of the time: its list is used as it is)
-        std::vector<FwOp> *one = nullptr;
+        OpList *one = nullptr;
         size_t n_lists = 0;
         for (auto &L : levels)
             if (!L.g.empty()) one = &L.g, n_lists++;
         if (n_lists != 1) {
             one = &ctx->ops_scratch;
             one->clear();
-            one->reserve(n_g);
-            for (auto &L : levels) one->insert(one->end(), L.g.begin(), L.g.end());
+            one->reserve_own(n_g);
+            for (auto &L : levels) one->append(L.g.begin(), L.g.end());
         }
-        std::vector<FwOp> &ops = *one;
+        OpList &ops = *one;
+        // the list lives in the parameter slot taken before the spawner loop (`pre_slot`), and so may its headers
+        const bool in_place = pre_slot >= 0 && one == &levels[0].g && ops.lent;
+        const bool hdr_done = in_place && pre_hdr_ok && pre_tracked == ops.size();
         // sorted by segment, emission order kept inside a segment; a single emission level is already in spawner
         // (= segment creation) order most of the time: skip the sort then
-        if (!std::is_sorted(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; }))
+        if (!hdr_done && !std::is_sorted(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; }))
             std::stable_sort(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; });
         a.n_ops = (uint32_t)ops.size();
         if (ops.size() <= FW_INLINE_OPS && (ops.empty() || !ctx->n_small)) {  // (small types read their ops from the table: fw_k_update_small)
@@ -623,34 +716,27 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             for (size_t i = 0; i < ops.size(); i++) inl.ops[i] = ops[i];
         } else {
             spawn_form = FW_SPAWN_TABLE;
-            struct OpHdr {  // FwUpdateArgs::seg_op_first: per segment {first op, one past its last, particles they spawn in all, 0}
-                uint32_t o0, o1, n, pad;
-            };
             const size_t off_ops = (size_t)n_seg * sizeof(OpHdr);
             const size_t bytes = off_ops + ops.size() * sizeof(FwOp);
-            if ((st = ensure_param_ring(ctx, bytes))) return st;
-            slot = (int)(ctx->ring_seq++ % kParamRing);
-            if (ctx->consumed_pending[slot]) {
-                FW_HIP(ctx, hipEventSynchronize(ctx->ev_consumed[slot]));
-                ctx->consumed_pending[slot] = false;
-            }
-            if (ctx->slot_frame[slot]) {  // zero-copy use: wait until a launch AFTER that frame has started
-                const volatile unsigned long long *tag = ctx->h_done;
-                for (int spin = 0; *tag < ctx->slot_frame[slot] && spin < 200000; spin++) __builtin_ia32_pause();
-                if (*tag < ctx->slot_frame[slot]) FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                ctx->slot_frame[slot] = 0;
+            if (in_place) {
+                slot = pre_slot;  // (taken, waited for and large enough since before the spawner loop; the ops are where they belong)
+            } else {
+                if ((st = ensure_ring(bytes))) return st;
+                if ((st = acquire_slot(&slot))) return st;
             }
             char *hp = ctx->h_param[slot];
             char *dp = ctx->d_param[slot];
-            OpHdr *hdr = (OpHdr *)hp;
-            size_t oi = 0;
-            for (uint32_t sgi = 0; sgi < n_seg; sgi++) {  // (ops are sorted by segment)
-                const size_t b = oi;
-                uint64_t n = 0;
-                while (oi < ops.size() && ops[oi].seg == sgi) n += ops[oi].n, oi++;
-                hdr[sgi] = OpHdr{(uint32_t)b, (uint32_t)oi, (uint32_t)std::min<uint64_t>(n, 0xFFFFFFFFull), 0u};
+            if (!hdr_done) {
+                OpHdr *hdr = (OpHdr *)hp;
+                size_t oi = 0;
+                for (uint32_t sgi = 0; sgi < n_seg; sgi++) {  // (ops are sorted by segment)
+                    const size_t b = oi;
+                    uint64_t n = 0;
+                    while (oi < ops.size() && ops[oi].seg == sgi) n += ops[oi].n, oi++;
+                    hdr[sgi] = OpHdr{(uint32_t)b, (uint32_t)oi, (uint32_t)std::min<uint64_t>(n, 0xFFFFFFFFull), 0u};
+                }
             }
-            memcpy(hp + off_ops, ops.data(), ops.size() * sizeof(FwOp));
+            if (!in_place) memcpy(hp + off_ops, ops.data(), ops.size() * sizeof(FwOp));
             if (ctx->ops_zerocopy) {
                 // pinned host memory is device-visible: the tiles read their few ops over the bus (tens of bytes each)
                 a.seg_op_first = (const uint4 *)hp;
@@ -685,7 +771,8 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         // the ring launch(es) of this frame: on the side stream when a general launch runs next to them (fw_ctx: fifo_stream)
         // (never on a caller-supplied stream: work the caller orders behind fw_step on ITS stream must cover the whole
         // frame, as it did before the side stream existed)
-        bool side = ctx->use_fifo_stream && ctx->own_stream && total_tiles != 0 && ctx->live_ring == nullptr;
+        // (the wave-per-type launch of small types counts as "a general launch" here: it touches none of the rings either)
+        bool side = ctx->use_fifo_stream && ctx->own_stream && (total_tiles != 0 || ctx->n_small != 0) && ctx->live_ring == nullptr;
         // (... nor with a colliding ring: a new collider set travels in the MAIN stream, fw_ctx_set_colliders)
         for (const SegHost &S : ctx->segs) side &= !(S.in_use && S.fifo && (S.fifo_mat || S.inst != nullptr || S.collides));
         if (side && (!ctx->fifo_last_side || ctx->main_reads_ring)) {

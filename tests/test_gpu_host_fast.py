@@ -1,0 +1,119 @@
+"""The host half of a frame with many small emitters (round 5: solo segments, ops and their per-segment headers written in place
+into the parameter slot -- csrc/fw_engine_step.cpp, fw_engine.h: OpList, fw_ctx::n_solo) at PRODUCT DEFAULTS: the bookkeeping the
+fast path skips or moves (frame_spawn, the frame-begin pass, the sort + header pass) must not change a single particle.  Every
+case against the oracle, bit for bit; the same world with FW_HOST_FAST=0 gives the same digest.  Needs an MI355X."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle  # noqa: F401
+from bevy_firework_amd import settings as S
+from bevy_firework_amd import workloads
+from parity import Pair
+
+pytestmark = pytest.mark.gpu
+DT = np.float32(1.0 / 60.0)
+SEED = workloads.SEED
+
+
+def _emitter(rate, life, k, entries=1, types=1, fed=0):
+    ps = [S.ParticleSettings(lifetime=S.RandF32(life, life * 1.3), linear_drag=0.1 + 0.01 * (k % 7),
+                             base_color=S.FireworkGradient.uneven_samples(workloads.STRESS_GRADIENT)) for _ in range(types)]
+    es = [S.EmissionSettings(particle_index=fed, emission_pacing=S.EmissionPacing.rate(rate * (1.0 + 0.5 * e)),
+                             initial_velocity=S.RandVec3(S.RandF32(1.0, 4.0), (0.0, 1.0, 0.0), 0.0)) for e in range(entries)]
+    return S.ParticleSpawner(ps, es)
+
+
+def _world(system, n_solo):
+    pairs = []
+    for k in range(n_solo):  # one type, one entry: solo segments; every third one emits only every few frames
+        rate = 25.0 if k % 3 == 2 else 500.0 + 3.0 * k
+        pairs.append(Pair(system, _emitter(rate, 0.2, k), S.Transform((float(k % 17), 0.0, float(k // 17))), seed=SEED, uid=1000 + k))
+    # two entries feed ONE small type: not solo (its ops of a frame share a header)
+    pairs.append(Pair(system, _emitter(300.0, 0.25, 7, entries=2), S.Transform((1.0, 2.0, 3.0)), seed=SEED, uid=5000))
+    # emitters that sustain ~300 particles on average -- small types when they are built -- but emit a cycle's worth in its first
+    # 0.3 s: 1100 live pass the bound of the wave-per-type kernel (the type continues on the compacting path, from the frame in
+    # which the op that does it is made), 2600 also pass the derived capacity (2048: the segment grows in that frame)
+    for j, (count, duration) in enumerate(((1100.0, 3.0), (2600.0, 8.0))):
+        ps = S.ParticleSettings(lifetime=S.RandF32(0.6, 0.78), base_color=S.FireworkGradient.uneven_samples(workloads.STRESS_GRADIENT))
+        es = S.EmissionSettings(emission_pacing=S.EmissionPacing.CountOverDuration(count, duration, 0.0, 0.3 / duration),
+                                initial_velocity=S.RandVec3(S.RandF32(1.0, 4.0), (0.0, 1.0, 0.0), 0.0))
+        pairs.append(Pair(system, S.ParticleSpawner([ps], [es]), S.Transform((3.0, float(j), 0.0)), seed=SEED, uid=5100 + j))
+    return pairs
+
+
+def _run(system, pairs, n, what, every=10, dt=DT):
+    for fr in range(n):
+        system.update(dt)
+        for p in pairs:
+            p.step_cpu(dt)
+        if fr % every == every - 1 or fr == n - 1:
+            for k, p in enumerate(pairs):
+                p.check(exact_all=True, what=f"{what}, frame {fr}, spawner {k}")
+
+
+def _scenario(system, digest=None):
+    from bevy_firework_amd.system import FwError
+
+    pairs = _world(system, 96)
+    assert {p.gpu.update_path(0)[0] for p in pairs} == {"small"}
+    _run(system, pairs, 25, "steady", every=5)
+    assert [p.gpu.update_path(0)[0] for p in pairs[-2:]] == ["general", "general"] and pairs[-1].gpu.count(0) > 2048
+    assert {p.gpu.update_path(0)[0] for p in pairs[:-2]} == {"small"}
+    # segment slots and spawner slots no longer run in step: a two-type spawner whose entry feeds its SECOND type takes the freed
+    # slot 3 and a slot at the end, the spawner built after it the freed slot 40 -- ops arrive out of segment order from here on
+    for k in (40, 3):
+        system.despawn(pairs[k].gpu)
+        del pairs[k]
+    pairs.append(Pair(system, _emitter(450.0, 0.2, 1, types=2, fed=1), S.Transform((0.5, 0.0, 0.0)), seed=SEED, uid=6000))
+    pairs.append(Pair(system, _emitter(520.0, 0.2, 2), S.Transform((0.0, 0.5, 0.0)), seed=SEED, uid=6001))
+    _run(system, pairs, 25, "after the slots were shuffled")
+    # a frame that cannot be enqueued (2^30 particles in one op) while ops already sit in the parameter slot: nothing changes
+    bad = system.spawn(S.ParticleSpawner([S.ParticleSettings(lifetime=S.RandF32.constant(0.5))],
+                                         [S.EmissionSettings(emission_pacing=S.EmissionPacing.OnDemand())]), S.Transform(), uid=7000)
+    bad.queue_particles((1 << 30) + 5)
+    for _ in range(2):
+        with pytest.raises(FwError) as e:
+            system.update(DT)
+        assert e.value.status == -4  # FW_ECAPACITY
+    system.despawn(bad)
+    for k, p in enumerate(pairs):
+        p.check(exact_all=True, what=f"after the failed frames, spawner {k}")
+    _run(system, pairs, 12, "after the failed frames")
+    if digest is not None:
+        for p in pairs:
+            for t in range(p.n_types):
+                digest.update(p.gpu.particles(t).tobytes())
+    return pairs
+
+
+def _product_defaults(monkeypatch):
+    for k in list(os.environ):
+        if k.startswith("FW_") and k != "FW_LIB_PATH":
+            monkeypatch.delenv(k, raising=False)
+
+
+def test_many_small_emitters_shuffled_slots_failed_frames_and_a_long_step(monkeypatch):
+    from bevy_firework_amd.system import ParticleSystem
+
+    _product_defaults(monkeypatch)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        _scenario(system)
+
+
+def test_the_same_world_without_the_fast_host_path(monkeypatch):
+    """FW_HOST_FAST=0 (the frame-begin pass over every segment, ops through a list + the sort + header pass) and the default
+    give the same particles, byte for byte"""
+    from bevy_firework_amd.system import ParticleSystem
+
+    _product_defaults(monkeypatch)
+    out = []
+    for fast in ("1", "0"):
+        monkeypatch.setenv("FW_ENABLE_KNOBS", "1"), monkeypatch.setenv("FW_HOST_FAST", fast)
+        h = hashlib.sha256()
+        with ParticleSystem(device=0, seed=SEED) as system:
+            _scenario(system, h)
+        out.append(h.hexdigest())
+    assert out[0] == out[1]
