@@ -200,6 +200,7 @@ struct EmissionHost {
     uint32_t emit_slot = 0;   // -> device serial counter (Nested)
     uint32_t dst_seg = 0;     // segment of es.particle_index (cached: the frame loop then touches only this record)
     float life_lo_safe = 0.f; // TypeHost::life_lo_safe of es.particle_index
+    float between = 0.f;      // (es.offset_end - es.offset_start) / es.count: fw_emission_count_unit
     bool enabled = false, emits_on_other_particles = false;
     bool assigned = false;    // emit_idx / emit_slot are owned by this entry
     fw_emission_settings es{};

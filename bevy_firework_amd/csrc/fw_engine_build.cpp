@@ -368,6 +368,7 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         EmissionHost &E = sp.em[i];
         const fw_emission_settings &e = d->emission_settings[i];
         E.es = e;
+        E.between = (e.offset_end - e.offset_start) / e.count;
         E.last_emission = 0.f, E.time_passed_in_cycle = 0.f;  // sync_spawner_data core.rs:350-358
         E.enabled = d->starts_enabled != 0;
         E.emits_on_other_particles = e.mode == FW_MODE_NESTED;

@@ -297,8 +297,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 } else {
                     E.time_passed_in_cycle = fw_rem_euclid(E.time_passed_in_cycle + dt, es.duration);  // core.rs:412-414
                     float next = 0.f;
-                    n = fw_emission_count(E.time_passed_in_cycle, E.last_emission, es.duration, es.offset_start,
-                                          es.offset_end, es.count, &next);
+                    n = es.duration == 1.0f
+                            ? fw_emission_count_unit(E.time_passed_in_cycle, E.last_emission, es.offset_start, es.offset_end, E.between, &next)
+                            : fw_emission_count(E.time_passed_in_cycle, E.last_emission, es.duration, es.offset_start, es.offset_end,
+                                                es.count, &next);
                     E.last_emission = next;
                 }
                 if (!n) continue;

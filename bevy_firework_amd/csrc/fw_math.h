@@ -61,6 +61,18 @@ FW_HD uint64_t fw_emission_count(float time_passed, float last_emission, float d
     return fw_as_usize(times);
 }
 
+// ... for an entry whose duration is exactly 1 (every EmissionPacing::rate, core.rs:36-43), with `between` = (end - start) /
+// per_cycle evaluated once when the entry is built: x / 1 and x * 1 are x in IEEE arithmetic, so this returns the very bits
+// fw_emission_count returns with one division instead of four (the host's spawner loop, thousands of emitters per frame)
+FW_HD uint64_t fw_emission_count_unit(float time_passed, float last_emission, float start, float end, float between, float *next_last) {
+    float base = fmaxf(last_emission, start);
+    float since = fminf(time_passed, end) - base;
+    float times = fw_div_euclid(since, between);
+    float adv = times * between;
+    *next_last = base + adv;
+    return fw_as_usize(times);
+}
+
 // Vec3::normalize_or_zero (src/core.rs:442,512)
 FW_HD fw_v3 fw_normalize_or_zero(fw_v3 a) {
     float rcp = 1.0f / sqrtf(fw_dot3(a, a));
