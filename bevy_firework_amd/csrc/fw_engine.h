@@ -36,6 +36,7 @@
 #include <vector>
 
 #include <sys/mman.h>
+#include <immintrin.h>
 
 #include "../../include/firework_hip.h"
 #include "../../include/firework_hip_debug.h"
@@ -708,7 +709,13 @@ struct fw_ctx {
     hipEvent_t ev_rtab = nullptr;
     bool rtab_pending = false;
     unsigned long long *d_rstatus = nullptr;  // look-back words of the OLD workgroups
-    char *h_rparam[kParamRing] = {};          // pinned per-frame records + ops, read by the kernel in place
+    char *h_rparam[kParamRing] = {};          // per-frame records + ops, written by the host, read by the kernel in place
+    // ... in DEVICE memory the host writes through the large BAR (fine-grained, hipExtMallocWithFlags) when the platform maps it, in
+    // pinned host memory otherwise: a workgroup's record is the first thing its loads depend on, and read over the bus it costs
+    // every launch ~3 us of dead time (tools/barwrite.hip, profiles/r05/rparam_ab.txt: one sparks.rs emitter 8.9 -> 5.7 us per frame,
+    // one GPU's share of configs[4] 90.3 -> 85.9, configs[2] 318 -> 311).  The host only ever WRITES such a buffer (write-combining
+    // stores, a fence, one read-back of the last word before the launch: posted writes may not pass it).  FW_PARAM_BAR=0: pinned.
+    bool param_bar = false;
     bool range_spread_new = true;   // FW_RANGE_SPREAD_NEW=0: a segment's NEW workgroups all in front of its YOUNG ones (A/B)
     // An in-place ring launch (FIFO / range) that streams more than nt_bytes uses the fully non-temporal form of its kernel:
     // several times the 256 MiB Infinity Cache, where allocating lines that cannot survive until the next frame only costs.

@@ -45,6 +45,17 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     fw_ctx *ctx = new fw_ctx();
     ctx->device = device;
     ctx->seed = seed;
+    {  // fw_ctx::param_bar: device memory the host can write (large BAR) -- asked of the runtime, then tried once
+        int large_bar = 0;
+        void *probe = nullptr;
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar != 0 &&
+            hipExtMallocWithFlags(&probe, 4096, hipDeviceMallocFinegrained) == hipSuccess) {
+            hipPointerAttribute_t at{};
+            ctx->param_bar = hipPointerGetAttributes(&at, probe) == hipSuccess && at.type == hipMemoryTypeDevice;
+            hipFree(probe);
+        }
+        (void)hipGetLastError();
+    }
     auto bail = [&](const char *what, hipError_t he) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(he);
         delete ctx;
@@ -109,6 +120,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_SMALL")) ctx->use_small = atoi(m) != 0;
     if (const char *m = getenv("FW_SMALL_MAX")) ctx->small_max = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_HOST_FAST")) ctx->host_fast = atoi(m) != 0;
+    if (const char *m = getenv("FW_PARAM_BAR")) ctx->param_bar = ctx->param_bar && atoi(m) != 0;
     if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_NT_WO_MB")) ctx->nt_wo_bytes = ctx->nt_wo_bytes_range = (uint64_t)atoll(m) << 20;
 #ifdef FW_AB
@@ -200,7 +212,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     if (ctx->d_rstatus) hipFree(ctx->d_rstatus);
     if (ctx->d_rts) hipFree(ctx->d_rts);
     for (int i = 0; i < kParamRing; i++) {
-        if (ctx->h_rparam[i]) hipHostFree(ctx->h_rparam[i]);
+        if (ctx->h_rparam[i]) ctx->param_bar ? hipFree(ctx->h_rparam[i]) : hipHostFree(ctx->h_rparam[i]);
     }
     if (ctx->ev_main) hipEventDestroy(ctx->ev_main);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);

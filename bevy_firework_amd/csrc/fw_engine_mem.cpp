@@ -206,9 +206,10 @@ fw_status ensure_range_arrays(fw_ctx *ctx) {
         if (st) return st;
         const size_t nb = need * 2;
         for (int i = 0; i < kParamRing; i++) {
-            if (ctx->h_rparam[i]) hipHostFree(ctx->h_rparam[i]);
+            if (ctx->h_rparam[i]) FW_HIP(ctx, ctx->param_bar ? hipFree(ctx->h_rparam[i]) : hipHostFree(ctx->h_rparam[i]));
             ctx->h_rparam[i] = nullptr;
-            FW_HIP(ctx, hipHostMalloc((void **)&ctx->h_rparam[i], nb, hipHostMallocDefault));
+            FW_HIP(ctx, ctx->param_bar ? hipExtMallocWithFlags((void **)&ctx->h_rparam[i], nb, hipDeviceMallocFinegrained)
+                                       : hipHostMalloc((void **)&ctx->h_rparam[i], nb, hipHostMallocDefault));
             memset(ctx->h_rparam[i], 0, nb);
             ctx->rslot_frame[i] = 0;
         }

@@ -1019,7 +1019,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             }
             S.young_lo = (uint32_t)(((uint64_t)S.young_lo + grad) % S.capacity);
             const uint32_t y_exist = S.range_dev ? 0u : S.young_n - std::min(S.young_n, grad);
-            FwRangeRec &Rc = recs[si];
+            FwRangeRec Rc{};  // (built here, stored once below: the slot is written, never read, by the host)
             Rc.b = S.young_lo, Rc.y_exist = y_exist, Rc.n_spawn = (mat_frame || S.range_dev) ? 0u : S.frame_spawn;
             Rc.grad = grad, Rc.flags = (mat_frame ? FW_RREC_MAT : 0u) | (S.range_dev ? (FW_RREC_MAT | FW_RREC_DEV) : 0u);
             Rc.report = S.range_dev ? S.h_report + (ctx->frame % kReportRing) : nullptr, Rc.pad2 = 0;
@@ -1075,6 +1075,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             // (START tickets, fw_kernels.h: every OLD workgroup the table provides for the segment takes one per launch -- r_old of
             // them, whether the table is re-sent this frame or not: fit() changes the number only together with `dirty`)
             Rc.ticket_base = S.ticket_base, S.ticket_base += S.r_old;
+            recs[si] = Rc;
         }
         if (dirty) {
             if (ctx->rtab_pending) {  // (one staging buffer: the previous upload must have left it)
@@ -1170,6 +1171,12 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         // bound their old part by the cohorts in it -- range_age_keep)
         while (!ctx->birth_age.empty() && !(ctx->birth_age.front().age < std::max(ctx->range_life_max, ctx->range_age_keep))) ctx->birth_age.pop_front();
         if (ctx->r_total) {
+            if (ctx->param_bar) {
+                // the records went through write-combining stores into device memory: drained, and -- a read may not pass posted
+                // writes on the bus -- known to have arrived before the launch is announced
+                _mm_sfence();
+                (void)*(volatile const uint32_t *)recs;
+            }
             FwRangeArgs ra{};
             ra.desc = ctx->d_rdesc, ra.recs = recs, ra.ops = rops, ra.status = ctx->d_rstatus;
             ra.total_tiles = ctx->r_total, ra.parity = p, ra.epoch = a.epoch, ra.spin_limit = ctx->spin_limit, ra.dbg = ctx->dbg;
