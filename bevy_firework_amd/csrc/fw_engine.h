@@ -56,6 +56,7 @@ inline hipError_t fw_memset_done(void *p, int v, size_t bytes) {
 }
 
 constexpr int kParamRing = 8;    // per-frame parameter buffers in flight
+constexpr size_t kBarParamBytes = 64u << 10;  // fw_ctx::b_param
 constexpr int kSnapRing = 8;     // live-count snapshots in flight
 constexpr int kSnapEvery = 4;    // frames between snapshots
 constexpr int kTabRing = 4;      // staging buffers for tile-table uploads
@@ -357,6 +358,7 @@ struct alignas(64) SegHost {
     // workgroup of the compacting kernels -- no tile table entry, no forecast.  Same buffers and layout as a compacting segment:
     // entering and leaving the mode is this flag (fw_ctx::n_small, small_eligible / leave_small).
     bool small = false;
+    bool small_ok = false;    // ... qualifies for it (small_eligible); `small` follows the context's mode (fw_ctx::small_on)
     bool one_feeder = false;  // exactly one emission entry (a Global one) spawns into the type (SegHost::solo)
     float expect_live = 0.f;  // live particles the emitters that feed the type sustain (what derive_capacity derives the capacity from)
     uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
@@ -642,6 +644,14 @@ struct fw_ctx {
     bool use_small = true;
     uint32_t small_max = 768;
     uint32_t n_small = 0;
+    // The kernel pays from a few hundred small types on: a wave walks its type's list round by round, ~15.6 us per launch whatever the
+    // number of types up to ~600, where a workgroup per type (the compacting kernels) takes 11.9 us for 96 types, 14.3 for 256, 18.9
+    // for 512 (profiles/r05/mid_emitters_paths.txt).  The context runs its eligible types (SegHost::small_ok, n_small_ok of them) on
+    // the kernel from small_min of them on and takes them off it again below three quarters of that (update_small_mode: when a
+    // spawner is built or destroyed -- the context is synchronised then; the flag flips, nothing is copied).  FW_SMALL_MIN
+    uint32_t small_min = 352;
+    uint32_t n_small_ok = 0;
+    bool small_on = false;
     // ... and the host half of their frames (thousands of emitters: the frame is bound by the cache lines fw_step streams).
     // A SOLO segment (SegHost::solo: a small type with one Global feeder) is not visited by the per-segment pass at the start of a
     // frame: what that pass does for it -- expire the lifetime window, tighten the bound -- happens in the spawner loop, right
@@ -676,7 +686,7 @@ struct fw_ctx {
     // Up to range_few segments in use, no FIFO ring among them (a FIFO launch and a range launch run one after the other), such a
     // type becomes a range ring whatever its size (SegHost::few_ring); the spawner that takes the context past either condition
     // sends those rings to the compacting path (drop_few_rings: build time, the context is synchronised).  FW_RANGE_FEW; 0: off
-    uint32_t range_few = 64;
+    uint32_t range_few = 160;  // (64 until the range launch read its records from device memory: profiles/r05/mid_emitters_paths.txt)
     uint32_t n_few = 0;     // SegHost::few_ring segments
     bool few_blocked = false;  // the context has outgrown the rule: no new small rings until it is back at half of range_few (a
                                // context whose spawners come and go around the limit would convert rings at every crossing)
@@ -716,6 +726,10 @@ struct fw_ctx {
     // one GPU's share of configs[4] 90.3 -> 85.9, configs[2] 318 -> 311).  The host only ever WRITES such a buffer (write-combining
     // stores, a fence, one read-back of the last word before the launch: posted writes may not pass it).  FW_PARAM_BAR=0: pinned.
     bool param_bar = false;
+    // ... and so do op TABLES of at most kBarParamBytes (a few hundred emitters on the compacting / wave-per-type launches: their
+    // workgroups read a header and an op each before they can spawn); larger tables stay in pinned memory, written in place
+    // (OpList): with thousands of emitters the frame is bound by the host, and write-combining stores cost it more than cached ones
+    char *b_param[kParamRing] = {};
     bool range_spread_new = true;   // FW_RANGE_SPREAD_NEW=0: a segment's NEW workgroups all in front of its YOUNG ones (A/B)
     // An in-place ring launch (FIFO / range) that streams more than nt_bytes uses the fully non-temporal form of its kernel:
     // several times the 256 MiB Infinity Cache, where allocating lines that cannot survive until the next frame only costs.
@@ -834,6 +848,7 @@ fw_status fifo_to_general(fw_ctx *ctx, uint32_t si);
 bool small_eligible(const fw_ctx *ctx, const SegHost &S);
 void enter_small(fw_ctx *ctx, SegHost &S);
 void leave_small(fw_ctx *ctx, SegHost &S);
+void update_small_mode(fw_ctx *ctx);
 fw_status drop_few_rings(fw_ctx *ctx);
 bool fifo_may_become_range(const fw_ctx *ctx, const SegHost &S);
 fw_status fifo_to_range(fw_ctx *ctx, uint32_t si);

@@ -119,8 +119,12 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_NEST_FUSE")) ctx->nest_fuse = atoi(m) != 0;
     if (const char *m = getenv("FW_SMALL")) ctx->use_small = atoi(m) != 0;
     if (const char *m = getenv("FW_SMALL_MAX")) ctx->small_max = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_SMALL_MIN")) ctx->small_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_HOST_FAST")) ctx->host_fast = atoi(m) != 0;
     if (const char *m = getenv("FW_PARAM_BAR")) ctx->param_bar = ctx->param_bar && atoi(m) != 0;
+    for (int i = 0; i < kParamRing && ctx->param_bar; i++)
+        if ((e = hipExtMallocWithFlags((void **)&ctx->b_param[i], kBarParamBytes, hipDeviceMallocFinegrained)) != hipSuccess)
+            return bail("hipExtMallocWithFlags(op tables)", e);
     if (const char *m = getenv("FW_NT_MB")) ctx->nt_bytes = (uint64_t)atoll(m) << 20;
     if (const char *m = getenv("FW_NT_WO_MB")) ctx->nt_wo_bytes = ctx->nt_wo_bytes_range = (uint64_t)atoll(m) << 20;
 #ifdef FW_AB
@@ -177,6 +181,7 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
     for (int i = 0; i < kParamRing; i++) {
         if (ctx->h_param[i]) hipHostFree(ctx->h_param[i]);
         if (ctx->d_param[i]) hipFree(ctx->d_param[i]);
+        if (ctx->b_param[i]) hipFree(ctx->b_param[i]);
         hipEventDestroy(ctx->ev_copied[i]);
         hipEventDestroy(ctx->ev_consumed[i]);
     }

@@ -456,8 +456,9 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         // (the hysteresis covers the arrival of a FIFO ring as well: a context in which one comes and goes would otherwise
         // convert its small rings at every arrival -- ADVICE r04)
         ctx->few_blocked = true;
-        return drop_few_rings(ctx);
+        if ((st = drop_few_rings(ctx))) return st;
     }
+    update_small_mode(ctx);
     return FW_OK;
 }
 
@@ -482,6 +483,7 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
         if (S.few_ring) ctx->n_few--;
         if (S.spilled) ctx->n_spilled--;
         if (S.small) ctx->n_small--, ctx->small_dirty = true;
+        if (S.small_ok) ctx->n_small_ok--;
         if (S.solo) ctx->n_solo--;
         ctx->n_in_use--, ctx->big_dirty = true;
         if (ctx->n_in_use <= ctx->range_few / 2) ctx->few_blocked = false;
@@ -494,6 +496,7 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
             FW_HIP(ctx, hipMemcpy(ctx->g.count + (size_t)r * ctx->max_seg + si, &zero, 4, hipMemcpyHostToDevice));
     }
     sp.seg.clear();
+    update_small_mode(ctx);
     return FW_OK;
 }
 

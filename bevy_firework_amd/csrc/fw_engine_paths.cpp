@@ -120,18 +120,38 @@ bool small_eligible(const fw_ctx *ctx, const SegHost &S) {
     return ctx->use_small && S.in_use && !S.ring() && !S.nested_fed && S.n_lplanes == 0 && !S.collides && S.inst == nullptr && !ctx->track_aabb &&
            !S.colors_dirty && S.expect_live * 2.0f <= (float)ctx->small_max;
 }
-void enter_small(fw_ctx *ctx, SegHost &S) {
+// on the kernel / off it: a flag (the same buffers, the same layout; the tile table is re-sent)
+static void small_activate(fw_ctx *ctx, SegHost &S) {
     if (S.small) return;
     S.small = true, ctx->n_small++, ctx->small_dirty = true;
     ctx->tab_force = true, ctx->fc_ok = false, ctx->boxes_epoch = 0;
 }
-// ... and back: the segment is a compacting segment again (the same buffers; the tile table is re-sent)
-void leave_small(fw_ctx *ctx, SegHost &S) {
+static void small_deactivate(fw_ctx *ctx, SegHost &S) {
     if (!S.small) return;
     S.small = false, ctx->n_small--, ctx->small_dirty = true;
     if (S.solo) S.solo = false, ctx->n_solo--;  // (fw_step's frame-begin pass visits it again: fw_ctx::big_list)
     ctx->big_dirty = true;
     ctx->tab_force = true, ctx->fc_ok = false, ctx->boxes_epoch = 0;
+}
+// the segment qualifies (small_eligible): on the kernel at once if the context runs it (fw_ctx::small_on), else with the others
+// when there are enough of them (update_small_mode)
+void enter_small(fw_ctx *ctx, SegHost &S) {
+    if (!S.small_ok) S.small_ok = true, ctx->n_small_ok++;
+    if (ctx->small_on) small_activate(ctx, S);
+}
+// ... and no longer does: a compacting segment from here on
+void leave_small(fw_ctx *ctx, SegHost &S) {
+    if (S.small_ok) S.small_ok = false, ctx->n_small_ok--;
+    small_deactivate(ctx, S);
+}
+// fw_ctx::small_min, with hysteresis; called where spawners are built and destroyed (the context is synchronised)
+void update_small_mode(fw_ctx *ctx) {
+    const uint32_t on_at = ctx->small_min, off_below = ctx->small_min - ctx->small_min / 4;
+    const bool want = ctx->use_small && (ctx->small_on ? ctx->n_small_ok >= off_below : ctx->n_small_ok >= on_at);
+    if (want == ctx->small_on) return;
+    ctx->small_on = want;
+    for (auto &S : ctx->segs)
+        if (S.in_use && S.small_ok) want ? small_activate(ctx, S) : small_deactivate(ctx, S);
 }
 
 // every SegHost::few_ring segment leaves its ring (fw_ctx::range_few), particles and order kept

@@ -227,8 +227,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     OpHdr *pre_hdr = nullptr;
     size_t pre_tracked = 0;     // ops of levels[0].g whose headers are up to date
     bool pre_hdr_ok = false;
-    uint32_t pre_last_seg = 0;
-    if (ctx->host_fast && ctx->n_small != 0 && ctx->update_mode == FW_MODE_FUSED && !levels.empty()) {
+    // (not a table small enough for host-written device memory -- fw_ctx::b_param: that one is copied there in one sequential pass)
+    if (ctx->host_fast && ctx->n_small != 0 && ctx->update_mode == FW_MODE_FUSED && !levels.empty() &&
+        !(ctx->param_bar && ctx->segs.size() * sizeof(OpHdr) + ((size_t)ctx->n_in_use + 16) * sizeof(FwOp) <= kBarParamBytes)) {
         const size_t n_seg0 = ctx->segs.size(), off_ops0 = n_seg0 * sizeof(OpHdr);
         const size_t want_ops = (size_t)ctx->n_in_use + 16;
         fw_status pst = FW_OK;
@@ -363,10 +364,12 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     if (i == 0 && pre_hdr_ok) {  // ... and, in a list that lives in a parameter slot, into the segment's header
                         const uint32_t idx = (uint32_t)G.size();
                         OpHdr &H = pre_hdr[dst];
-                        if (H.o1 == 0 && dst >= pre_last_seg) H.o0 = idx, H.o1 = idx + 1u, H.n = (uint32_t)n;
-                        else if (H.o1 == idx && H.o1 != 0) H.o1 = idx + 1u, H.n = (uint32_t)std::min<uint64_t>((uint64_t)H.n + n, 0xFFFFFFFFull);
-                        else pre_hdr_ok = false;  // (out of segment order: the sort + header pass below)
-                        pre_last_seg = dst, pre_tracked = idx + 1u;
+                        // (the kernels read a segment's ops through its header only: the ops of a segment must sit next to each other,
+                        // in emission order -- segments need not ascend, which they do not once slots have been re-used)
+                        if (H.o1 == 0) H.o0 = idx, H.o1 = idx + 1u, H.n = (uint32_t)n;
+                        else if (H.o1 == idx) H.o1 = idx + 1u, H.n = (uint32_t)std::min<uint64_t>((uint64_t)H.n + n, 0xFFFFFFFFull);
+                        else pre_hdr_ok = false;  // (ops of one segment apart: the sort + header pass below)
+                        pre_tracked = idx + 1u;
                     }
                     fill(G.push_slot());
                 } else {
@@ -726,7 +729,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 if ((st = ensure_ring(bytes))) return st;
                 if ((st = acquire_slot(&slot))) return st;
             }
-            char *hp = ctx->h_param[slot];
+            // (a small table goes to device memory the host writes through the large BAR: fw_ctx::b_param)
+            const bool bar = !in_place && ctx->param_bar && ctx->ops_zerocopy && bytes <= kBarParamBytes;
+            char *hp = bar ? ctx->b_param[slot] : ctx->h_param[slot];
             char *dp = ctx->d_param[slot];
             if (!hdr_done) {
                 OpHdr *hdr = (OpHdr *)hp;
@@ -739,6 +744,10 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 }
             }
             if (!in_place) memcpy(hp + off_ops, ops.data(), ops.size() * sizeof(FwOp));
+            if (bar) {  // (write-combining stores: drained, and known to have arrived -- a read may not pass posted writes)
+                _mm_sfence();
+                (void)*(volatile const uint32_t *)hp;
+            }
             if (ctx->ops_zerocopy) {
                 // pinned host memory is device-visible: the tiles read their few ops over the bus (tens of bytes each)
                 a.seg_op_first = (const uint4 *)hp;

@@ -71,6 +71,7 @@ def fw_path(request, monkeypatch):
         monkeypatch.setenv("FW_RANGE", "0")
         monkeypatch.setenv("FW_SMALL", "1")
         monkeypatch.setenv("FW_SMALL_MAX", "2000000000")
+        monkeypatch.setenv("FW_SMALL_MIN", "0")
     if mode == "fifo":
         monkeypatch.setenv("FW_FIFO", "1")
         monkeypatch.setenv("FW_FIFO_MIN", "0")

@@ -29,7 +29,7 @@ def _emitter(rate, life, k, entries=1, types=1, fed=0):
 def _world(system, n_solo):
     pairs = []
     for k in range(n_solo):  # one type, one entry: solo segments; every third one emits only every few frames
-        rate = 25.0 if k % 3 == 2 else 500.0 + 3.0 * k
+        rate = 25.0 if k % 3 == 2 else 500.0 + 0.5 * k
         pairs.append(Pair(system, _emitter(rate, 0.2, k), S.Transform((float(k % 17), 0.0, float(k // 17))), seed=SEED, uid=1000 + k))
     # two entries feed ONE small type: not solo (its ops of a frame share a header)
     pairs.append(Pair(system, _emitter(300.0, 0.25, 7, entries=2), S.Transform((1.0, 2.0, 3.0)), seed=SEED, uid=5000))
@@ -57,7 +57,7 @@ def _run(system, pairs, n, what, every=10, dt=DT):
 def _scenario(system, digest=None):
     from bevy_firework_amd.system import FwError
 
-    pairs = _world(system, 96)
+    pairs = _world(system, 360)  # (the wave-per-type kernel runs from 352 eligible types on: fw_ctx::small_min)
     assert {p.gpu.update_path(0)[0] for p in pairs} == {"small"}
     _run(system, pairs, 25, "steady", every=5)
     assert [p.gpu.update_path(0)[0] for p in pairs[-2:]] == ["general", "general"] and pairs[-1].gpu.count(0) > 2048

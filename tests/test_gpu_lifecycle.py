@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 SEED = 0x11FE
 CASES = int(os.environ.get("FW_LIFECYCLE_CASES", "200"))
 OFF = int(os.environ.get("FW_LIFECYCLE_OFFSET", "0"))
-KNOBS = ("FW_ENABLE_KNOBS", "FW_SMALL", "FW_SMALL_MAX", "FW_FIFO", "FW_FIFO_MIN", "FW_FIFO_SMALL", "FW_RANGE", "FW_RANGE_MIN", "FW_RANGE_SMALL", "FW_RANGE_FEW", "FW_NOSPIN",
+RANGE_FEW, SMALL_MIN = 160, 352  # fw_ctx::range_few / small_min (csrc/fw_engine.h)
+KNOBS = ("FW_ENABLE_KNOBS", "FW_SMALL", "FW_SMALL_MAX", "FW_SMALL_MIN", "FW_HOST_FAST", "FW_PARAM_BAR", "FW_FIFO", "FW_FIFO_MIN", "FW_FIFO_SMALL", "FW_RANGE", "FW_RANGE_MIN", "FW_RANGE_SMALL", "FW_RANGE_FEW", "FW_NOSPIN",
          "FW_NEST_FUSE", "FW_NT_MB", "FW_NT_WO_MB", "FW_FORECAST", "FW_STREAM", "FW_STATIC_NEW", "FW_UPDATE_MODE", "FW_FIFO_STREAM")
 
 
@@ -48,6 +49,9 @@ def make(rng, kind):
     if kind == "tiny":  # a few hundred particles: a small range ring in a context of few segments, the compacting path among many
         lo = float(rng.uniform(0.12, 0.4))
         return S.ParticleSpawner([_type(rng, lo, lo + rng.uniform(0.05, 0.3), rng.random() < 0.4, spin)], [_entry(rng, 0, rng.uniform(300.0, 1500.0), spin)])
+    if kind == "dust":  # ~50-250 particles: always eligible for the wave-per-type kernel (which runs from SMALL_MIN such types on)
+        lo = float(rng.uniform(0.12, 0.3))
+        return S.ParticleSpawner([_type(rng, lo, lo + 0.1, rng.random() < 0.4, spin)], [_entry(rng, 0, rng.uniform(200.0, 600.0), spin)])
     if kind == "mid":  # a derived capacity past 8192 slots: a range ring at any time (lifetime range), ~4-6k particles
         lo = float(rng.uniform(0.2, 0.3))
         return S.ParticleSpawner([_type(rng, lo, lo + 0.2, False, spin)], [_entry(rng, 0, rng.uniform(14000.0, 20000.0), spin)])
@@ -120,20 +124,20 @@ class World:
 
 
 def scenario_many(w):
-    """few -> many -> few: the context crosses fw_ctx::range_few (64 segments) upwards -- every small range ring continues on the
+    """few -> many -> few: the context crosses fw_ctx::range_few (160 segments) upwards -- every small range ring continues on the
     compacting path -- and comes back below HALF of it, where new small types take rings again"""
     for _ in range(int(w.rng.integers(1, 5))):
         w.add(str(w.rng.choice(["tiny", "tiny", "mid", "two"])))
     w.step(int(w.rng.integers(8, 30)))
     w.check("few")
     assert all(p in ("range", "fifo") for row in w.paths() for p in row), w.paths()  # (few segments: everybody on a ring)
-    while w.segments() <= 64:
+    while w.segments() <= RANGE_FEW:
         w.add("tiny")
-        if w.rng.random() < 0.15:
+        if w.rng.random() < 0.1:
             w.step(1)
-    assert all(p in ("small", "general") for row, kind in zip(w.paths(), w.kinds) for p in row if kind == "tiny"), w.paths()
-    assert any(row == ("small",) for row in w.paths()), w.paths()  # (off their rings: the wave-per-type kernel, fw_k_small.hip)
-    w.check("right after the 65th segment")
+    # (off their rings: workgroups of the compacting kernels -- the wave-per-type kernel takes over from SMALL_MIN eligible types on)
+    assert all(p == "general" for row, kind in zip(w.paths(), w.kinds) for p in row if kind == "tiny"), w.paths()
+    w.check("right after the context outgrew fw_ctx::range_few")
     w.step(int(w.rng.integers(5, 25)))
     w.check("many")
     while w.segments() > int(w.rng.integers(8, 30)):
@@ -146,6 +150,37 @@ def scenario_many(w):
         w.rebuild(int(w.rng.integers(0, len(w.pairs))))
     w.step(int(w.rng.integers(10, 30)))
     w.check("few again")
+
+
+def scenario_small_mode(w):
+    """few -> hundreds -> fewer: small types leave their rings past fw_ctx::range_few segments (workgroups of the compacting kernels),
+    move to the wave-per-type kernel TOGETHER when SMALL_MIN of them exist (fw_ctx::small_on: a flag per segment, particles stay where
+    they are), and back below three quarters of that"""
+    for _ in range(int(w.rng.integers(1, 4))):
+        w.add("tiny")
+    w.step(int(w.rng.integers(5, 15)))
+    w.check("few")
+    while w.segments() <= RANGE_FEW:
+        w.add("dust")
+    assert not any(p == "small" for row in w.paths() for p in row), w.paths()
+    w.step(int(w.rng.integers(3, 10)))
+    w.check("on the compacting kernels", limit=8)
+    while sum(kind == "dust" for kind in w.kinds) < SMALL_MIN + int(w.rng.integers(0, 12)):
+        w.add("dust")
+        if w.rng.random() < 0.03:
+            w.step(1)
+    assert all(row == ("small",) for row, kind in zip(w.paths(), w.kinds) if kind == "dust"), [r for r in w.paths() if r != ("small",)]
+    w.check("right after the wave-per-type kernel took over", limit=14)
+    w.step(int(w.rng.integers(8, 20)))
+    w.check("one wave per type", limit=12)
+    while w.segments() >= SMALL_MIN * 3 // 4 - int(w.rng.integers(0, 10)):
+        w.remove(int(w.rng.integers(0, len(w.pairs))))
+        if w.rng.random() < 0.03:
+            w.step(1)
+    assert not any(p == "small" for row in w.paths() for p in row), w.paths()
+    w.check("right after the compacting kernels took over again", limit=14)
+    w.step(int(w.rng.integers(8, 20)))
+    w.check("a workgroup per type again", limit=12)
 
 
 def scenario_fifo(w):
@@ -225,7 +260,7 @@ def scenario_spill(w):
     w.check("fewer of them", limit=4)
 
 
-SCENARIOS = [scenario_many] * 8 + [scenario_fifo] * 7 + [scenario_nested] * 3 + [scenario_spill] * 2
+SCENARIOS = [scenario_many] * 7 + [scenario_fifo] * 7 + [scenario_nested] * 3 + [scenario_spill] * 2 + [scenario_small_mode]
 SEEN = {}
 
 
@@ -246,7 +281,8 @@ def test_lifecycle_cases_were_not_trivial():
     if len(SEEN) < 40:
         pytest.skip("the lifecycle cases did not run in this session")
     names = {v[0] for v in SEEN.values()}
-    assert names == {"scenario_many", "scenario_fifo", "scenario_nested", "scenario_spill"}, names
-    assert all(set(v[1]) >= {"range", "small"} for v in SEEN.values() if v[0] == "scenario_many"), SEEN
-    assert all("fifo" in v[1] for v in SEEN.values() if v[0] != "scenario_many"), SEEN
+    assert names == {"scenario_many", "scenario_fifo", "scenario_nested", "scenario_spill", "scenario_small_mode"}, names
+    assert all(set(v[1]) >= {"range", "general"} for v in SEEN.values() if v[0] == "scenario_many"), SEEN
+    assert all(set(v[1]) >= {"range", "general", "small"} for v in SEEN.values() if v[0] == "scenario_small_mode"), SEEN
+    assert all("fifo" in v[1] for v in SEEN.values() if v[0] not in ("scenario_many", "scenario_small_mode")), SEEN
     assert sum(v[3] for v in SEEN.values()) > 20000 * len(SEEN) // 10, SEEN
