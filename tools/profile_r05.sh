@@ -30,6 +30,7 @@ cd $R
 timeout 600 python tools/bench_configs.py c1 c3 c4 c5 cc > $OUT/configs.txt 2>&1
 timeout 600 python tools/r04_examples_latency.py > $OUT/examples_latency.txt 2>&1
 timeout 900 python tools/r04_few_small_emitters.py > $OUT/few_small_emitters.txt 2>&1
-timeout 900 python tools/soak_r05.py > $OUT/soak_r05.txt 2>&1
+timeout 300 python tools/r05_mid_emitters.py > $OUT/mid_emitters_default.txt 2>&1
+timeout 1500 python tools/soak_r05.py > $OUT/soak_r05.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -delete; rm -rf $OUT/pmc/*/ 2>/dev/null
 ls $OUT

@@ -8,7 +8,7 @@ from bevy_firework_amd import workloads
 from bevy_firework_amd.system import ParticleSystem
 dt = np.float32(1 / 60)
 CASES = ((2048, 200), (1024, 600), (1024, 1000), (512, 1500), (512, 2000), (512, 3000), (256, 4000), (256, 6000), (128, 8000))
-MINS = (12288, 8192, 6144, 5120)
+MINS = tuple(int(x) for x in os.environ.get("FW_SWEEP_MINS", "12288,8192,6144,5120").split(","))
 print("emitters x live  | " + " | ".join(f"min {m:5d}" for m in MINS) + "   (us per frame, best of 2; paths)")
 for n_em, per in CASES:
     row, paths = [], []

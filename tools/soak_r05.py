@@ -22,7 +22,7 @@ seen, seen_now = set(), set()
 t0 = time.perf_counter()
 with ParticleSystem(device=0, seed=L.SEED) as system:
     w = L.World(system, rng, 0)
-    phase, target = "grow", 180
+    phase, target, cycle = "grow", 180, -1
     while w.frames < frames:
         big = sum(k in ("fifo", "nested_big") for k in w.kinds)
         # ---- one lifecycle action, then a stretch of frames
@@ -43,7 +43,9 @@ with ParticleSystem(device=0, seed=L.SEED) as system:
         else:
             if len(w.pairs) > 1:
                 w.remove(int(rng.integers(0, len(w.pairs)))); events["despawned"] += 1
-            if w.segments() <= target: phase, target = "grow", int(rng.choice([60, 120, 180, 200, 420]))
+            if w.segments() <= target:
+                cycle += 1
+                phase, target = "grow", (560, 120, 200, 60)[cycle % 4]  # (every fourth growth passes fw_ctx::small_min)
         if r < 0.03 and w.pairs:
             w.rebuild(int(rng.integers(0, len(w.pairs)))); events["rebuilt"] += 1
         # (a burst of large one-lifetime types now and then: the spill rule)
