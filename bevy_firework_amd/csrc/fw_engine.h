@@ -56,7 +56,10 @@ inline hipError_t fw_memset_done(void *p, int v, size_t bytes) {
 }
 
 constexpr int kParamRing = 8;    // per-frame parameter buffers in flight
-constexpr size_t kBarParamBytes = 64u << 10;  // fw_ctx::b_param
+#ifndef FW_BAR_PARAM_KB
+#define FW_BAR_PARAM_KB 64
+#endif
+constexpr size_t kBarParamBytes = (size_t)FW_BAR_PARAM_KB << 10;  // fw_ctx::b_param
 constexpr int kSnapRing = 8;     // live-count snapshots in flight
 constexpr int kSnapEvery = 4;    // frames between snapshots
 constexpr int kTabRing = 4;      // staging buffers for tile-table uploads
@@ -359,6 +362,7 @@ struct alignas(64) SegHost {
     // entering and leaving the mode is this flag (fw_ctx::n_small, small_eligible / leave_small).
     bool small = false;
     bool small_ok = false;    // ... qualifies for it (small_eligible); `small` follows the context's mode (fw_ctx::small_on)
+    bool wide = false;        // ... as a WIDE type: up to a few thousand particles, a workgroup instead of a wave (fw_ctx::wide_max)
     bool one_feeder = false;  // exactly one emission entry (a Global one) spawns into the type (SegHost::solo)
     float expect_live = 0.f;  // live particles the emitters that feed the type sustain (what derive_capacity derives the capacity from)
     uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
@@ -649,6 +653,18 @@ struct fw_ctx {
     // for 512 (profiles/r05/mid_emitters_paths.txt).  The context runs its eligible types (SegHost::small_ok, n_small_ok of them) on
     // the kernel from small_min of them on and takes them off it again below three quarters of that (update_small_mode: when a
     // spawner is built or destroyed -- the context is synchronised then; the flag flips, nothing is copied).  FW_SMALL_MIN
+    // WIDE types: emitters that sustain up to wide_max particles (hundreds of emitters of a thousand particles: two workgroups per
+    // type on the compacting kernels, each a chain of tile table -> forecast -> count -> look-back) are walked by ONE workgroup of the
+    // same kernel, the same launch; a narrow type whose bound passes small_max becomes a wide one, a wide one leaves the mode past
+    // 2 x wide_max.  FW_WIDE_MAX; 0: no wide types
+    // ... in contexts of wide_min eligible types or more (with the same hysteresis as small_min): 1024 x 600 / 1024 x 1000 particles 26 /
+    // 31 us per launch against 29 / 53 on the compacting kernels, but 512 x 1500 24 against 20.5 (profiles/r05/wide_sweep.txt) -- a
+    // workgroup's frame ends with the serial tail header -> op -> emitter record -> spawn, which the compacting kernels give to
+    // workgroups of their own.  FW_WIDE_MIN
+    uint32_t wide_min = 768;
+    bool wide_on = false;
+    uint32_t wide_max = 2048;
+    uint32_t n_narrow = 0;   // of small_list (narrow types first)
     uint32_t small_min = 352;
     uint32_t n_small_ok = 0;
     bool small_on = false;
@@ -849,6 +865,7 @@ bool small_eligible(const fw_ctx *ctx, const SegHost &S);
 void enter_small(fw_ctx *ctx, SegHost &S);
 void leave_small(fw_ctx *ctx, SegHost &S);
 void update_small_mode(fw_ctx *ctx);
+void small_suspend(fw_ctx *ctx, SegHost &S);  // off the kernel, still eligible (a narrow type that became wide while wide_on is off)
 fw_status drop_few_rings(fw_ctx *ctx);
 bool fifo_may_become_range(const fw_ctx *ctx, const SegHost &S);
 fw_status fifo_to_range(fw_ctx *ctx, uint32_t si);

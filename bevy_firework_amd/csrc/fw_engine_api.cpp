@@ -91,8 +91,8 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     ctx->h_err = ctx->h_done + 4, ctx->h_err[0] = ctx->h_err[1] = 0ull, ctx->g.err_host = ctx->h_err;
     if ((e = hipMalloc((void **)&ctx->g.err, 64)) != hipSuccess) return bail("hipMalloc", e);
     fw_memset_done(ctx->g.err, 0, 64);
-    if ((e = hipMalloc((void **)&ctx->g.stats, 64)) != hipSuccess) return bail("hipMalloc", e);
-    fw_memset_done(ctx->g.stats, 0, 64);
+    if ((e = hipMalloc((void **)&ctx->g.stats, FW_STAT_SLOTS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    fw_memset_done(ctx->g.stats, 0, FW_STAT_SLOTS * sizeof(unsigned long long));
     if ((e = hipMalloc((void **)&ctx->d_aabb, 256 * 8 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&ctx->d_total, 64)) != hipSuccess) return bail("hipMalloc", e);
     ctx->g.seed = seed;
@@ -120,6 +120,8 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_SMALL")) ctx->use_small = atoi(m) != 0;
     if (const char *m = getenv("FW_SMALL_MAX")) ctx->small_max = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_SMALL_MIN")) ctx->small_min = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_WIDE_MAX")) ctx->wide_max = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_WIDE_MIN")) ctx->wide_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_HOST_FAST")) ctx->host_fast = atoi(m) != 0;
     if (const char *m = getenv("FW_PARAM_BAR")) ctx->param_bar = ctx->param_bar && atoi(m) != 0;
     for (int i = 0; i < kParamRing && ctx->param_bar; i++)
@@ -872,8 +874,9 @@ fw_status fw_ctx_last_step_updated(fw_ctx *ctx, uint64_t *out) {
     hipSetDevice(ctx->device);
     fw_status st = sync(ctx);
     if (st) return st;
-    unsigned long long now = 0;
-    FW_HIP(ctx, hipMemcpy(&now, ctx->g.stats, sizeof now, hipMemcpyDeviceToHost));
+    unsigned long long now = 0, slots[FW_STAT_SLOTS];
+    FW_HIP(ctx, hipMemcpy(slots, ctx->g.stats, sizeof slots, hipMemcpyDeviceToHost));
+    for (unsigned long long v : slots) now += v;
     *out = now;  // running total of particles that entered update_particles
     return FW_OK;
 }
@@ -906,8 +909,9 @@ fw_status fw_ctx_kernel_timing(fw_ctx *ctx, int32_t enable) {
     }
     ctx->timing = enable != 0;
     ctx->tev_used = 0, ctx->tev_frames = 0;
-    unsigned long long now = 0;
-    FW_HIP(ctx, hipMemcpy(&now, ctx->g.stats, sizeof now, hipMemcpyDeviceToHost));
+    unsigned long long now = 0, slots[FW_STAT_SLOTS];
+    FW_HIP(ctx, hipMemcpy(slots, ctx->g.stats, sizeof slots, hipMemcpyDeviceToHost));
+    for (unsigned long long v : slots) now += v;
     ctx->timing_particles_start = now;
     return FW_OK;
 }
@@ -926,8 +930,9 @@ fw_status fw_ctx_kernel_timing_read(fw_ctx *ctx, double *ms_total, uint64_t *lau
     const uint64_t nl = ctx->tev_frames;  // frames: a frame's update may be several launches (FIFO + general), all summed
     if (ms_total) *ms_total = ms;
     if (launches) *launches = nl;
-    unsigned long long now = 0;
-    FW_HIP(ctx, hipMemcpy(&now, ctx->g.stats, sizeof now, hipMemcpyDeviceToHost));
+    unsigned long long now = 0, slots[FW_STAT_SLOTS];
+    FW_HIP(ctx, hipMemcpy(slots, ctx->g.stats, sizeof slots, hipMemcpyDeviceToHost));
+    for (unsigned long long v : slots) now += v;
     if (particles) *particles = now - ctx->timing_particles_start;
     return FW_OK;
 }
@@ -980,7 +985,7 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t
     if (!sp || type >= sp->seg.size()) return FW_EINVAL;
     const SegHost &S = ctx->segs[sp->seg[type]];
     const TypeHost &T = sp->types[type];
-    if (mode) *mode = S.fifo ? 1 : (S.range ? 2 : (S.small ? 3 : 0));
+    if (mode) *mode = S.fifo ? 1 : (S.range ? 2 : (S.small ? (S.wide ? 4 : 3) : 0));
     const uint32_t colours = (T.base.kind != 0 ? 16u : 0u) + (T.emis.kind != 0 ? 16u : 0u);  // one-key gradients: never rewritten
     uint32_t moved, algo;
     if (S.ring()) {

@@ -118,7 +118,7 @@ fw_status fifo_to_general(fw_ctx *ctx, uint32_t si) {
 // SegHost::small: may this compacting segment be updated by the wave-per-type kernel?
 bool small_eligible(const fw_ctx *ctx, const SegHost &S) {
     return ctx->use_small && S.in_use && !S.ring() && !S.nested_fed && S.n_lplanes == 0 && !S.collides && S.inst == nullptr && !ctx->track_aabb &&
-           !S.colors_dirty && S.expect_live * 2.0f <= (float)ctx->small_max;
+           !S.colors_dirty && (S.expect_live * 2.0f <= (float)ctx->small_max || S.expect_live <= (float)ctx->wide_max);
 }
 // on the kernel / off it: a flag (the same buffers, the same layout; the tile table is re-sent)
 static void small_activate(fw_ctx *ctx, SegHost &S) {
@@ -136,9 +136,10 @@ static void small_deactivate(fw_ctx *ctx, SegHost &S) {
 // the segment qualifies (small_eligible): on the kernel at once if the context runs it (fw_ctx::small_on), else with the others
 // when there are enough of them (update_small_mode)
 void enter_small(fw_ctx *ctx, SegHost &S) {
-    if (!S.small_ok) S.small_ok = true, ctx->n_small_ok++;
-    if (ctx->small_on) small_activate(ctx, S);
+    if (!S.small_ok) S.small_ok = true, ctx->n_small_ok++, S.wide = S.expect_live * 2.0f > (float)ctx->small_max;
+    if (S.wide ? ctx->wide_on : ctx->small_on) small_activate(ctx, S);
 }
+void small_suspend(fw_ctx *ctx, SegHost &S) { small_deactivate(ctx, S); }
 // ... and no longer does: a compacting segment from here on
 void leave_small(fw_ctx *ctx, SegHost &S) {
     if (S.small_ok) S.small_ok = false, ctx->n_small_ok--;
@@ -148,10 +149,13 @@ void leave_small(fw_ctx *ctx, SegHost &S) {
 void update_small_mode(fw_ctx *ctx) {
     const uint32_t on_at = ctx->small_min, off_below = ctx->small_min - ctx->small_min / 4;
     const bool want = ctx->use_small && (ctx->small_on ? ctx->n_small_ok >= off_below : ctx->n_small_ok >= on_at);
-    if (want == ctx->small_on) return;
-    ctx->small_on = want;
+    // ... and its wide role from wide_min of them on (fw_ctx::wide_min)
+    const bool want_wide = want && ctx->wide_max != 0 &&
+                           (ctx->wide_on ? ctx->n_small_ok >= ctx->wide_min - ctx->wide_min / 4 : ctx->n_small_ok >= ctx->wide_min);
+    if (want == ctx->small_on && want_wide == ctx->wide_on) return;
+    ctx->small_on = want, ctx->wide_on = want_wide;
     for (auto &S : ctx->segs)
-        if (S.in_use && S.small_ok) want ? small_activate(ctx, S) : small_deactivate(ctx, S);
+        if (S.in_use && S.small_ok) (S.wide ? want_wide : want) ? small_activate(ctx, S) : small_deactivate(ctx, S);
 }
 
 // every SegHost::few_ring segment leaves its ring (fw_ctx::range_few), particles and order kept

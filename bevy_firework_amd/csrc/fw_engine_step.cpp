@@ -387,7 +387,18 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 E.serial += n;
                 if (!S.solo) S.frame_spawn += (uint32_t)n;  // (a solo segment's one op of the frame carries the count)
                 S.ub = (uint32_t)std::min<uint64_t>((uint64_t)S.ub + n, 0xFFFFFFFFull);
-                if (S.small && S.ub > ctx->small_max) {  // no longer a few hundred particles: a compacting segment from this frame on
+                if (S.small && S.ub > ctx->small_max && !S.wide) {
+                    // no longer a few hundred particles: a WIDE type (a workgroup of the same kernel) from this frame on -- or, in a
+                    // context that does not run wide types (fw_ctx::wide_on), a compacting segment that stays eligible
+                    S.wide = true, ctx->small_dirty = true;
+                    if (!ctx->wide_on) {
+                        const bool was_solo = S.solo;
+                        small_suspend(ctx, S);
+                        if (was_solo) S.frame_spawn = (uint32_t)n;
+                    }
+                }
+                if (S.small && S.wide && S.ub > std::max(ctx->small_max, 2u * ctx->wide_max)) {
+                    // ... no longer a few thousand: a compacting segment
                     const bool was_solo = S.solo;
                     leave_small(ctx, S);
                     if (was_solo) S.frame_spawn = (uint32_t)n;
@@ -1209,8 +1220,11 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     if (ctx->n_small) {
         if (ctx->small_dirty) {  // the list changed (a spawner built or destroyed, a type that outgrew the mode): re-sent through the stream
             ctx->small_list.clear();
-            for (uint32_t si = 0; si < n_seg; si++)
-                if (ctx->segs[si].in_use && ctx->segs[si].small) ctx->small_list.push_back(si);
+            for (int wide = 0; wide < 2; wide++) {  // narrow types first, then the wide ones (FwSmallArgs::n_narrow)
+                for (uint32_t si = 0; si < n_seg; si++)
+                    if (ctx->segs[si].in_use && ctx->segs[si].small && (int)ctx->segs[si].wide == wide) ctx->small_list.push_back(si);
+                if (!wide) ctx->n_narrow = (uint32_t)ctx->small_list.size();
+            }
             if (ctx->small_list.size() > ctx->small_cap) return poison_segment(ctx, kNoSeg, "small-type list overflow");
             if (ctx->small_pending) {
                 FW_HIP(ctx, hipEventSynchronize(ctx->ev_small));
@@ -1222,7 +1236,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             ctx->small_pending = true, ctx->small_dirty = false;
         }
         FwSmallArgs sa{};
-        sa.list = ctx->d_small, sa.n = (uint32_t)ctx->small_list.size(), sa.parity = p, sa.epoch = a.epoch, sa.dt = dt;
+        sa.list = ctx->d_small, sa.n = (uint32_t)ctx->small_list.size(), sa.n_narrow = ctx->n_narrow, sa.parity = p, sa.epoch = a.epoch, sa.dt = dt;
         sa.seg_op_first = spawn_form == FW_SPAWN_TABLE ? a.seg_op_first : nullptr, sa.ops = a.ops;
         sa.force_colors = a.force_colors, sa.dbg = ctx->dbg;
         sa.done_tag = a.done_tag, sa.done_value = a.done_value;

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         g.ndestroyed[seg] = n_tot - nc;
         if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;  // one 8-byte store: tag + count
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
+        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats + (seg % FW_STAT_SLOTS), (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
     }
 }
 
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         g.ndestroyed[seg] = n_tot - nc;
         if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;  // one 8-byte store: tag + count
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
+        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats + (seg % FW_STAT_SLOTS), (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
     }
 }
 
@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpda
         g.ndestroyed[seg] = n_tot - nc;
         if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
+        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats + (seg % FW_STAT_SLOTS), (unsigned long long)n_tot);  // (FW_DEBUG 128: profiling, no statistics)
     }
 }
 

@@ -465,7 +465,7 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
         g.ndestroyed[F.seg] = n_all - nc;
         if (a.host_counts) a.host_counts[F.seg] = ((unsigned long long)a.epoch << 32) | nc;
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)n_all);
+        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats + (F.seg % FW_STAT_SLOTS), (unsigned long long)n_all);
     }
 }
 
@@ -833,7 +833,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
             if (Rc.report) *Rc.report = ((unsigned long long)a.epoch << 32) | n_added;
             if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;
             if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-            if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)nc);
+            if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats + (seg % FW_STAT_SLOTS), (unsigned long long)nc);
         }
         return;
     }
@@ -992,7 +992,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
         if (Rc.report) *Rc.report = ((unsigned long long)a.epoch << 32) | n_added;
         if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | nc;
         if (a.live_out) atomicAdd(a.live_out, (unsigned long long)nc);
-        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, (unsigned long long)(n_old_in + y_exist + n_spawn));
+        if (!FW_DBG(a.dbg, 128u)) atomicAdd(g.stats + (seg % FW_STAT_SLOTS), (unsigned long long)(n_old_in + y_exist + n_spawn));
     }
 }
 

@@ -15,119 +15,176 @@
 // ping-pong pair -- the layout of the compacting path, so a type enters and leaves this mode by a flag on the host, nothing is
 // copied --, then spawns the frame's new particles behind them (virtual particles, as in the compacting kernels) or, in frames
 // that materialised them (Nested passes, collisions elsewhere in the context), finds them behind the live ones.
+//
+// WIDE types (round 5, later): a type of up to a few thousand particles -- hundreds of emitters of a thousand particles each: 1024 x
+// 1000 takes the compacting kernels 55 us a frame, two workgroups per type, each a chain of tile table -> forecast -> count ->
+// look-back -> update -- is walked the same way by a WORKGROUP: rounds of 256 lanes, the waves' survivor counts exchanged through LDS
+// (one barrier per round, double-buffered), everything else as above.  One launch serves both kinds: its first workgroups take four
+// narrow types each, the rest one wide type each (a workgroup-uniform branch).
 #include "fw_dev.h"
+#ifndef FW_SMALL_EXP  // (profiling experiments, results wrong: 1 no spawn phase, 2 no integration, 4 no statistics atomics, 8 no op/header reads)
+#define FW_SMALL_EXP 0
+#endif
+
+// one particle type: by one wave (WIDE = false; `lanes` = 64) or by the four waves of a workgroup (WIDE = true; `lanes` = FW_BLOCK)
+template <bool WIDE>
+__device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallArgs &a, uint32_t seg, float *s_keys, uint32_t (*s_cnt)[FW_BLOCK / 64],
+                                              unsigned long long &entered, unsigned long long &live) {
+    constexpr int NW = FW_BLOCK / 64;
+    constexpr uint32_t LANES = WIDE ? (uint32_t)FW_BLOCK : 64u;
+    const uint32_t wlane = threadIdx.x & 63u;
+    // WIDE: which quarter of a round a wave takes ROTATES with the workgroup.  A type spawns a handful of particles per frame -- less
+    // than one wave's worth -- and spawning is a long serial instruction stream (three Philox blocks, trigonometry): with the first
+    // 64 new particles always on hardware wave 0, the four workgroups of a CU ran their spawn streams on ONE SIMD, one after the
+    // other (16 of the kernel's 32 us at 1024 types x 1000 particles: profiles/r05/wide_ablations.txt).
+    // (workgroups that share a CU: consecutive ones of an XCD's round-robin share -- blockIdx / 8 -- or ones a whole layer of the chip
+    // apart -- blockIdx / 256 --, depending on how the dispatcher fills CUs: the rotation differs among them either way)
+    const uint32_t rot = ((blockIdx.x >> 3) + (blockIdx.x >> 8)) % NW;
+    const uint32_t wave = WIDE ? __builtin_amdgcn_readfirstlane(((threadIdx.x >> 6) + NW - rot) % NW)
+                               : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = WIDE ? wave * 64u + wlane : wlane;  // index within the round
+    const FwSeg *Sp = &g.segs[seg];
+    const uint32_t C = Sp->capacity, n_lplanes = Sp->n_lplanes;
+    const char *ib = Sp->buf[a.parity];
+    char *ob = Sp->buf[a.parity ^ 1u];
+    char *destroyed = Sp->destroyed;
+    const uint32_t sidx = a.parity * g.max_seg + seg, oidx = (a.parity ^ 1u) * g.max_seg + seg;
+    const uint32_t n_cnt = g.count[sidx];
+    const uint32_t n_in = min(n_cnt + g.spawned[sidx] + g.appended[sidx], C);  // loaded: the live ones + what a pass materialised
+    // this frame's spawn ops of the segment (table form: one header per segment)
+    uint32_t o0 = 0u, o1 = 0u, n_spawn = 0u;
+    if (a.seg_op_first && !(FW_SMALL_EXP & 8)) {
+        const uint4 oh = a.seg_op_first[seg];
+        o0 = oh.x, o1 = oh.y, n_spawn = oh.z;
+    }
+    const uint32_t room = C - n_in;
+    if (n_spawn > room) {  // virtual spawns beyond the capacity are dropped (and reported), as everywhere
+        n_spawn = room;
+        if (lane == 0) fw_flag(g, FW_ERR_CAPACITY);
+    }
+    const FwType T = g.types[Sp->type_idx];
+    for (uint32_t i = lane; i < T.keys_len; i += LANES) s_keys[i] = g.keys[T.keys_off + i];
+    const bool nospin = (T.flags & FW_TYPE_NOSPIN) != 0u;
+    const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
+    const FwOutWin W = fw_out_window(ob, C, 0u, T, a.force_colors, n_lplanes);
+    const char *p0 = ib + FW_OFF_Q0(C), *p1 = ib + FW_OFF_Q1(C), *p2 = ib + FW_OFF_Q2(C), *p3 = ib + FW_OFF_Q3(C);
+    const char *pl = ib + FW_OFF_L(C, n_lplanes);  // lifetimes of a type that cannot turn (FwOutWin::lf)
+    if (WIDE) {
+        __syncthreads();
+    } else {  // (the wave's LDS row was written by its own lanes: a wave-scope fence orders it against the reads below)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    uint32_t run = 0u;  // survivors stored so far = the next output slot
+    uint32_t xr = 0u;   // WIDE: rounds so far (which half of the count exchange a round uses)
+    // where a lane's survivor goes: behind the survivors so far, behind those of the lower waves of this round (WIDE), behind those of
+    // the lower lanes of its wave; every lane leaves with `run` advanced by the round's total
+    auto place = [&](bool alive, uint32_t *o) {
+        const unsigned long long m = __ballot(alive);
+        uint32_t base = run, tot = (uint32_t)__popcll(m);
+        if (WIDE) {
+            if (wlane == 0u) s_cnt[xr & 1u][wave] = tot;
+            __syncthreads();  // (the other half is not written before every wave has passed the NEXT round's barrier: no second one)
+            tot = 0u;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const uint32_t c = s_cnt[xr & 1u][w];
+                base += (uint32_t)w < wave ? c : 0u;
+                tot += c;
+            }
+            xr++;
+        }
+        *o = base + fw_lane_prefix(m);
+        run += tot;
+    };
+    // ---- the particles that are in memory, in list order
+    const uint32_t rounds = (n_in + LANES - 1u) / LANES;
+    auto load = [&](uint32_t r, float4 &q0, float4 &q1, float4 &q2, float4 &q3) {
+        const uint32_t i = min(r * LANES + lane, n_in ? n_in - 1u : 0u);  // (unconditional loads at a clamped index)
+        q0 = fw_ld4w(p0, i * 16u), q1 = fw_ld4w(p1, i * 16u);
+        if (nospin) {  // (uniform branch)
+            q2 = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            q3 = make_float4(0.0f, 0.0f, 0.0f, fw_ld1w(pl, i * 4u));
+        } else {
+            q2 = fw_ld4w(p2, i * 16u), q3 = fw_ld4w(p3, i * 16u);
+        }
+    };
+    float4 q0n, q1n, q2n, q3n;
+    if (rounds) load(0u, q0n, q1n, q2n, q3n);
+    for (uint32_t r = 0; r < rounds; r++) {
+        const float4 q0 = q0n, q1 = q1n, q2 = q2n, q3 = q3n;
+        if (r + 1u < rounds) load(r + 1u, q0n, q1n, q2n, q3n);
+        const uint32_t i = r * LANES + lane;
+        const bool valid = i < n_in;
+        float age_new;
+        const bool alive = valid && fw_survives(q0.w, a.dt, q3.w, &age_new);
+        uint32_t o;
+        place(alive, &o);
+        if (alive && (FW_SMALL_EXP & 2)) {
+            fw_st4(W.q0, o, q0), fw_st4(W.q1, o, q1);
+        } else if (alive) {
+            fw_integrate_store(T, s_keys, a.dt, q0, q1, q2, q3, age_new, W, o);
+        } else if (valid && want_destroyed) {
+            // (a particle a pass materialised this frame carries its spawn-time scale and colours: evaluated, not read)
+            fw_store_destroyed(destroyed, ib, C, i, i < n_cnt, T, s_keys, q0, q1, q2, q3, age_new, i - o);
+        }
+    }
+    // ---- this frame's new particles: spawn_particles (core.rs:437-469) right before update_particles, in op order
+    for (uint32_t x = o0; x < ((FW_SMALL_EXP & 1) ? o0 : o1); x++) {
+        const FwOp &op = a.ops[x];  // (uniform: scalar loads)
+        const uint32_t rel = op.rel_base, cnt = rel < n_spawn ? min(op.n, n_spawn - rel) : 0u;
+        const FwEmit &e = g.emits[op.emit];
+        for (uint32_t c0 = 0; c0 < cnt; c0 += LANES) {
+            const uint32_t k = c0 + lane;
+            const bool valid = k < cnt;
+            FwSpawnOut so;
+            so.q0 = so.q1 = so.q2 = so.q3 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid)
+                so = fw_spawn_one(e, g.seed, op.serial_base + k, fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
+                                  fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
+                                  fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
+            float age_new;
+            const bool alive = valid && fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);
+            uint32_t o;
+            place(alive, &o);
+            const uint32_t i = n_in + rel + k;  // its list index before the update
+            if (alive) {
+                fw_integrate_store(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, o);
+            } else if (valid && want_destroyed) {  // born and destroyed in the same frame (dt >= its lifetime)
+                fw_store_destroyed(destroyed, ib, C, i, false, T, s_keys, so.q0, so.q1, so.q2, so.q3, age_new, i - o);
+            }
+        }
+    }
+    const uint32_t n_tot = n_in + n_spawn;
+    if (lane == 0) {
+        g.count[oidx] = run, g.spawned[oidx] = 0, g.appended[oidx] = 0;
+        g.ndestroyed[seg] = n_tot - run;
+        if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | run;
+    }
+    entered = n_tot, live = run;
+}
 
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_small(FwGlobals g, FwSmallArgs a) {
     constexpr int NW = FW_BLOCK / 64;
     __shared__ __attribute__((aligned(16))) float s_keys_all[NW][FW_KEYS_MAX];
     __shared__ unsigned long long s_entered[NW], s_live[NW];
+    __shared__ uint32_t s_cnt[2][NW];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (a scalar: everything indexed by it is wave-uniform)
-    const uint32_t idx = blockIdx.x * NW + wave;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (a.live_next) *a.live_next = 0ull;
         if (a.done_tag) *a.done_tag = a.done_value;
     }
     unsigned long long entered = 0ull, live = 0ull;
-    if (idx < a.n) {
-        const uint32_t seg = a.list[idx];
-        const FwSeg *Sp = &g.segs[seg];
-        const uint32_t C = Sp->capacity, n_lplanes = Sp->n_lplanes;
-        const char *ib = Sp->buf[a.parity];
-        char *ob = Sp->buf[a.parity ^ 1u];
-        char *destroyed = Sp->destroyed;
-        const uint32_t sidx = a.parity * g.max_seg + seg, oidx = (a.parity ^ 1u) * g.max_seg + seg;
-        const uint32_t n_cnt = g.count[sidx];
-        const uint32_t n_in = min(n_cnt + g.spawned[sidx] + g.appended[sidx], C);  // loaded: the live ones + what a pass materialised
-        // this frame's spawn ops of the segment (table form, pinned host memory: one header per segment)
-        uint32_t o0 = 0u, o1 = 0u, n_spawn = 0u;
-        if (a.seg_op_first) {
-            const uint4 oh = a.seg_op_first[seg];
-            o0 = oh.x, o1 = oh.y, n_spawn = oh.z;
-        }
-        const uint32_t room = C - n_in;
-        if (n_spawn > room) {  // virtual spawns beyond the capacity are dropped (and reported), as everywhere
-            n_spawn = room;
-            if (lane == 0) fw_flag(g, FW_ERR_CAPACITY);
-        }
-        const FwType T = g.types[Sp->type_idx];
-        float *s_keys = s_keys_all[wave];
-        for (uint32_t i = lane; i < T.keys_len; i += 64u) s_keys[i] = g.keys[T.keys_off + i];
-        const bool nospin = (T.flags & FW_TYPE_NOSPIN) != 0u;
-        const bool want_destroyed = T.report_destroyed && destroyed != nullptr;
-        const FwOutWin W = fw_out_window(ob, C, 0u, T, a.force_colors, n_lplanes);
-        const char *p0 = ib + FW_OFF_Q0(C), *p1 = ib + FW_OFF_Q1(C), *p2 = ib + FW_OFF_Q2(C), *p3 = ib + FW_OFF_Q3(C);
-        const char *pl = ib + FW_OFF_L(C, n_lplanes);  // lifetimes of a type that cannot turn (FwOutWin::lf)
-        // (the wave's LDS row was written by its own lanes: a wave-scope fence orders it against the reads below)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint32_t run = 0u;  // survivors stored so far = the next output slot
-        // ---- the particles that are in memory, in list order
-        const uint32_t rounds = (n_in + 63u) / 64u;
-        auto load = [&](uint32_t r, float4 &q0, float4 &q1, float4 &q2, float4 &q3) {
-            const uint32_t i = min(r * 64u + lane, n_in ? n_in - 1u : 0u);  // (unconditional loads at a clamped index)
-            q0 = fw_ld4w(p0, i * 16u), q1 = fw_ld4w(p1, i * 16u);
-            if (nospin) {  // (wave-uniform branch)
-                q2 = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-                q3 = make_float4(0.0f, 0.0f, 0.0f, fw_ld1w(pl, i * 4u));
-            } else {
-                q2 = fw_ld4w(p2, i * 16u), q3 = fw_ld4w(p3, i * 16u);
-            }
-        };
-        float4 q0n, q1n, q2n, q3n;
-        if (rounds) load(0u, q0n, q1n, q2n, q3n);
-        for (uint32_t r = 0; r < rounds; r++) {
-            const float4 q0 = q0n, q1 = q1n, q2 = q2n, q3 = q3n;
-            if (r + 1u < rounds) load(r + 1u, q0n, q1n, q2n, q3n);
-            const uint32_t i = r * 64u + lane;
-            const bool valid = i < n_in;
-            float age_new;
-            const bool alive = valid && fw_survives(q0.w, a.dt, q3.w, &age_new);
-            const unsigned long long m = __ballot(alive);
-            const uint32_t o = run + fw_lane_prefix(m);
-            if (alive) {
-                fw_integrate_store(T, s_keys, a.dt, q0, q1, q2, q3, age_new, W, o);
-            } else if (valid && want_destroyed) {
-                // (a particle a pass materialised this frame carries its spawn-time scale and colours: evaluated, not read)
-                fw_store_destroyed(destroyed, ib, C, i, i < n_cnt, T, s_keys, q0, q1, q2, q3, age_new, i - o);
-            }
-            run += (uint32_t)__popcll(m);
-        }
-        // ---- this frame's new particles: spawn_particles (core.rs:437-469) right before update_particles, in op order
-        for (uint32_t x = o0; x < o1; x++) {
-            const FwOp &op = a.ops[x];  // (wave-uniform: scalar loads, over the bus)
-            const uint32_t rel = op.rel_base, cnt = rel < n_spawn ? min(op.n, n_spawn - rel) : 0u;
-            const FwEmit &e = g.emits[op.emit];
-            for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {
-                const uint32_t k = c0 + lane;
-                const bool valid = k < cnt;
-                FwSpawnOut so;
-                so.q0 = so.q1 = so.q2 = so.q3 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid)
-                    so = fw_spawn_one(e, g.seed, op.serial_base + k, fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
-                                      fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
-                                      fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
-                float age_new;
-                const bool alive = valid && fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);
-                const unsigned long long m = __ballot(alive);
-                const uint32_t o = run + fw_lane_prefix(m);
-                const uint32_t i = n_in + rel + k;  // its list index before the update
-                if (alive) {
-                    fw_integrate_store(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, o);
-                } else if (valid && want_destroyed) {  // born and destroyed in the same frame (dt >= its lifetime)
-                    fw_store_destroyed(destroyed, ib, C, i, false, T, s_keys, so.q0, so.q1, so.q2, so.q3, age_new, i - o);
-                }
-                run += (uint32_t)__popcll(m);
-            }
-        }
-        const uint32_t n_tot = n_in + n_spawn;
-        if (lane == 0) {
-            g.count[oidx] = run, g.spawned[oidx] = 0, g.appended[oidx] = 0;
-            g.ndestroyed[seg] = n_tot - run;
-            if (a.host_counts) a.host_counts[seg] = ((unsigned long long)a.epoch << 32) | run;
-        }
-        entered = n_tot, live = run;
+    const uint32_t narrow_wg = (a.n_narrow + NW - 1u) / NW;  // the first workgroups: a narrow type per wave
+    if (blockIdx.x < narrow_wg) {
+        const uint32_t idx = blockIdx.x * NW + wave;
+        if (idx < a.n_narrow) fw_small_type<false>(g, a, a.list[idx], s_keys_all[wave], s_cnt, entered, live);
+    } else {  // ... then a wide type per workgroup
+        unsigned long long e = 0ull, l = 0ull;
+        fw_small_type<true>(g, a, a.list[a.n_narrow + (blockIdx.x - narrow_wg)], s_keys_all[0], s_cnt, e, l);
+        if (wave == 0u) entered = e, live = l;  // (every wave leaves with the type's totals: counted once)
     }
     // statistics and the frame's live total: one atomic each per WORKGROUP (thousands on one word serialise at the memory side)
     if (lane == 0) s_entered[wave] = entered, s_live[wave] = live;
@@ -136,14 +193,17 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_small(FwGlobals g, FwSma
         unsigned long long e = 0ull, l = 0ull;
 #pragma unroll
         for (int w = 0; w < NW; w++) e += s_entered[w], l += s_live[w];
-        if (e && !FW_DBG(a.dbg, 128u)) atomicAdd(g.stats, e);
-        if (a.live_out && l) atomicAdd(a.live_out, l);
+        // (thousands of workgroups: the running total is kept in FW_STAT_SLOTS words -- readers add them up -- or the adds queue up
+        // behind each other on one address: 3-5 us of a 1024-workgroup launch)
+        if (e && !FW_DBG(a.dbg, 128u) && !(FW_SMALL_EXP & 4)) atomicAdd(g.stats + (blockIdx.x % FW_STAT_SLOTS), e);
+        if (a.live_out && l && !(FW_SMALL_EXP & 4)) atomicAdd(a.live_out, l);
     }
 }
 
 hipError_t fw_launch_update_small(hipStream_t s, const FwGlobals &g, const FwSmallArgs &a, hipEvent_t e0, hipEvent_t e1) {
     if (!a.n) return hipSuccess;
-    const dim3 grid((a.n + FW_BLOCK / 64 - 1) / (FW_BLOCK / 64)), block(FW_BLOCK);
+    const uint32_t nw = FW_BLOCK / 64;
+    const dim3 grid((a.n_narrow + nw - 1) / nw + (a.n - a.n_narrow)), block(FW_BLOCK);
     FW_LAUNCH_T(fw_k_update_small, grid, block, s, e0, e1, g, a);
     return hipGetLastError();
 }

@@ -17,6 +17,7 @@
 #endif
 
 // pointers to the context's persistent device state (passed by value as a kernel argument)
+#define FW_STAT_SLOTS 32
 struct FwGlobals {
     FwSeg *segs;
     FwType *types;
@@ -43,7 +44,7 @@ struct FwGlobals {
     // 0xFFFFFFFF = not tied to one), so that the NEXT fw_step sees it without a synchronisation and stops stepping the
     // spawner it belongs to (fw_engine.cpp: poll_device_error) -- an in-place ring update that went wrong cannot be redone
     unsigned long long *err_host;
-    unsigned long long *stats;       // [0] particles that entered update (running total)
+    unsigned long long *stats;       // [FW_STAT_SLOTS] particles that entered update (running total = their sum; most kernels add to [0])
     unsigned long long *dbg_ts;      // FW_DEBUG & 8: 4 timestamps per tile of the last update (profiling)
     unsigned long long *emit_serial; // RNG serials of Nested emission entries
     unsigned long long *nest_status; // [nested tiles] look-back words of fw_k_nest, tagged with the launch's sequence number
@@ -296,8 +297,9 @@ struct FwRangeArgs {
 // scalar registers -- four types per workgroup, thousands of emitters resident at once.  Same ping-pong layout as the compacting
 // path: a type enters and leaves the mode by a host flag (SegHost::small).
 struct FwSmallArgs {
-    const uint32_t *list;          // [n] segments of the launch (device)
-    uint32_t n, parity, epoch;
+    const uint32_t *list;          // [n] segments of the launch (device): n_narrow types a wave walks, then n - n_narrow WIDE ones
+                                   // (up to a few thousand particles: a workgroup each)
+    uint32_t n, n_narrow, parity, epoch;
     float dt;
     const uint4 *seg_op_first;     // as FwUpdateArgs (table form: pinned host memory), or null: no virtual spawns this frame
     const FwOp *ops;

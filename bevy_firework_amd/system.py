@@ -153,7 +153,14 @@ class SpawnerData:
         mode, moved, algo = C.c_int32(), C.c_uint32(), C.c_uint32()
         self._sys._check(self._sys._lib.fw_debug_update_path(self._sys._ctx, self.handle, particle_type, C.byref(mode),
                                                              C.byref(moved), C.byref(algo)))
-        return {0: "general", 1: "fifo", 2: "range", 3: "small"}[mode.value], int(moved.value), int(algo.value)
+        # (4: a WIDE small type -- a workgroup of the same kernel instead of a wave; update_mode() tells the two apart)
+        return {0: "general", 1: "fifo", 2: "range", 3: "small", 4: "small"}[mode.value], int(moved.value), int(algo.value)
+
+    def update_mode(self, particle_type: int = 0) -> int:
+        """the raw mode of fw_debug_update_path: 0 compacting, 1 FIFO ring, 2 range ring, 3 small (a wave), 4 small (a workgroup)"""
+        mode = C.c_int32()
+        self._sys._check(self._sys._lib.fw_debug_update_path(self._sys._ctx, self.handle, particle_type, C.byref(mode), None, None))
+        return int(mode.value)
 
     def aabb(self):
         """(any, min, max) of position -/+ scale over all particle types (render.rs:677-703)."""

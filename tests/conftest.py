@@ -81,8 +81,13 @@ def fw_path(request, monkeypatch):
         monkeypatch.setenv("FW_FIFO", "0")
         monkeypatch.setenv("FW_RANGE", "0")
         monkeypatch.setenv("FW_SMALL", "1")
-        monkeypatch.setenv("FW_SMALL_MAX", "2000000000")
         monkeypatch.setenv("FW_SMALL_MIN", "0")
+        # (every eligible type whatever its size: on a WAVE each in half of the test functions, a WORKGROUP each -- the kernel's wide
+        # role -- for what sustains more than a few hundred particles in the other half)
+        if (_name_bits(request) >> 3) & 1:
+            monkeypatch.setenv("FW_SMALL_MAX", "2000000000"), monkeypatch.setenv("FW_WIDE_MAX", "0")
+        else:
+            monkeypatch.setenv("FW_WIDE_MAX", "2000000000"), monkeypatch.setenv("FW_WIDE_MIN", "0")
     if mode == "fifo":
         monkeypatch.setenv("FW_FIFO", "1")
         monkeypatch.setenv("FW_FIFO_MIN", "0")

@@ -34,8 +34,9 @@ def _world(system, n_solo):
     # two entries feed ONE small type: not solo (its ops of a frame share a header)
     pairs.append(Pair(system, _emitter(300.0, 0.25, 7, entries=2), S.Transform((1.0, 2.0, 3.0)), seed=SEED, uid=5000))
     # emitters that sustain ~300 particles on average -- small types when they are built -- but emit a cycle's worth in its first
-    # 0.3 s: 1100 live pass the bound of the wave-per-type kernel (the type continues on the compacting path, from the frame in
-    # which the op that does it is made), 2600 also pass the derived capacity (2048: the segment grows in that frame)
+    # 0.3 s: 1100 live pass what a WAVE is given (the type continues as a wide one -- here, among fewer than 768 eligible types, on
+    # the compacting kernels -- from the frame in which the op that does it is made), 2600 also pass the derived capacity (2048: the
+    # segment grows in that frame)
     for j, (count, duration) in enumerate(((1100.0, 3.0), (2600.0, 8.0))):
         ps = S.ParticleSettings(lifetime=S.RandF32(0.6, 0.78), base_color=S.FireworkGradient.uneven_samples(workloads.STRESS_GRADIENT))
         es = S.EmissionSettings(emission_pacing=S.EmissionPacing.CountOverDuration(count, duration, 0.0, 0.3 / duration),
@@ -60,8 +61,10 @@ def _scenario(system, digest=None):
     pairs = _world(system, 360)  # (the wave-per-type kernel runs from 352 eligible types on: fw_ctx::small_min)
     assert {p.gpu.update_path(0)[0] for p in pairs} == {"small"}
     _run(system, pairs, 25, "steady", every=5)
-    assert [p.gpu.update_path(0)[0] for p in pairs[-2:]] == ["general", "general"] and pairs[-1].gpu.count(0) > 2048
-    assert {p.gpu.update_path(0)[0] for p in pairs[:-2]} == {"small"}
+    # (past the bound of a wave: a WIDE type -- which this context, of fewer than fw_ctx::wide_min eligible types, runs on the
+    # compacting kernels: mode 0; the others keep their wave -- mode 3)
+    assert [p.gpu.update_mode(0) for p in pairs[-2:]] == [0, 0] and pairs[-1].gpu.count(0) > 2048
+    assert {p.gpu.update_mode(0) for p in pairs[:-2]} == {3}
     # segment slots and spawner slots no longer run in step: a two-type spawner whose entry feeds its SECOND type takes the freed
     # slot 3 and a slot at the end, the spawner built after it the freed slot 40 -- ops arrive out of segment order from here on
     for k in (40, 3):
@@ -117,3 +120,30 @@ def test_the_same_world_without_the_fast_host_path(monkeypatch):
             _scenario(system, h)
         out.append(h.hexdigest())
     assert out[0] == out[1]
+
+
+def test_hundreds_of_mid_size_emitters_on_a_workgroup_each(monkeypatch):
+    """720 emitters of 450-1300 particles (wide types: a workgroup of fw_k_update_small each, in a context of fw_ctx::wide_min = 768
+    eligible types or more) next to 80 of ~150 (a wave each) in ONE launch; every fourth wide type reports its destroyed particles; lifetimes cross, so the workgroups compact across their waves"""
+    from bevy_firework_amd.system import ParticleSystem
+
+    _product_defaults(monkeypatch)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        pairs = []
+        for k in range(800):
+            wide = k % 10 != 9
+            life = 0.3 + 0.002 * (k % 50)
+            ps = S.ParticleSettings(lifetime=S.RandF32(life, life * 1.25), linear_drag=0.1 + 0.01 * (k % 7), acceleration=(0.0, -2.0, 0.1 * (k % 5)),
+                                    scale_curve=S.FireworkCurve.even_samples([1.0, 2.0, 0.5]), base_color=S.FireworkGradient.uneven_samples(workloads.STRESS_GRADIENT),
+                                    particles_destroyed=(lambda recs: None) if k % 4 == 0 else None)
+            es = S.EmissionSettings(emission_pacing=S.EmissionPacing.rate((1500.0 + 1.5 * k) if wide else 400.0),
+                                    initial_velocity=S.RandVec3(S.RandF32(1.0, 4.0), (0.0, 1.0, 0.0), 0.0))
+            pairs.append(Pair(system, S.ParticleSpawner([ps], [es]), S.Transform((float(k % 40), 0.0, float(k // 40))), seed=SEED, uid=9000 + k))
+        modes = [p.gpu.update_mode(0) for p in pairs]
+        assert modes.count(4) == 720 and modes.count(3) == 80, (modes.count(4), modes.count(3), set(modes))
+        from parity import assert_particles_match
+        for rep in range(3):
+            _run(system, pairs, 15, "a workgroup per mid-size type", every=15)
+            for k in range(0, 800, 4):  # the destroyed stream of the last frame (core.rs:596-599), in list order
+                assert_particles_match(pairs[k].gpu.destroyed(0), pairs[k].cpu.destroyed(0), True, f"destroyed records, spawner {k}, round {rep}")
+        assert min(p.gpu.count(0) for p in pairs) > 100 and max(p.gpu.count(0) for p in pairs) > 1000
