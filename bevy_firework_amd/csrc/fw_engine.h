@@ -658,9 +658,9 @@ struct fw_ctx {
     // same kernel, the same launch; a narrow type whose bound passes small_max becomes a wide one, a wide one leaves the mode past
     // 2 x wide_max.  FW_WIDE_MAX; 0: no wide types
     // ... in contexts of wide_min eligible types or more (with the same hysteresis as small_min): 1024 x 600 / 1024 x 1000 particles 26 /
-    // 31 us per launch against 29 / 53 on the compacting kernels, but 512 x 1500 24 against 20.5 (profiles/r05/wide_sweep.txt) -- a
-    // workgroup's frame ends with the serial tail header -> op -> emitter record -> spawn, which the compacting kernels give to
-    // workgroups of their own.  FW_WIDE_MIN
+    // 31 us per launch against 29 / 53 on the compacting kernels, but 512 x 1500 24 against 20.5 (profiles/r05/wide_sweep.txt,
+    // wide_ablations.txt): one workgroup walks a type's rounds one after the other, the compacting kernels spread them over several
+    // workgroups -- which pays until those no longer fit the chip at once.  FW_WIDE_MIN
     uint32_t wide_min = 768;
     bool wide_on = false;
     uint32_t wide_max = 2048;

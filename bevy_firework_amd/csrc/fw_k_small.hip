@@ -22,7 +22,8 @@
 // (one barrier per round, double-buffered), everything else as above.  One launch serves both kinds: its first workgroups take four
 // narrow types each, the rest one wide type each (a workgroup-uniform branch).
 #include "fw_dev.h"
-#ifndef FW_SMALL_EXP  // (profiling experiments, results wrong: 1 no spawn phase, 2 no integration, 4 no statistics atomics, 8 no op/header reads)
+#ifndef FW_SMALL_EXP  // (profiling experiments, results wrong: 1 no spawn phase -- the populations die out --, 2 no integration, 4 no statistics atomics,
+                      // 8 no op / header reads, 16 spawn without random numbers and trigonometry)
 #define FW_SMALL_EXP 0
 #endif
 
@@ -33,15 +34,7 @@ __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallA
     constexpr int NW = FW_BLOCK / 64;
     constexpr uint32_t LANES = WIDE ? (uint32_t)FW_BLOCK : 64u;
     const uint32_t wlane = threadIdx.x & 63u;
-    // WIDE: which quarter of a round a wave takes ROTATES with the workgroup.  A type spawns a handful of particles per frame -- less
-    // than one wave's worth -- and spawning is a long serial instruction stream (three Philox blocks, trigonometry): with the first
-    // 64 new particles always on hardware wave 0, the four workgroups of a CU ran their spawn streams on ONE SIMD, one after the
-    // other (16 of the kernel's 32 us at 1024 types x 1000 particles: profiles/r05/wide_ablations.txt).
-    // (workgroups that share a CU: consecutive ones of an XCD's round-robin share -- blockIdx / 8 -- or ones a whole layer of the chip
-    // apart -- blockIdx / 256 --, depending on how the dispatcher fills CUs: the rotation differs among them either way)
-    const uint32_t rot = ((blockIdx.x >> 3) + (blockIdx.x >> 8)) % NW;
-    const uint32_t wave = WIDE ? __builtin_amdgcn_readfirstlane(((threadIdx.x >> 6) + NW - rot) % NW)
-                               : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = WIDE ? wave * 64u + wlane : wlane;  // index within the round
     const FwSeg *Sp = &g.segs[seg];
     const uint32_t C = Sp->capacity, n_lplanes = Sp->n_lplanes;
@@ -140,7 +133,10 @@ __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallA
             const bool valid = k < cnt;
             FwSpawnOut so;
             so.q0 = so.q1 = so.q2 = so.q3 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid)
+            if (valid && (FW_SMALL_EXP & 16)) {  // (no RNG, no trigonometry: what the memory chain of the spawn phase costs by itself)
+                so.q0 = make_float4(op.origin_pos[0], op.origin_pos[1], op.origin_pos[2], 0.0f);
+                so.q1 = make_float4(0.f, op.speed, 0.f, op.scale), so.q2 = make_float4(0.f, 0.f, 0.f, 1.f), so.q3 = make_float4(0.f, 0.f, 0.f, e.life_min);
+            } else if (valid)
                 so = fw_spawn_one(e, g.seed, op.serial_base + k, fw_v3{op.origin_pos[0], op.origin_pos[1], op.origin_pos[2]},
                                   fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
                                   fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
