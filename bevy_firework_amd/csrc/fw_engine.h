@@ -363,6 +363,7 @@ struct alignas(64) SegHost {
     bool small = false;
     bool small_ok = false;    // ... qualifies for it (small_eligible); `small` follows the context's mode (fw_ctx::small_on)
     bool wide = false;        // ... as a WIDE type: up to a few thousand particles, a workgroup instead of a wave (fw_ctx::wide_max)
+    bool wide_big = false;    // ... one that sustains more than fw_ctx::wide_mid particles: on the kernel only among wide_min types
     bool one_feeder = false;  // exactly one emission entry (a Global one) spawns into the type (SegHost::solo)
     float expect_live = 0.f;  // live particles the emitters that feed the type sustain (what derive_capacity derives the capacity from)
     uint32_t r_old = 0, r_new = 0, r_young = 0;  // workgroups of each role the device table provides for the segment
@@ -661,8 +662,13 @@ struct fw_ctx {
     // 31 us per launch against 29 / 53 on the compacting kernels, but 512 x 1500 24 against 20.5 (profiles/r05/wide_sweep.txt,
     // wide_ablations.txt): one workgroup walks a type's rounds one after the other, the compacting kernels spread them over several
     // workgroups -- which pays until those no longer fit the chip at once.  FW_WIDE_MIN
+    // Types of up to wide_mid particles (four rounds of a workgroup) gain from a third of that on already: 256 x 600 14.9 against 16.8 us
+    // per frame, 384 x 1000 19.3 against 23.1, 512 x 1000 20.3 against 25.6 (profiles/r05/mid_paths_sweep.txt); larger ones -- 1500
+    // particles, six rounds -- lose up to 512 types (24.3 against 21.2) and win where the compacting launch no longer fits the chip.
     uint32_t wide_min = 768;
-    bool wide_on = false;
+    bool wide_on = false;      // wide types of more than wide_mid particles run on the kernel
+    bool wide_mid_on = false;  // ... those of up to wide_mid do
+    uint32_t wide_mid = 1400;
     uint32_t wide_max = 2048;
     uint32_t n_narrow = 0;   // of small_list (narrow types first)
     uint32_t small_min = 352;
@@ -702,7 +708,7 @@ struct fw_ctx {
     // Up to range_few segments in use, no FIFO ring among them (a FIFO launch and a range launch run one after the other), such a
     // type becomes a range ring whatever its size (SegHost::few_ring); the spawner that takes the context past either condition
     // sends those rings to the compacting path (drop_few_rings: build time, the context is synchronised).  FW_RANGE_FEW; 0: off
-    uint32_t range_few = 160;  // (64 until the range launch read its records from device memory: profiles/r05/mid_emitters_paths.txt)
+    uint32_t range_few = 192;  // (64 until the range launch read its records from device memory: profiles/r05/mid_emitters_paths.txt)
     uint32_t n_few = 0;     // SegHost::few_ring segments
     bool few_blocked = false;  // the context has outgrown the rule: no new small rings until it is back at half of range_few (a
                                // context whose spawners come and go around the limit would convert rings at every crossing)

@@ -122,6 +122,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_SMALL_MIN")) ctx->small_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_WIDE_MAX")) ctx->wide_max = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_WIDE_MIN")) ctx->wide_min = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_WIDE_MID")) ctx->wide_mid = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_HOST_FAST")) ctx->host_fast = atoi(m) != 0;
     if (const char *m = getenv("FW_PARAM_BAR")) ctx->param_bar = ctx->param_bar && atoi(m) != 0;
     for (int i = 0; i < kParamRing && ctx->param_bar; i++)

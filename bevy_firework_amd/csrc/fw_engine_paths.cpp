@@ -136,8 +136,9 @@ static void small_deactivate(fw_ctx *ctx, SegHost &S) {
 // the segment qualifies (small_eligible): on the kernel at once if the context runs it (fw_ctx::small_on), else with the others
 // when there are enough of them (update_small_mode)
 void enter_small(fw_ctx *ctx, SegHost &S) {
-    if (!S.small_ok) S.small_ok = true, ctx->n_small_ok++, S.wide = S.expect_live * 2.0f > (float)ctx->small_max;
-    if (S.wide ? ctx->wide_on : ctx->small_on) small_activate(ctx, S);
+    if (!S.small_ok)
+        S.small_ok = true, ctx->n_small_ok++, S.wide = S.expect_live * 2.0f > (float)ctx->small_max, S.wide_big = S.expect_live > (float)ctx->wide_mid;
+    if (S.wide ? (S.wide_big ? ctx->wide_on : ctx->wide_mid_on) : ctx->small_on) small_activate(ctx, S);
 }
 void small_suspend(fw_ctx *ctx, SegHost &S) { small_deactivate(ctx, S); }
 // ... and no longer does: a compacting segment from here on
@@ -150,12 +151,15 @@ void update_small_mode(fw_ctx *ctx) {
     const uint32_t on_at = ctx->small_min, off_below = ctx->small_min - ctx->small_min / 4;
     const bool want = ctx->use_small && (ctx->small_on ? ctx->n_small_ok >= off_below : ctx->n_small_ok >= on_at);
     // ... and its wide role from wide_min of them on (fw_ctx::wide_min)
-    const bool want_wide = want && ctx->wide_max != 0 &&
+    const bool want_wide = ctx->use_small && ctx->wide_max != 0 &&
                            (ctx->wide_on ? ctx->n_small_ok >= ctx->wide_min - ctx->wide_min / 4 : ctx->n_small_ok >= ctx->wide_min);
-    if (want == ctx->small_on && want_wide == ctx->wide_on) return;
-    ctx->small_on = want, ctx->wide_on = want_wide;
+    const uint32_t mid_at = ctx->wide_min / 3;  // (fw_ctx::wide_mid)
+    const bool want_mid = ctx->use_small && ctx->wide_max != 0 &&
+                          (ctx->wide_mid_on ? ctx->n_small_ok >= mid_at - mid_at / 4 : ctx->n_small_ok >= mid_at);
+    if (want == ctx->small_on && want_wide == ctx->wide_on && want_mid == ctx->wide_mid_on) return;
+    ctx->small_on = want, ctx->wide_on = want_wide, ctx->wide_mid_on = want_mid;
     for (auto &S : ctx->segs)
-        if (S.in_use && S.small_ok) (S.wide ? want_wide : want) ? small_activate(ctx, S) : small_deactivate(ctx, S);
+        if (S.in_use && S.small_ok) (S.wide ? (S.wide_big ? want_wide : want_mid) : want) ? small_activate(ctx, S) : small_deactivate(ctx, S);
 }
 
 // every SegHost::few_ring segment leaves its ring (fw_ctx::range_few), particles and order kept

@@ -389,9 +389,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 S.ub = (uint32_t)std::min<uint64_t>((uint64_t)S.ub + n, 0xFFFFFFFFull);
                 if (S.small && S.ub > ctx->small_max && !S.wide) {
                     // no longer a few hundred particles: a WIDE type (a workgroup of the same kernel) from this frame on -- or, in a
-                    // context that does not run wide types (fw_ctx::wide_on), a compacting segment that stays eligible
-                    S.wide = true, ctx->small_dirty = true;
-                    if (!ctx->wide_on) {
+                    // context that does not run wide types (fw_ctx::wide_mid_on), a compacting segment that stays eligible
+                    S.wide = true, S.wide_big = false, ctx->small_dirty = true;
+                    if (!ctx->wide_mid_on) {
                         const bool was_solo = S.solo;
                         small_suspend(ctx, S);
                         if (was_solo) S.frame_spawn = (uint32_t)n;

@@ -34,9 +34,8 @@ def _world(system, n_solo):
     # two entries feed ONE small type: not solo (its ops of a frame share a header)
     pairs.append(Pair(system, _emitter(300.0, 0.25, 7, entries=2), S.Transform((1.0, 2.0, 3.0)), seed=SEED, uid=5000))
     # emitters that sustain ~300 particles on average -- small types when they are built -- but emit a cycle's worth in its first
-    # 0.3 s: 1100 live pass what a WAVE is given (the type continues as a wide one -- here, among fewer than 768 eligible types, on
-    # the compacting kernels -- from the frame in which the op that does it is made), 2600 also pass the derived capacity (2048: the
-    # segment grows in that frame)
+    # 0.3 s: 1100 live pass what a WAVE is given (the type continues as a wide one, on a workgroup, from the frame in which the op
+    # that does it is made), 2600 also pass the derived capacity (2048: the segment grows in that frame)
     for j, (count, duration) in enumerate(((1100.0, 3.0), (2600.0, 8.0))):
         ps = S.ParticleSettings(lifetime=S.RandF32(0.6, 0.78), base_color=S.FireworkGradient.uneven_samples(workloads.STRESS_GRADIENT))
         es = S.EmissionSettings(emission_pacing=S.EmissionPacing.CountOverDuration(count, duration, 0.0, 0.3 / duration),
@@ -61,9 +60,8 @@ def _scenario(system, digest=None):
     pairs = _world(system, 360)  # (the wave-per-type kernel runs from 352 eligible types on: fw_ctx::small_min)
     assert {p.gpu.update_path(0)[0] for p in pairs} == {"small"}
     _run(system, pairs, 25, "steady", every=5)
-    # (past the bound of a wave: a WIDE type -- which this context, of fewer than fw_ctx::wide_min eligible types, runs on the
-    # compacting kernels: mode 0; the others keep their wave -- mode 3)
-    assert [p.gpu.update_mode(0) for p in pairs[-2:]] == [0, 0] and pairs[-1].gpu.count(0) > 2048
+    # (past the bound of a wave: a WIDE type, a workgroup of the same kernel -- mode 4; the others keep their wave -- mode 3)
+    assert [p.gpu.update_mode(0) for p in pairs[-2:]] == [4, 4] and pairs[-1].gpu.count(0) > 2048
     assert {p.gpu.update_mode(0) for p in pairs[:-2]} == {3}
     # segment slots and spawner slots no longer run in step: a two-type spawner whose entry feeds its SECOND type takes the freed
     # slot 3 and a slot at the end, the spawner built after it the freed slot 40 -- ops arrive out of segment order from here on

@@ -1,5 +1,5 @@
 """10 000 frames of ONE context at product defaults (no knob set) in which spawners come and go the whole time: the segment count
-crosses fw_ctx::range_few (160) in both directions again and again, now and then fw_ctx::small_min (352 small types: the wave-per-type
+crosses fw_ctx::range_few (192) in both directions again and again, now and then fw_ctx::small_min (352 small types: the wave-per-type
 kernel takes them over, and hands them back below 264), FIFO rings arrive and leave, a ninth large one-lifetime type
 arrives (the FIFO rings become range rings where they stand) and the converted rings drain away, a Nested spawner's entry runs inside
 its FIFO launch; small types are updated by one wave each.  The state of a random subset of the spawners against the ORACLE every
