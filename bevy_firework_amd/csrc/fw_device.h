@@ -57,7 +57,7 @@ struct alignas(16) FwSeg {
     uint32_t inst_cap;    // records that fit in `inst`
     char *inst;           // attached ParticleInstance output (render hand-off fused into the update), or null
     // A type other particles' entries emit from, spawned INSIDE its ring's update kernel even in frames with a Nested pass
-    // (fw_engine.cpp: SegHost::virt_parent): the FwEmit of the Nested entry that owns last_emitted_age plane k (k < 2), or
+    // (fw_engine.h: SegHost::virt_parent): the FwEmit of the Nested entry that owns last_emitted_age plane k (k < 2), or
     // 0xFFFFFFFF.  The pass of the frame would have visited the new particle -- age 0, last_emitted_age f32::MIN -- emitted
     // nothing (offsets >= 0) and left `next` in the plane (core.rs:488-500): the spawning lane computes that value itself
     // (fw_init_last_emitted) and fw_k_spawn has nothing to materialise.

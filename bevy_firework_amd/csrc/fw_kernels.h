@@ -1,4 +1,4 @@
-// fw_kernels.h -- launch interface between the host engine (fw_engine.cpp) and the
+// fw_kernels.h -- launch interface between the host engine (fw_engine.h, fw_engine_*.cpp) and the
 // gfx950 kernels (fw_k_general.hip, fw_k_rings.hip, fw_k_nested.hip, fw_k_aux.hip; shared device helpers: fw_dev.h).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -42,7 +42,7 @@ struct FwGlobals {
     uint32_t *err;                   // sticky FW_ERR_* flags
     // pinned host word: the first internal error of a kernel also lands here ({1 : 1 | check : 31 | segment : 32}, segment
     // 0xFFFFFFFF = not tied to one), so that the NEXT fw_step sees it without a synchronisation and stops stepping the
-    // spawner it belongs to (fw_engine.cpp: poll_device_error) -- an in-place ring update that went wrong cannot be redone
+    // spawner it belongs to (fw_engine_mem.cpp: poll_device_error) -- an in-place ring update that went wrong cannot be redone
     unsigned long long *err_host;
     unsigned long long *stats;       // [FW_STAT_SLOTS] particles that entered update (running total = their sum; most kernels add to [0])
     unsigned long long *dbg_ts;      // FW_DEBUG & 8: 4 timestamps per tile of the last update (profiling)
