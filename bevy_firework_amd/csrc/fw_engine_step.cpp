@@ -1037,7 +1037,11 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     S.gcoh.pop_front();
                 }
             }
-            S.young_lo = (uint32_t)(((uint64_t)S.young_lo + grad) % S.capacity);
+            {  // (young_lo + grad) mod capacity without a 64-bit division: both terms are below the capacity
+                uint64_t nb = (uint64_t)S.young_lo + grad;
+                while (nb >= S.capacity) nb -= S.capacity;
+                S.young_lo = (uint32_t)nb;
+            }
             const uint32_t y_exist = S.range_dev ? 0u : S.young_n - std::min(S.young_n, grad);
             FwRangeRec Rc{};  // (built here, stored once below: the slot is written, never read, by the host)
             Rc.b = S.young_lo, Rc.y_exist = y_exist, Rc.n_spawn = (mat_frame || S.range_dev) ? 0u : S.frame_spawn;
@@ -1049,19 +1053,20 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             S.young_n = S.range_dev ? 0u : y_exist + S.frame_spawn;
             // workgroups of each role (bands: the table is re-sent only when a need leaves its band)
             const uint32_t YT = ctx->range_small ? (uint32_t)FW_BLOCK : ctx->range_young_rounds * (uint32_t)FW_BLOCK;
+            const uint32_t ysh = (uint32_t)__builtin_ctz(YT), osh = (uint32_t)__builtin_ctz(OT);  // (powers of two: shifts, not divisions, per segment)
             uint32_t need_old, need_new, need_young;
             if (S.range_dev) {
                 // the old part: at most the cohorts that have joined it and may still hold survivors (all sizes known); the young
                 // part: somewhere behind b -- the grid covers the ring, a tile without young particles leaves at once
-                need_old = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((S.gcoh_sum + OT - 1) / OT, S.capacity / OT + 1));
+                need_old = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((S.gcoh_sum + OT - 1) >> osh, (S.capacity >> osh) + 1));
                 need_new = 0u;
-                need_young = S.capacity / YT;
+                need_young = S.capacity >> ysh;
             } else {
                 const uint32_t live_before_ub = std::min(S.ub - std::min(S.ub, S.frame_spawn), S.capacity);
                 const uint32_t old_ub = live_before_ub - std::min(live_before_ub, y_exist);
-                need_old = std::max(1u, (old_ub + OT - 1) / OT);
+                need_old = std::max(1u, (old_ub + OT - 1) >> osh);
                 need_new = mat_frame ? 0u : (S.frame_spawn + FW_BLOCK - 1) / FW_BLOCK;
-                need_young = std::min(S.capacity / YT, (S.young_lo % YT + y_exist + (mat_frame ? S.frame_spawn : 0u) + YT - 1) / YT);
+                need_young = std::min(S.capacity >> ysh, ((S.young_lo & (YT - 1u)) + y_exist + (mat_frame ? S.frame_spawn : 0u) + YT - 1) >> ysh);
             }
             // every provisioned workgroup is dispatched every frame, active or not (~3 us of a slot each): small needs get
             // one spare, large ones an eighth -- a re-sent table is a copy in the stream, an idle workgroup a cost in every frame
@@ -1084,14 +1089,14 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 // the table, where they run while the launch drains (a tile that does hold particles simply updates them
                 // there); the split follows the count in steps of an eighth
                 const uint64_t est = (uint64_t)((double)S.dev_count * 1.2 + 8.0 * (double)S.dev_rate) + 2 * YT;
-                const uint32_t likely = (uint32_t)std::min<uint64_t>(need_young, (est + YT - 1) / YT);
+                const uint32_t likely = (uint32_t)std::min<uint64_t>(need_young, (est + YT - 1) >> ysh);
                 if (likely > S.r_young_main || likely + likely / 4 + 8 < S.r_young_main) S.r_young_main = std::min(need_young, likely + likely / 8 + 2), dirty = true;
                 S.r_need[2] = S.r_young_main;
             }
             fit(S.r_old, need_old, need_old >= 8 ? need_old / 4 : 1u, S.r_low[0]);
             fit(S.r_new, need_new, need_new ? (need_new >= 8 ? need_new / 8 : 1u) : 0u, S.r_low[1]);
             fit(S.r_young, need_young, need_young >= 16 ? need_young / 8 : 1u, S.r_low[2]);
-            S.r_young = std::min(S.r_young, S.capacity / YT);
+            S.r_young = std::min(S.r_young, S.capacity >> ysh);
             // (START tickets, fw_kernels.h: every OLD workgroup the table provides for the segment takes one per launch -- r_old of
             // them, whether the table is re-sent this frame or not: fit() changes the number only together with `dirty`)
             Rc.ticket_base = S.ticket_base, S.ticket_base += S.r_old;

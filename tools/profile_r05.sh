@@ -25,12 +25,20 @@ for v in "small_emitters 1" "small_emitters_workgroup_per_type 0"; do set -- $v
   t=$(find $R/$OUT/tmp_$1 -name "$1_kernel_trace.csv" | head -1); [ -n "$t" ] && python $R/profiles/analyze_trace.py $t 300 > $R/$OUT/$1_trace_summary.txt 2>&1
   rm -rf $R/$OUT/tmp_$1
 done
+# ... and of hundreds of mid-size emitters (1024 x 1000 particles): a workgroup per type (the wide role of fw_k_update_small) against the compacting kernels
+for v in "mid_emitters_wide 2048" "mid_emitters_compacting 0"; do set -- $v
+  rm -rf $R/$OUT/tmp_$1; FW_WIDE_MAX=$2 FW_CASES=1024x1000 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/tmp_$1 -o $1 --output-format csv -- python $R/tools/r05_mid_kernel.py > $R/$OUT/$1.log 2>&1
+  f=$(find $R/$OUT/tmp_$1 -name "$1_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/$OUT/$1_kernel_stats.csv
+  t=$(find $R/$OUT/tmp_$1 -name "$1_kernel_trace.csv" | head -1); [ -n "$t" ] && python $R/profiles/analyze_trace.py $t 300 > $R/$OUT/$1_trace_summary.txt 2>&1
+  rm -rf $R/$OUT/tmp_$1
+done
 cd $R
 # 5. every config on one GPU, the examples at their own sizes, the few-emitters sweep, the spill sweep, the soak
 timeout 600 python tools/bench_configs.py c1 c3 c4 c5 cc > $OUT/configs.txt 2>&1
 timeout 600 python tools/r04_examples_latency.py > $OUT/examples_latency.txt 2>&1
 timeout 900 python tools/r04_few_small_emitters.py > $OUT/few_small_emitters.txt 2>&1
 timeout 300 python tools/r05_mid_emitters.py > $OUT/mid_emitters_default.txt 2>&1
+FW_CASES=192x600,256x600,384x600,512x600,768x600,256x1000,384x1000,512x1000,768x1000,1024x1000,256x1500,512x1500,768x1500,1024x1500 timeout 300 python tools/r05_mid_kernel.py > $OUT/mid_kernel_default.txt 2>&1
 timeout 1500 python tools/soak_r05.py > $OUT/soak_r05.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -delete; rm -rf $OUT/pmc/*/ 2>/dev/null
 ls $OUT

@@ -18,7 +18,7 @@ import test_gpu_lifecycle as L
 frames = int(os.environ.get("FW_SOAK_FRAMES", "10000"))
 rng = np.random.default_rng(2025)
 events = {"created": 0, "despawned": 0, "rebuilt": 0, "checks": 0, "crossed range_few upwards": 0, "small mode on": 0, "ninth one-lifetime type": 0}
-seen, seen_now = set(), set()
+seen, seen_now, dust_was_small = set(), set(), False
 t0 = time.perf_counter()
 with ParticleSystem(device=0, seed=L.SEED) as system:
     w = L.World(system, rng, 0)
@@ -37,7 +37,9 @@ with ParticleSystem(device=0, seed=L.SEED) as system:
             before = segs
             w.add(kind); events["created"] += 1
             if before <= L.RANGE_FEW < w.segments(): events["crossed range_few upwards"] += 1
-            if "small" in w.paths()[-1] and "small" not in seen_now: events["small mode on"] += 1
+            dust_small = any(row == ("small",) for row, k2 in zip(w.paths(), w.kinds) if k2 == "dust")
+            if dust_small and not dust_was_small: events["small mode on"] += 1
+            dust_was_small = dust_small
             if sum(k == "fifo" for k in w.kinds) == 9 and kind == "fifo": events["ninth one-lifetime type"] += 1
             if w.segments() >= target: phase, target = "shrink", int(rng.integers(6, 30))
         else:
