@@ -195,6 +195,7 @@ def assemble_line(args, world, workload, rows, roof, extras, cpu, hist, rccl_ran
             "speedup_vs_configs4_one_gpu": (extras["configs4_one_gpu"]["ms_per_step"] / (elapsed / args.steps * 1e3)
                                             if world > 1 and extras.get("configs4_one_gpu") else None),
             "update_mode": os.environ.get("FW_UPDATE_MODE", "fused"),
+            "records_in_host_written_device_memory": extras.get("param_bar"),
         },
         "hbm_gbs_algorithmic_whole_step": value * (roof["algorithmic_bytes_per_particle"] if roof else SURVEY_BYTES) / 1e9,
     }
@@ -409,6 +410,8 @@ def main():
     hist = sh.global_live_history if dist is not None else []  # the RCCL-reduced per-frame totals (brought to the host only here)
 
     extras = {}
+    # (per-frame records / small op tables in device memory the host writes through the large BAR, or in pinned host memory: fw_ctx::param_bar)
+    extras["param_bar"] = bool(ps.param_bar()) if ps is not None and hasattr(ps, "param_bar") else None
     rccl_ranks = dist.get_world_size() if dist is not None else 1
     # N > 1: the base point of the strong-scaling curve -- ALL emitters of configs[4] on rank 0's GPU alone, measured in
     # the same process right after the timed region (the other ranks wait at the barrier), so the line carries

@@ -262,12 +262,13 @@ SYMBOLS = [
     ("fw_debug_read_range_timestamps", C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("fw_debug_update_path", C.c_int, [_P, C.c_int, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("fw_debug_nest_frames", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("fw_debug_param_bar", C.c_int, [_P, C.POINTER(C.c_int32)]),
     ("fw_compute_emission_count", C.c_uint64,
      [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]),
 ]
 
 # entry points added after round 4 (ABI 5 + a measurement hook): absent from the older builds the A/B tools load through FW_LIB_PATH
-NEWER_THAN_R04 = {"fw_debug_nest_frames", "fw_ctx_set_parent_velocities", "fw_ctx_set_modifiers", "fw_ctx_queue"}
+NEWER_THAN_R04 = {"fw_debug_nest_frames", "fw_debug_param_bar", "fw_ctx_set_parent_velocities", "fw_ctx_set_modifiers", "fw_ctx_queue"}
 _lib = None
 
 

@@ -4,6 +4,28 @@
 
 thread_local std::string fwh::g_create_error;  // (fw_last_error(nullptr): per calling thread, like errno)
 
+// Is `p` inside a mapping of this process that the host may write?  (The runtime reserves the device's address range in the host's
+// address space whether or not the memory behind an address is reachable through the BAR: a reserved-only page is mapped PROT_NONE,
+// and a store to it would be a SIGSEGV, not an error code -- so the page's permissions are read from /proc/self/maps, once, when a
+// context is created.)
+static bool host_maps_writable(const void *p) {
+    FILE *f = fopen("/proc/self/maps", "r");
+    if (!f) return false;
+    char line[512];
+    bool ok = false;
+    const unsigned long long a = (unsigned long long)(uintptr_t)p;
+    while (fgets(line, sizeof line, f)) {
+        unsigned long long lo = 0, hi = 0;
+        char perms[8] = {0};
+        if (sscanf(line, "%llx-%llx %7s", &lo, &hi, perms) == 3 && a >= lo && a < hi) {
+            ok = perms[0] == 'r' && perms[1] == 'w';
+            break;
+        }
+    }
+    fclose(f);
+    return ok;
+}
+
 extern "C" {
 
 
@@ -51,7 +73,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
         if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar != 0 &&
             hipExtMallocWithFlags(&probe, 4096, hipDeviceMallocFinegrained) == hipSuccess) {
             hipPointerAttribute_t at{};
-            ctx->param_bar = hipPointerGetAttributes(&at, probe) == hipSuccess && at.type == hipMemoryTypeDevice;
+            ctx->param_bar = hipPointerGetAttributes(&at, probe) == hipSuccess && at.type == hipMemoryTypeDevice && host_maps_writable(probe);
             hipFree(probe);
         }
         (void)hipGetLastError();
@@ -1029,6 +1051,11 @@ fw_status fw_debug_nest_frames(fw_ctx *ctx, uint64_t *fused, uint64_t *separate)
     if (!ctx) return FW_EINVAL;
     if (fused) *fused = ctx->fused_nest_frames;
     if (separate) *separate = ctx->nest_pass_frames;
+    return FW_OK;
+}
+fw_status fw_debug_param_bar(fw_ctx *ctx, int32_t *on) {  // fw_ctx::param_bar
+    if (!ctx || !on) return FW_EINVAL;
+    *on = ctx->param_bar ? 1 : 0;
     return FW_OK;
 }
 fw_status fw_debug_read_timestamps(fw_ctx *ctx, unsigned long long *out, uint64_t max_tiles, uint64_t *n_tiles) {

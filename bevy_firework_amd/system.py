@@ -339,6 +339,14 @@ class ParticleSystem:
         self._check(self._lib.fw_ctx_kernel_timing_overhead(self._ctx, C.byref(out)))
         return out.value * 1e3
 
+    def param_bar(self) -> bool:
+        """per-frame records and small op tables live in device memory the host writes through the large BAR (else: pinned host memory)"""
+        on = C.c_int32()
+        if not hasattr(self._lib, "fw_debug_param_bar"):
+            return False
+        self._check(self._lib.fw_debug_param_bar(self._ctx, C.byref(on)))
+        return bool(on.value)
+
     def nest_frames(self):
         """(frames whose Nested entries ran inside the FIFO ring launch, frames that ran the separate fw_k_spawn / fw_k_nest passes)"""
         a, b = C.c_uint64(), C.c_uint64()

@@ -50,6 +50,11 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner spawner, uint32_t type, i
  * 4.0) and those that ran the separate fw_k_spawn / fw_k_nest passes first */
 fw_status fw_debug_nest_frames(fw_ctx *ctx, uint64_t *fused, uint64_t *separate);
 
+/* *on = 1: the context keeps the per-frame records of its range launches and its small op tables in DEVICE memory that the host writes
+ * through the large BAR; 0: in pinned host memory (the platform does not map device memory for the host, or
+ * FW_PARAM_BAR=0) */
+fw_status fw_debug_param_bar(fw_ctx *ctx, int32_t *on);
+
 #ifdef __cplusplus
 }
 #endif
