@@ -726,7 +726,8 @@ static fw_status attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void
         if ((st = fifo_to_general(ctx, sp->seg[type]))) return st;
     }
     SegHost &S = ctx->segs[sp->seg[type]];
-    if (d_out) leave_small(ctx, S);  // (instance records are written by the compacting kernels)
+    // (a small type keeps its kernel: fw_k_update_small<INST> writes the records of its survivors itself)
+    ctx->n_inst += (d_out != nullptr ? 1u : 0u) - (S.inst != nullptr ? 1u : 0u);
     S.inst = (char *)d_out;
     S.inst_cap = d_out ? (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull) : 0u;
     S.inst_window = d_out != nullptr && window;

@@ -484,6 +484,7 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
         if (S.spilled) ctx->n_spilled--;
         if (S.small) ctx->n_small--, ctx->small_dirty = true;
         if (S.small_ok) ctx->n_small_ok--;
+        if (S.inst) ctx->n_inst--;
         if (S.solo) ctx->n_solo--;
         ctx->n_in_use--, ctx->big_dirty = true;
         if (ctx->n_in_use <= ctx->range_few / 2) ctx->few_blocked = false;

@@ -1244,6 +1244,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         sa.list = ctx->d_small, sa.n = (uint32_t)ctx->small_list.size(), sa.n_narrow = ctx->n_narrow, sa.parity = p, sa.epoch = a.epoch, sa.dt = dt;
         sa.seg_op_first = spawn_form == FW_SPAWN_TABLE ? a.seg_op_first : nullptr, sa.ops = a.ops;
         sa.force_colors = a.force_colors, sa.dbg = ctx->dbg;
+        sa.any_inst = ctx->n_inst != 0 ? 1u : 0u;
         sa.done_tag = a.done_tag, sa.done_value = a.done_value;
         sa.host_counts = a.host_counts, sa.live_out = a.live_out, sa.live_next = a.live_next;
         if (sa.n) {

@@ -28,7 +28,9 @@
 #endif
 
 // one particle type: by one wave (WIDE = false; `lanes` = 64) or by the four waves of a workgroup (WIDE = true; `lanes` = FW_BLOCK)
-template <bool WIDE>
+// (INST: some type of the launch has an instance buffer attached -- fw_spawner_attach_instances: the update writes the 64-byte render
+// record of every survivor itself, at its list index, and the type's scale / colour planes are not stored: FW_TYPE_DERIVED)
+template <bool WIDE, bool INST>
 __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallArgs &a, uint32_t seg, float *s_keys, uint32_t (*s_cnt)[FW_BLOCK / 64],
                                               unsigned long long &entered, unsigned long long &live) {
     constexpr int NW = FW_BLOCK / 64;
@@ -41,9 +43,20 @@ __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallA
     const char *ib = Sp->buf[a.parity];
     char *ob = Sp->buf[a.parity ^ 1u];
     char *destroyed = Sp->destroyed;
+    char *inst = INST ? Sp->inst : nullptr;
+    const uint32_t inst_cap = INST ? Sp->inst_cap : 0u;
     const uint32_t sidx = a.parity * g.max_seg + seg, oidx = (a.parity ^ 1u) * g.max_seg + seg;
     const uint32_t n_cnt = g.count[sidx];
     const uint32_t n_in = min(n_cnt + g.spawned[sidx] + g.appended[sidx], C);  // loaded: the live ones + what a pass materialised
+    // a survivor's update: integrate, store its planes at slot o -- and its render record, when the type has a buffer for them
+    auto update_one = [&](float4 q0, float4 q1, float4 q2, float4 q3, float age_new, const FwType &T_, const float *keys, const FwOutWin &W_, uint32_t o) {
+        float4 rec[4];
+        fw_integrate_store(T_, keys, a.dt, q0, q1, q2, q3, age_new, W_, o, INST ? rec : nullptr);
+        if (INST && inst != nullptr && o < inst_cap) {
+            fw_st4(inst, o * 4u + 0u, rec[0]), fw_st4(inst, o * 4u + 1u, rec[1]);
+            fw_st4(inst, o * 4u + 2u, rec[2]), fw_st4(inst, o * 4u + 3u, rec[3]);
+        }
+    };
     // this frame's spawn ops of the segment (table form: one header per segment)
     uint32_t o0 = 0u, o1 = 0u, n_spawn = 0u;
     if (a.seg_op_first && !(FW_SMALL_EXP & 8)) {
@@ -117,7 +130,7 @@ __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallA
         if (alive && (FW_SMALL_EXP & 2)) {
             fw_st4(W.q0, o, q0), fw_st4(W.q1, o, q1);
         } else if (alive) {
-            fw_integrate_store(T, s_keys, a.dt, q0, q1, q2, q3, age_new, W, o);
+            update_one(q0, q1, q2, q3, age_new, T, s_keys, W, o);
         } else if (valid && want_destroyed) {
             // (a particle a pass materialised this frame carries its spawn-time scale and colours: evaluated, not read)
             fw_store_destroyed(destroyed, ib, C, i, i < n_cnt, T, s_keys, q0, q1, q2, q3, age_new, i - o);
@@ -146,7 +159,7 @@ __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallA
             place(alive, &o);
             const uint32_t i = n_in + rel + k;  // its list index before the update
             if (alive) {
-                fw_integrate_store(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, o);
+                update_one(so.q0, so.q1, so.q2, so.q3, age_new, T, s_keys, W, o);
             } else if (valid && want_destroyed) {  // born and destroyed in the same frame (dt >= its lifetime)
                 fw_store_destroyed(destroyed, ib, C, i, false, T, s_keys, so.q0, so.q1, so.q2, so.q3, age_new, i - o);
             }
@@ -161,6 +174,7 @@ __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallA
     entered = n_tot, live = run;
 }
 
+template <bool INST>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_small(FwGlobals g, FwSmallArgs a) {
     constexpr int NW = FW_BLOCK / 64;
     __shared__ __attribute__((aligned(16))) float s_keys_all[NW][FW_KEYS_MAX];
@@ -176,10 +190,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_small(FwGlobals g, FwSma
     const uint32_t narrow_wg = (a.n_narrow + NW - 1u) / NW;  // the first workgroups: a narrow type per wave
     if (blockIdx.x < narrow_wg) {
         const uint32_t idx = blockIdx.x * NW + wave;
-        if (idx < a.n_narrow) fw_small_type<false>(g, a, a.list[idx], s_keys_all[wave], s_cnt, entered, live);
+        if (idx < a.n_narrow) fw_small_type<false, INST>(g, a, a.list[idx], s_keys_all[wave], s_cnt, entered, live);
     } else {  // ... then a wide type per workgroup
         unsigned long long e = 0ull, l = 0ull;
-        fw_small_type<true>(g, a, a.list[a.n_narrow + (blockIdx.x - narrow_wg)], s_keys_all[0], s_cnt, e, l);
+        fw_small_type<true, INST>(g, a, a.list[a.n_narrow + (blockIdx.x - narrow_wg)], s_keys_all[0], s_cnt, e, l);
         if (wave == 0u) entered = e, live = l;  // (every wave leaves with the type's totals: counted once)
     }
     // statistics and the frame's live total: one atomic each per WORKGROUP (thousands on one word serialise at the memory side)
@@ -200,6 +214,7 @@ hipError_t fw_launch_update_small(hipStream_t s, const FwGlobals &g, const FwSma
     if (!a.n) return hipSuccess;
     const uint32_t nw = FW_BLOCK / 64;
     const dim3 grid((a.n_narrow + nw - 1) / nw + (a.n - a.n_narrow)), block(FW_BLOCK);
-    FW_LAUNCH_T(fw_k_update_small, grid, block, s, e0, e1, g, a);
+    if (a.any_inst) FW_LAUNCH_T(fw_k_update_small<true>, grid, block, s, e0, e1, g, a);
+    else FW_LAUNCH_T(fw_k_update_small<false>, grid, block, s, e0, e1, g, a);
     return hipGetLastError();
 }

@@ -300,6 +300,7 @@ struct FwSmallArgs {
     const uint32_t *list;          // [n] segments of the launch (device): n_narrow types a wave walks, then n - n_narrow WIDE ones
                                    // (up to a few thousand particles: a workgroup each)
     uint32_t n, n_narrow, parity, epoch;
+    uint32_t any_inst;             // some type of the launch has an instance buffer attached (FwSeg::inst): the INST instantiation
     float dt;
     const uint4 *seg_op_first;     // as FwUpdateArgs (table form: pinned host memory), or null: no virtual spawns this frame
     const FwOp *ops;

@@ -145,3 +145,32 @@ def test_hundreds_of_mid_size_emitters_on_a_workgroup_each(monkeypatch):
             for k in range(0, 800, 4):  # the destroyed stream of the last frame (core.rs:596-599), in list order
                 assert_particles_match(pairs[k].gpu.destroyed(0), pairs[k].cpu.destroyed(0), True, f"destroyed records, spawner {k}, round {rep}")
         assert min(p.gpu.count(0) for p in pairs) > 100 and max(p.gpu.count(0) for p in pairs) > 1000
+
+
+def test_small_types_write_their_render_records(monkeypatch):
+    """instance buffers attached to types the wave- / workgroup-per-type kernel updates (what a renderer does for every spawner): the
+    types keep their kernel (its INST instantiation), the records the update leaves are the packed records of the survivors, the
+    particles still match the oracle; detaching goes back to the plain instantiation"""
+    import torch
+    from bevy_firework_amd.system import ParticleSystem
+
+    _product_defaults(monkeypatch)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        pairs = _world(system, 360)
+        _run(system, pairs, 12, "before", every=12)
+        modes = [p.gpu.update_mode(0) for p in pairs]
+        chosen = [0, 1, 5, 77, 200, 359, 360, 361, 362]  # waves, the type two entries feed, the two that burst (workgroups by now)
+        bufs = {k: torch.full((4096 * 16,), float("nan"), dtype=torch.float32, device="cuda") for k in chosen}
+        for k in chosen:
+            pairs[k].gpu.attach_instances(bufs[k].data_ptr(), 4096, particle_type=0)
+        assert [p.gpu.update_mode(0) for p in pairs] == modes  # nobody left the kernel
+        for rep in range(3):
+            _run(system, pairs, 9, "with instance buffers", every=9)
+            for k in chosen:
+                n = min(pairs[k].gpu.count(0), 4096)
+                want = pairs[k].gpu.instances(0)[:n].view(np.uint32).reshape(n, 16)
+                got = bufs[k][: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
+                assert n > 0 and np.array_equal(got, want), f"instance records of spawner {k}, round {rep}"
+        for k in chosen[:4]:
+            pairs[k].gpu.attach_instances(0, 0, particle_type=0)
+        _run(system, pairs, 10, "some detached", every=10)

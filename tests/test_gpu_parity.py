@@ -458,7 +458,7 @@ def test_attached_instances_replace_the_scale_and_colour_planes(system):
             # continues on the compacting path once records are wanted)
             # (a range ring continues on the compacting path once records are wanted: 4 B more for the lifetime plane it rewrites)
             # (+ the 64-byte record itself, which the update now writes per survivor)
-            # (a small type -- one wave, fw_k_small.hip -- continues on the compacting kernels too: the same layout, the same bytes)
+            # (a small type -- fw_k_small.hip -- keeps its kernel: the same layout, the same bytes)
             assert attached[0][1] == before[0] - 36 + 64 + (4 if attached[0][0] != pair_path0 and pair_path0 != "small" else 0), (before, attached)
         if fr == 100:
             for t in (0, 1):
@@ -499,8 +499,9 @@ def test_windowed_attach_is_the_plain_attach_where_the_list_starts_at_record_zer
     paths = [pair.gpu.update_path(t)[0] for t in (0, 1)]
     for t in (0, 1):
         pair.gpu.attach_instances_window(bufs[t].data_ptr(), 32768, particle_type=t)
-    # nobody changes path for a windowed buffer (a type updated by one wave continues on the compacting kernels, which write records)
-    assert [pair.gpu.update_path(t)[0] for t in (0, 1)] == ["general" if x == "small" else x for x in paths]
+    # nobody changes path for a windowed buffer (a type updated by a wave or a workgroup of fw_k_update_small keeps it: its INST
+    # instantiation writes the records)
+    assert [pair.gpu.update_path(t)[0] for t in (0, 1)] == paths
     for fr in range(90):
         system.update(DT)
         pair.step_cpu(DT)

@@ -3,6 +3,8 @@ tools/r04_range_min_sweep.py.  FW_WIDE_MAX=0: without the workgroup-per-type rol
 import os as _os; _os.environ.setdefault("FW_ENABLE_KNOBS", "1")
 import os, sys, time
 import numpy as np
+if os.environ.get("FW_ATTACH"):
+    import torch; torch.cuda.init()  # (before the library's own first HIP call)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from bevy_firework_amd import workloads
 from bevy_firework_amd.system import ParticleSystem
@@ -12,6 +14,9 @@ for n_em, per in CASES:
     ps = ParticleSystem(seed=workloads.SEED)
     ems = workloads.many_emitters(n_em, per)
     hs = [ps.spawn(ems[e][0], ems[e][1], uid=e) for e in range(n_em)]
+    if os.environ.get("FW_ATTACH"):  # an instance buffer per emitter (what a renderer attaches): the update writes the render records
+        keep = [torch.empty(int(per * 1.5) * 16, dtype=torch.float32, device="cuda") for _ in range(n_em)]
+        for h, b in zip(hs, keep): h.attach_instances(b.data_ptr(), int(per * 1.5), particle_type=0)
     ps.update(dt)
     for _ in range(90): ps.step(dt)
     best = 1e9
