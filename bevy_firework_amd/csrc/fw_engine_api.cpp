@@ -808,12 +808,12 @@ fw_status fw_spawner_aabb(fw_ctx *ctx, fw_spawner h, float out_min[3], float out
     for (size_t t0 = 0; t0 < nt || t0 == 0; t0 += 8) {
         const uint32_t n = (uint32_t)std::min<size_t>(8, nt - std::min(nt, t0));
         if (!n) break;
-        bool any_ring = false;  // rings leave no per-tile boxes: the two-pass query reads them
+        bool any_ring = false;  // rings (and types a wave / workgroup of fw_k_update_small updates) leave no per-tile boxes: the two-pass query reads them
         uint32_t heads[8] = {}, range_y[8], life_plane[8];
         float life_const[8];
         for (uint32_t t = 0; t < n; t++) {
             const SegHost &S = ctx->segs[sp->seg[t0 + t]];
-            any_ring |= S.ring();
+            any_ring |= S.ring() || S.small;
             heads[t] = S.range ? S.young_lo : (S.fifo ? S.head : 0u);
             range_y[t] = S.range ? 1u : 0xFFFFFFFFu;  // (a range ring: the kernel takes the old part's size from FwGlobals::rold)
             life_plane[t] = S.life_plane(), life_const[t] = S.fifo_life;
@@ -851,9 +851,7 @@ fw_status fw_ctx_track_aabbs(fw_ctx *ctx, int32_t enable) {
     if (!ctx) return FW_EINVAL;
     ctx->track_aabb = enable != 0;
     if (!enable) ctx->boxes_epoch = 0;
-    if (enable)  // (per-tile boxes are left by the compacting kernels' tiles)
-        for (SegHost &S : ctx->segs)
-            if (S.in_use) leave_small(ctx, S);
+    // (per-tile boxes are left by the compacting kernels' tiles; rings and small types are answered by the two-pass query)
     return FW_OK;
 }
 

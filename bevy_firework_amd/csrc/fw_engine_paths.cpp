@@ -117,7 +117,7 @@ fw_status fifo_to_general(fw_ctx *ctx, uint32_t si) {
 
 // SegHost::small: may this compacting segment be updated by the wave-per-type kernel?
 bool small_eligible(const fw_ctx *ctx, const SegHost &S) {
-    return ctx->use_small && S.in_use && !S.ring() && !S.nested_fed && S.n_lplanes == 0 && !S.collides && !ctx->track_aabb &&
+    return ctx->use_small && S.in_use && !S.ring() && !S.nested_fed && S.n_lplanes == 0 && !S.collides &&
            !S.colors_dirty && (S.expect_live * 2.0f <= (float)ctx->small_max || S.expect_live <= (float)ctx->wide_max);
 }
 // on the kernel / off it: a flag (the same buffers, the same layout; the tile table is re-sent)
