@@ -674,6 +674,7 @@ struct fw_ctx {
     uint32_t small_min = 352;
     uint32_t n_small_ok = 0;
     uint32_t n_inst = 0;     // segments with an instance buffer attached (SegHost::inst): which instantiation the small launch runs
+    uint32_t n_small_coll = 0;  // types on the kernel that have collision settings: its COLL instantiation
     bool small_on = false;
     // ... and the host half of their frames (thousands of emitters: the frame is bound by the cache lines fw_step streams).
     // A SOLO segment (SegHost::solo: a small type with one Global feeder) is not visited by the per-segment pass at the start of a

@@ -482,7 +482,7 @@ fw_status release_spawner_segments(fw_ctx *ctx, SpawnerHost &sp) {
         if (S.range) ctx->n_range--, ctx->r_force = true;
         if (S.few_ring) ctx->n_few--;
         if (S.spilled) ctx->n_spilled--;
-        if (S.small) ctx->n_small--, ctx->small_dirty = true;
+        if (S.small) ctx->n_small--, ctx->small_dirty = true, ctx->n_small_coll -= S.collides ? 1u : 0u;
         if (S.small_ok) ctx->n_small_ok--;
         if (S.inst) ctx->n_inst--;
         if (S.solo) ctx->n_solo--;

@@ -117,18 +117,22 @@ fw_status fifo_to_general(fw_ctx *ctx, uint32_t si) {
 
 // SegHost::small: may this compacting segment be updated by the wave-per-type kernel?
 bool small_eligible(const fw_ctx *ctx, const SegHost &S) {
-    return ctx->use_small && S.in_use && !S.ring() && !S.nested_fed && S.n_lplanes == 0 && !S.collides &&
+    // (a colliding type qualifies -- the kernel's COLL instantiation, destroy_on_collision included: the stable compaction removes a
+    // destroyed particle like one that died of age --; one whose curve keys exceed the LDS staging area does not: SegHost::bigkeys)
+    return ctx->use_small && S.in_use && !S.ring() && !S.nested_fed && S.n_lplanes == 0 && !S.bigkeys &&
            !S.colors_dirty && (S.expect_live * 2.0f <= (float)ctx->small_max || S.expect_live <= (float)ctx->wide_max);
 }
 // on the kernel / off it: a flag (the same buffers, the same layout; the tile table is re-sent)
 static void small_activate(fw_ctx *ctx, SegHost &S) {
     if (S.small) return;
     S.small = true, ctx->n_small++, ctx->small_dirty = true;
+    if (S.collides) ctx->n_small_coll++;
     ctx->tab_force = true, ctx->fc_ok = false, ctx->boxes_epoch = 0;
 }
 static void small_deactivate(fw_ctx *ctx, SegHost &S) {
     if (!S.small) return;
     S.small = false, ctx->n_small--, ctx->small_dirty = true;
+    if (S.collides) ctx->n_small_coll--;
     if (S.solo) S.solo = false, ctx->n_solo--;  // (fw_step's frame-begin pass visits it again: fw_ctx::big_list)
     ctx->big_dirty = true;
     ctx->tab_force = true, ctx->fc_ok = false, ctx->boxes_epoch = 0;

@@ -126,7 +126,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         S.frame_spawn = 0;
         if (!S.in_use) continue;
         S.dead_at_end = false;  // (set again below for the segments this frame updates as range rings)
-        any_coll |= S.collides && !S.ring();  // (a colliding type in a ring is updated by its ring kernel)
+        any_coll |= S.collides && !S.ring() && !S.small;  // (a colliding type in a ring / on the small kernel is updated by that kernel)
         // (what decides the tile size of the ring launches -- fifo_small / range_small below -- gathered while the record is hot)
         if (S.fifo) ring_stats.fifo_parts += S.ub, ring_stats.fifo_dev |= S.fifo_dev, ring_stats.fifo_coll |= S.collides, ring_stats.fifo_inst |= S.inst != nullptr;
         if (S.range) ring_stats.range_parts += S.ub, ring_stats.range_dev |= S.range_dev, ring_stats.range_coll |= S.collides, ring_stats.range_inst |= S.inst != nullptr;
@@ -537,7 +537,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // Particle types with collision settings (core.rs:607-624) run the count / scan / update-with-collisions launches
     // (everything materialised first, like FW_UPDATE_MODE=split); the streaming kernels never see a collider.
     if (ctx->seg_kind_changed)  // (a colliding ring that left its mode inside the spawner loop is a compacting segment from this frame on)
-        for (const SegHost &S : ctx->segs) any_coll |= S.in_use && S.collides && !S.ring();
+        for (const SegHost &S : ctx->segs) any_coll |= S.in_use && S.collides && !S.ring() && !S.small;
     const int frame_mode = any_coll ? FW_MODE_SPLIT_COLL : ctx->update_mode;
     const bool legacy = (n_n != 0 && !fuse) || frame_mode != FW_MODE_FUSED;  // (fuse: the Nested entries run inside the FIFO launch)
 
@@ -1245,6 +1245,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         sa.seg_op_first = spawn_form == FW_SPAWN_TABLE ? a.seg_op_first : nullptr, sa.ops = a.ops;
         sa.force_colors = a.force_colors, sa.dbg = ctx->dbg;
         sa.any_inst = ctx->n_inst != 0 ? 1u : 0u;
+        sa.any_coll = ctx->n_small_coll != 0 ? 1u : 0u;
         sa.done_tag = a.done_tag, sa.done_value = a.done_value;
         sa.host_counts = a.host_counts, sa.live_out = a.live_out, sa.live_next = a.live_next;
         if (sa.n) {

@@ -22,6 +22,7 @@
 // (one barrier per round, double-buffered), everything else as above.  One launch serves both kinds: its first workgroups take four
 // narrow types each, the rest one wide type each (a workgroup-uniform branch).
 #include "fw_dev.h"
+#include "fw_collide.h"
 #ifndef FW_SMALL_EXP  // (profiling experiments, results wrong: 1 no spawn phase -- the populations die out --, 2 no integration, 4 no statistics atomics,
                       // 8 no op / header reads, 16 spawn without random numbers and trigonometry)
 #define FW_SMALL_EXP 0
@@ -30,7 +31,10 @@
 // one particle type: by one wave (WIDE = false; `lanes` = 64) or by the four waves of a workgroup (WIDE = true; `lanes` = FW_BLOCK)
 // (INST: some type of the launch has an instance buffer attached -- fw_spawner_attach_instances: the update writes the 64-byte render
 // record of every survivor itself, at its list index, and the type's scale / colour planes are not stored: FW_TYPE_DERIVED)
-template <bool WIDE, bool INST>
+// (COLL: some type of the launch has collision settings -- core.rs:607-643: a particle that survives the age test is moved by
+// particle_collision instead of the plain Euler step, and destroyed by it when the type says destroy_on_collision; the stable
+// compaction takes a destroyed particle out like one that died of age, so ANY colliding type can live here)
+template <bool WIDE, bool INST, bool COLL>
 __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallArgs &a, uint32_t seg, float *s_keys, uint32_t (*s_cnt)[FW_BLOCK / 64],
                                               unsigned long long &entered, unsigned long long &live) {
     constexpr int NW = FW_BLOCK / 64;
@@ -48,10 +52,15 @@ __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallA
     const uint32_t sidx = a.parity * g.max_seg + seg, oidx = (a.parity ^ 1u) * g.max_seg + seg;
     const uint32_t n_cnt = g.count[sidx];
     const uint32_t n_in = min(n_cnt + g.spawned[sidx] + g.appended[sidx], C);  // loaded: the live ones + what a pass materialised
+    FwTypeColl TC{};
+    if (COLL) TC = g.type_coll[Sp->type_idx];
+    const bool coll = COLL && (TC.coll_flags & FW_COLL_ENABLED) != 0u, coll_kill = COLL && (TC.coll_flags & FW_COLL_DESTROY) != 0u;
     // a survivor's update: integrate, store its planes at slot o -- and its render record, when the type has a buffer for them
-    auto update_one = [&](float4 q0, float4 q1, float4 q2, float4 q3, float age_new, const FwType &T_, const float *keys, const FwOutWin &W_, uint32_t o) {
+    auto update_one = [&](float4 q0, float4 q1, float4 q2, float4 q3, float age_new, const FwType &T_, const float *keys, const FwOutWin &W_, uint32_t o,
+                          const fw_v3 &cpos, const fw_v3 &cvel) {
         float4 rec[4];
-        fw_integrate_store(T_, keys, a.dt, q0, q1, q2, q3, age_new, W_, o, INST ? rec : nullptr);
+        fw_integrate_store(T_, keys, a.dt, q0, q1, q2, q3, age_new, W_, o, INST ? rec : nullptr, COLL ? &cpos : nullptr, COLL ? &cvel : nullptr, nullptr,
+                           false, false, coll);
         if (INST && inst != nullptr && o < inst_cap) {
             fw_st4(inst, o * 4u + 0u, rec[0]), fw_st4(inst, o * 4u + 1u, rec[1]);
             fw_st4(inst, o * 4u + 2u, rec[2]), fw_st4(inst, o * 4u + 3u, rec[3]);
@@ -82,6 +91,32 @@ __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallA
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    // the record of a particle a collision destroyed (core.rs:633-639): new position, velocity and scale; the rest as it was
+    // (existed: it was there before this frame's spawns; in_memory: its planes can be read -- a virtual new particle has none)
+    auto store_killed = [&](uint32_t i, bool existed, bool in_memory, float4 q0, float4 q1, float4 q2, float4 q3, float age_new, const fw_v3 &cpos,
+                            const fw_v3 &cvel, uint32_t d) {
+        const float sc = q1.w * fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_new / q3.w);
+        float *rec = reinterpret_cast<float *>(destroyed) + (size_t)d * 26;
+        float4 bc, em;
+        if ((T.flags & FW_TYPE_DERIVED) && existed) {
+            float unused;
+            fw_derived_values(T, s_keys, q0.w, q3.w, q1.w, &bc, &em, &unused);
+        } else if (in_memory) {  // (materialised this frame: its slot was written in full when it was spawned)
+            bc = fw_ld4(ib + FW_OFF_Q5(C), i), em = fw_ld4(ib + FW_OFF_Q6(C), i);
+        } else {  // spawn-time colours (core.rs:457-461)
+            float b4[4], e4[4];
+            fw_gradient_sample(T.bc_kind, T.bc_n, s_keys + T.o_bc_t, s_keys + T.o_bc_v, 0.0f, b4);
+            fw_gradient_sample(T.em_kind, T.em_n, s_keys + T.o_em_t, s_keys + T.o_em_v, 0.0f, e4);
+            bc = make_float4(b4[0], b4[1], b4[2], b4[3]), em = make_float4(e4[0], e4[1], e4[2], e4[3]);
+        }
+        const float4 r2 = fw_record_rotation(T, q2);
+        rec[0] = cpos.x, rec[1] = cpos.y, rec[2] = cpos.z, rec[3] = cvel.x, rec[4] = cvel.y, rec[5] = cvel.z;
+        rec[6] = r2.x, rec[7] = r2.y, rec[8] = r2.z, rec[9] = r2.w, rec[10] = q3.x, rec[11] = q3.y, rec[12] = q3.z;
+        rec[13] = q1.w, rec[14] = sc, rec[15] = age_new, rec[16] = q3.w;
+        rec[17] = bc.x, rec[18] = bc.y, rec[19] = bc.z, rec[20] = bc.w;
+        rec[21] = em.x, rec[22] = em.y, rec[23] = em.z, rec[24] = em.w;
+        reinterpret_cast<int32_t *>(rec)[25] = T.pbr;
+    };
     uint32_t run = 0u;  // survivors stored so far = the next output slot
     uint32_t xr = 0u;   // WIDE: rounds so far (which half of the count exchange a round uses)
     // where a lane's survivor goes: behind the survivors so far, behind those of the lower waves of this round (WIDE), behind those of
@@ -124,16 +159,22 @@ __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallA
         const uint32_t i = r * LANES + lane;
         const bool valid = i < n_in;
         float age_new;
-        const bool alive = valid && fw_survives(q0.w, a.dt, q3.w, &age_new);
+        const bool young = valid && fw_survives(q0.w, a.dt, q3.w, &age_new);
+        fw_v3 cpos{q0.x, q0.y, q0.z}, cvel{q1.x, q1.y, q1.z};
+        bool killed = false;
+        if (COLL && young && coll)
+            killed = fw_particle_collision(&cpos, &cvel, a.dt, TC.coll_restitution, TC.coll_friction, coll_kill, TC.coll_mask, g.colliders, g.n_colliders);
+        const bool alive = young && !killed;
         uint32_t o;
         place(alive, &o);
         if (alive && (FW_SMALL_EXP & 2)) {
             fw_st4(W.q0, o, q0), fw_st4(W.q1, o, q1);
         } else if (alive) {
-            update_one(q0, q1, q2, q3, age_new, T, s_keys, W, o);
+            update_one(q0, q1, q2, q3, age_new, T, s_keys, W, o, cpos, cvel);
         } else if (valid && want_destroyed) {
             // (a particle a pass materialised this frame carries its spawn-time scale and colours: evaluated, not read)
-            fw_store_destroyed(destroyed, ib, C, i, i < n_cnt, T, s_keys, q0, q1, q2, q3, age_new, i - o);
+            if (!COLL || !killed) fw_store_destroyed(destroyed, ib, C, i, i < n_cnt, T, s_keys, q0, q1, q2, q3, age_new, i - o);
+            else store_killed(i, i < n_cnt, true, q0, q1, q2, q3, age_new, cpos, cvel, i - o);
         }
     }
     // ---- this frame's new particles: spawn_particles (core.rs:437-469) right before update_particles, in op order
@@ -154,14 +195,20 @@ __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallA
                                   fw_q4{op.origin_rot[0], op.origin_rot[1], op.origin_rot[2], op.origin_rot[3]},
                                   fw_v3{op.parent_vel[0], op.parent_vel[1], op.parent_vel[2]}, op.speed, op.scale);
             float age_new;
-            const bool alive = valid && fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);
+            const bool young = valid && fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);
+            fw_v3 cpos{so.q0.x, so.q0.y, so.q0.z}, cvel{so.q1.x, so.q1.y, so.q1.z};
+            bool killed = false;
+            if (COLL && young && coll)
+                killed = fw_particle_collision(&cpos, &cvel, a.dt, TC.coll_restitution, TC.coll_friction, coll_kill, TC.coll_mask, g.colliders, g.n_colliders);
+            const bool alive = young && !killed;
             uint32_t o;
             place(alive, &o);
             const uint32_t i = n_in + rel + k;  // its list index before the update
             if (alive) {
-                update_one(so.q0, so.q1, so.q2, so.q3, age_new, T, s_keys, W, o);
-            } else if (valid && want_destroyed) {  // born and destroyed in the same frame (dt >= its lifetime)
-                fw_store_destroyed(destroyed, ib, C, i, false, T, s_keys, so.q0, so.q1, so.q2, so.q3, age_new, i - o);
+                update_one(so.q0, so.q1, so.q2, so.q3, age_new, T, s_keys, W, o, cpos, cvel);
+            } else if (valid && want_destroyed) {  // born and destroyed in the same frame (dt >= its lifetime, or a collision)
+                if (!COLL || !killed) fw_store_destroyed(destroyed, ib, C, i, false, T, s_keys, so.q0, so.q1, so.q2, so.q3, age_new, i - o);
+                else store_killed(i, false, false, so.q0, so.q1, so.q2, so.q3, age_new, cpos, cvel, i - o);
             }
         }
     }
@@ -174,7 +221,7 @@ __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallA
     entered = n_tot, live = run;
 }
 
-template <bool INST>
+template <bool INST, bool COLL>
 __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_small(FwGlobals g, FwSmallArgs a) {
     constexpr int NW = FW_BLOCK / 64;
     __shared__ __attribute__((aligned(16))) float s_keys_all[NW][FW_KEYS_MAX];
@@ -190,10 +237,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_small(FwGlobals g, FwSma
     const uint32_t narrow_wg = (a.n_narrow + NW - 1u) / NW;  // the first workgroups: a narrow type per wave
     if (blockIdx.x < narrow_wg) {
         const uint32_t idx = blockIdx.x * NW + wave;
-        if (idx < a.n_narrow) fw_small_type<false, INST>(g, a, a.list[idx], s_keys_all[wave], s_cnt, entered, live);
+        if (idx < a.n_narrow) fw_small_type<false, INST, COLL>(g, a, a.list[idx], s_keys_all[wave], s_cnt, entered, live);
     } else {  // ... then a wide type per workgroup
         unsigned long long e = 0ull, l = 0ull;
-        fw_small_type<true, INST>(g, a, a.list[a.n_narrow + (blockIdx.x - narrow_wg)], s_keys_all[0], s_cnt, e, l);
+        fw_small_type<true, INST, COLL>(g, a, a.list[a.n_narrow + (blockIdx.x - narrow_wg)], s_keys_all[0], s_cnt, e, l);
         if (wave == 0u) entered = e, live = l;  // (every wave leaves with the type's totals: counted once)
     }
     // statistics and the frame's live total: one atomic each per WORKGROUP (thousands on one word serialise at the memory side)
@@ -214,7 +261,9 @@ hipError_t fw_launch_update_small(hipStream_t s, const FwGlobals &g, const FwSma
     if (!a.n) return hipSuccess;
     const uint32_t nw = FW_BLOCK / 64;
     const dim3 grid((a.n_narrow + nw - 1) / nw + (a.n - a.n_narrow)), block(FW_BLOCK);
-    if (a.any_inst) FW_LAUNCH_T(fw_k_update_small<true>, grid, block, s, e0, e1, g, a);
-    else FW_LAUNCH_T(fw_k_update_small<false>, grid, block, s, e0, e1, g, a);
+    if (a.any_coll && a.any_inst) FW_LAUNCH_T((fw_k_update_small<true, true>), grid, block, s, e0, e1, g, a);
+    else if (a.any_coll) FW_LAUNCH_T((fw_k_update_small<false, true>), grid, block, s, e0, e1, g, a);
+    else if (a.any_inst) FW_LAUNCH_T((fw_k_update_small<true, false>), grid, block, s, e0, e1, g, a);
+    else FW_LAUNCH_T((fw_k_update_small<false, false>), grid, block, s, e0, e1, g, a);
     return hipGetLastError();
 }

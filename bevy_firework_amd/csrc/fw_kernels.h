@@ -301,6 +301,7 @@ struct FwSmallArgs {
                                    // (up to a few thousand particles: a workgroup each)
     uint32_t n, n_narrow, parity, epoch;
     uint32_t any_inst;             // some type of the launch has an instance buffer attached (FwSeg::inst): the INST instantiation
+    uint32_t any_coll;             // ... collision settings (FwTypeColl): the COLL instantiation
     float dt;
     const uint4 *seg_op_first;     // as FwUpdateArgs (table form: pinned host memory), or null: no virtual spawns this frame
     const FwOp *ops;

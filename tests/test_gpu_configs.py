@@ -333,8 +333,8 @@ def _run_collision_example(monkeypatch, general, spawner, tf, world, frames, che
     monkeypatch.setenv("FW_ENABLE_KNOBS", "1")
     for k in ("FW_FIFO", "FW_FIFO_MIN", "FW_RANGE", "FW_RANGE_MIN"):
         monkeypatch.delenv(k, raising=False)
-    if general:
-        monkeypatch.setenv("FW_FIFO", "0"), monkeypatch.setenv("FW_RANGE", "0")
+    if general:  # (... and not on the wave- / workgroup-per-type kernel either, whose COLL instantiation takes colliding types too)
+        monkeypatch.setenv("FW_FIFO", "0"), monkeypatch.setenv("FW_RANGE", "0"), monkeypatch.setenv("FW_SMALL", "0")
     with ParticleSystem(device=0, seed=SEED) as system:
         system.set_colliders(world)
         pair = Pair(system, spawner, tf, seed=SEED, uid=0)

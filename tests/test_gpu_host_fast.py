@@ -44,14 +44,15 @@ def _world(system, n_solo):
     return pairs
 
 
-def _run(system, pairs, n, what, every=10, dt=DT):
+def _run(system, pairs, n, what, every=10, dt=DT, loose=()):
+    """(`loose`: pairs whose spawn uses trigonometry -- cones, circles: their vector fields within the tolerance of tests/parity.py)"""
     for fr in range(n):
         system.update(dt)
         for p in pairs:
             p.step_cpu(dt)
         if fr % every == every - 1 or fr == n - 1:
             for k, p in enumerate(pairs):
-                p.check(exact_all=True, what=f"{what}, frame {fr}, spawner {k}")
+                p.check(exact_all=not any(p is q for q in loose), what=f"{what}, frame {fr}, spawner {k}")
 
 
 def _scenario(system, digest=None):
@@ -174,3 +175,38 @@ def test_small_types_write_their_render_records(monkeypatch):
         for k in chosen[:4]:
             pairs[k].gpu.attach_instances(0, 0, particle_type=0)
         _run(system, pairs, 10, "some detached", every=10)
+
+
+def test_colliding_small_types_among_hundreds(monkeypatch):
+    """a few colliding emitters (examples/collision.rs: bouncing, and the same with destroy_on_collision) among 360 small ones: they run
+    on the COLL instantiation of the small kernel -- a frame stays ONE launch for everybody (one such type used to send the whole
+    context through the materialise -> count -> scan -> update passes: 16.7 -> 49 us per frame at 512 emitters,
+    profiles/r05/coll_cliff_*.txt) --; particles and destroyed records against the oracle"""
+    import copy
+    from bevy_firework_amd.system import ParticleSystem
+    from parity import assert_particles_match
+
+    _product_defaults(monkeypatch)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        pairs = _world(system, 360)
+        sp, tf, world = workloads.example_collision()
+        system.set_colliders(world)
+        colliding = []
+        for k in range(4):
+            spk = copy.deepcopy(sp)
+            cs = spk.particle_settings[0].collision_settings
+            spk.particle_settings[0].collision_settings = S.ParticleCollisionSettings(cs.restitution, cs.friction, k >= 2, cs.filter_mask)
+            spk.particle_settings[0].particles_destroyed = lambda recs: None
+            spk.emission_settings[0].emission_pacing = S.EmissionPacing.rate(100.0 + 20.0 * k)
+            p = Pair(system, spk, S.Transform((tf.translation[0] + 0.3 * k, tf.translation[1], tf.translation[2]), tf.rotation), seed=SEED, uid=8000 + k)
+            p.cpu.set_colliders(world)
+            colliding.append(p)
+        pairs += colliding
+        assert {p.gpu.update_path(0)[0] for p in pairs} == {"small"}
+        for rep in range(6):
+            _run(system, pairs, 30, "colliding types on the small kernel", every=30, loose=colliding)
+            for p in colliding:
+                assert_particles_match(p.gpu.destroyed(0), p.cpu.destroyed(0), False, f"destroyed records of a colliding type, round {rep}")
+        # (the bouncing ones have met the slab by now; the destroy-on-collision ones have lost particles to it)
+        assert colliding[2].gpu.count(0) < colliding[0].gpu.count(0)
+        assert {p.gpu.update_path(0)[0] for p in pairs} == {"small"}
