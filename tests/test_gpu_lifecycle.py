@@ -158,6 +158,8 @@ def scenario_small_mode(w):
     they are), and back below three quarters of that"""
     for _ in range(int(w.rng.integers(1, 4))):
         w.add("tiny")
+    if w.rng.random() < 0.5:  # (a spawner with a Nested entry: its frames run the separate spawn / nest passes -- the small types of such a
+        w.add("nested_small")  # frame find their new particles materialised instead of spawning them themselves)
     w.step(int(w.rng.integers(5, 15)))
     w.check("few")
     while w.segments() <= RANGE_FEW:
