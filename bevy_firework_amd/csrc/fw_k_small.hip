@@ -21,6 +21,11 @@
 // look-back -> update -- is walked the same way by a WORKGROUP: rounds of 256 lanes, the waves' survivor counts exchanged through LDS
 // (one barrier per round, double-buffered), everything else as above.  One launch serves both kinds: its first workgroups take four
 // narrow types each, the rest one wide type each (a workgroup-uniform branch).
+//
+// Instantiations <INST, COLL>: INST writes the 64-byte render record of every survivor into the type's attached instance buffer
+// (render.rs:95-115; the scale / colour planes are then not stored: FW_TYPE_DERIVED); COLL runs particle_collision (core.rs:607-643) on
+// every particle that passed the age test, destroy_on_collision included.  The host picks the instantiation per launch from what the
+// context's small types need (FwSmallArgs::any_inst / any_coll): the plain one keeps its 120 registers.
 #include "fw_dev.h"
 #include "fw_collide.h"
 #ifndef FW_SMALL_EXP  // (profiling experiments, results wrong: 1 no spawn phase -- the populations die out --, 2 no integration, 4 no statistics atomics,
