@@ -619,11 +619,26 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     FwInlineOps inl;
     int spawn_form = FW_SPAWN_NONE;
     int slot = -1;
+    // the op table of the small launch (fw_k_update_small): the frame's table in Global-only frames, one of its own in frames that
+    // run the separate passes
+    const uint4 *small_hdr = nullptr;
+    const FwOp *small_ops = nullptr;
     prof(4);
 
     if (legacy) {
         // Frames with Nested entries: parents spawned earlier in the frame must exist in memory before the
         // per-parent pass reads them (core.rs:488), so Global ops are materialised by fw_k_spawn, level by level.
+        // Not those of SMALL types (round 5): no Nested entry reads them, their kernel spawns them itself (virtual particles) from a
+        // table as in any other frame -- one spawner with a Nested entry among hundreds of small emitters used to send every op of
+        // the context through fw_k_spawn and its staged table: 512 small emitters 16.7 us per frame, with examples/textures.rs next
+        // to them 56.3 (profiles/r05/nested_among_small.txt).
+        const bool small_virtual = ctx->n_small != 0 && ctx->ops_zerocopy && ctx->host_fast;
+        auto stays_virtual = [&](const FwOp &op) { return small_virtual && ctx->segs[op.seg].small; };
+        size_t n_virtual = 0;
+        if (small_virtual)
+            for (auto &L : levels)
+                for (const FwOp &op : L.g) n_virtual += stays_virtual(op) ? 1u : 0u;
+        n_g -= n_virtual;
         const size_t off_nops = n_g * sizeof(FwOp);
         const size_t bytes = off_nops + n_n * sizeof(FwNestOp) + 16;
         if ((st = ensure_ring(bytes))) return st;
@@ -648,6 +663,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         };
         for (auto &L : levels) {
             for (FwOp op : L.g) {
+                if (stays_virtual(op)) continue;
                 op.first_block = pend_blocks;
                 pend_blocks += (op.n + FW_BLOCK - 1) / FW_BLOCK;
                 h_ops[gi++] = op;
@@ -704,6 +720,50 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             }
         }
         if (!staged) slot = -1;  // nothing in the ring slot is read by the device: no consumed-event needed
+        if (n_virtual) {
+            // ---- the table of the small launch: {first op, one past the last, particles} per segment, then the ops
+            const size_t off_ops = (size_t)n_seg * sizeof(OpHdr);
+            bool others = false;  // small types' ops at an emission level other than the first
+            for (size_t li = 1; li < levels.size(); li++)
+                for (const FwOp &op : levels[li].g) others |= stays_virtual(op);
+            OpList &g0 = levels[0].g;
+            int tslot = -1;
+            char *hp = nullptr;
+            if (pre_slot >= 0 && g0.lent && !others && pre_hdr_ok && pre_tracked == g0.size()) {
+                // the list of the first level lives in the slot taken before the spawner loop, headers and all: the ops of the other
+                // types next to the small ones' are simply not looked at (fw_k_update_small reads its segments' headers only)
+                tslot = pre_slot, hp = ctx->h_param[tslot];
+            } else {
+                OpList &ops = ctx->ops_scratch;
+                ops.clear();
+                ops.reserve_own(n_virtual);
+                for (auto &L : levels)
+                    for (const FwOp &op : L.g)
+                        if (stays_virtual(op)) ops.push_back(op);
+                if (!std::is_sorted(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; }))
+                    std::stable_sort(ops.begin(), ops.end(), [](const FwOp &x, const FwOp &y) { return x.seg < y.seg; });
+                const size_t tbytes = off_ops + ops.size() * sizeof(FwOp);
+                if ((st = ensure_ring(tbytes))) return st;
+                if ((st = acquire_slot(&tslot))) return st;
+                const bool bar = ctx->param_bar && tbytes <= kBarParamBytes;
+                hp = bar ? ctx->b_param[tslot] : ctx->h_param[tslot];
+                OpHdr *hdr = (OpHdr *)hp;
+                size_t oi = 0;
+                for (uint32_t sgi = 0; sgi < n_seg; sgi++) {  // (ops are sorted by segment)
+                    const size_t b = oi;
+                    uint64_t n = 0;
+                    while (oi < ops.size() && ops[oi].seg == sgi) n += ops[oi].n, oi++;
+                    hdr[sgi] = OpHdr{(uint32_t)b, (uint32_t)oi, (uint32_t)std::min<uint64_t>(n, 0xFFFFFFFFull), 0u};
+                }
+                memcpy(hp + off_ops, ops.data(), ops.size() * sizeof(FwOp));
+                if (bar) {
+                    _mm_sfence();
+                    (void)*(volatile const uint32_t *)hp;
+                }
+            }
+            small_hdr = (const uint4 *)hp, small_ops = (const FwOp *)(hp + off_ops);
+            ctx->slot_frame[tslot] = ctx->frame + 1;  // (read in place: free once a launch after this frame has started)
+        }
     } else {
         // Global-only frame: spawn is fused into the update kernel (virtual particles).  Ops sorted by segment;
         // the order inside a segment stays the emission order (rel_base was assigned in that order).
@@ -772,6 +832,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 a.seg_op_first = (const uint4 *)dp;
                 a.ops = (const FwOp *)(dp + off_ops);
             }
+            small_hdr = a.seg_op_first, small_ops = a.ops;
         }
     }
     if (ctx->h_done) a.done_tag = ctx->h_done, a.done_value = ctx->frame;
@@ -1242,7 +1303,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         }
         FwSmallArgs sa{};
         sa.list = ctx->d_small, sa.n = (uint32_t)ctx->small_list.size(), sa.n_narrow = ctx->n_narrow, sa.parity = p, sa.epoch = a.epoch, sa.dt = dt;
-        sa.seg_op_first = spawn_form == FW_SPAWN_TABLE ? a.seg_op_first : nullptr, sa.ops = a.ops;
+        sa.seg_op_first = small_hdr, sa.ops = small_ops;
         sa.force_colors = a.force_colors, sa.dbg = ctx->dbg;
         sa.any_inst = ctx->n_inst != 0 ? 1u : 0u;
         sa.any_coll = ctx->n_small_coll != 0 ? 1u : 0u;

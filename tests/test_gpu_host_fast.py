@@ -210,3 +210,29 @@ def test_colliding_small_types_among_hundreds(monkeypatch):
         # (the bouncing ones have met the slab by now; the destroy-on-collision ones have lost particles to it)
         assert colliding[2].gpu.count(0) < colliding[0].gpu.count(0)
         assert {p.gpu.update_path(0)[0] for p in pairs} == {"small"}
+
+
+def test_small_types_next_to_a_nested_spawner(monkeypatch):
+    """a spawner with a Nested entry (examples/textures.rs) among 360 small emitters: its frames run the separate spawn / nest passes,
+    the small types keep spawning their own particles (virtual, from a table of their own) -- everything against the oracle; half way
+    the slots are shuffled, so the table is no longer the list that was written in place"""
+    from bevy_firework_amd.system import ParticleSystem
+
+    _product_defaults(monkeypatch)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        pairs = _world(system, 360)
+        sp, tf, world = workloads.example_textures()
+        system.set_colliders(world)
+        nested = Pair(system, sp, tf, seed=SEED, uid=8100)
+        nested.cpu.set_colliders(world)
+        pairs.append(nested)
+        _run(system, pairs, 40, "next to a Nested spawner", every=20, loose=[nested])
+        assert system.nest_frames()[1] > 30  # (the separate passes ran)
+        assert {p.gpu.update_mode(0) for p in pairs[:-3]} == {3}
+        for k in (40, 3):
+            system.despawn(pairs[k].gpu)
+            del pairs[k]
+        pairs.insert(0, Pair(system, _emitter(450.0, 0.2, 1, types=2, fed=1), S.Transform((0.5, 0.0, 0.0)), seed=SEED, uid=6000))
+        pairs.insert(1, Pair(system, _emitter(520.0, 0.2, 2, entries=2), S.Transform((0.0, 0.5, 0.0)), seed=SEED, uid=6001))
+        _run(system, pairs, 40, "slots shuffled, next to a Nested spawner", every=20, loose=[nested])
+        assert nested.gpu.count(1) > 0
