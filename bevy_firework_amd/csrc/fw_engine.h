@@ -675,6 +675,15 @@ struct fw_ctx {
     uint32_t n_small_ok = 0;
     uint32_t n_inst = 0;     // segments with an instance buffer attached (SegHost::inst): which instantiation the small launch runs
     uint32_t n_small_coll = 0;  // types on the kernel that have collision settings: its COLL instantiation
+    // In frames that run the collision passes (materialise -> count -> scan -> update: four dependent launches on the main stream, 49 us
+    // for a destroy_on_collision type of 20 000 particles) the small launch -- which touches nothing those passes touch -- runs next to
+    // them on the ring stream (fifo_stream): 512 / 2048 small emitters next to such a type 66.9 / 84.3 -> 53.1 / 67.3 us per frame
+    // (profiles/r05/nested_among_small_side.txt).  Not in frames whose separate passes are a Nested entry's only: those are bound by the
+    // host's launches, and the extra event costs more than the overlap gives (44.4 -> 48.0).  Under the rules of a ring launch there:
+    // own stream only, no live-count ring, no colliding small type (a new collider set travels in the main stream), not in a frame that
+    // re-sends the list (a type left the mode: the compacting launch of this very frame updates it).
+    // Its op table is then recycled by an event on that stream, not by the main stream's "frame started" word.
+    bool small_last_side = false;
     bool small_on = false;
     // ... and the host half of their frames (thousands of emitters: the frame is bound by the cache lines fw_step streams).
     // A SOLO segment (SegHost::solo: a small type with one Global feeder) is not visited by the per-segment pass at the start of a

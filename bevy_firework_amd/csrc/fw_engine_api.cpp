@@ -698,7 +698,7 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
     const SegHost &S = ctx->segs[si];
     const uint32_t ub = (uint32_t)std::min<uint64_t>(S.nested_fed ? S.capacity : std::min(S.ub, S.capacity), cap);
     if (n_upper_bound) *n_upper_bound = ub;
-    if (S.fifo) {
+    if (S.fifo || S.small) {  // (whose launches may run on the ring stream)
         fw_status jst = join_side(ctx);
         if (jst) return jst;
     }

@@ -623,6 +623,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // run the separate passes
     const uint4 *small_hdr = nullptr;
     const FwOp *small_ops = nullptr;
+    int small_tslot = -1;  // ... the parameter slot it lives in, in the latter case
     prof(4);
 
     if (legacy) {
@@ -762,7 +763,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 }
             }
             small_hdr = (const uint4 *)hp, small_ops = (const FwOp *)(hp + off_ops);
-            ctx->slot_frame[tslot] = ctx->frame + 1;  // (read in place: free once a launch after this frame has started)
+            small_tslot = tslot;  // (read in place: recycled where the small launch is enqueued, below)
         }
     } else {
         // Global-only frame: spawn is fused into the update kernel (virtual particles).  Ops sorted by segment;
@@ -1284,6 +1285,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     // ---- small types: one wave each (fw_k_small.hip)
     bool small_launched = false;
     if (ctx->n_small) {
+        const bool list_resent = ctx->small_dirty;
         if (ctx->small_dirty) {  // the list changed (a spawner built or destroyed, a type that outgrew the mode): re-sent through the stream
             ctx->small_list.clear();
             for (int wide = 0; wide < 2; wide++) {  // narrow types first, then the wide ones (FwSmallArgs::n_narrow)
@@ -1309,10 +1311,34 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         sa.any_coll = ctx->n_small_coll != 0 ? 1u : 0u;
         sa.done_tag = a.done_tag, sa.done_value = a.done_value;
         sa.host_counts = a.host_counts, sa.live_out = a.live_out, sa.live_next = a.live_next;
+        // next to the collision passes of the frame, on the ring stream (fw_ctx::small_last_side)
+        const bool small_side = legacy && frame_mode != FW_MODE_FUSED && sa.n != 0 && ctx->host_fast && ctx->use_fifo_stream && ctx->own_stream && ctx->live_ring == nullptr &&
+                                ctx->n_small_coll == 0 && !list_resent;
         if (sa.n) {
+            if (small_side && (!ctx->small_last_side || ctx->main_reads_ring)) {
+                // the previous small launch, or a reader of its types' data, sits on the main stream: this launch comes after it
+                FW_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+                FW_HIP(ctx, hipStreamWaitEvent(ctx->fifo_stream, ctx->ev_main, 0));
+                ctx->main_reads_ring = false;
+            } else if (!small_side && ctx->small_last_side && ctx->side_dirty) {
+                FW_HIP(ctx, hipEventRecord(ctx->ev_side, ctx->fifo_stream));
+                FW_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+                ctx->side_dirty = false;
+            }
+            ctx->small_last_side = small_side;
+            if (small_side) sa.done_tag = nullptr;  // (the "frame has started" word recycles buffers the MAIN stream's launches read)
             hipEvent_t e0, e1;
             next_timing_pair(&e0, &e1);
-            FW_HIP(ctx, fw_launch_update_small(ctx->stream, ctx->g, sa, e0, e1));
+            FW_HIP(ctx, fw_launch_update_small(small_side ? ctx->fifo_stream : ctx->stream, ctx->g, sa, e0, e1));
+            if (small_side) ctx->side_dirty = true;
+            if (small_tslot >= 0) {
+                if (small_side) {
+                    FW_HIP(ctx, hipEventRecord(ctx->ev_consumed[small_tslot], ctx->fifo_stream));
+                    ctx->consumed_pending[small_tslot] = true;
+                } else {
+                    ctx->slot_frame[small_tslot] = ctx->frame + 1;  // free once a launch after this frame has started
+                }
+            }
             small_launched = true;
         }
     }

@@ -236,3 +236,33 @@ def test_small_types_next_to_a_nested_spawner(monkeypatch):
         pairs.insert(1, Pair(system, _emitter(520.0, 0.2, 2, entries=2), S.Transform((0.0, 0.5, 0.0)), seed=SEED, uid=6001))
         _run(system, pairs, 40, "slots shuffled, next to a Nested spawner", every=20, loose=[nested])
         assert nested.gpu.count(1) > 0
+
+
+def test_small_types_next_to_a_large_destroy_on_collision_type(monkeypatch):
+    """a destroy_on_collision type of ~20 000 particles (neither a ring nor small: the materialise -> count -> scan -> update passes)
+    among 360 small emitters: the small launch runs next to those passes on the ring stream, from a table of its own that an event on
+    that stream recycles; types leave the wave for a workgroup on the way (the list is re-sent: that frame runs on the main stream);
+    an instance buffer is packed from a small type between frames (a reader on the main stream).  Everything against the oracle."""
+    import copy
+    import torch
+    from bevy_firework_amd.system import ParticleSystem
+
+    _product_defaults(monkeypatch)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        sp, tf, world = workloads.example_collision()
+        big = copy.deepcopy(sp)
+        cs = big.particle_settings[0].collision_settings
+        big.particle_settings[0].collision_settings = S.ParticleCollisionSettings(cs.restitution, cs.friction, True, cs.filter_mask)
+        big.emission_settings[0].emission_pacing = S.EmissionPacing.rate(20000.0)
+        system.set_colliders(world)
+        bigp = Pair(system, big, tf, seed=SEED, uid=8200)
+        bigp.cpu.set_colliders(world)
+        pairs = [bigp] + _world(system, 360)
+        assert bigp.gpu.update_path(0)[0] == "general"
+        buf = torch.empty(4096 * 16, dtype=torch.float32, device="cuda")
+        for rep in range(5):
+            _run(system, pairs, 16, "next to the collision passes", every=16, loose=[bigp])
+            n = pairs[7].gpu.count(0)
+            got = pairs[7].gpu.instances(0)  # (packed on the main stream from a type the ring stream's launch updates)
+            assert len(got) == n and n > 0
+        assert bigp.gpu.count(0) > 5000 and {p.gpu.update_mode(0) for p in pairs[1:]} == {3, 4}
