@@ -396,8 +396,9 @@ struct alignas(64) SegHost {
     uint32_t rold_seen = 0;     // the old part's size as of the last exact read (refresh_counts_exact): FwGlobals::rold
     uint32_t r_young_main = 0;  // range_dev: young tiles the current table keeps in front (the rest: probably idle, at its end)
     bool ring() const { return fifo || range; }  // one buffer, particle 0 not in slot 0
-    // FW_TYPE_DERIVED (fw_device.h): an instance buffer is attached -- its records carry scale and colours, the planes S4 / Q5 /
-    // Q6 are not stored by the update; every reader evaluates them from age / lifetime / initial_scale
+    // FW_TYPE_DERIVED (fw_device.h): the planes S4 / Q5 / Q6 are not stored by the update; every reader evaluates scale and
+    // colours from age / lifetime / initial_scale (an attached instance buffer receives them in its records).  Every type but
+    // colliding ones and those whose curve keys exceed the LDS staging (fw_ctx::derive_all, wants_derived)
     bool derived = false;
     // ... but not yet: the caller wrote particles (any scale, any colours), and those that die in the very next step carry
     // what was written in their destroyed records -- the planes are read for one more frame, then the mode starts
@@ -627,7 +628,13 @@ struct fw_ctx {
     bool use_fifo = true;      // FW_FIFO=0: constant-lifetime types take the general (compacting) path too (A/B, tests)
     bool fifo_nested = true;   // FW_FIFO_NESTED=0: ... those of spawners with Nested entries do (A/B)
     bool use_nospin = true;    // FW_NOSPIN=0: every type keeps its rotation plane (A/B)
-    bool use_derived = true;   // FW_DERIVED=0: types with an attached instance buffer keep storing scale / colour planes (A/B)
+    bool use_derived = true;   // FW_DERIVED=0: every type stores its scale / colour planes, attached instance buffer or not (A/B)
+    // Round 6: scale, base colour and emissive colour are pure functions of (age, lifetime, initial_scale) (core.rs:601-605,
+    // 652-655) -- the update of EVERY type whose curves fit the LDS staging stops storing them (36 of the 100 B a configs[2]
+    // particle moved), not only of types with an attached instance buffer: the renderer extracts visible spawners only
+    // (render.rs:382-403), the planes were written for nobody in every other frame.  FW_DERIVED=1: only with a buffer attached
+    // (rounds 3-5; a share of the test functions keeps that form under the suite).
+    bool derive_all = true;
     // Smallest (derived or given) capacity that makes a type a FIFO ring (FW_FIFO_MIN; the tests set 0).  Below a few
     // tens of thousands of particles a frame is launch latency whatever the path.  Next to compacting segments the ring
     // launch runs on its own stream (fifo_stream) and wins at any size (tools/fifo_threshold.py, tools/mixed_context.py);
@@ -889,6 +896,11 @@ fw_status fifo_to_range(fw_ctx *ctx, uint32_t si);
 fw_status spill_fifo_rings(fw_ctx *ctx);
 fw_status leave_nospin(fw_ctx *ctx, uint32_t si);
 fw_status set_derived(fw_ctx *ctx, uint32_t si, bool on, bool refill = true);
+// does the type's update leave scale and colours to its readers?  (colliding types -- and `bigkeys` ones, which run on their
+// kernels -- stay as they are: the feature path reads the stored planes)
+static inline bool wants_derived(const fw_ctx *ctx, const SegHost &S) {
+    return ctx->use_derived && !S.collides && (ctx->derive_all || S.inst != nullptr);
+}
 fw_status grow_nested_children(fw_ctx *ctx, SpawnerHost &sp, uint32_t parent_type, int depth = 0);
 void copy_curve(CurveCopy &dst, int32_t kind, int32_t n, const float *times, const float *values, int stride);
 fw_status validate_desc(fw_ctx *ctx, const fw_spawner_desc *d);

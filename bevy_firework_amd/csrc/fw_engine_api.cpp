@@ -138,6 +138,8 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_RANGE_SMALL")) ctx->range_small_tiles = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_RANGE_YOUNG_BIG")) ctx->range_young_big = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_NOSPIN")) ctx->use_nospin = atoi(m) != 0;
+    // 0: scale / colour planes always stored; 1: not stored for types with an attached instance buffer; 2 (default): for no type
+    if (const char *m = getenv("FW_DERIVED")) ctx->use_derived = atoi(m) != 0, ctx->derive_all = atoi(m) >= 2;
     if (const char *m = getenv("FW_NEST_FUSE")) ctx->nest_fuse = atoi(m) != 0;
     if (const char *m = getenv("FW_SMALL")) ctx->use_small = atoi(m) != 0;
     if (const char *m = getenv("FW_SMALL_MAX")) ctx->small_max = (uint32_t)strtoul(m, nullptr, 10);
@@ -156,7 +158,6 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     // -- the experiment surface: only in the `make ab` build (libfirework_hip_ab.so; the tools load it through FW_LIB_PATH)
     if (const char *m = getenv("FW_DEBUG")) ctx->dbg = (uint32_t)atoi(m);
     if (const char *m = getenv("FW_FIFO_NESTED")) ctx->fifo_nested = atoi(m) != 0;
-    if (const char *m = getenv("FW_DERIVED")) ctx->use_derived = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_IDLE_LAST")) ctx->range_idle_last = atoi(m) != 0;
     if (const char *m = getenv("FW_RANGE_SPREAD_NEW")) ctx->range_spread_new = atoi(m) != 0;
     if (const char *m = getenv("FW_AABB")) ctx->track_aabb = atoi(m) != 0;  // same as fw_ctx_track_aabbs(ctx, 1)
@@ -625,7 +626,7 @@ fw_status fw_spawner_write_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, c
     // ... and scales and colours: the planes are stored and read again until every particle has been through an update
     // (an attached buffer keeps receiving records; the mode comes back after the next step)
     if ((st = set_derived(ctx, si, false, false))) return st;
-    ctx->segs[si].derive_pending = ctx->segs[si].inst != nullptr && ctx->use_derived && !ctx->segs[si].collides;
+    ctx->segs[si].derive_pending = wants_derived(ctx, ctx->segs[si]);
     if (n > ctx->segs[si].capacity) {
         ctx->segs[si].ub = 0;
         const uint32_t zero = 0;
@@ -734,7 +735,7 @@ static fw_status attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void
     // the records carry scale and colours from now on: the update stops storing the three planes that would duplicate them
     // (every reader of those planes evaluates them instead, so a buffer smaller than the live count loses nothing either);
     // colliding types stay as they are (the feature path)
-    const bool derive = d_out != nullptr && ctx->use_derived && !S.collides;
+    const bool derive = wants_derived(ctx, S);
     S.derive_pending = derive && S.colors_dirty;  // (particles written by the caller, not updated yet: one frame later)
     if ((st = set_derived(ctx, sp->seg[type], derive && !S.colors_dirty))) return st;
     return upload_seg(ctx, sp->seg[type]);

@@ -242,6 +242,10 @@ fw_status build_spawner(fw_ctx *ctx, int h, const fw_spawner_desc *d, const std:
         ctx->n_in_use++, ctx->big_dirty = true;
         S.keys_off = dt.keys_off, S.keys_len = dt.keys_len, S.keys_cap = kwin_cap, S.bigkeys = bigkeys;
         S.nospin = nospin, S.n_xplanes = nospin ? 1u : 0u;
+        // scale and colours are left to the readers from the first frame on (fw_ctx::derive_all; wants_derived: not for a type that
+        // runs on the collision kernels)
+        S.derived = ctx->use_derived && ctx->derive_all && !(p.collision.enabled != 0 || bigkeys);
+        if (S.derived) dt.flags |= FW_TYPE_DERIVED;
         memcpy(S.const_rot, dt.const_rot, sizeof S.const_rot);
         sp.seg[t] = si;
         FW_HIP(ctx, hipMemcpy(ctx->d_keys.d + dt.keys_off, keys.data(), keys.size() * sizeof(float),

@@ -101,7 +101,12 @@ uint32_t seg_tiles(const SegHost &s, uint32_t vt_rounds) {
         const uint64_t live_ub = std::min(s.ub - std::min(s.ub, s.frame_spawn), s.capacity);
         return std::max<uint32_t>(1, (uint32_t)((live_ub + s.frame_spawn + FW_TILE - 1) / FW_TILE));
     }
-    return std::max<uint32_t>(1, seg_live_tiles(s) + (s.frame_spawn + vtile - 1) / vtile + 1);
+    // (new particles beyond the capacity are dropped by the kernels -- spawn_room -- and need no tiles: a burst of 30 000 queued
+    // particles into a type with 4096 caller-given slots used to ask for 118 new-particle tiles, more than the tile scratch of the
+    // context -- ensure_tile_arrays, sized from the capacities -- holds: the entries of tiles beyond it were written out of bounds
+    // (round 6: found as `check 2` under GPU contention, tools/r06_burst_repro.py))
+    const uint32_t spawn_eff = std::min(s.frame_spawn, s.capacity);
+    return std::max<uint32_t>(1, seg_live_tiles(s) + (spawn_eff + vtile - 1) / vtile + 1);
 }
 
 // (size of the new-particle tiles of a frame, update_tile_table: the smallest -- most parallel -- of 1 or 2 rounds for
@@ -112,7 +117,9 @@ uint32_t seg_tiles(const SegHost &s, uint32_t vt_rounds) {
 fw_status ensure_tile_arrays(fw_ctx *ctx) {
     size_t tiles = 0, nest_tiles = 0, nest_ops = 0;
     for (auto &s : ctx->segs)
-        if (s.in_use && !s.ring()) tiles += (s.capacity + FW_VTILE - 1) / FW_VTILE + 2;  // worst case: every slot a new particle
+        // (worst case: every slot a new particle -- in one-round tiles -- behind a full buffer of live ones that all die: the bound of
+        // update_tile_table's cap_tiles, whatever the frame asks for)
+        if (s.in_use && !s.ring()) tiles += (s.capacity + FW_TILE - 1) / FW_TILE + (s.capacity + FW_VTILE - 1) / FW_VTILE + 3;
     for (auto &sp : ctx->spawners) {
         if (!sp.alive) continue;
         for (auto &e : sp.em)

@@ -360,8 +360,9 @@ fw_status update_tile_table(fw_ctx *ctx) {
         const SegHost &S = ctx->segs[i];
         if (S.in_use && !S.ring() && !S.small) {
             const uint32_t live = seg_live_tiles(S);
-            act1 += live + (S.frame_spawn + FW_VTILE - 1) / FW_VTILE;
-            act2 += live + (S.frame_spawn + 2 * FW_VTILE - 1) / (2 * FW_VTILE);
+            const uint32_t spawn_eff = std::min(S.frame_spawn, S.capacity);  // (what exceeds the capacity is dropped: seg_tiles)
+            act1 += live + (spawn_eff + FW_VTILE - 1) / FW_VTILE;
+            act2 += live + (spawn_eff + 2 * FW_VTILE - 1) / (2 * FW_VTILE);
         }
         // provision for one-round new-particle tiles whatever vt_rounds says: a lone segment picks its tile size on
         // the device from exact counts and may use the smaller tiles when the host, with looser bounds, would not
@@ -372,7 +373,7 @@ fw_status update_tile_table(fw_ctx *ctx) {
             continue;
         }
         const uint32_t cap_tiles =
-            (S.capacity + FW_TILE - 1) / FW_TILE + (S.frame_spawn + FW_VTILE - 1) / FW_VTILE + 1;
+            (S.capacity + FW_TILE - 1) / FW_TILE + (std::min(S.frame_spawn, S.capacity) + FW_VTILE - 1) / FW_VTILE + 1;
         // slack: an eighth for large segments; a small segment (thousands of small emitters) gets one spare tile --
         // idle workgroups are cheap one by one, but two per segment doubled such a grid
         if (need > have || have > need + need / 4 + (need >= 16 ? 8u : 2u) || have > cap_tiles) {

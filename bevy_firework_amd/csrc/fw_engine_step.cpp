@@ -32,7 +32,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             SegHost &S = ctx->segs[i];
             if (!S.in_use || !S.derive_ready) continue;
             S.derive_ready = false;
-            if (S.inst == nullptr || S.colors_dirty || S.collides || !ctx->use_derived) continue;  // (detached / rewritten since)
+            if (S.colors_dirty || !wants_derived(ctx, S)) continue;  // (detached / rewritten since)
             const fw_status dst = set_derived(ctx, i, true);
             if (dst) return dst;
         }
@@ -526,6 +526,9 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
     prof(2);
     if (st) return rollback(st);
     const uint32_t total_tiles = ctx->total_tiles_dev;
+    // (every per-tile array of the context -- status words, forecast entries, tile boxes -- holds tiles_cap entries: a table that
+    // asks for more is a bookkeeping error, and nothing of the frame has been enqueued yet)
+    if (total_tiles > ctx->tiles_cap) return rollback(fail(ctx, FW_EHIP, "internal error: the tile table exceeds the tile scratch (frame not enqueued)"));
 
     size_t n_g = 0, n_n = 0;
     for (auto &L : levels) n_g += L.g.size(), n_n += L.n.size();
@@ -603,6 +606,11 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         if (usable) a.fc_in = ctx->d_fc + (size_t)((ctx->fc_seq + 2u) % 3u) * ctx->fc_len;
         ctx->fc_seq++;
         ctx->fc_sums_prev = a.fc_sums;
+        if (ctx->trace)
+            fprintf(stderr, "[fw] frame %llu epoch %u fc: usable=%d ok=%d dt_same=%d tab %llu/%llu sums %u legacy=%d new_static=%u seq %llu tiles %u\n",
+                    (unsigned long long)ctx->frame, a.epoch, (int)usable, (int)ctx->fc_ok, (int)(ctx->fc_dt_bits == dt_bits),
+                    (unsigned long long)ctx->fc_tab_seq, (unsigned long long)ctx->tab_seq, a.fc_sums, (int)legacy, a.new_static,
+                    (unsigned long long)ctx->fc_seq, total_tiles);
     }
     // a snapshot row stays armed until its stores have been seen (a free-running host can be hundreds of frames
     // ahead of the device; re-arming by frame number would never catch one)
@@ -1298,6 +1306,13 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 FW_HIP(ctx, hipEventSynchronize(ctx->ev_small));
                 ctx->small_pending = false;
             }
+            if (ctx->small_last_side && ctx->side_dirty) {
+                // the previous frame's small launch ran on the ring stream and may not have read the OLD list yet: the copy below
+                // (main stream) comes after it (the join used to be enqueued only further down, after the copy)
+                FW_HIP(ctx, hipEventRecord(ctx->ev_side, ctx->fifo_stream));
+                FW_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+                ctx->side_dirty = false;
+            }
             memcpy(ctx->h_small, ctx->small_list.data(), ctx->small_list.size() * sizeof(uint32_t));
             FW_HIP(ctx, hipMemcpyAsync(ctx->d_small, ctx->h_small, ctx->small_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
             FW_HIP(ctx, hipEventRecord(ctx->ev_small, ctx->stream));
@@ -1313,7 +1328,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         sa.host_counts = a.host_counts, sa.live_out = a.live_out, sa.live_next = a.live_next;
         // next to the collision passes of the frame, on the ring stream (fw_ctx::small_last_side)
         const bool small_side = legacy && frame_mode != FW_MODE_FUSED && sa.n != 0 && ctx->host_fast && ctx->use_fifo_stream && ctx->own_stream && ctx->live_ring == nullptr &&
-                                ctx->n_small_coll == 0 && !list_resent;
+                                ctx->n_small_coll == 0 && !list_resent && ctx->ops_zerocopy;  // (materialised ops: fw_k_spawn writes small segments on the main stream)
         if (sa.n) {
             if (small_side && (!ctx->small_last_side || ctx->main_reads_ring)) {
                 // the previous small launch, or a reader of its types' data, sits on the main stream: this launch comes after it
@@ -1367,7 +1382,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         for (uint32_t i = 0; i < n_seg; i++)
             if (ctx->segs[i].in_use && ctx->segs[i].derive_pending) {
                 ctx->segs[i].derive_pending = false;
-                if (ctx->segs[i].inst != nullptr) ctx->segs[i].derive_ready = true, ctx->derive_ready_any = true;
+                if (wants_derived(ctx, ctx->segs[i])) ctx->segs[i].derive_ready = true, ctx->derive_ready_any = true;
             }
     }
     prof(6);

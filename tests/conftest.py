@@ -75,6 +75,11 @@ def fw_path(request, monkeypatch):
     # hash as the tile sizes below) run the pinned form, so both stay under the suite whatever the box offers.
     if mode is not None and (_name_bits(request) >> 1) & 3 == 0:
         monkeypatch.setenv("FW_PARAM_BAR", "0")
+    # Round 6: the update of every type leaves scale and colours to its readers (FW_TYPE_DERIVED for all, fw_ctx::derive_all); a
+    # quarter of the test functions of the path matrix keeps the form of rounds 3-5 -- the three planes stored unless an instance
+    # buffer is attached (FW_DERIVED=1) -- so the stores, fw_k_rederive and the transitions between the two stay under the suite.
+    if mode is not None and (_name_bits(request) >> 5) & 3 == 0 and "FW_DERIVED" not in os.environ:
+        monkeypatch.setenv("FW_DERIVED", "1")
     if mode in ("fifo", "range", "general"):
         monkeypatch.setenv("FW_SMALL", "0")
     if mode == "small":
@@ -103,4 +108,11 @@ def fw_path(request, monkeypatch):
     elif mode == "general":
         monkeypatch.setenv("FW_FIFO", "0")
         monkeypatch.setenv("FW_RANGE", "0")
+    if mode is not None:
+        # which instantiations this test function ran (the choice depends on the test's name -- it is in the log of
+        # a failing test and in the junit properties)
+        variant = {k: os.environ.get(k) for k in ("FW_PARAM_BAR", "FW_DERIVED", "FW_FIFO_SMALL", "FW_RANGE_SMALL", "FW_SMALL_MAX", "FW_WIDE_MAX")
+                   if os.environ.get(k) is not None}
+        request.node.user_properties.append(("fw_variant", f"{mode}: {variant}"))
+        print(f"[fw variant] path={mode} {variant}")
     return mode

@@ -8,6 +8,7 @@ import oracle  # noqa: F401
 from bevy_firework_amd import settings as S
 from bevy_firework_amd import workloads
 from parity import Pair, assert_particles_match
+import parity
 
 pytestmark = pytest.mark.gpu
 DT = np.float32(1.0 / 60.0)
@@ -223,7 +224,8 @@ def test_unchanged_planes_are_not_written_but_changed_ones_are(system):
         # (default colours are one-key gradients: never rewritten; so is a constant scale curve; a type that cannot turn
         # reads neither its rotation nor its angular-velocity / lifetime plane: position+age and velocity in, the same out;
         # the second type spins and its angular velocity decays: all four state planes in, all of them + the scale out)
-        assert pair.gpu.update_path(0)[1] == 32 + 32 and pair.gpu.update_path(1)[1] == 64 + 32 + 32 + 4
+        # (round 6: the scale is left to the readers as well -- FW_TYPE_DERIVED for every type, parity.planes_left_to_readers)
+        assert pair.gpu.update_path(0)[1] == 32 + 32 and pair.gpu.update_path(1)[1] == 64 + 32 + 32 + 4 * (1 - parity.planes_left_to_readers())
     for fr in range(90):
         system.update(DT)
         pair.step_cpu(DT)
