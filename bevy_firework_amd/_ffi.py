@@ -263,12 +263,13 @@ SYMBOLS = [
     ("fw_debug_update_path", C.c_int, [_P, C.c_int, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("fw_debug_nest_frames", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("fw_debug_param_bar", C.c_int, [_P, C.POINTER(C.c_int32)]),
+    ("fw_debug_tile_scratch", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("fw_compute_emission_count", C.c_uint64,
      [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]),
 ]
 
 # entry points added after round 4 (ABI 5 + a measurement hook): absent from the older builds the A/B tools load through FW_LIB_PATH
-NEWER_THAN_R04 = {"fw_debug_nest_frames", "fw_debug_param_bar", "fw_ctx_set_parent_velocities", "fw_ctx_set_modifiers", "fw_ctx_queue"}
+NEWER_THAN_R04 = {"fw_debug_nest_frames", "fw_debug_param_bar", "fw_debug_tile_scratch", "fw_ctx_set_parent_velocities", "fw_ctx_set_modifiers", "fw_ctx_queue"}
 _lib = None
 
 
@@ -283,13 +284,18 @@ def load() -> C.CDLL:
             "There is no CPU fallback for the particle path."
         )
     lib = C.CDLL(LIB_PATH)
+    # An OLDER build loaded for an A/B measurement (tools/, through FW_LIB_PATH) lacks what was added since and reports ABI 4: accepted
+    # only on the explicit FW_ALLOW_OLD_ABI=1 (FW_LIB_PATH alone used to switch both checks off, so a stale or
+    # mismatched library bound with ABI-5 argument types)
+    allow_old = os.environ.get("FW_ALLOW_OLD_ABI") == "1" and bool(os.environ.get("FW_LIB_PATH"))
     for name, res, args in SYMBOLS:
-        if os.environ.get("FW_LIB_PATH") and name in NEWER_THAN_R04 and not hasattr(lib, name):
-            continue  # an OLDER build loaded for an A/B measurement (tools/): it lacks what was added since
+        if allow_old and name in NEWER_THAN_R04 and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.fw_abi_version() != 5 and not os.environ.get("FW_LIB_PATH"):  # (an older build loaded for an A/B measurement: tools/)
-        raise ImportError("libfirework_hip.so ABI version mismatch")
+    if lib.fw_abi_version() != 5 and not (allow_old and lib.fw_abi_version() == 4):
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.fw_abi_version()}, this binding is for 5"
+                          " (an older A/B build: FW_ALLOW_OLD_ABI=1 accepts version 4)")
     _lib = lib
     return lib

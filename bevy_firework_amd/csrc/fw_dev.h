@@ -379,9 +379,20 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
                                                    bool box_on = false, bool full = false, bool use_c = true) {
     if (T.flags & FW_TYPE_NOSPIN) q2 = make_float4(T.const_rot[0], T.const_rot[1], T.const_rot[2], T.const_rot[3]);
     const float lifetime = q3.w;
-    const float age_percent = age_new / lifetime;
-    const float scale_factor = fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_percent);
-    const float scale = q1.w * scale_factor;
+    // scale and colours (core.rs:601-605, 652-655).  A FW_TYPE_DERIVED type stores none of them: unless this launch writes an
+    // instance record or tracks the boxes, nobody asks for them here -- the division, the curve and both gradients are skipped
+    // (a workgroup-uniform branch on the type record: round 6, when that became the state of EVERY type; their readers evaluate
+    // fw_derived_values from the stored age)
+    const bool need_cs = !(T.flags & FW_TYPE_DERIVED) || rec != nullptr || box_on;
+    float scale = 0.0f;
+    float bc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, em[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (need_cs) {
+        const float age_percent = age_new / lifetime;
+        const float scale_factor = fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_percent);
+        scale = q1.w * scale_factor;
+        fw_gradient_sample(T.bc_kind, T.bc_n, s_keys + T.o_bc_t, s_keys + T.o_bc_v, age_percent, bc);
+        fw_gradient_sample(T.em_kind, T.em_n, s_keys + T.o_em_t, s_keys + T.o_em_v, age_percent, em);
+    }
     // explicit Euler with the OLD velocity (core.rs:626-631, 641-643); cpos / cvel: what particle_collision returned
     // for a type with collision settings (core.rs:607-624) -- the velocity update then starts from the new velocity
     // (use_c: a runtime "this type collides" next to pointers that are null or not at compile time -- a pointer SELECTED at
@@ -394,14 +405,17 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     const float vy = uy + (T.acc[1] - uy * T.lin_drag) * dt;
     const float vz = uz + (T.acc[2] - uz * T.lin_drag) * dt;
     // rotation = from_scaled_axis(angvel * dt) * rotation, no renormalisation (core.rs:645-647)
-    const fw_q4 dq = fw_quat_step(fw_v3{q3.x * dt, q3.y * dt, q3.z * dt});
-    const fw_q4 nr = fw_quat_mul(dq, fw_q4{q2.x, q2.y, q2.z, q2.w});
-    const float wx = q3.x + (T.angacc[0] - T.ang_drag * q3.x) * dt;  // core.rs:648-650
-    const float wy = q3.y + (T.angacc[1] - T.ang_drag * q3.y) * dt;
-    const float wz = q3.z + (T.angacc[2] - T.ang_drag * q3.z) * dt;
-    float bc[4], em[4];
-    fw_gradient_sample(T.bc_kind, T.bc_n, s_keys + T.o_bc_t, s_keys + T.o_bc_v, age_percent, bc);
-    fw_gradient_sample(T.em_kind, T.em_n, s_keys + T.o_em_t, s_keys + T.o_em_v, age_percent, em);
+    // (a type that cannot turn, FW_TYPE_NOSPIN: angular velocity 0, from_scaled_axis(0) * const_rot = const_rot bit for bit -- its
+    // components carry no negative zero, fw_engine_build.cpp -- and neither plane is stored: nothing to evaluate; workgroup-uniform)
+    fw_q4 nr{q2.x, q2.y, q2.z, q2.w};
+    float wx = 0.0f, wy = 0.0f, wz = 0.0f;
+    if (!(T.flags & FW_TYPE_NOSPIN)) {
+        const fw_q4 dq = fw_quat_step(fw_v3{q3.x * dt, q3.y * dt, q3.z * dt});
+        nr = fw_quat_mul(dq, fw_q4{q2.x, q2.y, q2.z, q2.w});
+        wx = q3.x + (T.angacc[0] - T.ang_drag * q3.x) * dt;  // core.rs:648-650
+        wy = q3.y + (T.angacc[1] - T.ang_drag * q3.y) * dt;
+        wz = q3.z + (T.angacc[2] - T.ang_drag * q3.z) * dt;
+    }
     const uint32_t b16 = (o - W.first) * 16u;  // < 16 KiB + a tile: the window starts at the tile's first output slot
     fw_st4w<NT == 2>(W.q0, b16, make_float4(px, py, pz, age_new));
     fw_st4w<NT == 2>(W.q1, b16, make_float4(vx, vy, vz, q1.w));
@@ -412,9 +426,11 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
                             (__float_as_uint(wz) ^ __float_as_uint(q3.z));
         if (W.wr2 && __any(full || d2 != 0u)) fw_st4w<NT == 2>(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));  // wave-uniform branches
         if (W.wr3 && __any(full || d3 != 0u)) fw_st4w<NT == 2>(W.q3, b16, make_float4(wx, wy, wz, lifetime));
-        if ((WM >= 0 ? (WM & 1) != 0 : W.wr5) || full) fw_st4w<NT != 0>(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
-        if ((WM >= 0 ? (WM & 2) != 0 : W.wr6) || full) fw_st4w<NT != 0>(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
-        if ((WM >= 0 ? (WM & 4) != 0 : (T.sc_kind != 0 && W.wr4)) || full) fw_st1w<NT != 0>(W.s4, (o - W.first) * 4u, scale);
+        // (`full` lanes -- slots that hold nothing yet -- write every plane the type MAINTAINS: W.wr4 is false exactly for FW_TYPE_DERIVED)
+        const bool fullk = full && W.wr4;
+        if ((WM >= 0 ? (WM & 1) != 0 : W.wr5) || fullk) fw_st4w<NT != 0>(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
+        if ((WM >= 0 ? (WM & 2) != 0 : W.wr6) || fullk) fw_st4w<NT != 0>(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
+        if ((WM >= 0 ? (WM & 4) != 0 : (T.sc_kind != 0 && W.wr4)) || fullk) fw_st1w<NT != 0>(W.s4, (o - W.first) * 4u, scale);
     } else {
         if (W.wr2) fw_st4w<NT == 2>(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
         if (W.wr3) fw_st4w<NT == 2>(W.q3, b16, make_float4(wx, wy, wz, lifetime));

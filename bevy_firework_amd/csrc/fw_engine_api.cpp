@@ -1053,6 +1053,12 @@ fw_status fw_debug_nest_frames(fw_ctx *ctx, uint64_t *fused, uint64_t *separate)
     if (separate) *separate = ctx->nest_pass_frames;
     return FW_OK;
 }
+fw_status fw_debug_tile_scratch(fw_ctx *ctx, uint64_t *table_tiles, uint64_t *scratch_tiles) {
+    if (!ctx) return FW_EINVAL;
+    if (table_tiles) *table_tiles = ctx->total_tiles_dev;
+    if (scratch_tiles) *scratch_tiles = ctx->tiles_cap;
+    return FW_OK;
+}
 fw_status fw_debug_param_bar(fw_ctx *ctx, int32_t *on) {  // fw_ctx::param_bar
     if (!ctx || !on) return FW_EINVAL;
     *on = ctx->param_bar ? 1 : 0;

@@ -347,6 +347,12 @@ class ParticleSystem:
         self._check(self._lib.fw_debug_param_bar(self._ctx, C.byref(on)))
         return bool(on.value)
 
+    def tile_scratch(self):
+        """(tiles of the compacting launch's table, entries every per-tile array of the context holds)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.fw_debug_tile_scratch(self._ctx, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def nest_frames(self):
         """(frames whose Nested entries ran inside the FIFO ring launch, frames that ran the separate fw_k_spawn / fw_k_nest passes)"""
         a, b = C.c_uint64(), C.c_uint64()

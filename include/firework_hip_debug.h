@@ -50,6 +50,10 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner spawner, uint32_t type, i
  * 4.0) and those that ran the separate fw_k_spawn / fw_k_nest passes first */
 fw_status fw_debug_nest_frames(fw_ctx *ctx, uint64_t *fused, uint64_t *separate);
 
+/* tiles of the compacting launch's tile table as of the last fw_step, and how many entries each per-tile array of the context (status
+ * words, forecast entries, tile boxes) holds: the first never exceeds the second (fw_step refuses the frame otherwise) */
+fw_status fw_debug_tile_scratch(fw_ctx *ctx, uint64_t *table_tiles, uint64_t *scratch_tiles);
+
 /* *on = 1: the context keeps the per-frame records of its range launches and its small op tables in DEVICE memory that the host writes
  * through the large BAR; 0: in pinned host memory (the platform does not map device memory for the host, or
  * FW_PARAM_BAR=0) */

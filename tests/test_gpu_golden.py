@@ -163,6 +163,11 @@ def test_global_burst_into_a_nested_fed_type_stays_in_bounds(system):
             h.queue_particles(30000)  # far beyond the 4096 slots
         system.update(DT)
         nb.step_cpu(DT)
+        # (round 6: the burst used to ask for 118 new-particle tiles -- 30 000 / 256 -- when the per-tile arrays of the context,
+        # sized from the capacities, held 36: forecast entries and status words of the tiles beyond were written out of bounds, and
+        # with other processes on the GPU an update kernel's `check 2` fired.  What exceeds the capacity needs no tile.)
+        table, scratch = system.tile_scratch()
+        assert table <= scratch, (fr, table, scratch)
     with pytest.raises(FwError) as e:
         h.counts()
     assert e.value.status == -4  # FW_ECAPACITY
