@@ -44,6 +44,12 @@ sys.path.insert(0, ROOT)
 
 SURVEY_BYTES = 156  # 64 B read + 92 B written per particle-update (every plane rewritten)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+INFINITY_CACHE_BYTES = 256 << 20  # MI355X_MICROARCH.md: 256 MiB memory-side cache; a working set below it is not an HBM stream
+# Round 6: scale, base colour and emissive colour are pure functions of (age, lifetime, initial_scale) (core.rs:601-605, 652-655)
+# and the update no longer stores them for any type (FW_TYPE_DERIVED): 36 of SURVEY's 92 written bytes are not moved.
+# `algorithmic_bytes_per_particle` is what the library reports for the path the type is on (fw_debug_update_path);
+# `at_survey_156B_per_particle` keeps the SURVEY figure next to it -- a rate of bytes the kernel does NOT move, above the peak at
+# configs[1]: a comparison with earlier rounds, not a bandwidth.
 
 
 def path_bytes(ps):
@@ -130,7 +136,13 @@ def roofline_dict(label, kt, per_launch, launches, mode, algo, moved):
             "particles_per_launch": per_launch, "avg_kernel_us": kt * 1e6, "launches": launches, "update_path": mode,
             "algorithmic_bytes_per_particle": algo, "moved_bytes_per_particle": moved,
             "at_survey_156B_per_particle": {"achieved": per_launch * SURVEY_BYTES / kt / 1e9,
-                                            "frac": per_launch * SURVEY_BYTES / kt / 1e9 / HBM_PEAK_GBS}}
+                                            "frac": per_launch * SURVEY_BYTES / kt / 1e9 / HBM_PEAK_GBS,
+                                            "note": "SURVEY 8(d)'s 156 B x particles / kernel time: bytes the kernel no longer "
+                                                    "moves (scale / colour planes are left to the readers), kept for comparison "
+                                                    "with rounds 1-5 only"},
+            # which memory level the launch streams from: the planes it touches against the 256 MiB Infinity Cache
+            "working_set_bytes": per_launch * moved,
+            "bound": "infinity_cache" if per_launch * moved < INFINITY_CACHE_BYTES else "hbm"}
 
 
 def kernel_roofline(ps, step, frames, label):
@@ -215,20 +227,21 @@ def assemble_line(args, world, workload, rows, roof, extras, cpu, hist, rccl_ran
                 traffic = None
         fifo = roof.get("update_path") == "fifo"
         roof.update({
-            "bound": "hbm",
             "kernel": ("fw_k_update_fifo (in-place ring update of a one-lifetime particle type, any dt)" if fifo else
                        "fw_k_update_range (in-place range rings: young part in place, old part compacted in place, any dt)"
                        if roof.get("update_path") == "range" else
                        "fw_k_update_stream (forecast frames; fw_k_update<fused> when dt changes)"),
             "traffic": traffic, "traffic_source": traffic_src,
             "measured_hbm_copy_GBps": measured_copy / 1e9,
-            "note": ("at 1M particles the 164 MB ring is resident in the 256 MiB Infinity Cache: `frac` is a cache-resident "
-                     "figure, not an HBM one; `hbm_resident` is configs[2], a 16.8M-particle working set whose lifetimes are a "
+            "note": ("at 1M particles the ring's planes (128 B per particle: four state planes read and written) are resident in the "
+                     "256 MiB Infinity Cache: `bound` says so, `frac` is a cache-resident figure against the HBM peak, not an HBM "
+                     "one; `hbm_resident` is configs[2], a 16.8M-particle working set whose lifetimes are a "
                      "range: in-place range rings (fw_k_update_range), with the compacting kernels on the same workload "
-                     "under `compacting_path`" if fifo and world == 1 else
-                     "one GPU's share of configs[4] (lifetime ranges: in-place range rings), 100 B algorithmic per particle; the "
-                     "share's ~420 MB exceed the 256 MiB Infinity Cache" if (world > 1 or workload == "configs4") else
-                     "at 1M particles the 200 MB ping-pong working set sits in the 256 MiB Infinity Cache; "
+                     "under `compacting_path`; `with_instance_records` is the frame a renderer asks for (update + 64-byte "
+                     "ParticleInstance records, render.rs:95-115)" if fifo and world == 1 else
+                     "one GPU's share of configs[4] (lifetime ranges: in-place range rings), 64 B algorithmic per particle "
+                     "(position+age and velocity in and out); the share's ~280 MB exceed the 256 MiB Infinity Cache" if (world > 1 or workload == "configs4") else
+                     "at 1M particles the ping-pong working set sits in the 256 MiB Infinity Cache; "
                      "`hbm_resident` is the same kernel on a 16.8M-particle working set"),
             "timing": "hipEvent start/stop attached to each update dispatch on the context's stream "
                       "(hipExtLaunchKernel: the packet's begin/end timestamps, the same duration rocprofv3 "
@@ -299,7 +312,7 @@ def launch_check(args, world, rank):
     dist.all_reduce(t)
     workload = args.workload if args.workload != "auto" else ("configs1" if world == 1 else "configs4")
     # stand-ins: rank r "ran" for 1 + r/10 s, updated 1000 (r + 1) particles, its kernel took 50 + r us per launch
-    roof = roofline_dict(workload, (50.0 + rank) * 1e-6, 100.0 * (rank + 1), 3, "range", 100, 104)
+    roof = roofline_dict(workload, (50.0 + rank) * 1e-6, 100.0 * (rank + 1), 3, "range", 64, 68)
     rows = gather_ranks(dist, world, "cpu", 1.0 + 0.1 * rank, 1000 * (rank + 1), 100 * (rank + 1), roof)
     if rank == 0:
         cpu = None if args.no_cpu else cpu_baseline(args, 1.0 / 60.0, world, check=True, workload=workload)
@@ -527,6 +540,42 @@ def main():
             torch.cuda.synchronize()
             extras["hbm_resident_ring"] = kernel_roofline(p3, lambda k: p3.step(dt), 100,
                                                           "configs[1] at 16x the rate: one ring of 15.7M live particles")
+        # (b'') the frame a RENDERER asks for: update + the 64-byte ParticleInstance record of every survivor (render.rs:95-115, 403)
+        # written by the update kernel itself into an attached device buffer (fw_spawner_attach_instances[_window]) -- what a Bevy
+        # host runs every frame for a visible spawner (render.rs:382-403).  configs[1] (one FIFO ring) and configs[2] (256 range
+        # rings; the windowed attach keeps them rings: the renderer draws buffer[first, first + count), render.rs:922-926).
+        recs = {}
+        for key, label, ems_, fill_, frames_, cap_, window_ in (
+                ("configs1", "configs[1] + instance records", [workloads.one_million(rate=args.rate)], 62 + 20, 300, 1 << 20, False),
+                ("configs2", "configs[2] + instance records (windowed)", workloads.many_emitters(256, 65536), 76 + 20, 60, 110000, True)):
+            with ParticleSystem(device=local_rank, seed=workloads.SEED, stream=stream.cuda_stream) as pi:
+                bufs = []
+                for e, (s_, tf_) in enumerate(ems_):
+                    h_ = pi.spawn(s_, tf_, uid=e)
+                    b_ = torch.empty(cap_ * 64, dtype=torch.uint8, device=f"cuda:{local_rank}")
+                    bufs.append(b_)
+                    (h_.attach_instances_window if window_ else h_.attach_instances)(b_.data_ptr(), cap_, particle_type=0)
+                pi.update(dt)
+                for _ in range(fill_):
+                    pi.step(dt)
+                torch.cuda.synchronize()
+                b0 = pi.updated_total()
+                t1 = time.perf_counter()
+                for _ in range(frames_):
+                    pi.step(dt)
+                pi.synchronize()
+                el = time.perf_counter() - t1
+                whole = (pi.updated_total() - b0) / el
+                r_ = kernel_roofline(pi, lambda k: pi.step(dt), frames_, label)
+                if r_:
+                    r_["whole_step_particles_per_s"], r_["whole_step_ms"] = whole, el / frames_ * 1e3
+                    r_["kernel"] = ("fw_k_update_fifo<INST>" if r_["update_path"] == "fifo" else
+                                    "fw_k_update_range<INST>" if r_["update_path"] == "range" else "fw_k_update_stream<INST>")
+                    r_["record_bytes_per_particle"] = 64
+                    r_["attach"] = "fw_spawner_attach_instances_window" if window_ else "fw_spawner_attach_instances"
+                recs[key] = r_
+                del bufs
+        extras["with_instance_records"] = recs
         # (c) configs[4] on this one GPU: the base point of the multi-GPU curve
         with ParticleSystem(device=local_rank, seed=workloads.SEED, stream=stream.cuda_stream) as p4:
             for e, (s_, tf_) in enumerate(workloads.many_emitters(args.emitters, args.live_per_emitter)):

@@ -1050,9 +1050,11 @@ hipError_t fw_launch_update_fifo(hipStream_t s, const FwGlobals &g, const FwFifo
         else                                                                               \
             FW_LAUNCH_T((fw_k_update_fifo<false, wm>), grid, block, s, e0, e1, g, a, inl); \
         break;
+    // (round 6: every type leaves scale and colours to its readers -- write mask 0 is what the product launches; the other seven
+    // compile-time masks of rounds 3-5 served types that stored those planes: FW_DERIVED=0 / 1 and colliding types now take the
+    // generic form -- 14 instantiations and a third of the library's build time less)
     switch (a.write_mask) {
-        FW_FIFO_CASE(0) FW_FIFO_CASE(1) FW_FIFO_CASE(2) FW_FIFO_CASE(3) FW_FIFO_CASE(4) FW_FIFO_CASE(5) FW_FIFO_CASE(6)
-        FW_FIFO_CASE(7)
+        FW_FIFO_CASE(0)
         default:
             if (a.any_inst)
                 FW_LAUNCH_T((fw_k_update_fifo<true, -1>), grid, block, s, e0, e1, g, a, inl);

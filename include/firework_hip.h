@@ -83,7 +83,12 @@ typedef struct fw_curve { int32_t kind; int32_t n; const float *times; const flo
 typedef struct fw_gradient { int32_t kind; int32_t n; const float *times; const float *rgba; } fw_gradient;
 
 /* ParticleCollisionSettings (core.rs:240-248, feature physics_avian): `enabled` = the Option is Some.
- * `filter_mask` stands in for SpatialQueryFilter: a collider takes part when (filter_mask & collider.layers) != 0. */
+ * `filter_mask` stands in for SpatialQueryFilter (core.rs:247, passed to cast_ray at core.rs:764): a collider takes part when
+ * (filter_mask & collider.layers) != 0 -- avian's `mask` against the collider's `memberships`.
+ * NOT SUPPORTED: `SpatialQueryFilter::excluded_entities`.  The device-resident set has no entity identity: a host that needs
+ * an exclusion keeps the excluded colliders out of the set it sends (fw_ctx_set_colliders; the set is per context, so this
+ * excludes them for every particle type of the context) or gives them a membership bit no particle type's mask contains
+ * (rust/src/hip/colliders.rs does the latter for entities listed in a `ParticleColliderExclusions` resource). */
 typedef struct fw_collision_settings {
     int32_t enabled;
     float restitution, friction;

@@ -16,12 +16,23 @@ use bevy::prelude::*;
 #[derive(Component, Default)]
 pub struct ParticleCollider;
 
-pub fn hip_sync_colliders(backend: NonSend<HipBackend>, q: Query<(&Collider, &GlobalTransform, Option<&CollisionLayers>), With<ParticleCollider>>) {
+/// `SpatialQueryFilter::excluded_entities` (core.rs:247, 764) has no counterpart on the device (include/firework_hip.h): entities
+/// listed here are sent with NO membership bit, so no particle type's mask selects them -- the one exclusion the backend can honour,
+/// and it holds for every particle type of the context.  A filter that excludes an entity for ONE type only keeps that spawner on
+/// the CPU systems.
+#[derive(Resource, Default)]
+pub struct ParticleColliderExclusions(pub bevy::platform::collections::HashSet<Entity>);
+
+pub fn hip_sync_colliders(
+    backend: NonSend<HipBackend>, excluded: Option<Res<ParticleColliderExclusions>>,
+    q: Query<(Entity, &Collider, &GlobalTransform, Option<&CollisionLayers>), With<ParticleCollider>>,
+) {
     let mut set = Vec::<fw_collider>::new();
-    for (collider, gt, layers) in &q {
+    for (entity, collider, gt, layers) in &q {
         let t = gt.compute_transform();
+        let out = excluded.as_ref().is_some_and(|x| x.0.contains(&entity));
         let base = fw_collider {
-            kind: 0, layers: layers.map_or(1, |l| l.memberships.0), position: t.translation.to_array(), rotation: t.rotation.to_array(),
+            kind: 0, layers: if out { 0 } else { layers.map_or(1, |l| l.memberships.0) }, position: t.translation.to_array(), rotation: t.rotation.to_array(),
             normal: [0., 1., 0.], radius: 0., half_extents: [0.; 3],
         };
         let shape = collider.shape_scaled();

@@ -19,11 +19,13 @@
 pub mod ffi;
 #[cfg(feature = "physics_avian")]
 pub mod colliders;
+pub mod render; // the renderer's half of the hand-off (src/render.rs:368-423, 568-584, 677-703, 922-926)
 
 use crate::core::*;
 use crate::emission_shape::EmissionShape;
 use bevy::prelude::*;
 use ffi::*;
+use std::collections::HashMap;
 use std::ffi::CStr;
 
 /// One context per GPU.  `!Send`: insert with `insert_non_send_resource` (calls on one context are serialised by its owner).
@@ -32,6 +34,11 @@ use std::ffi::CStr;
 pub struct HipBackend {
     pub ctx: *mut fw_ctx,
     next_uid: u32,
+    /// Entity -> device spawner, kept HERE and not only in the `HipSpawner` component: when an entity is despawned -- the normal
+    /// end of a one-shot effect, `ParticleSpawnerFinished` then `despawn` (examples/one_shot.rs:137-141) -- its components are gone
+    /// by the time `RemovedComponents<ParticleSpawner>` is read, and a lookup through the removed entity finds nothing: every
+    /// despawned emitter would leak its device segments.
+    spawners: HashMap<Entity, fw_spawner>,
 }
 
 /// The handle of a spawner's device-resident state, next to its `ParticleSpawnerData`.
@@ -50,7 +57,7 @@ impl HipBackend {
             return Err(HipError(st, msg)); // FW_ENODEV: there is no CPU fallback in the library; the caller keeps the CPU systems
         }
         assert_eq!(unsafe { fw_abi_version() }, 5);
-        Ok(Self { ctx, next_uid: 0 })
+        Ok(Self { ctx, next_uid: 0, spawners: HashMap::new() })
     }
     pub fn check(&self, st: i32) -> Result<(), HipError> {
         if st == 0 { return Ok(()); }
@@ -132,10 +139,14 @@ fn build_desc(s: &ParticleSpawner) -> Desc {
 pub fn hip_sync_spawner_data(
     mut backend: NonSendMut<HipBackend>, mut commands: Commands,
     spawners: Query<(Entity, &ParticleSpawner, Option<&HipSpawner>), Changed<ParticleSpawner>>,
-    mut removed: RemovedComponents<ParticleSpawner>, handles: Query<&HipSpawner>,
+    mut removed: RemovedComponents<ParticleSpawner>,
 ) {
+    // (component removed OR entity despawned: the handle comes from the backend's own map, see HipBackend::spawners)
     for e in removed.read() {
-        if let Ok(h) = handles.get(e) { unsafe { fw_spawner_destroy(backend.ctx, h.0); } }
+        if let Some(h) = backend.spawners.remove(&e) {
+            unsafe { fw_spawner_destroy(backend.ctx, h); }
+            if let Ok(mut ec) = commands.get_entity(e) { ec.remove::<(HipSpawner, render::HipInstances)>(); }
+        }
     }
     for (entity, settings, handle) in &spawners {
         let d = build_desc(settings);
@@ -151,7 +162,8 @@ pub fn hip_sync_spawner_data(
                 let mut h: fw_spawner = -1;
                 if backend.check(unsafe { fw_spawner_create(backend.ctx, &desc, &mut h) }).is_ok() {
                     backend.next_uid += 1;
-                    commands.entity(entity).insert(HipSpawner(h));
+                    backend.spawners.insert(entity, h);
+                    commands.entity(entity).insert((HipSpawner(h), render::HipInstances::default()));
                 } // FW_EINVAL mirrors the reference's panics (0-sample curves, indices out of range): log and skip
             }
         }
@@ -161,7 +173,7 @@ pub fn hip_sync_spawner_data(
 /// spawn_particles + update_particles (core.rs:367-670) for EVERY spawner: the per-frame inputs in one FFI call each, then one
 /// asynchronous `fw_step`.
 pub fn hip_frame(
-    backend: NonSend<HipBackend>, time: Res<Time>,
+    backend: NonSend<HipBackend>, time: Res<Time>, mut commands: Commands,
     mut q: Query<(&Transform, &GlobalTransform, &ParticleSpawner, &mut ParticleSpawnerData, &HipSpawner, Option<&EffectModifier>)>,
 ) {
     let (mut hs, mut ts, mut rs) = (Vec::<fw_spawner>::new(), Vec::<f32>::new(), Vec::<f32>::new());
@@ -192,8 +204,42 @@ pub fn hip_frame(
         // is INVALID until it is rebuilt (re-insert its ParticleSpawner) or despawned -- INTEGRATION.md section 3, Errors
         if let Err(e) = backend.check(fw_step(backend.ctx, time.delta_secs())) { error!("fw_step: {} {}", e.0, e.1); }
     }
-    // particles_destroyed handlers (core.rs:660-667), only for the types that registered one:
-    //   fw_spawner_read_destroyed(ctx, h, ty, buf, cap, &mut n) -> commands.run_system_with(handler, Vec<ParticleData>)
+    // particles_destroyed handlers (core.rs:660-667): `run_system_with(handler, destroyed)` for every particle type that registered
+    // one and lost particles in this step.  Reading the records waits for the frame -- only spawners with a handler pay for it
+    // (`report_destroyed` was set from `event_handlers.particles_destroyed.is_some()` in build_desc); the records hold what the
+    // reference's `destroyed` vector holds: age already >= lifetime, pose of the previous frame for an age death (core.rs:596-599),
+    // of this frame for a collision death (core.rs:636-639).
+    let mut buf = Vec::<fw_particle>::new();
+    for (_, _, settings, _, h, _) in &q {
+        for (ty, p) in settings.particle_settings.iter().enumerate() {
+            let Some(handler) = p.event_handlers.particles_destroyed else { continue };
+            let mut n = 0u64;
+            unsafe { fw_spawner_read_destroyed(backend.ctx, h.0, ty as u32, std::ptr::null_mut(), 0, &mut n); } // size query
+            if n == 0 { continue; }
+            buf.clear();
+            buf.reserve(n as usize);
+            let st = unsafe { fw_spawner_read_destroyed(backend.ctx, h.0, ty as u32, buf.as_mut_ptr(), n, &mut n) };
+            if backend.check(st).is_err() { continue; }
+            unsafe { buf.set_len(n as usize); }
+            let n_emissions = settings.emission_settings.len();
+            let destroyed: Vec<ParticleData> = buf.iter().map(|r| particle_data(r, n_emissions)).collect();
+            commands.run_system_with(handler, destroyed); // deferred to the next sync point, like ParallelCommands in the reference
+        }
+    }
+}
+
+/// fw_particle (104-byte record of the ABI) -> ParticleData (core.rs:305-321).  `last_emitted_age` is not part of the record: a
+/// handler that needs it reads `fw_spawner_read_last_emitted`; the vector has the reference's length and its initial value
+/// (core.rs:467).
+pub fn particle_data(r: &fw_particle, n_emissions: usize) -> ParticleData {
+    ParticleData {
+        position: Vec3::from_array(r.position), velocity: Vec3::from_array(r.velocity), rotation: Quat::from_array(r.rotation),
+        angular_velocity: Vec3::from_array(r.angular_velocity), initial_scale: r.initial_scale, scale: r.scale, age: r.age,
+        lifetime: r.lifetime,
+        base_color: LinearRgba::new(r.base_color[0], r.base_color[1], r.base_color[2], r.base_color[3]),
+        emissive_color: LinearRgba::new(r.emissive_color[0], r.emissive_color[1], r.emissive_color[2], r.emissive_color[3]),
+        pbr: r.pbr != 0, last_emitted_age: vec![f32::MIN; n_emissions],
+    }
 }
 
 /// notify_finished_particle_spawners (core.rs:674-688).  Reads device counts: this is the one call of the frame that WAITS for

@@ -17,7 +17,10 @@
                 sync_parent_velocity, // unchanged (core.rs:706-736); its result travels in fw_ctx_set_parent_velocities
                 #[cfg(feature = "physics_avian")]
                 crate::hip::colliders::hip_sync_colliders, // the world particle_collision casts its rays into (core.rs:756-765)
-                hip_frame,            // spawn_particles + update_particles (core.rs:367-670): ONE asynchronous call
+                hip_frame,            // spawn_particles + update_particles (core.rs:367-670): ONE asynchronous call; dispatches the
+                                      // particles_destroyed handlers (core.rs:660-667)
+                crate::hip::render::hip_fill_instances, // the records the render extract reads (render.rs:368-423, 403); form B of
+                                      // src/hip/render.rs uses hip_instance_windows here instead
                 hip_notify_finished,  // notify_finished_particle_spawners (core.rs:674-688)
             )
                 .chain(),
