@@ -14,6 +14,13 @@
 //   ./examples/sharded --gpus N [...]                               ONE process drives N devices (ncclCommInitAll)
 //   ./examples/sharded --rank r --world N --id-file /path [...]     one process per GPU (rank 0 writes the ncclUniqueId
 //                                                                   to the file, the others read it: ncclCommInitRank)
+//   ./examples/sharded --ranks-on-one-device N [...]                REHEARSAL on one GPU (round 6: no multi-GPU node has been
+//                                                                   available to any round): N contexts on device 0, one host
+//                                                                   thread each, emitter e in context e mod N -- the share,
+//                                                                   the streams, the live-count rings and the bucketing of the
+//                                                                   N-rank run, with a host-side sum of the buckets standing in
+//                                                                   for ncclAllReduce (RCCL refuses two ranks on one device).
+//                                                                   Prints each context's steady-state us per frame.
 //   common: --emitters E (4096) --live L (8192 per emitter) --frames F (96) --reduce-every K (16)
 // Output (rank 0): one line per reduced frame "frame f global_live X", then a digest of the per-emitter counts of this
 // process and the rate.  tests/test_cpp_host.py compares these lines with bevy_firework_amd.sharding on the same workload.
@@ -87,13 +94,14 @@ struct Shard {  // one GPU: its context, its share of the emitters, its feed of 
 };
 
 int main(int argc, char **argv) {
-    int gpus = 1, rank = -1, world = 0, emitters = 4096, frames = 96, every = 16;
+    int gpus = 1, rank = -1, world = 0, emitters = 4096, frames = 96, every = 16, one_device = 0;
     double live = 8192.0;
     std::string id_file;
     for (int i = 1; i < argc; i++) {
         auto arg = [&](const char *name) { return !strcmp(argv[i], name) && i + 1 < argc; };
         if (arg("--gpus")) gpus = atoi(argv[++i]);
         else if (arg("--rank")) rank = atoi(argv[++i]);
+        else if (arg("--ranks-on-one-device")) one_device = atoi(argv[++i]);
         else if (arg("--world")) world = atoi(argv[++i]);
         else if (arg("--id-file")) id_file = argv[++i];
         else if (arg("--emitters")) emitters = atoi(argv[++i]);
@@ -115,9 +123,14 @@ int main(int argc, char **argv) {
         std::fprintf(stderr, "no HIP device available; this backend has no CPU fallback\n");
         return 1;
     }
+    if (one_device > 0 && (multi_process || gpus != 1)) {
+        std::fprintf(stderr, "--ranks-on-one-device excludes --gpus / --rank\n");
+        return 2;
+    }
+    if (one_device > 0) gpus = one_device;
     const int n_ranks = multi_process ? world : gpus;       // GPUs the emitters are spread over
     const int n_local = multi_process ? 1 : gpus;           // ... of which this process drives
-    if (!multi_process && gpus > visible) {
+    if (!multi_process && one_device == 0 && gpus > visible) {
         std::fprintf(stderr, "--gpus %d but only %d devices are visible: refusing to run fewer ranks\n", gpus, visible);
         return 1;
     }
@@ -144,6 +157,8 @@ int main(int argc, char **argv) {
             shards[0].device = rank % visible;
             HIPCHECK(hipSetDevice(shards[0].device));
             NCCLCHECK(ncclCommInitRank(&shards[0].comm, world, id, rank));
+        } else if (one_device > 0) {
+            for (int d = 0; d < n_local; d++) shards[d].device = 0;  // no communicator: the buckets are summed on the host
         } else {
             std::vector<int> devs(n_local);
             std::vector<ncclComm_t> comms(n_local);
@@ -173,6 +188,86 @@ int main(int argc, char **argv) {
         // ---- frames.  Nothing here waits for a GPU: fw_step enqueues, the bucket copy and the collective are enqueued on
         // the same stream behind the frames that wrote the bucket.
         const float dt = 1.0f / 60.0f;
+        if (one_device > 0) {
+            // ---- the rehearsal: every context is driven by its own host thread, as N ranks would be by N processes; a bucket of
+            // per-frame totals leaves each context as ONE copy into pinned memory behind the frames that wrote it
+            std::vector<unsigned long long *> h_b(n_local, nullptr);
+            std::vector<double> steady_us(n_local, 0.0), all_us(n_local, 0.0);
+            for (int l = 0; l < n_local; l++) {
+                HIPCHECK(hipHostMalloc((void **)&h_b[l], (size_t)n_buckets * every * sizeof(unsigned long long), hipHostMallocDefault));
+                memset(h_b[l], 0, (size_t)n_buckets * every * sizeof(unsigned long long));
+            }
+            const int half = frames / 2;
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<std::thread> th;
+            std::vector<int> failed(n_local, 0);
+            for (int l = 0; l < n_local; l++)
+                th.emplace_back([&, l]() {
+                    try {
+                        Shard &S = shards[l];
+                        HIPCHECK(hipSetDevice(0));
+                        const auto a0 = std::chrono::steady_clock::now();
+                        auto a1 = a0;
+                        int sent = 0;
+                        auto flush = [&](int first, int n) {
+                            HIPCHECK(hipMemcpyAsync(h_b[l] + first, S.ring + first % (2 * every), (size_t)n * sizeof(unsigned long long),
+                                                    hipMemcpyDeviceToHost, S.stream));
+                        };
+                        for (int f = 0; f < frames; f++) {
+                            if (f == half) {  // the steady half is timed on its own: wait for the fill, start the clock
+                                HIPCHECK(hipStreamSynchronize(S.stream));
+                                S.app->synchronize();
+                                a1 = std::chrono::steady_clock::now();
+                            }
+                            if (f == 0) S.app->update(dt);
+                            else S.app->step(dt);
+                            if (f + 1 - sent == every) flush(sent, every), sent = f + 1;
+                        }
+                        if (frames > sent) flush(sent, frames - sent);
+                        S.app->synchronize();
+                        HIPCHECK(hipStreamSynchronize(S.stream));
+                        const auto a2 = std::chrono::steady_clock::now();
+                        steady_us[l] = std::chrono::duration<double, std::micro>(a2 - a1).count() / std::max(1, frames - half);
+                        all_us[l] = std::chrono::duration<double, std::micro>(a2 - a0).count() / frames;
+                    } catch (const Error &e) {
+                        std::fprintf(stderr, "context %d: firework error %d: %s\n", l, (int)e.status, e.what());
+                        failed[l] = 1;
+                    }
+                });
+            for (auto &t : th) t.join();
+            for (int l = 0; l < n_local; l++)
+                if (failed[l]) return 1;
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            for (int f = 0; f < frames; f++) {  // the stand-in for ncclAllReduce(sum): live counts only, a few bytes per frame
+                unsigned long long g = 0;
+                for (int l = 0; l < n_local; l++) g += h_b[l][f];
+                std::printf("frame %d global_live %llu\n", f, g);
+            }
+            uint64_t updated = 0, live_total = 0;
+            double worst = 0.0;
+            for (int l = 0; l < n_local; l++) {
+                Shard &S = shards[l];
+                uint64_t live_here = 0;
+                for (auto *em : S.emitters) live_here += em->counts()[0];
+                live_total += live_here;
+                updated += S.app->updated_total();
+                worst = std::max(worst, steady_us[l]);
+                std::printf("context %d of %d on device 0: %zu emitters, %llu live, steady %.1f us per frame (frames %d..%d), %.1f us per frame over all\n",
+                            l, n_local, S.emitters.size(), (unsigned long long)live_here, steady_us[l], half, frames - 1, all_us[l]);
+            }
+            std::printf("ranks_on_one_device %d emitters %d live_total %llu slowest_context_steady_us %.1f particles_per_s_all_contexts_steady %.3e\n",
+                        n_local, emitters, (unsigned long long)live_total, worst, worst > 0 ? live_total / (worst * 1e-6) : 0.0);
+            std::printf("particles updated/s (this process, incl. the fill): %.3e over %d frames, %.1f us per frame\n", updated / sec,
+                        frames, sec / frames * 1e6);
+            for (int l = 0; l < n_local; l++) {
+                Shard &S = shards[l];
+                S.app->check(fw_ctx_live_count_ring(S.app->raw(), nullptr, 0));
+                S.app.reset();
+                (void)hipFree(S.ring), (void)hipFree(S.buckets), (void)hipHostFree(h_b[l]);
+                (void)hipStreamDestroy(S.stream);
+            }
+            return 0;
+        }
         const auto t0 = std::chrono::steady_clock::now();
         int sent = 0;
         auto reduce = [&](int first, int n) {

@@ -39,7 +39,7 @@ def pytest_collection_modifyitems(config, items):
 # both switched off (everything on the general, compacting path).  The knobs are read when a context is created, so setting
 # the environment before the test body is enough.
 def pytest_generate_tests(metafunc):
-    if metafunc.module.__name__.split(".")[-1] in ("test_gpu_range", "test_gpu_lifecycle", "test_gpu_host_fast"):
+    if metafunc.module.__name__.split(".")[-1] in ("test_gpu_range", "test_gpu_lifecycle", "test_gpu_host_fast", "test_gpu_thresholds"):
         return  # (set their own knobs: every test of test_gpu_range is about one path, the other two run at product defaults)
     if metafunc.definition.get_closest_marker("gpu") and "fw_path" in metafunc.fixturenames:
         metafunc.parametrize("fw_path", ["fifo", "range", "general", "small"], indirect=True)

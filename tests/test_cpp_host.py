@@ -153,6 +153,15 @@ def test_native_sharded_host_matches_the_python_sharding(tmp_path):
             h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert f"{h:016x}" == cpp_digest
     sh.system.close()
+    # round 6: the rehearsal of N ranks on ONE device (N contexts, N host threads, host-side sum of the buckets instead of
+    # ncclAllReduce): emitter e in context e mod 4 -- the per-frame global totals do not depend on how the emitters are spread
+    r = subprocess.run([exe, "--ranks-on-one-device", "4"] + common, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert [int(ln.split()[3]) for ln in lines if ln.startswith("frame ")] == cpp_hist
+    per_ctx = [ln for ln in lines if ln.startswith("context ")]
+    assert len(per_ctx) == 4 and all("12 emitters" in ln for ln in per_ctx)
+    assert re.search(r"ranks_on_one_device 4 emitters 48 live_total (\d+)", r.stdout).group(1) == str(cpp_hist[-1])
 
 
 @pytest.mark.gpu
