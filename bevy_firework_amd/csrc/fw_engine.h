@@ -540,6 +540,7 @@ struct fw_ctx {
     int update_mode = FW_MODE_FUSED;
     uint32_t spin_limit = 1u << 16;
     uint32_t dbg = 0;  // FW_DEBUG: profiling-only kernel ablations (results are wrong when set)
+    uint64_t recovered_rings = 0;  // rings sent to the compacting path because a cohort report was missing (fw_step: recoverable)
 
     std::vector<SpawnerHost, HugeAlloc<SpawnerHost>> spawners;  // (HugePool: huge pages)
     std::vector<SegHost, HugeAlloc<SegHost>> segs;

@@ -1059,6 +1059,11 @@ fw_status fw_debug_tile_scratch(fw_ctx *ctx, uint64_t *table_tiles, uint64_t *sc
     if (scratch_tiles) *scratch_tiles = ctx->tiles_cap;
     return FW_OK;
 }
+fw_status fw_debug_recovered_rings(fw_ctx *ctx, uint64_t *n) {
+    if (!ctx || !n) return FW_EINVAL;
+    *n = ctx->recovered_rings;
+    return FW_OK;
+}
 fw_status fw_debug_param_bar(fw_ctx *ctx, int32_t *on) {  // fw_ctx::param_bar
     if (!ctx || !on) return FW_EINVAL;
     *on = ctx->param_bar ? 1 : 0;

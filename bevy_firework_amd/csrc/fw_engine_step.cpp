@@ -79,6 +79,50 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         }
     }
     if (!ctx->n_range) ctx->birth_age.clear();
+    // Round 6: rings that receive Nested children need the size of a cohort -- which only the device knows -- in
+    // the frame that cohort may start to die; the update of the cohort's own frame left it in a pinned report ring, a lifetime.min
+    // ago.  A report that is STILL missing after the stream has been waited for used to be found in the middle of the frame's
+    // bookkeeping (clocks advanced, earlier ring launches possibly out): nothing could be rolled back and the spawner was
+    // poisoned.  It is looked for HERE, before anything of the frame is committed: such a ring continues on the compacting path
+    // -- exact counts from the device, particles and order kept (fifo_to_general) -- and the frame goes ahead.  A failed check
+    // of the host's bookkeeping costs a conversion, not the spawner's particles.  (FW_DEBUG 512 in the `ab` build pretends the
+    // report of the first due cohort of frame 60 is missing: tests/test_gpu_range.py.)
+    if (ctx->n_fifo || ctx->n_range) {
+        auto report_missing = [&](const SegHost &S, uint64_t frame) -> bool {
+            if (FW_DBG(ctx->dbg, 512u) && ctx->frame == 60u) return true;
+            const uint32_t ep = (uint32_t)((frame + 1) & 0x3FFFFFFFu) ? (uint32_t)((frame + 1) & 0x3FFFFFFFu) : 1u;
+            const volatile unsigned long long *row = S.h_report + (frame % kReportRing);
+            for (int spin = 0; (uint32_t)(*row >> 32) != ep && spin < 100000; spin++) __builtin_ia32_pause();
+            if ((uint32_t)(*row >> 32) == ep) return false;
+            if (sync(ctx) != FW_OK) return true;
+            return (uint32_t)(*row >> 32) != ep;
+        };
+        for (uint32_t si = 0; si < ctx->segs.size(); si++) {
+            SegHost &S = ctx->segs[si];
+            if (!S.in_use || !S.h_report) continue;
+            bool missing = false;
+            if (S.fifo && S.fifo_dev) {
+                for (const SegHost::Cohort &c : S.coh) {
+                    if (!(c.age + dt >= S.fifo_life)) break;  // (the oldest die first: fw_step's own test, below)
+                    if (!c.known && c.frame != ctx->frame && report_missing(S, c.frame)) missing = true;
+                }
+            } else if (S.range && S.range_dev) {
+                for (const SegHost::DCohort &c : S.dcoh) {
+                    float age = INFINITY;  // (age_before of the range block below)
+                    if (!ctx->birth_age.empty() && c.frame >= ctx->birth_age.front().frame) {
+                        const size_t i = (size_t)(c.frame - ctx->birth_age.front().frame);
+                        age = i < ctx->birth_age.size() ? ctx->birth_age[i].age : 0.0f;
+                    }
+                    if (age + dt < S.range_life_lo) break;
+                    if (!c.known && report_missing(S, c.frame)) missing = true;
+                }
+            }
+            if (!missing) continue;
+            ctx->recovered_rings++;
+            fw_status cst = fifo_to_general(ctx, si);
+            if (cst) return cst;
+        }
+    }
     // (frame_spawn is reset in the lifetime-window pass below: one pass over the segments instead of two)
     bool new_static = std::isfinite(dt);  // cleared by any Global op whose particles might not survive this step
 

@@ -353,6 +353,12 @@ class ParticleSystem:
         self._check(self._lib.fw_debug_tile_scratch(self._ctx, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    def recovered_rings(self) -> int:
+        """rings moved to the compacting path (particles kept) because a cohort report was missing when it was due"""
+        n = C.c_uint64()
+        self._check(self._lib.fw_debug_recovered_rings(self._ctx, C.byref(n)))
+        return int(n.value)
+
     def nest_frames(self):
         """(frames whose Nested entries ran inside the FIFO ring launch, frames that ran the separate fw_k_spawn / fw_k_nest passes)"""
         a, b = C.c_uint64(), C.c_uint64()

@@ -54,6 +54,11 @@ fw_status fw_debug_nest_frames(fw_ctx *ctx, uint64_t *fused, uint64_t *separate)
  * words, forecast entries, tile boxes) holds: the first never exceeds the second (fw_step refuses the frame otherwise) */
 fw_status fw_debug_tile_scratch(fw_ctx *ctx, uint64_t *table_tiles, uint64_t *scratch_tiles);
 
+/* rings that fw_step moved to the compacting path -- particles and order kept -- because the device's report of a cohort size was
+ * still missing when the cohort was due (a failed check of the host's bookkeeping that is found BEFORE the frame is committed:
+ * recoverable) */
+fw_status fw_debug_recovered_rings(fw_ctx *ctx, uint64_t *n);
+
 /* *on = 1: the context keeps the per-frame records of its range launches and its small op tables in DEVICE memory that the host writes
  * through the large BAR; 0: in pinned host memory (the platform does not map device memory for the host, or
  * FW_PARAM_BAR=0) */

@@ -376,6 +376,64 @@ def test_an_internal_error_is_sticky_for_its_spawner_until_it_is_rebuilt():
     assert r.returncode == 0 and "STICKY-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("rings", ["fifo", "range"])
+def test_a_missing_cohort_report_costs_the_ring_not_the_particles(rings):
+    """Fault injection (the `make ab` build, FW_DEBUG 512: in frame 60 the pinned report of every cohort that is due counts as
+    missing).  A ring that receives Nested children needs that report -- the size of a cohort only the device knows -- when the
+    cohort may start to die.  Until round 5 its absence was found in the middle of the frame's bookkeeping and poisoned the
+    spawner (FW_ERR_FORECAST, unrecoverable).  Now fw_step looks for it BEFORE anything of the frame is committed: the ring
+    continues on the compacting path, exact counts from the device, particles and order kept -- the run goes on and matches the
+    oracle on every frame, before and after.  A one-lifetime child type (FIFO ring) and a lifetime range (range ring)."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ab = os.path.join(root, "bevy_firework_amd", "csrc", "libfirework_hip_ab.so")
+    if not os.path.exists(ab):
+        pytest.skip("libfirework_hip_ab.so not built (make -C bevy_firework_amd/csrc ab)")
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np
+        import oracle
+        from bevy_firework_amd import settings as S
+        from bevy_firework_amd.system import ParticleSystem
+        from parity import Pair
+        DT = np.float32(1 / 60)
+        rings = %r
+        child_life = S.RandF32.constant(0.5) if rings == "fifo" else S.RandF32(0.4, 0.7)
+        sparks = S.ParticleSettings(lifetime=S.RandF32.constant(0.6) if rings == "fifo" else S.RandF32(0.5, 0.8), linear_drag=0.2)
+        smoke = S.ParticleSettings(lifetime=child_life, acceleration=(0.0, 0.5, 0.0))
+        e0 = S.EmissionSettings(particle_index=0, emission_pacing=S.EmissionPacing.rate(4000.0),
+                                initial_velocity=S.RandVec3(S.RandF32(1.0, 5.0), (0.0, 1.0, 0.0), 0.0))
+        e1 = S.EmissionSettings(particle_index=1, emission_mode=S.EmissionMode.Nested(0), inherit_parent_velocity=False,
+                                emission_pacing=S.EmissionPacing.CountOverDuration(6.0, 0.0, 0.0, 0.5))
+        with ParticleSystem(device=0, seed=11) as ps:
+            pair = Pair(ps, S.ParticleSpawner([sparks, smoke], [e0, e1]), seed=11, uid=3)
+            by = Pair(ps, S.ParticleSpawner([S.ParticleSettings(lifetime=S.RandF32.constant(1.0))],
+                                            [S.EmissionSettings(emission_pacing=S.EmissionPacing.rate(9000.0))]), seed=11, uid=4)
+            assert pair.gpu.update_path(1)[0] == rings, pair.gpu.update_path(1)
+            for fr in range(140):
+                ps.update(DT)
+                pair.step_cpu(DT), by.step_cpu(DT)
+                if fr %% 10 == 9 or fr in (59, 60, 61):
+                    pair.check(exact_all=True, what="frame %%d" %% fr)
+                    by.check(exact_all=True, what="bystander, frame %%d" %% fr)
+                if fr == 59:
+                    assert ps.recovered_rings() == 0 and pair.gpu.update_path(1)[0] == rings
+                if fr == 60:
+                    assert ps.recovered_rings() >= 1 and pair.gpu.update_path(1)[0] == "general", (ps.recovered_rings(), pair.gpu.update_path(1))
+            assert pair.gpu.count(1) > 5000 and pair.gpu.update_path(0)[0] in ("fifo", "range", "general")
+        print("RECOVERED-OK")
+    """) % (root, root, rings)
+    env = dict(os.environ, FW_ENABLE_KNOBS="1", FW_LIB_PATH=ab, FW_DEBUG="512", FW_SMALL="0")
+    env.update({"FW_FIFO": "1", "FW_FIFO_MIN": "0", "FW_RANGE": "0"} if rings == "fifo" else {"FW_FIFO": "0", "FW_RANGE": "1", "FW_RANGE_MIN": "0"})
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RECOVERED-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 # ---- fw_ctx::range_few: in a context of few segments a small type runs on a range ring too ------------------------------------
 def _defaults(monkeypatch, **env):
     for k in ("FW_ENABLE_KNOBS", "FW_FIFO", "FW_FIFO_MIN", "FW_RANGE", "FW_RANGE_MIN", "FW_RANGE_SMALL", "FW_RANGE_FEW", "FW_NOSPIN"):
