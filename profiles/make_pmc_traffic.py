@@ -8,12 +8,12 @@ import json
 import re
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r04/pmc_summary.txt"
+src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r06/pmc_summary.txt"
 txt = open(src).read()
 # the steady-state kernel of the bench: the in-place FIFO ring update (configs[1]'s particle type has one lifetime value; no
 # attached instance buffers, base / emissive / scale planes all written: write mask 7); with FW_FIFO=0 the streaming
 # kernel of the general path (forecast frames, inline spawn ops, per-tile forecast entries, lone segment)
-for kern in ("fw_k_update_fifo<false, 7, 0, false, 4>", "fw_k_update_fifo<false, 7, 0, false>", "fw_k_update_fifo<false, 7, 0>", "fw_k_update_fifo<false, 7>", "fw_k_update_stream<1, false, false, true>"):
+for kern in ("fw_k_update_fifo<false, 0, 0, false, 4>", "fw_k_update_fifo<false, 7, 0, false, 4>", "fw_k_update_fifo<false, 7, 0, false>", "fw_k_update_fifo<false, 7, 0>", "fw_k_update_fifo<false, 7>", "fw_k_update_stream<1, false, false, true>"):
     m = re.search(re.escape(kern) + r"\s+FETCH_SIZE=([0-9.e+]+)", txt)
     if m:
         break
