@@ -673,6 +673,15 @@ struct fw_ctx {
     // Types of up to wide_mid particles (four rounds of a workgroup) gain from a third of that on already: 256 x 600 14.9 against 16.8 us
     // per frame, 384 x 1000 19.3 against 23.1, 512 x 1000 20.3 against 25.6 (profiles/r05/mid_paths_sweep.txt); larger ones -- 1500
     // particles, six rounds -- lose up to 512 types (24.3 against 21.2) and win where the compacting launch no longer fits the chip.
+    // Round 6 (tools/threshold_sweep.py, tools/r06_wave_vs_workgroup.py): from about as many types as the chip has SIMDs (1024) a WAVE per
+    // type beats a WORKGROUP per type at EVERY size the kernel takes -- 1024 x 1000 particles 23.2 against 34.8 us per frame, 2048 x
+    // 1000 39.1 against 58.0, 2048 x 2000 58.6 against 85.9, 1024 x 300 20.3 against 28.5 -- while at 512 types the workgroup wins from
+    // 1000 particles on (16.4 against 19.1) and 768 types are a draw (profiles/r06/wave_vs_workgroup.txt): every SIMD holds a wave
+    // of its own either way, and the workgroup form pays a barrier and an LDS exchange per round for parallelism nobody lacks.  From
+    // wave_all_min eligible types on (off again below five sixths of it) the wide types of the context are laid out in the wave
+    // role: the same kernel, the same launch, only the list's partition (FwSmallArgs::n_narrow) moves.  FW_WAVE_ALL_MIN; 0: never
+    uint32_t wave_all_min = 896;
+    bool wave_all_on = false;
     uint32_t wide_min = 768;
     bool wide_on = false;      // wide types of more than wide_mid particles run on the kernel
     bool wide_mid_on = false;  // ... those of up to wide_mid do

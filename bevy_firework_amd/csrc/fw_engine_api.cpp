@@ -147,6 +147,7 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     if (const char *m = getenv("FW_WIDE_MAX")) ctx->wide_max = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_WIDE_MIN")) ctx->wide_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_WIDE_MID")) ctx->wide_mid = (uint32_t)strtoul(m, nullptr, 10);
+    if (const char *m = getenv("FW_WAVE_ALL_MIN")) ctx->wave_all_min = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_HOST_FAST")) ctx->host_fast = atoi(m) != 0;
     if (const char *m = getenv("FW_PARAM_BAR")) ctx->param_bar = ctx->param_bar && atoi(m) != 0;
     for (int i = 0; i < kParamRing && ctx->param_bar; i++)
@@ -1008,7 +1009,7 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t
     if (!sp || type >= sp->seg.size()) return FW_EINVAL;
     const SegHost &S = ctx->segs[sp->seg[type]];
     const TypeHost &T = sp->types[type];
-    if (mode) *mode = S.fifo ? 1 : (S.range ? 2 : (S.small ? (S.wide ? 4 : 3) : 0));
+    if (mode) *mode = S.fifo ? 1 : (S.range ? 2 : (S.small ? ((S.wide && !ctx->wave_all_on) ? 4 : 3) : 0));
     const uint32_t colours = (T.base.kind != 0 ? 16u : 0u) + (T.emis.kind != 0 ? 16u : 0u);  // one-key gradients: never rewritten
     uint32_t moved, algo;
     if (S.ring()) {

@@ -160,6 +160,10 @@ void update_small_mode(fw_ctx *ctx) {
     const uint32_t mid_at = ctx->wide_min / 3;  // (fw_ctx::wide_mid)
     const bool want_mid = ctx->use_small && ctx->wide_max != 0 &&
                           (ctx->wide_mid_on ? ctx->n_small_ok >= mid_at - mid_at / 4 : ctx->n_small_ok >= mid_at);
+    // ... and from wave_all_min types on EVERY type of the kernel -- wide ones included -- is walked by a wave (fw_ctx::wave_all_min)
+    const bool want_wave_all = ctx->use_small && ctx->wave_all_min != 0 &&
+                               (ctx->wave_all_on ? ctx->n_small_ok >= ctx->wave_all_min - ctx->wave_all_min / 6 : ctx->n_small_ok >= ctx->wave_all_min);
+    if (want_wave_all != ctx->wave_all_on) ctx->wave_all_on = want_wave_all, ctx->small_dirty = true;  // (the list is laid out by role)
     if (want == ctx->small_on && want_wide == ctx->wide_on && want_mid == ctx->wide_mid_on) return;
     ctx->small_on = want, ctx->wide_on = want_wide, ctx->wide_mid_on = want_mid;
     for (auto &S : ctx->segs)

@@ -1342,7 +1342,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
             ctx->small_list.clear();
             for (int wide = 0; wide < 2; wide++) {  // narrow types first, then the wide ones (FwSmallArgs::n_narrow)
                 for (uint32_t si = 0; si < n_seg; si++)
-                    if (ctx->segs[si].in_use && ctx->segs[si].small && (int)ctx->segs[si].wide == wide) ctx->small_list.push_back(si);
+                    if (ctx->segs[si].in_use && ctx->segs[si].small && (int)(ctx->segs[si].wide && !ctx->wave_all_on) == wide) ctx->small_list.push_back(si);
                 if (!wide) ctx->n_narrow = (uint32_t)ctx->small_list.size();
             }
             if (ctx->small_list.size() > ctx->small_cap) return poison_segment(ctx, kNoSeg, "small-type list overflow");

@@ -476,8 +476,13 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifo
 // ... with Nested entries inside the launch (FwFifoNest).  A kernel of its own so that the plain instantiations keep their code
 // and their register budget; pinned at 4 waves per SIMD (the nest phase took the four-round form to 133 VGPRs: the bulk of such
 // a launch is the child ring's streaming tiles, which want the fourth workgroup per CU)
+// (FW_NEST_WAVES: compile-time A/B -- `tools/build_variant.sh nest3 -DFW_NEST_WAVES=3` is the form without scratch,
+// profiles/r06/nest_waves_ab.txt)
+#ifndef FW_NEST_WAVES
+#define FW_NEST_WAVES 4
+#endif
 template <int NT, int TR>
-__global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void fw_k_update_fifo_nest(FwGlobals g, FwFifoArgs a, FwInlineOps inl) {
+__global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(FW_NEST_WAVES))) void fw_k_update_fifo_nest(FwGlobals g, FwFifoArgs a, FwInlineOps inl) {
     fw_update_fifo_body<false, -1, NT, false, TR, true>(g, a, inl);
 }
 

@@ -277,3 +277,26 @@ def test_small_types_next_to_a_large_destroy_on_collision_type(monkeypatch):
             got = pairs[7].gpu.instances(0)  # (packed on the main stream from a type the ring stream's launch updates)
             assert len(got) == n and n > 0
         assert bigp.gpu.count(0) > 5000 and {p.gpu.update_mode(0) for p in pairs[1:]} <= {0, 3, 4} and queued.gpu.count(0) > 100
+
+
+def test_from_about_a_thousand_types_on_every_small_type_is_walked_by_a_wave(monkeypatch):
+    """fw_ctx::wave_all_min (round 6: tools/threshold_sweep.py found a wave per type 27-44 % faster than a workgroup per type at 1024
+    emitters x 1000 particles): 930 emitters that sustain ~600 particles each -- wide types, a workgroup each among a few hundred --
+    run in the WAVE role of the same kernel; below five sixths of the threshold they are workgroups again.  The list's partition is
+    all that moves: particles against the oracle across both transitions."""
+    from bevy_firework_amd.system import ParticleSystem
+
+    _product_defaults(monkeypatch)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        hs = [system.spawn(_emitter(1500.0, 0.4, k), S.Transform((float(k % 31), 0.0, float(k // 31))), uid=20000 + k) for k in range(880)]
+        checked = [Pair(system, _emitter(1500.0 + 7.0 * k, 0.4, k), S.Transform((float(k), 1.0, 0.0)), seed=SEED, uid=21000 + k) for k in range(50)]
+        assert {p.gpu.update_mode(0) for p in checked} == {3} and hs[0].update_mode(0) == 3  # 930 eligible types: waves
+        _run(system, checked, 45, "930 mid-size types, a wave each", every=15)
+        assert checked[0].gpu.count(0) > 500
+        for h in hs[:250]:
+            system.despawn(h)
+        assert {p.gpu.update_mode(0) for p in checked} == {4} and hs[300].update_mode(0) == 4  # 680 < 747: workgroups
+        _run(system, checked, 30, "680 mid-size types, a workgroup each", every=15)
+        more = [system.spawn(_emitter(1500.0, 0.4, k), S.Transform((float(k % 31), 2.0, float(k // 31))), uid=23000 + k) for k in range(230)]
+        assert {p.gpu.update_mode(0) for p in checked} == {3} and more[0].update_mode(0) == 3     # 910: waves again
+        _run(system, checked, 30, "910 mid-size types, a wave each again", every=15)

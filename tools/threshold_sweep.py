@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Round 6: do the path thresholds of csrc/fw_engine.h -- range_few 192, small_min 352, wide_min 768,
-wide_mid 1400, range_min 8192 -- pick a path within 10 % of the BEST forced path on THIS box?
+wide_mid 1400, wave_all_min 896 (added because this sweep found the miss), range_min 8192 -- pick a path within 10 % of the BEST forced path on THIS box?
 
 Six (emitters x particles per emitter) points on either side of the thresholds; at each, us per frame (pipelined, best of 3 x 200 frames)
 of the product's own choice and of every forced path:
     range      every type on an in-place range ring whatever its size           FW_RANGE_MIN=0 FW_RANGE_FEW=100000 FW_SMALL=0
     compacting one workgroup chain per type on the compacting kernels            FW_RANGE_MIN=4000000000 FW_RANGE_FEW=0 FW_SMALL=0
     wave       one WAVE per type (fw_k_update_small, narrow role)                FW_RANGE_FEW=0 FW_SMALL_MIN=0 FW_SMALL_MAX=2000000000 FW_WIDE_MAX=0
-    workgroup  one WORKGROUP per type (fw_k_update_small, wide role)             FW_RANGE_FEW=0 FW_SMALL_MIN=0 FW_WIDE_MIN=0 FW_WIDE_MAX=2000000000 FW_SMALL_MAX=0
+    workgroup  one WORKGROUP per type (fw_k_update_small, wide role)             FW_RANGE_FEW=0 FW_SMALL_MIN=0 FW_WIDE_MIN=0 FW_WIDE_MAX=2000000000 FW_SMALL_MAX=0 FW_WAVE_ALL_MIN=0
 The last line says PASS when the product is within TOL (default 1.10) of the best at every point.  The GPU test
 tests/test_gpu_thresholds.py runs the same code at three of the points.      python tools/threshold_sweep.py      (GPU box)"""
 import os
@@ -22,12 +22,13 @@ from bevy_firework_amd import workloads  # noqa: E402
 from bevy_firework_amd.system import ParticleSystem  # noqa: E402
 
 DT = np.float32(1 / 60)
-KNOBS = ("FW_RANGE", "FW_RANGE_MIN", "FW_RANGE_FEW", "FW_SMALL", "FW_SMALL_MIN", "FW_SMALL_MAX", "FW_WIDE_MIN", "FW_WIDE_MAX", "FW_FIFO")
+KNOBS = ("FW_RANGE", "FW_RANGE_MIN", "FW_RANGE_FEW", "FW_SMALL", "FW_SMALL_MIN", "FW_SMALL_MAX", "FW_WIDE_MIN", "FW_WIDE_MAX", "FW_FIFO", "FW_WAVE_ALL_MIN")
 FORCED = {
     "range": {"FW_RANGE_MIN": "0", "FW_RANGE_FEW": "100000", "FW_SMALL": "0"},
     "compacting": {"FW_RANGE_MIN": "4000000000", "FW_RANGE_FEW": "0", "FW_SMALL": "0"},
     "wave": {"FW_RANGE_FEW": "0", "FW_RANGE_MIN": "4000000000", "FW_SMALL_MIN": "0", "FW_SMALL_MAX": "2000000000", "FW_WIDE_MAX": "0"},
-    "workgroup": {"FW_RANGE_FEW": "0", "FW_RANGE_MIN": "4000000000", "FW_SMALL_MIN": "0", "FW_WIDE_MIN": "0", "FW_WIDE_MAX": "2000000000", "FW_SMALL_MAX": "0"},
+    "workgroup": {"FW_RANGE_FEW": "0", "FW_RANGE_MIN": "4000000000", "FW_SMALL_MIN": "0", "FW_WIDE_MIN": "0", "FW_WIDE_MAX": "2000000000", "FW_SMALL_MAX": "0",
+                  "FW_WAVE_ALL_MIN": "0"},
 }
 # (emitters, particles per emitter): below / above range_few, around small_min, around wide_min / wide_mid, and the ring threshold
 POINTS = [(64, 700), (256, 300), (512, 300), (512, 1000), (1024, 1000), (256, 9000)]
