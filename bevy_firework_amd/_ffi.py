@@ -265,12 +265,13 @@ SYMBOLS = [
     ("fw_debug_param_bar", C.c_int, [_P, C.POINTER(C.c_int32)]),
     ("fw_debug_tile_scratch", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("fw_debug_recovered_rings", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("fw_debug_tf_frames", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("fw_compute_emission_count", C.c_uint64,
      [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]),
 ]
 
 # entry points added after round 4 (ABI 5 + a measurement hook): absent from the older builds the A/B tools load through FW_LIB_PATH
-NEWER_THAN_R04 = {"fw_debug_nest_frames", "fw_debug_param_bar", "fw_debug_tile_scratch", "fw_debug_recovered_rings", "fw_ctx_set_parent_velocities", "fw_ctx_set_modifiers", "fw_ctx_queue"}
+NEWER_THAN_R04 = {"fw_debug_nest_frames", "fw_debug_param_bar", "fw_debug_tile_scratch", "fw_debug_recovered_rings", "fw_debug_tf_frames", "fw_ctx_set_parent_velocities", "fw_ctx_set_modifiers", "fw_ctx_queue"}
 _lib = None
 
 

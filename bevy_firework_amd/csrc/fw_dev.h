@@ -707,6 +707,37 @@ __device__ __forceinline__ uint32_t fw_fce_prefix_part(const uint4 (&e)[FW_FCE_U
     return part;
 }
 
+// Threshold forecast, producer side (FwUpdateArgs::fc_theta): a stored survivor that a step of `theta` would destroy leaves its
+// (age, lifetime) in the tile's list -- from the front when it was stored into output tile A (o < fc_bnd), from the back otherwise.
+// s_tf: two LDS counters of the workgroup (zeroed before the first round).  Wave-uniform fast exit: nobody is risky in most rounds.
+__device__ __forceinline__ void fw_tf_note(float theta, float2 *list, uint32_t *s_tf, bool alive, float age_new, float lifetime,
+                                           uint32_t o, uint32_t fc_bnd) {
+    const bool risky = alive && (age_new + theta >= lifetime);  // == !fw_survives(age_new, theta, lifetime)
+    const unsigned long long mr = __ballot(risky);
+    if (mr == 0ull) return;
+    const bool ra = risky && o < fc_bnd, rb = risky && !(o < fc_bnd);
+    const unsigned long long ma = __ballot(ra), mb = __ballot(rb);
+    uint32_t ba = 0, bb = 0;
+    if ((threadIdx.x & 63u) == 0u) {
+        if (ma) ba = atomicAdd(&s_tf[0], (uint32_t)__popcll(ma));
+        if (mb) bb = atomicAdd(&s_tf[1], (uint32_t)__popcll(mb));
+    }
+    ba = __builtin_amdgcn_readfirstlane(ba), bb = __builtin_amdgcn_readfirstlane(bb);
+    if (ra) {
+        const uint32_t i = ba + fw_lane_prefix(ma);
+        if (i < FW_TF_K) list[i] = make_float2(age_new, lifetime);
+    } else if (rb) {
+        const uint32_t j = bb + fw_lane_prefix(mb);
+        if (j < FW_TF_K) list[FW_TF_K - 1u - j] = make_float2(age_new, lifetime);
+    }
+}
+// ... and the tile's header once all its rounds are done (one thread; the counters are final: a barrier lies in between)
+__device__ __forceinline__ void fw_tf_header(uint4 *fct, uint32_t tile, const uint32_t *s_tf, uint32_t excl, uint32_t run, uint32_t fc_bnd) {
+    const uint32_t ta = min(run, fc_bnd) - min(excl, fc_bnd), tb = (run - excl) - ta;
+    const uint32_t na = s_tf[0], nb = s_tf[1];
+    fct[tile] = make_uint4(ta, tb, (na + nb > FW_TF_K) ? 0xFFFFFFFFu : (na | (nb << 16)), excl);
+}
+
 // every workgroup (active or not) clears its own slot of the buffer the frame after the next will accumulate into
 __device__ __forceinline__ void fw_fc_housekeeping(const FwUpdateArgs &a) {
     if (threadIdx.x == 0 && a.fc_zero) {

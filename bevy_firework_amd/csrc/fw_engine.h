@@ -618,6 +618,21 @@ struct fw_ctx {
     uint32_t fc_dt_bits = 0;   // ... computed for this dt
     uint64_t fc_tab_seq = 0;   // ... under this tile table
     bool use_forecast = true;  // FW_FORECAST=0 disables (A/B, debugging)
+    // Threshold forecast (round 6, fw_kernels.h: FwUpdateArgs::fc_theta, fw_k_fc_resolve): a dt that does NOT repeat used to send every
+    // compacting frame through the decoupled look-back (configs[2] on this path: 400 us per frame against 247 with a forecast).
+    // Once the host has seen dt change, forecast frames of tf_min_tiles tiles or more (per-tile entries only) also leave, per tile,
+    // the survivors a step of theta = 1.25 dt would destroy; the next frame, whatever its dt below that theta, runs fw_k_fc_resolve
+    // (a wave per tile: ~3 us) in front of the streaming kernel instead of the look-back schedule.  A dt at or beyond theta, a
+    // changed tile table, sums-format forecasts and small frames (a look-back costs them less than a launch) take the look-back as before.
+    // FW_TF=0 switches it off, FW_TF_MIN_TILES=n (the tests: 0).
+    bool use_tf = true;
+    uint32_t tf_min_tiles = 2048;
+    uint4 *d_fct = nullptr;     // [2][tiles_cap] headers, double-buffered like d_fce
+    float2 *d_fcl = nullptr;    // [2][tiles_cap][FW_TF_K] (age, lifetime) of the risky survivors
+    size_t tf_cap = 0;          // tiles_cap the two arrays were allocated for (0: not yet)
+    uint32_t tf_armed = 0;      // frames left in which producers write lists (re-armed whenever dt differs from the last frame's)
+    float tf_prev_theta = 0.0f; // theta the PREVIOUS forecast frame's lists were made for (0: it made none)
+    uint64_t tf_frames = 0;     // frames that ran fw_k_fc_resolve + the streaming schedule instead of the look-back
     bool use_static_new = true;  // static output slots for new particles when all of them survive (FW_STATIC_NEW)
     uint32_t snap_every = kSnapEvery;  // frames between live-count snapshots (FW_SNAP_EVERY)
     bool use_stream = true;    // FW_STREAM=0: forecast frames keep the count-park-store kernel (A/B)

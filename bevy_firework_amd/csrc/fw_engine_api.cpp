@@ -125,6 +125,8 @@ fw_status fw_ctx_create(int device, uint32_t seed, void *stream, fw_ctx **out) {
     // -- path selectors: every one of them names a path the product takes by itself under some workload; the tests force each
     if (const char *m = getenv("FW_UPDATE_MODE")) ctx->update_mode = !strcmp(m, "split") ? FW_MODE_SPLIT : FW_MODE_FUSED;
     if (const char *m = getenv("FW_FORECAST")) ctx->use_forecast = atoi(m) != 0;
+    if (const char *m = getenv("FW_TF")) ctx->use_tf = atoi(m) != 0;
+    if (const char *m = getenv("FW_TF_MIN_TILES")) ctx->tf_min_tiles = (uint32_t)strtoul(m, nullptr, 10);
     if (const char *m = getenv("FW_STREAM")) ctx->use_stream = atoi(m) != 0;
     if (const char *m = getenv("FW_STATIC_NEW")) ctx->use_static_new = atoi(m) != 0;  // 0: always count + look back
     if (const char *m = getenv("FW_SPIN_LIMIT")) ctx->spin_limit = (uint32_t)strtoul(m, nullptr, 10);
@@ -224,6 +226,8 @@ fw_status fw_ctx_destroy(fw_ctx *ctx) {
         if (ctx->h_keys[i]) hipHostFree(ctx->h_keys[i]);
     if (ctx->d_fc) hipFree(ctx->d_fc);
     if (ctx->d_fce) hipFree(ctx->d_fce);
+    if (ctx->d_fct) hipFree(ctx->d_fct);
+    if (ctx->d_fcl) hipFree(ctx->d_fcl);
     if (ctx->h_snap) hipHostFree(ctx->h_snap);
     if (ctx->h_aabb) hipHostFree(ctx->h_aabb);
     if (ctx->h_done) hipHostFree(ctx->h_done);
@@ -1063,6 +1067,11 @@ fw_status fw_debug_tile_scratch(fw_ctx *ctx, uint64_t *table_tiles, uint64_t *sc
 fw_status fw_debug_recovered_rings(fw_ctx *ctx, uint64_t *n) {
     if (!ctx || !n) return FW_EINVAL;
     *n = ctx->recovered_rings;
+    return FW_OK;
+}
+fw_status fw_debug_tf_frames(fw_ctx *ctx, uint64_t *n) {
+    if (!ctx || !n) return FW_EINVAL;
+    *n = ctx->tf_frames;
     return FW_OK;
 }
 fw_status fw_debug_param_bar(fw_ctx *ctx, int32_t *on) {  // fw_ctx::param_bar

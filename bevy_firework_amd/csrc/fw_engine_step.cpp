@@ -648,6 +648,44 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
         a.fce_out = ctx->d_fce + (size_t)(ctx->fc_seq & 1u) * ctx->tiles_cap;
         a.fce_in = ctx->d_fce + (size_t)((ctx->fc_seq + 1u) & 1u) * ctx->tiles_cap;
         if (usable) a.fc_in = ctx->d_fc + (size_t)((ctx->fc_seq + 2u) % 3u) * ctx->fc_len;
+        // ---- threshold forecast (fw_ctx::use_tf): a dt that differs from the previous frame's, below the theta its lists were made for
+        const bool dt_same = ctx->fc_dt_bits == dt_bits;
+        const bool tf_size = ctx->use_tf && !a.fc_sums && total_tiles >= ctx->tf_min_tiles && a.use_stream && dt > 0.0f && std::isfinite(dt);
+        if (!usable && tf_size && ctx->tf_prev_theta > 0.0f && dt < ctx->tf_prev_theta && !dt_same && ctx->fc_ok &&
+            ctx->fc_tab_seq == ctx->tab_seq && a.epoch != 1u && ctx->fc_sums_prev == a.fc_sums && (!legacy || a.new_static) &&
+            ctx->tf_cap == ctx->tiles_cap) {
+            FwResolveArgs ra{};
+            ra.fce = ctx->d_fce + (size_t)((ctx->fc_seq + 1u) & 1u) * ctx->tiles_cap;
+            ra.fct = ctx->d_fct + (size_t)((ctx->fc_seq + 1u) & 1u) * ctx->tiles_cap;
+            ra.fcl = ctx->d_fcl + (size_t)((ctx->fc_seq + 1u) & 1u) * ctx->tiles_cap * FW_TF_K;
+            ra.tile_desc = n_seg == 1 ? nullptr : ctx->d_tile_desc;
+            ra.total_tiles = total_tiles, ra.parity = p, ra.epoch = a.epoch, ra.dt = dt;
+            FW_HIP(ctx, fw_launch_fc_resolve(ctx->stream, ctx->g, ra));
+            a.fc_in = ctx->d_fc + (size_t)((ctx->fc_seq + 2u) % 3u) * ctx->fc_len;  // (per-tile entries: only its non-nullness matters)
+            ctx->tf_frames++;
+        }
+        // producers: lists for the NEXT frame while dt has been seen to vary (64 frames after the last change)
+        if (!dt_same && ctx->fc_ok) ctx->tf_armed = 64u;
+        ctx->tf_prev_theta = 0.0f;
+        if (tf_size && ctx->tf_armed) {
+            ctx->tf_armed--;
+            if (ctx->tf_cap != ctx->tiles_cap) {  // (first use, or the tile scratch grew: ensure_tile_arrays)
+                if (ctx->d_fct) (void)hipFree(ctx->d_fct), ctx->d_fct = nullptr;
+                if (ctx->d_fcl) (void)hipFree(ctx->d_fcl), ctx->d_fcl = nullptr;
+                ctx->tf_cap = 0;
+                if (hipMalloc((void **)&ctx->d_fct, 2 * ctx->tiles_cap * sizeof(uint4)) == hipSuccess &&
+                    hipMalloc((void **)&ctx->d_fcl, 2 * ctx->tiles_cap * FW_TF_K * sizeof(float2)) == hipSuccess)
+                    ctx->tf_cap = ctx->tiles_cap;
+                else
+                    (void)hipGetLastError();  // (no memory for the lists: the look-back schedule stays)
+            }
+            if (ctx->tf_cap == ctx->tiles_cap) {
+                a.fc_theta = dt * 1.25f;
+                a.fct_out = ctx->d_fct + (size_t)(ctx->fc_seq & 1u) * ctx->tiles_cap;
+                a.fcl_out = ctx->d_fcl + (size_t)(ctx->fc_seq & 1u) * ctx->tiles_cap * FW_TF_K;
+                ctx->tf_prev_theta = a.fc_theta;
+            }
+        }
         ctx->fc_seq++;
         ctx->fc_sums_prev = a.fc_sums;
         if (ctx->trace)

@@ -50,8 +50,10 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     __shared__ uint32_t s_wcnt[R + 1][NW];  // row R: the extra round of a tile that carries its segment's few new particles
     __shared__ uint32_t s_lb[2 * LBW * NW];
     __shared__ uint32_t s_part[4][NW];  // per-wave partials: forecast prefix, new survivors, next-frame sums A / B
+    __shared__ uint32_t s_tf[2];        // threshold forecast: risky survivors noted so far (into A / into A + 1)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_tf[0] = 0u, s_tf[1] = 0u;  // (the count barrier lies between this and the first round)
     const unsigned long long ts0 = FW_DBG(a.dbg, 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // workgroup -> (segment, tile in segment): one table read instead of a dependent binary search
     uint32_t seg, first, seg_tiles, type_idx;
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     if (n_tot == 0 || tis >= n_act) {
         if (tid == 0) {
             if (fc_out && fc_small) a.fce_out[tile] = make_uint4(0u, 0u, 0u, a.epoch);  // contributes nothing next frame
+            if (fc_out && fc_small && a.fc_theta > 0.0f) a.fct_out[tile] = make_uint4(0u, 0u, 0u, 0u);
             if (n_tot == 0 && tis == 0) {  // empty segment: its first tile still owns the bookkeeping
                 g.count[oidx] = 0;
                 g.spawned[oidx] = 0;
@@ -348,6 +351,8 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     const FwOutWin W = fw_out_window(ob, C, excl, T, a.force_colors, n_lplanes);
     const uint32_t fcA = excl / FW_TILE, fc_bnd = (fcA + 1u) * FW_TILE;  // output tiles this workgroup feeds
     uint32_t fa = 0, fb = 0;
+    const float tf_theta = (fc_out && fc_small) ? a.fc_theta : 0.0f;  // threshold forecast (fw_kernels.h): per-tile entries only
+    float2 *tf_list = tf_theta > 0.0f ? a.fcl_out + (size_t)tile * FW_TF_K : nullptr;
     float box[6] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f, FW_F32_MIN, FW_F32_MIN, FW_F32_MIN};
     const bool box_on = a.boxes != 0u;  // workgroup-uniform
     uint32_t run = excl;  // output slot of the first survivor of (round r, wave 0)
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             const bool nx = alive && fw_survives(age_new, a.dt, q3.w, &an2);
             fa += (uint32_t)__popcll(__ballot(nx && o < fc_bnd));
             fb += (uint32_t)__popcll(__ballot(nx && o >= fc_bnd));
+            if (tf_theta > 0.0f) fw_tf_note(tf_theta, tf_list, s_tf, alive, age_new, q3.w, o, fc_bnd);
         }
         if (alive && FW_DBG(a.dbg, 2u)) {  // profiling only: stream without arithmetic
             const uint32_t b16 = (o - W.first) * 16u;
@@ -432,6 +438,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             const bool nx = alive && fw_survives(age_new, a.dt, so.q3.w, &an2);
             fa += (uint32_t)__popcll(__ballot(nx && o < fc_bnd));
             fb += (uint32_t)__popcll(__ballot(nx && o >= fc_bnd));
+            if (tf_theta > 0.0f) fw_tf_note(tf_theta, tf_list, s_tf, alive, age_new, so.q3.w, o, fc_bnd);
         }
         if (alive) {
             float4 rec[4];
@@ -455,6 +462,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             for (int w = 0; w < NW; w++) sa += s_part[2][w], sb += s_part[3][w];
             if (fc_small) a.fce_out[tile] = make_uint4(sa, sb, fcA, a.epoch);
             else fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, seg_tiles);
+            if (tf_theta > 0.0f) fw_tf_header(a.fct_out, tile, s_tf, excl, excl + cnt, fc_bnd);  // (cnt: every survivor of the tile)
         }
     }
     if (a.boxes) {
@@ -511,12 +519,14 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
                                                 const FwOutWin &W, char *destroyed, bool want_destroyed, uint32_t C,
                                                 uint32_t n_lplanes, bool forecast, uint32_t fc_bnd, FwRoundOut &acc,
                                                 float4 *rec = nullptr, float *box = nullptr, bool box_on = false,
-                                                bool fresh = false) {  // fresh: materialised this frame, never updated
+                                                bool fresh = false, float tf_theta = 0.0f, float2 *tf_list = nullptr,
+                                                uint32_t *s_tf = nullptr) {  // fresh: materialised this frame, never updated
     if (forecast) {  // will it survive one more step of the same dt?  (same expression as fw_survives)
         float an2;
         const bool nx = alive && fw_survives(age_new, dt, q3.w, &an2);
         acc.fa += (uint32_t)__popcll(__ballot(nx && o < fc_bnd));
         acc.fb += (uint32_t)__popcll(__ballot(nx && o >= fc_bnd));
+        if (tf_theta > 0.0f) fw_tf_note(tf_theta, tf_list, s_tf, alive, age_new, q3.w, o, fc_bnd);  // (workgroup-uniform)
     }
     if (alive && FW_DBG(dbg, 2u)) {  // profiling only: stream without arithmetic
         const uint32_t b16 = (o - W.first) * 16u;
@@ -553,8 +563,10 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     __shared__ uint32_t s_c[2][NW];     // survivors per wave of the current round (double-buffered)
     __shared__ uint32_t s_lb[2 * LBW * NW];
     __shared__ uint32_t s_part[4][NW];  // per-wave partials: forecast prefix, new survivors, next-frame sums A / B
+    __shared__ uint32_t s_tf[2];        // threshold forecast: risky survivors noted so far (into A / into A + 1)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_tf[0] = 0u, s_tf[1] = 0u;  // (a barrier lies between this and the first round)
     const unsigned long long ts0 = FW_DBG(a.dbg, 8u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t seg, first, seg_tiles, type_idx, keys_off, keys_len;
     if (LONE) {
@@ -673,6 +685,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     if (n_tot == 0 || tis >= n_act) {
         if (tid == 0) {
             if (fc_small) a.fce_out[tile] = make_uint4(0u, 0u, 0u, a.epoch);
+            if (fc_small && a.fc_theta > 0.0f) a.fct_out[tile] = make_uint4(0u, 0u, 0u, 0u);
             if (n_tot == 0 && tis == 0) {
                 g.count[oidx] = 0;
                 g.spawned[oidx] = 0;
@@ -693,6 +706,8 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     }
     if (blockIdx.x == 0 && tid == 0 && a.live_next) *a.live_next = 0ull;
     if (blockIdx.x == 0 && tid == 0 && a.done_tag) *a.done_tag = a.done_value;
+    const float tf_theta = fc_small ? a.fc_theta : 0.0f;  // (threshold forecast: per-tile entries only)
+    float2 *tf_list = tf_theta > 0.0f ? a.fcl_out + (size_t)tile * FW_TF_K : nullptr;
 
     const unsigned long long tsA = FW_DBG(a.dbg, 8u) ? (__builtin_amdgcn_s_memrealtime() + (C & 0u)) : 0ull;
     // round 0 of a live tile goes out now (unless the speculative request above already covers it)
@@ -856,7 +871,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             // the lane's instance record goes to its rank in the wave's LDS area as soon as each part is computed
             float4 *rec = (INST && inst != nullptr) ? s_inst + wave * 256u + (o - wbase) * 4u : nullptr;
             fw_round_finish(T, s_keys, a.dt, a.dbg, q0c, q1c, q2c, q3c, valid, alive, true, age_new, idx, o, ib, ob, W,
-                            destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec, box, box_on, idx >= n_in);
+                            destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec, box, box_on, idx >= n_in, tf_theta, tf_list, s_tf);
             if (INST && inst != nullptr && !FW_DBG(a.dbg, 2u)) fw_inst_flush(inst, inst_cap, s_inst + wave * 256u, lane, m, wbase);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n, lfc = lfn;
             if (FW_DBG(a.dbg, 8u) && r == 0) tsR1 = __builtin_amdgcn_s_memrealtime() + (o & 0u);
@@ -907,7 +922,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             const uint32_t o = wbase + fw_lane_prefix(m);
             float4 *rec = (INST && inst != nullptr) ? s_inst + wave * 256u + (o - wbase) * 4u : nullptr;
             fw_round_finish(T, s_keys, a.dt, a.dbg, so.q0, so.q1, so.q2, so.q3, valid, alive, false, age_new, idx, o, ib,
-                            ob, W, destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec, box, box_on);
+                            ob, W, destroyed, want_destroyed, C, n_lplanes, true, fc_bnd, acc, rec, box, box_on, false, tf_theta, tf_list, s_tf);
             if (INST && inst != nullptr && !FW_DBG(a.dbg, 2u)) fw_inst_flush(inst, inst_cap, s_inst + wave * 256u, lane, m, wbase);
         }
 #undef FW_OPS
@@ -920,6 +935,7 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         for (int w = 0; w < NW; w++) sa += s_part[2][w], sb += s_part[3][w];
         if (fc_small) a.fce_out[tile] = make_uint4(sa, sb, fcA, a.epoch);
         else fw_fc_add(fc_out, a.fc_s2, first + fcA, sa, sb, seg_tiles);
+        if (tf_theta > 0.0f) fw_tf_header(a.fct_out, tile, s_tf, excl, run, fc_bnd);
     }
     if (a.boxes) fw_tile_box_flush<NW>(g.tile_box, tile, a.epoch, box, reinterpret_cast<float (*)[6]>(s_lb));
     if (FW_DBG(a.dbg, 8u) && g.dbg_ts && tid == 0) {
@@ -1170,6 +1186,58 @@ static void fw_launch_update_r(hipStream_t s, const FwGlobals &g, const FwUpdate
     } else {
         FW_LAUNCH_T((fw_k_update<true, FW_SPAWN_NONE, R, INST, SUMS>), grid, block, s, e0, e1, g, a, io);
     }
+}
+
+// ---------------------------------------------------------------------------------
+// fw_k_fc_resolve (round 6): the previous frame's forecast entries -- "survivors of one more step of the SAME dt" -- turned into the
+// forecast for THIS frame's dt (threshold forecast, fw_kernels.h).  One wave per tile of the previous update: its stored
+// survivors minus those of its risky ones that a step of `dt` destroys -- fw_survives on the listed (age, lifetime) pairs, the
+// update's own expression on the update's own operands, so the counts are what a counting pass over the particles would find.
+// A tile that listed more than FW_TF_K risky survivors (lifetimes of a few frames) is recounted from the particles it stored:
+// slots [first, first + n) of this frame's input buffer.  Everybody not listed survives any dt below the previous frame's theta
+// (fp32 addition is monotone in dt); the host launches this only for such a dt.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(FW_BLOCK) void fw_k_fc_resolve(FwGlobals g, FwResolveArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * (FW_BLOCK / 64u) + (threadIdx.x >> 6);
+    if (tile >= a.total_tiles) return;
+    const uint4 e = a.fce[tile];
+    if (e.w != a.epoch - 1u) return;  // (not written by the previous update: the consumer's own tag check reports it)
+    const uint4 h = a.fct[tile];
+    const uint32_t ta = h.x, tb = h.y;
+    uint32_t da = 0, db = 0;  // risky survivors this dt destroys: stored into A / into A + 1
+    if (h.z != 0xFFFFFFFFu) {
+        const uint32_t na = h.z & 0xFFFFu, nb = h.z >> 16;
+        const float2 *L = a.fcl + (size_t)tile * FW_TF_K;
+        if (lane < na + nb) {
+            const bool isb = lane >= na;
+            const float2 v = L[isb ? FW_TF_K - 1u - (lane - na) : lane];
+            float an;
+            const bool dies = !fw_survives(v.x, a.dt, v.y, &an);
+            da = (dies && !isb) ? 1u : 0u, db = (dies && isb) ? 1u : 0u;
+        }
+    } else {
+        const uint32_t seg = a.tile_desc ? a.tile_desc[tile].x : 0u;
+        const FwSeg &S = g.segs[seg];
+        const char *ib = S.buf[a.parity];
+        const uint32_t C = S.capacity, fc_bnd = (e.z + 1u) * FW_TILE;
+        const bool nospin = (g.types[S.type_idx].flags & FW_TYPE_NOSPIN) != 0u;
+        for (uint32_t i = h.w + lane; i < h.w + ta + tb; i += 64u) {
+            const float age = fw_ld4(ib + FW_OFF_Q0(C), i).w;
+            const float lf = fw_load_q3(ib, C, S.n_lplanes, i, nospin).w;
+            float an;
+            const bool dies = !fw_survives(age, a.dt, lf, &an);
+            da += (dies && i < fc_bnd) ? 1u : 0u, db += (dies && !(i < fc_bnd)) ? 1u : 0u;
+        }
+    }
+    da = fw_wave_sum(da), db = fw_wave_sum(db);
+    if (lane == 0) a.fce[tile] = make_uint4(ta - da, tb - db, e.z, e.w);
+}
+hipError_t fw_launch_fc_resolve(hipStream_t s, const FwGlobals &g, const FwResolveArgs &a) {
+    if (!a.total_tiles) return hipSuccess;
+    const uint32_t per = FW_BLOCK / 64u;
+    hipLaunchKernelGGL(fw_k_fc_resolve, dim3((a.total_tiles + per - 1u) / per), dim3(FW_BLOCK), 0, s, g, a);
+    return hipGetLastError();
 }
 
 hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps *inl,

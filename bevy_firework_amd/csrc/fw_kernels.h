@@ -128,6 +128,27 @@ struct FwUpdateArgs {
     uint32_t boxes;    // 1: every tile also leaves the box of position -/+ scale of its survivors in FwGlobals::tile_box
     uint32_t fc_sums;  // 1: some segment exceeds FW_FC_DIRECT tiles -> this launch uses the sums (all segments)
     uint32_t fc_s2, fc_tag;
+    // Threshold forecast (round 6, per-tile entries only): the forecast above counts the survivors of ONE more step of the SAME dt.
+    // With fc_theta > 0 every tile also leaves what the next frame needs to turn its entry into the forecast for ANY dt' < fc_theta:
+    // fct_out[tile] = {survivors stored into output tile A, into A + 1, nA | nB << 16 (0xFFFFFFFF: more than FW_TF_K), first
+    // output slot} and the (age, lifetime) pairs of the "risky" survivors -- those a step of fc_theta would destroy -- in
+    // fcl_out[tile * FW_TF_K ..]: the ones stored into A from the front, those into A + 1 from the back.  fw_k_fc_resolve
+    // (a wave per tile, launched in front of the next update when its dt differs) evaluates fw_survives(age, dt', lifetime) on
+    // the pairs -- the update's own expression -- and rewrites the entry's two counts: the streaming schedule then runs as if
+    // dt had repeated.  Everybody else survives any dt' < fc_theta (fp32 addition is monotone).
+    float fc_theta;
+    uint4 *fct_out;
+    float2 *fcl_out;
+};
+#define FW_TF_K 64u
+// fw_k_fc_resolve: the previous frame's entries / headers / lists, this frame's dt and parity
+struct FwResolveArgs {
+    uint4 *fce;            // entries of the previous frame (this frame's fce_in): .x / .y are rewritten
+    const uint4 *fct;
+    const float2 *fcl;
+    const uint4 *tile_desc;  // tile -> {segment, ...} (null: one segment)
+    uint32_t total_tiles, parity, epoch;
+    float dt;
 };
 
 // small frames carry their spawn ops in the kernel arguments: no H2D copy, no extra dependency
@@ -321,6 +342,7 @@ enum { FW_MODE_FUSED = 0, FW_MODE_SPLIT = 1, FW_MODE_SPLIT_COLL = 2 };  // SPLIT
 // d_ops: device table, or null -> the (at most FW_INLINE_OPS) ops at h_ops travel in the kernel arguments
 hipError_t fw_launch_spawn(hipStream_t s, const FwGlobals &g, const FwOp *d_ops, const FwOp *h_ops, uint32_t n_ops,
                            uint32_t total_blocks, uint32_t parity);
+hipError_t fw_launch_fc_resolve(hipStream_t s, const FwGlobals &g, const FwResolveArgs &a);
 hipError_t fw_launch_update(hipStream_t s, const FwGlobals &g, const FwUpdateArgs &a, const FwInlineOps *inl,
                             int spawn_form, int mode, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // in-place update of up to FW_FIFO_PER_LAUNCH FIFO segments (their spawn ops in `inl`)

@@ -353,6 +353,12 @@ class ParticleSystem:
         self._check(self._lib.fw_debug_tile_scratch(self._ctx, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    def tf_frames(self) -> int:
+        """frames whose dt differed from the previous one's and that ran fw_k_fc_resolve + the streaming schedule (threshold forecast)"""
+        n = C.c_uint64()
+        self._check(self._lib.fw_debug_tf_frames(self._ctx, C.byref(n)))
+        return int(n.value)
+
     def recovered_rings(self) -> int:
         """rings moved to the compacting path (particles kept) because a cohort report was missing when it was due"""
         n = C.c_uint64()

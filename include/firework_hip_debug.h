@@ -59,6 +59,10 @@ fw_status fw_debug_tile_scratch(fw_ctx *ctx, uint64_t *table_tiles, uint64_t *sc
  * recoverable) */
 fw_status fw_debug_recovered_rings(fw_ctx *ctx, uint64_t *n);
 
+/* frames of the compacting launch that ran under a dt different from the previous frame's on the STREAMING schedule (threshold
+ * forecast: fw_k_fc_resolve in front of fw_k_update_stream) instead of the decoupled look-back */
+fw_status fw_debug_tf_frames(fw_ctx *ctx, uint64_t *n);
+
 /* *on = 1: the context keeps the per-frame records of its range launches and its small op tables in DEVICE memory that the host writes
  * through the large BAR; 0: in pinned host memory (the platform does not map device memory for the host, or
  * FW_PARAM_BAR=0) */

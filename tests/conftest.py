@@ -39,7 +39,7 @@ def pytest_collection_modifyitems(config, items):
 # both switched off (everything on the general, compacting path).  The knobs are read when a context is created, so setting
 # the environment before the test body is enough.
 def pytest_generate_tests(metafunc):
-    if metafunc.module.__name__.split(".")[-1] in ("test_gpu_range", "test_gpu_lifecycle", "test_gpu_host_fast", "test_gpu_thresholds"):
+    if metafunc.module.__name__.split(".")[-1] in ("test_gpu_range", "test_gpu_lifecycle", "test_gpu_host_fast", "test_gpu_thresholds", "test_gpu_vardt"):
         return  # (set their own knobs: every test of test_gpu_range is about one path, the other two run at product defaults)
     if metafunc.definition.get_closest_marker("gpu") and "fw_path" in metafunc.fixturenames:
         metafunc.parametrize("fw_path", ["fifo", "range", "general", "small"], indirect=True)
@@ -108,10 +108,14 @@ def fw_path(request, monkeypatch):
     elif mode == "general":
         monkeypatch.setenv("FW_FIFO", "0")
         monkeypatch.setenv("FW_RANGE", "0")
+        # (round 6: the threshold forecast -- fw_k_fc_resolve in front of the streaming kernel when dt differs from the previous
+        # frame's -- engages from 2048 tiles on in the product; half of the test functions run it at any size)
+        if (_name_bits(request) >> 7) & 1:
+            monkeypatch.setenv("FW_TF_MIN_TILES", "0")
     if mode is not None:
         # which instantiations this test function ran (the choice depends on the test's name -- it is in the log of
         # a failing test and in the junit properties)
-        variant = {k: os.environ.get(k) for k in ("FW_PARAM_BAR", "FW_DERIVED", "FW_FIFO_SMALL", "FW_RANGE_SMALL", "FW_SMALL_MAX", "FW_WIDE_MAX")
+        variant = {k: os.environ.get(k) for k in ("FW_PARAM_BAR", "FW_DERIVED", "FW_FIFO_SMALL", "FW_RANGE_SMALL", "FW_SMALL_MAX", "FW_WIDE_MAX", "FW_TF_MIN_TILES")
                    if os.environ.get(k) is not None}
         request.node.user_properties.append(("fw_variant", f"{mode}: {variant}"))
         print(f"[fw variant] path={mode} {variant}")

@@ -14,10 +14,11 @@ n_em = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 live = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 jit = [np.float32((1.0 / 60.0) * (1.0 + 0.1 * np.sin(0.7 * k))) for k in range(64)]
 fixed = [np.float32(1.0 / 60.0)] * 64
-for name, env, dts in (("forecast (fixed dt)", {}, fixed), ("look-back (variable dt)", {}, jit),
-                       ("split: count -> scan -> update (variable dt)", {"FW_UPDATE_MODE": "split"}, jit),
-                       ("look-back, FW_STATIC_NEW=0 (variable dt)", {"FW_STATIC_NEW": "0"}, jit)):
-    for k in ("FW_UPDATE_MODE", "FW_STATIC_NEW"):
+for name, env, dts in (("forecast (fixed dt)", {}, fixed),
+                       ("threshold forecast: resolve + stream (variable dt; the product)", {}, jit),
+                       ("decoupled look-back, FW_TF=0 (variable dt; rounds 1-5)", {"FW_TF": "0"}, jit),
+                       ("split: count -> scan -> update (variable dt)", {"FW_UPDATE_MODE": "split", "FW_TF": "0"}, jit)):
+    for k in ("FW_UPDATE_MODE", "FW_STATIC_NEW", "FW_TF"):
         os.environ.pop(k, None)
     os.environ["FW_RANGE"] = "0"
     os.environ.update(env)
@@ -41,5 +42,5 @@ for name, env, dts in (("forecast (fixed dt)", {}, fixed), ("look-back (variable
         h = next(iter(ps.spawners.values()))
         mode, moved, algo = h.update_path(0)
         k_us = ev_ms * 1e3 / max(launches, 1)
-        print(f"{name:48s} {best:7.1f} us per frame   update launches {k_us:7.1f} us   path {mode} {moved} B moved / {algo} B algorithmic"
+        print(f"{name:68s} tf frames {ps.tf_frames():4d}  {best:7.1f} us per frame   update launches {k_us:7.1f} us   path {mode} {moved} B moved / {algo} B algorithmic"
               f"   {parts / max(launches, 1) * algo / (k_us * 1e-6) / 8e12:.3f} of 8 TB/s", flush=True)
