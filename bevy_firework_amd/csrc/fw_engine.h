@@ -626,7 +626,7 @@ struct fw_ctx {
     // changed tile table, sums-format forecasts and small frames (a look-back costs them less than a launch) take the look-back as before.
     // FW_TF=0 switches it off, FW_TF_MIN_TILES=n (the tests: 0).
     bool use_tf = true;
-    uint32_t tf_min_tiles = 2048;
+    uint32_t tf_min_tiles = 768;  // (tools/r06_tf_min_tiles.py: 977 tiles 30.1 -> 22.2 us per frame, 256 tiles 17.0 -> 18.2)
     uint4 *d_fct = nullptr;     // [2][tiles_cap] headers, double-buffered like d_fce
     float2 *d_fcl = nullptr;    // [2][tiles_cap][FW_TF_K] (age, lifetime) of the risky survivors
     size_t tf_cap = 0;          // tiles_cap the two arrays were allocated for (0: not yet)

@@ -1202,32 +1202,55 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_fc_resolve(FwGlobals g, FwResol
     const uint32_t tile = blockIdx.x * (FW_BLOCK / 64u) + (threadIdx.x >> 6);
     if (tile >= a.total_tiles) return;
     const uint4 e = a.fce[tile];
+    const uint4 h = a.fct[tile];  // (requested together with the entry)
     if (e.w != a.epoch - 1u) return;  // (not written by the previous update: the consumer's own tag check reports it)
-    const uint4 h = a.fct[tile];
     const uint32_t ta = h.x, tb = h.y;
     uint32_t da = 0, db = 0;  // risky survivors this dt destroys: stored into A / into A + 1
+    // (every load of a trip is requested before the first is looked at: a wave that waited for them one by one -- sixteen dependent
+    // round trips in the recount -- set the duration of the whole launch: 18.4 us at configs[2] for 8 MB of traffic)
     if (h.z != 0xFFFFFFFFu) {
-        const uint32_t na = h.z & 0xFFFFu, nb = h.z >> 16;
-        const float2 *L = a.fcl + (size_t)tile * FW_TF_K;
-        if (lane < na + nb) {
-            const bool isb = lane >= na;
-            const float2 v = L[isb ? FW_TF_K - 1u - (lane - na) : lane];
-            float an;
-            const bool dies = !fw_survives(v.x, a.dt, v.y, &an);
-            da = (dies && !isb) ? 1u : 0u, db = (dies && isb) ? 1u : 0u;
+        const uint32_t na = h.z & 0xFFFFu, nb = h.z >> 16, n = na + nb;
+        if (n != 0u) {  // (wave-uniform; most tiles are young: nobody is listed)
+            const float2 *L = a.fcl + (size_t)tile * FW_TF_K;
+            constexpr int U = FW_TF_K / 64u;
+            float2 v[U];
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const uint32_t k = min(lane + (uint32_t)j * 64u, n - 1u);
+                v[j] = L[k >= na ? FW_TF_K - 1u - (k - na) : k];
+            }
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const uint32_t k = lane + (uint32_t)j * 64u;
+                float an;
+                const bool dies = k < n && !fw_survives(v[j].x, a.dt, v[j].y, &an);
+                da += (dies && k < na) ? 1u : 0u, db += (dies && !(k < na)) ? 1u : 0u;
+            }
         }
     } else {
         const uint32_t seg = a.tile_desc ? a.tile_desc[tile].x : 0u;
         const FwSeg &S = g.segs[seg];
         const char *ib = S.buf[a.parity];
-        const uint32_t C = S.capacity, fc_bnd = (e.z + 1u) * FW_TILE;
+        const uint32_t C = S.capacity, fc_bnd = (e.z + 1u) * FW_TILE, end = h.w + ta + tb;
         const bool nospin = (g.types[S.type_idx].flags & FW_TYPE_NOSPIN) != 0u;
-        for (uint32_t i = h.w + lane; i < h.w + ta + tb; i += 64u) {
-            const float age = fw_ld4(ib + FW_OFF_Q0(C), i).w;
-            const float lf = fw_load_q3(ib, C, S.n_lplanes, i, nospin).w;
-            float an;
-            const bool dies = !fw_survives(age, a.dt, lf, &an);
-            da += (dies && i < fc_bnd) ? 1u : 0u, db += (dies && !(i < fc_bnd)) ? 1u : 0u;
+        const uint32_t ls = nospin ? 4u : 16u;
+        const char *pa = ib + FW_OFF_Q0(C) + (size_t)h.w * 16u + 12u;  // ages: .w of Q0, from the tile's first slot on
+        const char *pl = (nospin ? ib + FW_OFF_L(C, S.n_lplanes) : ib + FW_OFF_Q3(C) + 12u) + (size_t)h.w * ls;  // lifetimes: their own plane, or .w of Q3
+        constexpr int U = FW_TILE / 64;
+        for (uint32_t i0 = h.w; i0 < end; i0 += FW_TILE) {  // (one trip: a tile stores at most FW_TILE survivors)
+            float ag[U], lf[U];
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const uint32_t i = min(i0 + (uint32_t)j * 64u + lane, end - 1u) - h.w;
+                ag[j] = fw_ld1w(pa, i * 16u), lf[j] = fw_ld1w(pl, i * ls);
+            }
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const uint32_t i = i0 + (uint32_t)j * 64u + lane;
+                float an;
+                const bool dies = i < end && !fw_survives(ag[j], a.dt, lf[j], &an);
+                da += (dies && i < fc_bnd) ? 1u : 0u, db += (dies && !(i < fc_bnd)) ? 1u : 0u;
+            }
         }
     }
     da = fw_wave_sum(da), db = fw_wave_sum(db);

@@ -140,7 +140,7 @@ struct FwUpdateArgs {
     uint4 *fct_out;
     float2 *fcl_out;
 };
-#define FW_TF_K 64u
+#define FW_TF_K 256u  // (2 KB per tile and buffer; a tile of lifetimes in [0.8, 1.2] s lists ~100 at 60 Hz: 64 overflowed on every OLD tile)
 // fw_k_fc_resolve: the previous frame's entries / headers / lists, this frame's dt and parity
 struct FwResolveArgs {
     uint4 *fce;            // entries of the previous frame (this frame's fce_in): .x / .y are rewritten
