@@ -501,8 +501,22 @@ def main():
                     p2c, lambda k: p2c.step(dt), 60, "configs[2] with FW_RANGE=0: the compacting kernels (survivor forecast)")
                 for k in range(32):
                     p2c.step(jit[k % 64])
-                extras["hbm_resident"]["compacting_path"]["variable_dt"] = kernel_roofline(
-                    p2c, lambda k: p2c.step(jit[k % 64]), 60, "... stepped with a dt that never repeats (decoupled look-back)")
+                tf0 = p2c.tf_frames()
+                vd = kernel_roofline(
+                    p2c, lambda k: p2c.step(jit[k % 64]), 60,
+                    "... stepped with a dt that never repeats (round 6, threshold forecast: fw_k_fc_resolve in front of the streaming "
+                    "schedule; `avg_kernel_us` is the update launch alone, `whole_frame` includes the resolve launch; rounds 1-5: "
+                    "decoupled look-back)")
+                vd["threshold_forecast_frames"] = p2c.tf_frames() - tf0  # of the 60 timed ones
+                p2c.synchronize()
+                tw = time.perf_counter()
+                for k in range(60):
+                    p2c.step(jit[k % 64])
+                p2c.synchronize()
+                wf = (time.perf_counter() - tw) / 60
+                vd["whole_frame"] = {"us": wf * 1e6, "achieved": vd["particles_per_launch"] * vd["algorithmic_bytes_per_particle"] / wf / 1e9,
+                                     "frac": vd["particles_per_launch"] * vd["algorithmic_bytes_per_particle"] / wf / 1e9 / vd["peak"]}
+                extras["hbm_resident"]["compacting_path"]["variable_dt"] = vd
             if saved_range is None:
                 del os.environ["FW_RANGE"]
             else:

@@ -35,6 +35,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -201,6 +202,7 @@ int main(int argc, char **argv) {
             const auto t0 = std::chrono::steady_clock::now();
             std::vector<std::thread> th;
             std::vector<int> failed(n_local, 0);
+            std::atomic<int> arrived{0};
             for (int l = 0; l < n_local; l++)
                 th.emplace_back([&, l]() {
                     try {
@@ -217,6 +219,8 @@ int main(int argc, char **argv) {
                             if (f == half) {  // the steady half is timed on its own: wait for the fill, start the clock
                                 HIPCHECK(hipStreamSynchronize(S.stream));
                                 S.app->synchronize();
+                                arrived.fetch_add(1);  // (every context starts its steady half together: the halves overlap in full)
+                                while (arrived.load() < n_local) std::this_thread::yield();
                                 a1 = std::chrono::steady_clock::now();
                             }
                             if (f == 0) S.app->update(dt);
@@ -232,6 +236,7 @@ int main(int argc, char **argv) {
                     } catch (const Error &e) {
                         std::fprintf(stderr, "context %d: firework error %d: %s\n", l, (int)e.status, e.what());
                         failed[l] = 1;
+                        arrived.fetch_add(n_local);  // (nobody waits for a context that has given up)
                     }
                 });
             for (auto &t : th) t.join();

@@ -14,11 +14,15 @@ TRIG_FIELDS = ("position", "velocity", "rotation", "angular_velocity")
 #     |got - want| <= RTOL * max(|want element|, |want vector|_2) + ATOL
 # - the vector norm enters because a rotation error moves a component by a fraction of the vector's LENGTH, not of that
 #   component (a velocity pointing almost along +y has an x component whose error comes from the y magnitude);
-# - ATOL is an absolute floor of about two fp32 ulps at magnitude 8 (ulp(8) = 9.5e-7): a position is a sum
+# - ATOL is an absolute floor of one fp32 ulp at magnitude 4..8 (ulp(4) = 4.8e-7): a position is a sum
 #   `origin + offset` and later `position + velocity * dt` (core.rs:454, 626), so a component that cancels to nearly
-#   zero still carries the rounding of its O(1..10) operands.  It is 1/750 of what the round-1 array-max floor allowed.
+#   zero still carries the rounding of its O(1..10) operands.  Round 6 measured how much of it is USED
+#   (profiles/r06/parity_error_budget.txt, tools/r06_error_budget.py): at configs[0]..[4] sizes NO element needs the floor and the
+#   worst error is 0.22 of the allowance; over the whole GPU suite seven scenarios do (fuzz cases 0 / 22 / 36 / 37 and the
+#   spinning particles of test_irregular_dt_zero_steps_and_spinning_particles: 22 of 1354 tests fail with ATOL = 0), all of them
+#   pass with 2.5e-7 (profiles/r06/parity_atol.txt).  5e-7 is a quarter of the 2e-6 of rounds 2-5 and 1/3000 of round 1's floor.
 RTOL = 1e-5
-ATOL = 2e-6
+ATOL = float(os.environ.get("FW_TEST_ATOL", "5e-7"))  # (the override exists for tools/r06_error_budget.py-style experiments only)
 
 
 def planes_left_to_readers() -> int:

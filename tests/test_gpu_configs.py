@@ -365,7 +365,9 @@ def test_stress_test_collision_example(monkeypatch):
     OCML vs the oracle's glibc: a last-bit difference in the initial velocity), and a bounce amplifies that difference --
     the hit point moves along the face, a ray that grazes an edge of the angled cube may take the other face -- so for
     particles that have bounced the usual 1e-5 does not bound it for any two libm's; the trig-free variant below is the
-    bit-exact statement about the collision arithmetic itself.  Here: 99 % of the particles inside 1e-4, all of the young ones
+    bit-exact statement about the collision arithmetic itself.  Here: 99.9 % of the particles inside 1e-4 (round 6,
+    profiles/r06/parity_error_budget.txt: 68 of 472 002 position elements are outside 1e-5 relative to the vector's length, the worst by
+    5.6e-4 absolute; rounds 4-5 allowed 1 %), all of the young ones
     (age < 0.3 s: nothing within reach yet) inside the allowance of tests/parity.py."""
     spawner, tf, world = workloads.stress_test_collision()
     ring, cpu = _run_collision_example(monkeypatch, False, spawner, tf, world, 150, 30, False)
@@ -380,7 +382,7 @@ def test_stress_test_collision_example(monkeypatch):
         want = cpu[f].astype(np.float64)
         err = np.abs(ring[f].astype(np.float64) - want).max(axis=1)
         allow = 1e-4 * np.maximum(np.sqrt((want * want).sum(axis=1)), 1.0)
-        assert np.count_nonzero(err > allow) < 0.01 * len(cpu), (f, int(np.count_nonzero(err > allow)))
+        assert np.count_nonzero(err > allow) < 0.001 * len(cpu), (f, int(np.count_nonzero(err > allow)))
     # nobody fell through the slab (its top face is y = 0; a bounce leaves the particle 1e-4 above the face it hit)
     p = ring
     inside = (np.abs(p["position"][:, 0]) < 3.9) & (np.abs(p["position"][:, 2]) < 3.9)

@@ -100,3 +100,33 @@ def test_threshold_forecast_with_a_nested_spawner_and_attached_instances(monkeyp
                 got = buf[: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
                 assert np.array_equal(got, inst.gpu.instances(0).view(np.uint32).reshape(n, 16)), fr
         assert nested.gpu.count(1) > 3000 and system.tf_frames() > 60, system.tf_frames()
+
+
+def test_product_defaults_a_million_particles_with_a_plain_attach_under_a_jittering_dt(monkeypatch):
+    """NO knob set: a lifetime-range type of ~1M particles whose renderer used the plain fw_spawner_attach_instances leaves its ring for
+    the compacting path (records counted from 0: DESIGN.md 4.0b) -- ~980 tiles, beyond fw_ctx::tf_min_tiles -- and is stepped with a dt
+    that never repeats: the product itself picks fw_k_fc_resolve + the streaming schedule.  Counts, order, every field and the
+    records against the oracle."""
+    import torch
+    from bevy_firework_amd.system import ParticleSystem
+
+    for k in list(__import__("os").environ):
+        if k.startswith("FW_") and k != "FW_LIB_PATH":
+            monkeypatch.delenv(k)
+    with ParticleSystem(device=0, seed=SEED) as system:
+        pair = Pair(system, _emitter(1.0e6, 0.8, 1.2), seed=SEED, uid=21)
+        cap = 1 << 21
+        buf = torch.full((cap * 16,), float("nan"), dtype=torch.float32, device="cuda")
+        pair.gpu.attach_instances(buf.data_ptr(), cap, particle_type=0)
+        assert pair.gpu.update_path(0)[0] == "general"
+        dts = _dts(100, seed=5, spikes=((70, 0.03),))
+        for fr, dt in enumerate(dts):
+            system.update(dt)
+            pair.step_cpu(dt)
+            if fr in (55, 69, 70, 71, 85, 99):
+                pair.check(exact_all=True, what=f"frame {fr} (dt {dt})")
+                n = pair.gpu.count(0)
+                got = buf[: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
+                assert np.array_equal(got, pair.gpu.instances(0).view(np.uint32).reshape(n, 16)), fr
+        assert pair.gpu.count(0) > 900000
+        assert system.tf_frames() > 30, system.tf_frames()  # (the first ~46 frames hold fewer than tf_min_tiles tiles)
