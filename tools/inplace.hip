@@ -48,6 +48,104 @@ __global__ __launch_bounds__(256) void k_upd_nt(char* __restrict__ buf, uint32_t
     }
 }
 
+
+// round 6 question: Q1 = {velocity, initial_scale} and Q3 = {angular velocity, lifetime} carry a constant in .w -- as packed float3
+// planes (12 B per lane, dwordx3) an in-place update moves 112 instead of 128 B (spin) / 56 instead of 64 (no spin).  Does the time follow?
+typedef float f3v __attribute__((ext_vector_type(3)));
+template <int SPIN, int NT>
+__global__ __launch_bounds__(256) void k_upd_v3(char* __restrict__ buf, uint32_t n, uint32_t C, int K) {
+    constexpr int R = 4;
+    const uint32_t base = blockIdx.x * 256 * R;
+    f4v q0[R], q2[R];
+    f3v q1[R], q3[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = min(base + r * 256 + threadIdx.x, n - 1);
+        const f4v* a0 = (const f4v*)(buf) + i;
+        const f3v* a1 = (const f3v*)(buf + (size_t)16 * C) + i;
+        q0[r] = NT ? __builtin_nontemporal_load(a0) : *a0;
+        q1[r] = NT ? __builtin_nontemporal_load(a1) : *a1;
+        if (SPIN) {
+            const f4v* a2 = (const f4v*)(buf + (size_t)32 * C) + i;
+            const f3v* a3 = (const f3v*)(buf + (size_t)48 * C) + i;
+            q2[r] = NT ? __builtin_nontemporal_load(a2) : *a2;
+            q3[r] = NT ? __builtin_nontemporal_load(a3) : *a3;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = base + r * 256 + threadIdx.x;
+        if (i < n) {
+            f4v a = q0[r]; f3v b = q1[r];
+            a.x = work(a.x + b.x, K); b.y += a.y;
+            f4v* o0 = (f4v*)(buf) + i; f3v* o1 = (f3v*)(buf + (size_t)16 * C) + i;
+            if (NT) { __builtin_nontemporal_store(a, o0); __builtin_nontemporal_store(b, o1); } else { *o0 = a; *o1 = b; }
+            if (SPIN) {
+                f4v c = q2[r]; f3v d = q3[r];
+                c.x += a.z; d.z += c.y;
+                f4v* o2 = (f4v*)(buf + (size_t)32 * C) + i; f3v* o3 = (f3v*)(buf + (size_t)48 * C) + i;
+                if (NT) { __builtin_nontemporal_store(c, o2); __builtin_nontemporal_store(d, o3); } else { *o2 = c; *o3 = d; }
+            }
+        }
+    }
+}
+
+
+// ... and the same question with Q1 / Q3 as THREE 4-byte planes each (dword per lane)
+template <int SPIN, int NT>
+__global__ __launch_bounds__(256) void k_upd_s3(char* __restrict__ buf, uint32_t n, uint32_t C, int K) {
+    constexpr int R = 4;
+    const uint32_t base = blockIdx.x * 256 * R;
+    f4v q0[R], q2[R];
+    float q1[R][3], q3[R][3];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = min(base + r * 256 + threadIdx.x, n - 1);
+        const f4v* a0 = (const f4v*)(buf) + i;
+        q0[r] = NT ? __builtin_nontemporal_load(a0) : *a0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float* a1 = (const float*)(buf + (size_t)(16 + 4 * c) * C) + i;
+            q1[r][c] = NT ? __builtin_nontemporal_load(a1) : *a1;
+        }
+        if (SPIN) {
+            const f4v* a2 = (const f4v*)(buf + (size_t)32 * C) + i;
+            q2[r] = NT ? __builtin_nontemporal_load(a2) : *a2;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float* a3 = (const float*)(buf + (size_t)(48 + 4 * c) * C) + i;
+                q3[r][c] = NT ? __builtin_nontemporal_load(a3) : *a3;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = base + r * 256 + threadIdx.x;
+        if (i < n) {
+            f4v a = q0[r];
+            a.x = work(a.x + q1[r][0], K); q1[r][1] += a.y; q1[r][2] += a.z; q1[r][0] += a.w;
+            f4v* o0 = (f4v*)(buf) + i;
+            if (NT) __builtin_nontemporal_store(a, o0); else *o0 = a;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float* o1 = (float*)(buf + (size_t)(16 + 4 * c) * C) + i;
+                if (NT) __builtin_nontemporal_store(q1[r][c], o1); else *o1 = q1[r][c];
+            }
+            if (SPIN) {
+                f4v cc = q2[r];
+                cc.x += a.z; q3[r][2] += cc.y; q3[r][0] += cc.z; q3[r][1] += cc.w;
+                f4v* o2 = (f4v*)(buf + (size_t)32 * C) + i;
+                if (NT) __builtin_nontemporal_store(cc, o2); else *o2 = cc;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    float* o3 = (float*)(buf + (size_t)(48 + 4 * c) * C) + i;
+                    if (NT) __builtin_nontemporal_store(q3[r][c], o3); else *o3 = q3[r][c];
+                }
+            }
+        }
+    }
+}
+
 template <int R, int RD, int WR, bool STSHIFT = false>
 __global__ __launch_bounds__(256) void k_upd(const char* __restrict__ in, char* __restrict__ out, uint32_t n, uint32_t C, uint32_t shift, int K) {
     const uint32_t base = blockIdx.x * 256 * R;
@@ -139,6 +237,25 @@ int main() {
 #define RUN_NT(RD, WR, NT, bytes, tag) \
             t = timeit([&](int i) { hipLaunchKernelGGL((k_upd_nt<RD, WR, NT>), g, b, 0, 0, p0, n, C, K); }, 50); \
             printf("n=%8u K=%3d %-44s: %8.2f us  %7.1f GB/s moved\n", n, K, tag, t * 1e6, (double)(bytes) * n / t / 1e9);
+            // round 6: the shapes left once scale and colours are the readers' business (FW_TYPE_DERIVED for every type)
+            RUN_NT(15, 15, 0, 128, "r6: ONE buffer in place r4 w4 (128 B)")
+            RUN_NT(15, 15, 2, 128, "  ... everything non-temporal")
+            RUN_NT(3, 3, 0, 64, "r6: ONE buffer in place r Q0 Q1 w Q0 Q1 (64 B)")
+            RUN_NT(3, 3, 2, 64, "  ... everything non-temporal")
+#define RUN_V3(SPIN, NT, bytes, tag) \
+            t = timeit([&](int i) { hipLaunchKernelGGL((k_upd_v3<SPIN, NT>), g, b, 0, 0, p0, n, C, K); }, 50); \
+            printf("n=%8u K=%3d %-44s: %8.2f us  %7.1f GB/s moved\n", n, K, tag, t * 1e6, (double)(bytes) * n / t / 1e9);
+            RUN_V3(1, 0, 112, "r6: Q0 Q2 float4 + Q1 Q3 float3 in place (112 B)")
+            RUN_V3(1, 1, 112, "  ... all non-temporal (112 B)")
+            RUN_V3(0, 0, 56, "r6: Q0 float4 + Q1 float3 in place (56 B)")
+            RUN_V3(0, 1, 56, "  ... all non-temporal (56 B)")
+#define RUN_S3(SPIN, NT, bytes, tag) \
+            t = timeit([&](int i) { hipLaunchKernelGGL((k_upd_s3<SPIN, NT>), g, b, 0, 0, p0, n, C, K); }, 50); \
+            printf("n=%8u K=%3d %-44s: %8.2f us  %7.1f GB/s moved\n", n, K, tag, t * 1e6, (double)(bytes) * n / t / 1e9);
+            RUN_S3(1, 0, 112, "r6: Q0 Q2 float4 + Q1 Q3 as 3 scalar planes (112 B)")
+            RUN_S3(1, 1, 112, "  ... all non-temporal, scalar planes (112 B)")
+            RUN_S3(0, 0, 56, "r6: Q0 float4 + Q1 as 3 scalar planes (56 B)")
+            RUN_S3(0, 1, 56, "  ... all non-temporal, scalar planes (56 B)")
             RUN_NT(15, 127, 0, 164, "ONE buffer in place r4 w7 (164 B)")
             RUN_NT(15, 127, 1, 164, "  ... Q5 Q6 S4 non-temporal")
             RUN_NT(15, 127, 2, 164, "  ... everything non-temporal")
