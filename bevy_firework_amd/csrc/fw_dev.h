@@ -139,6 +139,41 @@ __device__ __forceinline__ uint4 fw_ld4u(const char *win, uint32_t byte_off) {
 __device__ __forceinline__ uint32_t fw_ld1u(const uint32_t *base, uint32_t idx) {
     return reinterpret_cast<const FW_GLOBAL uint32_t *>(reinterpret_cast<uintptr_t>(base))[idx];
 }
+// ---- component planes (round 6, fw_device.h): the Q1 and Q3 regions of a buffer hold their four components as four 4-byte planes
+// of C slots each -- x at +0, y at +4C, z at +8C, w at +12C bytes -- because `.w` of both (initial_scale, lifetime) never changes:
+// an in-place update loads and stores three dwords per lane and plane instead of a dwordx4 (tools/inplace.hip: the shapes follow the
+// bytes with scalar planes, 1M particles 16.6 -> 14.7 us, 16M 167.5 -> 147.5; packed float3 planes -- dwordx3 -- get SLOWER).
+// `reg`: the region's base (buf + FW_OFF_Q1 / Q3); `win`: the x plane advanced to a window's first slot; off4 = 4 * (slot - first).
+#define FW_CP(C) ((size_t)4 * (C))  // bytes between two component planes of a region
+__device__ __forceinline__ float4 fw_ldc4(const char *reg, uint32_t C, uint32_t i) {
+    const size_t cp = FW_CP(C);
+    return make_float4(fw_ld1(reg, i), fw_ld1(reg + cp, i), fw_ld1(reg + 2 * cp, i), fw_ld1(reg + 3 * cp, i));
+}
+__device__ __forceinline__ float4 fw_ldc3(const char *reg, uint32_t C, uint32_t i, float w) {
+    const size_t cp = FW_CP(C);
+    return make_float4(fw_ld1(reg, i), fw_ld1(reg + cp, i), fw_ld1(reg + 2 * cp, i), w);
+}
+__device__ __forceinline__ void fw_stc4(char *reg, uint32_t C, uint32_t i, float4 v) {
+    const size_t cp = FW_CP(C);
+    fw_st1(reg, i, v.x), fw_st1(reg + cp, i, v.y), fw_st1(reg + 2 * cp, i, v.z), fw_st1(reg + 3 * cp, i, v.w);
+}
+template <bool NT = false>
+__device__ __forceinline__ float4 fw_ldc4w(const char *win, size_t cp, uint32_t off4) {
+    return make_float4(fw_ld1w<NT>(win, off4), fw_ld1w<NT>(win + cp, off4), fw_ld1w<NT>(win + 2 * cp, off4), fw_ld1w<NT>(win + 3 * cp, off4));
+}
+template <bool NT = false>
+__device__ __forceinline__ float4 fw_ldc3w(const char *win, size_t cp, uint32_t off4, float w) {
+    return make_float4(fw_ld1w<NT>(win, off4), fw_ld1w<NT>(win + cp, off4), fw_ld1w<NT>(win + 2 * cp, off4), w);
+}
+template <bool NT = false>
+__device__ __forceinline__ void fw_stc3w(char *win, size_t cp, uint32_t off4, float x, float y, float z) {
+    fw_st1w<NT>(win, off4, x), fw_st1w<NT>(win + cp, off4, y), fw_st1w<NT>(win + 2 * cp, off4, z);
+}
+template <bool NT = false>
+__device__ __forceinline__ void fw_stc4w(char *win, size_t cp, uint32_t off4, float4 v) {
+    fw_st1w<NT>(win, off4, v.x), fw_st1w<NT>(win + cp, off4, v.y), fw_st1w<NT>(win + 2 * cp, off4, v.z), fw_st1w<NT>(win + 3 * cp, off4, v.w);
+}
+
 // Bounds-checked window loads (buffer_load through a 128-bit resource descriptor): a lane whose offset falls outside
 // [0, bytes) gets zeros and costs NO memory traffic -- a negative offset wraps to a huge one, so one descriptor clips a tile at
 // both ends.  Used where a tile of a ring only partly holds the particles it is dispatched for (the ends of a range ring's
@@ -165,7 +200,8 @@ __device__ __forceinline__ float fw_ldb1(fw_rsrc r, uint32_t byte_off) {
 }
 
 struct FwOutWin {  // output planes advanced to slot `first` (workgroup-uniform)
-    char *q0, *q1, *q2, *q3, *q5, *q6, *s4;
+    char *q0, *q1, *q2, *q3, *q5, *q6, *s4;  // (q1 / q3: the x plane of the region, advanced by 4 * first; components `cp` bytes apart)
+    size_t cp;
     uint32_t first;
     // A gradient with a single key (the reference's default emissive colour, core.rs:205) gives every particle of the
     // type the same colour for ever: both buffers of the segment are filled with it once (fw_k_fill_colors) and the
@@ -181,9 +217,9 @@ struct FwOutWin {  // output planes advanced to slot `first` (workgroup-uniform)
 };
 __device__ __forceinline__ FwOutWin fw_out_window(char *ob, uint32_t C, uint32_t first, const FwType &T, uint32_t force_colors,
                                                   uint32_t n_lplanes = 0u) {
-    const size_t f16 = (size_t)first * 16u;
-    return FwOutWin{ob + FW_OFF_Q0(C) + f16, ob + FW_OFF_Q1(C) + f16, ob + FW_OFF_Q2(C) + f16, ob + FW_OFF_Q3(C) + f16,
-                    ob + FW_OFF_Q5(C) + f16, ob + FW_OFF_Q6(C) + f16, ob + FW_OFF_S4(C) + (size_t)first * 4u, first,
+    const size_t f16 = (size_t)first * 16u, f4 = (size_t)first * 4u;
+    return FwOutWin{ob + FW_OFF_Q0(C) + f16, ob + FW_OFF_Q1(C) + f4, ob + FW_OFF_Q2(C) + f16, ob + FW_OFF_Q3(C) + f4,
+                    ob + FW_OFF_Q5(C) + f16, ob + FW_OFF_Q6(C) + f16, ob + FW_OFF_S4(C) + f4, FW_CP(C), first,
                     (T.bc_kind != 0 || force_colors != 0u) && !(T.flags & FW_TYPE_DERIVED),
                     (T.em_kind != 0 || force_colors != 0u) && !(T.flags & FW_TYPE_DERIVED), !(T.flags & FW_TYPE_NOSPIN),
                     !(T.flags & FW_TYPE_NOSPIN), ob + FW_OFF_L(C, n_lplanes) + (size_t)first * 4u, !(T.flags & FW_TYPE_DERIVED)};
@@ -206,7 +242,11 @@ __device__ __forceinline__ uint32_t fw_range_head(uint32_t b, uint32_t rold, uin
 // plane (FwOutWin::lf)
 __device__ __forceinline__ float4 fw_load_q3(const char *buf, uint32_t C, uint32_t n_lplanes, uint32_t idx, bool nospin) {
     if (nospin) return make_float4(0.0f, 0.0f, 0.0f, fw_ld1(buf + FW_OFF_L(C, n_lplanes), idx));
-    return fw_ld4(buf + FW_OFF_Q3(C), idx);
+    return fw_ldc4(buf + FW_OFF_Q3(C), C, idx);
+}
+// ... and the lifetime alone
+__device__ __forceinline__ float fw_load_lifetime(const char *buf, uint32_t C, uint32_t n_lplanes, uint32_t idx, bool nospin) {
+    return fw_ld1(nospin ? buf + FW_OFF_L(C, n_lplanes) : buf + FW_OFF_Q3(C) + 3 * FW_CP(C), idx);
 }
 
 // alive test of update_particles: `if particle.age >= particle.lifetime { destroyed }` (core.rs:594-599)
@@ -305,9 +345,9 @@ __device__ __forceinline__ void fw_store_new(const FwGlobals &g, const FwSeg &S,
     fw_gradient_sample(T.bc_kind, T.bc_n, keys + T.o_bc_t, keys + T.o_bc_v, 0.0f, bc);
     fw_gradient_sample(T.em_kind, T.em_n, keys + T.o_em_t, keys + T.o_em_v, 0.0f, em);
     fw_st4(buf + FW_OFF_Q0(C), slot, o.q0);
-    fw_st4(buf + FW_OFF_Q1(C), slot, o.q1);
+    fw_stc4(buf + FW_OFF_Q1(C), C, slot, o.q1);
     fw_st4(buf + FW_OFF_Q2(C), slot, o.q2);
-    fw_st4(buf + FW_OFF_Q3(C), slot, o.q3);
+    fw_stc4(buf + FW_OFF_Q3(C), C, slot, o.q3);
     if (T.flags & FW_TYPE_NOSPIN) fw_st1(buf + FW_OFF_L(C, S.n_lplanes), slot, o.q3.w);  // the lifetime plane (FwOutWin::lf)
     fw_st4(buf + FW_OFF_Q5(C), slot, make_float4(bc[0], bc[1], bc[2], bc[3]));
     fw_st4(buf + FW_OFF_Q6(C), slot, make_float4(em[0], em[1], em[2], em[3]));
@@ -371,12 +411,17 @@ __device__ __forceinline__ fw_q4 fw_quat_step(fw_v3 v) {
 // that do not spin, the scale under a constant curve); `full` marks a lane whose slot holds nothing yet (a particle
 // spawned this frame): it writes everything.
 // WM >= 0: which of the optional planes the launch writes is a compile-time fact (bit 0 base colour, 1 emissive, 2 scale)
+// wmode (INPLACE only): where the particle's two constants -- initial_scale in q1.w, lifetime in q3.w -- are.  FW_W_REGS: in the
+// arguments, and a `full` lane (generated in this kernel) stores them; FW_W_MEM: in the slot already (a particle of an earlier frame, or
+// one another kernel materialised) and q1.w is valid; FW_W_MEM_LAZY: in the slot, q1.w NOT loaded -- the streaming loops leave it there
+// unless somebody needs the scale (a type whose planes are stored, an instance record, the boxes): then it is read here.
+enum { FW_W_REGS = 0, FW_W_MEM = 1, FW_W_MEM_LAZY = 2 };
 template <bool INPLACE = false, int WM = -1, int NT = 0>
 __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float *s_keys, float dt, float4 q0, float4 q1,
                                                    float4 q2, float4 q3, float age_new, const FwOutWin &W, uint32_t o,
                                                    float4 *rec = nullptr, const fw_v3 *cpos = nullptr,
                                                    const fw_v3 *cvel = nullptr, float *box = nullptr,
-                                                   bool box_on = false, bool full = false, bool use_c = true) {
+                                                   bool box_on = false, bool full = false, bool use_c = true, int wmode = FW_W_REGS) {
     if (T.flags & FW_TYPE_NOSPIN) q2 = make_float4(T.const_rot[0], T.const_rot[1], T.const_rot[2], T.const_rot[3]);
     const float lifetime = q3.w;
     // scale and colours (core.rs:601-605, 652-655).  A FW_TYPE_DERIVED type stores none of them: unless this launch writes an
@@ -387,9 +432,11 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     float scale = 0.0f;
     float bc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, em[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (need_cs) {
+        float iscale = q1.w;
+        if (INPLACE && wmode == FW_W_MEM_LAZY) iscale = fw_ld1w<NT == 2>(W.q1 + 3 * W.cp, (o - W.first) * 4u);  // (workgroup-uniform branch)
         const float age_percent = age_new / lifetime;
         const float scale_factor = fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_percent);
-        scale = q1.w * scale_factor;
+        scale = iscale * scale_factor;
         fw_gradient_sample(T.bc_kind, T.bc_n, s_keys + T.o_bc_t, s_keys + T.o_bc_v, age_percent, bc);
         fw_gradient_sample(T.em_kind, T.em_n, s_keys + T.o_em_t, s_keys + T.o_em_v, age_percent, em);
     }
@@ -418,14 +465,20 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     }
     const uint32_t b16 = (o - W.first) * 16u;  // < 16 KiB + a tile: the window starts at the tile's first output slot
     fw_st4w<NT == 2>(W.q0, b16, make_float4(px, py, pz, age_new));
-    fw_st4w<NT == 2>(W.q1, b16, make_float4(vx, vy, vz, q1.w));
+    const uint32_t b4 = (o - W.first) * 4u;
+    fw_stc3w<NT == 2>(W.q1, W.cp, b4, vx, vy, vz);
     if (INPLACE) {
+        // (initial_scale and lifetime never change: in place only a slot that holds nothing yet writes them -- wave-uniform branch)
+        if (wmode == FW_W_REGS && __any(full)) {
+            if (full) fw_st1w<NT == 2>(W.q1 + 3 * W.cp, b4, q1.w);
+            if (full && W.wr3) fw_st1w<NT == 2>(W.q3 + 3 * W.cp, b4, lifetime);
+        }
         const uint32_t d2 = (__float_as_uint(nr.x) ^ __float_as_uint(q2.x)) | (__float_as_uint(nr.y) ^ __float_as_uint(q2.y)) |
                             (__float_as_uint(nr.z) ^ __float_as_uint(q2.z)) | (__float_as_uint(nr.w) ^ __float_as_uint(q2.w));
         const uint32_t d3 = (__float_as_uint(wx) ^ __float_as_uint(q3.x)) | (__float_as_uint(wy) ^ __float_as_uint(q3.y)) |
                             (__float_as_uint(wz) ^ __float_as_uint(q3.z));
         if (W.wr2 && __any(full || d2 != 0u)) fw_st4w<NT == 2>(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));  // wave-uniform branches
-        if (W.wr3 && __any(full || d3 != 0u)) fw_st4w<NT == 2>(W.q3, b16, make_float4(wx, wy, wz, lifetime));
+        if (W.wr3 && __any(full || d3 != 0u)) fw_stc3w<NT == 2>(W.q3, W.cp, b4, wx, wy, wz);
         // (`full` lanes -- slots that hold nothing yet -- write every plane the type MAINTAINS: W.wr4 is false exactly for FW_TYPE_DERIVED)
         const bool fullk = full && W.wr4;
         if ((WM >= 0 ? (WM & 1) != 0 : W.wr5) || fullk) fw_st4w<NT != 0>(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));
@@ -433,8 +486,9 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
         if ((WM >= 0 ? (WM & 4) != 0 : (T.sc_kind != 0 && W.wr4)) || fullk) fw_st1w<NT != 0>(W.s4, (o - W.first) * 4u, scale);
     } else {
         if (W.wr2) fw_st4w<NT == 2>(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
-        if (W.wr3) fw_st4w<NT == 2>(W.q3, b16, make_float4(wx, wy, wz, lifetime));
-        else fw_st1w<NT == 2>(W.lf, (o - W.first) * 4u, lifetime);
+        fw_st1w<NT == 2>(W.q1 + 3 * W.cp, b4, q1.w);  // (out of place: the constants move with the particle)
+        if (W.wr3) fw_stc4w<NT == 2>(W.q3, W.cp, b4, make_float4(wx, wy, wz, lifetime));
+        else fw_st1w<NT == 2>(W.lf, b4, lifetime);
         if (W.wr5) fw_st4w<NT != 0>(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));  // workgroup-uniform branches
         if (W.wr6) fw_st4w<NT != 0>(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
         if (W.wr4) fw_st1w<NT != 0>(W.s4, (o - W.first) * 4u, scale);

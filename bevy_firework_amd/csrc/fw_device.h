@@ -12,9 +12,10 @@
 // 16-byte aligned):
 //
 //   Q0  float4 {pos.x, pos.y, pos.z, age}            offset   0*C   read+write
-//   Q1  float4 {vel.x, vel.y, vel.z, initial_scale}  offset  16*C   read+write
+//   Q1  4 x float {vel.x | vel.y | vel.z | initial_scale}  offset 16*C  COMPONENT planes of C floats each, 4*C bytes apart
+//       (round 6: initial_scale never changes -- an in-place update loads and stores three dwords, not a dwordx4; fw_dev.h: FW_CP)
 //   Q2  float4 {rot.x, rot.y, rot.z, rot.w}          offset  32*C   read+write
-//   Q3  float4 {angvel.x, .y, .z, lifetime}          offset  48*C   read+write
+//   Q3  4 x float {angvel.x | .y | .z | lifetime}    offset  48*C   component planes like Q1 (lifetime never changes)
 //   Q5  float4 base_color rgba                       offset  64*C   write only
 //   Q6  float4 emissive_color rgba                   offset  80*C   write only
 //   S4  float  scale                                 offset  96*C   write only

@@ -1027,12 +1027,16 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t
         const bool acc = aa[0] != 0.f || aa[1] != 0.f || aa[2] != 0.f;
         const uint32_t q2 = (spins || acc) ? 16u : 0u, q3 = ((spins && T.ps.angular_drag != 0.f) || acc) ? 16u : 0u;
         // (a type that cannot turn: neither the rotation nor the angular-velocity / lifetime plane is read)
-        moved = (S.nospin ? 32u : 64u) + 32u + q2 + q3 + (T.scale.kind != 0 ? 4u : 0u) + colours;
-        algo = moved - 4u - (q3 ? 4u : 0u);
-        // (a range ring: lifetimes differ from particle to particle -- 4 B read for a type that cannot turn, Q3 otherwise --
-        // and the scale depends on initial_scale; the part of the list that may lose particles, a fifth of configs[2], is
-        // compacted in place and rewrites every plane it keeps: the figure is the young part's)
-        if (S.range && S.nospin) moved += 4u, algo += 4u;
+        // (round 6: Q1 / Q3 are component planes -- velocity and angular velocity move as 12 bytes each way, the constants that
+        // shared their float4, initial_scale and lifetime, stay where they are: every byte moved is algorithmic)
+        moved = (S.nospin ? 28u : 56u) + 28u + q2 + (q3 ? 12u : 0u) + (T.scale.kind != 0 ? 4u : 0u) + colours;
+        algo = moved;
+        // (a range ring: lifetimes differ from particle to particle -- 4 B read, from the lifetime plane of a type that cannot turn or
+        // from the w plane of Q3; the part of the list that may lose particles, a fifth of configs[2], is compacted in place and
+        // rewrites every plane it keeps: the figure is the young part's)
+        if (S.range) moved += 4u, algo += 4u;
+        // (initial_scale is read where somebody evaluates the scale: a type whose planes are stored, an attached instance buffer)
+        if (!S.derived || S.inst != nullptr) moved += 4u, algo += 4u;
     } else {
         // compacting: every state plane lands at a new slot (+ the last_emitted planes of a Nested parent, read and written);
         // a type that cannot turn keeps no rotation plane: -16 B read, -16 B written,

@@ -57,9 +57,10 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
     };
     const size_t OC = old.capacity, NC = ncap;
     FW_HIP(ctx, cp(FW_OFF_Q0(NC), FW_OFF_Q0(OC), 16));
-    FW_HIP(ctx, cp(FW_OFF_Q1(NC), FW_OFF_Q1(OC), 16));
+    // (Q1 / Q3: four component planes of 4-byte elements each, fw_device.h -- their distance follows the capacity)
+    for (size_t c = 0; c < 4; c++) FW_HIP(ctx, cp(FW_OFF_Q1(NC) + c * 4 * NC, FW_OFF_Q1(OC) + c * 4 * OC, 4));
     FW_HIP(ctx, cp(FW_OFF_Q2(NC), FW_OFF_Q2(OC), 16));
-    FW_HIP(ctx, cp(FW_OFF_Q3(NC), FW_OFF_Q3(OC), 16));
+    for (size_t c = 0; c < 4; c++) FW_HIP(ctx, cp(FW_OFF_Q3(NC) + c * 4 * NC, FW_OFF_Q3(OC) + c * 4 * OC, 4));
     FW_HIP(ctx, cp(FW_OFF_Q5(NC), FW_OFF_Q5(OC), 16));
     FW_HIP(ctx, cp(FW_OFF_Q6(NC), FW_OFF_Q6(OC), 16));
     FW_HIP(ctx, cp(FW_OFF_S4(NC), FW_OFF_S4(OC), 4));

@@ -13,10 +13,10 @@ __global__ void fw_k_gather(const char *buf, uint32_t C, uint32_t head, uint32_t
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
     const uint32_t i = fw_ring_slot(head, li, C);
-    const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i), q1 = fw_ld4(buf + FW_OFF_Q1(C), i),
+    const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i), q1 = fw_ldc4(buf + FW_OFF_Q1(C), C, i),
                  q2 = nospin ? rot : fw_ld4(buf + FW_OFF_Q2(C), i),
                  // (cannot turn: angular velocity 0; the lifetime from its plane, or -- a ring -- the type's one value)
-                 q3 = !nospin ? fw_ld4(buf + FW_OFF_Q3(C), i)
+                 q3 = !nospin ? fw_ldc4(buf + FW_OFF_Q3(C), C, i)
                               : make_float4(0.0f, 0.0f, 0.0f, life_plane != 0xFFFFFFFFu ? fw_ld1(buf + FW_OFF_L(C, life_plane), i) : life_const),
                  bc0 = fw_ld4(buf + FW_OFF_Q5(C), i), em0 = fw_ld4(buf + FW_OFF_Q6(C), i);
     float4 bc = bc0, em = em0;
@@ -38,9 +38,9 @@ __global__ void fw_k_scatter(char *buf, uint32_t C, uint32_t n, uint32_t n_lplan
     if (i >= n) return;
     const float *r = in + (size_t)i * 26;
     fw_st4(buf + FW_OFF_Q0(C), i, make_float4(r[0], r[1], r[2], r[15]));
-    fw_st4(buf + FW_OFF_Q1(C), i, make_float4(r[3], r[4], r[5], r[13]));
+    fw_stc4(buf + FW_OFF_Q1(C), C, i, make_float4(r[3], r[4], r[5], r[13]));
     fw_st4(buf + FW_OFF_Q2(C), i, make_float4(r[6], r[7], r[8], r[9]));
-    fw_st4(buf + FW_OFF_Q3(C), i, make_float4(r[10], r[11], r[12], r[16]));
+    fw_stc4(buf + FW_OFF_Q3(C), C, i, make_float4(r[10], r[11], r[12], r[16]));
     fw_st4(buf + FW_OFF_Q5(C), i, make_float4(r[17], r[18], r[19], r[20]));
     fw_st4(buf + FW_OFF_Q6(C), i, make_float4(r[21], r[22], r[23], r[24]));
     reinterpret_cast<float *>(buf + FW_OFF_S4(C))[i] = r[14];
@@ -62,11 +62,11 @@ __global__ void fw_k_rederive(char *buf, uint32_t C, const FwType *T, const floa
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C) return;
     const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i);
-    const float life = !nospin ? fw_ld4(buf + FW_OFF_Q3(C), i).w
+    const float life = !nospin ? fw_ld1(buf + FW_OFF_Q3(C) + 3 * FW_CP(C), i)
                                : (life_plane != 0xFFFFFFFFu ? fw_ld1(buf + FW_OFF_L(C, life_plane), i) : life_const);
     float4 bc, em;
     float sc;
-    fw_derived_values(*T, keys + T->keys_off, q0.w, life, fw_ld4(buf + FW_OFF_Q1(C), i).w, &bc, &em, &sc);
+    fw_derived_values(*T, keys + T->keys_off, q0.w, life, fw_ld1(buf + FW_OFF_Q1(C) + 3 * FW_CP(C), i), &bc, &em, &sc);
     fw_st4(buf + FW_OFF_Q5(C), i, bc), fw_st4(buf + FW_OFF_Q6(C), i, em), fw_st1(buf + FW_OFF_S4(C), i, sc);
 }
 hipError_t fw_launch_rederive(hipStream_t s, char *buf, uint32_t capacity, const FwType *d_type, const float *d_keys, bool nospin,
@@ -96,8 +96,8 @@ __global__ void fw_k_restore_q3(char *buf0, char *buf1, uint32_t C, uint32_t lif
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C) return;
     const bool pl = life_plane != 0xFFFFFFFFu;
-    fw_st4(buf0 + FW_OFF_Q3(C), i, make_float4(0.f, 0.f, 0.f, pl ? fw_ld1(buf0 + FW_OFF_L(C, life_plane), i) : life_const));
-    if (buf1) fw_st4(buf1 + FW_OFF_Q3(C), i, make_float4(0.f, 0.f, 0.f, pl ? fw_ld1(buf1 + FW_OFF_L(C, life_plane), i) : life_const));
+    fw_stc4(buf0 + FW_OFF_Q3(C), C, i, make_float4(0.f, 0.f, 0.f, pl ? fw_ld1(buf0 + FW_OFF_L(C, life_plane), i) : life_const));
+    if (buf1) fw_stc4(buf1 + FW_OFF_Q3(C), C, i, make_float4(0.f, 0.f, 0.f, pl ? fw_ld1(buf1 + FW_OFF_L(C, life_plane), i) : life_const));
 }
 
 // ParticleInstance packing (reference src/render.rs:95-115): {pos, scale, rot, base, emissive}
@@ -120,9 +120,9 @@ __global__ __launch_bounds__(256) void fw_k_pack(const char *buf, uint32_t C, ui
         float4 q5 = fw_ld4(buf + FW_OFF_Q5(C), i);
         float4 q6 = fw_ld4(buf + FW_OFF_Q6(C), i);
         if (derived) {  // FW_TYPE_DERIVED: the three planes are not maintained -- what the last update computed, again
-            const float life = !nospin ? fw_ld4(buf + FW_OFF_Q3(C), i).w
+            const float life = !nospin ? fw_ld1(buf + FW_OFF_Q3(C) + 3 * FW_CP(C), i)
                                        : (life_plane != 0xFFFFFFFFu ? fw_ld1(buf + FW_OFF_L(C, life_plane), i) : life_const);
-            fw_derived_values(*derived, keys + derived->keys_off, q0.w, life, fw_ld4(buf + FW_OFF_Q1(C), i).w, &q5, &q6, &sc);
+            fw_derived_values(*derived, keys + derived->keys_off, q0.w, life, fw_ld1(buf + FW_OFF_Q1(C) + 3 * FW_CP(C), i), &q5, &q6, &sc);
         }
         s_rec[tid * 4 + 0] = make_float4(q0.x, q0.y, q0.z, sc);
         s_rec[tid * 4 + 1] = q2;
@@ -189,10 +189,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, FwSegList L, 
             const float4 q0 = fw_ld4(buf + FW_OFF_Q0(S.capacity), i);
             float sc = fw_ld1(buf + FW_OFF_S4(S.capacity), i);
             if (TT.flags & FW_TYPE_DERIVED) {  // the scale plane is not maintained: what the last update computed, again
-                const float life = !(TT.flags & FW_TYPE_NOSPIN) ? fw_ld4(buf + FW_OFF_Q3(S.capacity), i).w
+                const float life = !(TT.flags & FW_TYPE_NOSPIN) ? fw_ld1(buf + FW_OFF_Q3(S.capacity) + 3 * FW_CP(S.capacity), i)
                                    : (L.life_plane[k] != 0xFFFFFFFFu ? fw_ld1(buf + FW_OFF_L(S.capacity, L.life_plane[k]), i) : L.life_const[k]);
                 const float *keys = g.keys + TT.keys_off;
-                sc = fw_ld4(buf + FW_OFF_Q1(S.capacity), i).w * fw_curve_sample(TT.sc_kind, TT.sc_n, keys, keys + TT.o_sc_v, q0.w / life);
+                sc = fw_ld1(buf + FW_OFF_Q1(S.capacity) + 3 * FW_CP(S.capacity), i) * fw_curve_sample(TT.sc_kind, TT.sc_n, keys, keys + TT.o_sc_v, q0.w / life);
             }
             mn[0] = fminf(mn[0], q0.x - sc), mn[1] = fminf(mn[1], q0.y - sc), mn[2] = fminf(mn[2], q0.z - sc);
             mx[0] = fmaxf(mx[0], q0.x + sc), mx[1] = fmaxf(mx[1], q0.y + sc), mx[2] = fmaxf(mx[2], q0.z + sc);

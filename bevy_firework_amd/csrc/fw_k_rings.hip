@@ -89,7 +89,7 @@ __device__ __forceinline__ void fw_fifo_nest_parents(const FwGlobals &g, const F
     const uint32_t C = F.capacity, head = F.head, Cc = Fc.capacity;
     char *pb = F.buf;
     // (window addressing as everywhere in this kernel: the tile's first slot on the scalar unit, 32-bit offsets per lane)
-    const char *w0 = pb + FW_OFF_Q0(C) + (size_t)sbase * 16u, *w1 = pb + FW_OFF_Q1(C) + (size_t)sbase * 16u;
+    const char *w0 = pb + FW_OFF_Q0(C) + (size_t)sbase * 16u, *w1 = pb + FW_OFF_Q1(C) + (size_t)sbase * 4u;  // (w1: component planes)
     const char *w2 = pb + FW_OFF_Q2(C) + (size_t)sbase * 16u;
     char *wl = pb + FW_OFF_L(C, N.parent_lplane) + (size_t)sbase * 4u;
     const bool pnospin = (F.type_idx & FW_TYPE_IDX_NOSPIN) != 0u;
@@ -177,7 +177,7 @@ __device__ __forceinline__ void fw_fifo_nest_parents(const FwGlobals &g, const F
         if (s_n[r][tid] != 0) {
             const uint32_t o16 = ((uint32_t)(r * BLK) + tid) * 16u;
             s_par[wave][0][lane] = fw_ld4w(w0, o16);
-            s_par[wave][1][lane] = fw_ld4w(w1, o16);
+            s_par[wave][1][lane] = fw_ldc3w(w1, FW_CP(C), o16 / 4u, 0.0f);  // (the parent's velocity: core.rs:706-736)
             s_par[wave][2][lane] = pnospin ? prot : fw_ld4w(w2, o16);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -287,26 +287,33 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
             fw_fifo_nest_parents<R, NT>(g, a, N, F, a.s[N.child], prank, sbase, n_in);
         }
     }
-    const size_t sfirst = (size_t)sbase * 16u;
-    const char *iw0 = buf + FW_OFF_Q0(C) + sfirst, *iw1 = buf + FW_OFF_Q1(C) + sfirst;
-    const char *iw2 = buf + FW_OFF_Q2(C) + sfirst, *iw3 = buf + FW_OFF_Q3(C) + sfirst;
+    const size_t sfirst = (size_t)sbase * 16u, cp = FW_CP(C);
+    // (Q1 / Q3: component planes, fw_dev.h -- windows of the x plane, offsets of 4 bytes per slot.  A ring type has ONE lifetime value
+    // (F.life) and its initial_scale matters to instance records and destroyed records only: neither `.w` is loaded by the streaming loop)
+    const char *iw0 = buf + FW_OFF_Q0(C) + sfirst, *iw1 = buf + FW_OFF_Q1(C) + sfirst / 4u;
+    const char *iw2 = buf + FW_OFF_Q2(C) + sfirst, *iw3 = buf + FW_OFF_Q3(C) + sfirst / 4u;
+    auto ld1 = [&](uint32_t o16) -> float4 {  // velocity (+ initial_scale when this launch writes instance records)
+        if constexpr (INST) return fw_ldc4w<NT == 2>(iw1, cp, o16 / 4u);
+        else return fw_ldc3w<NT == 2>(iw1, cp, o16 / 4u, 0.0f);
+    };
+    auto ld3 = [&](uint32_t o16) -> float4 { return fw_ldc3w<NT == 2>(iw3, cp, (o16 & m2) / 4u, F.life); };
     if (!spawner && !defer) {
-        q0c = fw_ld4w<NT == 2>(iw0, tid * 16u), q3c = fw_ld4w<NT == 2>(iw3, (tid * 16u) & m2);
-        q1c = fw_ld4w<NT == 2>(iw1, tid * 16u), q2c = fw_ld4w<NT == 2>(iw2, (tid * 16u) & m2);
+        q0c = fw_ld4w<NT == 2>(iw0, tid * 16u), q3c = ld3(tid * 16u);
+        q1c = ld1(tid * 16u), q2c = fw_ld4w<NT == 2>(iw2, (tid * 16u) & m2);
         if constexpr (R > 1) {
-            q0n = fw_ld4w<NT == 2>(iw0, i1), q3n = fw_ld4w<NT == 2>(iw3, i1 & m2);
-            q1n = fw_ld4w<NT == 2>(iw1, i1), q2n = fw_ld4w<NT == 2>(iw2, i1 & m2);
+            q0n = fw_ld4w<NT == 2>(iw0, i1), q3n = ld3(i1);
+            q1n = ld1(i1), q2n = fw_ld4w<NT == 2>(iw2, i1 & m2);
         }
     }
     if (defer) {
         uint32_t i0 = sbase - head;
         if (sbase < head) i0 += C;
         if (tis != 0u && !(i0 < n_tot || (i0 + TILE > C && n_tot != 0u))) return;
-        q0c = fw_ld4w<NT == 2>(iw0, tid * 16u), q3c = fw_ld4w<NT == 2>(iw3, (tid * 16u) & m2);
-        q1c = fw_ld4w<NT == 2>(iw1, tid * 16u), q2c = fw_ld4w<NT == 2>(iw2, (tid * 16u) & m2);
+        q0c = fw_ld4w<NT == 2>(iw0, tid * 16u), q3c = ld3(tid * 16u);
+        q1c = ld1(tid * 16u), q2c = fw_ld4w<NT == 2>(iw2, (tid * 16u) & m2);
         if constexpr (R > 1) {
-            q0n = fw_ld4w<NT == 2>(iw0, i1), q3n = fw_ld4w<NT == 2>(iw3, i1 & m2);
-            q1n = fw_ld4w<NT == 2>(iw1, i1), q2n = fw_ld4w<NT == 2>(iw2, i1 & m2);
+            q0n = fw_ld4w<NT == 2>(iw0, i1), q3n = ld3(i1);
+            q1n = ld1(i1), q2n = fw_ld4w<NT == 2>(iw2, i1 & m2);
         }
     }
     if (blockIdx.x == 0 && tid == 0) {
@@ -378,8 +385,8 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
                 if (s < head) i += C;
                 if (i < n_dead && i < n_in) {
                     const uint32_t b16 = (uint32_t)(r * BLK + (int)tid) * 16u;
-                    const float4 q0 = fw_ld4w<NT == 2>(iw0, b16), q1 = fw_ld4w<NT == 2>(iw1, b16), q2 = fw_ld4w<NT == 2>(iw2, b16 & m2);
-                    const float4 q3 = nospin ? q3s : fw_ld4w<NT == 2>(iw3, b16);
+                    const float4 q0 = fw_ld4w<NT == 2>(iw0, b16), q1 = fw_ldc4w<NT == 2>(iw1, cp, b16 / 4u), q2 = fw_ld4w<NT == 2>(iw2, b16 & m2);
+                    const float4 q3 = nospin ? q3s : fw_ldc4w<NT == 2>(iw3, cp, b16 / 4u);
                     // (a materialised particle that dies in its first update carries the spawn-time colours and scale, like any
                     // particle born and destroyed in one frame: evaluated, not read -- the planes of a FW_TYPE_DERIVED type
                     // are not maintained, and for everybody else they hold exactly these values)
@@ -395,8 +402,8 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
             const uint32_t in_ = (uint32_t)(min(r + 2, R - 1) * BLK + (int)tid) * 16u;  // two rounds ahead (the last re-read)
             float4 q0f = q0c, q3f = q3c, q1f = q1c, q2f = q2c;
             if constexpr (R > 1) {  // (a one-round workgroup has nothing to prefetch)
-                q0f = fw_ld4w<NT == 2>(iw0, in_), q3f = fw_ld4w<NT == 2>(iw3, in_ & m2);
-                q1f = fw_ld4w<NT == 2>(iw1, in_), q2f = fw_ld4w<NT == 2>(iw2, in_ & m2);
+                q0f = fw_ld4w<NT == 2>(iw0, in_), q3f = ld3(in_);
+                q1f = ld1(in_), q2f = fw_ld4w<NT == 2>(iw2, in_ & m2);
             }
             if (nospin) q3c = q3s;
             uint32_t i = s - head;  // logical index of the slot
@@ -413,13 +420,13 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
             if (alive) {
                 if FW_DBG(a.dbg, 2u) {  // profiling only: stream without arithmetic
                     const uint32_t b16 = (s - W.first) * 16u;
-                    fw_st4w<NT == 2>(W.q0, b16, make_float4(q0c.x, q0c.y, q0c.z, age_new)), fw_st4w<NT == 2>(W.q1, b16, q1c);
+                    fw_st4w<NT == 2>(W.q0, b16, make_float4(q0c.x, q0c.y, q0c.z, age_new)), fw_stc3w<NT == 2>(W.q1, W.cp, b16 / 4u, q1c.x, q1c.y, q1c.z);
                     if (WM >= 0 ? (WM & 1) != 0 : W.wr5) fw_st4w<NT != 0>(W.q5, b16, q0c);
                     if (WM >= 0 ? (WM & 2) != 0 : W.wr6) fw_st4w<NT != 0>(W.q6, b16, q1c);
                     if (WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) fw_st1w<NT != 0>(W.s4, (s - W.first) * 4u, q1c.w);
                 } else {
                     fw_integrate_store<true, WM, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, COLL ? &cpos : nullptr,
-                                                 COLL ? &cvel : nullptr, nullptr, false, i >= full_from, CA.on);
+                                                 COLL ? &cvel : nullptr, nullptr, false, i >= full_from, CA.on, INST ? FW_W_MEM : FW_W_MEM_LAZY);
                 }
             }
             fw_fifo_inst_out<INST, NT == 2>(F, inst, s_inst_wave, rec, lane, m, alive, i - n_dead);
@@ -630,7 +637,9 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
         if (a.done_tag) *a.done_tag = a.done_value;
     }
     const char *p0 = buf + FW_OFF_Q0(C), *p1 = buf + FW_OFF_Q1(C), *p2 = buf + FW_OFF_Q2(C), *p3 = buf + FW_OFF_Q3(C);
-    const char *pl = buf + FW_OFF_L(C, Sp->n_lplanes);  // lifetimes of a type that cannot turn (FwOutWin::lf)
+    const size_t cp = FW_CP(C);  // (Q1 / Q3: component planes, fw_dev.h)
+    // lifetimes: a plane of their own for a type that cannot turn (FwOutWin::lf), the w plane of Q3 otherwise
+    const char *pl = nospin ? buf + FW_OFF_L(C, Sp->n_lplanes) : p3 + 3 * cp;
     char *inst = INST ? Sp->inst : nullptr;
     const uint32_t inst_cap = INST ? Sp->inst_cap : 0u;
     float4 *s_inst_wave = s_inst + (INST ? wave * 256u : 0u);
@@ -660,8 +669,20 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
             if (yi0 < y_exist) w_n = min(YT, y_exist - yi0);
             else w_lo = b, w_n = (b >= sbase && b - sbase < YT) ? min(sbase + YT - b, y_exist) : 0u;
         }
-        const fw_rsrc r0 = fw_make_rsrc(p0 + (size_t)w_lo * 16u, w_n * 16u), r1 = fw_make_rsrc(p1 + (size_t)w_lo * 16u, w_n * 16u);
+        const fw_rsrc r0 = fw_make_rsrc(p0 + (size_t)w_lo * 16u, w_n * 16u);
+        // (velocity: one descriptor per component plane; initial_scale is loaded only when the launch writes instance records -- a
+        // zero-length window otherwise -- whoever else needs it reads it in fw_integrate_store: FW_W_MEM_LAZY)
+        const fw_rsrc r1x = fw_make_rsrc(p1 + (size_t)w_lo * 4u, w_n * 4u), r1y = fw_make_rsrc(p1 + cp + (size_t)w_lo * 4u, w_n * 4u);
+        const fw_rsrc r1z = fw_make_rsrc(p1 + 2 * cp + (size_t)w_lo * 4u, w_n * 4u);
+        const fw_rsrc r1w = fw_make_rsrc(p1 + 3 * cp + (size_t)w_lo * 4u, INST ? w_n * 4u : 0u);
         const fw_rsrc rl = fw_make_rsrc(pl + (size_t)w_lo * 4u, w_n * 4u);
+        auto ldq1 = [&](uint32_t ir) -> float4 {
+            const uint32_t i4 = ir / 4u;
+            float w = 0.0f;
+            if constexpr (INST) w = fw_ldb1<NT == 2>(r1w, i4);
+            return make_float4(fw_ldb1<NT == 2>(r1x, i4), fw_ldb1<NT == 2>(r1y, i4), fw_ldb1<NT == 2>(r1z, i4), w);
+        };
+        constexpr int WMODE = INST ? FW_W_MEM : FW_W_MEM_LAZY;
         // this lane's byte offset in the window, round r; a slot below the window gets an offset far beyond it (clipped like one
         // above it) -- not the wrapped negative one, whose last bytes would wrap back to offset 0 in the range check
         const int wd0 = (int)(sbase - w_lo) + (int)tid;
@@ -679,7 +700,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
 #pragma unroll
             for (int r = 0; r < PF; r++) {
                 const uint32_t ir = woff(r);
-                q0a[r] = fw_ldb4<NT == 2>(r0, ir), lfa[r] = fw_ldb1<NT == 2>(rl, ir / 4u), q1a[r] = fw_ldb4<NT == 2>(r1, ir);
+                q0a[r] = fw_ldb4<NT == 2>(r0, ir), lfa[r] = fw_ldb1<NT == 2>(rl, ir / 4u), q1a[r] = ldq1(ir);
             }
             const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
             const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & ~FW_TYPE_IDX_NOSPIN);
@@ -698,7 +719,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
                 const float4 q3v = make_float4(0.0f, 0.0f, 0.0f, lfa[r % PF]);
                 if (r + PF < YR) {
                     const uint32_t ir = woff(r + PF);
-                    q0a[r % PF] = fw_ldb4<NT == 2>(r0, ir), lfa[r % PF] = fw_ldb1<NT == 2>(rl, ir / 4u), q1a[r % PF] = fw_ldb4<NT == 2>(r1, ir);
+                    q0a[r % PF] = fw_ldb4<NT == 2>(r0, ir), lfa[r % PF] = fw_ldb1<NT == 2>(rl, ir / 4u), q1a[r % PF] = ldq1(ir);
                 }
                 float age_new;
                 const bool surv = fw_survives(q0v.w, a.dt, q3v.w, &age_new);
@@ -709,7 +730,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
                 fw_coll_step<COLL>(g, CA, mine, a.dt, q0v, q1v, &cpos, &cvel);
                 if (mine)
                     fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0v, q1v, q3v, q3v, age_new, W, s, rec, COLL ? &cpos : nullptr,
-                                                     COLL ? &cvel : nullptr, nullptr, false, yi >= y_full, CA.on);
+                                                     COLL ? &cvel : nullptr, nullptr, false, yi >= y_full, CA.on, WMODE);
                 if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             }
             if (__any(bad) && lane == 0) fw_raise(g, 7u, seg, blockIdx.x);
@@ -720,13 +741,19 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
         float lfc, lfn;
         // (a type that cannot turn reads neither rotation nor angular velocity: a zero-length window; one that can reads its
         // lifetime in Q3, not in the lifetime plane)
-        const fw_rsrc r2 = fw_make_rsrc(p2 + (size_t)w_lo * 16u, m2 ? w_n * 16u : 0u), r3 = fw_make_rsrc(p3 + (size_t)w_lo * 16u, m2 ? w_n * 16u : 0u);
-        const fw_rsrc rlf = fw_make_rsrc(pl + (size_t)w_lo * 4u, m2 ? 0u : w_n * 4u);
+        const fw_rsrc r2 = fw_make_rsrc(p2 + (size_t)w_lo * 16u, m2 ? w_n * 16u : 0u);
+        const fw_rsrc r3x = fw_make_rsrc(p3 + (size_t)w_lo * 4u, m2 ? w_n * 4u : 0u), r3y = fw_make_rsrc(p3 + cp + (size_t)w_lo * 4u, m2 ? w_n * 4u : 0u);
+        const fw_rsrc r3z = fw_make_rsrc(p3 + 2 * cp + (size_t)w_lo * 4u, m2 ? w_n * 4u : 0u);
+        const fw_rsrc rlf = rl;  // (the lifetime: `pl` is the w plane of Q3 for a type that can turn)
+        auto ldq3 = [&](uint32_t ir) -> float4 {
+            if constexpr (ALLNOSPIN) return make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            else return make_float4(fw_ldb1<NT == 2>(r3x, ir / 4u), fw_ldb1<NT == 2>(r3y, ir / 4u), fw_ldb1<NT == 2>(r3z, ir / 4u), 0.0f);
+        };
         const uint32_t i0 = woff(0), i1 = woff(min(1, YR - 1));
-        q0c = fw_ldb4<NT == 2>(r0, i0), q3c = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r3, i0), lfc = fw_ldb1<NT == 2>(rlf, i0 / 4u);
-        q1c = fw_ldb4<NT == 2>(r1, i0), q2c = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r2, i0);
-        q0n = fw_ldb4<NT == 2>(r0, i1), q3n = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r3, i1), lfn = fw_ldb1<NT == 2>(rlf, i1 / 4u);
-        q1n = fw_ldb4<NT == 2>(r1, i1), q2n = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r2, i1);
+        q0c = fw_ldb4<NT == 2>(r0, i0), q3c = ldq3(i0), lfc = fw_ldb1<NT == 2>(rlf, i0 / 4u);
+        q1c = ldq1(i0), q2c = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r2, i0);
+        q0n = fw_ldb4<NT == 2>(r0, i1), q3n = ldq3(i1), lfn = fw_ldb1<NT == 2>(rlf, i1 / 4u);
+        q1n = ldq1(i1), q2n = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r2, i1);
         const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
         const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & ~FW_TYPE_IDX_NOSPIN);
         if (tid < keys_len) s_keys[tid] = key0;
@@ -740,10 +767,10 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
         for (int r = 0; r < YR; r++) {
             const uint32_t s = sbase + r * BLK + tid;
             const uint32_t in_ = woff(min(r + 2, YR - 1));  // two rounds ahead (the last re-read)
-            const float4 q0f = fw_ldb4<NT == 2>(r0, in_), q3f = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r3, in_);
+            const float4 q0f = fw_ldb4<NT == 2>(r0, in_), q3f = ldq3(in_);
             const float lff = fw_ldb1<NT == 2>(rlf, in_ / 4u);
-            const float4 q1f = fw_ldb4<NT == 2>(r1, in_), q2f = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r2, in_);
-            if (nospin) q3c = make_float4(0.0f, 0.0f, 0.0f, lfc);
+            const float4 q1f = ldq1(in_), q2f = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r2, in_);
+            q3c.w = lfc;  // (a type that cannot turn: x, y, z came back as zeros -- a zero-length window)
             uint32_t yi = s - b;  // index within the young part
             if (s < b) yi += C;
             const bool mine = yi < y_exist;
@@ -756,7 +783,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
             fw_coll_step<COLL>(g, CA, mine, a.dt, q0c, q1c, &cpos, &cvel);
             if (mine)
                 fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, COLL ? &cpos : nullptr,
-                                                 COLL ? &cvel : nullptr, nullptr, false, yi >= y_full, CA.on);
+                                                 COLL ? &cvel : nullptr, nullptr, false, yi >= y_full, CA.on, WMODE);
             if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n, lfc = lfn;
             q0n = q0f, q1n = q1f, q2n = q2f, q3n = q3f, lfn = lff;
@@ -859,11 +886,12 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
         uint32_t s = bm1 - d;  // in [0, 2 C)
         if (s >= C) s -= C;
         q0[r] = fw_ld4w<NT == 2>(p0, s * 16u);
-        const float4 q3v = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p3, (s * 16u) & m2);
-        const float lf = fw_ld1w<NT == 2>(m2 ? p0 : pl, m2 ? 0u : s * 4u);
-        q1[r] = fw_ld4w<NT == 2>(p1, s * 16u);
+        const float lf = fw_ld1w<NT == 2>(pl, s * 4u);  // (the lifetime plane, or the w plane of Q3)
+        float4 q3v = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        if constexpr (!ALLNOSPIN) q3v = fw_ldc3w<NT == 2>(p3, cp, (s * 4u) & m2, lf);
+        q1[r] = fw_ldc4w<NT == 2>(p1, cp, s * 4u);  // (compacted: initial_scale moves with the particle)
         const float4 q2v = fw_ld4w_opt<ALLNOSPIN, NT == 2>(p2, (s * 16u) & m2);
-        lifev[r] = nospin ? lf : q3v.w;
+        lifev[r] = lf;
         if constexpr (!ALLNOSPIN) {
             if (!nospin) s_q2[r * BLK + tid] = q2v, s_q3[r * BLK + tid] = q3v;  // (workgroup-uniform branch)
         }
@@ -918,7 +946,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
         m[r] = __ballot(alive);
         uint32_t c = (uint32_t)__popcll(m[r]);
         asm volatile("; fw_k_update_range: input held before the count is published"
-                     : "+v"(c) : "v"(q0[r].x), "v"(q1[r].x), "v"(lifev[r]));
+                     : "+v"(c) : "v"(q0[r].x), "v"(q1[r].x), "v"(q1[r].y), "v"(q1[r].z), "v"(q1[r].w), "v"(lifev[r]));
         if (nlp) asm volatile("; ... and the last_emitted_age planes" : "+v"(c) : "v"(lkv[0][r]), "v"(lkv[1][r]));
         if (lane == 0) s_cnt[r][wave] = c;
     }

@@ -225,7 +225,10 @@ def test_unchanged_planes_are_not_written_but_changed_ones_are(system):
         # reads neither its rotation nor its angular-velocity / lifetime plane: position+age and velocity in, the same out;
         # the second type spins and its angular velocity decays: all four state planes in, all of them + the scale out)
         # (round 6: the scale is left to the readers as well -- FW_TYPE_DERIVED for every type, parity.planes_left_to_readers)
-        assert pair.gpu.update_path(0)[1] == 32 + 32 and pair.gpu.update_path(1)[1] == 64 + 32 + 32 + 4 * (1 - parity.planes_left_to_readers())
+        # (round 6, component planes: velocity and angular velocity move as 12 bytes, their constants stay; initial_scale is read -- 4 B --
+        # only where the scale plane is stored)
+        Dm = 1 - parity.planes_left_to_readers()
+        assert pair.gpu.update_path(0)[1] == 28 + 28 + 4 * Dm and pair.gpu.update_path(1)[1] == 56 + 28 + 16 + 12 + 8 * Dm
     for fr in range(90):
         system.update(DT)
         pair.step_cpu(DT)
