@@ -100,6 +100,11 @@ struct alignas(16) FwType {
 // (the update kernels of the general path learn the flag before the type record arrives -- their loads depend on it --
 // from bit 31 of the type index in the tile descriptor / FwUpdateArgs::seg0_type / FwFifoSeg::type_idx)
 #define FW_TYPE_IDX_NOSPIN 0x80000000u
+// (range descriptors, round 6: bit 30 = FW_TYPE_DERIVED and no attached instance buffer -- nobody in a YOUNG tile needs the particle's
+// lifetime except the consistency check, which the tile at the boundary to the old part runs for everybody: ages never increase along
+// the list, so if the oldest young particles cannot die nobody behind them can.  The other young tiles do not load it: 60 -> 56 B)
+#define FW_TYPE_IDX_NOLIFE 0x40000000u
+#define FW_TYPE_IDX_MASK 0x3FFFFFFFu
 // collision_settings of a particle type (core.rs:137-138, 240-248), in a table of its own next to FwType: only the
 // collision kernels read it, the streaming kernels' per-type record (and their scalar-register budget) stays as it was
 struct alignas(16) FwTypeColl {

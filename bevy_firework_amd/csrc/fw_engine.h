@@ -765,7 +765,7 @@ struct fw_ctx {
     // rings of the context hold range_young_big particles each or more on average (hysteresis of a quarter; a change re-sends the
     // table), 1024 (4) otherwise and always with an attached instance buffer.  FW_RANGE_YOUNG_BIG=n (0: never)
     uint32_t range_young_rounds = 4;
-    uint32_t range_young_big = 32768;
+    uint32_t range_young_big = 0xFFFFFFFFu;  // (round 6, component planes: young tiles of 1024 slots at every size -- configs[2] 199 -> 185 us; 32768 before)
     std::vector<FwOp> range_ops;  // this frame's Global ops that feed range rings
     // age, BEFORE the current frame's update, of a particle born in frame f -- the same for every segment of the context:
     // born with age 0, then one fp32 addition per frame (core.rs:594), exactly the device's additions

@@ -737,6 +737,7 @@ static fw_status attach_instances(fw_ctx *ctx, fw_spawner h, uint32_t type, void
     S.inst = (char *)d_out;
     S.inst_cap = d_out ? (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull) : 0u;
     S.inst_window = d_out != nullptr && window;
+    if (S.range) ctx->r_force = true;  // (the range descriptors carry FW_TYPE_IDX_NOLIFE: derived AND no buffer attached)
     // the records carry scale and colours from now on: the update stops storing the three planes that would duplicate them
     // (every reader of those planes evaluates them instead, so a buffer smaller than the live count loses nothing either);
     // colliding types stay as they are (the feature path)
@@ -1031,12 +1032,12 @@ fw_status fw_debug_update_path(fw_ctx *ctx, fw_spawner h, uint32_t type, int32_t
         // shared their float4, initial_scale and lifetime, stay where they are: every byte moved is algorithmic)
         moved = (S.nospin ? 28u : 56u) + 28u + q2 + (q3 ? 12u : 0u) + (T.scale.kind != 0 ? 4u : 0u) + colours;
         algo = moved;
-        // (a range ring: lifetimes differ from particle to particle -- 4 B read, from the lifetime plane of a type that cannot turn or
-        // from the w plane of Q3; the part of the list that may lose particles, a fifth of configs[2], is compacted in place and
-        // rewrites every plane it keeps: the figure is the young part's)
-        if (S.range) moved += 4u, algo += 4u;
-        // (initial_scale is read where somebody evaluates the scale: a type whose planes are stored, an attached instance buffer)
-        if (!S.derived || S.inst != nullptr) moved += 4u, algo += 4u;
+        // (a range ring: the part of the list that may lose particles, a fifth of configs[2], is compacted in place and reads and
+        // rewrites every plane it keeps, the 4-byte lifetime included: the figure is the young part's)
+        // (initial_scale -- and in a range ring the lifetime -- are read where somebody evaluates the scale: a type whose planes are
+        // stored, an attached instance buffer.  Otherwise the young tile at the boundary to the old part alone reads the lifetimes, for the
+        // consistency check: FW_TYPE_IDX_NOLIFE)
+        if (!S.derived || S.inst != nullptr) moved += S.range ? 8u : 4u, algo += S.range ? 8u : 4u;
     } else {
         // compacting: every state plane lands at a new slot (+ the last_emitted planes of a Nested parent, read and written);
         // a type that cannot turn keeps no rotation plane: -16 B read, -16 B written,

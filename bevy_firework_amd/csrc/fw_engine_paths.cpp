@@ -312,6 +312,7 @@ fw_status set_derived(fw_ctx *ctx, uint32_t si, bool on, bool refill) {
     FW_HIP(ctx, hipMemcpy((char *)(ctx->d_types.d + s.type_idx) + offsetof(FwType, flags), &flags, sizeof flags, hipMemcpyHostToDevice));
     s.derived = on;
     ctx->fc_ok = false, ctx->boxes_epoch = 0;
+    if (s.range) ctx->r_force = true;  // (the range descriptors carry FW_TYPE_IDX_NOLIFE)
     return FW_OK;
 }
 

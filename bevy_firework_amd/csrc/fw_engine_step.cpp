@@ -1277,7 +1277,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                 const SegHost &S = ctx->segs[si];
                 FwRangeDesc &D = ctx->h_rdesc[t++];
                 D.seg = si, D.role_k = (role << 30) | k, D.old_first = S.r_status_base;
-                D.type_idx = S.type_idx | (S.nospin ? FW_TYPE_IDX_NOSPIN : 0u);
+                D.type_idx = S.type_idx | (S.nospin ? FW_TYPE_IDX_NOSPIN : 0u) | ((S.derived && S.inst == nullptr) ? FW_TYPE_IDX_NOLIFE : 0u);
                 D.keys_off = S.keys_off, D.keys_len = S.keys_len, D.n_old = S.r_old, D.pad = 0;
             };
             // Workgroups that are provisioned but probably idle -- the spares of every role, and the upper part of the OLD range

@@ -618,10 +618,13 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         const size_t sfirst = spec_base != 0xFFFFFFFFu ? (size_t)spec_base * 16u : (size_t)0;
         const uint32_t i0 = tid * 16u;
         q0c = fw_ld4w(ib + FW_OFF_Q0(C) + sfirst, i0);
-        q3c = fw_ldc4w(ib + FW_OFF_Q3(C) + sfirst / 4u, FW_CP(C), (i0 & m2) / 4u);  // (component planes, fw_dev.h)
-        lfc = fw_ld1w((m2 ? ib + FW_OFF_Q0(C) : ib + FW_OFF_L(C, n_lplanes)) + (m2 ? (size_t)0 : sfirst / 4u), m2 ? 0u : i0 / 4u);
+        // (Q1 / Q3: component planes, fw_dev.h.  The lifetime: a plane of its own for a type that cannot turn, the w plane of Q3 otherwise --
+        // one load either way; rotation and angular velocity under a workgroup-UNIFORM branch: three dummy loads per round cost the
+        // compacting launches of configs[2] address-unit time they do not have)
+        lfc = fw_ld1w((m2 ? ib + FW_OFF_Q3(C) + 3 * FW_CP(C) : ib + FW_OFF_L(C, n_lplanes)) + sfirst / 4u, i0 / 4u);
         q1c = fw_ldc4w(ib + FW_OFF_Q1(C) + sfirst / 4u, FW_CP(C), i0 / 4u);
-        q2c = fw_ld4w(ib + FW_OFF_Q2(C) + sfirst, i0 & m2);
+        q3c = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q2c = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        if (m2) q3c = fw_ldc3w(ib + FW_OFF_Q3(C) + sfirst / 4u, FW_CP(C), i0 / 4u, 0.0f), q2c = fw_ld4w(ib + FW_OFF_Q2(C) + sfirst, i0);
     }
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
     // SPAWN_NONE frames may have had this frame's new particles MATERIALISED behind the live ones (Global ops of a frame
@@ -722,14 +725,14 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     const size_t cp = FW_CP(C);  // (Q1 / Q3: component planes -- windows of the x plane, 4 bytes per slot)
     const char *iw0 = ib + FW_OFF_Q0(C) + ifirst, *iw1 = ib + FW_OFF_Q1(C) + ifirst / 4u;
     const char *iw2 = ib + FW_OFF_Q2(C) + ifirst, *iw3 = ib + FW_OFF_Q3(C) + ifirst / 4u;
-    const char *iwl = m2 ? iw0 : ib + FW_OFF_L(C, n_lplanes) + ifirst / 4u;  // lifetime plane (or any valid address)
+    const char *iwl = (m2 ? ib + FW_OFF_Q3(C) + 3 * cp : ib + FW_OFF_L(C, n_lplanes)) + ifirst / 4u;  // lifetimes: the w plane of Q3, or their own plane
     if (!LONE || (loaded_tile && base != spec_base)) {  // LONE: only a tile whose role differs from the guess reloads
         const uint32_t i0 = loaded_tile ? min(tid, last - base) * 16u : 0u;
         q0c = fw_ld4w(iw0, i0);
-        q3c = fw_ldc4w(iw3, cp, (i0 & m2) / 4u);
-        lfc = fw_ld1w(iwl, m2 ? 0u : i0 / 4u);
+        lfc = fw_ld1w(iwl, i0 / 4u);
         q1c = fw_ldc4w(iw1, cp, i0 / 4u);
-        q2c = fw_ld4w(iw2, i0 & m2);
+        q3c = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q2c = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        if (m2) q3c = fw_ldc3w(iw3, cp, i0 / 4u, 0.0f), q2c = fw_ld4w(iw2, i0);
     }
     const FwType T = g.types[type_idx];  // scalar loads; first needed in the round loop
     if (tid < keys_len) s_keys[tid] = key0;
@@ -850,11 +853,11 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             const uint32_t idx = base + r * BLK + tid;
             const uint32_t in_ = min((r + 1) * BLK + tid, last - base) * 16u;  // next round's slot (clamped: see above)
             const float4 q0n = fw_ld4w(iw0, in_);
-            const float4 q3n = fw_ldc4w(iw3, cp, (in_ & m2) / 4u);
-            const float lfn = fw_ld1w(iwl, m2 ? 0u : in_ / 4u);
+            const float lfn = fw_ld1w(iwl, in_ / 4u);
             const float4 q1n = fw_ldc4w(iw1, cp, in_ / 4u);
-            const float4 q2n = fw_ld4w(iw2, in_ & m2);
-            if (!m2) q3c = make_float4(0.0f, 0.0f, 0.0f, lfc);
+            float4 q3n = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q2n = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            if (m2) q3n = fw_ldc3w(iw3, cp, in_ / 4u, 0.0f), q2n = fw_ld4w(iw2, in_);  // (workgroup-uniform)
+            q3c.w = lfc;
             const bool valid = idx < lim;
             float age_new;
             const bool alive = valid && fw_survives(q0c.w, a.dt, q3c.w, &age_new);

@@ -296,13 +296,23 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
         if constexpr (INST) return fw_ldc4w<NT == 2>(iw1, cp, o16 / 4u);
         else return fw_ldc3w<NT == 2>(iw1, cp, o16 / 4u, 0.0f);
     };
-    auto ld3 = [&](uint32_t o16) -> float4 { return fw_ldc3w<NT == 2>(iw3, cp, (o16 & m2) / 4u, F.life); };
+    // (rotation and angular velocity of a type that cannot turn: not even dummy loads -- a workgroup-uniform branch)
+    auto ld3 = [&](uint32_t o16) -> float4 {
+        float4 v = q3s;
+        if (!nospin) v = fw_ldc3w<NT == 2>(iw3, cp, o16 / 4u, F.life);
+        return v;
+    };
+    auto ld2 = [&](uint32_t o16) -> float4 {
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        if (!nospin) v = fw_ld4w<NT == 2>(iw2, o16);
+        return v;
+    };
     if (!spawner && !defer) {
         q0c = fw_ld4w<NT == 2>(iw0, tid * 16u), q3c = ld3(tid * 16u);
-        q1c = ld1(tid * 16u), q2c = fw_ld4w<NT == 2>(iw2, (tid * 16u) & m2);
+        q1c = ld1(tid * 16u), q2c = ld2(tid * 16u);
         if constexpr (R > 1) {
             q0n = fw_ld4w<NT == 2>(iw0, i1), q3n = ld3(i1);
-            q1n = ld1(i1), q2n = fw_ld4w<NT == 2>(iw2, i1 & m2);
+            q1n = ld1(i1), q2n = ld2(i1);
         }
     }
     if (defer) {
@@ -310,10 +320,10 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
         if (sbase < head) i0 += C;
         if (tis != 0u && !(i0 < n_tot || (i0 + TILE > C && n_tot != 0u))) return;
         q0c = fw_ld4w<NT == 2>(iw0, tid * 16u), q3c = ld3(tid * 16u);
-        q1c = ld1(tid * 16u), q2c = fw_ld4w<NT == 2>(iw2, (tid * 16u) & m2);
+        q1c = ld1(tid * 16u), q2c = ld2(tid * 16u);
         if constexpr (R > 1) {
             q0n = fw_ld4w<NT == 2>(iw0, i1), q3n = ld3(i1);
-            q1n = ld1(i1), q2n = fw_ld4w<NT == 2>(iw2, i1 & m2);
+            q1n = ld1(i1), q2n = ld2(i1);
         }
     }
     if (blockIdx.x == 0 && tid == 0) {
@@ -403,7 +413,7 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
             float4 q0f = q0c, q3f = q3c, q1f = q1c, q2f = q2c;
             if constexpr (R > 1) {  // (a one-round workgroup has nothing to prefetch)
                 q0f = fw_ld4w<NT == 2>(iw0, in_), q3f = ld3(in_);
-                q1f = ld1(in_), q2f = fw_ld4w<NT == 2>(iw2, in_ & m2);
+                q1f = ld1(in_), q2f = ld2(in_);
             }
             if (nospin) q3c = q3s;
             uint32_t i = s - head;  // logical index of the slot
@@ -675,7 +685,9 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
         const fw_rsrc r1x = fw_make_rsrc(p1 + (size_t)w_lo * 4u, w_n * 4u), r1y = fw_make_rsrc(p1 + cp + (size_t)w_lo * 4u, w_n * 4u);
         const fw_rsrc r1z = fw_make_rsrc(p1 + 2 * cp + (size_t)w_lo * 4u, w_n * 4u);
         const fw_rsrc r1w = fw_make_rsrc(p1 + 3 * cp + (size_t)w_lo * 4u, INST ? w_n * 4u : 0u);
-        const fw_rsrc rl = fw_make_rsrc(pl + (size_t)w_lo * 4u, w_n * 4u);
+        // (the lifetime: every tile of a type somebody evaluates the scale of; otherwise the boundary tile alone -- FW_TYPE_IDX_NOLIFE)
+        const bool need_lf = INST || k == 0u || !(D.type_idx & FW_TYPE_IDX_NOLIFE);
+        const fw_rsrc rl = fw_make_rsrc(pl + (size_t)w_lo * 4u, need_lf ? w_n * 4u : 0u);
         auto ldq1 = [&](uint32_t ir) -> float4 {
             const uint32_t i4 = ir / 4u;
             float w = 0.0f;
@@ -702,8 +714,8 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
                 const uint32_t ir = woff(r);
                 q0a[r] = fw_ldb4<NT == 2>(r0, ir), lfa[r] = fw_ldb1<NT == 2>(rl, ir / 4u), q1a[r] = ldq1(ir);
             }
-            const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
-            const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & ~FW_TYPE_IDX_NOSPIN);
+            const FwType T = g.types[D.type_idx & FW_TYPE_IDX_MASK];
+            const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & FW_TYPE_IDX_MASK);
             if (tid < keys_len) s_keys[tid] = key0;
             for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
             __syncthreads();
@@ -723,7 +735,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
                 }
                 float age_new;
                 const bool surv = fw_survives(q0v.w, a.dt, q3v.w, &age_new);
-                bad |= mine && !surv;
+                bad |= need_lf && mine && !surv;
                 const unsigned long long mi = (INST && inst != nullptr) ? __ballot(mine) : 0ull;
                 float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(mi) * 4u : nullptr;
                 fw_v3 cpos, cvel;
@@ -754,8 +766,8 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
         q1c = ldq1(i0), q2c = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r2, i0);
         q0n = fw_ldb4<NT == 2>(r0, i1), q3n = ldq3(i1), lfn = fw_ldb1<NT == 2>(rlf, i1 / 4u);
         q1n = ldq1(i1), q2n = fw_ldb4_opt<ALLNOSPIN, NT == 2>(r2, i1);
-        const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
-        const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & ~FW_TYPE_IDX_NOSPIN);
+        const FwType T = g.types[D.type_idx & FW_TYPE_IDX_MASK];
+        const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & FW_TYPE_IDX_MASK);
         if (tid < keys_len) s_keys[tid] = key0;
         for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
         __syncthreads();
@@ -776,7 +788,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
             const bool mine = yi < y_exist;
             float age_new;
             const bool surv = fw_survives(q0c.w, a.dt, q3c.w, &age_new);
-            bad |= mine && !surv;  // the host's cohort ages say nobody young can die
+            bad |= need_lf && mine && !surv;  // the host's cohort ages say nobody young can die
             const unsigned long long mi = (INST && inst != nullptr) ? __ballot(mine) : 0ull;
             float4 *rec = (INST && inst != nullptr) ? s_inst_wave + fw_lane_prefix(mi) * 4u : nullptr;
             fw_v3 cpos, cvel;
@@ -801,8 +813,8 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
 
     if (role == FW_RANGE_NEW) {
         if (k * BLK >= n_spawn_h) return;
-        const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
-        const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & ~FW_TYPE_IDX_NOSPIN);
+        const FwType T = g.types[D.type_idx & FW_TYPE_IDX_MASK];
+        const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & FW_TYPE_IDX_MASK);
         if (tid < keys_len) s_keys[tid] = key0;
         for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
         __syncthreads();
@@ -929,8 +941,8 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
                 if ((uint32_t)j < nlp) lkv[j][r] = fw_ld1w<NT == 2>(buf + FW_OFF_L(C, j), s * 4u);
         }
     }
-    const FwType T = g.types[D.type_idx & ~FW_TYPE_IDX_NOSPIN];
-    const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & ~FW_TYPE_IDX_NOSPIN);
+    const FwType T = g.types[D.type_idx & FW_TYPE_IDX_MASK];
+    const FwCollArm CA = fw_coll_arm<COLL>(g, D.type_idx & FW_TYPE_IDX_MASK);
     if (tid < keys_len) s_keys[tid] = key0;
     for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
     float age_new[R];

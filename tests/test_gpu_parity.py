@@ -465,14 +465,14 @@ def test_attached_instances_replace_the_scale_and_colour_planes(system):
             # evaluates the scale: with stored planes, or with records; a range ring that continues on the compacting path moves the
             # 16 bytes of Q1 and the lifetime plane both ways again: 60 -> 72)
             if attached[0][0] == pair_path0:
-                adj = 4 * D if pair_path0 in ("fifo", "range") else 0
+                adj = (8 if pair_path0 == "range" else 4) * D if pair_path0 in ("fifo", "range") else 0
             else:
-                adj = 12 - 4 * (1 - D)
+                adj = 16 - 8 * (1 - D)  # (range ring, planes left to the readers: 56; with stored planes + lifetime + initial_scale)
             assert attached[0][1] == before[0] - 36 * (1 - D) + 64 + adj, (before, attached)
         if fr == 100:
             for t in (0, 1):
                 pair.gpu.attach_instances(0, 0, particle_type=t)
-            assert pair.gpu.update_path(0)[1] == attached[0][1] + 36 * (1 - D) - 64 - (4 * D if attached[0][0] in ("fifo", "range") else 0)
+            assert pair.gpu.update_path(0)[1] == attached[0][1] + 36 * (1 - D) - 64 - ((8 if attached[0][0] == "range" else 4) * D if attached[0][0] in ("fifo", "range") else 0)
             check("right after detaching")
         dt = np.float32(0.55 if fr == 70 else DT)  # frame 70: longer than type 0 lives -- born and destroyed in one frame
         system.update(dt)
@@ -646,7 +646,7 @@ def test_two_entries_with_different_rotations_keep_the_plane(system):
     # (ring, round 6: Q0 + rotation as float4, velocity + angular velocity as 12 bytes in; Q0 + velocity out; + the lifetime of a range ring,
     # + initial_scale where the scale plane is stored)
     D = parity.planes_left_to_readers()
-    assert pair.gpu.update_path(0)[1] in (164 - 32 - 4 * D, 56 + 28 + 8 * (1 - D), 56 + 28 + 4 + 8 * (1 - D))
+    assert pair.gpu.update_path(0)[1] in (164 - 32 - 4 * D, 56 + 28 + 4 * (1 - D), 56 + 28 + 8 * (1 - D))
     run(system, pair, 60, check_every=12, exact_all=True)
     assert len(np.unique(pair.gpu.particles(0)["rotation"], axis=0)) == 2
 
@@ -659,8 +659,8 @@ def test_a_non_finite_step_brings_the_rotation_plane_back(system):
     run(system, pair, 5, exact_all=True)
     before = pair.gpu.update_path(0)[1]
     D = parity.planes_left_to_readers()  # (the 4-byte scale plane is left to the readers)
-    if pair.gpu.update_path(0)[0] == "range":  # in place: position+age, velocity (12 B) and the 4-byte lifetime in, the first two out
-        before += 164 - 32 - 56 - 4 * D - (28 + 4 + 28 + 8 * (1 - D))
+    if pair.gpu.update_path(0)[0] == "range":  # in place: position+age and velocity (12 B) in and out
+        before += 164 - 32 - 56 - 4 * D - (28 + 28 + 8 * (1 - D))  # (+ lifetime and initial_scale where the scale plane is stored)
     system.update(np.float32("nan"))
     pair.step_cpu(np.float32("nan"))
     assert before == 164 - 32 - 56 - 4 * D and pair.gpu.update_path(0)[1] == 164 - 32 - 4 * D and pair.gpu.update_path(0)[0] in ("general", "small")
