@@ -139,10 +139,13 @@ __device__ __forceinline__ uint4 fw_ld4u(const char *win, uint32_t byte_off) {
 __device__ __forceinline__ uint32_t fw_ld1u(const uint32_t *base, uint32_t idx) {
     return reinterpret_cast<const FW_GLOBAL uint32_t *>(reinterpret_cast<uintptr_t>(base))[idx];
 }
-// ---- component planes (round 6, fw_device.h): the Q1 and Q3 regions of a buffer hold their four components as four 4-byte planes
-// of C slots each -- x at +0, y at +4C, z at +8C, w at +12C bytes -- because `.w` of both (initial_scale, lifetime) never changes:
+// ---- component planes (round 6, fw_device.h; RING segments only -- FwSeg::cpl): the Q1 and Q3 regions of a ring's buffer hold their
+// four components as four 4-byte planes of C slots each -- x at +0, y at +4C, z at +8C, w at +12C bytes -- because `.w` of both (initial_scale, lifetime) never changes:
 // an in-place update loads and stores three dwords per lane and plane instead of a dwordx4 (tools/inplace.hip: the shapes follow the
 // bytes with scalar planes, 1M particles 16.6 -> 14.7 us, 16M 167.5 -> 147.5; packed float3 planes -- dwordx3 -- get SLOWER).
+// Segments on the compacting paths keep float4 planes: out of place everything moves anyway, and four dword accesses where one dwordx4
+// did cost the streaming kernel 5-9 % (profiles/r06/component_planes.txt); a ring that leaves for those paths is transposed where it
+// is copied (realloc_segment).  Readers take the layout as a flag (fw_ldq).
 // `reg`: the region's base (buf + FW_OFF_Q1 / Q3); `win`: the x plane advanced to a window's first slot; off4 = 4 * (slot - first).
 #define FW_CP(C) ((size_t)4 * (C))  // bytes between two component planes of a region
 __device__ __forceinline__ float4 fw_ldc4(const char *reg, uint32_t C, uint32_t i) {
@@ -156,6 +159,17 @@ __device__ __forceinline__ float4 fw_ldc3(const char *reg, uint32_t C, uint32_t 
 __device__ __forceinline__ void fw_stc4(char *reg, uint32_t C, uint32_t i, float4 v) {
     const size_t cp = FW_CP(C);
     fw_st1(reg, i, v.x), fw_st1(reg + cp, i, v.y), fw_st1(reg + 2 * cp, i, v.z), fw_st1(reg + 3 * cp, i, v.w);
+}
+// element i of a Q1 / Q3 region in either layout (cpl: component planes) -- the readers
+__device__ __forceinline__ float4 fw_ldq(const char *reg, uint32_t C, uint32_t i, bool cpl) {
+    return cpl ? fw_ldc4(reg, C, i) : fw_ld4(reg, i);
+}
+__device__ __forceinline__ float fw_ldq_w(const char *reg, uint32_t C, uint32_t i, bool cpl) {
+    return cpl ? fw_ld1(reg + 3 * FW_CP(C), i) : fw_ld4(reg, i).w;
+}
+__device__ __forceinline__ void fw_stq(char *reg, uint32_t C, uint32_t i, float4 v, bool cpl) {
+    if (cpl) fw_stc4(reg, C, i, v);
+    else fw_st4(reg, i, v);
 }
 template <bool NT = false>
 __device__ __forceinline__ float4 fw_ldc4w(const char *win, size_t cp, uint32_t off4) {
@@ -200,7 +214,7 @@ __device__ __forceinline__ float fw_ldb1(fw_rsrc r, uint32_t byte_off) {
 }
 
 struct FwOutWin {  // output planes advanced to slot `first` (workgroup-uniform)
-    char *q0, *q1, *q2, *q3, *q5, *q6, *s4;  // (q1 / q3: the x plane of the region, advanced by 4 * first; components `cp` bytes apart)
+    char *q0, *q1, *q2, *q3, *q5, *q6, *s4;  // (q1 / q3 of a ring -- component planes: the x plane advanced by 4 * first, `cp` bytes apart)
     size_t cp;
     uint32_t first;
     // A gradient with a single key (the reference's default emissive colour, core.rs:205) gives every particle of the
@@ -216,9 +230,9 @@ struct FwOutWin {  // output planes advanced to slot `first` (workgroup-uniform)
     bool wr4;  // scale plane (false, like wr5 / wr6, for a type whose instance records carry it: FW_TYPE_DERIVED)
 };
 __device__ __forceinline__ FwOutWin fw_out_window(char *ob, uint32_t C, uint32_t first, const FwType &T, uint32_t force_colors,
-                                                  uint32_t n_lplanes = 0u) {
-    const size_t f16 = (size_t)first * 16u, f4 = (size_t)first * 4u;
-    return FwOutWin{ob + FW_OFF_Q0(C) + f16, ob + FW_OFF_Q1(C) + f4, ob + FW_OFF_Q2(C) + f16, ob + FW_OFF_Q3(C) + f4,
+                                                  uint32_t n_lplanes = 0u, bool cpl = false) {
+    const size_t f16 = (size_t)first * 16u, f4 = (size_t)first * 4u, fq = cpl ? f4 : f16;
+    return FwOutWin{ob + FW_OFF_Q0(C) + f16, ob + FW_OFF_Q1(C) + fq, ob + FW_OFF_Q2(C) + f16, ob + FW_OFF_Q3(C) + fq,
                     ob + FW_OFF_Q5(C) + f16, ob + FW_OFF_Q6(C) + f16, ob + FW_OFF_S4(C) + f4, FW_CP(C), first,
                     (T.bc_kind != 0 || force_colors != 0u) && !(T.flags & FW_TYPE_DERIVED),
                     (T.em_kind != 0 || force_colors != 0u) && !(T.flags & FW_TYPE_DERIVED), !(T.flags & FW_TYPE_NOSPIN),
@@ -240,13 +254,14 @@ __device__ __forceinline__ uint32_t fw_range_head(uint32_t b, uint32_t rold, uin
 
 // Q3 (angular velocity, lifetime) of particle `idx`: from the plane, or -- a type that cannot turn -- zero and the lifetime
 // plane (FwOutWin::lf)
-__device__ __forceinline__ float4 fw_load_q3(const char *buf, uint32_t C, uint32_t n_lplanes, uint32_t idx, bool nospin) {
+__device__ __forceinline__ float4 fw_load_q3(const char *buf, uint32_t C, uint32_t n_lplanes, uint32_t idx, bool nospin, bool cpl = false) {
     if (nospin) return make_float4(0.0f, 0.0f, 0.0f, fw_ld1(buf + FW_OFF_L(C, n_lplanes), idx));
-    return fw_ldc4(buf + FW_OFF_Q3(C), C, idx);
+    return fw_ldq(buf + FW_OFF_Q3(C), C, idx, cpl);
 }
 // ... and the lifetime alone
-__device__ __forceinline__ float fw_load_lifetime(const char *buf, uint32_t C, uint32_t n_lplanes, uint32_t idx, bool nospin) {
-    return fw_ld1(nospin ? buf + FW_OFF_L(C, n_lplanes) : buf + FW_OFF_Q3(C) + 3 * FW_CP(C), idx);
+__device__ __forceinline__ float fw_load_lifetime(const char *buf, uint32_t C, uint32_t n_lplanes, uint32_t idx, bool nospin, bool cpl) {
+    if (nospin) return fw_ld1(buf + FW_OFF_L(C, n_lplanes), idx);
+    return fw_ldq_w(buf + FW_OFF_Q3(C), C, idx, cpl);
 }
 
 // alive test of update_particles: `if particle.age >= particle.lifetime { destroyed }` (core.rs:594-599)
@@ -345,9 +360,9 @@ __device__ __forceinline__ void fw_store_new(const FwGlobals &g, const FwSeg &S,
     fw_gradient_sample(T.bc_kind, T.bc_n, keys + T.o_bc_t, keys + T.o_bc_v, 0.0f, bc);
     fw_gradient_sample(T.em_kind, T.em_n, keys + T.o_em_t, keys + T.o_em_v, 0.0f, em);
     fw_st4(buf + FW_OFF_Q0(C), slot, o.q0);
-    fw_stc4(buf + FW_OFF_Q1(C), C, slot, o.q1);
+    fw_stq(buf + FW_OFF_Q1(C), C, slot, o.q1, S.cpl != 0u);  // (a ring's Q1 / Q3: component planes)
     fw_st4(buf + FW_OFF_Q2(C), slot, o.q2);
-    fw_stc4(buf + FW_OFF_Q3(C), C, slot, o.q3);
+    fw_stq(buf + FW_OFF_Q3(C), C, slot, o.q3, S.cpl != 0u);
     if (T.flags & FW_TYPE_NOSPIN) fw_st1(buf + FW_OFF_L(C, S.n_lplanes), slot, o.q3.w);  // the lifetime plane (FwOutWin::lf)
     fw_st4(buf + FW_OFF_Q5(C), slot, make_float4(bc[0], bc[1], bc[2], bc[3]));
     fw_st4(buf + FW_OFF_Q6(C), slot, make_float4(em[0], em[1], em[2], em[3]));
@@ -416,7 +431,8 @@ __device__ __forceinline__ fw_q4 fw_quat_step(fw_v3 v) {
 // one another kernel materialised) and q1.w is valid; FW_W_MEM_LAZY: in the slot, q1.w NOT loaded -- the streaming loops leave it there
 // unless somebody needs the scale (a type whose planes are stored, an instance record, the boxes): then it is read here.
 enum { FW_W_REGS = 0, FW_W_MEM = 1, FW_W_MEM_LAZY = 2 };
-template <bool INPLACE = false, int WM = -1, int NT = 0>
+// CPL: the output segment is a ring -- Q1 / Q3 are component planes (the ring kernels; everybody else writes float4 planes)
+template <bool INPLACE = false, int WM = -1, int NT = 0, bool CPL = false>
 __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float *s_keys, float dt, float4 q0, float4 q1,
                                                    float4 q2, float4 q3, float age_new, const FwOutWin &W, uint32_t o,
                                                    float4 *rec = nullptr, const fw_v3 *cpos = nullptr,
@@ -433,7 +449,7 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     float bc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, em[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (need_cs) {
         float iscale = q1.w;
-        if (INPLACE && wmode == FW_W_MEM_LAZY) iscale = fw_ld1w<NT == 2>(W.q1 + 3 * W.cp, (o - W.first) * 4u);  // (workgroup-uniform branch)
+        if (INPLACE && CPL && wmode == FW_W_MEM_LAZY) iscale = fw_ld1w<NT == 2>(W.q1 + 3 * W.cp, (o - W.first) * 4u);  // (workgroup-uniform branch)
         const float age_percent = age_new / lifetime;
         const float scale_factor = fw_curve_sample(T.sc_kind, T.sc_n, s_keys, s_keys + T.o_sc_v, age_percent);
         scale = iscale * scale_factor;
@@ -466,8 +482,10 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
     const uint32_t b16 = (o - W.first) * 16u;  // < 16 KiB + a tile: the window starts at the tile's first output slot
     fw_st4w<NT == 2>(W.q0, b16, make_float4(px, py, pz, age_new));
     const uint32_t b4 = (o - W.first) * 4u;
-    fw_stc3w<NT == 2>(W.q1, W.cp, b4, vx, vy, vz);
+    if constexpr (CPL) fw_stc3w<NT == 2>(W.q1, W.cp, b4, vx, vy, vz);
+    else fw_st4w<NT == 2>(W.q1, b16, make_float4(vx, vy, vz, q1.w));
     if (INPLACE) {
+        static_assert(!INPLACE || CPL, "in place = a ring = component planes");
         // (initial_scale and lifetime never change: in place only a slot that holds nothing yet writes them -- wave-uniform branch)
         if (wmode == FW_W_REGS && __any(full)) {
             if (full) fw_st1w<NT == 2>(W.q1 + 3 * W.cp, b4, q1.w);
@@ -486,9 +504,13 @@ __device__ __forceinline__ void fw_integrate_store(const FwType &T, const float 
         if ((WM >= 0 ? (WM & 4) != 0 : (T.sc_kind != 0 && W.wr4)) || fullk) fw_st1w<NT != 0>(W.s4, (o - W.first) * 4u, scale);
     } else {
         if (W.wr2) fw_st4w<NT == 2>(W.q2, b16, make_float4(nr.x, nr.y, nr.z, nr.w));
-        fw_st1w<NT == 2>(W.q1 + 3 * W.cp, b4, q1.w);  // (out of place: the constants move with the particle)
-        if (W.wr3) fw_stc4w<NT == 2>(W.q3, W.cp, b4, make_float4(wx, wy, wz, lifetime));
-        else fw_st1w<NT == 2>(W.lf, b4, lifetime);
+        if constexpr (CPL) {
+            fw_st1w<NT == 2>(W.q1 + 3 * W.cp, b4, q1.w);  // (the old part of a range ring, its new particles: the constants are stored too)
+            if (W.wr3) fw_stc4w<NT == 2>(W.q3, W.cp, b4, make_float4(wx, wy, wz, lifetime));
+        } else {
+            if (W.wr3) fw_st4w<NT == 2>(W.q3, b16, make_float4(wx, wy, wz, lifetime));
+        }
+        if (!W.wr3) fw_st1w<NT == 2>(W.lf, b4, lifetime);
         if (W.wr5) fw_st4w<NT != 0>(W.q5, b16, make_float4(bc[0], bc[1], bc[2], bc[3]));  // workgroup-uniform branches
         if (W.wr6) fw_st4w<NT != 0>(W.q6, b16, make_float4(em[0], em[1], em[2], em[3]));
         if (W.wr4) fw_st1w<NT != 0>(W.s4, (o - W.first) * 4u, scale);

@@ -12,10 +12,11 @@
 // 16-byte aligned):
 //
 //   Q0  float4 {pos.x, pos.y, pos.z, age}            offset   0*C   read+write
-//   Q1  4 x float {vel.x | vel.y | vel.z | initial_scale}  offset 16*C  COMPONENT planes of C floats each, 4*C bytes apart
-//       (round 6: initial_scale never changes -- an in-place update loads and stores three dwords, not a dwordx4; fw_dev.h: FW_CP)
+//   Q1  float4 {vel.x, vel.y, vel.z, initial_scale}  offset  16*C   read+write
 //   Q2  float4 {rot.x, rot.y, rot.z, rot.w}          offset  32*C   read+write
-//   Q3  4 x float {angvel.x | .y | .z | lifetime}    offset  48*C   component planes like Q1 (lifetime never changes)
+//   Q3  float4 {angvel.x, .y, .z, lifetime}          offset  48*C   read+write
+//       (round 6, RING segments -- FwSeg::cpl: the Q1 and Q3 regions hold their four components as four planes of C floats each,
+//       4*C bytes apart: initial_scale and lifetime never change, an in-place update moves three dwords per lane, not a dwordx4)
 //   Q5  float4 base_color rgba                       offset  64*C   write only
 //   Q6  float4 emissive_color rgba                   offset  80*C   write only
 //   S4  float  scale                                 offset  96*C   write only
@@ -63,6 +64,9 @@ struct alignas(16) FwSeg {
     // nothing (offsets >= 0) and left `next` in the plane (core.rs:488-500): the spawning lane computes that value itself
     // (fw_init_last_emitted) and fw_k_spawn has nothing to materialise.
     uint32_t lplane_emit[2];
+    // 1: a RING segment (FIFO / range ring) -- its Q1 and Q3 regions are component planes (fw_dev.h: FW_CP); 0: float4 planes
+    uint32_t cpl;
+    uint32_t pad_[3];
 };
 
 // per particle type constants (ParticleSettings, reference src/core.rs:99-142)
@@ -174,7 +178,8 @@ struct alignas(16) FwNestOp {
     float n_count, n_start, n_end;  // CountOverDuration of the entry (core.rs:474-481)
     uint32_t parent_head;    // ring heads of the two segments (FIFO rings; 0 otherwise): particle i sits in slot
     uint32_t child_head;     // (head + i) mod capacity
-    uint32_t parent_nospin;  // the parent type cannot turn (FW_TYPE_NOSPIN): its rotation is parent_rot, not in the plane,
+    uint32_t parent_nospin;  // bit 0: the parent type cannot turn (FW_TYPE_NOSPIN): its rotation is parent_rot, not in the plane,
+                             // (bit 1: the parent segment is a ring -- its Q1 / Q3 are component planes, FwSeg::cpl)
     uint32_t parent_life_plane;  // ... and its lifetimes sit in this 4-byte plane (FW_OFF_L index), not in Q3;
     float parent_life_const;     // 0xFFFFFFFF: the parent is a ring, all its particles have this lifetime
     float parent_rot[4];

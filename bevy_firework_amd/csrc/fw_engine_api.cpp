@@ -549,7 +549,7 @@ static fw_status stage_buffer(fw_ctx *ctx, size_t bytes, void **out) {
 
 static fw_status read_records(fw_ctx *ctx, const char *buf, uint32_t cap_seg, uint32_t n, int32_t pbr, bool aos,
                               fw_particle *out, uint64_t cap, uint32_t head = 0, const float *const_rot = nullptr,
-                              uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.f, const FwType *derived = nullptr) {
+                              uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.f, const FwType *derived = nullptr, bool cpl = false) {
     const uint64_t m = std::min<uint64_t>(n, cap);
     if (!m || !out) return FW_OK;
     if (aos) {
@@ -560,7 +560,7 @@ static fw_status read_records(fw_ctx *ctx, const char *buf, uint32_t cap_seg, ui
     fw_status st = stage_buffer(ctx, m * sizeof(fw_particle), &tmp);
     if (st) return st;
     hipError_t e = fw_launch_gather(ctx->stream, buf, cap_seg, head, (uint32_t)m, pbr, tmp, const_rot, life_plane, life_const,
-                                    derived, ctx->d_keys.d);
+                                    derived, ctx->d_keys.d, cpl);
     // (the copy goes through the stream the kernel ran on, then one wait for both)
     if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, m * sizeof(fw_particle), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -583,7 +583,7 @@ fw_status fw_spawner_read_particles(fw_ctx *ctx, fw_spawner h, uint32_t type, fw
     fw_status st2 = read_records(ctx, S.buf[ctx->parity], S.capacity, n, sp->types[type].ps.pbr, false, out, cap,
                                  ring_head_exact(S, n), S.nospin ? S.const_rot : nullptr,
                                  (S.nospin && !S.fifo) ? S.n_lplanes : 0xFFFFFFFFu, S.fifo_life,
-                                 S.derived ? ctx->d_types.d + S.type_idx : nullptr);
+                                 S.derived ? ctx->d_types.d + S.type_idx : nullptr, S.ring());
     return st2 ? st2 : st;
 }
 
@@ -712,7 +712,7 @@ fw_status fw_spawner_pack_instances_device(fw_ctx *ctx, fw_spawner h, uint32_t t
     FW_HIP(ctx, fw_launch_pack_instances(ctx->stream, S.buf[ctx->parity], S.capacity, S.range ? S.young_lo : (S.fifo ? S.head : 0u),
                                          ctx->g.count + (size_t)ctx->parity * ctx->max_seg + si, ub, d_out,
                                          S.nospin ? S.const_rot : nullptr, S.range ? ctx->g.rold + (size_t)ctx->parity * ctx->max_seg + si : nullptr,
-                                         S.derived ? ctx->d_types.d + S.type_idx : nullptr, ctx->d_keys.d, S.life_plane(), S.fifo_life));
+                                         S.derived ? ctx->d_types.d + S.type_idx : nullptr, ctx->d_keys.d, S.life_plane(), S.fifo_life, S.ring()));
     return FW_OK;
 }
 

@@ -260,6 +260,7 @@ fw_status upload_seg(fw_ctx *ctx, uint32_t si) {
     d.type_idx = s.type_idx;
     d.n_lplanes = s.n_lplanes;
     d.inst = s.inst, d.inst_cap = s.inst_cap;
+    d.cpl = s.ring() ? 1u : 0u;  // (a ring's Q1 / Q3 regions: component planes, fw_device.h)
     d.lplane_emit[0] = d.lplane_emit[1] = 0xFFFFFFFFu;
     if (s.virt_parent && s.spawner >= 0)
         for (uint32_t k = 0; k < s.n_lplanes && k < 2u; k++) {

@@ -57,10 +57,27 @@ fw_status realloc_segment(fw_ctx *ctx, uint32_t si, uint32_t ncap, bool make_gen
     };
     const size_t OC = old.capacity, NC = ncap;
     FW_HIP(ctx, cp(FW_OFF_Q0(NC), FW_OFF_Q0(OC), 16));
-    // (Q1 / Q3: four component planes of 4-byte elements each, fw_device.h -- their distance follows the capacity)
-    for (size_t c = 0; c < 4; c++) FW_HIP(ctx, cp(FW_OFF_Q1(NC) + c * 4 * NC, FW_OFF_Q1(OC) + c * 4 * OC, 4));
+    // Q1 / Q3 of a RING are four component planes of 4-byte elements each (fw_device.h; their distance follows the capacity), of a segment
+    // of the compacting path float4 planes: a ring that grows keeps its layout, one that leaves for that path is transposed as it is
+    // unwrapped (hipMemcpy2D: rows of 4 bytes, 4 apart in the source, 16 apart in the destination)
+    const bool was_cpl = old.ring(), is_cpl = s.ring();
+    auto cpq = [&](size_t noff, size_t ooff) -> hipError_t {
+        if (!was_cpl) return cp(noff, ooff, 16);  // (float4 -> float4; nothing becomes a ring here)
+        hipError_t e = hipSuccess;
+        for (size_t c = 0; c < 4 && e == hipSuccess; c++) {
+            if (is_cpl) {
+                e = cp(noff + c * 4 * NC, ooff + c * 4 * OC, 4);
+            } else {
+                if (n1) e = hipMemcpy2D(s.buf[p] + noff + c * 4, 16, old.buf[p] + ooff + c * 4 * OC + (size_t)h * 4, 4, 4, n1, hipMemcpyDeviceToDevice);
+                if (e == hipSuccess && n > n1)
+                    e = hipMemcpy2D(s.buf[p] + noff + (size_t)n1 * 16 + c * 4, 16, old.buf[p] + ooff + c * 4 * OC, 4, 4, n - n1, hipMemcpyDeviceToDevice);
+            }
+        }
+        return e;
+    };
+    FW_HIP(ctx, cpq(FW_OFF_Q1(NC), FW_OFF_Q1(OC)));
     FW_HIP(ctx, cp(FW_OFF_Q2(NC), FW_OFF_Q2(OC), 16));
-    for (size_t c = 0; c < 4; c++) FW_HIP(ctx, cp(FW_OFF_Q3(NC) + c * 4 * NC, FW_OFF_Q3(OC) + c * 4 * OC, 4));
+    FW_HIP(ctx, cpq(FW_OFF_Q3(NC), FW_OFF_Q3(OC)));
     FW_HIP(ctx, cp(FW_OFF_Q5(NC), FW_OFF_Q5(OC), 16));
     FW_HIP(ctx, cp(FW_OFF_Q6(NC), FW_OFF_Q6(OC), 16));
     FW_HIP(ctx, cp(FW_OFF_S4(NC), FW_OFF_S4(OC), 4));
@@ -286,7 +303,7 @@ fw_status leave_nospin(fw_ctx *ctx, uint32_t si) {
     if (st) return st;
     FW_HIP(ctx, fw_launch_fill_rotation(ctx->stream, s.buf[0], s.ring() ? nullptr : s.buf[1], s.capacity, s.const_rot));
     FW_HIP(ctx, fw_launch_restore_q3(ctx->stream, s.buf[0], s.ring() ? nullptr : s.buf[1], s.capacity,
-                                     s.fifo ? 0xFFFFFFFFu : s.n_lplanes, s.fifo_life));
+                                     s.fifo ? 0xFFFFFFFFu : s.n_lplanes, s.fifo_life, s.ring()));
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t flags = s.derived ? FW_TYPE_DERIVED : 0u;
     FW_HIP(ctx, hipMemcpy((char *)(ctx->d_types.d + s.type_idx) + offsetof(FwType, flags), &flags, sizeof flags, hipMemcpyHostToDevice));
@@ -305,7 +322,7 @@ fw_status set_derived(fw_ctx *ctx, uint32_t si, bool on, bool refill) {
     if (st) return st;
     if (!on && refill) {
         FW_HIP(ctx, fw_launch_rederive(ctx->stream, s.buf[ctx->parity], s.capacity, ctx->d_types.d + s.type_idx, ctx->d_keys.d, s.nospin,
-                                       s.life_plane(), s.fifo_life));
+                                       s.life_plane(), s.fifo_life, s.ring()));
         FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     uint32_t flags = (s.nospin ? FW_TYPE_NOSPIN : 0u) | (on ? FW_TYPE_DERIVED : 0u);

@@ -774,7 +774,7 @@ fw_status fw_step(fw_ctx *ctx, float dt) {
                     op.parent_head = PS.fifo ? PS.head : (PS.range ? PS.young_lo : 0u);
                     op.child_head = CS.fifo ? CS.head : (CS.range ? CS.young_lo : 0u);
                     op.parent_range = PS.range ? 1u : 0u, op.child_range = CS.range ? 1u : 0u;
-                    op.parent_nospin = ctx->segs[op.parent_seg].nospin ? 1u : 0u;
+                    op.parent_nospin = (ctx->segs[op.parent_seg].nospin ? 1u : 0u) | (ctx->segs[op.parent_seg].ring() ? 2u : 0u);
                     memcpy(op.parent_rot, ctx->segs[op.parent_seg].const_rot, sizeof op.parent_rot);
                     // (its lifetimes: the lifetime plane of a compacting segment, one value for a ring)
                     op.parent_life_plane = ctx->segs[op.parent_seg].fifo ? 0xFFFFFFFFu : ctx->segs[op.parent_seg].n_lplanes;

@@ -9,14 +9,14 @@
 // SoA planes -> fw_particle records (26 x 4 B)
 // (rot: the rotation of every particle of a type that cannot turn -- FW_TYPE_NOSPIN, its plane is not maintained -- or null)
 __global__ void fw_k_gather(const char *buf, uint32_t C, uint32_t head, uint32_t n, int32_t pbr, float *out, bool nospin, float4 rot,
-                            uint32_t life_plane, float life_const, const FwType *derived, const float *keys) {
+                            uint32_t life_plane, float life_const, const FwType *derived, const float *keys, bool cpl) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
     const uint32_t i = fw_ring_slot(head, li, C);
-    const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i), q1 = fw_ldc4(buf + FW_OFF_Q1(C), C, i),
+    const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i), q1 = fw_ldq(buf + FW_OFF_Q1(C), C, i, cpl),
                  q2 = nospin ? rot : fw_ld4(buf + FW_OFF_Q2(C), i),
                  // (cannot turn: angular velocity 0; the lifetime from its plane, or -- a ring -- the type's one value)
-                 q3 = !nospin ? fw_ldc4(buf + FW_OFF_Q3(C), C, i)
+                 q3 = !nospin ? fw_ldq(buf + FW_OFF_Q3(C), C, i, cpl)
                               : make_float4(0.0f, 0.0f, 0.0f, life_plane != 0xFFFFFFFFu ? fw_ld1(buf + FW_OFF_L(C, life_plane), i) : life_const),
                  bc0 = fw_ld4(buf + FW_OFF_Q5(C), i), em0 = fw_ld4(buf + FW_OFF_Q6(C), i);
     float4 bc = bc0, em = em0;
@@ -38,9 +38,9 @@ __global__ void fw_k_scatter(char *buf, uint32_t C, uint32_t n, uint32_t n_lplan
     if (i >= n) return;
     const float *r = in + (size_t)i * 26;
     fw_st4(buf + FW_OFF_Q0(C), i, make_float4(r[0], r[1], r[2], r[15]));
-    fw_stc4(buf + FW_OFF_Q1(C), C, i, make_float4(r[3], r[4], r[5], r[13]));
+    fw_st4(buf + FW_OFF_Q1(C), i, make_float4(r[3], r[4], r[5], r[13]));  // (the caller's particles: always a segment of the compacting path -- float4 planes)
     fw_st4(buf + FW_OFF_Q2(C), i, make_float4(r[6], r[7], r[8], r[9]));
-    fw_stc4(buf + FW_OFF_Q3(C), C, i, make_float4(r[10], r[11], r[12], r[16]));
+    fw_st4(buf + FW_OFF_Q3(C), i, make_float4(r[10], r[11], r[12], r[16]));
     fw_st4(buf + FW_OFF_Q5(C), i, make_float4(r[17], r[18], r[19], r[20]));
     fw_st4(buf + FW_OFF_Q6(C), i, make_float4(r[21], r[22], r[23], r[24]));
     reinterpret_cast<float *>(buf + FW_OFF_S4(C))[i] = r[14];
@@ -58,21 +58,21 @@ __global__ void fw_k_fill_colors(char *buf0, char *buf1, uint32_t C, float4 bc, 
 
 // a type leaves FW_TYPE_DERIVED (its instance buffer is detached): scale and colour planes of every slot, evaluated from
 // the slot's age / lifetime / initial_scale -- what the updates would have stored
-__global__ void fw_k_rederive(char *buf, uint32_t C, const FwType *T, const float *keys, bool nospin, uint32_t life_plane, float life_const) {
+__global__ void fw_k_rederive(char *buf, uint32_t C, const FwType *T, const float *keys, bool nospin, uint32_t life_plane, float life_const, bool cpl) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C) return;
     const float4 q0 = fw_ld4(buf + FW_OFF_Q0(C), i);
-    const float life = !nospin ? fw_ld1(buf + FW_OFF_Q3(C) + 3 * FW_CP(C), i)
+    const float life = !nospin ? fw_ldq_w(buf + FW_OFF_Q3(C), C, i, cpl)
                                : (life_plane != 0xFFFFFFFFu ? fw_ld1(buf + FW_OFF_L(C, life_plane), i) : life_const);
     float4 bc, em;
     float sc;
-    fw_derived_values(*T, keys + T->keys_off, q0.w, life, fw_ld1(buf + FW_OFF_Q1(C) + 3 * FW_CP(C), i), &bc, &em, &sc);
+    fw_derived_values(*T, keys + T->keys_off, q0.w, life, fw_ldq_w(buf + FW_OFF_Q1(C), C, i, cpl), &bc, &em, &sc);
     fw_st4(buf + FW_OFF_Q5(C), i, bc), fw_st4(buf + FW_OFF_Q6(C), i, em), fw_st1(buf + FW_OFF_S4(C), i, sc);
 }
 hipError_t fw_launch_rederive(hipStream_t s, char *buf, uint32_t capacity, const FwType *d_type, const float *d_keys, bool nospin,
-                              uint32_t life_plane, float life_const) {
+                              uint32_t life_plane, float life_const, bool cpl) {
     if (!capacity) return hipSuccess;
-    hipLaunchKernelGGL(fw_k_rederive, dim3((capacity + 255) / 256), dim3(256), 0, s, buf, capacity, d_type, d_keys, nospin, life_plane, life_const);
+    hipLaunchKernelGGL(fw_k_rederive, dim3((capacity + 255) / 256), dim3(256), 0, s, buf, capacity, d_type, d_keys, nospin, life_plane, life_const, cpl);
     return hipGetLastError();
 }
 
@@ -92,12 +92,12 @@ __global__ void fw_k_fill_plane1(char *buf0, char *buf1, size_t plane_off, uint3
     if (buf1) fw_st1(buf1 + plane_off, i, v);
 }
 // a type leaves FW_TYPE_NOSPIN: Q3 = {0, 0, 0, lifetime} again, the lifetime from its plane (or one value: a ring)
-__global__ void fw_k_restore_q3(char *buf0, char *buf1, uint32_t C, uint32_t life_plane, float life_const) {
+__global__ void fw_k_restore_q3(char *buf0, char *buf1, uint32_t C, uint32_t life_plane, float life_const, bool cpl) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C) return;
     const bool pl = life_plane != 0xFFFFFFFFu;
-    fw_stc4(buf0 + FW_OFF_Q3(C), C, i, make_float4(0.f, 0.f, 0.f, pl ? fw_ld1(buf0 + FW_OFF_L(C, life_plane), i) : life_const));
-    if (buf1) fw_stc4(buf1 + FW_OFF_Q3(C), C, i, make_float4(0.f, 0.f, 0.f, pl ? fw_ld1(buf1 + FW_OFF_L(C, life_plane), i) : life_const));
+    fw_stq(buf0 + FW_OFF_Q3(C), C, i, make_float4(0.f, 0.f, 0.f, pl ? fw_ld1(buf0 + FW_OFF_L(C, life_plane), i) : life_const), cpl);
+    if (buf1) fw_stq(buf1 + FW_OFF_Q3(C), C, i, make_float4(0.f, 0.f, 0.f, pl ? fw_ld1(buf1 + FW_OFF_L(C, life_plane), i) : life_const), cpl);
 }
 
 // ParticleInstance packing (reference src/render.rs:95-115): {pos, scale, rot, base, emissive}
@@ -106,7 +106,7 @@ __global__ void fw_k_restore_q3(char *buf0, char *buf1, uint32_t C, uint32_t lif
 // its own record with four float4 stores would touch 64 lines a quarter at a time).
 __global__ __launch_bounds__(256) void fw_k_pack(const char *buf, uint32_t C, uint32_t head, const uint32_t *d_count,
                                                  uint32_t n_upper, float4 *out, bool nospin, float4 rot, const uint32_t *d_rold,
-                                                 const FwType *derived, const float *keys, uint32_t life_plane, float life_const) {
+                                                 const FwType *derived, const float *keys, uint32_t life_plane, float life_const, bool cpl) {
     __shared__ float4 s_rec[256 * 4];
     // a range ring (d_rold: the size of its old part, FwGlobals::rold): `head` is the slot of the first young particle
     if (d_rold) head = fw_range_head(head, *d_rold, C);
@@ -120,9 +120,9 @@ __global__ __launch_bounds__(256) void fw_k_pack(const char *buf, uint32_t C, ui
         float4 q5 = fw_ld4(buf + FW_OFF_Q5(C), i);
         float4 q6 = fw_ld4(buf + FW_OFF_Q6(C), i);
         if (derived) {  // FW_TYPE_DERIVED: the three planes are not maintained -- what the last update computed, again
-            const float life = !nospin ? fw_ld1(buf + FW_OFF_Q3(C) + 3 * FW_CP(C), i)
+            const float life = !nospin ? fw_ldq_w(buf + FW_OFF_Q3(C), C, i, cpl)
                                        : (life_plane != 0xFFFFFFFFu ? fw_ld1(buf + FW_OFF_L(C, life_plane), i) : life_const);
-            fw_derived_values(*derived, keys + derived->keys_off, q0.w, life, fw_ld1(buf + FW_OFF_Q1(C) + 3 * FW_CP(C), i), &q5, &q6, &sc);
+            fw_derived_values(*derived, keys + derived->keys_off, q0.w, life, fw_ldq_w(buf + FW_OFF_Q1(C), C, i, cpl), &q5, &q6, &sc);
         }
         s_rec[tid * 4 + 0] = make_float4(q0.x, q0.y, q0.z, sc);
         s_rec[tid * 4 + 1] = q2;
@@ -189,10 +189,10 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_aabb(FwGlobals g, FwSegList L, 
             const float4 q0 = fw_ld4(buf + FW_OFF_Q0(S.capacity), i);
             float sc = fw_ld1(buf + FW_OFF_S4(S.capacity), i);
             if (TT.flags & FW_TYPE_DERIVED) {  // the scale plane is not maintained: what the last update computed, again
-                const float life = !(TT.flags & FW_TYPE_NOSPIN) ? fw_ld1(buf + FW_OFF_Q3(S.capacity) + 3 * FW_CP(S.capacity), i)
+                const float life = !(TT.flags & FW_TYPE_NOSPIN) ? fw_ldq_w(buf + FW_OFF_Q3(S.capacity), S.capacity, i, S.cpl != 0u)
                                    : (L.life_plane[k] != 0xFFFFFFFFu ? fw_ld1(buf + FW_OFF_L(S.capacity, L.life_plane[k]), i) : L.life_const[k]);
                 const float *keys = g.keys + TT.keys_off;
-                sc = fw_ld1(buf + FW_OFF_Q1(S.capacity) + 3 * FW_CP(S.capacity), i) * fw_curve_sample(TT.sc_kind, TT.sc_n, keys, keys + TT.o_sc_v, q0.w / life);
+                sc = fw_ldq_w(buf + FW_OFF_Q1(S.capacity), S.capacity, i, S.cpl != 0u) * fw_curve_sample(TT.sc_kind, TT.sc_n, keys, keys + TT.o_sc_v, q0.w / life);
             }
             mn[0] = fminf(mn[0], q0.x - sc), mn[1] = fminf(mn[1], q0.y - sc), mn[2] = fminf(mn[2], q0.z - sc);
             mx[0] = fmaxf(mx[0], q0.x + sc), mx[1] = fmaxf(mx[1], q0.y + sc), mx[2] = fmaxf(mx[2], q0.z + sc);
@@ -326,11 +326,11 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_copy(const float4 *src, float4 
 // ---- launch wrappers
 
 hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, uint32_t n, int32_t pbr, void *d_out,
-                            const float *const_rot, uint32_t life_plane, float life_const, const FwType *derived, const float *keys) {
+                            const float *const_rot, uint32_t life_plane, float life_const, const FwType *derived, const float *keys, bool cpl) {
     if (!n) return hipSuccess;
     const float4 rot = const_rot ? make_float4(const_rot[0], const_rot[1], const_rot[2], const_rot[3]) : make_float4(0.f, 0.f, 0.f, 1.f);
     hipLaunchKernelGGL(fw_k_gather, dim3((n + 255) / 256), dim3(256), 0, s, buf, capacity, head, n, pbr, (float *)d_out,
-                       const_rot != nullptr, rot, life_plane, life_const, derived, keys);
+                       const_rot != nullptr, rot, life_plane, life_const, derived, keys, cpl);
     return hipGetLastError();
 }
 
@@ -354,9 +354,9 @@ hipError_t fw_launch_fill_plane1(hipStream_t s, char *buf0, char *buf1, size_t p
     hipLaunchKernelGGL(fw_k_fill_plane1, dim3((capacity + 255) / 256), dim3(256), 0, s, buf0, buf1, plane_off, capacity, v);
     return hipGetLastError();
 }
-hipError_t fw_launch_restore_q3(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, uint32_t life_plane, float life_const) {
+hipError_t fw_launch_restore_q3(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, uint32_t life_plane, float life_const, bool cpl) {
     if (!capacity) return hipSuccess;
-    hipLaunchKernelGGL(fw_k_restore_q3, dim3((capacity + 255) / 256), dim3(256), 0, s, buf0, buf1, capacity, life_plane, life_const);
+    hipLaunchKernelGGL(fw_k_restore_q3, dim3((capacity + 255) / 256), dim3(256), 0, s, buf0, buf1, capacity, life_plane, life_const, cpl);
     return hipGetLastError();
 }
 
@@ -369,13 +369,13 @@ hipError_t fw_launch_fill_rotation(hipStream_t s, char *buf0, char *buf1, uint32
 
 hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, const uint32_t *d_count,
                                     uint32_t n_upper, void *d_out, const float *const_rot, const uint32_t *d_rold, const FwType *derived,
-                                    const float *keys, uint32_t life_plane, float life_const) {
+                                    const float *keys, uint32_t life_plane, float life_const, bool cpl) {
     if (!n_upper) return hipSuccess;
     uint32_t blocks = (n_upper + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     const float4 rot = const_rot ? make_float4(const_rot[0], const_rot[1], const_rot[2], const_rot[3]) : make_float4(0.f, 0.f, 0.f, 1.f);
     hipLaunchKernelGGL(fw_k_pack, dim3(blocks), dim3(256), 0, s, buf, capacity, head, d_count, n_upper, (float4 *)d_out,
-                       const_rot != nullptr, rot, d_rold, derived, keys, life_plane, life_const);
+                       const_rot != nullptr, rot, d_rold, derived, keys, life_plane, life_const, cpl);
     return hipGetLastError();
 }
 

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
             // unconditional, clamped into the tile (a predicated load would be waited for in its own basic block)
             const uint32_t idx = has_new ? 0u : min(base + r * BLK + tid, lim - 1u);
             t0[r] = fw_ld4(ib + FW_OFF_Q0(C), idx);
-            t3[r] = fw_ldc4(ib + FW_OFF_Q3(C), C, idx & m2);  // (Q1 / Q3: component planes, fw_dev.h)
+            t3[r] = fw_ld4(ib + FW_OFF_Q3(C), idx & m2);
             // a type that cannot turn: Q3 is not kept, the lifetime comes from its own plane (both loads unconditional: the
             // one that is not needed asks for one and the same slot of a plane that exists)
             const float lf = fw_ld1((m2 ? ib + FW_OFF_Q0(C) : ib + FW_OFF_L(C, n_lplanes)), m2 ? 0u : idx);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
     float4 q1c, q2c;
     {
         const uint32_t i0 = has_new ? 0u : min(base + tid, lim - 1u);
-        q1c = fw_ldc4(ib + FW_OFF_Q1(C), C, i0);
+        q1c = fw_ld4(ib + FW_OFF_Q1(C), i0);
         q2c = fw_ld4(ib + FW_OFF_Q2(C), i0 & m2);
     }
 
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
                 for (uint32_t i = (use_fc ? n_in : 0u) + tid; i < base; i += BLK) {  // base is a particle index
                     float an, ag = 0.0f, lf;
                     if (i < n_in) {
-                        ag = fw_ld4(ib + FW_OFF_Q0(C), i).w, lf = fw_load_lifetime(ib, C, n_lplanes, i, m2 == 0u);
+                        ag = fw_ld4(ib + FW_OFF_Q0(C), i).w, lf = fw_load_q3(ib, C, n_lplanes, i, m2 == 0u).w;
                     } else {  // a spawned particle: only its lifetime draw matters (RNG block 2, word 0)
                         const uint32_t k = i - n_in;
                         uint32_t oi = o0;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         const uint32_t idx = base + r * BLK + tid;
         // prefetch the next round's Q1 / Q2 (new particles were materialised above, so idx < n_tot is enough)
         const uint32_t in_ = has_new ? 0u : min(idx + BLK, lim - 1u);  // clamped, unconditional
-        const float4 q1n = fw_ldc4(ib + FW_OFF_Q1(C), C, in_);
+        const float4 q1n = fw_ld4(ib + FW_OFF_Q1(C), in_);
         const float4 q2n = fw_ld4(ib + FW_OFF_Q2(C), in_ & m2);
         const bool valid = idx < lim, loaded = !has_new;
         const bool updated_before = loaded && idx < n_before;  // (destroyed records: evaluate / read the planes vs spawn-time values)
@@ -389,8 +389,8 @@ __global__ __launch_bounds__(FW_TILE / R) void fw_k_update(FwGlobals g, FwUpdate
         }
         if (alive && FW_DBG(a.dbg, 2u)) {  // profiling only: stream without arithmetic
             const uint32_t b16 = (o - W.first) * 16u;
-            fw_st4w(W.q0, b16, make_float4(q0.x, q0.y, q0.z, age_new)), fw_stc4w(W.q1, W.cp, b16 / 4u, q1c);
-            fw_st4w(W.q2, b16, q2c), fw_stc4w(W.q3, W.cp, b16 / 4u, q3);
+            fw_st4w(W.q0, b16, make_float4(q0.x, q0.y, q0.z, age_new)), fw_st4w(W.q1, b16, q1c);
+            fw_st4w(W.q2, b16, q2c), fw_st4w(W.q3, b16, q3);
             fw_st4w(W.q5, b16, q0), fw_st4w(W.q6, b16, q1c);
             fw_st1w(W.s4, (o - W.first) * 4u, q1c.w);
         } else if (alive) {
@@ -530,8 +530,8 @@ __device__ __forceinline__ void fw_round_finish(const FwType &T, const float *s_
     }
     if (alive && FW_DBG(dbg, 2u)) {  // profiling only: stream without arithmetic
         const uint32_t b16 = (o - W.first) * 16u;
-        fw_st4w(W.q0, b16, make_float4(q0.x, q0.y, q0.z, age_new)), fw_stc4w(W.q1, W.cp, b16 / 4u, q1);
-        fw_st4w(W.q2, b16, q2), fw_stc4w(W.q3, W.cp, b16 / 4u, q3);
+        fw_st4w(W.q0, b16, make_float4(q0.x, q0.y, q0.z, age_new)), fw_st4w(W.q1, b16, q1);
+        fw_st4w(W.q2, b16, q2), fw_st4w(W.q3, b16, q3);
         fw_st4w(W.q5, b16, q0), fw_st4w(W.q6, b16, q1);
         fw_st1w(W.s4, (o - W.first) * 4u, q1.w);
     } else if (alive) {
@@ -618,13 +618,10 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
         const size_t sfirst = spec_base != 0xFFFFFFFFu ? (size_t)spec_base * 16u : (size_t)0;
         const uint32_t i0 = tid * 16u;
         q0c = fw_ld4w(ib + FW_OFF_Q0(C) + sfirst, i0);
-        // (Q1 / Q3: component planes, fw_dev.h.  The lifetime: a plane of its own for a type that cannot turn, the w plane of Q3 otherwise --
-        // one load either way; rotation and angular velocity under a workgroup-UNIFORM branch: three dummy loads per round cost the
-        // compacting launches of configs[2] address-unit time they do not have)
-        lfc = fw_ld1w((m2 ? ib + FW_OFF_Q3(C) + 3 * FW_CP(C) : ib + FW_OFF_L(C, n_lplanes)) + sfirst / 4u, i0 / 4u);
-        q1c = fw_ldc4w(ib + FW_OFF_Q1(C) + sfirst / 4u, FW_CP(C), i0 / 4u);
-        q3c = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q2c = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-        if (m2) q3c = fw_ldc3w(ib + FW_OFF_Q3(C) + sfirst / 4u, FW_CP(C), i0 / 4u, 0.0f), q2c = fw_ld4w(ib + FW_OFF_Q2(C) + sfirst, i0);
+        q3c = fw_ld4w(ib + FW_OFF_Q3(C) + sfirst, i0 & m2);
+        lfc = fw_ld1w((m2 ? ib + FW_OFF_Q0(C) : ib + FW_OFF_L(C, n_lplanes)) + (m2 ? (size_t)0 : sfirst / 4u), m2 ? 0u : i0 / 4u);
+        q1c = fw_ld4w(ib + FW_OFF_Q1(C) + sfirst, i0);
+        q2c = fw_ld4w(ib + FW_OFF_Q2(C) + sfirst, i0 & m2);
     }
     const uint32_t sidx = p * g.max_seg + seg, oidx = (p ^ 1u) * g.max_seg + seg;
     // SPAWN_NONE frames may have had this frame's new particles MATERIALISED behind the live ones (Global ops of a frame
@@ -722,17 +719,16 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
     // input windows: the planes advanced to the tile's first slot (slot 0 for a new-particle tile, which loads nothing real)
     const bool loaded_tile = !has_new || SPAWN == FW_SPAWN_NONE;  // block-uniform
     const size_t ifirst = loaded_tile ? (size_t)base * 16u : (size_t)0;
-    const size_t cp = FW_CP(C);  // (Q1 / Q3: component planes -- windows of the x plane, 4 bytes per slot)
-    const char *iw0 = ib + FW_OFF_Q0(C) + ifirst, *iw1 = ib + FW_OFF_Q1(C) + ifirst / 4u;
-    const char *iw2 = ib + FW_OFF_Q2(C) + ifirst, *iw3 = ib + FW_OFF_Q3(C) + ifirst / 4u;
-    const char *iwl = (m2 ? ib + FW_OFF_Q3(C) + 3 * cp : ib + FW_OFF_L(C, n_lplanes)) + ifirst / 4u;  // lifetimes: the w plane of Q3, or their own plane
+    const char *iw0 = ib + FW_OFF_Q0(C) + ifirst, *iw1 = ib + FW_OFF_Q1(C) + ifirst;
+    const char *iw2 = ib + FW_OFF_Q2(C) + ifirst, *iw3 = ib + FW_OFF_Q3(C) + ifirst;
+    const char *iwl = m2 ? iw0 : ib + FW_OFF_L(C, n_lplanes) + ifirst / 4u;  // lifetime plane (or any valid address)
     if (!LONE || (loaded_tile && base != spec_base)) {  // LONE: only a tile whose role differs from the guess reloads
         const uint32_t i0 = loaded_tile ? min(tid, last - base) * 16u : 0u;
         q0c = fw_ld4w(iw0, i0);
-        lfc = fw_ld1w(iwl, i0 / 4u);
-        q1c = fw_ldc4w(iw1, cp, i0 / 4u);
-        q3c = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q2c = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-        if (m2) q3c = fw_ldc3w(iw3, cp, i0 / 4u, 0.0f), q2c = fw_ld4w(iw2, i0);
+        q3c = fw_ld4w(iw3, i0 & m2);
+        lfc = fw_ld1w(iwl, m2 ? 0u : i0 / 4u);
+        q1c = fw_ld4w(iw1, i0);
+        q2c = fw_ld4w(iw2, i0 & m2);
     }
     const FwType T = g.types[type_idx];  // scalar loads; first needed in the round loop
     if (tid < keys_len) s_keys[tid] = key0;
@@ -853,11 +849,11 @@ __global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) v
             const uint32_t idx = base + r * BLK + tid;
             const uint32_t in_ = min((r + 1) * BLK + tid, last - base) * 16u;  // next round's slot (clamped: see above)
             const float4 q0n = fw_ld4w(iw0, in_);
-            const float lfn = fw_ld1w(iwl, in_ / 4u);
-            const float4 q1n = fw_ldc4w(iw1, cp, in_ / 4u);
-            float4 q3n = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q2n = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-            if (m2) q3n = fw_ldc3w(iw3, cp, in_ / 4u, 0.0f), q2n = fw_ld4w(iw2, in_);  // (workgroup-uniform)
-            q3c.w = lfc;
+            const float4 q3n = fw_ld4w(iw3, in_ & m2);
+            const float lfn = fw_ld1w(iwl, m2 ? 0u : in_ / 4u);
+            const float4 q1n = fw_ld4w(iw1, in_);
+            const float4 q2n = fw_ld4w(iw2, in_ & m2);
+            if (!m2) q3c = make_float4(0.0f, 0.0f, 0.0f, lfc);
             const bool valid = idx < lim;
             float age_new;
             const bool alive = valid && fw_survives(q0c.w, a.dt, q3c.w, &age_new);
@@ -991,9 +987,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_count(FwGlobals g, FwUpdateArgs
             if (idx < n_tot) {
                 float an;
                 const float4 q0 = fw_ld4(ib + FW_OFF_Q0(S.capacity), idx);
-                bool al = fw_survives(q0.w, a.dt, fw_load_lifetime(ib, S.capacity, S.n_lplanes, idx, nospin), &an);
+                bool al = fw_survives(q0.w, a.dt, fw_load_q3(ib, S.capacity, S.n_lplanes, idx, nospin).w, &an);
                 if (al && coll_kill) {  // destroy_on_collision removes particles too (core.rs:636-639)
-                    const float4 q1 = fw_ldc4(ib + FW_OFF_Q1(S.capacity), S.capacity, idx);
+                    const float4 q1 = fw_ld4(ib + FW_OFF_Q1(S.capacity), idx);
                     fw_v3 pos{q0.x, q0.y, q0.z}, vel{q1.x, q1.y, q1.z};
                     al = !fw_particle_collision(&pos, &vel, a.dt, T.coll_restitution, T.coll_friction, true, T.coll_mask,
                                                 g.colliders, g.n_colliders);
@@ -1062,7 +1058,7 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_update_coll(FwGlobals g, FwUpda
         const uint32_t idx = base + r * FW_BLOCK + tid;
         const bool valid = idx < lim;
         const uint32_t li = min(idx, lim - 1u);
-        const float4 q0 = fw_ld4(ib + FW_OFF_Q0(C), li), q1 = fw_ldc4(ib + FW_OFF_Q1(C), C, li),
+        const float4 q0 = fw_ld4(ib + FW_OFF_Q0(C), li), q1 = fw_ld4(ib + FW_OFF_Q1(C), li),
                      q2 = fw_ld4(ib + FW_OFF_Q2(C), li), q3 = fw_load_q3(ib, C, n_lplanes, li, (T.flags & FW_TYPE_NOSPIN) != 0u);
         float age_new;
         const bool young = valid && fw_survives(q0.w, a.dt, q3.w, &age_new);
@@ -1237,9 +1233,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_fc_resolve(FwGlobals g, FwResol
         const char *ib = S.buf[a.parity];
         const uint32_t C = S.capacity, fc_bnd = (e.z + 1u) * FW_TILE, end = h.w + ta + tb;
         const bool nospin = (g.types[S.type_idx].flags & FW_TYPE_NOSPIN) != 0u;
-        const uint32_t ls = 4u;
+        const uint32_t ls = nospin ? 4u : 16u;
         const char *pa = ib + FW_OFF_Q0(C) + (size_t)h.w * 16u + 12u;  // ages: .w of Q0, from the tile's first slot on
-        const char *pl = (nospin ? ib + FW_OFF_L(C, S.n_lplanes) : ib + FW_OFF_Q3(C) + 3 * FW_CP(C)) + (size_t)h.w * ls;  // lifetimes: their own plane, or the w plane of Q3
+        const char *pl = (nospin ? ib + FW_OFF_L(C, S.n_lplanes) : ib + FW_OFF_Q3(C) + 12u) + (size_t)h.w * ls;  // lifetimes: their own plane, or .w of Q3
         constexpr int U = FW_TILE / 64;
         for (uint32_t i0 = h.w; i0 < end; i0 += FW_TILE) {  // (one trip: a tile stores at most FW_TILE survivors)
             float ag[U], lf[U];

@@ -126,9 +126,9 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
     for (int r = 0; r < FW_NEST_TILE / FW_BLOCK; r++) {
         const uint32_t ci = fw_ring_slot(parent_head, min(pbase + r * FW_BLOCK + tid, op.parent_cap - 1u), op.parent_cap);
         p_age[r] = fw_ld4(op.parent_buf + FW_OFF_Q0(op.parent_cap), ci).w;
-        p_life[r] = (op.parent_nospin != 0u && op.parent_life_plane == 0xFFFFFFFFu)
+        p_life[r] = ((op.parent_nospin & 1u) != 0u && op.parent_life_plane == 0xFFFFFFFFu)
                         ? op.parent_life_const
-                        : fw_load_lifetime(op.parent_buf, op.parent_cap, op.parent_life_plane, ci, op.parent_nospin != 0u);
+                        : fw_load_lifetime(op.parent_buf, op.parent_cap, op.parent_life_plane, ci, (op.parent_nospin & 1u) != 0u, (op.parent_nospin & 2u) != 0u);
         p_lea[r] = fw_ld1(op.parent_buf + FW_OFF_L(op.parent_cap, op.parent_lplane), ci);
     }
     const uint32_t n_par = g.count[sidx] + g.spawned[sidx] + g.appended[sidx];  // bound fixed once (core.rs:488)
@@ -214,8 +214,8 @@ __global__ __launch_bounds__(FW_BLOCK) void fw_k_nest(FwGlobals g, FwNestInline 
             if (n[r] != 0) {
                 const uint32_t ps = fw_ring_slot(parent_head, idx, PC);
                 s_par[wave][0][lane] = fw_ld4(pb + FW_OFF_Q0(PC), ps);
-                s_par[wave][1][lane] = fw_ldc3(pb + FW_OFF_Q1(PC), PC, ps, 0.0f);  // (the parent's velocity; component planes, fw_dev.h)
-                s_par[wave][2][lane] = op.parent_nospin ? make_float4(op.parent_rot[0], op.parent_rot[1], op.parent_rot[2], op.parent_rot[3])
+                s_par[wave][1][lane] = fw_ldq(pb + FW_OFF_Q1(PC), PC, ps, (op.parent_nospin & 2u) != 0u);  // (the parent's velocity; a ring's Q1: component planes)
+                s_par[wave][2][lane] = (op.parent_nospin & 1u) ? make_float4(op.parent_rot[0], op.parent_rot[1], op.parent_rot[2], op.parent_rot[3])
                                                         : fw_ld4(pb + FW_OFF_Q2(PC), ps);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -157,7 +157,7 @@ __device__ __forceinline__ void fw_fifo_nest_parents(const FwGlobals &g, const F
         __hip_atomic_store(&g.nest_status[tile], fw_pack_status(N.tag, FW_ST_INCL, incl64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)incl64), RLX, AGENT);
     if (tile_total == 0u) return;  // (workgroup-uniform: most tiles of a ring hold parents past their emission window)
     // ---- children, wave-cooperatively (parent-major order), spawned and given their first update
-    const FwOutWin Wc = fw_out_window(Fc.buf, Cc, 0u, Tc, 0u);  // (child capacity <= FW_RANGE_MAX_CAPACITY: 32-bit byte offsets, the host checks)
+    const FwOutWin Wc = fw_out_window(Fc.buf, Cc, 0u, Tc, 0u, 0u, true);  // (child capacity <= FW_RANGE_MAX_CAPACITY: 32-bit byte offsets, the host checks)
     float4 prot = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
     if (pnospin) {
         const FwType &Tp = g.types[F.type_idx & ~FW_TYPE_IDX_NOSPIN];
@@ -200,7 +200,7 @@ __device__ __forceinline__ void fw_fifo_nest_parents(const FwGlobals &g, const F
                                                        fw_v3{pq1.x, pq1.y, pq1.z}, N.speed, N.scale);
                     float age_new;
                     fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);  // (the host keeps a step as long as the child lifetime off this path)
-                    fw_integrate_store<true, -1, NT>(Tc, s_ckeys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, Wc,
+                    fw_integrate_store<true, -1, NT, true>(Tc, s_ckeys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, Wc,
                                                      fw_ring_slot(Fc.head, (uint32_t)slotl, Cc), nullptr, nullptr, nullptr, nullptr, false, true, false);
                 }
             }
@@ -344,7 +344,7 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
     }
     char *inst = INST ? F.inst : nullptr;
     float4 *s_inst_wave = s_inst + (INST ? wave * 256u : 0u);
-    const FwOutWin W = fw_out_window(buf, C, sbase, T, 0u);
+    const FwOutWin W = fw_out_window(buf, C, sbase, T, 0u, 0u, true);
     bool bad = false;
     if (spawner) {
         // ---- this frame's new particles: spawn_particles (core.rs:437-469) right before update_particles, each in the
@@ -377,7 +377,7 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
         fw_v3 cpos, cvel;
         fw_coll_step<COLL>(g, CA, alive, a.dt, so.q0, so.q1, &cpos, &cvel);
         if (alive) {
-            fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, COLL ? &cpos : nullptr,
+            fw_integrate_store<true, -1, NT, true>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, COLL ? &cpos : nullptr,
                                          COLL ? &cvel : nullptr, nullptr, false, true, CA.on);
             if (F.n_lplanes) fw_init_last_emitted(g, g.segs[F.seg], buf, s, new_ei, so.q3.w);  // (a type other particles' entries emit from)
         } else if (is_new && want_destroyed)  // born and destroyed in the same frame (dt >= lifetime)
@@ -435,7 +435,7 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
                     if (WM >= 0 ? (WM & 2) != 0 : W.wr6) fw_st4w<NT != 0>(W.q6, b16, q1c);
                     if (WM >= 0 ? (WM & 4) != 0 : T.sc_kind != 0) fw_st1w<NT != 0>(W.s4, (s - W.first) * 4u, q1c.w);
                 } else {
-                    fw_integrate_store<true, WM, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, COLL ? &cpos : nullptr,
+                    fw_integrate_store<true, WM, NT, true>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, COLL ? &cpos : nullptr,
                                                  COLL ? &cvel : nullptr, nullptr, false, i >= full_from, CA.on, INST ? FW_W_MEM : FW_W_MEM_LAZY);
                 }
             }
@@ -719,7 +719,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
             if (tid < keys_len) s_keys[tid] = key0;
             for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
             __syncthreads();
-            const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
+            const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes, true);
             bool bad = false;
 #pragma unroll
             for (int r = 0; r < YR; r++) {
@@ -741,7 +741,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
                 fw_v3 cpos, cvel;
                 fw_coll_step<COLL>(g, CA, mine, a.dt, q0v, q1v, &cpos, &cvel);
                 if (mine)
-                    fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0v, q1v, q3v, q3v, age_new, W, s, rec, COLL ? &cpos : nullptr,
+                    fw_integrate_store<true, -1, NT, true>(T, s_keys, a.dt, q0v, q1v, q3v, q3v, age_new, W, s, rec, COLL ? &cpos : nullptr,
                                                      COLL ? &cvel : nullptr, nullptr, false, yi >= y_full, CA.on, WMODE);
                 if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             }
@@ -772,7 +772,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
         for (uint32_t i = tid + BLK; i < keys_len; i += BLK) s_keys[i] = g.keys[keys_off + i];
         __syncthreads();
         FW_STAMP(2, T.flags);  // type record + keys in LDS
-        const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
+        const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes, true);
         bool bad = false;
         FW_STAMP(6, __float_as_uint(q0c.w) | __float_as_uint(q1c.w));  // the first round's particles have arrived
 #pragma unroll
@@ -794,7 +794,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
             fw_v3 cpos, cvel;
             fw_coll_step<COLL>(g, CA, mine, a.dt, q0c, q1c, &cpos, &cvel);
             if (mine)
-                fw_integrate_store<true, -1, NT>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, COLL ? &cpos : nullptr,
+                fw_integrate_store<true, -1, NT, true>(T, s_keys, a.dt, q0c, q1c, q2c, q3c, age_new, W, s, rec, COLL ? &cpos : nullptr,
                                                  COLL ? &cvel : nullptr, nullptr, false, yi >= y_full, CA.on, WMODE);
             if (INST) fw_range_inst_out<NT == 2>(inst, inst_cap, s_inst_wave, rec, lane, mi, rec0 + yi, false);
             q0c = q0n, q1c = q1n, q2c = q2n, q3c = q3n, lfc = lfn;
@@ -841,10 +841,10 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
             const bool surv = fw_survives(so.q0.w, a.dt, so.q3.w, &age_new);
             if (!surv) fw_raise(g, 8u, seg, kk);
             // (the colour plane of a constant gradient holds that colour in every slot since the buffer was allocated)
-            const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
+            const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes, true);
             fw_v3 cpos, cvel;
             fw_coll_step<COLL>(g, CA, true, a.dt, so.q0, so.q1, &cpos, &cvel);
-            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, COLL ? &cpos : nullptr,
+            fw_integrate_store<false, -1, NT, true>(T, s_keys, a.dt, so.q0, so.q1, so.q2, so.q3, age_new, W, s, rec, COLL ? &cpos : nullptr,
                                               COLL ? &cvel : nullptr, nullptr, false, false, CA.on);
             if (Sp->n_lplanes) fw_init_last_emitted(g, *Sp, buf, s, g.emits[op.emit].emission_index, so.q3.w);  // (other particles' entries emit from it)
         }
@@ -983,7 +983,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
     }
     if (tid == 0 && !withhold) __hip_atomic_store(&a.status[tile], fw_pack_status(a.epoch, FW_ST_INCL, excl + tile_surv), RLX, AGENT);
     const bool want_destroyed = T.report_destroyed && want_destroyed_any;
-    const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes);
+    const FwOutWin W = fw_out_window(buf, C, 0u, T, 0u, Sp->n_lplanes, true);
     uint32_t run = excl;
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -1005,7 +1005,7 @@ void fw_k_update_range(FwGlobals g, FwRangeArgs a) {
         if (alive) {
             uint32_t s = bm1 - od;
             if (s >= C) s -= C;
-            fw_integrate_store<false, -1, NT>(T, s_keys, a.dt, q0[r], q1[r], old_q2(r), old_q3(r), age_new[r], W, s, rec, COLL ? &cpos : nullptr,
+            fw_integrate_store<false, -1, NT, true>(T, s_keys, a.dt, q0[r], q1[r], old_q2(r), old_q3(r), age_new[r], W, s, rec, COLL ? &cpos : nullptr,
                                               COLL ? &cvel : nullptr, nullptr, false, false, CA.on);
             if (nlp) {
 #pragma unroll

@@ -148,12 +148,12 @@ __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallA
     const uint32_t rounds = (n_in + LANES - 1u) / LANES;
     auto load = [&](uint32_t r, float4 &q0, float4 &q1, float4 &q2, float4 &q3) {
         const uint32_t i = min(r * LANES + lane, n_in ? n_in - 1u : 0u);  // (unconditional loads at a clamped index)
-        q0 = fw_ld4w(p0, i * 16u), q1 = fw_ldc4w(p1, FW_CP(C), i * 4u);  // (Q1 / Q3: component planes, fw_dev.h)
+        q0 = fw_ld4w(p0, i * 16u), q1 = fw_ld4w(p1, i * 16u);
         if (nospin) {  // (uniform branch)
             q2 = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
             q3 = make_float4(0.0f, 0.0f, 0.0f, fw_ld1w(pl, i * 4u));
         } else {
-            q2 = fw_ld4w(p2, i * 16u), q3 = fw_ldc4w(p3, FW_CP(C), i * 4u);
+            q2 = fw_ld4w(p2, i * 16u), q3 = fw_ld4w(p3, i * 16u);
         }
     };
     float4 q0n, q1n, q2n, q3n;
@@ -173,7 +173,7 @@ __device__ __forceinline__ void fw_small_type(const FwGlobals &g, const FwSmallA
         uint32_t o;
         place(alive, &o);
         if (alive && (FW_SMALL_EXP & 2)) {
-            fw_st4(W.q0, o, q0), fw_stc4w(W.q1, W.cp, o * 4u, q1);
+            fw_st4(W.q0, o, q0), fw_st4(W.q1, o, q1);
         } else if (alive) {
             update_one(q0, q1, q2, q3, age_new, T, s_keys, W, o, cpos, cvel);
         } else if (valid && want_destroyed) {

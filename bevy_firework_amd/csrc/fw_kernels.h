@@ -363,12 +363,13 @@ hipError_t fw_launch_nested(hipStream_t s, const FwGlobals &g, const FwNestOp *d
 // (derived: the type's device record when it is FW_TYPE_DERIVED -- scale and colours are then evaluated, not read -- + the key pool)
 hipError_t fw_launch_gather(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, uint32_t n, int32_t pbr, void *d_out,
                             const float *const_rot = nullptr, uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.0f,
-                            const FwType *derived = nullptr, const float *keys = nullptr);
+                            const FwType *derived = nullptr, const float *keys = nullptr, bool cpl = false);
+// (cpl: the segment is a ring -- its Q1 / Q3 regions are component planes, fw_dev.h)
 // fills the scale / colour planes of one buffer from age, lifetime and initial_scale (a type leaves FW_TYPE_DERIVED)
 hipError_t fw_launch_rederive(hipStream_t s, char *buf, uint32_t capacity, const FwType *d_type, const float *d_keys, bool nospin,
-                              uint32_t life_plane, float life_const);
+                              uint32_t life_plane, float life_const, bool cpl);
 hipError_t fw_launch_fill_plane1(hipStream_t s, char *buf0, char *buf1, size_t plane_off, uint32_t capacity, float v);
-hipError_t fw_launch_restore_q3(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, uint32_t life_plane, float life_const);
+hipError_t fw_launch_restore_q3(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, uint32_t life_plane, float life_const, bool cpl);
 hipError_t fw_launch_scatter(hipStream_t s, char *buf, uint32_t capacity, uint32_t n, uint32_t n_lplanes,
                              const void *d_in);
 // fills the base / emissive colour planes of one (buf1 == nullptr) or both buffers of a segment (capacity slots each)
@@ -378,7 +379,7 @@ hipError_t fw_launch_fill_colors(hipStream_t s, char *buf0, char *buf1, uint32_t
 hipError_t fw_launch_pack_instances(hipStream_t s, const char *buf, uint32_t capacity, uint32_t head, const uint32_t *d_count,
                                     uint32_t n_upper, void *d_out, const float *const_rot = nullptr,
                                     const uint32_t *d_rold = nullptr, const FwType *derived = nullptr, const float *keys = nullptr,
-                                    uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.0f);
+                                    uint32_t life_plane = 0xFFFFFFFFu, float life_const = 0.0f, bool cpl = false);
 // fills the rotation plane of both buffers of a segment (a type leaves FW_TYPE_NOSPIN)
 hipError_t fw_launch_fill_rotation(hipStream_t s, char *buf0, char *buf1, uint32_t capacity, const float rot[4]);
 // seg_ids: host array; d_part: device scratch of 256 * 8 floats; h_out8: PINNED host {min.xyz, any, max.xyz, -}
