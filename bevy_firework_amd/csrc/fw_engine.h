@@ -763,9 +763,11 @@ struct fw_ctx {
     bool range_small = false;
     // Rounds of the YOUNG workgroups of a four-round launch, chosen per launch (round 5): tiles of 512 slots (2) when the range
     // rings of the context hold range_young_big particles each or more on average (hysteresis of a quarter; a change re-sends the
-    // table), 1024 (4) otherwise and always with an attached instance buffer.  FW_RANGE_YOUNG_BIG=n (0: never)
+    // table), 1024 (4) otherwise and always with an attached instance buffer.  FW_RANGE_YOUNG_BIG=n (0: never).
+    // Round 6: never -- with 56 instead of 100 bytes per particle a 512-slot tile keeps too few bytes in flight (configs[2] 199 us per
+    // frame on 512-slot tiles, 185 on 1024-slot ones; 2048-slot ones -- FW_RANGE_YR=8 -- lose 2 %); the rule of round 5 was 32768.
     uint32_t range_young_rounds = 4;
-    uint32_t range_young_big = 0xFFFFFFFFu;  // (round 6, component planes: young tiles of 1024 slots at every size -- configs[2] 199 -> 185 us; 32768 before)
+    uint32_t range_young_big = 0;
     std::vector<FwOp> range_ops;  // this frame's Global ops that feed range rings
     // age, BEFORE the current frame's update, of a particle born in frame f -- the same for every segment of the context:
     // born with age 0, then one fp32 addition per frame (core.rs:594), exactly the device's additions

@@ -308,6 +308,20 @@ def test_non_temporal_form_of_the_kernel(system, monkeypatch, case, knob):
         case(nt_system)
 
 
+@pytest.mark.parametrize("case", [test_small_ring_wraps_many_times_bit_exact, test_irregular_dt_zero_steps_and_spinning_particles,
+                                  test_growth_while_wrapped_and_bursts, test_many_segments_in_one_launch_with_churn], ids=lambda f: f.__name__[5:])
+def test_young_tiles_of_512_slots(system, monkeypatch, case):
+    """the YRP = 2 instantiations of fw_k_update_range (young tiles of 512 slots: the product's choice for large rings in round 5, a knob
+    since the component planes of round 6 -- fw_ctx::range_young_big): the same results, forced here at every size that runs four-round
+    tiles"""
+    from bevy_firework_amd.system import ParticleSystem
+
+    monkeypatch.setenv("FW_RANGE_YOUNG_BIG", "1")
+    monkeypatch.setenv("FW_RANGE_SMALL", "0")  # (four-round tiles at every size: the 512-slot form belongs to them)
+    with ParticleSystem(device=0, seed=SEED) as y_system:
+        case(y_system)
+
+
 def test_an_internal_error_is_sticky_for_its_spawner_until_it_is_rebuilt():
     """Fault injection (the `make ab` build, FW_DEBUG 256: the second OLD tile of every range ring never publishes its count):
     whoever waits for it times out -- an in-place update that went wrong cannot be redone.  The library must not carry on as
