@@ -63,7 +63,11 @@ def _four_round_tiles(request) -> bool:
 def _name_bits(request) -> int:
     import zlib
 
-    return zlib.crc32(request.node.originalname.encode() if getattr(request.node, "originalname", None) else request.node.name.encode())
+    # (which instantiation a test function runs follows from its NAME -- FW_TEST_ROTATE=n, any integer, deals the variants out
+    # differently: a run of the suite with another n covers the combinations the committed one does not; the variant is in every log)
+    rot = os.environ.get("FW_TEST_ROTATE", "")
+    name = request.node.originalname if getattr(request.node, "originalname", None) else request.node.name
+    return zlib.crc32((name + rot).encode())
 
 
 @pytest.fixture(autouse=True)
