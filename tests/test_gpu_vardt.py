@@ -103,10 +103,10 @@ def test_threshold_forecast_with_a_nested_spawner_and_attached_instances(monkeyp
 
 
 def test_product_defaults_a_million_particles_with_a_plain_attach_under_a_jittering_dt(monkeypatch):
-    """NO knob set: a lifetime-range type of ~1M particles whose renderer used the plain fw_spawner_attach_instances leaves its ring for
-    the compacting path (records counted from 0: DESIGN.md 4.0b) -- ~980 tiles, beyond fw_ctx::tf_min_tiles -- and is stepped with a dt
-    that never repeats: the product itself picks fw_k_fc_resolve + the streaming schedule.  Counts, order, every field and the
-    records against the oracle."""
+    """NO knob set: a lifetime-range type of ~1M particles runs on its range ring under a dt that never repeats; at frame 45 its renderer
+    uses the plain fw_spawner_attach_instances and the type leaves the ring for the compacting path (records counted from 0: DESIGN.md
+    4.0b) -- ~980 tiles, beyond fw_ctx::tf_min_tiles: the product itself picks fw_k_fc_resolve + the streaming schedule.  Counts, order,
+    every field and the records against the oracle, before, at and after the change of paths."""
     import torch
     from bevy_firework_amd.system import ParticleSystem
 
@@ -117,16 +117,22 @@ def test_product_defaults_a_million_particles_with_a_plain_attach_under_a_jitter
         pair = Pair(system, _emitter(1.0e6, 0.8, 1.2), seed=SEED, uid=21)
         cap = 1 << 21
         buf = torch.full((cap * 16,), float("nan"), dtype=torch.float32, device="cuda")
-        pair.gpu.attach_instances(buf.data_ptr(), cap, particle_type=0)
-        assert pair.gpu.update_path(0)[0] == "general"
-        dts = _dts(100, seed=5, spikes=((70, 0.03),))
+        assert pair.gpu.update_path(0)[0] == "range"
+        dts = _dts(110, seed=5, spikes=((80, 0.03),))
         for fr, dt in enumerate(dts):
+            if fr == 45:
+                # (round 6: the ring -- ~740 000 particles by now, component planes, wrapped or not -- is unwrapped AND transposed into the
+                # float4 planes of the compacting path here: realloc_segment)
+                pair.gpu.attach_instances(buf.data_ptr(), cap, particle_type=0)
+                assert pair.gpu.update_path(0)[0] == "general"
+                pair.check(exact_all=True, what="right after the attach")
             system.update(dt)
             pair.step_cpu(dt)
-            if fr in (55, 69, 70, 71, 85, 99):
+            if fr in (30, 44, 46, 65, 79, 80, 81, 95, 109):
                 pair.check(exact_all=True, what=f"frame {fr} (dt {dt})")
-                n = pair.gpu.count(0)
-                got = buf[: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
-                assert np.array_equal(got, pair.gpu.instances(0).view(np.uint32).reshape(n, 16)), fr
+                if fr > 45:
+                    n = pair.gpu.count(0)
+                    got = buf[: n * 16].cpu().numpy().view(np.uint32).reshape(n, 16)
+                    assert np.array_equal(got, pair.gpu.instances(0).view(np.uint32).reshape(n, 16)), fr
         assert pair.gpu.count(0) > 900000
         assert system.tf_frames() > 30, system.tf_frames()  # (the first ~46 frames hold fewer than tf_min_tiles tiles)
