@@ -274,6 +274,17 @@ def assemble_line(args, world, workload, rows, roof, extras, cpu, hist, rccl_ran
     return out
 
 
+def flush_c_stdio():
+    """fflush(NULL): whatever native libraries left in the C-level stdout / stderr buffers goes out now, not at exit"""
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def self_launch(args):
     """--gpus N > 1 without a launcher: start the N ranks here (one per device) and hand their exit code back.  Never a
     silent fallback: fewer than N visible devices is an error (the curve is N ranks or nothing)."""
@@ -367,6 +378,12 @@ def main():
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL writes a version banner to the C-level stdout when its communicator is created -- buffered there, it would come out at
+        # process exit, AFTER the JSON line.  Create the communicator now and flush C stdio: the line stays the last thing on stdout.
+        _w = torch.zeros(1, device=torch.device("cuda", local_rank))
+        dist.all_reduce(_w)
+        torch.cuda.synchronize()
+        flush_c_stdio()
 
     dt = np.float32(1.0 / 60.0)
     workload = args.workload if args.workload != "auto" else ("configs1" if world == 1 else "configs4")
@@ -617,6 +634,7 @@ def main():
     if rank == 0:
         out = assemble_line(args, world, workload, rows, roof, extras, cpu, hist, rccl_ranks, measured_copy,
                             args.reduce_every if dist is not None else None)
+        flush_c_stdio()
         print(json.dumps(out), flush=True)
     if dist is not None:
         barrier()
