@@ -86,6 +86,8 @@ static ParticleSpawner emitter_settings(int e, double live_per_emitter) {
 struct Shard {  // one GPU: its context, its share of the emitters, its feed of the exchange
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t cstream = nullptr;  // the collective's stream: behind the bucket copy, never in front of the next frame (round 6)
+    hipEvent_t ev_bucket = nullptr;
     std::unique_ptr<ParticleSystemPlugin> app;
     std::vector<ParticleSpawnerData *> emitters;
     std::vector<int> global_index;
@@ -174,6 +176,8 @@ int main(int argc, char **argv) {
             const int r = multi_process ? rank : l;
             HIPCHECK(hipSetDevice(S.device));
             HIPCHECK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+            HIPCHECK(hipStreamCreateWithFlags(&S.cstream, hipStreamNonBlocking));
+            HIPCHECK(hipEventCreateWithFlags(&S.ev_bucket, hipEventDisableTiming));
             S.app = std::make_unique<ParticleSystemPlugin>(S.device, 0x00C0FFEE, S.stream);
             for (int e = r; e < emitters; e += n_ranks) {
                 const Transform tf{{(float)(3.0 * (e % side)), 0.0f, (float)(3.0 * (e / side))}, {}};
@@ -269,7 +273,7 @@ int main(int argc, char **argv) {
                 S.app->check(fw_ctx_live_count_ring(S.app->raw(), nullptr, 0));
                 S.app.reset();
                 (void)hipFree(S.ring), (void)hipFree(S.buckets), (void)hipHostFree(h_b[l]);
-                (void)hipStreamDestroy(S.stream);
+                (void)hipStreamDestroy(S.stream), (void)hipStreamDestroy(S.cstream), (void)hipEventDestroy(S.ev_bucket);
             }
             return 0;
         }
@@ -277,12 +281,20 @@ int main(int argc, char **argv) {
         int sent = 0;
         auto reduce = [&](int first, int n) {
             const int lo = first % (2 * every), b = first / every;
-            NCCLCHECK(ncclGroupStart());
+            // the bucket leaves the ring IN ORDER with the frames (the ring's slots are rewritten 2 * every frames later); the collective
+            // itself -- a few bytes, latency-bound -- runs on a stream of its own behind that copy: the next frames do not wait for it
             for (Shard &S : shards) {
                 HIPCHECK(hipSetDevice(S.device));
                 unsigned long long *dst = S.buckets + (size_t)b * every;
                 HIPCHECK(hipMemcpyAsync(dst, S.ring + lo, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, S.stream));
-                NCCLCHECK(ncclAllReduce(dst, dst, (size_t)n, ncclUint64, ncclSum, S.comm, S.stream));  // live counts only
+                HIPCHECK(hipEventRecord(S.ev_bucket, S.stream));
+                HIPCHECK(hipStreamWaitEvent(S.cstream, S.ev_bucket, 0));
+            }
+            NCCLCHECK(ncclGroupStart());
+            for (Shard &S : shards) {
+                HIPCHECK(hipSetDevice(S.device));
+                unsigned long long *dst = S.buckets + (size_t)b * every;
+                NCCLCHECK(ncclAllReduce(dst, dst, (size_t)n, ncclUint64, ncclSum, S.comm, S.cstream));  // live counts only
             }
             NCCLCHECK(ncclGroupEnd());
         };
@@ -300,6 +312,7 @@ int main(int argc, char **argv) {
             HIPCHECK(hipSetDevice(S.device));
             S.app->synchronize();
             HIPCHECK(hipStreamSynchronize(S.stream));
+            HIPCHECK(hipStreamSynchronize(S.cstream));
             updated += S.app->updated_total();
         }
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -333,7 +346,7 @@ int main(int argc, char **argv) {
             S.app.reset();
             (void)ncclCommDestroy(S.comm);
             (void)hipFree(S.ring), (void)hipFree(S.buckets);
-            (void)hipStreamDestroy(S.stream);
+            (void)hipStreamDestroy(S.stream), (void)hipStreamDestroy(S.cstream), (void)hipEventDestroy(S.ev_bucket);
         }
     } catch (const Error &e) {
         std::fprintf(stderr, "firework error %d: %s\n", (int)e.status, e.what());
