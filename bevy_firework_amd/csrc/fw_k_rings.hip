@@ -486,8 +486,14 @@ __device__ __forceinline__ void fw_update_fifo_body(const FwGlobals &g, const Fw
     }
 }
 
+// (FW_FIFO_WAVES: compile-time A/B -- a minimum of waves per SIMD for the plain streaming instantiations: configs[1]'s grid is 1042
+// workgroups, 18 more than the 1024 slots that 4 workgroups per CU give)
+#ifndef FW_FIFO_WAVES
+#define FW_FIFO_WAVES 1
+#endif
 template <bool INST, int WM, int NT = 0, bool COLL = false, int TR = FW_ROUNDS>
-__global__ __launch_bounds__(FW_BLOCK) void fw_k_update_fifo(FwGlobals g, FwFifoArgs a, FwInlineOps inl) {
+__global__ __launch_bounds__(FW_BLOCK) __attribute__((amdgpu_waves_per_eu((!INST && !COLL && TR == FW_ROUNDS) ? FW_FIFO_WAVES : 1)))
+void fw_k_update_fifo(FwGlobals g, FwFifoArgs a, FwInlineOps inl) {
     fw_update_fifo_body<INST, WM, NT, COLL, TR, false>(g, a, inl);
 }
 // ... with Nested entries inside the launch (FwFifoNest).  A kernel of its own so that the plain instantiations keep their code
